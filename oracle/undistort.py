@@ -1,0 +1,55 @@
+"""numpy restatement of cv::undistort(src, dst, K, D) as used by the reference's
+test fixture and EuRoC reader (xrslam-test/test/src/test_feature_track.cpp:10-22,
+xrslam-pc/player/src/IO/euroc_dataset_reader.cpp:62-69).
+
+TEST INFRASTRUCTURE ONLY.  Published OpenCV algorithm restated:
+initUndistortRectifyMap(CV_16SC2 fixed-point maps, INTER_BITS=5) followed by
+remap(INTER_LINEAR, BORDER_CONSTANT 0) with the 15-bit fixed-point bilinear table.
+K and D are rounded through float32 first because both call sites build CV_32F
+matrices.
+"""
+import numpy as np
+
+INTER_BITS = 5
+INTER_TAB_SIZE = 1 << INTER_BITS
+INTER_REMAP_COEF_BITS = 15
+
+
+def undistort(gray, K4, D4):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    fx, fy, cx, cy = [float(np.float32(v)) for v in K4]
+    k1, k2, p1, p2 = [float(np.float32(v)) for v in D4]
+    j = np.arange(w, dtype=np.float64)[None, :]
+    i = np.arange(h, dtype=np.float64)[:, None]
+    x = (j - cx) / fx + 0.0 * i
+    y = (i - cy) / fy + 0.0 * j
+    x2 = x * x
+    y2 = y * y
+    r2 = x2 + y2
+    _2xy = 2 * x * y
+    kr = 1 + ((0.0 * r2 + k2) * r2 + k1) * r2
+    xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2)
+    yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy
+    u = fx * xd + cx
+    v = fy * yd + cy
+    iu = np.rint(u * INTER_TAB_SIZE).astype(np.int64)
+    iv = np.rint(v * INTER_TAB_SIZE).astype(np.int64)
+    sx = (iu >> INTER_BITS).astype(np.int64)
+    sy = (iv >> INTER_BITS).astype(np.int64)
+    ax = (iu & (INTER_TAB_SIZE - 1)).astype(np.int64)
+    ay = (iv & (INTER_TAB_SIZE - 1)).astype(np.int64)
+    # 15-bit fixed-point bilinear weights: ((32-ay)(32-ax), (32-ay)ax, ay(32-ax), ay ax) * 32
+    w00 = (INTER_TAB_SIZE - ay) * (INTER_TAB_SIZE - ax) * 32
+    w01 = (INTER_TAB_SIZE - ay) * ax * 32
+    w10 = ay * (INTER_TAB_SIZE - ax) * 32
+    w11 = ay * ax * 32
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+        val = gray[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)].astype(np.int64)
+        return np.where(ok, val, 0)
+
+    acc = tap(sy, sx) * w00 + tap(sy, sx + 1) * w01 + tap(sy + 1, sx) * w10 + tap(sy + 1, sx + 1) * w11
+    out = (acc + (1 << (INTER_REMAP_COEF_BITS - 1))) >> INTER_REMAP_COEF_BITS
+    return np.clip(out, 0, 255).astype(np.uint8)

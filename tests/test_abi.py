@@ -1,0 +1,62 @@
+"""CPU-side checks of the C-ABI library: it builds, loads, exports every symbol
+declared in include/*.h, and refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    syms = set()
+    for name in os.listdir(os.path.join(ROOT, "include")):
+        if not name.endswith(".h"):
+            continue
+        text = open(os.path.join(ROOT, "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        for m in re.finditer(r"\b((?:xrhip_|XRSLAM)[A-Za-z0-9_]*)\s*\(", text):
+            syms.add(m.group(1))
+    return sorted(syms)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from xrslam_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return C.CDLL(_lib.LIB_PATH)
+
+
+def test_exports_every_declared_symbol(lib):
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
+
+
+def test_fails_loudly_without_gpu(lib):
+    from xrslam_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = lib.xrhip_klt_create(752, 480, 200, C.byref(h))
+    assert rc == _lib.XRHIP_ENODEVICE
+    lib.xrhip_last_error.restype = C.c_char_p
+    assert b"no CPU fallback" in lib.xrhip_last_error()
+
+
+def test_product_does_not_reference_oracle():
+    """The product tree must not import, include or link anything under oracle/."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "xrslam_amd")):
+        if "_obj" in base or base.endswith("lib"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", ".sh")):
+                t = open(os.path.join(base, f), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle|#\s*include[^\n]*oracle|liboracle|-[LlI][^\n ]*oracle", t, flags=re.M):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad

@@ -1,0 +1,191 @@
+"""GPU parity tests of the KLT front-end: HIP path (through the C ABI) vs the CPU
+oracle on identical inputs.  Integer/byte data and status bits must be bit-exact;
+LK positions are bit-exact too because both sides use exact integer reductions
+and identical scalar float math (tolerance kept at 1e-4 relative per north_star,
+asserted tighter where it holds)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import noise_image, warp_affine
+
+pytestmark = pytest.mark.gpu
+
+DUMP = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from oracle import klt_oracle as ko
+    from xrslam_amd import klt
+    return ko, klt
+
+
+def _dump(name, **arrs):
+    try:
+        os.makedirs(DUMP, exist_ok=True)
+        np.savez_compressed(os.path.join(DUMP, name + ".npz"), **arrs)
+    except Exception:
+        pass
+
+
+def _pair(ko, klt, a, b, clip=6.0, tiles=8):
+    h, w = a.shape
+    ctx = klt.KltContext(w, h, 600)
+    HA, HB = ctx.image(a), ctx.image(b)
+    HA.preprocess(clip, tiles, tiles)
+    HB.preprocess(clip, tiles, tiles)
+    OA, OB = ko.OracleImage(a), ko.OracleImage(b)
+    OA.preprocess(clip, tiles, tiles)
+    OB.preprocess(clip, tiles, tiles)
+    return ctx, HA, HB, OA, OB
+
+
+def _assert_pyramid_equal(H, O, tag):
+    for l in range(4):
+        hi, hd = H.level(l)
+        oi, od = O.level(l)
+        if not (np.array_equal(hi, oi) and np.array_equal(hd, od)):
+            _dump("pyr_mismatch_%s_l%d" % (tag, l), hi=hi, oi=oi, hd=hd, od=od)
+        assert hi.shape == oi.shape
+        np.testing.assert_array_equal(hi, oi, err_msg="%s level %d image" % (tag, l))
+        np.testing.assert_array_equal(hd, od, err_msg="%s level %d deriv" % (tag, l))
+
+
+@pytest.mark.parametrize("shape,tiles", [((480, 752), 8), ((480, 640), 8), ((479, 641), 8), ((720, 1280), 8),
+                                         ((480, 752), 4)])
+def test_preprocess_bit_exact(mods, shape, tiles):
+    ko, klt = mods
+    g = noise_image(shape[1], shape[0], seed=21)
+    ctx, HA, HB, OA, OB = _pair(ko, klt, g, g, 6.0, tiles)
+    _assert_pyramid_equal(HA, OA, "noise%dx%d" % shape)
+
+
+def test_golden_pair_full_parity(mods, golden_pair, klt_expected):
+    ko, klt = mods
+    a, b = golden_pair
+    ctx, HA, HB, OA, OB = _pair(ko, klt, a, b)
+    _assert_pyramid_equal(HA, OA, "golden_a")
+    _assert_pyramid_equal(HB, OB, "golden_b")
+    hr = HA.harris()
+    orr = ko.harris_response(OA.image)
+    if not np.array_equal(hr, orr):
+        _dump("harris_mismatch", hr=hr, orr=orr)
+    np.testing.assert_array_equal(hr, orr)
+    kp_h = HA.detect_keypoints(np.zeros((0, 2)), 200, 20.0)
+    np.testing.assert_array_equal(kp_h, klt_expected["keypoints"])
+    nx_h, st_h = HA.track_keypoints(HB, kp_h, kp_h.copy())
+    if not (np.array_equal(st_h, klt_expected["status"]) and np.array_equal(nx_h, klt_expected["next"])):
+        _dump("track_mismatch_golden", nx_h=nx_h, st_h=st_h, nx_o=klt_expected["next"], st_o=klt_expected["status"])
+    np.testing.assert_array_equal(st_h, klt_expected["status"])
+    np.testing.assert_array_equal(nx_h, klt_expected["next"])
+    # the reference's known answers (xrslam-test/test/src/test_feature_track.cpp:41,64) within +-1
+    assert abs(len(kp_h) - 164) <= 1 and abs(int(st_h.sum()) - 161) <= 1
+
+
+@pytest.mark.parametrize("w,h,n,seed", [(752, 480, 200, 31), (640, 480, 150, 32), (1280, 720, 600, 33)])
+def test_detect_and_track_parity_synthetic(mods, w, h, n, seed):
+    ko, klt = mods
+    g = noise_image(w, h, seed=seed)
+    ang = 0.01
+    M = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+    g2 = warp_affine(g, M, np.array([2.3, -1.7]))
+    ctx, HA, HB, OA, OB = _pair(ko, klt, g, g2)
+    kp_o = OA.detect_keypoints(np.zeros((0, 2)), n, 20.0)
+    kp_h = HA.detect_keypoints(np.zeros((0, 2)), n, 20.0)
+    np.testing.assert_array_equal(kp_h, kp_o)
+    assert len(kp_o) > n // 2
+    for guess in (None, kp_o + np.array([1.0, -0.5])):
+        nx_o, st_o = OA.track_keypoints(OB, kp_o, guess)
+        nx_h, st_h = HA.track_keypoints(HB, kp_o, guess)
+        if not (np.array_equal(st_h, st_o) and np.array_equal(nx_h, nx_o)):
+            _dump("track_mismatch_%d" % seed, nx_h=nx_h, st_h=st_h, nx_o=nx_o, st_o=st_o, kp=kp_o)
+        np.testing.assert_array_equal(st_h, st_o)
+        assert st_o.mean() > 0.8
+        np.testing.assert_allclose(nx_h[st_o > 0], nx_o[st_o > 0], rtol=1e-4, atol=0)
+        np.testing.assert_array_equal(nx_h, nx_o)
+    # second detection with already tracked points present
+    kp2_o = OB.detect_keypoints(nx_o[st_o > 0], n, 20.0)
+    kp2_h = HB.detect_keypoints(nx_o[st_o > 0], n, 20.0)
+    np.testing.assert_array_equal(kp2_h, kp2_o)
+
+
+def test_plain_lk_parity_including_failures(mods):
+    ko, klt = mods
+    g = noise_image(752, 480, seed=41)
+    g2 = warp_affine(g, np.eye(2), np.array([-4.0, 3.0]))
+    g2[:, 600:] = 90        # textureless strip -> minEig rejections
+    g[:, 600:] = 90
+    ctx, HA, HB, OA, OB = _pair(ko, klt, g, g2)
+    rng = np.random.RandomState(5)
+    pts = (rng.rand(300, 2) * [800, 520] - [24, 20]).astype(np.float32)   # includes out-of-image points
+    guess = pts + rng.randn(300, 2).astype(np.float32) * 3
+    nx_o, st_o, _ = OA.lk(OB, pts, guess)
+    nx_h, st_h = HA.lk(HB, pts, guess)
+    if not (np.array_equal(st_h, st_o) and np.array_equal(nx_h, nx_o)):
+        _dump("lk_plain_mismatch", nx_h=nx_h, st_h=st_h, nx_o=nx_o, st_o=st_o, pts=pts, guess=guess)
+    np.testing.assert_array_equal(st_h, st_o)
+    assert 0 < st_o.sum() < len(st_o)
+    np.testing.assert_array_equal(nx_h, nx_o)
+
+
+def test_track_edge_cases(mods):
+    ko, klt = mods
+    g = noise_image(640, 480, seed=51)
+    ctx, HA, HB, OA, OB = _pair(ko, klt, g, g.copy())
+    nx, st = HA.track_keypoints(HB, np.zeros((0, 2)), None)          # empty input
+    assert len(st) == 0
+    pts = np.array([[5.0, 5.0], [635.0, 475.0], [19.9, 240.0], [320.0, 240.0], [-30.0, 100.0], [700.0, 100.0],
+                    [20.0, 20.0], [619.99, 459.99]])
+    nx_o, st_o = OA.track_keypoints(OB, pts, pts.copy())
+    nx_h, st_h = HA.track_keypoints(HB, pts, pts.copy())
+    np.testing.assert_array_equal(st_h, st_o)
+    np.testing.assert_array_equal(nx_h, nx_o)
+    flat = np.full((480, 640), 100, np.uint8)
+    ctx2, FA, FB, _, _ = _pair(ko, klt, flat, flat)
+    _, stf = FA.track_keypoints(FB, pts, pts.copy())
+    assert not stf.any()
+    assert len(FA.detect_keypoints(np.zeros((0, 2)), 100, 20.0)) == 0   # no corners on a flat image
+
+
+def test_error_behaviour(mods):
+    ko, klt = mods
+    from xrslam_amd._lib import XrhipError, XRHIP_ESTATE, XRHIP_EINVAL
+    ctx = klt.KltContext(640, 480, 100)
+    im = ctx.image()
+    with pytest.raises(XrhipError) as e:
+        im.preprocess()
+    assert e.value.code == XRHIP_ESTATE
+    im.upload(noise_image(640, 480, seed=1))
+    with pytest.raises(XrhipError) as e:
+        im.detect_keypoints(np.zeros((0, 2)), 10, 20.0)
+    assert e.value.code == XRHIP_ESTATE
+    with pytest.raises(XrhipError) as e:
+        klt.KltContext(10, 10, 10)
+    assert e.value.code == XRHIP_EINVAL
+    im.preprocess()
+    im.release_image_buffer()
+    with pytest.raises(XrhipError):
+        im.detect_keypoints(np.zeros((0, 2)), 10, 20.0)
+
+
+def test_full_size_properties(mods):
+    """Size-independent properties at the BASELINE workload size (752x480, 150 pts):
+    tracking an image onto itself is the identity; a pure translation is recovered."""
+    ko, klt = mods
+    g = noise_image(752, 480, seed=61)
+    shift = np.array([5.5, 3.25])
+    g2 = warp_affine(g, np.eye(2), -shift)
+    ctx = klt.KltContext(752, 480, 150)
+    A, B, C2 = ctx.image(g), ctx.image(g), ctx.image(g2)
+    for im in (A, B, C2):
+        im.preprocess()
+    kp = A.detect_keypoints(np.zeros((0, 2)), 150, 20.0)
+    assert len(kp) == 150
+    nx, st = A.track_keypoints(B, kp, kp.copy())
+    assert st.all() and np.abs(nx - kp).max() < 1e-3
+    nx, st = A.track_keypoints(C2, kp, None)
+    ok = st > 0
+    assert ok.mean() > 0.9
+    assert np.median(np.abs(nx[ok] - kp[ok] - shift)) < 0.05

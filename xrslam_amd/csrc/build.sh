@@ -1,0 +1,22 @@
+#!/bin/bash
+# Builds libxrslam_hip.so (gfx950 only) in-tree.  Usage: build.sh [extra hipcc flags]
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT" "$HERE/_obj"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -I$HERE/../../include"
+SRCS=$(ls "$HERE"/*.hip)
+OBJS=""
+pids=()
+for s in $SRCS; do
+  o="$HERE/_obj/$(basename "$s" .hip).o"
+  OBJS="$OBJS $o"
+  if [ ! -f "$o" ] || [ -n "$(find "$HERE" "$HERE/../../include" -maxdepth 1 \( -name '*.h' -o -name '*.hpp' -o -name "$(basename "$s")" \) -newer "$o" | head -1)" ]; then
+    $HIPCC $FLAGS "$@" -c "$s" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libxrslam_hip.so" $OBJS
+echo "built $OUT/libxrslam_hip.so"

@@ -1,0 +1,510 @@
+// klt_api.hip -- C ABI of the KLT front-end (include/xrslam_hip.h, plug point #1).
+// Host side of xrslam::Image for gfx950: buffer management, launches on the
+// context's stream, and the order-defining selections (host_select.hpp).
+#include "../../include/xrslam_hip.h"
+#include "common.hip.h"
+#include "host_select.hpp"
+#include "klt_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+using namespace xrhip;
+
+namespace {
+
+struct LevelBuf {
+    int w = 0, h = 0;
+    int istride = 0;   // bytes per padded image row
+    int rows = 0;      // padded rows
+    uint8_t *img_base = nullptr;
+    short2 *der_base = nullptr;
+    uint8_t *img = nullptr;   // pixel (0,0)
+    short2 *der = nullptr;    // pixel (0,0)
+};
+
+}   // namespace
+
+struct xrhip_klt {
+    int device = 0;
+    int w = 0, h = 0, max_points = 0;
+    hipStream_t stream = nullptr;
+    // scratch shared by the images of this sequence
+    uint8_t *lut = nullptr;          // tiles*256
+    int lut_tiles = 0;
+    float *resp = nullptr;           // w*h Harris response
+    int *max_key = nullptr;          // 1 int (+ candidate counter next to it)
+    int *cand_count = nullptr;
+    HarrisCand *cand = nullptr;
+    int cand_cap = 0;
+    HarrisCand *h_cand = nullptr;    // pinned
+    int *h_count = nullptr;          // pinned (2 ints)
+    // track scratch
+    int pts_cap = 0;
+    double2 *d_curr = nullptr, *d_next = nullptr;
+    uint8_t *d_status = nullptr;
+    float2 *d_fprev = nullptr, *d_fnext = nullptr;
+    LkCounters *d_counters = nullptr;
+    LkCounters *h_counters = nullptr;   // pinned
+    // profiling: event pairs are recorded on the stream without synchronising and
+    // resolved lazily in xrhip_klt_get_stats(), so timing runs inside the timed region
+    bool profiling = false;
+    struct Pending {
+        hipEvent_t e0, e1;
+        int cat;
+    };
+    std::vector<Pending> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    xrhip_klt_stats stats{};
+};
+
+struct xrhip_image {
+    xrhip_klt *ctx = nullptr;
+    uint8_t *raw = nullptr;    // w*h, unpadded upload target (CLAHE input)
+    bool have_raw = false;
+    bool have_pyramid = false;
+    LevelBuf lv[KLT_LEVELS];
+};
+
+static PyrView make_view(const xrhip_image *img) {
+    PyrView v;
+    for (int l = 0; l < KLT_LEVELS; ++l) {
+        v.lv[l].img = img->lv[l].img;
+        v.lv[l].der = img->lv[l].der;
+        v.lv[l].w = img->lv[l].w;
+        v.lv[l].h = img->lv[l].h;
+        v.lv[l].istride = img->lv[l].istride;
+        v.lv[l].pstride = img->lv[l].istride;
+    }
+    return v;
+}
+
+static int ensure_points(xrhip_klt *c, int n) {
+    if (n <= c->pts_cap) return XRHIP_OK;
+    int cap = std::max(n, std::max(256, c->pts_cap * 2));
+    hipFree(c->d_curr);
+    hipFree(c->d_next);
+    hipFree(c->d_status);
+    hipFree(c->d_fprev);
+    hipFree(c->d_fnext);
+    c->d_curr = c->d_next = nullptr;
+    c->d_status = nullptr;
+    c->d_fprev = c->d_fnext = nullptr;
+    XR_HIP(hipMalloc(&c->d_curr, sizeof(double2) * cap));
+    XR_HIP(hipMalloc(&c->d_next, sizeof(double2) * cap));
+    XR_HIP(hipMalloc(&c->d_status, cap));
+    XR_HIP(hipMalloc(&c->d_fprev, sizeof(float2) * cap));
+    XR_HIP(hipMalloc(&c->d_fnext, sizeof(float2) * cap));
+    c->pts_cap = cap;
+    return XRHIP_OK;
+}
+
+enum { CAT_PRE = 0, CAT_TRACK = 1, CAT_DETECT = 2 };
+
+static int resolve_pending(xrhip_klt *c) {
+    if (c->pending.empty()) return XRHIP_OK;
+    XR_HIP(hipStreamSynchronize(c->stream));
+    for (auto &p : c->pending) {
+        float ms = 0.f;
+        XR_HIP(hipEventElapsedTime(&ms, p.e0, p.e1));
+        if (p.cat == CAT_PRE) c->stats.ms_preprocess += ms;
+        else if (p.cat == CAT_TRACK) c->stats.ms_track += ms;
+        else c->stats.ms_detect += ms;
+        c->free_events.emplace_back(p.e0, p.e1);
+    }
+    c->pending.clear();
+    return XRHIP_OK;
+}
+
+struct ProfScope {
+    xrhip_klt *c;
+    int cat;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(xrhip_klt *c_, int cat_) : c(c_), cat(cat_) {
+        if (!c->profiling) return;
+        if (c->pending.size() >= 8192) resolve_pending(c);
+        if (!c->free_events.empty()) {
+            e0 = c->free_events.back().first;
+            e1 = c->free_events.back().second;
+            c->free_events.pop_back();
+        } else {
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+        }
+        hipEventRecord(e0, c->stream);
+    }
+    void finish() {
+        if (c->profiling && e0) {
+            hipEventRecord(e1, c->stream);
+            c->pending.push_back({e0, e1, cat});
+        }
+        if (cat == CAT_PRE) c->stats.n_preprocess++;
+        else if (cat == CAT_TRACK) c->stats.n_track++;
+        else c->stats.n_detect++;
+    }
+};
+
+extern "C" {
+
+int xrhip_klt_create(int width, int height, int max_points, xrhip_klt **out) {
+    if (!out || width < 64 || height < 64 || max_points < 0) return xr_fail(XRHIP_EINVAL, "xrhip_klt_create: bad arguments");
+    int rc = xr_require_device();
+    if (rc) return rc;
+    xrhip_klt *c = new xrhip_klt();
+    hipGetDevice(&c->device);
+    c->w = width;
+    c->h = height;
+    c->max_points = max_points;
+    XR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->lut_tiles = 0;
+    XR_HIP(hipMalloc(&c->resp, sizeof(float) * (size_t)width * height));
+    XR_HIP(hipMalloc(&c->max_key, sizeof(int) * 2));
+    c->cand_count = c->max_key + 1;
+    c->cand_cap = width * height / 2;
+    XR_HIP(hipMalloc(&c->cand, sizeof(HarrisCand) * (size_t)c->cand_cap));
+    XR_HIP(hipHostMalloc(&c->h_cand, sizeof(HarrisCand) * (size_t)c->cand_cap, hipHostMallocDefault));
+    XR_HIP(hipHostMalloc(&c->h_count, sizeof(int) * 2, hipHostMallocDefault));
+    XR_HIP(hipMalloc(&c->d_counters, sizeof(LkCounters)));
+    XR_HIP(hipMemset(c->d_counters, 0, sizeof(LkCounters)));
+    XR_HIP(hipHostMalloc(&c->h_counters, sizeof(LkCounters), hipHostMallocDefault));
+    rc = ensure_points(c, std::max(256, max_points * 2));
+    if (rc) return rc;
+    *out = c;
+    return XRHIP_OK;
+}
+
+void xrhip_klt_destroy(xrhip_klt *c) {
+    if (!c) return;
+    hipStreamSynchronize(c->stream);
+    hipFree(c->lut);
+    hipFree(c->resp);
+    hipFree(c->max_key);
+    hipFree(c->cand);
+    hipHostFree(c->h_cand);
+    hipHostFree(c->h_count);
+    hipFree(c->d_curr);
+    hipFree(c->d_next);
+    hipFree(c->d_status);
+    hipFree(c->d_fprev);
+    hipFree(c->d_fnext);
+    hipFree(c->d_counters);
+    hipHostFree(c->h_counters);
+    for (auto &p : c->pending) {
+        hipEventDestroy(p.e0);
+        hipEventDestroy(p.e1);
+    }
+    for (auto &p : c->free_events) {
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int xrhip_image_create(xrhip_klt *c, xrhip_image **out) {
+    if (!c || !out) return xr_fail(XRHIP_EINVAL, "xrhip_image_create: null argument");
+    xrhip_image *im = new xrhip_image();
+    im->ctx = c;
+    XR_HIP(hipMalloc(&im->raw, (size_t)c->w * c->h));
+    int w = c->w, h = c->h;
+    for (int l = 0; l < KLT_LEVELS; ++l) {
+        LevelBuf &L = im->lv[l];
+        L.w = w;
+        L.h = h;
+        L.istride = (KLT_PADX + w + KLT_PAD + 63) / 64 * 64;
+        L.rows = h + 2 * KLT_PAD;
+        XR_HIP(hipMalloc(&L.img_base, (size_t)L.rows * L.istride));
+        XR_HIP(hipMalloc(&L.der_base, sizeof(short2) * (size_t)L.rows * L.istride));
+        // derivative borders are BORDER_CONSTANT(0) and never rewritten
+        XR_HIP(hipMemsetAsync(L.der_base, 0, sizeof(short2) * (size_t)L.rows * L.istride, c->stream));
+        XR_HIP(hipMemsetAsync(L.img_base, 0, (size_t)L.rows * L.istride, c->stream));
+        L.img = L.img_base + (size_t)KLT_PAD * L.istride + KLT_PADX;
+        L.der = L.der_base + (size_t)KLT_PAD * L.istride + KLT_PADX;
+        w = (w + 1) / 2;
+        h = (h + 1) / 2;
+    }
+    *out = im;
+    return XRHIP_OK;
+}
+
+void xrhip_image_destroy(xrhip_image *im) {
+    if (!im) return;
+    hipStreamSynchronize(im->ctx->stream);
+    hipFree(im->raw);
+    for (int l = 0; l < KLT_LEVELS; ++l) {
+        hipFree(im->lv[l].img_base);
+        hipFree(im->lv[l].der_base);
+    }
+    delete im;
+}
+
+int xrhip_image_upload(xrhip_image *im, const uint8_t *gray, int stride) {
+    if (!im || !gray || stride < im->ctx->w) return xr_fail(XRHIP_EINVAL, "xrhip_image_upload: bad arguments");
+    xrhip_klt *c = im->ctx;
+    XR_HIP(hipMemcpy2DAsync(im->raw, c->w, gray, stride, c->w, c->h, hipMemcpyHostToDevice, c->stream));
+    // the host buffer may be reused by the caller as soon as we return (PushImage deep-copies)
+    XR_HIP(hipStreamSynchronize(c->stream));
+    im->have_raw = true;
+    im->have_pyramid = false;
+    return XRHIP_OK;
+}
+
+int xrhip_image_upload_device(xrhip_image *im, const void *gray_dev, int stride) {
+    if (!im || !gray_dev || stride < im->ctx->w) return xr_fail(XRHIP_EINVAL, "xrhip_image_upload_device: bad arguments");
+    xrhip_klt *c = im->ctx;
+    XR_HIP(hipMemcpy2DAsync(im->raw, c->w, gray_dev, stride, c->w, c->h, hipMemcpyDeviceToDevice, c->stream));
+    im->have_raw = true;
+    im->have_pyramid = false;
+    return XRHIP_OK;
+}
+
+int xrhip_image_preprocess(xrhip_image *im, double clip_limit, int tiles_x, int tiles_y) {
+    if (!im || tiles_x < 1 || tiles_y < 1 || tiles_x * tiles_y > 4096)
+        return xr_fail(XRHIP_EINVAL, "xrhip_image_preprocess: bad arguments");
+    if (!im->have_raw) return xr_fail(XRHIP_ESTATE, "xrhip_image_preprocess: no image uploaded");
+    xrhip_klt *c = im->ctx;
+    const int w = c->w, h = c->h;
+    const int ew = w + (tiles_x - (w % tiles_x)) % tiles_x, eh = h + (tiles_y - (h % tiles_y)) % tiles_y;
+    const int tw = ew / tiles_x, th = eh / tiles_y;
+    const int tiles = tiles_x * tiles_y;
+    if (tiles > c->lut_tiles) {
+        hipFree(c->lut);
+        c->lut = nullptr;
+        XR_HIP(hipMalloc(&c->lut, (size_t)tiles * 256));
+        c->lut_tiles = tiles;
+    }
+    const int area = tw * th;
+    const float lut_scale = 255.0f / area;
+    int clip = 0;
+    if (clip_limit > 0.0) {
+        clip = (int)(clip_limit * area / 256);
+        if (clip < 1) clip = 1;
+    }
+    ProfScope prof(c, CAT_PRE);
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles), dim3(256), 0, c->stream, im->raw, w, w, h, tw, th, tiles_x, clip,
+                       lut_scale, c->lut);
+    {
+        LevelBuf &L = im->lv[0];
+        dim3 blk(64, 4);
+        dim3 grd((w + 2 * KLT_PAD + 63) / 64, (h + 2 * KLT_PAD + 3) / 4);
+        hipLaunchKernelGGL(k_clahe_apply, grd, blk, 0, c->stream, im->raw, w, w, h, tw, th, tiles_x, tiles_y, c->lut,
+                           L.img, L.istride);
+    }
+    PyrView pv = make_view(im);
+    for (int l = 1; l < KLT_LEVELS; ++l) {
+        LevelBuf &D = im->lv[l];
+        dim3 blk(64, 4);
+        dim3 grd((D.w + 2 * KLT_PAD + 63) / 64, (D.h + 2 * KLT_PAD + 3) / 4);
+        hipLaunchKernelGGL(k_pyrdown, grd, blk, 0, c->stream, pv.lv[l - 1], D.img, D.w, D.h, D.istride);
+    }
+    ScharrArgs sa;
+    int off = 0;
+    for (int l = 0; l < KLT_LEVELS; ++l) {
+        sa.lv[l] = pv.lv[l];
+        sa.out[l] = im->lv[l].der;
+        sa.blk_off[l] = off;
+        sa.blk_w[l] = (im->lv[l].w + 63) / 64;
+        off += sa.blk_w[l] * ((im->lv[l].h + 3) / 4);
+    }
+    sa.blk_off[KLT_LEVELS] = off;
+    hipLaunchKernelGGL(k_scharr, dim3(off), dim3(256), 0, c->stream, sa);
+    XR_HIP(hipGetLastError());
+    prof.finish();
+    im->have_pyramid = true;
+    return XRHIP_OK;
+}
+
+int xrhip_image_release(xrhip_image *im) {
+    if (!im) return xr_fail(XRHIP_EINVAL, "xrhip_image_release: null");
+    // buffers are pooled per image object; releasing only invalidates the contents
+    im->have_raw = false;
+    im->have_pyramid = false;
+    return XRHIP_OK;
+}
+
+static int run_harris(xrhip_image *im) {
+    xrhip_klt *c = im->ctx;
+    PyrView pv = make_view(im);
+    const int w = c->w, h = c->h;
+    double scale = (double)(1 << 2) * 3;
+    scale *= 255.0;
+    scale = 1.0 / scale;
+    const float s2 = (float)(scale * scale);
+    const int init[2] = {(int)0x80000000, 0};
+    XR_HIP(hipMemcpyAsync(c->max_key, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_harris, dim3((w + 63) / 64, (h + 15) / 16), dim3(256), 0, c->stream, pv.lv[0], 0.04, s2,
+                       c->resp, c->max_key);
+    return XRHIP_OK;
+}
+
+int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, int max_points, double min_distance,
+                       double *out_xy, int *n_out) {
+    if (!im || !out_xy || !n_out || n_exist < 0 || (n_exist > 0 && !existing_xy))
+        return xr_fail(XRHIP_EINVAL, "xrhip_image_detect: bad arguments");
+    if (!im->have_pyramid) return xr_fail(XRHIP_ESTATE, "xrhip_image_detect: preprocess() has not run");
+    xrhip_klt *c = im->ctx;
+    const int w = c->w, h = c->h;
+    ProfScope prof(c, CAT_DETECT);
+    int rc = run_harris(im);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_harris_nms, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, c->stream, c->resp, w, h,
+                       c->max_key, 1.0e-3, c->cand, c->cand_count, c->cand_cap);
+    XR_HIP(hipGetLastError());
+    prof.finish();
+    XR_HIP(hipMemcpyAsync(c->h_count, c->max_key, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipStreamSynchronize(c->stream));
+    const int nc = c->h_count[1];
+    if (nc > c->cand_cap) return xr_fail(XRHIP_EOVERFLOW, "xrhip_image_detect: corner candidate buffer overflow");
+    if (nc > 0) {
+        XR_HIP(hipMemcpyAsync(c->h_cand, c->cand, sizeof(HarrisCand) * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
+        XR_HIP(hipStreamSynchronize(c->stream));
+    }
+    // total order: response desc, then linear index desc (cv greaterThanPtr)
+    std::vector<HarrisCand> cs(c->h_cand, c->h_cand + nc);
+    std::sort(cs.begin(), cs.end(), [](const HarrisCand &a, const HarrisCand &b) {
+        if (a.v > b.v) return true;
+        if (a.v < b.v) return false;
+        return a.idx > b.idx;
+    });
+    std::vector<int> order(nc);
+    for (int i = 0; i < nc; ++i) order[i] = cs[i].idx;
+    // GFTTDetector(max_points, 1e-3, 20, 3, harris) -- minDistance is the literal 20 of opencv_image.cpp:186
+    std::vector<int> corners = greedy_min_distance(order, w, h, 20.0, max_points);
+    int n = 0;
+    if (!corners.empty()) {
+        PoissonDisk2 filter(min_distance);
+        for (int i = 0; i < n_exist; ++i) filter.preset(existing_xy[2 * i], existing_xy[2 * i + 1]);
+        for (int idx : corners) {
+            const double x = (double)(float)(idx % w), y = (double)(float)(idx / w);
+            if (!filter.insert(x, y)) continue;
+            if (x < 20 || y < 20 || x >= w - 20 || y >= h - 20) continue;
+            out_xy[2 * n] = x;
+            out_xy[2 * n + 1] = y;
+            ++n;
+        }
+    }
+    *n_out = n;
+    return XRHIP_OK;
+}
+
+int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const double *curr_xy, double *next_xy_inout,
+                      int has_guess, uint8_t *status, int n) {
+    if (!cur || !next || n < 0 || (n > 0 && (!curr_xy || !next_xy_inout || !status)))
+        return xr_fail(XRHIP_EINVAL, "xrhip_image_track: bad arguments");
+    if (cur->ctx != next->ctx) return xr_fail(XRHIP_EINVAL, "xrhip_image_track: images belong to different contexts");
+    if (!cur->have_pyramid || !next->have_pyramid)
+        return xr_fail(XRHIP_ESTATE, "xrhip_image_track: preprocess() has not run on both images");
+    if (n == 0) return XRHIP_OK;
+    xrhip_klt *c = cur->ctx;
+    int rc = ensure_points(c, n);
+    if (rc) return rc;
+    XR_HIP(hipMemcpyAsync(c->d_curr, curr_xy, sizeof(double2) * n, hipMemcpyHostToDevice, c->stream));
+    if (has_guess)
+        XR_HIP(hipMemcpyAsync(c->d_next, next_xy_inout, sizeof(double2) * n, hipMemcpyHostToDevice, c->stream));
+    PyrView A = make_view(cur), B = make_view(next);
+    ProfScope prof(c, CAT_TRACK);
+    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, c->stream, A, B, c->d_curr, c->d_next, has_guess ? 1 : 0,
+                       c->d_status, n, c->profiling ? c->d_counters : (LkCounters *)nullptr);
+    XR_HIP(hipGetLastError());
+    prof.finish();
+    c->stats.lk_points += n;
+    // results: status first, positions only where status != 0 (reference semantics)
+    std::vector<double> tmp(2 * (size_t)n);
+    XR_HIP(hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipMemcpyAsync(tmp.data(), c->d_next, sizeof(double2) * n, hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) {
+        if (status[i]) {
+            next_xy_inout[2 * i] = tmp[2 * i];
+            next_xy_inout[2 * i + 1] = tmp[2 * i + 1];
+        }
+    }
+    return XRHIP_OK;
+}
+
+int xrhip_image_lk(const xrhip_image *prev, const xrhip_image *next, const float *prev_xy, float *next_xy_inout,
+                   uint8_t *status, int n) {
+    if (!prev || !next || n < 0 || (n > 0 && (!prev_xy || !next_xy_inout || !status)))
+        return xr_fail(XRHIP_EINVAL, "xrhip_image_lk: bad arguments");
+    if (!prev->have_pyramid || !next->have_pyramid) return xr_fail(XRHIP_ESTATE, "xrhip_image_lk: preprocess() has not run");
+    if (n == 0) return XRHIP_OK;
+    xrhip_klt *c = prev->ctx;
+    int rc = ensure_points(c, n);
+    if (rc) return rc;
+    XR_HIP(hipMemcpyAsync(c->d_fprev, prev_xy, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    XR_HIP(hipMemcpyAsync(c->d_fnext, next_xy_inout, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    PyrView A = make_view(prev), B = make_view(next);
+    hipLaunchKernelGGL(k_lk_plain, dim3(n), dim3(64), 0, c->stream, A, B, c->d_fprev, c->d_fnext, c->d_status, n);
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipMemcpyAsync(next_xy_inout, c->d_fnext, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipStreamSynchronize(c->stream));
+    return XRHIP_OK;
+}
+
+int xrhip_image_level_dims(const xrhip_image *im, int level, int *w, int *h) {
+    if (!im || level < 0 || level >= KLT_LEVELS || !w || !h) return xr_fail(XRHIP_EINVAL, "xrhip_image_level_dims: bad arguments");
+    *w = im->lv[level].w;
+    *h = im->lv[level].h;
+    return XRHIP_OK;
+}
+
+int xrhip_image_download_level(const xrhip_image *im, int level, uint8_t *img_out, int16_t *deriv_out) {
+    if (!im || level < 0 || level >= KLT_LEVELS) return xr_fail(XRHIP_EINVAL, "xrhip_image_download_level: bad arguments");
+    if (!im->have_pyramid) return xr_fail(XRHIP_ESTATE, "xrhip_image_download_level: preprocess() has not run");
+    const LevelBuf &L = im->lv[level];
+    xrhip_klt *c = im->ctx;
+    if (img_out)
+        XR_HIP(hipMemcpy2DAsync(img_out, L.w, L.img, L.istride, L.w, L.h, hipMemcpyDeviceToHost, c->stream));
+    if (deriv_out)
+        XR_HIP(hipMemcpy2DAsync(deriv_out, (size_t)L.w * 4, L.der, (size_t)L.istride * 4, (size_t)L.w * 4, L.h,
+                                hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipStreamSynchronize(c->stream));
+    return XRHIP_OK;
+}
+
+int xrhip_image_download_harris(xrhip_image *im, float *resp_out) {
+    if (!im || !resp_out) return xr_fail(XRHIP_EINVAL, "xrhip_image_download_harris: bad arguments");
+    if (!im->have_pyramid) return xr_fail(XRHIP_ESTATE, "xrhip_image_download_harris: preprocess() has not run");
+    xrhip_klt *c = im->ctx;
+    int rc = run_harris(im);
+    if (rc) return rc;
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipMemcpyAsync(resp_out, c->resp, sizeof(float) * (size_t)c->w * c->h, hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipStreamSynchronize(c->stream));
+    return XRHIP_OK;
+}
+
+int xrhip_klt_set_profiling(xrhip_klt *c, int enable) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_klt_set_profiling: null");
+    c->profiling = enable != 0;
+    return XRHIP_OK;
+}
+
+int xrhip_klt_get_stats(xrhip_klt *c, xrhip_klt_stats *out, int reset) {
+    if (!c || !out) return xr_fail(XRHIP_EINVAL, "xrhip_klt_get_stats: null");
+    int rc = resolve_pending(c);
+    if (rc) return rc;
+    XR_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(LkCounters), hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipStreamSynchronize(c->stream));
+    c->stats.lk_templates = (long long)c->h_counters->templates;
+    c->stats.lk_iterations = (long long)c->h_counters->iterations;
+    *out = c->stats;
+    if (reset) {
+        c->stats = xrhip_klt_stats{};
+        XR_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(LkCounters), c->stream));
+        XR_HIP(hipStreamSynchronize(c->stream));
+    }
+    return XRHIP_OK;
+}
+
+int xrhip_klt_synchronize(xrhip_klt *c) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_klt_synchronize: null");
+    XR_HIP(hipStreamSynchronize(c->stream));
+    return XRHIP_OK;
+}
+
+}   // extern "C"

@@ -1,0 +1,524 @@
+// klt_kernels.hip.h -- gfx950 device kernels of the KLT front-end.
+//
+// Replaces the OpenCV calls behind xrslam::extra::OpenCvImage
+// (/root/reference/xrslam-extra/src/xrslam/extra/opencv_image.cpp):
+//   k_clahe_lut / k_clahe_apply  <- cv::CLAHE::apply           (:157, :179-182)
+//   k_pyrdown / k_scharr         <- cv::buildOpticalFlowPyramid (:159)
+//   k_lk_track                   <- cv::calcOpticalFlowPyrLK x2 + gates (:94-135)
+//   k_harris / k_harris_nms      <- cv::GFTTDetector::detect    (:44, :184-188)
+//
+// Arithmetic contract (shared with oracle/klt_oracle.c, which is the checker):
+// every image quantity is integer-exact; LK normal-equation sums are exact
+// int64 reductions converted to float once; all per-point float math is scalar
+// IEEE (compiled with -ffp-contract=off) so status bits AND positions are
+// bit-identical to the oracle.
+//
+// Execution model: wave64.  LK runs one wavefront per keypoint, the 21x21
+// window is spread over the 64 lanes (7 pixels per lane, template held in
+// registers), and the 2x2 normal-equation sums are reduced with cross-lane
+// butterflies -- no LDS, no barriers, no atomics in the iteration loop.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xrhip {
+
+constexpr int KLT_LEVELS = 4;
+constexpr int KLT_WIN = 21;
+constexpr int KLT_PAD = 21;    // border rows above/below and logical border columns
+constexpr int KLT_PADX = 32;   // physical left border in pixels (keeps x=0 32-byte aligned)
+
+struct LevelView {
+    const uint8_t *img;   // pointer to pixel (0,0) of the padded image
+    const short2 *der;    // pointer to pixel (0,0) of the padded derivative image (dx,dy)
+    int w, h;
+    int istride;          // bytes (== pixels) per padded image row
+    int pstride;          // short2 elements per padded derivative row
+};
+
+struct PyrView {
+    LevelView lv[KLT_LEVELS];
+};
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        else i = 2 * (n - 1) - i;
+    }
+    return i;
+}
+
+// ---------------------------------------------------------------- CLAHE LUT
+// One workgroup per tile: LDS histogram, clip + redistribute, inclusive scan,
+// LUT.  (cv::CLAHE_CalcLut_Body restated; integer exact.)
+__global__ __launch_bounds__(256) void k_clahe_lut(const uint8_t *__restrict__ src, int sstride, int w, int h,
+                                                   int tw, int th, int tiles_x, int clip, float lut_scale,
+                                                   uint8_t *__restrict__ lut) {
+    __shared__ int hist[256];
+    __shared__ int scan[2][256];
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    hist[tid] = 0;
+    __syncthreads();
+    const int area = tw * th;
+    for (int i = tid; i < area; i += 256) {
+        int y = i / tw;
+        int x = i - y * tw;
+        int gx = reflect101(tx * tw + x, w), gy = reflect101(ty * th + y, h);
+        atomicAdd(&hist[src[(size_t)gy * sstride + gx]], 1);
+    }
+    __syncthreads();
+    int hv = hist[tid];
+    if (clip > 0) {
+        int excess = hv > clip ? hv - clip : 0;
+        if (hv > clip) hv = clip;
+        scan[0][tid] = excess;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) scan[0][tid] += scan[0][tid + s];
+            __syncthreads();
+        }
+        int clipped = scan[0][0];
+        __syncthreads();
+        int redist = clipped / 256;
+        int residual = clipped - redist * 256;
+        hv += redist;
+        if (residual != 0) {
+            int step = 256 / residual;
+            if (step < 1) step = 1;
+            if (tid % step == 0 && tid / step < residual) hv++;
+        }
+    }
+    // inclusive scan (Hillis-Steele, double buffered)
+    int cur = 0;
+    scan[0][tid] = hv;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int v = scan[cur][tid];
+        if (tid >= off) v += scan[cur][tid - off];
+        scan[cur ^ 1][tid] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    int sum = scan[cur][tid];
+    int v = __float2int_rn((float)sum * lut_scale);
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    lut[(size_t)blockIdx.x * 256 + tid] = (uint8_t)v;
+}
+
+// -------------------------------------------------------------- CLAHE apply
+// Writes pyramid level 0 INCLUDING its reflect-101 border in one pass.
+// (cv::CLAHE_Interpolation_Body restated; float math as in the oracle.)
+__global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__ src, int sstride, int w, int h,
+                                                     int tw, int th, int tiles_x, int tiles_y,
+                                                     const uint8_t *__restrict__ lut, uint8_t *__restrict__ dst0,
+                                                     int dstride) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x - KLT_PAD;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y - KLT_PAD;
+    if (x >= w + KLT_PAD || y >= h + KLT_PAD) return;
+    const int sx = reflect101(x, w), sy = reflect101(y, h);
+    const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    float tyf = sy * inv_th - 0.5f;
+    int ty1 = (int)floorf(tyf);
+    int ty2 = ty1 + 1;
+    float ya = tyf - ty1, ya1 = 1.0f - ya;
+    if (ty1 < 0) ty1 = 0;
+    if (ty2 > tiles_y - 1) ty2 = tiles_y - 1;
+    float txf = sx * inv_tw - 0.5f;
+    int tx1 = (int)floorf(txf);
+    int tx2 = tx1 + 1;
+    float xa = txf - tx1, xa1 = 1.0f - xa;
+    if (tx1 < 0) tx1 = 0;
+    if (tx2 > tiles_x - 1) tx2 = tiles_x - 1;
+    const int v = src[(size_t)sy * sstride + sx];
+    const uint8_t *p1 = lut + (size_t)ty1 * tiles_x * 256;
+    const uint8_t *p2 = lut + (size_t)ty2 * tiles_x * 256;
+    const int i1 = tx1 * 256 + v, i2 = tx2 * 256 + v;
+    float res = (p1[i1] * xa1 + p1[i2] * xa) * ya1 + (p2[i1] * xa1 + p2[i2] * xa) * ya;
+    int r = __float2int_rn(res);
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    dst0[(ptrdiff_t)y * dstride + x] = (uint8_t)r;
+}
+
+// ------------------------------------------------------------------ pyrDown
+// cv::pyrDown 8U ([1 4 6 4 1]^2, (sum+128)>>8).  The source level already
+// carries a reflect-101 border >= 2, so taps read it directly.  Writes the
+// destination level including its own reflect-101 border.
+__global__ __launch_bounds__(256) void k_pyrdown(LevelView src, uint8_t *__restrict__ dst0, int dw, int dh,
+                                                 int dstride) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x - KLT_PAD;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y - KLT_PAD;
+    if (x >= dw + KLT_PAD || y >= dh + KLT_PAD) return;
+    const int ox = reflect101(x, dw), oy = reflect101(y, dh);
+    const uint8_t *s = src.img + (ptrdiff_t)(2 * oy - 2) * src.istride + (2 * ox - 2);
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int wj = (j == 0 || j == 4) ? 1 : ((j == 2) ? 6 : 4);
+        const uint8_t *r = s + (ptrdiff_t)j * src.istride;
+        int row = r[0] + r[4] + 4 * (r[1] + r[3]) + 6 * r[2];
+        acc += wj * row;
+    }
+    dst0[(ptrdiff_t)y * dstride + x] = (uint8_t)((acc + 128) >> 8);
+}
+
+// ------------------------------------------------------------------- Scharr
+// cv::detail::calcSharrDeriv for all levels in one launch.  blk_off[l] is the
+// first linear block index of level l (blocks are 64x4 pixel tiles).
+struct ScharrArgs {
+    LevelView lv[KLT_LEVELS];
+    short2 *out[KLT_LEVELS];   // pixel (0,0) of each padded derivative buffer
+    int blk_off[KLT_LEVELS + 1];
+    int blk_w[KLT_LEVELS];     // blocks per row of each level
+};
+
+__global__ __launch_bounds__(256) void k_scharr(ScharrArgs a) {
+    int b = blockIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < KLT_LEVELS; ++i)
+        if (b >= a.blk_off[i]) l = i;
+    b -= a.blk_off[l];
+    const LevelView L = a.lv[l];
+    const int bx = b % a.blk_w[l], by = b / a.blk_w[l];
+    const int x = bx * 64 + (threadIdx.x & 63);
+    const int y = by * 4 + (threadIdx.x >> 6);
+    if (x >= L.w || y >= L.h) return;
+    const uint8_t *r0 = L.img + (ptrdiff_t)(y - 1) * L.istride + x;
+    const uint8_t *r1 = r0 + L.istride;
+    const uint8_t *r2 = r1 + L.istride;
+    int t0m = (r0[-1] + r2[-1]) * 3 + r1[-1] * 10;
+    int t0p = (r0[1] + r2[1]) * 3 + r1[1] * 10;
+    int t1m = r2[-1] - r0[-1];
+    int t1c = r2[0] - r0[0];
+    int t1p = r2[1] - r0[1];
+    short2 d;
+    d.x = (short)(t0p - t0m);
+    d.y = (short)((t1p + t1m) * 3 + t1c * 10);
+    a.out[l][(ptrdiff_t)y * L.pstride + x] = d;
+}
+
+// ------------------------------------------------------------------- Harris
+__device__ __forceinline__ int float_order_key(float f) {
+    int b = __float_as_int(f);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float float_from_key(int k) {
+    return __int_as_float(k ^ ((k >> 31) & 0x7fffffff));
+}
+
+// cv::cornerHarris(8U, block 3, ksize 3, k) on the CLAHE image (pyramid level 0).
+// 64x16 output tile per workgroup; Sobel dx/dy staged in LDS as int16, the 3x3
+// window sums are exact int32.  Also reduces the global maximum.
+__global__ __launch_bounds__(256) void k_harris(LevelView L, double kk, float s2, float *__restrict__ resp,
+                                                int *__restrict__ max_key) {
+    __shared__ short sdx[18][66];
+    __shared__ short sdy[18][66];
+    const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * 16;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 18 * 66; i += 256) {
+        int cy = i / 66, cx = i - cy * 66;
+        int px = reflect101(X0 - 1 + cx, L.w), py = reflect101(Y0 - 1 + cy, L.h);
+        const uint8_t *r0 = L.img + (ptrdiff_t)(py - 1) * L.istride + px;
+        const uint8_t *r1 = r0 + L.istride;
+        const uint8_t *r2 = r1 + L.istride;
+        int dx = (r0[1] - r0[-1]) + 2 * (r1[1] - r1[-1]) + (r2[1] - r2[-1]);
+        int dy = (r2[-1] - r0[-1]) + 2 * (r2[0] - r0[0]) + (r2[1] - r0[1]);
+        sdx[cy][cx] = (short)dx;
+        sdy[cy][cx] = (short)dy;
+    }
+    __syncthreads();
+    const int lx = tid & 63, ly0 = tid >> 6;
+    float best = -3.402823466e+38f;
+    for (int q = 0; q < 4; ++q) {
+        const int ly = ly0 + 4 * q;
+        const int x = X0 + lx, y = Y0 + ly;
+        if (x < L.w && y < L.h) {
+            int sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    int dx = sdx[ly + j][lx + i], dy = sdy[ly + j][lx + i];
+                    sxx += dx * dx;
+                    sxy += dx * dy;
+                    syy += dy * dy;
+                }
+            float a = (float)sxx * s2, b = (float)sxy * s2, c = (float)syy * s2;
+            float t1 = a * c;
+            float t2 = b * b;
+            float t3 = t1 - t2;
+            float apc = a + c;
+            float r = (float)((double)t3 - kk * (double)apc * (double)apc);
+            resp[(size_t)y * L.w + x] = r;
+            best = fmaxf(best, r);
+        }
+    }
+    // wave max then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+    if ((tid & 63) == 0) atomicMax(max_key, float_order_key(best));
+}
+
+struct HarrisCand {
+    float v;
+    int idx;   // y*w + x
+};
+
+// threshold (quality * max) + 3x3 non-maximum suppression; candidates appended
+// in arbitrary order (the host orders them by the total order (v desc, idx desc)).
+__global__ __launch_bounds__(256) void k_harris_nms(const float *__restrict__ resp, int w, int h,
+                                                    const int *__restrict__ max_key, double quality,
+                                                    HarrisCand *__restrict__ cand, int *__restrict__ count,
+                                                    int capacity) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) return;
+    const float maxv = float_from_key(*max_key);
+    const float thr = (float)((double)maxv * quality);
+    const float *p = resp + (size_t)y * w + x;
+    const float v = p[0];
+    if (!(v > thr)) return;
+    if (v == 0.f) return;
+    bool ok = v >= p[-1] && v >= p[1] && v >= p[-w - 1] && v >= p[-w] && v >= p[-w + 1] && v >= p[w - 1] &&
+              v >= p[w] && v >= p[w + 1];
+    if (!ok) return;
+    int slot = atomicAdd(count, 1);
+    if (slot < capacity) {
+        cand[slot].v = v;
+        cand[slot].idx = y * w + x;
+    }
+}
+
+// ----------------------------------------------------------------------- LK
+constexpr int LK_SLOTS = 7;   // ceil(441 / 64)
+constexpr int LK_W_BITS = 14;
+
+__device__ __forceinline__ int lk_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+struct LkCounters {
+    unsigned long long templates;
+    unsigned long long iterations;
+};
+
+// One direction of cv::calcOpticalFlowPyrLK for ONE point, executed by one
+// wavefront (all lanes carry identical scalar state; the window is lane-striped).
+// Returns the status bit; nx,ny are the OPTFLOW_USE_INITIAL_FLOW guess on entry
+// and the tracked position on exit (level-0 pixels).
+__device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, float px0, float py0, float &nx_io,
+                                          float &ny_io, const int (&wx)[LK_SLOTS], const int (&wy)[LK_SLOTS],
+                                          const bool (&wvalid)[LK_SLOTS], unsigned &n_templates,
+                                          unsigned &n_iters) {
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float half = (KLT_WIN - 1) * 0.5f;
+    const double epsilon = 0.01 * 0.01;
+    int status = 1;
+    float outx = nx_io, outy = ny_io;
+    for (int level = KLT_LEVELS - 1; level >= 0; --level) {
+        const LevelView I = A.lv[level];
+        const LevelView J = B.lv[level];
+        const float lscale = (float)(1. / (1 << level));
+        float px = px0 * lscale, py = py0 * lscale;
+        float nx, ny;
+        if (level == KLT_LEVELS - 1) {
+            nx = outx * lscale;
+            ny = outy * lscale;
+        } else {
+            nx = outx * 2.f;
+            ny = outy * 2.f;
+        }
+        outx = nx;
+        outy = ny;
+        px -= half;
+        py -= half;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -KLT_WIN || ipx >= I.w || ipy < -KLT_WIN || ipy >= I.h) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        float a = px - ipx, b = py - ipy;
+        int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+        int iw01 = __float2int_rn(a * (1.f - b) * (1 << LK_W_BITS));
+        int iw10 = __float2int_rn((1.f - a) * b * (1 << LK_W_BITS));
+        int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+        int Iv[LK_SLOTS], Ix[LK_SLOTS], Iy[LK_SLOTS];
+        long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+        for (int s = 0; s < LK_SLOTS; ++s) {
+            Iv[s] = 0;
+            Ix[s] = 0;
+            Iy[s] = 0;
+            if (wvalid[s]) {
+                const uint8_t *s0 = I.img + (ptrdiff_t)(ipy + wy[s]) * I.istride + (ipx + wx[s]);
+                const uint8_t *s1 = s0 + I.istride;
+                const short2 *d0 = I.der + (ptrdiff_t)(ipy + wy[s]) * I.pstride + (ipx + wx[s]);
+                const short2 *d1 = d0 + I.pstride;
+                short2 g00 = d0[0], g01 = d0[1], g10 = d1[0], g11 = d1[1];
+                int ival = lk_descale(s0[0] * iw00 + s0[1] * iw01 + s1[0] * iw10 + s1[1] * iw11, LK_W_BITS - 5);
+                int ixval = lk_descale(g00.x * iw00 + g01.x * iw01 + g10.x * iw10 + g11.x * iw11, LK_W_BITS);
+                int iyval = lk_descale(g00.y * iw00 + g01.y * iw01 + g10.y * iw10 + g11.y * iw11, LK_W_BITS);
+                // OpenCV stores these as int16 (Iptr/dIptr are short)
+                ival = (short)ival;
+                ixval = (short)ixval;
+                iyval = (short)iyval;
+                Iv[s] = ival;
+                Ix[s] = ixval;
+                Iy[s] = iyval;
+                sA11 += (long long)(ixval * ixval);
+                sA12 += (long long)(ixval * iyval);
+                sA22 += (long long)(iyval * iyval);
+            }
+        }
+        sA11 = wave_sum_i64(sA11);
+        sA12 = wave_sum_i64(sA12);
+        sA22 = wave_sum_i64(sA22);
+        n_templates++;
+        const float A11 = (float)sA11 * FLT_SCALE;
+        const float A12 = (float)sA12 * FLT_SCALE;
+        const float A22 = (float)sA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig =
+            (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * KLT_WIN * KLT_WIN);
+        if (minEig < 1e-4f || D < 1.1920929e-07f) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nx -= half;
+        ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < 30; ++j) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -KLT_WIN || inx >= J.w || iny < -KLT_WIN || iny >= J.h) {
+                if (level == 0) status = 0;
+                break;
+            }
+            a = nx - inx;
+            b = ny - iny;
+            iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+            iw01 = __float2int_rn(a * (1.f - b) * (1 << LK_W_BITS));
+            iw10 = __float2int_rn((1.f - a) * b * (1 << LK_W_BITS));
+            iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+            long long sb1 = 0, sb2 = 0;
+#pragma unroll
+            for (int s = 0; s < LK_SLOTS; ++s) {
+                if (wvalid[s]) {
+                    const uint8_t *j0 = J.img + (ptrdiff_t)(iny + wy[s]) * J.istride + (inx + wx[s]);
+                    const uint8_t *j1 = j0 + J.istride;
+                    int diff =
+                        lk_descale(j0[0] * iw00 + j0[1] * iw01 + j1[0] * iw10 + j1[1] * iw11, LK_W_BITS - 5) - Iv[s];
+                    sb1 += (long long)(diff * Ix[s]);
+                    sb2 += (long long)(diff * Iy[s]);
+                }
+            }
+            sb1 = wave_sum_i64(sb1);
+            sb2 = wave_sum_i64(sb2);
+            n_iters++;
+            const float b1 = (float)sb1 * FLT_SCALE;
+            const float b2 = (float)sb2 * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D;
+            const float dy = (A12 * b1 - A11 * b2) * D;
+            nx += dx;
+            ny += dy;
+            outx = nx + half;
+            outy = ny + half;
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= epsilon) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                outx -= dx * 0.5f;
+                outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx;
+            pdy = dy;
+        }
+    }
+    nx_io = outx;
+    ny_io = outy;
+    return status;
+}
+
+__device__ __forceinline__ void lk_lane_layout(int lane, int (&wx)[LK_SLOTS], int (&wy)[LK_SLOTS],
+                                               bool (&wvalid)[LK_SLOTS]) {
+#pragma unroll
+    for (int s = 0; s < LK_SLOTS; ++s) {
+        int p = lane + 64 * s;
+        wvalid[s] = p < KLT_WIN * KLT_WIN;
+        if (!wvalid[s]) p = 0;
+        wy[s] = p / KLT_WIN;
+        wx[s] = p - wy[s] * KLT_WIN;
+    }
+}
+
+// OpenCvImage::track_keypoints: forward LK, border/displacement gates, backward
+// LK, 0.5 px round-trip check -- fused, one wavefront per keypoint.
+__global__ __launch_bounds__(64) void k_lk_track(PyrView A, PyrView B, const double2 *__restrict__ curr,
+                                                 double2 *__restrict__ next_io, int has_guess,
+                                                 uint8_t *__restrict__ status_out, int n,
+                                                 LkCounters *__restrict__ counters) {
+    const int pt = blockIdx.x;
+    if (pt >= n) return;
+    const int lane = threadIdx.x;
+    int wx[LK_SLOTS], wy[LK_SLOTS];
+    bool wvalid[LK_SLOTS];
+    lk_lane_layout(lane, wx, wy, wvalid);
+    const double2 c = curr[pt];
+    const float cx = (float)c.x, cy = (float)c.y;   // to_opencv(): double -> float
+    float nx = cx, ny = cy;
+    if (has_guess) {
+        const double2 g = next_io[pt];
+        nx = (float)g.x;
+        ny = (float)g.y;
+    }
+    unsigned n_templates = 0, n_iters = 0;
+    int status = lk_one_way(A, B, cx, cy, nx, ny, wx, wy, wvalid, n_templates, n_iters);
+    const int cols = A.lv[0].w, rows = A.lv[0].h;
+    if (nx < 20 || nx >= cols - 20 || ny < 20 || ny >= rows - 20) status = 0;
+    if (status) {
+        const float dx = nx - cx, dy = ny - cy;
+        const double nrm = sqrt((double)dx * (double)dx + (double)dy * (double)dy);
+        if (nrm > rows / 4) status = 0;
+    }
+    if (status) {
+        float rx = cx, ry = cy;
+        int st2 = lk_one_way(B, A, nx, ny, rx, ry, wx, wy, wvalid, n_templates, n_iters);
+        const float dx = cx - rx, dy = cy - ry;
+        const double nrm = sqrt((double)dx * (double)dx + (double)dy * (double)dy);
+        if (!st2 || nrm > 0.5) status = 0;
+    }
+    if (lane == 0) {
+        status_out[pt] = (uint8_t)status;
+        if (status) next_io[pt] = make_double2((double)nx, (double)ny);
+        if (counters) {
+            atomicAdd(&counters->templates, (unsigned long long)n_templates);
+            atomicAdd(&counters->iterations, (unsigned long long)n_iters);
+        }
+    }
+}
+
+// plain calcOpticalFlowPyrLK (float in/out, every point) -- parity aid
+__global__ __launch_bounds__(64) void k_lk_plain(PyrView A, PyrView B, const float2 *__restrict__ prev,
+                                                 float2 *__restrict__ next_io, uint8_t *__restrict__ status_out,
+                                                 int n) {
+    const int pt = blockIdx.x;
+    if (pt >= n) return;
+    const int lane = threadIdx.x;
+    int wx[LK_SLOTS], wy[LK_SLOTS];
+    bool wvalid[LK_SLOTS];
+    lk_lane_layout(lane, wx, wy, wvalid);
+    const float2 p = prev[pt];
+    float2 q = next_io[pt];
+    unsigned a = 0, b = 0;
+    int status = lk_one_way(A, B, p.x, p.y, q.x, q.y, wx, wy, wvalid, a, b);
+    if (lane == 0) {
+        status_out[pt] = (uint8_t)status;
+        next_io[pt] = q;
+    }
+}
+
+}   // namespace xrhip
