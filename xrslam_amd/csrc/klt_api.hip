@@ -350,7 +350,7 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
     ProfScope prof(c, CAT_DETECT);
     int rc = run_harris(im);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_harris_nms, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, c->stream, c->resp, w, h,
+    hipLaunchKernelGGL(k_harris_nms, dim3((w + 63) / 64, (h + 15) / 16), dim3(256), 0, c->stream, c->resp, w, h,
                        c->max_key, 1.0e-3, c->cand, c->cand_count, c->cand_cap);
     XR_HIP(hipGetLastError());
     prof.finish();
@@ -362,17 +362,27 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
         XR_HIP(hipMemcpyAsync(c->h_cand, c->cand, sizeof(HarrisCand) * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
         XR_HIP(hipStreamSynchronize(c->stream));
     }
-    // total order: response desc, then linear index desc (cv greaterThanPtr)
-    std::vector<HarrisCand> cs(c->h_cand, c->h_cand + nc);
-    std::sort(cs.begin(), cs.end(), [](const HarrisCand &a, const HarrisCand &b) {
+    // total order: response desc, then linear index desc (cv greaterThanPtr).  The greedy
+    // spacing pass usually stops after a few hundred candidates (max_points corners), so the
+    // order is produced lazily from a heap instead of sorting all candidates.
+    auto before = [](const HarrisCand &a, const HarrisCand &b) {   // a is visited before b
         if (a.v > b.v) return true;
         if (a.v < b.v) return false;
         return a.idx > b.idx;
-    });
-    std::vector<int> order(nc);
-    for (int i = 0; i < nc; ++i) order[i] = cs[i].idx;
+    };
+    auto heap_less = [&](const HarrisCand &a, const HarrisCand &b) { return before(b, a); };
+    HarrisCand *hb = c->h_cand, *he = c->h_cand + nc;
+    std::make_heap(hb, he, heap_less);
     // GFTTDetector(max_points, 1e-3, 20, 3, harris) -- minDistance is the literal 20 of opencv_image.cpp:186
-    std::vector<int> corners = greedy_min_distance(order, w, h, 20.0, max_points);
+    std::vector<int> corners = greedy_min_distance(
+        [&](int &idx) {
+            if (hb == he) return false;
+            std::pop_heap(hb, he, heap_less);
+            --he;
+            idx = he->idx;
+            return true;
+        },
+        w, h, 20.0, max_points);
     int n = 0;
     if (!corners.empty()) {
         PoissonDisk2 filter(min_distance);

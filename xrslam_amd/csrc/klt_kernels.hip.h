@@ -265,28 +265,46 @@ struct HarrisCand {
     int idx;   // y*w + x
 };
 
-// threshold (quality * max) + 3x3 non-maximum suppression; candidates appended
-// in arbitrary order (the host orders them by the total order (v desc, idx desc)).
+// threshold (quality * max) + 3x3 non-maximum suppression over a 64x16 tile per
+// workgroup.  Candidates are gathered in LDS and appended with ONE global atomic
+// per workgroup (a per-pixel atomic on a single counter serialises at ~100
+// atomics/us on this chip).  Order is arbitrary; the host orders candidates by
+// the total order (v desc, idx desc).
 __global__ __launch_bounds__(256) void k_harris_nms(const float *__restrict__ resp, int w, int h,
                                                     const int *__restrict__ max_key, double quality,
                                                     HarrisCand *__restrict__ cand, int *__restrict__ count,
                                                     int capacity) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) return;
+    __shared__ HarrisCand local[1024];
+    __shared__ int nlocal;
+    __shared__ int base;
+    const int tid = threadIdx.x;
+    if (tid == 0) nlocal = 0;
+    __syncthreads();
     const float maxv = float_from_key(*max_key);
     const float thr = (float)((double)maxv * quality);
-    const float *p = resp + (size_t)y * w + x;
-    const float v = p[0];
-    if (!(v > thr)) return;
-    if (v == 0.f) return;
-    bool ok = v >= p[-1] && v >= p[1] && v >= p[-w - 1] && v >= p[-w] && v >= p[-w + 1] && v >= p[w - 1] &&
-              v >= p[w] && v >= p[w + 1];
-    if (!ok) return;
-    int slot = atomicAdd(count, 1);
-    if (slot < capacity) {
-        cand[slot].v = v;
-        cand[slot].idx = y * w + x;
+    const int lx = tid & 63, ly0 = tid >> 6;
+    for (int q = 0; q < 4; ++q) {
+        const int x = blockIdx.x * 64 + lx;
+        const int y = blockIdx.y * 16 + ly0 + 4 * q;
+        if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
+        const float *p = resp + (size_t)y * w + x;
+        const float v = p[0];
+        if (!(v > thr) || v == 0.f) continue;
+        bool ok = v >= p[-1] && v >= p[1] && v >= p[-w - 1] && v >= p[-w] && v >= p[-w + 1] && v >= p[w - 1] &&
+                  v >= p[w] && v >= p[w + 1];
+        if (!ok) continue;
+        int slot = atomicAdd(&nlocal, 1);
+        local[slot].v = v;
+        local[slot].idx = y * w + x;
+    }
+    __syncthreads();
+    const int n = nlocal;
+    if (n == 0) return;
+    if (tid == 0) base = atomicAdd(count, n);
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        int slot = base + i;
+        if (slot < capacity) cand[slot] = local[i];
     }
 }
 
