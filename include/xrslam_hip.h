@@ -117,6 +117,112 @@ int xrhip_klt_set_profiling(xrhip_klt *ctx, int enable);
 int xrhip_klt_get_stats(xrhip_klt *ctx, xrhip_klt_stats *out, int reset);
 int xrhip_klt_synchronize(xrhip_klt *ctx);
 
+
+/* ------------------------------------------------------------------------
+ * Plug point #2: sliding-window visual-inertial bundle adjustment.
+ *
+ * The reference's Solver facade receives Frame / Track pointers and registers
+ * raw double* blocks with Ceres (solver.cpp:84-173).  Here the same problem is
+ * described by flat SoA arrays; states are read and written IN PLACE exactly
+ * like the reference (Frame::pose/motion, Track::landmark.inv_depth).
+ * ---------------------------------------------------------------------- */
+#define XRHIP_STATE_DIM 16 /* q(x,y,z,w) p(3) v(3) bg(3) ba(3): estimation/state.h:12-19, solver.cpp:86 */
+#define XRHIP_ES_DIM 15    /* error-state size ES_SIZE */
+/* one pre-integrated IMU factor (PreIntegrator::Delta + Jacobian, preintegrator.h:11-48):
+ * [0] dt, [1..4] dq(x,y,z,w), [5..7] dp, [8..10] dv,
+ * [11..55] dq_dbg, dp_dbg, dp_dba, dv_dbg, dv_dba (3x3 row-major each),
+ * [56..280] sqrt_inv_cov (15x15 row-major) */
+#define XRHIP_IMU_DIM 281
+
+#define XRHIP_FIX_POSE 1   /* FT_FIX_POSE, or the frame is only referenced as a constant */
+#define XRHIP_FIX_MOTION 2 /* FT_FIX_MOTION, or the motion blocks are not part of the problem */
+
+typedef struct xrhip_ba_problem {
+    /* frames: add_frame_states (solver.cpp:84-106) */
+    int n_frames;
+    double *frame_state;          /* [n_frames][16], in/out */
+    const uint8_t *frame_fix;     /* [n_frames], XRHIP_FIX_* bits */
+    double cam_q_bc[4], cam_p_bc[3]; /* Frame::camera (q_cs xyzw, p_cs), identical for all frames (detail.cpp:110-111) */
+    double imu_q_bi[4], imu_p_bi[3]; /* Frame::imu */
+    double sqrt_inv_cov[2];       /* Frame::sqrt_inv_cov diagonal = (fx,fy)/sqrt(keypoint noise) (detail.cpp:107-109) */
+    /* landmarks: add_track_states (solver.cpp:108-110) */
+    int n_landmarks;
+    double *inv_depth;            /* [n_landmarks], in/out */
+    const uint8_t *landmark_fix;  /* [n_landmarks], 1 = constant (ReprojectionPriorFactor) */
+    /* CeresReprojectionErrorFactor / CeresReprojectionPriorFactor (ceres/reprojection_factor.h:25-123), CauchyLoss(1) */
+    int n_obs;
+    const int *obs_tgt, *obs_ref, *obs_lm; /* frame index of the observing frame, of track->first_frame(), landmark index */
+    const double *obs_z_tgt, *obs_z_ref;   /* [n_obs][3] unit bearings */
+    /* CeresRotationPriorFactor (ceres/rotation_factor.h:23-59), CauchyLoss(1) */
+    int n_rot;
+    const int *rot_tgt, *rot_ref;
+    const double *rot_z_tgt, *rot_z_ref;   /* [n_rot][3] */
+    /* CeresPreIntegrationErrorFactor / ...PriorFactor (ceres/preintegration_factor.h:20-199), no loss */
+    int n_imu;
+    const int *imu_i, *imu_j;
+    const double *imu_data;       /* [n_imu][XRHIP_IMU_DIM] */
+    /* CeresMarginalizationFactor (ceres/marginalization_factor.h:27-72), no loss; prior_n == 0 -> absent */
+    int prior_n;                  /* number of frames in linearization_frames() */
+    const int *prior_frames;      /* [prior_n] indices into the frame arrays */
+    const double *prior_sqrt_info; /* [15 prior_n][15 prior_n] row-major sqrt_inv_cov */
+    const double *prior_infovec;  /* [15 prior_n] */
+    const double *prior_lin;      /* [prior_n][16] linearisation points */
+    /* Solver::solve options (solver.cpp:176-190): SPARSE_SCHUR + DOGLEG, Ceres 1.14 defaults otherwise */
+    int max_iterations;           /* config solver.iteration_limit */
+} xrhip_ba_problem;
+
+#define XRHIP_BA_CONVERGENCE 0
+#define XRHIP_BA_NO_CONVERGENCE 1
+#define XRHIP_BA_FAILURE 2
+
+typedef struct xrhip_ba_summary {
+    int iterations;        /* trust-region iterations executed (successful + unsuccessful) */
+    int successful_steps;
+    int termination;       /* XRHIP_BA_* */
+    int usable;            /* Summary::IsSolutionUsable() */
+    double initial_cost, final_cost;
+    double ms_solve;       /* HIP-event time of the whole solve on the BA stream */
+} xrhip_ba_summary;
+
+/* marginalisation of one frame (CeresMarginalizationFactor::marginalize,
+ * ceres/marginalization_factor.h:74-475).  All map frames are given in map order. */
+typedef struct xrhip_marg_problem {
+    int n_frames;                 /* base_map->frame_num() at call time */
+    int victim;                   /* index of the frame to remove (the reference only ever passes 0) */
+    const double *frame_state;    /* [n_frames][16] */
+    double cam_q_bc[4], cam_p_bc[3], imu_q_bi[4], imu_p_bi[3], sqrt_inv_cov[2];
+    /* old prior (factor state before the call) */
+    int prior_n;
+    const int *prior_frames;
+    const double *prior_sqrt_info, *prior_infovec, *prior_lin;
+    /* IMU factors touching the victim: (victim-1,victim) and (victim,victim+1) where they exist */
+    int n_imu;
+    const int *imu_i, *imu_j;
+    const double *imu_data;       /* keyframe_preintegration of frame j */
+    /* reprojection factors of tracks seen in the victim (marginalization_factor.h:234-380); no robust loss */
+    int n_landmarks;
+    const double *inv_depth;
+    int n_obs;
+    const int *obs_tgt, *obs_ref, *obs_lm;
+    const double *obs_z_tgt, *obs_z_ref;
+} xrhip_marg_problem;
+
+typedef struct xrhip_ba xrhip_ba;
+int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **out);
+void xrhip_ba_destroy(xrhip_ba *ctx);
+/* replaces: Solver::solve() over a problem assembled with add_frame_states/add_track_states/add_factor */
+int xrhip_ba_solve(xrhip_ba *ctx, const xrhip_ba_problem *problem, xrhip_ba_summary *summary);
+/* replaces: MarginalizationFactor::marginalize(index).  Outputs the new prior over the n_frames-1
+ * remaining frames (map order): sqrt_info [(15(n-1))^2], infovec [15(n-1)], lin [(n-1)][16]. */
+int xrhip_ba_marginalize(xrhip_ba *ctx, const xrhip_marg_problem *problem, double *out_sqrt_info,
+                         double *out_infovec, double *out_lin);
+/* replaces: PreIntegrator::integrate(t, bg, ba, compute_jacobian, compute_covariance)
+ * (preintegrator.cpp:78-100).  samples: [n][7] = t, w(3), a(3); noise: cov_w, cov_a, cov_bg, cov_ba as
+ * 3x3 row-major (36 doubles).  out: XRHIP_IMU_DIM doubles. */
+int xrhip_ba_preintegrate(xrhip_ba *ctx, const double *samples, int n, double t_end, const double *bg,
+                          const double *ba, const double *noise_cov36, int compute_jacobian,
+                          int compute_covariance, double *out);
+
 #ifdef __cplusplus
 }
 #endif
