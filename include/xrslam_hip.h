@@ -223,6 +223,12 @@ int xrhip_ba_preintegrate(xrhip_ba *ctx, const double *samples, int n, double t_
                           const double *ba, const double *noise_cov36, int compute_jacobian,
                           int compute_covariance, double *out);
 
+/* parity/testing aids (not part of the reference interface): the unreduced normal equations of one
+ * linearisation, and the MFMA Schur product kernel on arbitrary inputs. */
+int xrhip_ba_debug_linearize(xrhip_ba *ctx, const xrhip_ba_problem *problem, double *H, double *g, double *hll,
+                             double *gl, double *W, double *cost);
+int xrhip_ba_debug_schur(xrhip_ba *ctx, const double *W, const double *w, int L, int P, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,95 @@
+"""ctypes mirror of plug point #2 (xrslam::Solver / MarginalizationFactor) over include/xrslam_hip.h."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, abi
+from ._lib import check
+
+_L = None
+
+
+def L():
+    global _L
+    if _L is None:
+        lib = _lib.lib()
+        vp = C.c_void_p
+        lib.xrhip_ba_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        lib.xrhip_ba_destroy.argtypes = [vp]
+        lib.xrhip_ba_destroy.restype = None
+        lib.xrhip_ba_solve.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary)]
+        lib.xrhip_ba_marginalize.argtypes = [vp, C.POINTER(abi.MargProblem), vp, vp, vp]
+        lib.xrhip_ba_preintegrate.argtypes = [vp, vp, C.c_int, C.c_double, vp, vp, vp, C.c_int, C.c_int, vp]
+        lib.xrhip_ba_debug_linearize.argtypes = [vp, C.POINTER(abi.BaProblem), vp, vp, vp, vp, vp, vp]
+        lib.xrhip_ba_debug_schur.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+        _L = lib
+    return _L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class BaContext:
+    """One per sequence: owns the BA stream and device arenas."""
+
+    def __init__(self, max_frames=24, max_landmarks=1024, max_obs=8192):
+        h = C.c_void_p()
+        check(L().xrhip_ba_create(int(max_frames), int(max_landmarks), int(max_obs), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L().xrhip_ba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, pd):
+        """Solver::solve(): optimises pd.frame_state / pd.inv_depth in place; returns abi.BaSummary."""
+        s = pd.struct()
+        sm = abi.BaSummary()
+        check(L().xrhip_ba_solve(self._h, C.byref(s), C.byref(sm)))
+        return sm
+
+    def marginalize(self, md):
+        s = md.struct()
+        k = len(md.frame_state) - 1
+        n = 15 * k
+        si = np.zeros((n, n))
+        iv = np.zeros(n)
+        lin = np.zeros((k, 16))
+        check(L().xrhip_ba_marginalize(self._h, C.byref(s), _p(si), _p(iv), _p(lin)))
+        return si, iv, lin
+
+    def preintegrate(self, samples, t_end, bg, ba, noise36, jac=True, cov=True):
+        samples = np.ascontiguousarray(samples, np.float64).reshape(-1, 7)
+        bg, ba, noise36 = [np.ascontiguousarray(v, np.float64) for v in (bg, ba, noise36)]
+        out = np.zeros(abi.IMU_DIM)
+        check(L().xrhip_ba_preintegrate(self._h, _p(samples), len(samples), float(t_end), _p(bg), _p(ba), _p(noise36),
+                                        int(jac), int(cov), _p(out)))
+        return out
+
+    def debug_linearize(self, pd):
+        s = pd.struct()
+        F, Ln = len(pd.frame_state), len(pd.inv_depth)
+        H = np.zeros((15 * F, 15 * F))
+        g = np.zeros(15 * F)
+        hll = np.zeros(max(Ln, 1))
+        gl = np.zeros(max(Ln, 1))
+        W = np.zeros((max(Ln, 1), 6 * F))
+        cost = C.c_double()
+        check(L().xrhip_ba_debug_linearize(self._h, C.byref(s), _p(H), _p(g), _p(hll), _p(gl), _p(W), C.byref(cost)))
+        return dict(H=H, g=g, hll=hll[:Ln], gl=gl[:Ln], W=W[:Ln], cost=cost.value)
+
+    def debug_schur(self, W, w):
+        W = np.ascontiguousarray(W, np.float64)
+        w = np.ascontiguousarray(w, np.float64)
+        Ln, P = W.shape
+        out = np.zeros((P, P))
+        check(L().xrhip_ba_debug_schur(self._h, _p(W), _p(w), Ln, P, _p(out)))
+        return out

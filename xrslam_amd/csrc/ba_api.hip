@@ -1,0 +1,523 @@
+// ba_api.hip -- C ABI of the bundle adjustment (include/xrslam_hip.h, plug point #2).
+// Host side of xrslam::Solver for gfx950: packs the factor graph into one device arena,
+// builds the gather indices, and drives the kernel sequence of ba_kernels.hip.h.  The
+// trust-region trial loop runs on the device (kb_try); the host only intervenes when a new
+// linearisation or a re-solve of the linear system is needed.
+#include "../../include/xrslam_hip.h"
+#include "ba_kernels.hip.h"
+#include "common.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+using namespace xrhip;
+
+namespace {
+
+struct Arena {   // bump allocator over one device buffer mirrored by a pinned host buffer
+    char *dev = nullptr, *host = nullptr;
+    size_t cap = 0, used = 0;
+    size_t take(size_t bytes) {
+        size_t off = (used + 255) & ~size_t(255);
+        used = off + bytes;
+        return off;
+    }
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}   // namespace
+
+struct xrhip_ba {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Arena in;         // inputs (uploaded every solve)
+    char *work = nullptr;   // device-only workspace
+    size_t work_cap = 0;
+    BaCtl *h_ctl = nullptr;   // pinned
+    double *h_out = nullptr;  // pinned readback (states + depths)
+    size_t h_out_cap = 0;
+    int lds_limit = 150 * 1024;
+    // last linearisation (debug/parity access)
+    BaDims dims{};
+    BaPtrs ptrs{};
+    bool have_lin = false;
+};
+
+static int ensure_arena(xrhip_ba *c, size_t in_bytes, size_t work_bytes, size_t out_doubles) {
+    if (in_bytes > c->in.cap) {
+        if (c->in.dev) hipFree(c->in.dev);
+        if (c->in.host) hipHostFree(c->in.host);
+        c->in.dev = c->in.host = nullptr;
+        size_t cap = std::max(in_bytes * 2, size_t(1) << 20);
+        XR_HIP(hipMalloc(&c->in.dev, cap));
+        XR_HIP(hipHostMalloc(&c->in.host, cap, hipHostMallocDefault));
+        c->in.cap = cap;
+    }
+    if (work_bytes > c->work_cap) {
+        if (c->work) hipFree(c->work);
+        c->work = nullptr;
+        size_t cap = std::max(work_bytes * 2, size_t(1) << 20);
+        XR_HIP(hipMalloc(&c->work, cap));
+        c->work_cap = cap;
+    }
+    if (out_doubles > c->h_out_cap) {
+        if (c->h_out) hipHostFree(c->h_out);
+        c->h_out = nullptr;
+        XR_HIP(hipHostMalloc(&c->h_out, sizeof(double) * out_doubles * 2, hipHostMallocDefault));
+        c->h_out_cap = out_doubles * 2;
+    }
+    return XRHIP_OK;
+}
+
+static int validate(const xrhip_ba_problem *P) {
+    if (!P || P->n_frames <= 0 || !P->frame_state || !P->frame_fix) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: frames missing");
+    if (P->n_landmarks < 0 || P->n_obs < 0 || P->n_rot < 0 || P->n_imu < 0 || P->prior_n < 0)
+        return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: negative count");
+    for (int o = 0; o < P->n_obs; ++o)
+        if (P->obs_tgt[o] < 0 || P->obs_tgt[o] >= P->n_frames || P->obs_ref[o] < 0 || P->obs_ref[o] >= P->n_frames ||
+            P->obs_lm[o] < 0 || P->obs_lm[o] >= P->n_landmarks || P->obs_tgt[o] == P->obs_ref[o])
+            return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: observation index out of range");
+    for (int o = 0; o < P->n_rot; ++o)
+        if (P->rot_tgt[o] < 0 || P->rot_tgt[o] >= P->n_frames || P->rot_ref[o] < 0 || P->rot_ref[o] >= P->n_frames)
+            return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: rotation factor index out of range");
+    for (int k = 0; k < P->n_imu; ++k)
+        if (P->imu_i[k] < 0 || P->imu_i[k] >= P->n_frames || P->imu_j[k] < 0 || P->imu_j[k] >= P->n_frames ||
+            P->imu_i[k] == P->imu_j[k])
+            return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: imu factor index out of range");
+    for (int k = 0; k < P->prior_n; ++k)
+        if (P->prior_frames[k] < 0 || P->prior_frames[k] >= P->n_frames)
+            return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: prior frame index out of range");
+    return XRHIP_OK;
+}
+
+// Packs the problem + gather indices into the input arena, carves the workspace and fills dims/ptrs.
+static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPtrs &p, Ext &cam, Ext &imu) {
+    d.F = P->n_frames;
+    d.n = 15 * d.F;
+    d.PF = round_up(6 * d.F, 16);
+    d.L = P->n_landmarks;
+    d.Lp = std::max(16, round_up(d.L, 16));
+    d.M = P->n_obs;
+    d.MR = P->n_rot;
+    d.NI = P->n_imu;
+    d.NP = P->prior_n;
+    d.np = 15 * d.NP;
+    d.NV = d.n + d.L;
+    const int F = d.F, L = d.L, M = d.M, MR = d.MR, NI = d.NI, NP = d.NP, np = d.np, n = d.n;
+
+    // ---- host-side index structures
+    std::vector<uint8_t> lact(std::max(L, 1), 0);
+    for (int o = 0; o < M; ++o) lact[P->obs_lm[o]] = 1;
+    for (int l = 0; l < L; ++l)
+        if (P->landmark_fix && P->landmark_fix[l]) lact[l] = 0;
+    std::vector<int> lm_start(L + 1, 0), lm_obs(std::max(M, 1));
+    for (int o = 0; o < M; ++o) lm_start[P->obs_lm[o] + 1]++;
+    for (int l = 0; l < L; ++l) lm_start[l + 1] += lm_start[l];
+    {
+        std::vector<int> fill(lm_start.begin(), lm_start.end() - 1);
+        for (int o = 0; o < M; ++o) lm_obs[fill[P->obs_lm[o]]++] = o;
+    }
+    std::vector<int> pair_start((size_t)F * F + 1, 0), pair_items(std::max(4 * M, 1));
+    auto pair_count = [&](int a, int b) { pair_start[(size_t)a * F + b + 1]++; };
+    for (int o = 0; o < M; ++o) {
+        const int t = P->obs_tgt[o], r = P->obs_ref[o];
+        pair_count(t, t);
+        pair_count(r, r);
+        pair_count(t, r);
+        pair_count(r, t);
+    }
+    for (size_t i = 0; i < (size_t)F * F; ++i) pair_start[i + 1] += pair_start[i];
+    {
+        std::vector<int> fill(pair_start.begin(), pair_start.end() - 1);
+        for (int o = 0; o < M; ++o) {
+            const int t = P->obs_tgt[o], r = P->obs_ref[o];
+            pair_items[fill[(size_t)t * F + t]++] = (o << 1) | 0;
+            pair_items[fill[(size_t)r * F + r]++] = (o << 1) | 1;
+            pair_items[fill[(size_t)t * F + r]++] = (o << 1) | 0;
+            pair_items[fill[(size_t)r * F + t]++] = (o << 1) | 1;
+        }
+    }
+    std::vector<int> rotf_start(F + 1, 0), rotf_items(std::max(MR, 1));
+    for (int o = 0; o < MR; ++o) rotf_start[P->rot_tgt[o] + 1]++;
+    for (int f = 0; f < F; ++f) rotf_start[f + 1] += rotf_start[f];
+    {
+        std::vector<int> fill(rotf_start.begin(), rotf_start.end() - 1);
+        for (int o = 0; o < MR; ++o) rotf_items[fill[P->rot_tgt[o]]++] = o;
+    }
+    std::vector<int> imuf(2 * F, -1), priorf(F, -1);
+    for (int k = 0; k < NI; ++k) {
+        if (imuf[2 * P->imu_j[k]] >= 0 || imuf[2 * P->imu_i[k] + 1] >= 0)
+            return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: a frame may end at most one IMU factor and start at most one");
+        imuf[2 * P->imu_j[k]] = k;
+        imuf[2 * P->imu_i[k] + 1] = k;
+    }
+    for (int k = 0; k < NP; ++k) priorf[P->prior_frames[k]] = k;
+
+    // ---- input arena layout
+    Arena &A = c->in;
+    A.used = 0;
+    struct Item {
+        size_t off;
+        const void *src;
+        size_t bytes;
+    };
+    std::vector<Item> items;
+    auto put = [&](const void *src, size_t bytes) {
+        size_t off = A.take(std::max(bytes, size_t(8)));
+        items.push_back({off, src, bytes});
+        return off;
+    };
+    std::vector<double> bias_ref((size_t)6 * std::max(NI, 1));
+    for (int k = 0; k < NI; ++k)
+        for (int i = 0; i < 6; ++i) bias_ref[6 * k + i] = P->frame_state[16 * P->imu_i[k] + 10 + i];
+    BaCtl ctl;
+    std::memset(&ctl, 0, sizeof(ctl));
+    ctl.radius = 1e4;
+    ctl.mu = 1e-8;
+    ctl.first = 1;
+    ctl.linear_ok = 1;
+    ctl.max_iterations = P->max_iterations;
+    ctl.termination = XRHIP_BA_NO_CONVERGENCE;
+    const size_t o_state = put(P->frame_state, sizeof(double) * 16 * F);
+    const size_t o_fix = put(P->frame_fix, F);
+    const size_t o_depth = put(P->inv_depth, sizeof(double) * L);
+    const size_t o_lact = put(lact.data(), std::max(L, 1));
+    const size_t o_ot = put(P->obs_tgt, sizeof(int) * M), o_or = put(P->obs_ref, sizeof(int) * M);
+    const size_t o_ol = put(P->obs_lm, sizeof(int) * M);
+    const size_t o_zt = put(P->obs_z_tgt, sizeof(double) * 3 * M), o_zr = put(P->obs_z_ref, sizeof(double) * 3 * M);
+    const size_t o_rt = put(P->rot_tgt, sizeof(int) * MR), o_rr = put(P->rot_ref, sizeof(int) * MR);
+    const size_t o_rzt = put(P->rot_z_tgt, sizeof(double) * 3 * MR), o_rzr = put(P->rot_z_ref, sizeof(double) * 3 * MR);
+    const size_t o_ii = put(P->imu_i, sizeof(int) * NI), o_ij = put(P->imu_j, sizeof(int) * NI);
+    const size_t o_idata = put(P->imu_data, sizeof(double) * XRHIP_IMU_DIM * NI);
+    const size_t o_bref = put(bias_ref.data(), sizeof(double) * 6 * NI);
+    const size_t o_pf = put(P->prior_frames, sizeof(int) * NP);
+    const size_t o_pS = put(P->prior_sqrt_info, sizeof(double) * (size_t)np * np);
+    const size_t o_pi = put(P->prior_infovec, sizeof(double) * np);
+    const size_t o_pl = put(P->prior_lin, sizeof(double) * 16 * NP);
+    const size_t o_lms = put(lm_start.data(), sizeof(int) * (L + 1)), o_lmo = put(lm_obs.data(), sizeof(int) * M);
+    const size_t o_ps = put(pair_start.data(), sizeof(int) * ((size_t)F * F + 1));
+    const size_t o_pit = put(pair_items.data(), sizeof(int) * 4 * M);
+    const size_t o_rfs = put(rotf_start.data(), sizeof(int) * (F + 1)), o_rfi = put(rotf_items.data(), sizeof(int) * MR);
+    const size_t o_imuf = put(imuf.data(), sizeof(int) * 2 * F), o_prf = put(priorf.data(), sizeof(int) * F);
+    const size_t o_ctl = put(&ctl, sizeof(ctl));
+    const size_t in_bytes = A.used + 256;
+
+    // ---- workspace layout (device only)
+    size_t w = 0;
+    auto carve = [&](size_t bytes) {
+        size_t off = (w + 255) & ~size_t(255);
+        w = off + std::max(bytes, size_t(8));
+        return off;
+    };
+    const size_t D8 = sizeof(double);
+    const size_t w_cand = carve(D8 * 16 * F), w_dcand = carve(D8 * L);
+    const size_t w_pLam = carve(D8 * (size_t)np * np);
+    const size_t w_orec = carve(D8 * OREC * M), w_ocost = carve(D8 * M);
+    const size_t w_rrec = carve(D8 * RREC * MR), w_rcost = carve(D8 * MR);
+    const size_t w_ir = carve(D8 * 15 * NI), w_iJi = carve(D8 * 225 * NI), w_iJj = carve(D8 * 225 * NI);
+    const size_t w_ic = carve(D8 * NI);
+    const size_t w_pr = carve(D8 * np), w_pt = carve(D8 * np), w_pJq = carve(D8 * 9 * NP), w_pc = carve(D8);
+    const size_t w_H = carve(D8 * (size_t)n * n), w_g = carve(D8 * n);
+    const size_t w_hll = carve(D8 * d.Lp), w_gl = carve(D8 * d.Lp), w_Wt = carve(D8 * (size_t)d.Lp * d.PF);
+    const size_t w_sp = carve(D8 * n), w_sl = carve(D8 * d.Lp), w_om = carve(D8 * d.Lp);
+    const size_t w_T = carve(D8 * (size_t)d.PF * d.PF), w_S = carve(D8 * (size_t)n * n);
+    const size_t w_dD = carve(D8 * d.NV), w_gr = carve(D8 * d.NV), w_gn = carve(D8 * d.NV), w_gs = carve(D8 * d.NV);
+    const size_t w_st = carve(D8 * d.NV), w_de = carve(D8 * d.NV), w_part = carve(D8 * 64);
+    int rc = ensure_arena(c, in_bytes, w + 256, (size_t)16 * F + L + 8);
+    if (rc) return rc;
+    for (const Item &it : items)
+        if (it.bytes) std::memcpy(A.host + it.off, it.src, it.bytes);
+    XR_HIP(hipMemcpyAsync(A.dev, A.host, in_bytes, hipMemcpyHostToDevice, c->stream));
+
+    char *I = A.dev, *W = c->work;
+    p.state = (double *)(I + o_state);
+    p.cand = (double *)(W + w_cand);
+    p.fix = (const uint8_t *)(I + o_fix);
+    p.depth = (double *)(I + o_depth);
+    p.depth_cand = (double *)(W + w_dcand);
+    p.lact = (const uint8_t *)(I + o_lact);
+    p.obs_tgt = (const int *)(I + o_ot);
+    p.obs_ref = (const int *)(I + o_or);
+    p.obs_lm = (const int *)(I + o_ol);
+    p.obs_zt = (const double *)(I + o_zt);
+    p.obs_zr = (const double *)(I + o_zr);
+    p.rot_tgt = (const int *)(I + o_rt);
+    p.rot_ref = (const int *)(I + o_rr);
+    p.rot_zt = (const double *)(I + o_rzt);
+    p.rot_zr = (const double *)(I + o_rzr);
+    p.imu_i = (const int *)(I + o_ii);
+    p.imu_j = (const int *)(I + o_ij);
+    p.imu_data = (const double *)(I + o_idata);
+    p.bias_ref = (double *)(I + o_bref);
+    p.prior_frames = (const int *)(I + o_pf);
+    p.pS = (const double *)(I + o_pS);
+    p.pinfo = (const double *)(I + o_pi);
+    p.plin = (const double *)(I + o_pl);
+    p.pLam = (double *)(W + w_pLam);
+    p.lm_start = (const int *)(I + o_lms);
+    p.lm_obs = (const int *)(I + o_lmo);
+    p.pair_start = (const int *)(I + o_ps);
+    p.pair_items = (const int *)(I + o_pit);
+    p.rotf_start = (const int *)(I + o_rfs);
+    p.rotf_items = (const int *)(I + o_rfi);
+    p.imuf = (const int *)(I + o_imuf);
+    p.priorf = (const int *)(I + o_prf);
+    p.orec = (double *)(W + w_orec);
+    p.ocost = (double *)(W + w_ocost);
+    p.rrec = (double *)(W + w_rrec);
+    p.rcost = (double *)(W + w_rcost);
+    p.imu_r = (double *)(W + w_ir);
+    p.imu_Ji = (double *)(W + w_iJi);
+    p.imu_Jj = (double *)(W + w_iJj);
+    p.imu_cost = (double *)(W + w_ic);
+    p.pr = (double *)(W + w_pr);
+    p.pt = (double *)(W + w_pt);
+    p.pJq = (double *)(W + w_pJq);
+    p.pcost = (double *)(W + w_pc);
+    p.Hpp = (double *)(W + w_H);
+    p.gp = (double *)(W + w_g);
+    p.hll = (double *)(W + w_hll);
+    p.gl = (double *)(W + w_gl);
+    p.Wt = (double *)(W + w_Wt);
+    p.sp = (double *)(W + w_sp);
+    p.sl = (double *)(W + w_sl);
+    p.omega = (double *)(W + w_om);
+    p.T = (double *)(W + w_T);
+    p.Sred = (double *)(W + w_S);
+    p.diagD = (double *)(W + w_dD);
+    p.grad = (double *)(W + w_gr);
+    p.gn = (double *)(W + w_gn);
+    p.gs = (double *)(W + w_gs);
+    p.step = (double *)(W + w_st);
+    p.delta = (double *)(W + w_de);
+    p.partial = (double *)(W + w_part);
+    p.ctl = (BaCtl *)(I + o_ctl);
+    cam.q = Q4{P->cam_q_bc[0], P->cam_q_bc[1], P->cam_q_bc[2], P->cam_q_bc[3]};
+    cam.p = V3{P->cam_p_bc[0], P->cam_p_bc[1], P->cam_p_bc[2]};
+    imu.q = Q4{P->imu_q_bi[0], P->imu_q_bi[1], P->imu_q_bi[2], P->imu_q_bi[3]};
+    imu.p = V3{P->imu_p_bi[0], P->imu_p_bi[1], P->imu_p_bi[2]};
+    return XRHIP_OK;
+}
+
+static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
+                             double sy) {
+    hipStream_t s = c->stream;
+    if (d.M) hipLaunchKernelGGL(kb_lin_obs, dim3((d.M + 255) / 256), dim3(256), 0, s, d, p, cam, sx, sy);
+    if (d.MR) hipLaunchKernelGGL(kb_lin_rot, dim3((d.MR + 255) / 256), dim3(256), 0, s, d, p, cam, sx, sy);
+    if (d.NI) hipLaunchKernelGGL(kb_lin_imu, dim3(d.NI), dim3(64), 0, s, d, p, imu);
+    hipLaunchKernelGGL(kb_lin_prior, dim3(1), dim3(256), sizeof(double) * std::max(d.np, 1), s, d, p);
+    hipLaunchKernelGGL(kb_landmark, dim3(d.Lp), dim3(64), 0, s, d, p);
+    hipLaunchKernelGGL(kb_assemble, dim3((d.n * d.n + 255) / 256), dim3(256), 0, s, d, p);
+    hipLaunchKernelGGL(kb_sum_cost, dim3(1), dim3(256), 0, s, d, p);
+    hipLaunchKernelGGL(kb_gradmax, dim3(1), dim3(256), 0, s, d, p);
+}
+
+static int launch_solve(xrhip_ba *c, const BaDims &d, const BaPtrs &p) {
+    hipStream_t s = c->stream;
+    hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);
+    const int tiles = d.PF / 16;
+    hipLaunchKernelGGL(kb_schur_mfma, dim3(tiles * tiles), dim3(256), 0, s, d, p);
+    size_t lds = sizeof(double) * ((size_t)((d.n + 1) & ~1) + (size_t)d.n * (d.n + 1) / 2);
+    int use_lds = 1;
+    if (lds > (size_t)c->lds_limit) {
+        use_lds = 0;
+        lds = sizeof(double) * (size_t)((d.n + 1) & ~1);
+    }
+    hipLaunchKernelGGL(kb_solve, dim3(1), dim3(512), lds, s, d, p, use_lds);
+    XR_HIP(hipGetLastError());
+    return XRHIP_OK;
+}
+
+extern "C" {
+
+int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **out) {
+    if (!out || max_frames <= 0 || max_landmarks < 0 || max_obs < 0) return xr_fail(XRHIP_EINVAL, "xrhip_ba_create: bad arguments");
+    int rc = xr_require_device();
+    if (rc) return rc;
+    xrhip_ba *c = new xrhip_ba();
+    XR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    XR_HIP(hipEventCreate(&c->ev0));
+    XR_HIP(hipEventCreate(&c->ev1));
+    XR_HIP(hipHostMalloc(&c->h_ctl, sizeof(BaCtl), hipHostMallocDefault));
+    XR_HIP(hipFuncSetAttribute((const void *)kb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+    XR_HIP(hipFuncSetAttribute((const void *)kb_try, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    // pre-size for the advertised maxima
+    size_t in_guess = (size_t)max_obs * 96 + (size_t)max_frames * max_frames * 15 * 15 * 8 + (size_t)max_frames * 3000 + 65536;
+    rc = ensure_arena(c, in_guess, in_guess * 4, (size_t)16 * max_frames + max_landmarks + 8);
+    if (rc) return rc;
+    *out = c;
+    return XRHIP_OK;
+}
+
+void xrhip_ba_destroy(xrhip_ba *c) {
+    if (!c) return;
+    hipStreamSynchronize(c->stream);
+    hipFree(c->in.dev);
+    hipHostFree(c->in.host);
+    hipFree(c->work);
+    hipHostFree(c->h_ctl);
+    hipHostFree(c->h_out);
+    hipEventDestroy(c->ev0);
+    hipEventDestroy(c->ev1);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: null context");
+    int rc = validate(P);
+    if (rc) return rc;
+    xrhip_ba_summary sm;
+    std::memset(&sm, 0, sizeof(sm));
+    // trivial problem: nothing to optimise
+    bool any_free = false;
+    for (int f = 0; f < P->n_frames; ++f)
+        if ((P->frame_fix[f] & 3) != 3) any_free = true;
+    if (!any_free) {
+        std::vector<char> used(std::max(P->n_landmarks, 1), 0);
+        for (int o = 0; o < P->n_obs; ++o) used[P->obs_lm[o]] = 1;
+        for (int l = 0; l < P->n_landmarks; ++l)
+            if (used[l] && !(P->landmark_fix && P->landmark_fix[l])) any_free = true;
+    }
+    if (!any_free) {
+        sm.termination = XRHIP_BA_CONVERGENCE;
+        sm.usable = 1;
+        if (summary) *summary = sm;
+        return XRHIP_OK;
+    }
+    BaDims d;
+    BaPtrs p;
+    Ext cam, imu;
+    XR_HIP(hipEventRecord(c->ev0, c->stream));
+    rc = stage_problem(c, P, d, p, cam, imu);
+    if (rc) return rc;
+    const double sx = P->sqrt_inv_cov[0], sy = P->sqrt_inv_cov[1];
+    hipStream_t s = c->stream;
+    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);
+    launch_linearize(c, d, p, cam, imu, sx, sy);
+    rc = launch_solve(c, d, p);
+    if (rc) return rc;
+    int mode = 1;
+    const size_t try_lds = sizeof(double) * std::max(d.np, 1);
+    for (int guard = 0; guard < 4 * (P->max_iterations + 8); ++guard) {
+        hipLaunchKernelGGL(kb_try, dim3(1), dim3(512), try_lds, s, d, p, cam, imu, sx, sy, mode);
+        XR_HIP(hipGetLastError());
+        XR_HIP(hipMemcpyAsync(c->h_ctl, p.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, s));
+        XR_HIP(hipStreamSynchronize(s));
+        const int st = c->h_ctl->status;
+        if (st == ST_DONE) break;
+        if (st == ST_ACCEPTED) {
+            launch_linearize(c, d, p, cam, imu, sx, sy);
+            rc = launch_solve(c, d, p);
+            if (rc) return rc;
+            mode = 1;
+        } else if (st == ST_RESOLVE || st == ST_RESOLVE_INNER) {
+            rc = launch_solve(c, d, p);
+            if (rc) return rc;
+            mode = (st == ST_RESOLVE) ? 2 : 3;
+        } else {
+            return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: unexpected device status");
+        }
+    }
+    // read back the optimised states (in place, like the reference)
+    XR_HIP(hipMemcpyAsync(c->h_out, p.state, sizeof(double) * 16 * d.F, hipMemcpyDeviceToHost, s));
+    if (d.L) XR_HIP(hipMemcpyAsync(c->h_out + 16 * d.F, p.depth, sizeof(double) * d.L, hipMemcpyDeviceToHost, s));
+    XR_HIP(hipEventRecord(c->ev1, s));
+    XR_HIP(hipStreamSynchronize(s));
+    std::memcpy(P->frame_state, c->h_out, sizeof(double) * 16 * d.F);
+    if (d.L) std::memcpy(P->inv_depth, c->h_out + 16 * d.F, sizeof(double) * d.L);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    const BaCtl &ctl = *c->h_ctl;
+    sm.iterations = ctl.iteration;
+    sm.successful_steps = ctl.successful_steps;
+    sm.termination = ctl.termination;
+    sm.usable = ctl.termination != XRHIP_BA_FAILURE;
+    sm.initial_cost = ctl.initial_cost;
+    sm.final_cost = ctl.x_cost;
+    sm.ms_solve = ms;
+    if (summary) *summary = sm;
+    c->dims = d;
+    c->ptrs = p;
+    c->have_lin = true;
+    return XRHIP_OK;
+}
+
+/* parity/testing aid: linearise the problem at its current states (no solve) and return the unreduced
+ * normal equations in "frame-major" layout: H [15F x 15F], g [15F], hll [L], gl [L], W [L x 6F] (row l =
+ * cross terms of landmark l with the pose dofs of every frame), cost.  Constant blocks have zero rows. */
+int xrhip_ba_debug_linearize(xrhip_ba *c, const xrhip_ba_problem *P, double *H, double *g, double *hll, double *gl,
+                             double *W, double *cost) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_debug_linearize: null context");
+    int rc = validate(P);
+    if (rc) return rc;
+    BaDims d;
+    BaPtrs p;
+    Ext cam, imu;
+    rc = stage_problem(c, P, d, p, cam, imu);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);
+    launch_linearize(c, d, p, cam, imu, P->sqrt_inv_cov[0], P->sqrt_inv_cov[1]);
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipMemcpyAsync(c->h_ctl, p.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, s));
+    if (H) XR_HIP(hipMemcpyAsync(H, p.Hpp, sizeof(double) * (size_t)d.n * d.n, hipMemcpyDeviceToHost, s));
+    if (g) XR_HIP(hipMemcpyAsync(g, p.gp, sizeof(double) * d.n, hipMemcpyDeviceToHost, s));
+    if (hll && d.L) XR_HIP(hipMemcpyAsync(hll, p.hll, sizeof(double) * d.L, hipMemcpyDeviceToHost, s));
+    if (gl && d.L) XR_HIP(hipMemcpyAsync(gl, p.gl, sizeof(double) * d.L, hipMemcpyDeviceToHost, s));
+    std::vector<double> wt;
+    if (W && d.L) {
+        wt.resize((size_t)d.Lp * d.PF);
+        XR_HIP(hipMemcpyAsync(wt.data(), p.Wt, sizeof(double) * wt.size(), hipMemcpyDeviceToHost, s));
+    }
+    XR_HIP(hipStreamSynchronize(s));
+    if (W && d.L)
+        for (int l = 0; l < d.L; ++l)
+            for (int a = 0; a < 6 * d.F; ++a) W[(size_t)l * 6 * d.F + a] = wt[(size_t)l * d.PF + a];
+    if (cost) *cost = c->h_ctl->x_cost;
+    return XRHIP_OK;
+}
+
+/* parity/testing aid: T = W^T diag(w) W through the MFMA kernel for arbitrary inputs.
+ * W: [L][P] row-major, w: [L]; out: [P][P].  P is padded to 16 and L to 16 internally. */
+int xrhip_ba_debug_schur(xrhip_ba *c, const double *W, const double *w, int L, int P, double *out) {
+    if (!c || !W || !w || !out || L <= 0 || P <= 0) return xr_fail(XRHIP_EINVAL, "xrhip_ba_debug_schur: bad arguments");
+    BaDims d;
+    std::memset(&d, 0, sizeof(d));
+    BaPtrs p;
+    std::memset(&p, 0, sizeof(p));
+    d.PF = round_up(P, 16);
+    d.L = L;
+    d.Lp = std::max(16, round_up(L, 16));
+    std::vector<double> wt((size_t)d.Lp * d.PF, 0.0), om(d.Lp, 0.0);
+    for (int l = 0; l < L; ++l) {
+        om[l] = w[l];
+        for (int a = 0; a < P; ++a) wt[(size_t)l * d.PF + a] = W[(size_t)l * P + a];
+    }
+    double *dW = nullptr, *dw = nullptr, *dT = nullptr;
+    XR_HIP(hipMalloc(&dW, sizeof(double) * wt.size()));
+    XR_HIP(hipMalloc(&dw, sizeof(double) * om.size()));
+    XR_HIP(hipMalloc(&dT, sizeof(double) * (size_t)d.PF * d.PF));
+    XR_HIP(hipMemcpy(dW, wt.data(), sizeof(double) * wt.size(), hipMemcpyHostToDevice));
+    XR_HIP(hipMemcpy(dw, om.data(), sizeof(double) * om.size(), hipMemcpyHostToDevice));
+    p.Wt = dW;
+    p.omega = dw;
+    p.T = dT;
+    const int tiles = d.PF / 16;
+    hipLaunchKernelGGL(kb_schur_mfma, dim3(tiles * tiles), dim3(256), 0, c->stream, d, p);
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipStreamSynchronize(c->stream));
+    std::vector<double> T((size_t)d.PF * d.PF);
+    XR_HIP(hipMemcpy(T.data(), dT, sizeof(double) * T.size(), hipMemcpyDeviceToHost));
+    for (int a = 0; a < P; ++a)
+        for (int b = 0; b < P; ++b) out[(size_t)a * P + b] = T[(size_t)a * d.PF + b];
+    hipFree(dW);
+    hipFree(dw);
+    hipFree(dT);
+    return XRHIP_OK;
+}
+
+}   // extern "C"

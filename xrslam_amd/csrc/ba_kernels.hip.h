@@ -1,0 +1,972 @@
+// ba_kernels.hip.h -- gfx950 kernels of the sliding-window visual-inertial bundle adjustment.
+//
+// Replaces what the reference delegates to Ceres 1.14 behind xrslam::Solver::solve()
+// (/root/reference/xrslam/src/xrslam/estimation/solver.cpp:176-190): residual/Jacobian
+// evaluation of the factor set, CauchyLoss correction, Jacobi scaling, Schur elimination of
+// the inverse-depth blocks, the reduced-system Cholesky and the traditional dogleg loop.
+//
+// Data flow per linearisation (all f64, everything stays in HBM/L2 between kernels):
+//   kb_lin_obs / kb_lin_rot / kb_lin_imu / kb_lin_prior   per-factor residuals + Jacobians
+//   kb_landmark     per-landmark (one wavefront each): H_ll, g_l and the dense cross-term row W_l
+//   kb_assemble     deterministic gather of all factor blocks into the (15F)^2 frame Hessian
+//   kb_prepare      Jacobi scales, dogleg diagonal, landmark Schur weights
+//   kb_schur_mfma   T = W^T diag(omega) W on the f64 matrix cores (v_mfma_f64_16x16x4_f64)
+//   kb_solve        reduced system, LDS-resident packed Cholesky, Gauss-Newton + Cauchy data
+//   kb_try          trust-region trials (dogleg point, candidate cost, accept/reject) on-device
+// Summation orders are fixed (no floating-point atomics), so results are run-to-run identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ba_math.hip.h"
+
+namespace xrhip {
+
+constexpr int OREC = 28;   // per-observation record: Jt(12) Jr(12) jl(2) r(2), robustified
+constexpr int RREC = 8;    // per-rotation-factor record: Jq(6) r(2)
+
+struct BaCtl {   // device-resident solver state (one per context)
+    double radius, mu;
+    double x_cost, cand_cost, minimum_cost;
+    double x_norm, gmax, alpha, step_norm;
+    double model_cost_change, initial_cost;
+    int iteration, successful_steps, invalid_steps;
+    int reuse;          // DoglegStrategy::reuse_
+    int status;         // ST_* below
+    int termination;    // XRHIP_BA_*
+    int linear_ok;      // result of the last kb_solve
+    int first;          // first linearisation of this solve (Jacobi scales are frozen afterwards)
+    int max_iterations;
+    int pad;
+};
+enum { ST_RUNNING = 0, ST_ACCEPTED = 1, ST_RESOLVE = 2, ST_DONE = 3, ST_RESOLVE_INNER = 102 };
+
+struct BaDims {
+    int F, n, PF;       // frames, 15F, pose dims padded to 16
+    int L, Lp;          // landmarks, padded to 16
+    int M, MR, NI;      // reprojection / rotation / imu factors
+    int NP, np;         // prior frames, 15*NP
+    int NV;             // n + L
+};
+
+struct BaPtrs {
+    // problem
+    double *state, *cand;            // [F][16]
+    const uint8_t *fix;              // [F]
+    double *depth, *depth_cand;      // [L]
+    const uint8_t *lact;             // [L] landmark is a free parameter
+    const int *obs_tgt, *obs_ref, *obs_lm;
+    const double *obs_zt, *obs_zr;
+    const int *rot_tgt, *rot_ref;
+    const double *rot_zt, *rot_zr;
+    const int *imu_i, *imu_j;
+    const double *imu_data;
+    double *bias_ref;                // [NI][6]
+    const int *prior_frames;
+    const double *pS, *pinfo, *plin;
+    double *pLam;                    // S^T S
+    // index structures (built on the host)
+    const int *lm_start, *lm_obs;    // CSR landmark -> observations
+    const int *pair_start, *pair_items;   // CSR (row frame, col frame) -> (obs << 1 | role)
+    const int *rotf_start, *rotf_items;   // CSR frame -> rotation factors
+    const int *imuf;                 // [F][2]: imu factor with j == f, imu factor with i == f (or -1)
+    const int *priorf;               // [F]: index in prior_frames or -1
+    // linearisation products
+    double *orec, *ocost;            // [M][28], [M]
+    double *rrec, *rcost;
+    double *imu_r, *imu_Ji, *imu_Jj, *imu_cost;   // [NI][15], [NI][225] x2, [NI]
+    double *pr, *pt, *pJq, *pcost;   // prior residual [np], S^T r [np], Jr^-1 [NP][9], cost [1]
+    double *Hpp, *gp;                // [n][n], [n]   unscaled frame Hessian / gradient
+    double *hll, *gl, *Wt;           // [L], [L], [Lp][PF]
+    double *sp, *sl, *omega;         // Jacobi scales [n], [L]; Schur weights [L]
+    double *T;                       // [PF][PF]
+    double *Sred;                    // [n][n] scratch (global fallback of the Cholesky)
+    double *diagD, *grad, *gn, *gs, *step, *delta;   // [NV] each
+    double *partial;                 // cost partial sums
+    BaCtl *ctl;
+};
+
+XD bool pose_free(uint8_t fix) { return !(fix & 1); }
+XD bool motion_free(uint8_t fix) { return !(fix & 2); }
+XD bool dof_active(const uint8_t *fix, int a) {   // a in [0, 15F)
+    const int f = a / 15, k = a - 15 * f;
+    return k < 6 ? pose_free(fix[f]) : motion_free(fix[f]);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// deterministic block-wide sum (fixed tree); scratch must hold blockDim.x/64 doubles
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double s = 0;
+    for (int i = 0; i < nw; ++i) s += scratch[i];
+    __syncthreads();
+    return s;
+}
+
+// --------------------------------------------------------------- reprojection factors
+// One thread per observation.  use_cand selects the candidate state (cost only).
+__device__ __forceinline__ double obs_eval(const BaDims &d, const BaPtrs &p, int o, const double *state,
+                                           const double *depth, const Ext &cam, double sx, double sy, bool want_j,
+                                           double *rec) {
+    const int ft = p.obs_tgt[o], fr = p.obs_ref[o], l = p.obs_lm[o];
+    const bool at = pose_free(p.fix[ft]), ar = pose_free(p.fix[fr]), al = p.lact[l] != 0;
+    if (!at && !ar && !al) {   // constant residual block: removed by Ceres' preprocessor
+        if (want_j)
+            for (int i = 0; i < OREC; ++i) rec[i] = 0.0;
+        return 0.0;
+    }
+    const FState st = load_state(state + 16 * ft), sr = load_state(state + 16 * fr);
+    const V3 zt = v3(p.obs_zt[3 * o], p.obs_zt[3 * o + 1], p.obs_zt[3 * o + 2]);
+    const V3 zr = v3(p.obs_zr[3 * o], p.obs_zr[3 * o + 1], p.obs_zr[3 * o + 2]);
+    double r[2], Jt[12], Jr[12], Jl[2];
+    eval_reprojection(st, sr, depth[l], zt, zr, cam, sx, sy, r, want_j, Jt, Jr, Jl);
+    const double s = r[0] * r[0] + r[1] * r[1];
+    if (want_j) {
+        // CauchyLoss(1): rho' = 1/(1+s), rho'' < 0  =>  residual and Jacobian scaled by sqrt(rho')
+        const double sc = sqrt(fmax(2.2250738585072014e-308, 1.0 / (1.0 + s)));
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            rec[i] = at ? Jt[i] * sc : 0.0;
+            rec[12 + i] = ar ? Jr[i] * sc : 0.0;
+        }
+        rec[24] = al ? Jl[0] * sc : 0.0;
+        rec[25] = al ? Jl[1] * sc : 0.0;
+        rec[26] = r[0] * sc;
+        rec[27] = r[1] * sc;
+    }
+    return 0.5 * log(1.0 + s);
+}
+
+__global__ __launch_bounds__(256) void kb_lin_obs(BaDims d, BaPtrs p, Ext cam, double sx, double sy) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= d.M) return;
+    double rec[OREC];
+    p.ocost[o] = obs_eval(d, p, o, p.state, p.depth, cam, sx, sy, true, rec);
+#pragma unroll
+    for (int i = 0; i < OREC; ++i) p.orec[(size_t)o * OREC + i] = rec[i];
+}
+
+__device__ __forceinline__ double rot_eval(const BaDims &d, const BaPtrs &p, int o, const double *state,
+                                           const Ext &cam, double sx, double sy, bool want_j, double *rec) {
+    const int ft = p.rot_tgt[o], fr = p.rot_ref[o];
+    if (!pose_free(p.fix[ft])) {
+        if (want_j)
+            for (int i = 0; i < RREC; ++i) rec[i] = 0.0;
+        return 0.0;
+    }
+    const FState st = load_state(state + 16 * ft), sr = load_state(state + 16 * fr);
+    double r[2], Jq[6];
+    eval_rotation(st, sr, v3(p.rot_zt[3 * o], p.rot_zt[3 * o + 1], p.rot_zt[3 * o + 2]),
+                  v3(p.rot_zr[3 * o], p.rot_zr[3 * o + 1], p.rot_zr[3 * o + 2]), cam, sx, sy, r, want_j, Jq);
+    const double s = r[0] * r[0] + r[1] * r[1];
+    if (want_j) {
+        const double sc = sqrt(fmax(2.2250738585072014e-308, 1.0 / (1.0 + s)));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rec[i] = Jq[i] * sc;
+        rec[6] = r[0] * sc;
+        rec[7] = r[1] * sc;
+    }
+    return 0.5 * log(1.0 + s);
+}
+
+__global__ __launch_bounds__(256) void kb_lin_rot(BaDims d, BaPtrs p, Ext cam, double sx, double sy) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= d.MR) return;
+    double rec[RREC];
+    p.rcost[o] = rot_eval(d, p, o, p.state, cam, sx, sy, true, rec);
+#pragma unroll
+    for (int i = 0; i < RREC; ++i) p.rrec[(size_t)o * RREC + i] = rec[i];
+}
+
+// --------------------------------------------------------------------- IMU factors
+// whitened residual only (15 values via out) -- used for costs; one thread does everything
+__device__ __forceinline__ double imu_cost_eval(const BaPtrs &p, int k, const double *state, const Ext &imu) {
+    const int fi = p.imu_i[k], fj = p.imu_j[k];
+    if (p.fix[fi] == 3 && p.fix[fj] == 3) return 0.0;
+    const double *data = p.imu_data + (size_t)k * XRHIP_IMU_DIM;
+    const ImuRec pre = load_imu(data);
+    double raw[15];
+    imu_raw_residual(load_state(state + 16 * fi), load_state(state + 16 * fj), pre,
+                     v3(p.bias_ref[6 * k], p.bias_ref[6 * k + 1], p.bias_ref[6 * k + 2]),
+                     v3(p.bias_ref[6 * k + 3], p.bias_ref[6 * k + 4], p.bias_ref[6 * k + 5]), imu, raw);
+    const double *S = data + 56;
+    double c = 0;
+    for (int i = 0; i < 15; ++i) {
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < 15; ++j) s += S[15 * i + j] * raw[j];
+        c += s * s;
+    }
+    return 0.5 * c;
+}
+
+// One 64-lane workgroup per IMU factor: lane 0 evaluates the (serial) SO(3) algebra into LDS, then all
+// lanes apply the 15x15 whitening to the residual and both Jacobians.
+__global__ __launch_bounds__(64) void kb_lin_imu(BaDims d, BaPtrs p, Ext imu) {
+    __shared__ double raw[15], Ji[225], Jj[225];
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const int fi = p.imu_i[k], fj = p.imu_j[k];
+    const double *data = p.imu_data + (size_t)k * XRHIP_IMU_DIM;
+    const bool active = !(p.fix[fi] == 3 && p.fix[fj] == 3);
+    for (int i = lane; i < 225; i += 64) {
+        Ji[i] = 0.0;
+        Jj[i] = 0.0;
+    }
+    __syncthreads();
+    if (lane == 0 && active) {
+        const FState si = load_state(p.state + 16 * fi), sj = load_state(p.state + 16 * fj);
+        const ImuRec pre = load_imu(data);
+        const V3 bg0 = v3(p.bias_ref[6 * k], p.bias_ref[6 * k + 1], p.bias_ref[6 * k + 2]);
+        const V3 ba0 = v3(p.bias_ref[6 * k + 3], p.bias_ref[6 * k + 4], p.bias_ref[6 * k + 5]);
+        double r15[15];
+        imu_raw_residual(si, sj, pre, bg0, ba0, imu, r15);
+        for (int i = 0; i < 15; ++i) raw[i] = r15[i];
+        imu_raw_jacobians(si, sj, pre, bg0, ba0, imu, v3(r15[0], r15[1], r15[2]), Ji, Jj);
+    }
+    __syncthreads();
+    const double *S = data + 56;
+    double cost = 0.0;
+    if (lane < 15) {
+        double s = 0;
+        if (active)
+            for (int j = 0; j < 15; ++j) s += S[15 * lane + j] * raw[j];
+        p.imu_r[15 * k + lane] = s;
+        cost = 0.5 * s * s;
+    }
+    cost = wave_sum(cost);
+    if (lane == 0) p.imu_cost[k] = cost;
+    for (int e = lane; e < 225; e += 64) {
+        const int i = e / 15, c = e - 15 * i;
+        double a = 0, b = 0;
+        if (active) {
+            for (int j = 0; j < 15; ++j) {
+                a += S[15 * i + j] * Ji[15 * j + c];
+                b += S[15 * i + j] * Jj[15 * j + c];
+            }
+            // constant blocks contribute no columns
+            if (!(c < 6 ? pose_free(p.fix[fi]) : motion_free(p.fix[fi]))) a = 0.0;
+            if (!(c < 6 ? pose_free(p.fix[fj]) : motion_free(p.fix[fj]))) b = 0.0;
+        }
+        p.imu_Ji[(size_t)225 * k + e] = a;
+        p.imu_Jj[(size_t)225 * k + e] = b;
+    }
+}
+
+// ------------------------------------------------------------------------ prior
+// delta and Jr^-1 of prior frame i at `state`
+__device__ __forceinline__ void prior_delta(const BaPtrs &p, int i, const double *state, double *delta15, M3 *Jq) {
+    const FState s = load_state(state + 16 * p.prior_frames[i]);
+    const FState l = load_state(p.plin + 16 * i);
+    const V3 rq = logmap(q_mul(q_conj(l.q), s.q));
+    delta15[0] = rq.x; delta15[1] = rq.y; delta15[2] = rq.z;
+    delta15[3] = s.p.x - l.p.x; delta15[4] = s.p.y - l.p.y; delta15[5] = s.p.z - l.p.z;
+    delta15[6] = s.v.x - l.v.x; delta15[7] = s.v.y - l.v.y; delta15[8] = s.v.z - l.v.z;
+    delta15[9] = s.bg.x - l.bg.x; delta15[10] = s.bg.y - l.bg.y; delta15[11] = s.bg.z - l.bg.z;
+    delta15[12] = s.ba.x - l.ba.x; delta15[13] = s.ba.y - l.ba.y; delta15[14] = s.ba.z - l.ba.z;
+    if (Jq) *Jq = inverse3(right_jacobian(rq));
+}
+
+// prior cost at `state`: 0.5 |S delta + infovec|^2 ; block-wide (any block size), delta staged in `sh` (np doubles)
+__device__ __forceinline__ double prior_cost_block(const BaDims &d, const BaPtrs &p, const double *state, double *sh,
+                                                   double *scratch, double *r_out) {
+    for (int i = threadIdx.x; i < d.NP; i += blockDim.x) {
+        double dl[15];
+        prior_delta(p, i, state, dl, nullptr);
+        for (int k = 0; k < 15; ++k) sh[15 * i + k] = dl[k];
+    }
+    __syncthreads();
+    double c = 0;
+    for (int i = threadIdx.x; i < d.np; i += blockDim.x) {
+        double s = p.pinfo[i];
+        const double *row = p.pS + (size_t)i * d.np;
+        for (int j = 0; j < d.np; ++j) s += row[j] * sh[j];
+        if (r_out) r_out[i] = s;
+        c += s * s;
+    }
+    return 0.5 * block_sum(c, scratch);
+}
+
+__global__ __launch_bounds__(256) void kb_lin_prior(BaDims d, BaPtrs p) {
+    extern __shared__ double sh[];   // np doubles
+    __shared__ double scratch[8];
+    if (d.NP == 0) {
+        if (threadIdx.x == 0) p.pcost[0] = 0.0;
+        return;
+    }
+    for (int i = threadIdx.x; i < d.NP; i += blockDim.x) {
+        double dl[15];
+        M3 Jq;
+        prior_delta(p, i, p.state, dl, &Jq);
+        for (int k = 0; k < 15; ++k) sh[15 * i + k] = dl[k];
+        for (int k = 0; k < 9; ++k) p.pJq[9 * i + k] = Jq.m[k];
+    }
+    __syncthreads();
+    double c = 0;
+    for (int i = threadIdx.x; i < d.np; i += blockDim.x) {
+        double s = p.pinfo[i];
+        const double *row = p.pS + (size_t)i * d.np;
+        for (int j = 0; j < d.np; ++j) s += row[j] * sh[j];
+        p.pr[i] = s;
+        c += s * s;
+    }
+    c = block_sum(c, scratch);
+    if (threadIdx.x == 0) p.pcost[0] = 0.5 * c;
+    __syncthreads();
+    // t = S^T r
+    for (int j = threadIdx.x; j < d.np; j += blockDim.x) {
+        double s = 0;
+        for (int i = 0; i < d.np; ++i) s += p.pS[(size_t)i * d.np + j] * p.pr[i];
+        p.pt[j] = s;
+    }
+}
+
+// Lam = S^T S (once per prior upload)
+__global__ __launch_bounds__(256) void kb_prior_lambda(int np, const double *__restrict__ S, double *__restrict__ Lam) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= np * np) return;
+    const int a = e / np, b = e - a * np;
+    double s = 0;
+    for (int i = 0; i < np; ++i) s += S[(size_t)i * np + a] * S[(size_t)i * np + b];
+    Lam[e] = s;
+}
+
+// -------------------------------------------------------------------- landmarks
+// One wavefront per landmark: H_ll, g_l and the cross-term row W_l (6 values per observing frame),
+// written as a dense row of Wt [Lp][PF] (zero elsewhere) so the Schur product is a plain MFMA SYRK.
+__global__ __launch_bounds__(64) void kb_landmark(BaDims d, BaPtrs p) {
+    const int l = blockIdx.x, lane = threadIdx.x;
+    double *row = p.Wt + (size_t)l * d.PF;
+    for (int c = lane; c < d.PF; c += 64) row[c] = 0.0;
+    if (l >= d.L) return;
+    const int b = p.lm_start[l], e = p.lm_start[l + 1];
+    double hll = 0, gl = 0, wr[6] = {0, 0, 0, 0, 0, 0};
+    int ref = -1;
+    __syncthreads();
+    for (int it = b + lane; it < e + ((64 - (e - b) % 64) % 64); it += 64) {   // uniform trip count for the shuffles
+        const bool valid = it < e;
+        double wt[6] = {0, 0, 0, 0, 0, 0};
+        int ft = -1;
+        if (valid) {
+            const int o = p.lm_obs[it];
+            const double *rec = p.orec + (size_t)o * OREC;
+            const double j0 = rec[24], j1 = rec[25];
+            hll += j0 * j0 + j1 * j1;
+            gl += j0 * rec[26] + j1 * rec[27];
+            ft = p.obs_tgt[o];
+            ref = p.obs_ref[o];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                wt[a] = rec[a] * j0 + rec[6 + a] * j1;
+                wr[a] += rec[12 + a] * j0 + rec[18 + a] * j1;
+            }
+        }
+        // a frame observes a landmark at most once, so target rows never collide
+        if (valid && p.lact[l])
+#pragma unroll
+            for (int a = 0; a < 6; ++a) row[6 * ft + a] = wt[a];
+    }
+    hll = wave_sum(hll);
+    gl = wave_sum(gl);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) wr[a] = wave_sum(wr[a]);
+    int refm = ref;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) refm = max(refm, __shfl_xor(refm, off));
+    __syncthreads();
+    if (lane == 0) {
+        p.hll[l] = hll;
+        p.gl[l] = gl;
+        if (refm >= 0 && p.lact[l])
+#pragma unroll
+            for (int a = 0; a < 6; ++a) row[6 * refm + a] += wr[a];
+    }
+}
+
+// --------------------------------------------------------------------- assembly
+// One thread per element (a,b) of the frame Hessian Hpp (15F x 15F) and, for b == 0, of g.
+// Every contribution list is visited in a fixed order: reprojection pairs (CSR), rotation factors,
+// the two IMU factors adjacent to the frame, the prior.
+__global__ __launch_bounds__(256) void kb_assemble(BaDims d, BaPtrs p) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.n * d.n) return;
+    const int a = e / d.n, b = e - a * d.n;
+    const int fa = a / 15, ka = a - 15 * fa, fb = b / 15, kb = b - 15 * fb;
+    double h = 0.0, g = 0.0;
+    const bool want_g = (b == 0);
+    if (dof_active(p.fix, a) && (dof_active(p.fix, b) || want_g)) {
+        const bool bact = dof_active(p.fix, b);
+        // reprojection blocks (pose dofs only)
+        if (ka < 6) {
+            if (kb < 6 && bact) {
+                const int s = p.pair_start[fa * d.F + fb], t = p.pair_start[fa * d.F + fb + 1];
+                for (int it = s; it < t; ++it) {
+                    const int code = p.pair_items[it];
+                    const double *rec = p.orec + (size_t)(code >> 1) * OREC;
+                    const int ra = (code & 1) ? 12 : 0;                       // role of the row frame
+                    const int rb = (fa == fb) ? ra : ((code & 1) ? 0 : 12);   // column frame: same or the other role
+                    h += rec[ra + ka] * rec[rb + kb] + rec[ra + 6 + ka] * rec[rb + 6 + kb];
+                }
+            }
+            if (want_g) {
+                const int s = p.pair_start[fa * d.F + fa], t = p.pair_start[fa * d.F + fa + 1];
+                for (int it = s; it < t; ++it) {
+                    const int code = p.pair_items[it];
+                    const double *rec = p.orec + (size_t)(code >> 1) * OREC;
+                    const int ra = (code & 1) ? 12 : 0;
+                    g += rec[ra + ka] * rec[26] + rec[ra + 6 + ka] * rec[27];
+                }
+            }
+            if (ka < 3) {
+                const int s = p.rotf_start[fa], t = p.rotf_start[fa + 1];
+                for (int it = s; it < t; ++it) {
+                    const double *rec = p.rrec + (size_t)p.rotf_items[it] * RREC;
+                    if (fb == fa && kb < 3 && bact) h += rec[ka] * rec[kb] + rec[3 + ka] * rec[3 + kb];
+                    if (want_g) g += rec[ka] * rec[6] + rec[3 + ka] * rec[7];
+                }
+            }
+        }
+        // IMU factors: k0 has j == fa, k1 has i == fa
+        for (int side = 0; side < 2; ++side) {
+            const int k = p.imuf[2 * fa + side];
+            if (k < 0) continue;
+            const double *Ja = (side == 0 ? p.imu_Jj : p.imu_Ji) + (size_t)225 * k;
+            const int fi = p.imu_i[k], fj = p.imu_j[k];
+            if (want_g) {
+                const double *r = p.imu_r + 15 * k;
+                for (int i = 0; i < 15; ++i) g += Ja[15 * i + ka] * r[i];
+            }
+            if (bact && (fb == fi || fb == fj)) {
+                const double *Jb = (fb == fj ? p.imu_Jj : p.imu_Ji) + (size_t)225 * k;
+                for (int i = 0; i < 15; ++i) h += Ja[15 * i + ka] * Jb[15 * i + kb];
+            }
+        }
+        // prior: H = B^T Lam B, g = B^T S^T r with B = blockdiag(Jr^-1 on q rows)
+        const int pa = p.priorf[fa];
+        if (pa >= 0) {
+            if (want_g) {
+                if (ka < 3) {
+                    for (int k = 0; k < 3; ++k) g += p.pJq[9 * pa + 3 * k + ka] * p.pt[15 * pa + k];
+                } else {
+                    g += p.pt[15 * pa + ka];
+                }
+            }
+            const int pb = p.priorf[fb];
+            if (pb >= 0 && bact) {
+                double v = 0;
+                if (ka < 3 && kb < 3) {
+                    for (int k = 0; k < 3; ++k)
+                        for (int m = 0; m < 3; ++m)
+                            v += p.pJq[9 * pa + 3 * k + ka] * p.pLam[(size_t)(15 * pa + k) * d.np + 15 * pb + m] *
+                                 p.pJq[9 * pb + 3 * m + kb];
+                } else if (ka < 3) {
+                    for (int k = 0; k < 3; ++k) v += p.pJq[9 * pa + 3 * k + ka] * p.pLam[(size_t)(15 * pa + k) * d.np + 15 * pb + kb];
+                } else if (kb < 3) {
+                    for (int m = 0; m < 3; ++m) v += p.pLam[(size_t)(15 * pa + ka) * d.np + 15 * pb + m] * p.pJq[9 * pb + 3 * m + kb];
+                } else {
+                    v = p.pLam[(size_t)(15 * pa + ka) * d.np + 15 * pb + kb];
+                }
+                h += v;
+            }
+        }
+        if (!bact) h = 0.0;
+    }
+    p.Hpp[e] = h;
+    if (want_g) p.gp[a] = g;
+}
+
+// ------------------------------------------------------------------ preparation
+// Jacobi scales (first linearisation only), dogleg diagonal, scaled gradient, landmark Schur weights.
+__global__ __launch_bounds__(256) void kb_prepare(BaDims d, BaPtrs p) {
+    const BaCtl *c = p.ctl;
+    const double mu = c->mu;
+    for (int a = threadIdx.x; a < d.n; a += blockDim.x) {
+        const double h = p.Hpp[(size_t)a * d.n + a];
+        if (c->first) p.sp[a] = 1.0 / (1.0 + sqrt(h));
+        const double s = p.sp[a];
+        p.diagD[a] = sqrt(fmin(fmax(s * s * h, 1e-6), 1e32));
+        p.gs[a] = s * p.gp[a];
+    }
+    for (int l = threadIdx.x; l < d.L; l += blockDim.x) {
+        const double h = p.hll[l];
+        if (c->first) p.sl[l] = 1.0 / (1.0 + sqrt(h));
+        const double s = p.sl[l];
+        const double D = sqrt(fmin(fmax(s * s * h, 1e-6), 1e32));
+        p.diagD[d.n + l] = D;
+        p.gs[d.n + l] = p.lact[l] ? s * p.gl[l] : 0.0;
+        p.omega[l] = p.lact[l] ? 1.0 / (h + mu * D * D / (s * s)) : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------- MFMA Schur
+// T = W^T diag(omega) W, i.e. H_pl H_ll'^-1 H_lp of the reduced camera system, on the f64 matrix
+// cores.  One workgroup (4 wavefronts) per 16x16 output tile; the landmark (K) dimension is split
+// across the 4 wavefronts and combined in LDS in a fixed order.
+// v_mfma_f64_16x16x4_f64 operands: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15];
+// D: col = lane&15, row = (lane>>4) + 4*reg.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void kb_schur_mfma(BaDims d, BaPtrs p) {
+    __shared__ double red[4][256];
+    const int tiles = d.PF / 16;
+    const int ti = blockIdx.x / tiles, tj = blockIdx.x - ti * tiles;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kq = d.Lp / 4;   // landmarks per wavefront (multiple of 4)
+    const int k0 = wave * kq;
+    const int i = lane & 15, kk = lane >> 4;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k = k0; k < k0 + kq; k += 4) {
+        const int l = k + kk;
+        const double w = (l < d.L) ? p.omega[l] : 0.0;
+        const double a = p.Wt[(size_t)l * d.PF + 16 * ti + i];
+        const double b = p.Wt[(size_t)l * d.PF + 16 * tj + i] * w;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(kk + 4 * r) * 16 + i] = acc[r];
+    __syncthreads();
+    const int e = threadIdx.x;   // 256 elements of the tile
+    const double s = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    const int row = e >> 4, col = e & 15;
+    p.T[(size_t)(16 * ti + row) * d.PF + 16 * tj + col] = s;
+}
+
+// -------------------------------------------------------------------- the solve
+// full quadratic form v^T Hs v over frames + landmarks (Hs = Jacobi-scaled Hessian); block-wide
+__device__ __forceinline__ double quad_form(const BaDims &d, const BaPtrs &p, const double *v, double *scratch) {
+    double acc = 0;
+    for (int a = threadIdx.x; a < d.n; a += blockDim.x) {
+        const double *row = p.Hpp + (size_t)a * d.n;
+        double s = 0;
+        for (int b = 0; b < d.n; ++b) s += row[b] * p.sp[b] * v[b];
+        acc += v[a] * p.sp[a] * s;
+    }
+    for (int l = threadIdx.x; l < d.L; l += blockDim.x) {
+        if (!p.lact[l]) continue;
+        const double *row = p.Wt + (size_t)l * d.PF;
+        const double vl = v[d.n + l] * p.sl[l];
+        double s = 0;
+        for (int f = 0; f < d.F; ++f)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s += row[6 * f + k] * p.sp[15 * f + k] * v[15 * f + k];
+        acc += 2.0 * vl * s + vl * vl * p.hll[l];
+    }
+    return block_sum(acc, scratch);
+}
+
+XD int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower triangle, j <= i
+
+// Reduced system + Cholesky + Gauss-Newton / Cauchy quantities.  One workgroup.
+// Dynamic LDS: packed lower triangle of the reduced matrix when it fits (use_lds), plus vectors.
+__global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds) {
+    extern __shared__ double lds[];
+    __shared__ double scratch[8];
+    __shared__ int fail;
+    BaCtl *c = p.ctl;
+    const int n = d.n, tid = threadIdx.x, nt = blockDim.x;
+    double *y = lds;              // [n] rhs / solution
+    double *A = lds + ((n + 1) & ~1);   // packed lower (LDS) ...
+    if (!use_lds) A = nullptr;
+    const double mu = c->mu;
+    if (tid == 0) fail = 0;
+    // ---- assemble  S = sp (Hpp - T) sp + mu D^2   (inactive dofs pinned), rhs = sp (gp - W^T (omega gl))
+    for (int e = tid; e < n * n; e += nt) {
+        const int a = e / n, b = e - a * n;
+        if (b > a) continue;
+        const bool act = dof_active(p.fix, a) && dof_active(p.fix, b);
+        double v = 0.0;
+        if (act) {
+            v = p.Hpp[e];
+            const int fa = a / 15, ka = a - 15 * fa, fb = b / 15, kb = b - 15 * fb;
+            if (ka < 6 && kb < 6) v -= p.T[(size_t)(6 * fa + ka) * d.PF + 6 * fb + kb];
+            v *= p.sp[a] * p.sp[b];
+            if (a == b) v += mu * p.diagD[a] * p.diagD[a];
+        } else if (a == b) {
+            v = 1.0;
+        }
+        if (use_lds) A[tri(a, b)] = v;
+        else p.Sred[(size_t)a * n + b] = v;
+    }
+    for (int a = tid; a < n; a += nt) {
+        double v = 0.0;
+        if (dof_active(p.fix, a)) {
+            v = p.gp[a];
+            const int fa = a / 15, ka = a - 15 * fa;
+            if (ka < 6) {
+                double s = 0;
+                for (int l = 0; l < d.L; ++l) s += p.Wt[(size_t)l * d.PF + 6 * fa + ka] * (p.omega[l] * p.gl[l]);
+                v -= s;
+            }
+            v *= p.sp[a];
+        }
+        y[a] = v;
+    }
+    __syncthreads();
+    // ---- Cholesky (left-looking, column by column)
+#define AE(i, j) (use_lds ? A[tri(i, j)] : p.Sred[(size_t)(i)*n + (j)])
+    for (int j = 0; j < n; ++j) {
+        for (int i = j + tid; i < n; i += nt) {
+            double s = AE(i, j);
+            for (int k = 0; k < j; ++k) s -= AE(i, k) * AE(j, k);
+            if (use_lds) A[tri(i, j)] = s;
+            else p.Sred[(size_t)i * n + j] = s;
+        }
+        __syncthreads();
+        const double djj = AE(j, j);
+        if (!(djj > 0.0) || !isfinite(djj)) {
+            if (tid == 0) fail = 1;
+        }
+        __syncthreads();
+        if (fail) break;
+        const double dj = sqrt(djj);
+        for (int i = j + tid; i < n; i += nt) {
+            const double v = (i == j) ? dj : AE(i, j) / dj;
+            if (use_lds) A[tri(i, j)] = v;
+            else p.Sred[(size_t)i * n + j] = v;
+        }
+        __syncthreads();
+    }
+    if (fail) {
+        if (tid == 0) c->linear_ok = 0;
+        return;
+    }
+    // ---- forward / backward substitution
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) y[j] = y[j] / AE(j, j);
+        __syncthreads();
+        const double yj = y[j];
+        for (int i = j + 1 + tid; i < n; i += nt) y[i] -= AE(i, j) * yj;
+        __syncthreads();
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        if (tid == 0) y[j] = y[j] / AE(j, j);
+        __syncthreads();
+        const double yj = y[j];
+        for (int i = tid; i < j; i += nt) y[i] -= AE(j, i) * yj;
+        __syncthreads();
+    }
+#undef AE
+    // ---- Gauss-Newton step (scaled space), landmark back-substitution, dogleg gradient
+    int bad = 0;
+    for (int a = tid; a < n; a += nt) {
+        const double D = p.diagD[a];
+        const double ya = dof_active(p.fix, a) ? y[a] : 0.0;
+        p.gn[a] = -D * ya;
+        p.grad[a] = dof_active(p.fix, a) ? p.gs[a] / D : 0.0;
+        if (!isfinite(ya)) bad = 1;
+    }
+    for (int l = tid; l < d.L; l += nt) {
+        double yl = 0.0;
+        const double D = p.diagD[n + l];
+        if (p.lact[l]) {
+            const double s = p.sl[l];
+            const double *row = p.Wt + (size_t)l * d.PF;
+            double w = 0;
+            for (int f = 0; f < d.F; ++f)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) w += row[6 * f + k] * p.sp[15 * f + k] * y[15 * f + k];
+            yl = (s * p.gl[l] - s * w) / (s * s * p.hll[l] + mu * D * D);
+            if (!isfinite(yl)) bad = 1;
+        }
+        p.gn[n + l] = -D * yl;
+        p.grad[n + l] = p.lact[l] ? p.gs[n + l] / D : 0.0;
+    }
+    if (bad) atomicExch(&fail, 1);
+    __syncthreads();
+    if (fail) {
+        if (tid == 0) c->linear_ok = 0;
+        return;
+    }
+    // ---- Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2 ; step buffer reused for sg = grad / D
+    double g2 = 0;
+    for (int a = tid; a < d.NV; a += nt) {
+        p.step[a] = p.grad[a] / p.diagD[a];
+        g2 += p.grad[a] * p.grad[a];
+    }
+    g2 = block_sum(g2, scratch);
+    __syncthreads();
+    const double jg2 = quad_form(d, p, p.step, scratch);
+    if (tid == 0) {
+        c->alpha = g2 / jg2;
+        c->linear_ok = 1;
+    }
+}
+
+// gradient_max_norm = |x - Plus(x, -g)|_inf in ambient coordinates (TrustRegionMinimizer::EvaluateGradientAndJacobian)
+__global__ __launch_bounds__(256) void kb_gradmax(BaDims d, BaPtrs p) {
+    __shared__ double red[256];
+    double m = 0;
+    for (int f = threadIdx.x; f < d.F; f += blockDim.x) {
+        double neg[15], out[16];
+        for (int k = 0; k < 15; ++k) neg[k] = -p.gp[15 * f + k];
+        const double *s = p.state + 16 * f;
+        state_plus(s, neg, pose_free(p.fix[f]), motion_free(p.fix[f]), out);
+        for (int k = 0; k < 16; ++k) m = fmax(m, fabs(s[k] - out[k]));
+    }
+    for (int l = threadIdx.x; l < d.L; l += blockDim.x)
+        if (p.lact[l]) m = fmax(m, fabs(p.gl[l]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.ctl->gmax = red[0];
+}
+
+// total cost at `state` (x) from the per-factor costs written by the linearisation kernels
+__global__ __launch_bounds__(256) void kb_sum_cost(BaDims d, BaPtrs p) {
+    __shared__ double scratch[8];
+    double c = 0;
+    for (int o = threadIdx.x; o < d.M; o += blockDim.x) c += p.ocost[o];
+    for (int o = threadIdx.x; o < d.MR; o += blockDim.x) c += p.rcost[o];
+    for (int k = threadIdx.x; k < d.NI; k += blockDim.x) c += p.imu_cost[k];
+    c = block_sum(c, scratch);
+    if (threadIdx.x == 0) {
+        c += p.pcost[0];
+        BaCtl *ctl = p.ctl;
+        ctl->x_cost = c;
+        if (ctl->first) {
+            ctl->initial_cost = c;
+            ctl->minimum_cost = c;
+        }
+    }
+}
+
+// ambient norm of the active parameter blocks of `state`/`depth`; block-wide
+__device__ __forceinline__ double ambient_norm2(const BaDims &d, const BaPtrs &p, const double *state,
+                                                const double *depth, double *scratch) {
+    double s = 0;
+    for (int f = threadIdx.x; f < d.F; f += blockDim.x) {
+        const double *x = state + 16 * f;
+        if (pose_free(p.fix[f]))
+            for (int k = 0; k < 7; ++k) s += x[k] * x[k];
+        if (motion_free(p.fix[f]))
+            for (int k = 7; k < 16; ++k) s += x[k] * x[k];
+    }
+    for (int l = threadIdx.x; l < d.L; l += blockDim.x)
+        if (p.lact[l]) s += depth[l] * depth[l];
+    return block_sum(s, scratch);
+}
+
+// ------------------------------------------------------------------- trial loop
+// TrustRegionMinimizer's per-iteration logic for as long as no new linearisation is needed:
+// dogleg point for the current radius, model cost change, candidate = Plus(x, delta), candidate
+// cost, tolerance checks, accept / reject / radius update.  One workgroup; exits with
+//   ST_ACCEPTED  a step was accepted -> host relinearises at the new x
+//   ST_RESOLVE   the step was invalid -> mu was increased, host re-solves the linear system
+//   ST_DONE      the minimiser terminated
+// `after_linearisation` = this launch directly follows a (re)linearisation or re-solve.
+__global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy,
+                                              int after_linearisation) {
+    extern __shared__ double sh[];   // np doubles for the prior delta
+    __shared__ double scratch[8];
+    __shared__ int s_status;
+    BaCtl *c = p.ctl;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    const double min_relative_decrease = 1e-3, min_radius = 1e-32, max_radius = 1e16;
+
+    // mode 1: directly after a (re)linearisation at a new x (initial point or accepted step)
+    // mode 2: after a re-solve caused by an invalid step (x unchanged)
+    // mode 3: inner retry of DoglegStrategy::ComputeGaussNewtonStep's mu loop (same iteration)
+    const int mode = after_linearisation;
+    if (mode == 1) {
+        // FinalizeIterationAndCheckIfMinimizerCanContinue of the iteration that produced this x:
+        // refresh the user state the IMU factors read their bias reference from (StateUpdatingCallback)
+        for (int k = tid; k < d.NI; k += nt) {
+            const double *s = p.state + 16 * p.imu_i[k];
+            for (int i = 0; i < 6; ++i) p.bias_ref[6 * k + i] = s[10 + i];
+        }
+        const double xn2 = ambient_norm2(d, p, p.state, p.depth, scratch);
+        if (tid == 0) {
+            c->x_norm = sqrt(xn2);
+            c->first = 0;
+        }
+        __syncthreads();
+    }
+    bool check_gradient = (mode == 1);   // the iteration that led here was successful
+    bool skip_finalize = (mode == 3);
+    while (true) {
+        // ---- finalize checks + start of the next iteration
+        if (tid == 0) {
+            int st = ST_RUNNING;
+            if (!skip_finalize) {
+                if (c->iteration >= c->max_iterations) {
+                    c->termination = XRHIP_BA_NO_CONVERGENCE;
+                    st = ST_DONE;
+                } else if (check_gradient && c->gmax <= gradient_tolerance) {
+                    c->termination = XRHIP_BA_CONVERGENCE;
+                    st = ST_DONE;
+                } else if (c->radius <= min_radius) {
+                    c->termination = XRHIP_BA_CONVERGENCE;
+                    st = ST_DONE;
+                }
+                if (st == ST_RUNNING) c->iteration += 1;
+            }
+            if (st == ST_RUNNING && !c->linear_ok) {
+                if (c->mu * 10.0 < 1.0) {
+                    c->mu *= 10.0;           // ComputeGaussNewtonStep: retry with a larger mu, same iteration
+                    st = ST_RESOLVE_INNER;
+                } else {
+                    c->invalid_steps += 1;   // LINEAR_SOLVER_FAILURE -> invalid step
+                    if (c->invalid_steps >= 5) {
+                        c->termination = XRHIP_BA_FAILURE;
+                        st = ST_DONE;
+                    } else {
+                        c->mu *= 10.0;
+                        c->reuse = 0;
+                        st = ST_RESOLVE;
+                    }
+                }
+            }
+            s_status = st;
+        }
+        skip_finalize = false;
+        check_gradient = false;
+        __syncthreads();
+        if (s_status != ST_RUNNING) break;
+        // ---- traditional dogleg for the current radius
+        double g2 = 0, n2 = 0, gd = 0;
+        for (int a = tid; a < d.NV; a += nt) {
+            g2 += p.grad[a] * p.grad[a];
+            n2 += p.gn[a] * p.gn[a];
+            gd += p.grad[a] * p.gn[a];
+        }
+        g2 = block_sum(g2, scratch);
+        n2 = block_sum(n2, scratch);
+        gd = block_sum(gd, scratch);
+        const double gnorm = sqrt(g2), gn_norm = sqrt(n2), radius = c->radius, alpha = c->alpha;
+        double ca = 0, cb = 0, step_norm = 0;   // step(scaled by D) = ca * grad + cb * gn
+        if (gn_norm <= radius) {
+            cb = 1.0;
+            step_norm = gn_norm;
+        } else if (gnorm * alpha >= radius) {
+            ca = -(radius / gnorm);
+            step_norm = radius;
+        } else {
+            const double b_dot_a = -alpha * gd;
+            const double a_sq = pow(alpha * gnorm, 2.0);
+            const double bma_sq = a_sq - 2 * b_dot_a + pow(gn_norm, 2);
+            const double cc = b_dot_a - a_sq;
+            const double dd = sqrt(cc * cc + bma_sq * (pow(radius, 2.0) - a_sq));
+            const double beta = (cc <= 0) ? (dd - cc) / bma_sq : (radius * radius - a_sq) / (dd + cc);
+            ca = -alpha * (1.0 - beta);
+            cb = beta;
+            step_norm = -1.0;
+        }
+        double sn2 = 0, sg = 0;
+        for (int a = tid; a < d.NV; a += nt) {
+            const double v = ca * p.grad[a] + cb * p.gn[a];
+            sn2 += v * v;
+            const double st = v / p.diagD[a];
+            p.step[a] = st;
+            sg += st * p.gs[a];
+            const double sc = a < d.n ? p.sp[a] : p.sl[a - d.n];
+            p.delta[a] = st * sc;
+        }
+        sn2 = block_sum(sn2, scratch);
+        sg = block_sum(sg, scratch);
+        if (step_norm < 0) step_norm = sqrt(sn2);
+        __syncthreads();
+        const double shs = quad_form(d, p, p.step, scratch);
+        const double model_cost_change = -sg - 0.5 * shs;
+        if (!(model_cost_change > 0.0)) {
+            if (tid == 0) {
+                c->invalid_steps += 1;
+                if (c->invalid_steps >= 5) {
+                    c->termination = XRHIP_BA_FAILURE;
+                    c->status = ST_DONE;
+                    s_status = ST_DONE;
+                } else {
+                    c->mu *= 10.0;   // StepIsInvalid
+                    c->reuse = 0;
+                    s_status = ST_RESOLVE;
+                }
+            }
+            __syncthreads();
+            break;
+        }
+        // ---- candidate point and its cost
+        for (int f = tid; f < d.F; f += nt)
+            state_plus(p.state + 16 * f, p.delta + 15 * f, pose_free(p.fix[f]), motion_free(p.fix[f]), p.cand + 16 * f);
+        for (int l = tid; l < d.L; l += nt) p.depth_cand[l] = p.depth[l] + (p.lact[l] ? p.delta[d.n + l] : 0.0);
+        __syncthreads();
+        double cost = 0;
+        for (int o = tid; o < d.M; o += nt) cost += obs_eval(d, p, o, p.cand, p.depth_cand, cam, sx, sy, false, nullptr);
+        for (int o = tid; o < d.MR; o += nt) cost += rot_eval(d, p, o, p.cand, cam, sx, sy, false, nullptr);
+        for (int k = tid; k < d.NI; k += nt) cost += imu_cost_eval(p, k, p.cand, imu);
+        cost = block_sum(cost, scratch);
+        if (d.NP > 0) cost += prior_cost_block(d, p, p.cand, sh, scratch, nullptr);
+        if (!isfinite(cost)) cost = 1.7976931348623157e308;
+        // ambient step norm |x - candidate|
+        double dn = 0;
+        for (int f = tid; f < d.F; f += nt) {
+            const double *a = p.state + 16 * f, *b = p.cand + 16 * f;
+            if (pose_free(p.fix[f]))
+                for (int k = 0; k < 7; ++k) dn += (a[k] - b[k]) * (a[k] - b[k]);
+            if (motion_free(p.fix[f]))
+                for (int k = 7; k < 16; ++k) dn += (a[k] - b[k]) * (a[k] - b[k]);
+        }
+        for (int l = tid; l < d.L; l += nt)
+            if (p.lact[l]) dn += (p.depth[l] - p.depth_cand[l]) * (p.depth[l] - p.depth_cand[l]);
+        dn = sqrt(block_sum(dn, scratch));
+        // ---- decisions (uniform across the workgroup)
+        const double x_cost = c->x_cost;
+        int st = ST_RUNNING;
+        bool accept = false;
+        double relative_decrease = 0;
+        if (dn <= parameter_tolerance * (c->x_norm + parameter_tolerance)) {
+            st = ST_DONE;
+        } else if (fabs(x_cost - cost) <= function_tolerance * x_cost) {
+            st = ST_DONE;
+        } else {
+            relative_decrease = (x_cost - cost) / model_cost_change;
+            accept = relative_decrease > min_relative_decrease;
+        }
+        __syncthreads();
+        if (st == ST_DONE) {
+            if (tid == 0) {
+                c->termination = XRHIP_BA_CONVERGENCE;
+                s_status = ST_DONE;
+            }
+            __syncthreads();
+            break;
+        }
+        if (accept) {
+            for (int e = tid; e < 16 * d.F; e += nt) p.state[e] = p.cand[e];
+            for (int l = tid; l < d.L; l += nt) p.depth[l] = p.depth_cand[l];
+            if (tid == 0) {
+                c->invalid_steps = 0;
+                c->successful_steps += 1;
+                if (relative_decrease < 0.25) c->radius *= 0.5;
+                if (relative_decrease > 0.75) c->radius = fmax(c->radius, 3.0 * step_norm);
+                c->radius = fmin(c->radius, max_radius);
+                c->mu = fmax(1e-8, 2.0 * c->mu / 10.0);
+                c->reuse = 0;
+                c->cand_cost = cost;
+                c->step_norm = step_norm;
+                s_status = ST_ACCEPTED;
+            }
+            __syncthreads();
+            break;
+        }
+        if (tid == 0) {
+            c->invalid_steps = 0;
+            c->radius *= 0.5;   // StepRejected
+            c->reuse = 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) c->status = s_status;
+}
+
+}   // namespace xrhip
