@@ -18,8 +18,10 @@ def L():
         lib.xrhip_ba_destroy.argtypes = [vp]
         lib.xrhip_ba_destroy.restype = None
         lib.xrhip_ba_solve.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary)]
-        lib.xrhip_ba_marginalize.argtypes = [vp, C.POINTER(abi.MargProblem), vp, vp, vp]
-        lib.xrhip_ba_preintegrate.argtypes = [vp, vp, C.c_int, C.c_double, vp, vp, vp, C.c_int, C.c_int, vp]
+        if hasattr(lib, "xrhip_ba_marginalize"):
+            lib.xrhip_ba_marginalize.argtypes = [vp, C.POINTER(abi.MargProblem), vp, vp, vp]
+        if hasattr(lib, "xrhip_ba_preintegrate"):
+            lib.xrhip_ba_preintegrate.argtypes = [vp, vp, C.c_int, C.c_double, vp, vp, vp, C.c_int, C.c_int, vp]
         lib.xrhip_ba_debug_linearize.argtypes = [vp, C.POINTER(abi.BaProblem), vp, vp, vp, vp, vp, vp]
         lib.xrhip_ba_debug_schur.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
         _L = lib
