@@ -222,6 +222,12 @@ int xrhip_ba_marginalize(xrhip_ba *ctx, const xrhip_marg_problem *problem, doubl
 int xrhip_ba_preintegrate(xrhip_ba *ctx, const double *samples, int n, double t_end, const double *bg,
                           const double *ba, const double *noise_cov36, int compute_jacobian,
                           int compute_covariance, double *out);
+/* batched form (one workgroup per IMU segment): job k integrates samples[sample_begin[k] .. +sample_count[k])
+ * up to t_end[k] at biases bg[3k..], ba[3k..]; out: [n_jobs][XRHIP_IMU_DIM]. */
+int xrhip_ba_preintegrate_batch(xrhip_ba *ctx, const double *samples, const int *sample_begin,
+                                const int *sample_count, const double *t_end, const double *bg, const double *ba,
+                                int n_jobs, const double *noise_cov36, int compute_jacobian, int compute_covariance,
+                                double *out);
 
 /* parity/testing aids (not part of the reference interface): the unreduced normal equations of one
  * linearisation, and the MFMA Schur product kernel on arbitrary inputs. */

@@ -173,3 +173,68 @@ def test_large_window_uses_global_cholesky_path(ctx, bo):
     """cfg-C sized window (15 KF): the reduced system exceeds the LDS budget -> global-memory Cholesky."""
     pd, _ = bs.make_window(K=16, L=300, seed=11)
     _solve_both(ctx, bo, pd, "k16")
+
+
+def _marg_problem(pd, victim=0):
+    seen = set(pd.obs_lm[(pd.obs_ref == victim) | (pd.obs_tgt == victim)])
+    sel = np.array([l in seen for l in pd.obs_lm])
+    obs = dict(tgt=pd.obs_tgt[sel], ref=pd.obs_ref[sel], lm=pd.obs_lm[sel], z_tgt=pd.obs_z_tgt[sel],
+               z_ref=pd.obs_z_ref[sel])
+    ki = np.array([k for k in range(len(pd.imu_i)) if pd.imu_i[k] == victim or pd.imu_j[k] == victim], int)
+    imu = dict(i=pd.imu_i[ki], j=pd.imu_j[ki], data=pd.imu_data[ki])
+    prior = dict(frames=pd.prior_frames, sqrt_info=pd.prior_sqrt_info, infovec=pd.prior_infovec, lin=pd.prior_lin)
+    return abi.MargProblemData(pd.frame_state, victim, pd.cam_ext, pd.imu_ext, pd.sqrt_inv_cov, prior, imu,
+                               pd.inv_depth, obs)
+
+
+@pytest.mark.parametrize("K,Ln,seed", [(11, 150, 21), (6, 80, 22), (16, 300, 23)])
+def test_marginalization_parity(ctx, bo, K, Ln, seed):
+    """sqrt_info / infovec are only defined up to an orthogonal transform of the eigenbasis, so parity is
+    asserted on the invariants the solver consumes: Lambda = S^T S and eta = S^T infovec."""
+    pd, _ = bs.make_window(K=K, L=Ln, seed=seed)
+    pd.frame_state[1:, 4:7] += 1e-3
+    md = _marg_problem(pd, 0)
+    si_o, iv_o, lin_o = bo.marginalize(md)
+    si_h, iv_h, lin_h = ctx.marginalize(md)
+    Lo, Lh = si_o.T @ si_o, si_h.T @ si_h
+    eo, eh = si_o.T @ iv_o, si_h.T @ iv_h
+    ok = np.abs(Lh - Lo).max() <= 1e-8 * np.abs(Lo).max() and np.abs(eh - eo).max() <= 1e-7 * max(1.0, np.abs(eo).max())
+    if not ok:
+        _dump("marg_mismatch_%d" % seed, Lo=Lo, Lh=Lh, eo=eo, eh=eh)
+    assert np.abs(Lh - Lo).max() <= 1e-8 * np.abs(Lo).max()
+    assert np.abs(eh - eo).max() <= 1e-7 * max(1.0, np.abs(eo).max())
+    np.testing.assert_array_equal(lin_h, lin_o)
+    # second marginalisation on top of the first (prior with a dense sqrt_info), via a solve in between
+    prior = dict(frames=np.arange(K - 1), sqrt_info=si_h, infovec=iv_h, lin=lin_h)
+    keep = (pd.obs_tgt > 0) & (pd.obs_ref > 0)
+    obs = dict(tgt=pd.obs_tgt[keep] - 1, ref=pd.obs_ref[keep] - 1, lm=pd.obs_lm[keep], z_tgt=pd.obs_z_tgt[keep],
+               z_ref=pd.obs_z_ref[keep])
+    ki = pd.imu_i > 0
+    imu = dict(i=pd.imu_i[ki] - 1, j=pd.imu_j[ki] - 1, data=pd.imu_data[ki])
+    p2 = abi.BaProblemData(pd.frame_state[1:], pd.frame_fix[1:], pd.cam_ext, pd.imu_ext, pd.sqrt_inv_cov, pd.inv_depth,
+                           None, obs=obs, imu=imu, prior=prior)
+    _solve_both(ctx, bo, p2, "after_marg%d" % seed, rtol=1e-6)
+
+
+def test_preintegration_parity(ctx, bo):
+    pd, truth = bs.make_window(K=5, L=20, seed=31)
+    for k, smp in enumerate(truth["samples"]):
+        t_end = truth["times"][k + 1]
+        bg, ba = pd.frame_state[k, 10:13], pd.frame_state[k, 13:16]
+        for jac, cov in ((True, True), (False, False)):
+            o = bo.preintegrate(smp, t_end, bg, ba, bs.NOISE36, jac, cov)
+            h = ctx.preintegrate(smp, t_end, bg, ba, bs.NOISE36, jac, cov)
+            np.testing.assert_allclose(h[:11], o[:11], rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(h[11:56], o[11:56], rtol=1e-10, atol=1e-13)
+            if cov:
+                U_o, U_h = o[56:].reshape(15, 15), h[56:].reshape(15, 15)
+                assert np.abs(U_h - U_o).max() <= 1e-7 * np.abs(U_o).max()
+                assert np.abs(U_h.T @ U_h - U_o.T @ U_o).max() <= 1e-8 * np.abs(U_o.T @ U_o).max()
+    # a single sample and a long (subframe-compressed) segment
+    one = truth["samples"][0][:1]
+    np.testing.assert_allclose(ctx.preintegrate(one, one[0, 0] + 0.005, np.zeros(3), np.zeros(3), bs.NOISE36)[:56],
+                               bo.preintegrate(one, one[0, 0] + 0.005, np.zeros(3), np.zeros(3), bs.NOISE36)[:56],
+                               rtol=1e-10, atol=1e-14)
+    long = np.concatenate(truth["samples"][:3])
+    np.testing.assert_allclose(ctx.preintegrate(long, truth["times"][3], bg, ba, bs.NOISE36)[:56],
+                               bo.preintegrate(long, truth["times"][3], bg, ba, bs.NOISE36)[:56], rtol=1e-9, atol=1e-13)

@@ -5,6 +5,7 @@
 // linearisation or a re-solve of the linear system is needed.
 #include "../../include/xrslam_hip.h"
 #include "ba_kernels.hip.h"
+#include "marg_kernels.hip.h"
 #include "common.hip.h"
 
 #include <algorithm>
@@ -36,6 +37,10 @@ struct xrhip_ba {
     Arena in;         // inputs (uploaded every solve)
     char *work = nullptr;   // device-only workspace
     size_t work_cap = 0;
+    char *work2 = nullptr;  // marginalisation / pre-integration workspace
+    size_t work2_cap = 0;
+    char *h_stage = nullptr;   // pinned staging for work2 transfers
+    size_t h_stage_cap = 0;
     BaCtl *h_ctl = nullptr;   // pinned
     double *h_out = nullptr;  // pinned readback (states + depths)
     size_t h_out_cap = 0;
@@ -106,6 +111,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     d.NP = P->prior_n;
     d.np = 15 * d.NP;
     d.NV = d.n + d.L;
+    d.robust = 1;
     const int F = d.F, L = d.L, M = d.M, MR = d.MR, NI = d.NI, NP = d.NP, np = d.np, n = d.n;
 
     // ---- host-side index structures
@@ -358,6 +364,8 @@ void xrhip_ba_destroy(xrhip_ba *c) {
     hipFree(c->in.dev);
     hipHostFree(c->in.host);
     hipFree(c->work);
+    hipFree(c->work2);
+    hipHostFree(c->h_stage);
     hipHostFree(c->h_ctl);
     hipHostFree(c->h_out);
     hipEventDestroy(c->ev0);
@@ -518,6 +526,184 @@ int xrhip_ba_debug_schur(xrhip_ba *c, const double *W, const double *w, int L, i
     hipFree(dw);
     hipFree(dT);
     return XRHIP_OK;
+}
+
+}   // extern "C"
+
+static int ensure_work2(xrhip_ba *c, size_t dev_bytes, size_t host_bytes) {
+    if (dev_bytes > c->work2_cap) {
+        if (c->work2) hipFree(c->work2);
+        c->work2 = nullptr;
+        size_t cap = std::max(dev_bytes * 2, size_t(1) << 20);
+        XR_HIP(hipMalloc(&c->work2, cap));
+        c->work2_cap = cap;
+    }
+    if (host_bytes > c->h_stage_cap) {
+        if (c->h_stage) hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        size_t cap = std::max(host_bytes * 2, size_t(1) << 20);
+        XR_HIP(hipHostMalloc(&c->h_stage, cap, hipHostMallocDefault));
+        c->h_stage_cap = cap;
+    }
+    return XRHIP_OK;
+}
+
+extern "C" {
+
+int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_sqrt_info, double *out_infovec,
+                         double *out_lin) {
+    if (!c || !M || !out_sqrt_info || !out_infovec || !out_lin) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: null argument");
+    if (M->n_frames < 2 || M->victim < 0 || M->victim >= M->n_frames)
+        return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: bad frame count / victim");
+    // express the marginalisation's linearisation as a BA problem with every block free and no robust loss
+    const int K = M->n_frames;
+    std::vector<double> state(M->frame_state, M->frame_state + 16 * (size_t)K);
+    std::vector<uint8_t> fix(K, 0);
+    std::vector<double> depth(M->inv_depth, M->inv_depth + std::max(M->n_landmarks, 0));
+    std::vector<uint8_t> lfix(std::max(M->n_landmarks, 1), 0);
+    xrhip_ba_problem P;
+    std::memset(&P, 0, sizeof(P));
+    P.n_frames = K;
+    P.frame_state = state.data();
+    P.frame_fix = fix.data();
+    std::memcpy(P.cam_q_bc, M->cam_q_bc, sizeof(P.cam_q_bc));
+    std::memcpy(P.cam_p_bc, M->cam_p_bc, sizeof(P.cam_p_bc));
+    std::memcpy(P.imu_q_bi, M->imu_q_bi, sizeof(P.imu_q_bi));
+    std::memcpy(P.imu_p_bi, M->imu_p_bi, sizeof(P.imu_p_bi));
+    std::memcpy(P.sqrt_inv_cov, M->sqrt_inv_cov, sizeof(P.sqrt_inv_cov));
+    P.n_landmarks = M->n_landmarks;
+    P.inv_depth = depth.data();
+    P.landmark_fix = lfix.data();
+    P.n_obs = M->n_obs;
+    P.obs_tgt = M->obs_tgt;
+    P.obs_ref = M->obs_ref;
+    P.obs_lm = M->obs_lm;
+    P.obs_z_tgt = M->obs_z_tgt;
+    P.obs_z_ref = M->obs_z_ref;
+    P.n_imu = M->n_imu;
+    P.imu_i = M->imu_i;
+    P.imu_j = M->imu_j;
+    P.imu_data = M->imu_data;
+    P.prior_n = M->prior_n;
+    P.prior_frames = M->prior_frames;
+    P.prior_sqrt_info = M->prior_sqrt_info;
+    P.prior_infovec = M->prior_infovec;
+    P.prior_lin = M->prior_lin;
+    P.max_iterations = 0;
+    int rc = validate(&P);
+    if (rc) return rc;
+    BaDims d;
+    BaPtrs p;
+    Ext cam, imu;
+    rc = stage_problem(c, &P, d, p, cam, imu);
+    if (rc) return rc;
+    d.robust = 0;
+    const int N = d.n, R = N - 15;
+    const size_t D8 = sizeof(double);
+    size_t w = 0;
+    auto carve = [&](size_t bytes) {
+        size_t off = (w + 255) & ~size_t(255);
+        w = off + std::max(bytes, size_t(8));
+        return off;
+    };
+    const size_t o_Hm = carve(D8 * (size_t)N * N), o_bm = carve(D8 * N), o_T2 = carve(D8 * (size_t)R * 15);
+    const size_t o_A = carve(D8 * (size_t)R * R), o_bp = carve(D8 * R), o_B = carve(D8 * (size_t)R * R);
+    const size_t o_V = carve(D8 * (size_t)R * R), o_si = carve(D8 * (size_t)R * R), o_iv = carve(D8 * R);
+    const size_t o_st = carve(sizeof(int) * 4);
+    rc = ensure_work2(c, w + 256, D8 * ((size_t)R * R + R) + 64);
+    if (rc) return rc;
+    char *W2 = c->work2;
+    double *Hm = (double *)(W2 + o_Hm), *bm = (double *)(W2 + o_bm), *T2 = (double *)(W2 + o_T2);
+    double *A = (double *)(W2 + o_A), *bp = (double *)(W2 + o_bp), *B = (double *)(W2 + o_B), *V = (double *)(W2 + o_V);
+    double *dsi = (double *)(W2 + o_si), *div = (double *)(W2 + o_iv);
+    int *dst = (int *)(W2 + o_st);
+    hipStream_t s = c->stream;
+    XR_HIP(hipMemsetAsync(dst, 0, sizeof(int) * 4, s));
+    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);
+    launch_linearize(c, d, p, cam, imu, M->sqrt_inv_cov[0], M->sqrt_inv_cov[1]);
+    hipLaunchKernelGGL(km_omega, dim3((std::max(d.L, 1) + 255) / 256), dim3(256), 0, s, d, p);
+    const int tiles = d.PF / 16;
+    hipLaunchKernelGGL(kb_schur_mfma, dim3(tiles * tiles), dim3(256), 0, s, d, p);
+    hipLaunchKernelGGL(km_permute, dim3((N * N + 255) / 256), dim3(256), 0, s, d, p, M->victim, Hm, bm);
+    hipLaunchKernelGGL(km_victim, dim3(1), dim3(256), 0, s, N, Hm, T2, dst);
+    hipLaunchKernelGGL(km_complement, dim3((R * R + 255) / 256), dim3(256), 0, s, N, Hm, bm, T2, A, bp);
+    int G = 8;
+    while (G > 1 && ((R + 1) / 2) * G > 1024) G >>= 1;
+    if (((R + 1) / 2) * G > 1024) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: window too large for the Jacobi kernel");
+    hipLaunchKernelGGL(km_jacobi, dim3(1), dim3(1024), 0, s, R, G, A, B, V, 60, dst + 1);
+    hipLaunchKernelGGL(km_finish, dim3(R), dim3(64), 0, s, R, B, V, bp, dsi, div);
+    XR_HIP(hipGetLastError());
+    double *hs = (double *)c->h_stage;
+    XR_HIP(hipMemcpyAsync(hs, dsi, D8 * (size_t)R * R, hipMemcpyDeviceToHost, s));
+    XR_HIP(hipMemcpyAsync(hs + (size_t)R * R, div, D8 * R, hipMemcpyDeviceToHost, s));
+    int hst[4] = {0, 0, 0, 0};
+    XR_HIP(hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, s));
+    XR_HIP(hipStreamSynchronize(s));
+    if (hst[0]) return xr_fail(XRHIP_ESTATE, "xrhip_ba_marginalize: singular victim block");
+    std::memcpy(out_sqrt_info, hs, D8 * (size_t)R * R);
+    std::memcpy(out_infovec, hs + (size_t)R * R, D8 * R);
+    int j = 0;
+    for (int i = 0; i < K; ++i) {
+        if (i == M->victim) continue;
+        std::memcpy(out_lin + 16 * (size_t)j, M->frame_state + 16 * (size_t)i, D8 * 16);
+        ++j;
+    }
+    return XRHIP_OK;
+}
+
+int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *sample_begin, const int *sample_count,
+                                const double *t_end, const double *bg, const double *ba, int n_jobs,
+                                const double *noise_cov36, int compute_jacobian, int compute_covariance, double *out) {
+    if (!c || !samples || !sample_begin || !sample_count || !t_end || !bg || !ba || !noise_cov36 || !out || n_jobs <= 0)
+        return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: bad arguments");
+    int total = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        if (sample_count[k] <= 0 || sample_begin[k] < 0) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: empty IMU segment");
+        total = std::max(total, sample_begin[k] + sample_count[k]);
+    }
+    const size_t D8 = sizeof(double);
+    const size_t b_jobs = sizeof(PreintJob) * n_jobs, b_smp = D8 * 7 * (size_t)total, b_noise = D8 * 36;
+    const size_t o_jobs = 0, o_smp = (b_jobs + 255) & ~size_t(255), o_noise = (o_smp + b_smp + 255) & ~size_t(255);
+    const size_t o_out = (o_noise + b_noise + 255) & ~size_t(255), o_st = o_out + D8 * XRHIP_IMU_DIM * (size_t)n_jobs;
+    const size_t bytes = o_st + sizeof(int) * n_jobs + 256;
+    int rc = ensure_work2(c, bytes, bytes);
+    if (rc) return rc;
+    char *H = c->h_stage, *Dv = c->work2;
+    PreintJob *jobs = (PreintJob *)(H + o_jobs);
+    for (int k = 0; k < n_jobs; ++k) {
+        jobs[k].sample_begin = sample_begin[k];
+        jobs[k].sample_count = sample_count[k];
+        jobs[k].t_end = t_end[k];
+        for (int i = 0; i < 3; ++i) {
+            jobs[k].bg[i] = bg[3 * k + i];
+            jobs[k].ba[i] = ba[3 * k + i];
+        }
+    }
+    std::memcpy(H + o_smp, samples, b_smp);
+    std::memcpy(H + o_noise, noise_cov36, b_noise);
+    std::memset(H + o_st, 0, sizeof(int) * n_jobs);
+    hipStream_t s = c->stream;
+    XR_HIP(hipMemcpyAsync(Dv, H, o_out, hipMemcpyHostToDevice, s));
+    XR_HIP(hipMemsetAsync(Dv + o_st, 0, sizeof(int) * n_jobs, s));
+    hipLaunchKernelGGL(kp_preintegrate, dim3(n_jobs), dim3(256), 0, s, (const PreintJob *)(Dv + o_jobs),
+                       (const double *)(Dv + o_smp), (const double *)(Dv + o_noise), compute_jacobian ? 1 : 0,
+                       compute_covariance ? 1 : 0, (double *)(Dv + o_out), (int *)(Dv + o_st));
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipMemcpyAsync(H + o_out, Dv + o_out, D8 * XRHIP_IMU_DIM * (size_t)n_jobs + sizeof(int) * n_jobs,
+                          hipMemcpyDeviceToHost, s));
+    XR_HIP(hipStreamSynchronize(s));
+    const int *st = (const int *)(H + o_st);
+    for (int k = 0; k < n_jobs; ++k)
+        if (st[k]) return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate: covariance is not positive definite");
+    std::memcpy(out, H + o_out, D8 * XRHIP_IMU_DIM * (size_t)n_jobs);
+    return XRHIP_OK;
+}
+
+int xrhip_ba_preintegrate(xrhip_ba *c, const double *samples, int n, double t_end, const double *bg, const double *ba,
+                          const double *noise_cov36, int compute_jacobian, int compute_covariance, double *out) {
+    const int begin = 0;
+    return xrhip_ba_preintegrate_batch(c, samples, &begin, &n, &t_end, bg, ba, 1, noise_cov36, compute_jacobian,
+                                       compute_covariance, out);
 }
 
 }   // extern "C"

@@ -47,6 +47,7 @@ struct BaDims {
     int M, MR, NI;      // reprojection / rotation / imu factors
     int NP, np;         // prior frames, 15*NP
     int NV;             // n + L
+    int robust;         // 1: CauchyLoss(1) on visual factors (Solver); 0: none (marginalisation)
 };
 
 struct BaPtrs {
@@ -132,7 +133,7 @@ __device__ __forceinline__ double obs_eval(const BaDims &d, const BaPtrs &p, int
     const double s = r[0] * r[0] + r[1] * r[1];
     if (want_j) {
         // CauchyLoss(1): rho' = 1/(1+s), rho'' < 0  =>  residual and Jacobian scaled by sqrt(rho')
-        const double sc = sqrt(fmax(2.2250738585072014e-308, 1.0 / (1.0 + s)));
+        const double sc = d.robust ? sqrt(fmax(2.2250738585072014e-308, 1.0 / (1.0 + s))) : 1.0;
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             rec[i] = at ? Jt[i] * sc : 0.0;
@@ -143,7 +144,7 @@ __device__ __forceinline__ double obs_eval(const BaDims &d, const BaPtrs &p, int
         rec[26] = r[0] * sc;
         rec[27] = r[1] * sc;
     }
-    return 0.5 * log(1.0 + s);
+    return d.robust ? 0.5 * log(1.0 + s) : 0.5 * s;
 }
 
 __global__ __launch_bounds__(256) void kb_lin_obs(BaDims d, BaPtrs p, Ext cam, double sx, double sy) {

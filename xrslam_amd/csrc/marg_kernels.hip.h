@@ -1,0 +1,419 @@
+// marg_kernels.hip.h -- gfx950 kernels for keyframe marginalisation and IMU pre-integration.
+//
+// Replaces CeresMarginalizationFactor::marginalize
+//   (/root/reference/xrslam/src/xrslam/estimation/ceres/marginalization_factor.h:74-475)
+// and PreIntegrator::integrate / increment / compute_sqrt_inv_cov
+//   (/root/reference/xrslam/src/xrslam/estimation/preintegrator.cpp:22-100).
+//
+// Marginalisation pipeline (the linearisation and the landmark Schur product reuse the BA
+// kernels with the robust loss switched off):
+//   kb_lin_* / kb_landmark / kb_assemble / kb_schur_mfma   unreduced H, b and W^T H_ll^-1 W
+//   km_permute     landmark-reduced system with the victim frame moved last
+//   km_victim      15x15 inverse of the victim block (pivoted Gauss-Jordan in LDS), T2 = H_rv H_vv^-1
+//   km_complement  H' = H_rr - T2 H_vr, b' = b_r - T2 b_v, lower triangle mirrored
+//   km_jacobi      symmetric eigen-decomposition by parallel one-sided Jacobi (round-robin pairs)
+//   km_finish      sqrt_info = diag(sqrt(lambda)) V^T, infovec = diag(1/sqrt(lambda)) V^T b' (lambda <= 1e-8 -> 0)
+#pragma once
+#include "ba_kernels.hip.h"
+
+namespace xrhip {
+
+// landmark weights for the marginalisation: omega = 1/H_ll (skipped when not finite)
+__global__ __launch_bounds__(256) void km_omega(BaDims d, BaPtrs p) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= d.L) return;
+    const double inv = 1.0 / p.hll[l];
+    p.omega[l] = isfinite(inv) ? inv : 0.0;
+}
+
+// Hm [N x N] (N = 15K) = permuted (Hpp - T on the pose dofs); bm = permuted (gp - W^T (gl/hll)).
+__global__ __launch_bounds__(256) void km_permute(BaDims d, BaPtrs p, int victim, double *__restrict__ Hm,
+                                                  double *__restrict__ bm) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int n = d.n;
+    if (e >= n * n) return;
+    const int a = e / n, b = e - a * n;
+    const int fa = a / 15, ka = a - 15 * fa, fb = b / 15, kb = b - 15 * fb;
+    const int pfa = fa < victim ? fa : (fa > victim ? fa - 1 : d.F - 1);
+    const int pfb = fb < victim ? fb : (fb > victim ? fb - 1 : d.F - 1);
+    double v = p.Hpp[e];
+    if (ka < 6 && kb < 6) v -= p.T[(size_t)(6 * fa + ka) * d.PF + 6 * fb + kb];
+    const int pa = 15 * pfa + ka, pb = 15 * pfb + kb;
+    Hm[(size_t)pa * n + pb] = v;
+    if (b == 0) {
+        double g = p.gp[a];
+        if (ka < 6) {
+            double s = 0;
+            for (int l = 0; l < d.L; ++l) s += p.Wt[(size_t)l * d.PF + 6 * fa + ka] * (p.omega[l] * p.gl[l]);
+            g -= s;
+        }
+        bm[pa] = g;
+    }
+}
+
+// In-LDS inverse of a 15x15 matrix by Gauss-Jordan with partial pivoting; >= 225 threads, all must call.
+// A is destroyed, I receives the inverse.  Returns false (uniformly) if a zero pivot is met.
+__device__ __forceinline__ bool inv15_block(double (*A)[15], double (*I)[15], int *s_piv, int *s_bad) {
+    const int tid = threadIdx.x;
+    const int i = tid / 15, j = tid - 15 * (tid / 15);
+    const bool in = tid < 225;
+    if (in) I[i][j] = (i == j) ? 1.0 : 0.0;
+    if (tid == 0) *s_bad = 0;
+    __syncthreads();
+    for (int k = 0; k < 15; ++k) {
+        if (tid == 0) {
+            int pp = k;
+            double best = fabs(A[k][k]);
+            for (int r = k + 1; r < 15; ++r)
+                if (fabs(A[r][k]) > best) {
+                    best = fabs(A[r][k]);
+                    pp = r;
+                }
+            *s_piv = pp;
+            if (!(best > 0.0)) *s_bad = 1;
+        }
+        __syncthreads();
+        if (*s_bad) return false;
+        const int pp = *s_piv;
+        if (pp != k && tid < 15) {
+            double t = A[k][tid];
+            A[k][tid] = A[pp][tid];
+            A[pp][tid] = t;
+            t = I[k][tid];
+            I[k][tid] = I[pp][tid];
+            I[pp][tid] = t;
+        }
+        __syncthreads();
+        const double dkk = A[k][k];
+        const double f = in ? A[i][k] : 0.0;
+        __syncthreads();
+        if (in && i == k) {
+            A[k][j] /= dkk;
+            I[k][j] /= dkk;
+        }
+        __syncthreads();
+        if (in && i != k) {
+            A[i][j] -= f * A[k][j];
+            I[i][j] -= f * I[k][j];
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+// One workgroup (256 threads): invert the victim block (last 15x15 of Hm) and form T2 = H_rv * inv (R x 15).
+__global__ __launch_bounds__(256) void km_victim(int N, const double *__restrict__ Hm, double *__restrict__ T2,
+                                                 int *__restrict__ status) {
+    __shared__ double A[15][15], I[15][15];
+    __shared__ int s_piv, s_bad;
+    const int R = N - 15, tid = threadIdx.x;
+    if (tid < 225) A[tid / 15][tid % 15] = Hm[(size_t)(R + tid / 15) * N + R + tid % 15];
+    __syncthreads();
+    if (!inv15_block(A, I, &s_piv, &s_bad)) {
+        if (tid == 0) *status = 1;
+        return;
+    }
+    for (int e = tid; e < R * 15; e += blockDim.x) {
+        const int i = e / 15, j = e - 15 * i;
+        double s = 0;
+        for (int k = 0; k < 15; ++k) s += Hm[(size_t)i * N + R + k] * I[k][j];
+        T2[e] = s;
+    }
+}
+
+// A [R x R] = H_rr - T2 H_vr (lower triangle mirrored: SelfAdjointEigenSolver reads the lower part),
+// bp [R] = b_r - T2 b_v.  One thread per element of the lower triangle's bounding square.
+__global__ __launch_bounds__(256) void km_complement(int N, const double *__restrict__ Hm, const double *__restrict__ bm,
+                                                     const double *__restrict__ T2, double *__restrict__ A,
+                                                     double *__restrict__ bp) {
+    const int R = N - 15;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= R * R) return;
+    const int i = e / R, j = e - i * R;
+    if (j <= i) {
+        double v = Hm[(size_t)i * N + j];
+        for (int k = 0; k < 15; ++k) v -= T2[i * 15 + k] * Hm[(size_t)(R + k) * N + j];
+        A[(size_t)i * R + j] = v;
+        A[(size_t)j * R + i] = v;
+    }
+    if (j == 0) {
+        double v = bm[i];
+        for (int k = 0; k < 15; ++k) v -= T2[i * 15 + k] * bm[R + k];
+        bp[i] = v;
+    }
+}
+
+// Parallel one-sided (Hestenes) Jacobi on the symmetric matrix A: B = A V is driven to orthogonal columns by
+// plane rotations applied to column pairs; the R/2 pairs of a round-robin round are disjoint and processed
+// concurrently by G-thread groups.  B, V are column-major R x R in global memory (L2 resident).
+// On exit column i of V is an eigenvector and lambda_i = v_i . b_i.
+__global__ __launch_bounds__(1024) void km_jacobi(int R, int G, const double *__restrict__ A, double *__restrict__ B,
+                                                  double *__restrict__ V, int max_sweeps, int *__restrict__ sweeps_out) {
+    __shared__ int rotated;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int e = tid; e < R * R; e += nt) {
+        const int c = e / R, r = e - c * R;
+        B[e] = A[(size_t)r * R + c];   // column-major copy (A symmetric)
+        V[e] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const int Rp = R + (R & 1);
+    const int pairs = Rp / 2;
+    const int k = tid / G, g = tid - k * G;
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        if (tid == 0) rotated = 0;
+        __syncthreads();
+        for (int r = 0; r < Rp - 1; ++r) {
+            int pi = -1, qi = -1;
+            if (k < pairs) {
+                if (k == 0) {
+                    pi = Rp - 1;
+                    qi = r;
+                } else {
+                    pi = (r + k) % (Rp - 1);
+                    qi = (r - k + (Rp - 1)) % (Rp - 1);
+                }
+                if (pi > qi) {
+                    const int t = pi;
+                    pi = qi;
+                    qi = t;
+                }
+                if (qi >= R) pi = -1;   // dummy player of an odd-sized tournament
+            }
+            double al = 0, be = 0, ga = 0;
+            if (pi >= 0) {
+                const double *bp = B + (size_t)pi * R, *bq = B + (size_t)qi * R;
+                for (int e = g; e < R; e += G) {
+                    const double x = bp[e], y = bq[e];
+                    al += x * x;
+                    be += y * y;
+                    ga += x * y;
+                }
+            }
+            for (int off = 1; off < G; off <<= 1) {   // groups are aligned power-of-two lane ranges
+                al += __shfl_xor(al, off);
+                be += __shfl_xor(be, off);
+                ga += __shfl_xor(ga, off);
+            }
+            if (pi >= 0 && ga != 0.0 && fabs(ga) > 1e-15 * sqrt(al * be)) {
+                const double zeta = (be - al) / (2.0 * ga);
+                double t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                if (zeta < 0) t = -t;
+                if (!isfinite(zeta)) t = 0.0;
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                double *bp = B + (size_t)pi * R, *bq = B + (size_t)qi * R;
+                double *vp = V + (size_t)pi * R, *vq = V + (size_t)qi * R;
+                for (int e = g; e < R; e += G) {
+                    const double x = bp[e], y = bq[e];
+                    bp[e] = cs * x - sn * y;
+                    bq[e] = sn * x + cs * y;
+                    const double u = vp[e], w = vq[e];
+                    vp[e] = cs * u - sn * w;
+                    vq[e] = sn * u + cs * w;
+                }
+                if (g == 0) rotated = 1;
+            }
+            __syncthreads();
+        }
+        const int any = rotated;
+        __syncthreads();
+        if (!any) break;
+    }
+    if (tid == 0) *sweeps_out = sweep;
+}
+
+// sqrt_info row i = sqrt(lambda_i) v_i^T, infovec_i = v_i . b' / sqrt(lambda_i), eigenvalues <= 1e-8 dropped.
+__global__ __launch_bounds__(64) void km_finish(int R, const double *__restrict__ B, const double *__restrict__ V,
+                                                const double *__restrict__ bp, double *__restrict__ sqrt_info,
+                                                double *__restrict__ infovec) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const double *v = V + (size_t)i * R, *b = B + (size_t)i * R;
+    double lam = 0, vb = 0;
+    for (int e = lane; e < R; e += 64) {
+        lam += v[e] * b[e];
+        vb += v[e] * bp[e];
+    }
+    lam = wave_sum(lam);
+    vb = wave_sum(vb);
+    const double sl = lam > 1.0e-8 ? sqrt(lam) : 0.0;
+    const double sli = lam > 1.0e-8 ? sqrt(1.0 / lam) : 0.0;
+    for (int e = lane; e < R; e += 64) sqrt_info[(size_t)i * R + e] = sl * v[e];
+    if (lane == 0) infovec[i] = sli * vb;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// IMU pre-integration.  One 128-thread workgroup per integration; the 9x9 covariance recursion
+// A Sigma A^T + B Q B^T and the five 3x3 bias Jacobians are spread over the lanes, the SO(3) algebra of each
+// sample is evaluated by lane 0.  Batched: blockIdx.x selects the integration.
+struct PreintJob {
+    int sample_begin, sample_count;   // into samples [.][7] = t, w, a
+    double t_end;
+    double bg[3], ba[3];
+};
+
+__global__ __launch_bounds__(256) void kp_preintegrate(const PreintJob *__restrict__ jobs,
+                                                       const double *__restrict__ samples,
+                                                       const double *__restrict__ noise36, int want_jac, int want_cov,
+                                                       double *__restrict__ out, int *__restrict__ status) {
+    __shared__ double cov[15][15], Am[9][9], Bm[9][6], Tm[9][9], Um[9][6];
+    __shared__ double Jac[5][9], Jnew[5][9];   // dq_dbg, dp_dbg, dp_dba, dv_dbg, dv_dba
+    __shared__ double dR[9], E[9], Jr[9], Ra[9];
+    __shared__ double sq[4], sp3[3], sv3[3], sdt;
+    __shared__ double inv[15][15];
+    __shared__ int s_piv, s_bad;
+    const PreintJob job = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    double *o = out + (size_t)blockIdx.x * XRHIP_IMU_DIM;
+    for (int e = tid; e < 225; e += blockDim.x) cov[e / 15][e % 15] = 0.0;
+    if (tid < 45) Jac[tid / 9][tid % 9] = 0.0;
+    if (tid == 0) {
+        sq[0] = sq[1] = sq[2] = 0.0;
+        sq[3] = 1.0;
+        for (int i = 0; i < 3; ++i) sp3[i] = sv3[i] = 0.0;
+        sdt = 0.0;
+    }
+    __syncthreads();
+    const V3 bg = v3(job.bg[0], job.bg[1], job.bg[2]), ba = v3(job.ba[0], job.ba[1], job.ba[2]);
+    for (int n = 0; n < job.sample_count; ++n) {
+        const double *smp = samples + (size_t)(job.sample_begin + n) * 7;
+        const double t1 = (n + 1 < job.sample_count) ? smp[7] : job.t_end;
+        const double dt = t1 - smp[0];
+        const V3 w = v3(smp[1], smp[2], smp[3]) - bg;
+        const V3 a = v3(smp[4], smp[5], smp[6]) - ba;
+        if (tid == 0) {
+            const Q4 q = Q4{sq[0], sq[1], sq[2], sq[3]};
+            const M3 R = q_mat(q), Em = q_mat(q_conj(expmap(w * dt))), J = right_jacobian(w * dt), ra = R * hat(a);
+            for (int i = 0; i < 9; ++i) {
+                dR[i] = R.m[i];
+                E[i] = Em.m[i];
+                Jr[i] = J.m[i];
+                Ra[i] = ra.m[i];
+            }
+        }
+        __syncthreads();
+        if (want_cov) {
+            if (tid < 81) {
+                const int i = tid / 9, j = tid % 9;
+                double v = (i == j) ? 1.0 : 0.0;
+                if (i < 3 && j < 3) v = E[3 * i + j];                                  // (ES_Q, ES_Q)
+                if (i >= 6 && j < 3) v = -dt * Ra[3 * (i - 6) + j];                    // (ES_V, ES_Q)
+                if (i >= 3 && i < 6 && j < 3) v = -0.5 * dt * dt * Ra[3 * (i - 3) + j];   // (ES_P, ES_Q)
+                if (i >= 3 && i < 6 && j >= 6) v = (i - 3 == j - 6) ? dt : 0.0;        // (ES_P, ES_V)
+                Am[i][j] = v;
+            }
+            if (tid >= 128 && tid < 128 + 54) {
+                const int e = tid - 128, i = e / 6, j = e % 6;
+                double v = 0.0;
+                if (i < 3 && j < 3) v = dt * Jr[3 * i + j];                            // (ES_Q, bg)
+                if (i >= 6 && j >= 3) v = dt * dR[3 * (i - 6) + (j - 3)];              // (ES_V, ba)
+                if (i >= 3 && i < 6 && j >= 3) v = 0.5 * dt * dt * dR[3 * (i - 3) + (j - 3)];   // (ES_P, ba)
+                Bm[i][j] = v;
+            }
+            __syncthreads();
+            const double inv_dt = 1.0 / fmax(dt, 1.0e-7);
+            if (tid < 81) {
+                const int i = tid / 9, j = tid % 9;
+                double s = 0;
+                for (int k = 0; k < 9; ++k) s += Am[i][k] * cov[k][j];
+                Tm[i][j] = s;
+            }
+            if (tid >= 128 && tid < 128 + 54) {
+                const int e = tid - 128, i = e / 6, j = e % 6;
+                double s = 0;
+                if (j < 3) {
+                    for (int k = 0; k < 3; ++k) s += Bm[i][k] * (noise36[3 * k + j] * inv_dt);
+                } else {
+                    for (int k = 0; k < 3; ++k) s += Bm[i][3 + k] * (noise36[9 + 3 * k + (j - 3)] * inv_dt);
+                }
+                Um[i][j] = s;
+            }
+            __syncthreads();
+            if (tid < 81) {
+                const int i = tid / 9, j = tid % 9;
+                double s = 0;
+                for (int k = 0; k < 9; ++k) s += Tm[i][k] * Am[j][k];
+                double u = 0;
+                for (int k = 0; k < 6; ++k) u += Um[i][k] * Bm[j][k];
+                cov[i][j] = s + u;
+            }
+            if (tid >= 128 && tid < 128 + 18) {
+                const int e = tid - 128, blk = e / 9, i = (e % 9) / 3, j = e % 3;
+                cov[9 + 3 * blk + i][9 + 3 * blk + j] += noise36[18 + 9 * blk + 3 * i + j] * dt;
+            }
+        }
+        if (want_jac && tid < 45) {
+            const int m = tid / 9, i = (tid % 9) / 3, j = tid % 3;
+            double radq = 0, edq = 0;   // (dR hat(a) dq_dbg)_ij and (E dq_dbg)_ij
+            for (int k = 0; k < 3; ++k) {
+                radq += Ra[3 * i + k] * Jac[0][3 * k + j];
+                edq += E[3 * i + k] * Jac[0][3 * k + j];
+            }
+            double v;
+            if (m == 1) v = Jac[1][3 * i + j] + dt * Jac[3][3 * i + j] - 0.5 * dt * dt * radq;        // dp_dbg
+            else if (m == 2) v = Jac[2][3 * i + j] + dt * Jac[4][3 * i + j] - 0.5 * dt * dt * dR[3 * i + j];   // dp_dba
+            else if (m == 3) v = Jac[3][3 * i + j] - dt * radq;                                      // dv_dbg
+            else if (m == 4) v = Jac[4][3 * i + j] - dt * dR[3 * i + j];                             // dv_dba
+            else v = edq - dt * Jr[3 * i + j];                                                       // dq_dbg
+            Jnew[m][3 * i + j] = v;
+        }
+        __syncthreads();
+        if (want_jac && tid < 45) Jac[tid / 9][tid % 9] = Jnew[tid / 9][tid % 9];
+        if (tid == 0) {
+            const Q4 q = Q4{sq[0], sq[1], sq[2], sq[3]};
+            const V3 qa = q_rot(q, a);
+            const V3 pv = v3(sp3[0], sp3[1], sp3[2]), vv = v3(sv3[0], sv3[1], sv3[2]);
+            const V3 pn = pv + vv * dt + qa * (0.5 * dt * dt);
+            const V3 vn = vv + qa * dt;
+            const Q4 qn = q_normalized(q_mul(q, expmap(w * dt)));
+            sdt = sdt + dt;
+            sp3[0] = pn.x; sp3[1] = pn.y; sp3[2] = pn.z;
+            sv3[0] = vn.x; sv3[1] = vn.y; sv3[2] = vn.z;
+            sq[0] = qn.x; sq[1] = qn.y; sq[2] = qn.z; sq[3] = qn.w;
+        }
+        __syncthreads();
+    }
+    // outputs
+    if (tid == 0) {
+        o[0] = sdt;
+        for (int i = 0; i < 4; ++i) o[1 + i] = sq[i];
+        for (int i = 0; i < 3; ++i) {
+            o[5 + i] = sp3[i];
+            o[8 + i] = sv3[i];
+        }
+    }
+    if (tid < 45) o[11 + tid] = Jac[tid / 9][tid % 9];
+    if (!want_cov) {
+        for (int e = tid; e < 225; e += blockDim.x) o[56 + e] = 0.0;
+        return;
+    }
+    // sqrt_inv_cov = LLT(cov^-1).matrixL().transpose()
+    __syncthreads();
+    if (!inv15_block(cov, inv, &s_piv, &s_bad)) {
+        if (tid == 0) status[blockIdx.x] = 2;
+        return;
+    }
+    // Cholesky of inv (lower) in place into cov (reused as L)
+    for (int e = tid; e < 225; e += blockDim.x) cov[e / 15][e % 15] = 0.0;
+    __syncthreads();
+    for (int j = 0; j < 15; ++j) {
+        if (tid < 15 && tid >= j) {
+            const int i = tid;
+            double s = inv[i][j];
+            for (int k = 0; k < j; ++k) s -= cov[i][k] * cov[j][k];
+            inv[i][j] = s;   // column j updated in place
+        }
+        __syncthreads();
+        const double djj = inv[j][j];
+        if (!(djj > 0.0)) {
+            if (tid == 0) status[blockIdx.x] = 3;
+            return;
+        }
+        const double dj = sqrt(djj);
+        if (tid < 15 && tid >= j) cov[tid][j] = (tid == j) ? dj : inv[tid][j] / dj;
+        __syncthreads();
+    }
+    for (int e = tid; e < 225; e += blockDim.x) o[56 + e] = cov[e % 15][e / 15];   // L^T, row-major
+}
+
+}   // namespace xrhip
