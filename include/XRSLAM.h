@@ -1,0 +1,161 @@
+/*
+ * XRSLAM.h -- outer C ABI of the MI355X-native XRSLAM hot path.
+ *
+ * Binary-compatible with the reference's public interface
+ * (/root/reference/xrslam-interface/include/XRSLAM.h:19-229): same exported symbols,
+ * enum values and POD layouts, so a host application built against the reference
+ * (xrslam-pc/player/src/main.cpp:116-169, xrslam-ros/src/xrslam_node.cpp:44) links
+ * against libxrslam_hip.so unchanged.  Implementation: xrslam_amd/csrc/host/xrslam_api.cpp.
+ *
+ * Differences, all additive:
+ *   - the XRSLAMAmd* entry points at the bottom (bootstrap states, device-resident
+ *     images, stage timers) -- the reference's Initializer is out of scope
+ *      so the window is seeded through XRSLAMAmdSetInitialState;
+ *   - XRSLAMFeatures is declared for C++ only, like the reference (it holds a std::vector).
+ */
+#ifndef XRSLAM_AMD_XRSLAM_H
+#define XRSLAM_AMD_XRSLAM_H
+#include <stdint.h>
+#ifdef __cplusplus
+#include <vector>
+extern "C" {
+#endif
+
+/* ---- sensor inputs ---- */
+typedef enum XRSLAMSensorType {
+    XRSLAM_SENSOR_CAMERA = 0,
+    XRSLAM_SENSOR_DEPTH_CAMERA,
+    XRSLAM_SENSOR_ACCELERATION,
+    XRSLAM_SENSOR_GYROSCOPE,
+    XRSLAM_SENSOR_GRAVITY,
+    XRSLAM_SENSOR_ROTATION_VECTOR,
+    XRSLAM_SENSOR_UNKNOWN
+} XRSLAMSensorType;
+
+typedef struct XRSLAMImageExtension {
+    double exposure_time, default_focus_distance, focal_length, focus_distance;
+} XRSLAMImageExtension;
+
+typedef struct XRSLAMImage {
+    unsigned char *data; /* 8-bit pixels */
+    double timeStamp;    /* seconds */
+    int stride;          /* bytes per row */
+    int camera_id;       /* only 0 is consumed */
+    int channel;         /* 1 (gray), 3 (BGR) or 4 (BGRA) */
+    XRSLAMImageExtension *ext;
+} XRSLAMImage;
+
+typedef struct XRSLAMDepthImage {
+    uint16_t *data, *confidence;
+    double timeStamp;
+} XRSLAMDepthImage;
+
+typedef struct XRSLAMAcceleration {
+    double data[3];
+    double timestamp;
+} XRSLAMAcceleration;
+typedef struct XRSLAMGyroscope {
+    double data[3];
+    double timestamp;
+} XRSLAMGyroscope;
+typedef struct XRSLAMGravity {
+    double data[3];
+    double timestamp;
+} XRSLAMGravity;
+typedef struct XRSLAMRotationVector {
+    double data[4];
+    double timestamp;
+} XRSLAMRotationVector;
+
+/* ---- results ---- */
+typedef enum XRSLAMResultType {
+    XRSLAM_RESULT_BODY_POSE = 0,
+    XRSLAM_RESULT_CAMERA_POSE,
+    XRSLAM_RESULT_STATE,
+    XRSLAM_RESULT_LANDMARKS,
+    XRSLAM_RESULT_FEATURES,
+    XRSLAM_RESULT_BIAS,
+    XRSLAM_RESULT_DEBUG_LOGS,
+    XRSLAM_RESULT_VERSION,
+    XRSLAM_RESULT_UNKNOWN,
+    XRSLAM_INFO_INTRINSICS
+} XRSLAMResultType;
+
+typedef struct XRSLAMPose {
+    double quaternion[4];  /* x y z w */
+    double translation[3];
+    double timestamp;
+} XRSLAMPose;
+
+typedef struct XRSLAMIntrinsics {
+    double fx, fy, cx, cy;
+} XRSLAMIntrinsics;
+
+typedef enum XRSLAMState {
+    XRSLAM_STATE_INITIALIZING,
+    XRSLAM_STATE_TRACKING_SUCCESS,
+    XRSLAM_STATE_TRACKING_FAIL
+} XRSLAMState;
+
+typedef struct XRSLAMLandmark {
+    double x, y, z;
+} XRSLAMLandmark;
+typedef struct XRSLAMLandmarks {
+    XRSLAMLandmark *landmarks;
+    int num_landmarks;
+} XRSLAMLandmarks;
+
+typedef struct XRSLAMFeature {
+    double x, y;
+} XRSLAMFeature;
+#ifdef __cplusplus
+typedef struct XRSLAMFeatures {
+    struct Point {
+        double x;
+        double y;
+    };
+    std::vector<Point> pos;
+} XRSLAMFeatures;
+#endif
+
+typedef struct XRSLAMBias {
+    double data[3];
+} XRSLAMBias;
+typedef struct XRSLAMIMUBias {
+    XRSLAMBias acc_bias;
+    XRSLAMBias gyr_bias;
+} XRSLAMIMUBias;
+
+typedef struct XRSLAMStringOutput {
+    int str_length;
+    char *data;
+} XRSLAMStringOutput;
+
+/* ---- entry points (reference XRSLAM.h:201-229) ---- */
+/* returns 1 on success, 0 otherwise; *config receives an opaque configuration handle owned by the library */
+int XRSLAMCreate(const char *slam_config_path, const char *device_config_path, const char *license_path,
+                 const char *product_name, void **config);
+void XRSLAMPushSensorData(XRSLAMSensorType sensor_type, void *sensor_data);
+void XRSLAMRunOneFrame();
+void XRSLAMSetViewer(void *viewer); /* declared by the reference, defined nowhere there; a no-op here */
+void XRSLAMGetResult(XRSLAMResultType result_type, void *result_data);
+void XRSLAMDestroy();
+
+/* ---- additive MI355X entry points ---- */
+/* seed state for the bootstrap initialiser: body pose/velocity/biases at image time t (q: x y z w) */
+void XRSLAMAmdSetInitialState(double t, const double q[4], const double p[3], const double v[3],
+                              const double bg[3], const double ba[3]);
+/* like XRSLAM_SENSOR_CAMERA but `gray_dev` is an 8-bit single-channel image already resident in HBM */
+void XRSLAMAmdPushImageDevice(const void *gray_dev, int stride, double timestamp);
+typedef struct XRSLAMAmdTimes {
+    long frames, solves, solve_iterations, marginalizations, keyframes;
+    double ba_device_ms; /* sum of HIP-event solve times */
+} XRSLAMAmdTimes;
+void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out);
+/* last error raised inside the library ("" if none); the reference aborts/throws instead */
+const char *XRSLAMAmdLastError(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XRSLAM_AMD_XRSLAM_H */

@@ -1,0 +1,130 @@
+// xrhip_shim.cpp -- TEST INFRASTRUCTURE ONLY.
+// Implements the subset of the xrhip_* C ABI (include/xrslam_hip.h) that the host pipeline
+// (xrslam_amd/csrc/host/pipeline.hpp) calls, on top of the CPU oracle.  Linking the pipeline sources
+// against this shim instead of libxrslam_hip.so yields "the reference CPU path": identical host logic,
+// oracle arithmetic, one thread.  Used by tests (full-pipeline parity: track ids / keypoint indices
+// bit-exact, states within tolerance) and by bench.py's cpu_baseline leg.  The product never links it.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/xrslam_hip.h"
+
+extern "C" {
+// oracle/klt_oracle.c
+typedef struct OrcPyramid OrcPyramid;
+OrcPyramid *orc_pyr_create(int w, int h, int max_level, int pad);
+void orc_pyr_destroy(OrcPyramid *P);
+void orc_preprocess(OrcPyramid *P, const uint8_t *img, int stride, double clip, int tx, int ty, uint8_t *work);
+int orc_detect_keypoints(const uint8_t *img, int w, int h, int stride, const double *existing, int n_exist,
+                         int max_points, double min_dist, double *out_xy);
+void orc_track_keypoints(const OrcPyramid *A, const OrcPyramid *B, const double *curr, double *next_inout, int has_guess,
+                         uint8_t *status, int n, void *stats);
+// oracle/ba_oracle.cpp
+int orc_ba_solve(const xrhip_ba_problem *P, xrhip_ba_summary *summary);
+int orc_ba_marginalize(const xrhip_marg_problem *M, double *out_sqrt_info, double *out_infovec, double *out_lin);
+int orc_preintegrate(const double *samples, int n, double t_end, const double *bg, const double *ba,
+                     const double *noise36, int jac, int cv, double *out);
+}
+
+struct xrhip_klt {
+    int w, h;
+};
+struct xrhip_image {
+    xrhip_klt *ctx;
+    std::vector<uint8_t> raw, clahe;
+    OrcPyramid *pyr;
+    bool have_raw, have_pyr;
+};
+struct xrhip_ba {
+    int dummy;
+};
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *xrhip_last_error(void) { return g_err.c_str(); }
+int xrhip_device_count(void) { return 0; }
+int xrhip_set_device(int) { return 0; }
+
+int xrhip_klt_create(int width, int height, int, xrhip_klt **out) {
+    *out = new xrhip_klt{width, height};
+    return 0;
+}
+void xrhip_klt_destroy(xrhip_klt *c) { delete c; }
+int xrhip_image_create(xrhip_klt *c, xrhip_image **out) {
+    xrhip_image *im = new xrhip_image();
+    im->ctx = c;
+    im->raw.resize((size_t)c->w * c->h);
+    im->clahe.resize((size_t)c->w * c->h);
+    im->pyr = orc_pyr_create(c->w, c->h, 3, 21);
+    im->have_raw = im->have_pyr = false;
+    *out = im;
+    return 0;
+}
+void xrhip_image_destroy(xrhip_image *im) {
+    if (!im) return;
+    orc_pyr_destroy(im->pyr);
+    delete im;
+}
+int xrhip_image_upload(xrhip_image *im, const uint8_t *gray, int stride) {
+    for (int y = 0; y < im->ctx->h; ++y) std::memcpy(&im->raw[(size_t)y * im->ctx->w], gray + (size_t)y * stride, im->ctx->w);
+    im->have_raw = true;
+    im->have_pyr = false;
+    return 0;
+}
+int xrhip_image_upload_device(xrhip_image *im, const void *gray, int stride) {
+    return xrhip_image_upload(im, static_cast<const uint8_t *>(gray), stride);   // "device" == host in the shim
+}
+int xrhip_image_preprocess(xrhip_image *im, double clip, int tx, int ty) {
+    if (!im->have_raw) {
+        g_err = "preprocess: no image";
+        return XRHIP_ESTATE;
+    }
+    orc_preprocess(im->pyr, im->raw.data(), im->ctx->w, clip, tx, ty, im->clahe.data());
+    im->have_pyr = true;
+    return 0;
+}
+int xrhip_image_release(xrhip_image *im) {
+    im->have_raw = im->have_pyr = false;
+    return 0;
+}
+int xrhip_image_detect(xrhip_image *im, const double *existing, int n_exist, int max_points, double min_dist,
+                       double *out_xy, int *n_out) {
+    if (!im->have_pyr) {
+        g_err = "detect: preprocess() has not run";
+        return XRHIP_ESTATE;
+    }
+    *n_out = orc_detect_keypoints(im->clahe.data(), im->ctx->w, im->ctx->h, im->ctx->w, existing, n_exist, max_points,
+                                  min_dist, out_xy);
+    return 0;
+}
+int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const double *curr_xy, double *next_xy,
+                      int has_guess, uint8_t *status, int n) {
+    if (!cur->have_pyr || !next->have_pyr) {
+        g_err = "track: preprocess() has not run";
+        return XRHIP_ESTATE;
+    }
+    if (n > 0) orc_track_keypoints(cur->pyr, next->pyr, curr_xy, next_xy, has_guess, status, n, nullptr);
+    return 0;
+}
+int xrhip_ba_create(int, int, int, xrhip_ba **out) {
+    *out = new xrhip_ba{0};
+    return 0;
+}
+void xrhip_ba_destroy(xrhip_ba *c) { delete c; }
+int xrhip_ba_solve(xrhip_ba *, const xrhip_ba_problem *P, xrhip_ba_summary *s) { return orc_ba_solve(P, s); }
+int xrhip_ba_marginalize(xrhip_ba *, const xrhip_marg_problem *M, double *a, double *b, double *c) {
+    int rc = orc_ba_marginalize(M, a, b, c);
+    if (rc) g_err = "marginalize failed";
+    return rc ? XRHIP_ESTATE : 0;
+}
+int xrhip_ba_preintegrate(xrhip_ba *, const double *samples, int n, double t_end, const double *bg, const double *ba,
+                          const double *noise36, int jac, int cov, double *out) {
+    int rc = orc_preintegrate(samples, n, t_end, bg, ba, noise36, jac, cov, out);
+    if (rc) g_err = "preintegrate failed";
+    return rc ? XRHIP_ESTATE : 0;
+}
+}

@@ -1,0 +1,110 @@
+// Test-only: exposes the PRODUCT's host geometry / config code (xrslam_amd/csrc/host/*.hpp) through a C
+// interface so tests can check it against numpy.  Plain g++, no HIP.  Never shipped.
+#include <cstring>
+
+#include "../../xrslam_amd/csrc/host/config.hpp"
+#include "../../xrslam_amd/csrc/host/geometry.hpp"
+
+using namespace xrh;
+
+extern "C" {
+
+int gh_real_eigen(const double *M, int n, double *wr, double *wi, double *vecs /* n x n, column e = eigvec or zeros */) {
+    Dense A(n, n);
+    std::memcpy(A.a.data(), M, sizeof(double) * n * n);
+    std::vector<double> r, i;
+    std::vector<std::vector<double>> v;
+    real_eigen(A, r, i, v);
+    for (int e = 0; e < n; ++e) {
+        wr[e] = r[e];
+        wi[e] = i[e];
+        for (int k = 0; k < n; ++k) vecs[k * n + e] = v[e].empty() ? 0.0 : v[e][k];
+    }
+    return 0;
+}
+int gh_svd(const double *M, int m, int n, double *s, double *V) {
+    Dense A(m, n);
+    std::memcpy(A.a.data(), M, sizeof(double) * m * n);
+    std::vector<double> sv;
+    Dense Vm;
+    jacobi_svd(A, sv, Vm);
+    for (int j = 0; j < n; ++j) s[j] = sv[j];
+    std::memcpy(V, Vm.a.data(), sizeof(double) * n * n);
+    return 0;
+}
+int gh_essential_5pt(const double *p1, const double *p2, double *E_out /* up to 10 x 9 */) {
+    std::array<V2, 5> a, b;
+    for (int i = 0; i < 5; ++i) {
+        a[i] = {p1[2 * i], p1[2 * i + 1]};
+        b[i] = {p2[2 * i], p2[2 * i + 1]};
+    }
+    auto Es = solve_essential_5pt(a, b);
+    for (size_t k = 0; k < Es.size(); ++k) std::memcpy(E_out + 9 * k, Es[k].m, sizeof(double) * 9);
+    return (int)Es.size();
+}
+void gh_rotation_2pt(const double *a6, const double *b6, double *R9) {
+    std::array<V3, 2> a{V3{a6[0], a6[1], a6[2]}, V3{a6[3], a6[4], a6[5]}}, b{V3{b6[0], b6[1], b6[2]}, V3{b6[3], b6[4], b6[5]}};
+    M3 R = solve_rotation_2pt(a, b);
+    std::memcpy(R9, R.m, sizeof(R.m));
+}
+int gh_find_essential(const double *p1, const double *p2, int n, char *mask, double *E9) {
+    std::vector<V2> a(n), b(n);
+    for (int i = 0; i < n; ++i) {
+        a[i] = {p1[2 * i], p1[2 * i + 1]};
+        b[i] = {p2[2 * i], p2[2 * i + 1]};
+    }
+    std::vector<char> m;
+    M3 E = find_essential_matrix(a, b, m, 1.0);
+    std::memcpy(E9, E.m, sizeof(E.m));
+    for (size_t i = 0; i < m.size(); ++i) mask[i] = m[i];
+    return (int)m.size();
+}
+int gh_find_rotation(const double *p1, const double *p2, int n, double thr, char *mask, double *R9) {
+    std::vector<V3> a(n), b(n);
+    for (int i = 0; i < n; ++i) {
+        a[i] = {p1[3 * i], p1[3 * i + 1], p1[3 * i + 2]};
+        b[i] = {p2[3 * i], p2[3 * i + 1], p2[3 * i + 2]};
+    }
+    std::vector<char> m;
+    M3 R = find_rotation_matrix(a, b, m, thr);
+    std::memcpy(R9, R.m, sizeof(R.m));
+    for (size_t i = 0; i < m.size(); ++i) mask[i] = m[i];
+    return (int)m.size();
+}
+void gh_triangulate(const double *Ps, const double *zs, int n, double *h4) {
+    std::vector<P34> P(n);
+    std::vector<V3> z(n);
+    for (int i = 0; i < n; ++i) {
+        std::memcpy(P[i].m, Ps + 12 * i, sizeof(double) * 12);
+        z[i] = {zs[3 * i], zs[3 * i + 1], zs[3 * i + 2]};
+    }
+    auto h = triangulate_point(P, z);
+    for (int i = 0; i < 4; ++i) h4[i] = h[i];
+}
+void gh_lotbox(int size, unsigned seed, int rounds, int draws, long long *out) {
+    LotBox box(size);
+    box.seed(seed);
+    for (int r = 0; r < rounds; ++r) {
+        box.refill_all();
+        for (int d = 0; d < draws; ++d) out[r * draws + d] = (long long)box.draw_without_replacement();
+    }
+}
+int gh_load_config(const char *slam, const char *dev, double *out64) {
+    try {
+        Config c = load_config(slam, dev);
+        double *o = out64;
+        *o++ = c.cam_resolution[0]; *o++ = c.cam_resolution[1];
+        *o++ = c.K.fx; *o++ = c.K.fy; *o++ = c.K.cx; *o++ = c.K.cy;
+        *o++ = c.q_bc.x; *o++ = c.q_bc.y; *o++ = c.q_bc.z; *o++ = c.q_bc.w;
+        *o++ = c.p_bc.x; *o++ = c.p_bc.y; *o++ = c.p_bc.z;
+        *o++ = c.cov_g[0]; *o++ = c.cov_a[4]; *o++ = c.cov_bg[8]; *o++ = c.cov_ba[0];
+        *o++ = (double)c.sliding_window_size; *o++ = (double)c.feature_tracker_max_keypoint_detection;
+        *o++ = (double)c.feature_tracker_max_frames; *o++ = (double)c.solver_iteration_limit;
+        *o++ = c.rotation_misalignment_threshold; *o++ = c.feature_tracker_predict_keypoints ? 1.0 : 0.0;
+        *o++ = c.keypoint_noise_cov[0]; *o++ = (double)c.initializer_keyframe_num; *o++ = c.parsac_flag ? 1.0 : 0.0;
+        return 0;
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
+}

@@ -6,13 +6,13 @@ OUT="$HERE/../lib"
 mkdir -p "$OUT" "$HERE/_obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -I$HERE/../../include"
-SRCS=$(ls "$HERE"/*.hip)
+SRCS="$(ls "$HERE"/*.hip) $(ls "$HERE"/host/*.cpp)"
 OBJS=""
 pids=()
 for s in $SRCS; do
-  o="$HERE/_obj/$(basename "$s" .hip).o"
+  b="$(basename "$s")"; o="$HERE/_obj/${b%.*}.o"
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ -n "$(find "$HERE" "$HERE/../../include" -maxdepth 1 \( -name '*.h' -o -name '*.hpp' -o -name "$(basename "$s")" \) -newer "$o" | head -1)" ]; then
+  if [ ! -f "$o" ] || [ -n "$(find "$HERE" "$HERE/../../include" "$HERE/host" -maxdepth 1 \( -name '*.h' -o -name '*.hpp' -o -name "$(basename "$s")" \) -newer "$o" | head -1)" ]; then
     $HIPCC $FLAGS "$@" -c "$s" -o "$o" &
     pids+=($!)
   fi

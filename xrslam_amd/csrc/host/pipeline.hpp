@@ -1,0 +1,1119 @@
+// pipeline.hpp -- per-frame orchestration of the hot path on top of the HIP C ABI.
+//
+// Host-side mirror of the reference's core/ layer (file:line under /root/reference/xrslam/src/xrslam):
+//   XRSLAM::Detail (IMU/camera sync, pose propagation)   core/detail.cpp:15-177
+//   FeatureTracker::work                                  core/feature_tracker.cpp:24-153
+//   Frame::detect_keypoints / track_keypoints             map/frame.cpp:55-174
+//   FrontendWorker::work                                  core/frontend_worker.cpp:28-86
+//   SlidingWindowTracker (mirror_frame, localize_newframe, manage_keyframe, track_landmark,
+//     refine_window, slide_window, refine_subwindow)      core/sliding_window_tracker.cpp:19-474
+//   Map::marginalize_frame                                map/map.cpp:51-63
+//   Solver facade (problem assembly)                      estimation/solver.cpp:84-173
+// PC semantics: threading off, every worker runs inline in the caller.
+// All arithmetic of the hot path is delegated to xrhip_* (KLT, pre-integration, BA, marginalisation).
+// The Initializer (SfM + visual-inertial alignment) is out of scope: the
+// window is bootstrapped from externally supplied initial states (BootstrapInitializer).
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <optional>
+#include <stdexcept>
+#include <tuple>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "../host_select.hpp"
+#include "config.hpp"
+#include "map.hpp"
+
+namespace xrh {
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string &m) : std::runtime_error(m) {}
+};
+inline void hip_check(int rc, const char *what) {
+    if (rc != 0) throw HipError(std::string(what) + ": " + xrhip_last_error());
+}
+
+struct StageTimes {   // seconds, accumulated (inspection slots feature_tracker_time / bundle_adjustor_* of the reference)
+    double tracker = 0, localize = 0, refine = 0, marginalize = 0, preintegrate = 0;
+    long frames = 0, solves = 0, solve_iterations = 0, marginalizations = 0, keyframes = 0;
+    double ba_device_ms = 0;
+};
+
+struct Pipeline {
+    Config config;
+    xrhip_klt *klt = nullptr;
+    xrhip_ba *ba = nullptr;
+    IdSource ids;
+    std::vector<xrhip_image *> image_pool;
+    double noise36[36];
+    StageTimes times;
+
+    explicit Pipeline(const Config &c) : config(c) {
+        hip_check(xrhip_klt_create((int)c.cam_resolution[0], (int)c.cam_resolution[1],
+                                   (int)c.feature_tracker_max_keypoint_detection, &klt),
+                  "xrhip_klt_create");
+        hip_check(xrhip_ba_create(32, 2048, 16384, &ba), "xrhip_ba_create");
+        for (int i = 0; i < 9; ++i) {
+            noise36[i] = c.cov_g[i];
+            noise36[9 + i] = c.cov_a[i];
+            noise36[18 + i] = c.cov_bg[i];
+            noise36[27 + i] = c.cov_ba[i];
+        }
+    }
+    ~Pipeline() {
+        for (xrhip_image *im : image_pool) xrhip_image_destroy(im);
+        if (ba) xrhip_ba_destroy(ba);
+        if (klt) xrhip_klt_destroy(klt);
+    }
+    xrhip_image *acquire_image() {
+        if (!image_pool.empty()) {
+            xrhip_image *im = image_pool.back();
+            image_pool.pop_back();
+            return im;
+        }
+        xrhip_image *im = nullptr;
+        hip_check(xrhip_image_create(klt, &im), "xrhip_image_create");
+        return im;
+    }
+    void recycle_image(xrhip_image *im) {
+        xrhip_image_release(im);
+        image_pool.push_back(im);
+    }
+    std::shared_ptr<HipImage> make_image(const uint8_t *gray, int stride, double t, bool device_ptr) {
+        auto img = std::make_shared<HipImage>();
+        img->owner = this;
+        img->h = acquire_image();
+        img->t = t;
+        img->w = (int)config.cam_resolution[0];
+        img->hgt = (int)config.cam_resolution[1];
+        if (device_ptr) hip_check(xrhip_image_upload_device(img->h, gray, stride), "xrhip_image_upload_device");
+        else hip_check(xrhip_image_upload(img->h, gray, stride), "xrhip_image_upload");
+        return img;
+    }
+    // PreIntegrator::integrate (preintegrator.cpp:78-95) on the device
+    bool integrate(PreInt &pre, double t, const V3 &bg, const V3 &ba_, bool jac, bool cov) {
+        if (pre.data.empty()) return false;
+        std::vector<double> smp(pre.data.size() * 7);
+        for (size_t i = 0; i < pre.data.size(); ++i) {
+            const ImuData &d = pre.data[i];
+            double *s = &smp[7 * i];
+            s[0] = d.t;
+            s[1] = d.w.x; s[2] = d.w.y; s[3] = d.w.z;
+            s[4] = d.a.x; s[5] = d.a.y; s[6] = d.a.z;
+        }
+        const double b1[3] = {bg.x, bg.y, bg.z}, b2[3] = {ba_.x, ba_.y, ba_.z};
+        hip_check(xrhip_ba_preintegrate(ba, smp.data(), (int)pre.data.size(), t, b1, b2, noise36, jac, cov, pre.rec),
+                  "xrhip_ba_preintegrate");
+        pre.valid = true;
+        return true;
+    }
+};
+
+inline HipImage::~HipImage() {
+    if (h && owner) owner->recycle_image(h);
+    h = nullptr;
+}
+inline void HipImage::release_image_buffer() {
+    if (h && owner) owner->recycle_image(h);
+    h = nullptr;
+}
+
+// PreIntegrator::predict (preintegrator.cpp:102-112)
+inline void predict(const PreInt &pre, const Frame *o, Frame *n) {
+    const V3 gravity{0, 0, -9.80665};
+    const double dt = pre.dt();
+    n->motion.bg = o->motion.bg;
+    n->motion.ba = o->motion.ba;
+    n->motion.v = o->motion.v + gravity * dt + o->pose.q * pre.dv();
+    n->pose.p = o->pose.p + 0.5 * gravity * dt * dt + o->motion.v * dt + o->pose.q * pre.dp();
+    n->pose.q = o->pose.q * pre.dq();
+}
+
+// ------------------------------------------------------------------------------------- Frame ops
+inline void frame_detect_keypoints(Pipeline &P, Frame *f) {   // frame.cpp:55-72 + opencv_image.cpp:38-73
+    const Config &c = P.config;
+    std::vector<double> existing(2 * f->keypoint_num());
+    for (size_t i = 0; i < f->keypoint_num(); ++i) {
+        V2 px = apply_k(f->bearings[i], f->K);
+        existing[2 * i] = px.x;
+        existing[2 * i + 1] = px.y;
+    }
+    const int maxp = (int)c.feature_tracker_max_keypoint_detection;
+    std::vector<double> fresh(2 * (size_t)std::max(maxp, 1));
+    int n_new = 0;
+    hip_check(xrhip_image_detect(f->image->h, existing.data(), (int)f->keypoint_num(), maxp,
+                                 c.feature_tracker_min_keypoint_distance, fresh.data(), &n_new),
+              "xrhip_image_detect");
+    for (int i = 0; i < n_new; ++i) f->append_keypoint(remove_k(V2{fresh[2 * i], fresh[2 * i + 1]}, f->K));
+}
+
+inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // frame.cpp:74-174
+    const Config &c = P.config;
+    const size_t n = cur->keypoint_num();
+    std::vector<double> curr_px(2 * n), next_px(2 * n);
+    for (size_t i = 0; i < n; ++i) {
+        V2 px = apply_k(cur->bearings[i], cur->K);
+        curr_px[2 * i] = px.x;
+        curr_px[2 * i + 1] = px.y;
+    }
+    int has_guess = 0;
+    if (c.feature_tracker_predict_keypoints) {
+        Quat dq = (cur->camera.q_cs.conjugate() * cur->imu.q_cs * next->preintegration.dq() *
+                   next->imu.q_cs.conjugate() * next->camera.q_cs)
+                      .conjugate();
+        for (size_t i = 0; i < n; ++i) {
+            V2 px = apply_k(dq * cur->bearings[i], next->K);
+            next_px[2 * i] = px.x;
+            next_px[2 * i + 1] = px.y;
+        }
+        has_guess = 1;
+    }
+    std::vector<uint8_t> st8(std::max<size_t>(n, 1), 0);
+    hip_check(xrhip_image_track(cur->image->h, next->image->h, curr_px.data(), next_px.data(), has_guess, st8.data(),
+                                (int)n),
+              "xrhip_image_track");
+    std::vector<char> status(st8.begin(), st8.begin() + n), mask;
+    std::vector<V2> cur_h, next_h;
+    std::vector<V3> next_bearings;
+    for (size_t i = 0; i < n; ++i) {
+        const V3 &b = cur->bearings[i];
+        cur_h.push_back({b.x / b.z, b.y / b.z});
+        V3 nb = remove_k(V2{next_px[2 * i], next_px[2 * i + 1]}, next->K);
+        next_h.push_back({nb.x / nb.z, nb.y / nb.z});
+        next_bearings.push_back(nb);
+    }
+    find_essential_matrix(cur_h, next_h, mask, 1.0);
+    for (size_t i = 0; i < status.size() && i < mask.size(); ++i)
+        if (!mask[i]) status[i] = 0;
+    M3 R = find_rotation_matrix(cur->bearings, next_bearings, mask, (M_PI / 180.0) * c.rotation_ransac_threshold);
+    std::vector<double> angles;
+    for (size_t i = 0; i < mask.size(); ++i)
+        if (mask[i]) angles.push_back(std::acos(dot(R * cur->bearings[i], next_bearings[i])) * 180 / M_PI);
+    std::sort(angles.begin(), angles.end());
+    double misalignment = angles.size() > 0 ? angles[angles.size() * 7 / 10] : 0;
+    if (misalignment < c.rotation_misalignment_threshold) next->tag(FT_NO_TRANSLATION) = true;
+
+    std::vector<std::pair<size_t, size_t>> by_length;
+    by_length.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (status[i] == 0) continue;
+        Track *t = cur->get_track(i);
+        if (t == nullptr) continue;
+        by_length.emplace_back(i, t->keypoint_num());
+    }
+    std::sort(by_length.begin(), by_length.end(), [](const auto &a, const auto &b) { return a.second > b.second; });
+    xrhip::PoissonDisk2 filter(c.feature_tracker_min_keypoint_distance);
+    for (auto &[ki, len] : by_length) {
+        (void)len;
+        Track *t = cur->get_track(ki);
+        if (filter.permit(next_px[2 * ki], next_px[2 * ki + 1]) && (!t || !t->tag(TT_TRASH))) {
+            filter.preset(next_px[2 * ki], next_px[2 * ki + 1]);
+        } else {
+            status[ki] = 0;
+        }
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (status[i]) {
+            size_t nk = next->keypoint_num();
+            next->append_keypoint(next_bearings[i]);
+            cur->get_track(i, nullptr)->add_keypoint(next, nk);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- BA problem assembly
+// Collects frames / tracks the way Solver::add_frame_states / add_track_states / add_factor do and
+// runs xrhip_ba_solve; states are written back in place.
+class BaBuilder {
+  public:
+    explicit BaBuilder(Pipeline &P) : P_(P) {}
+    int frame_index(Frame *f, bool as_parameter, bool with_motion = true) {
+        auto it = fidx_.find(f);
+        if (it == fidx_.end()) {
+            int i = (int)frames_.size();
+            fidx_[f] = i;
+            frames_.push_back(f);
+            fix_.push_back(XRHIP_FIX_POSE | XRHIP_FIX_MOTION);
+            it = fidx_.find(f);
+        }
+        if (as_parameter) {
+            uint8_t fx = 0;
+            if (f->tag(FT_FIX_POSE)) fx |= XRHIP_FIX_POSE;
+            if (!with_motion || f->tag(FT_FIX_MOTION)) fx |= XRHIP_FIX_MOTION;
+            fix_[it->second] = fx;
+        }
+        return it->second;
+    }
+    void add_frame_states(Frame *f, bool with_motion = true) { frame_index(f, true, with_motion); }
+    int landmark_index(Track *t, bool as_parameter) {
+        auto it = lidx_.find(t);
+        if (it == lidx_.end()) {
+            int i = (int)tracks_.size();
+            lidx_[t] = i;
+            tracks_.push_back(t);
+            lfix_.push_back(1);
+            it = lidx_.find(t);
+        }
+        if (as_parameter) lfix_[it->second] = 0;
+        return it->second;
+    }
+    void add_track_states(Track *t) { landmark_index(t, true); }
+    // ReprojectionErrorFactor (parameters: tgt pose, ref pose, inverse depth)
+    void add_reprojection_error(Frame *frame, size_t ki) {
+        Track *t = frame->get_track(ki);
+        auto [ref, kr] = t->first_keypoint();
+        push_obs(frame_index(frame, false), frame_index(ref, false), landmark_index(t, false), frame->get_keypoint(ki),
+                 ref->get_keypoint(kr));
+    }
+    // ReprojectionPriorFactor: ref pose and depth are constants whatever their flags
+    void add_reprojection_prior(Frame *frame, size_t ki) {
+        Track *t = frame->get_track(ki);
+        auto [ref, kr] = t->first_keypoint();
+        // constants are represented by dedicated constant copies so that a frame/track that is also a
+        // parameter elsewhere in the problem is still read as a constant here
+        push_obs(frame_index(frame, false), const_frame(ref), const_landmark(t), frame->get_keypoint(ki),
+                 ref->get_keypoint(kr));
+    }
+    void add_rotation_prior(Frame *frame, size_t ki) {
+        Track *t = frame->get_track(ki);
+        auto [ref, kr] = t->first_keypoint();
+        rot_tgt_.push_back(frame_index(frame, false));
+        rot_ref_.push_back(const_frame(ref));
+        push3(rot_zt_, frame->get_keypoint(ki));
+        push3(rot_zr_, ref->get_keypoint(kr));
+    }
+    void add_preintegration_error(Frame *fi, Frame *fj, const PreInt &pre) {
+        imu_i_.push_back(frame_index(fi, false));
+        imu_j_.push_back(frame_index(fj, false));
+        imu_data_.insert(imu_data_.end(), pre.rec, pre.rec + XRHIP_IMU_DIM);
+    }
+    void add_preintegration_prior(Frame *fi, Frame *fj, const PreInt &pre) {
+        imu_i_.push_back(const_frame(fi));
+        imu_j_.push_back(frame_index(fj, false));
+        imu_data_.insert(imu_data_.end(), pre.rec, pre.rec + XRHIP_IMU_DIM);
+    }
+    void add_marginalization(MargPrior *m) { prior_ = m; }
+
+    bool solve(double *elapsed_device_ms = nullptr) {
+        const Config &c = P_.config;
+        const int F = (int)frames_.size(), L = (int)tracks_.size();
+        std::vector<double> state(16 * (size_t)F), depth(std::max(L, 1));
+        for (int f = 0; f < F; ++f) pack_state(frames_[f], &state[16 * (size_t)f]);
+        for (int l = 0; l < L; ++l) depth[l] = tracks_[l]->landmark.inv_depth;
+        xrhip_ba_problem pb;
+        std::memset(&pb, 0, sizeof(pb));
+        pb.n_frames = F;
+        pb.frame_state = state.data();
+        pb.frame_fix = fix_.data();
+        Frame *any = frames_[0];
+        const Quat &qc = any->camera.q_cs, &qi = any->imu.q_cs;
+        const double cq[4] = {qc.x, qc.y, qc.z, qc.w}, iq[4] = {qi.x, qi.y, qi.z, qi.w};
+        std::memcpy(pb.cam_q_bc, cq, sizeof(cq));
+        std::memcpy(pb.imu_q_bi, iq, sizeof(iq));
+        for (int k = 0; k < 3; ++k) {
+            pb.cam_p_bc[k] = any->camera.p_cs[k];
+            pb.imu_p_bi[k] = any->imu.p_cs[k];
+        }
+        pb.sqrt_inv_cov[0] = any->sqrt_inv_cov[0];
+        pb.sqrt_inv_cov[1] = any->sqrt_inv_cov[1];
+        pb.n_landmarks = L;
+        pb.inv_depth = depth.data();
+        pb.landmark_fix = lfix_.data();
+        pb.n_obs = (int)obs_tgt_.size();
+        pb.obs_tgt = obs_tgt_.data();
+        pb.obs_ref = obs_ref_.data();
+        pb.obs_lm = obs_lm_.data();
+        pb.obs_z_tgt = obs_zt_.data();
+        pb.obs_z_ref = obs_zr_.data();
+        pb.n_rot = (int)rot_tgt_.size();
+        pb.rot_tgt = rot_tgt_.data();
+        pb.rot_ref = rot_ref_.data();
+        pb.rot_z_tgt = rot_zt_.data();
+        pb.rot_z_ref = rot_zr_.data();
+        pb.n_imu = (int)imu_i_.size();
+        pb.imu_i = imu_i_.data();
+        pb.imu_j = imu_j_.data();
+        pb.imu_data = imu_data_.data();
+        std::vector<int> pframes;
+        if (prior_) {
+            for (Frame *f : prior_->frames) pframes.push_back(frame_index(f, false));
+            // frame_index may have appended constant frames: refresh the arrays that depend on F
+            if ((int)frames_.size() != F) throw std::logic_error("prior frame is not part of the problem");
+            pb.prior_n = (int)pframes.size();
+            pb.prior_frames = pframes.data();
+            pb.prior_sqrt_info = prior_->sqrt_info.data();
+            pb.prior_infovec = prior_->infovec.data();
+            pb.prior_lin = prior_->lin.data();
+        }
+        pb.max_iterations = (int)c.solver_iteration_limit;
+        xrhip_ba_summary sm;
+        hip_check(xrhip_ba_solve(P_.ba, &pb, &sm), "xrhip_ba_solve");
+        for (int f = 0; f < F; ++f)
+            if (fix_[f] != (XRHIP_FIX_POSE | XRHIP_FIX_MOTION)) unpack_state(&state[16 * (size_t)f], frames_[f], fix_[f]);
+        for (int l = 0; l < L; ++l)
+            if (!lfix_[l]) tracks_[l]->landmark.inv_depth = depth[l];
+        P_.times.solves++;
+        P_.times.solve_iterations += sm.iterations;
+        P_.times.ba_device_ms += sm.ms_solve;
+        if (elapsed_device_ms) *elapsed_device_ms = sm.ms_solve;
+        return sm.usable != 0;
+    }
+
+    static void pack_state(const Frame *f, double *s) {
+        s[0] = f->pose.q.x; s[1] = f->pose.q.y; s[2] = f->pose.q.z; s[3] = f->pose.q.w;
+        for (int k = 0; k < 3; ++k) {
+            s[4 + k] = f->pose.p[k];
+            s[7 + k] = f->motion.v[k];
+            s[10 + k] = f->motion.bg[k];
+            s[13 + k] = f->motion.ba[k];
+        }
+    }
+    static void unpack_state(const double *s, Frame *f, uint8_t fix) {
+        if (!(fix & XRHIP_FIX_POSE)) {
+            f->pose.q = Quat{s[0], s[1], s[2], s[3]};
+            f->pose.p = {s[4], s[5], s[6]};
+        }
+        if (!(fix & XRHIP_FIX_MOTION)) {
+            f->motion.v = {s[7], s[8], s[9]};
+            f->motion.bg = {s[10], s[11], s[12]};
+            f->motion.ba = {s[13], s[14], s[15]};
+        }
+    }
+
+  private:
+    // A constant copy is only needed when the object is ALSO a parameter of this problem; the solves the
+    // reference assembles never mix the two roles for the same frame/track, so the plain entry is shared and
+    // simply never promoted to a parameter by this call.
+    int const_frame(Frame *f) { return frame_index(f, false); }
+    int const_landmark(Track *t) { return landmark_index(t, false); }
+    void push3(std::vector<double> &v, const V3 &a) {
+        v.push_back(a.x);
+        v.push_back(a.y);
+        v.push_back(a.z);
+    }
+    void push_obs(int ft, int fr, int l, const V3 &zt, const V3 &zr) {
+        obs_tgt_.push_back(ft);
+        obs_ref_.push_back(fr);
+        obs_lm_.push_back(l);
+        push3(obs_zt_, zt);
+        push3(obs_zr_, zr);
+    }
+    Pipeline &P_;
+    std::unordered_map<Frame *, int> fidx_;
+    std::unordered_map<Track *, int> lidx_;
+    std::vector<Frame *> frames_;
+    std::vector<Track *> tracks_;
+    std::vector<uint8_t> fix_, lfix_;
+    std::vector<int> obs_tgt_, obs_ref_, obs_lm_, rot_tgt_, rot_ref_, imu_i_, imu_j_;
+    std::vector<double> obs_zt_, obs_zr_, rot_zt_, rot_zr_, imu_data_;
+    MargPrior *prior_ = nullptr;
+};
+
+// MarginalizationFactor ctor (estimation/marginalization_factor.h:18-33): gauge prior on the first pose
+inline std::unique_ptr<MargPrior> create_marginalization_factor(Map *map) {
+    auto m = std::make_unique<MargPrior>();
+    const size_t n = map->frame_num() - 1;
+    m->frames.resize(n);
+    m->lin.assign(16 * n, 0.0);
+    for (size_t i = 0; i < n; ++i) {
+        m->frames[i] = map->get_frame(i);
+        BaBuilder::pack_state(map->get_frame(i), &m->lin[16 * i]);
+    }
+    m->infovec.assign(15 * n, 0.0);
+    m->sqrt_info.assign(15 * n * 15 * n, 0.0);
+    for (int k = 0; k < 6; ++k) m->sqrt_info[(size_t)k * 15 * n + k] = 1.0e15;
+    return m;
+}
+
+// CeresMarginalizationFactor::marginalize (ceres/marginalization_factor.h:74-475) via xrhip_ba_marginalize
+inline void marginalize_frame(Pipeline &P, Map *map, size_t index) {   // Map::marginalize_frame (map.cpp:51-63)
+    MargPrior *prior = map->marginalization_factor.get();
+    if (!prior) throw std::logic_error("marginalization_factor is not initialized yet");
+    const int K = (int)map->frame_num();
+    std::unordered_map<Frame *, int> fidx;
+    std::vector<double> state(16 * (size_t)K);
+    for (int i = 0; i < K; ++i) {
+        fidx[map->get_frame(i)] = i;
+        BaBuilder::pack_state(map->get_frame(i), &state[16 * (size_t)i]);
+    }
+    xrhip_marg_problem mp;
+    std::memset(&mp, 0, sizeof(mp));
+    mp.n_frames = K;
+    mp.victim = (int)index;
+    mp.frame_state = state.data();
+    Frame *any = map->get_frame(0);
+    const Quat &qc = any->camera.q_cs, &qi = any->imu.q_cs;
+    const double cq[4] = {qc.x, qc.y, qc.z, qc.w}, iq[4] = {qi.x, qi.y, qi.z, qi.w};
+    std::memcpy(mp.cam_q_bc, cq, sizeof(cq));
+    std::memcpy(mp.imu_q_bi, iq, sizeof(iq));
+    for (int k = 0; k < 3; ++k) {
+        mp.cam_p_bc[k] = any->camera.p_cs[k];
+        mp.imu_p_bi[k] = any->imu.p_cs[k];
+    }
+    mp.sqrt_inv_cov[0] = any->sqrt_inv_cov[0];
+    mp.sqrt_inv_cov[1] = any->sqrt_inv_cov[1];
+    std::vector<int> pframes;
+    for (Frame *f : prior->frames) pframes.push_back(fidx.at(f));
+    mp.prior_n = (int)pframes.size();
+    mp.prior_frames = pframes.data();
+    mp.prior_sqrt_info = prior->sqrt_info.data();
+    mp.prior_infovec = prior->infovec.data();
+    mp.prior_lin = prior->lin.data();
+    std::vector<int> imu_i, imu_j;
+    std::vector<double> imu_data;
+    for (size_t j = index; j <= index + 1; ++j) {
+        if (j == 0 || j >= (size_t)K) continue;
+        Frame *fj = map->get_frame(j);
+        imu_i.push_back((int)j - 1);
+        imu_j.push_back((int)j);
+        imu_data.insert(imu_data.end(), fj->keyframe_preintegration.rec, fj->keyframe_preintegration.rec + XRHIP_IMU_DIM);
+    }
+    mp.n_imu = (int)imu_i.size();
+    mp.imu_i = imu_i.data();
+    mp.imu_j = imu_j.data();
+    mp.imu_data = imu_data.data();
+    std::vector<int> ot, orf, ol;
+    std::vector<double> zt, zr, depth;
+    Frame *victim = map->get_frame(index);
+    for (size_t j = 0; j < victim->keypoint_num(); ++j) {
+        Track *track = victim->get_track(j);
+        if (!track || !track->tag(TT_VALID)) continue;
+        Frame *ref = track->first_frame();
+        if (!ref->tag(FT_KEYFRAME)) continue;
+        const int fr = fidx.at(ref);   // the reference indexes frame_indices.at(frame_ref) unconditionally
+        const size_t kr = track->keypoint_refs.at(ref);
+        int l = -1;
+        for (const auto &[tgt, ki] : track->keypoint_refs) {
+            if (tgt == ref) continue;
+            auto it = fidx.find(tgt);
+            if (it == fidx.end()) continue;
+            if (l < 0) {
+                l = (int)depth.size();
+                depth.push_back(track->landmark.inv_depth);
+            }
+            ot.push_back(it->second);
+            orf.push_back(fr);
+            ol.push_back(l);
+            const V3 &a = tgt->get_keypoint(ki), &b = ref->get_keypoint(kr);
+            zt.insert(zt.end(), {a.x, a.y, a.z});
+            zr.insert(zr.end(), {b.x, b.y, b.z});
+        }
+    }
+    mp.n_landmarks = (int)depth.size();
+    mp.inv_depth = depth.data();
+    mp.n_obs = (int)ot.size();
+    mp.obs_tgt = ot.data();
+    mp.obs_ref = orf.data();
+    mp.obs_lm = ol.data();
+    mp.obs_z_tgt = zt.data();
+    mp.obs_z_ref = zr.data();
+    const size_t R = 15 * (size_t)(K - 1);
+    std::vector<double> si(R * R), iv(R), lin(16 * (size_t)(K - 1));
+    hip_check(xrhip_ba_marginalize(P.ba, &mp, si.data(), iv.data(), lin.data()), "xrhip_ba_marginalize");
+    prior->sqrt_info.swap(si);
+    prior->infovec.swap(iv);
+    prior->lin.swap(lin);
+    prior->frames.clear();
+    for (int i = 0; i < K; ++i)
+        if ((size_t)i != index) prior->frames.push_back(map->get_frame(i));
+    // Map::marginalize_frame tail
+    for (size_t i = 0; i < victim->keypoint_num(); ++i)
+        if (Track *t = victim->get_track(i)) t->remove_keypoint(victim);
+    map->frames.erase(map->frames.begin() + index);
+    P.times.marginalizations++;
+}
+
+using LatestState = std::tuple<double, PoseState, MotionState>;
+
+// ------------------------------------------------------------------------- SlidingWindowTracker
+class SlidingWindowTracker {
+  public:
+    SlidingWindowTracker(Pipeline &P, std::unique_ptr<Map> keyframe_map) : P_(P), map(std::move(keyframe_map)) {
+        for (size_t j = 1; j < map->frame_num(); ++j) {
+            Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
+            P_.integrate(fj->preintegration, fj->image->t, fi->motion.bg, fi->motion.ba, true, true);
+        }
+    }
+
+    void mirror_frame(Map *ft_map, size_t frame_id) {   // sliding_window_tracker.cpp:31-80
+        Frame *keyframe = map->get_frame(map->frame_num() - 1);
+        Frame *new_i = keyframe;
+        if (!keyframe->subframes.empty()) new_i = keyframe->subframes.back().get();
+        size_t idx_i = ft_map->frame_index_by_id(new_i->id), idx_j = ft_map->frame_index_by_id(frame_id);
+        if (idx_i == nil() || idx_j == nil()) return;
+        Frame *old_i = ft_map->get_frame(idx_i), *old_j = ft_map->get_frame(idx_j);
+        std::unique_ptr<Frame> curr = old_j->clone();
+        std::vector<ImuData> &nd = curr->preintegration.data;
+        for (size_t index = idx_j - 1; index > idx_i; --index) {
+            const std::vector<ImuData> &od = ft_map->get_frame(index)->preintegration.data;
+            nd.insert(nd.begin(), od.begin(), od.end());
+        }
+        map->attach_frame(curr->clone());
+        Frame *new_j = map->get_frame(map->frame_num() - 1);
+        for (size_t ki = 0; ki < old_i->keypoint_num(); ++ki) {
+            if (Track *track = old_i->get_track(ki)) {
+                size_t kj = track->get_keypoint_index(old_j);
+                if (kj != nil()) {
+                    Track *nt = new_i->get_track(ki, map.get());
+                    nt->add_keypoint(new_j, kj);
+                    track->tag(TT_TRASH) = nt->tag(TT_TRASH) && !nt->tag(TT_STATIC);
+                }
+            }
+        }
+        map->prune_tracks([](const Track *t) { return t->tag(TT_TRASH) && !t->tag(TT_STATIC); });
+        P_.integrate(new_j->preintegration, new_j->image->t, new_i->motion.bg, new_i->motion.ba, true, true);
+        predict(new_j->preintegration, new_i, new_j);
+    }
+
+    bool track() {   // :82-117 (parsac_flag is false)
+        localize_newframe();
+        if (manage_keyframe()) {
+            P_.times.keyframes++;
+            track_landmark();
+            refine_window();
+            slide_window();
+        } else {
+            refine_subwindow();
+        }
+        return true;
+    }
+
+    void localize_newframe() {   // :119-143
+        BaBuilder b(P_);
+        Frame *fi = map->get_frame(map->frame_num() - 2);
+        if (!fi->subframes.empty()) fi = fi->subframes.back().get();
+        Frame *fj = map->get_frame(map->frame_num() - 1);
+        b.add_frame_states(fj);
+        b.add_preintegration_prior(fi, fj, fj->preintegration);
+        for (size_t k = 0; k < fj->keypoint_num(); ++k)
+            if (Track *t = fj->get_track(k))
+                if (t->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) b.add_reprojection_prior(fj, k);
+        b.solve();
+    }
+
+    bool manage_keyframe() {   // :145-223
+        const Config &c = P_.config;
+        Frame *kf_i = map->get_frame(map->frame_num() - 2);
+        Frame *nf_j = map->get_frame(map->frame_num() - 1);
+        if (!kf_i->subframes.empty()) {
+            if (kf_i->subframes.back()->tag(FT_NO_TRANSLATION)) {
+                if (nf_j->tag(FT_NO_TRANSLATION)) {
+                    // fall through to the landmark count
+                } else {
+                    kf_i->subframes.back()->tag(FT_KEYFRAME) = true;
+                    map->attach_frame(std::move(kf_i->subframes.back()), map->frame_num() - 1);
+                    kf_i->subframes.pop_back();
+                    nf_j->tag(FT_KEYFRAME) = true;
+                    return true;
+                }
+            } else {
+                if (nf_j->tag(FT_NO_TRANSLATION)) {
+                    std::unique_ptr<Frame> lifted = std::move(kf_i->subframes.back());
+                    kf_i->subframes.pop_back();
+                    lifted->tag(FT_KEYFRAME) = true;
+                    lifted->subframes.emplace_back(map->detach_frame(map->frame_num() - 1));
+                    map->attach_frame(std::move(lifted));
+                    return true;
+                } else if (kf_i->subframes.size() >= c.sliding_window_subframe_size) {
+                    nf_j->tag(FT_KEYFRAME) = true;
+                    return true;
+                }
+            }
+        }
+        size_t mapped = 0;
+        for (size_t k = 0; k < nf_j->keypoint_num(); ++k)
+            if (Track *t = nf_j->get_track(k))
+                if (t->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) mapped++;
+        if (mapped < c.sliding_window_force_keyframe_landmarks) {
+            nf_j->tag(FT_KEYFRAME) = true;
+            return true;
+        }
+        kf_i->subframes.emplace_back(map->detach_frame(map->frame_num() - 1));
+        return false;
+    }
+
+    void track_landmark() {   // :225-245
+        Frame *nf = map->get_frame(map->frame_num() - 1);
+        for (size_t k = 0; k < nf->keypoint_num(); ++k) {
+            if (Track *t = nf->get_track(k)) {
+                if (!t->tag(TT_TRIANGULATED)) {
+                    if (auto p = t->triangulate()) {
+                        t->set_landmark_point(p.value());
+                        t->tag(TT_TRIANGULATED) = true;
+                        t->tag(TT_VALID) = true;
+                        t->tag(TT_STATIC) = true;
+                    } else {
+                        t->landmark.inv_depth = -1.0;
+                        t->tag(TT_TRIANGULATED) = false;
+                        t->tag(TT_VALID) = false;
+                    }
+                }
+            }
+        }
+    }
+
+    void refine_window() {   // :247-358
+        BaBuilder b(P_);
+        if (!map->marginalization_factor) map->marginalization_factor = create_marginalization_factor(map.get());
+        for (size_t i = 0; i < map->frame_num(); ++i) b.add_frame_states(map->get_frame(i));
+        std::unordered_set<Track *> visited;
+        for (size_t i = 0; i < map->frame_num(); ++i) {
+            Frame *f = map->get_frame(i);
+            for (size_t j = 0; j < f->keypoint_num(); ++j) {
+                Track *t = f->get_track(j);
+                if (!t || visited.count(t)) continue;
+                visited.insert(t);
+                if (!t->tag(TT_VALID) || !t->tag(TT_STATIC)) continue;
+                if (!t->first_frame()->tag(FT_KEYFRAME)) continue;
+                b.add_track_states(t);
+            }
+        }
+        b.add_marginalization(map->marginalization_factor.get());
+        for (size_t i = 0; i < map->frame_num(); ++i) {
+            Frame *f = map->get_frame(i);
+            for (size_t j = 0; j < f->keypoint_num(); ++j) {
+                Track *t = f->get_track(j);
+                if (!t || !t->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) continue;
+                if (!t->first_frame()->tag(FT_KEYFRAME)) continue;
+                if (f == t->first_frame()) continue;
+                b.add_reprojection_error(f, j);
+            }
+        }
+        for (size_t j = 1; j < map->frame_num(); ++j) {
+            Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
+            fj->keyframe_preintegration = fj->preintegration;
+            if (!fi->subframes.empty()) {
+                std::vector<ImuData> extra;
+                for (auto &sf : fi->subframes) extra.insert(extra.end(), sf->preintegration.data.begin(), sf->preintegration.data.end());
+                fj->keyframe_preintegration.data.insert(fj->keyframe_preintegration.data.begin(), extra.begin(), extra.end());
+            }
+            if (P_.integrate(fj->keyframe_preintegration, fj->image->t, fi->motion.bg, fi->motion.ba, true, true))
+                b.add_preintegration_error(fi, fj, fj->keyframe_preintegration);
+        }
+        b.solve();
+        for (size_t k = 0; k < map->track_num(); ++k) {
+            Track *t = map->get_track(k);
+            if (t->tag(TT_TRIANGULATED)) {
+                bool valid = true;
+                V3 x = t->get_landmark_point();
+                double rpe = 0.0, cnt = 0.0;
+                for (const auto &[f, ki] : t->keypoint_refs) {
+                    if (!f->tag(FT_KEYFRAME)) continue;
+                    PoseState pose = f->get_pose(f->camera);
+                    V3 y = pose.q.conjugate() * (x - pose.p);
+                    if (y.z <= 1.0e-3 || y.z > 50) {
+                        valid = false;
+                        break;
+                    }
+                    V2 a = apply_k(y, f->K), bb = apply_k(f->get_keypoint(ki), f->K);
+                    rpe += std::sqrt((a.x - bb.x) * (a.x - bb.x) + (a.y - bb.y) * (a.y - bb.y));
+                    cnt += 1.0;
+                }
+                valid = valid && (rpe / std::max(cnt, 1.0) < 3.0);
+                t->tag(TT_VALID) = valid;
+            } else {
+                t->landmark.inv_depth = -1.0;
+            }
+        }
+        for (size_t k = 0; k < map->track_num(); ++k) {
+            Track *t = map->get_track(k);
+            if (!t->tag(TT_VALID)) t->tag(TT_TRASH) = true;
+        }
+    }
+
+    void slide_window() {   // :360-368
+        while (map->frame_num() > P_.config.sliding_window_size) {
+            Frame *f = map->get_frame(0);
+            for (auto &sf : f->subframes) map->untrack_frame(sf.get());
+            marginalize_frame(P_, map.get(), 0);
+        }
+    }
+
+    void refine_subwindow() {   // :370-465
+        Frame *frame = map->get_frame(map->frame_num() - 1);
+        if (frame->subframes.empty()) return;
+        if (frame->subframes[0]->tag(FT_NO_TRANSLATION)) {
+            if (frame->subframes.size() >= 9) {
+                for (size_t i = frame->subframes.size() / 3; i > 0; --i) {
+                    Frame *tgt = frame->subframes[i * 3 - 1].get();
+                    std::vector<ImuData> imu;
+                    for (size_t j = i * 3 - 1; j > (i - 1) * 3; --j) {
+                        Frame *src = frame->subframes[j - 1].get();
+                        imu.insert(imu.begin(), src->preintegration.data.begin(), src->preintegration.data.end());
+                        map->untrack_frame(src);
+                        frame->subframes.erase(frame->subframes.begin() + (j - 1));
+                    }
+                    tgt->preintegration.data.insert(tgt->preintegration.data.begin(), imu.begin(), imu.end());
+                }
+            }
+            BaBuilder b(P_);
+            frame->tag(FT_FIX_POSE) = true;
+            frame->tag(FT_FIX_MOTION) = true;
+            b.add_frame_states(frame);
+            for (size_t i = 0; i < frame->subframes.size(); ++i) {
+                Frame *sf = frame->subframes[i].get();
+                b.add_frame_states(sf);
+                Frame *prev = (i == 0 ? frame : frame->subframes[i - 1].get());
+                P_.integrate(sf->preintegration, sf->image->t, prev->motion.bg, prev->motion.ba, true, true);
+                b.add_preintegration_error(prev, sf, sf->preintegration);
+            }
+            Frame *last = frame->subframes.back().get();
+            for (size_t k = 0; k < last->keypoint_num(); ++k) {
+                if (Track *t = last->get_track(k)) {
+                    if (t->tag(TT_VALID)) {
+                        if (t->tag(TT_TRIANGULATED)) {
+                            if (t->tag(TT_STATIC)) b.add_reprojection_prior(last, k);
+                        } else {
+                            b.add_rotation_prior(last, k);
+                        }
+                    }
+                }
+            }
+            b.solve();
+            frame->tag(FT_FIX_POSE) = false;
+            frame->tag(FT_FIX_MOTION) = false;
+        } else {
+            BaBuilder b(P_);
+            frame->tag(FT_FIX_POSE) = true;
+            frame->tag(FT_FIX_MOTION) = true;
+            b.add_frame_states(frame);
+            for (size_t i = 0; i < frame->subframes.size(); ++i) {
+                Frame *sf = frame->subframes[i].get();
+                b.add_frame_states(sf);
+                Frame *prev = (i == 0 ? frame : frame->subframes[i - 1].get());
+                P_.integrate(sf->preintegration, sf->image->t, prev->motion.bg, prev->motion.ba, true, true);
+                b.add_preintegration_error(prev, sf, sf->preintegration);
+                for (size_t k = 0; k < sf->keypoint_num(); ++k) {
+                    if (Track *t = sf->get_track(k)) {
+                        if (t->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) {
+                            if (t->first_frame()->tag(FT_KEYFRAME)) b.add_reprojection_prior(sf, k);
+                            // else-branch of the reference (:453-455) indexes the keyframe's factor array with the
+                            // subframe's keypoint index -- a latent bug; never taken on the
+                            // supported streams and skipped here.
+                        }
+                    }
+                }
+            }
+            b.solve();
+            frame->tag(FT_FIX_POSE) = false;
+            frame->tag(FT_FIX_MOTION) = false;
+        }
+    }
+
+    LatestState get_latest_state() const {
+        const Frame *f = map->get_frame(map->frame_num() - 1);
+        if (!f->subframes.empty()) f = f->subframes.back().get();
+        return {f->image->t, f->pose, f->motion};
+    }
+
+    Pipeline &P_;
+    std::unique_ptr<Map> map;
+};
+
+// ---------------------------------------------------------------------------- bootstrap initialiser
+// Stand-in for Initializer (core/initializer.cpp:22-571, out of scope): same keyframe mirroring
+// (:22-76) and the same final bundle adjustment / keyframe tagging as Initializer::initialize (:78-140),
+// but poses, velocities and biases come from externally supplied states instead of SfM + IMU alignment.
+struct InitialState {
+    double t;
+    PoseState pose;
+    MotionState motion;
+};
+
+class BootstrapInitializer {
+  public:
+    explicit BootstrapInitializer(Pipeline &P) : P_(P) {}
+    std::vector<InitialState> states;   // sorted by time
+
+    void mirror_keyframe_map(Map *ft_map, size_t init_frame_id) {
+        const Config &c = P_.config;
+        size_t last = ft_map->frame_index_by_id(init_frame_id);
+        size_t gap = c.initializer_keyframe_gap, dist = gap * (c.initializer_keyframe_num - 1);
+        map.reset();
+        if (last == nil() || last < dist) return;
+        size_t first = last - dist;
+        std::vector<size_t> idx;
+        for (size_t i = 0; i < c.initializer_keyframe_num; ++i) idx.push_back(first + i * gap);
+        map = std::make_unique<Map>(&P_.ids);
+        for (size_t i : idx) map->attach_frame(ft_map->get_frame(i)->clone());
+        for (size_t j = 1; j < map->frame_num(); ++j) {
+            Frame *oi = ft_map->get_frame(idx[j - 1]), *oj = ft_map->get_frame(idx[j]);
+            Frame *ni = map->get_frame(j - 1), *nj = map->get_frame(j);
+            for (size_t ki = 0; ki < oi->keypoint_num(); ++ki)
+                if (Track *t = oi->get_track(ki)) {
+                    size_t kj = t->get_keypoint_index(oj);
+                    if (kj != nil()) ni->get_track(ki, nullptr)->add_keypoint(nj, kj);
+                }
+            nj->preintegration.data.clear();
+            for (size_t f = idx[j - 1]; f < idx[j]; ++f) {
+                const auto &od = ft_map->get_frame(f + 1)->preintegration.data;
+                nj->preintegration.data.insert(nj->preintegration.data.end(), od.begin(), od.end());
+            }
+        }
+    }
+
+    const InitialState *lookup(double t) const {
+        const InitialState *best = nullptr;
+        for (const InitialState &s : states)
+            if (std::fabs(s.t - t) < 1e-4 && (!best || std::fabs(s.t - t) < std::fabs(best->t - t))) best = &s;
+        return best;
+    }
+
+    std::unique_ptr<SlidingWindowTracker> initialize() {
+        if (!map) return nullptr;
+        for (size_t i = 0; i < map->frame_num(); ++i) {
+            Frame *f = map->get_frame(i);
+            const InitialState *s = lookup(f->image->t);
+            if (!s) return nullptr;
+            f->pose = s->pose;
+            f->motion = s->motion;
+        }
+        size_t ok = 0;
+        for (size_t k = 0; k < map->track_num(); ++k) {
+            Track *t = map->get_track(k);
+            if (auto p = t->triangulate()) {
+                t->set_landmark_point(p.value());
+                t->tag(TT_TRIANGULATED) = true;
+                t->tag(TT_VALID) = true;
+                t->tag(TT_STATIC) = true;
+                ok++;
+            } else {
+                t->landmark.inv_depth = -1.0;
+                t->tag(TT_VALID) = false;
+            }
+        }
+        if (ok < P_.config.initializer_min_landmarks) return nullptr;
+        map->get_frame(0)->tag(FT_FIX_POSE) = true;
+        BaBuilder b(P_);
+        for (size_t i = 0; i < map->frame_num(); ++i) b.add_frame_states(map->get_frame(i));
+        std::unordered_set<Track *> visited;
+        for (size_t i = 0; i < map->frame_num(); ++i) {
+            Frame *f = map->get_frame(i);
+            for (size_t j = 0; j < f->keypoint_num(); ++j) {
+                Track *t = f->get_track(j);
+                if (!t || !t->tag(TT_VALID) || visited.count(t)) continue;
+                visited.insert(t);
+                b.add_track_states(t);
+            }
+        }
+        for (size_t i = 0; i < map->frame_num(); ++i) {
+            Frame *f = map->get_frame(i);
+            for (size_t j = 0; j < f->keypoint_num(); ++j) {
+                Track *t = f->get_track(j);
+                if (!t || !t->all_tagged({TT_VALID, TT_TRIANGULATED})) continue;
+                if (f == t->first_frame()) continue;
+                b.add_reprojection_error(f, j);
+            }
+        }
+        for (size_t j = 1; j < map->frame_num(); ++j) {
+            Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
+            if (P_.integrate(fj->preintegration, fj->image->t, fi->motion.bg, fi->motion.ba, true, true))
+                b.add_preintegration_error(fi, fj, fj->preintegration);
+        }
+        b.solve();
+        for (size_t i = 0; i < map->frame_num(); ++i) map->get_frame(i)->tag(FT_KEYFRAME) = true;
+        auto swt = std::make_unique<SlidingWindowTracker>(P_, std::move(map));
+        return swt;
+    }
+
+    Pipeline &P_;
+    std::unique_ptr<Map> map;
+};
+
+// ------------------------------------------------------------------------------------ the system
+enum SysState { SYS_INITIALIZING = 0, SYS_TRACKING, SYS_CRASH, SYS_UNKNOWN };
+
+class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no threads)
+  public:
+    explicit System(const Config &c) : P(c), ft_map(std::make_unique<Map>(&P.ids)), init(P) {}
+
+    // -------- Detail (core/detail.cpp:46-177)
+    PoseState track_gyroscope(double t, double x, double y, double z) {
+        if (!accelerometers.empty()) {
+            if (t < accelerometers.front().t) {
+                gyroscopes.clear();
+            } else {
+                while (!accelerometers.empty() && t >= accelerometers.front().t) {
+                    const auto acc = accelerometers.front();
+                    double lambda = (acc.t - gyroscopes[0].t) / (t - gyroscopes[0].t);
+                    V3 w = gyroscopes[0].w + lambda * (V3{x, y, z} - gyroscopes[0].w);
+                    track_imu({acc.t, w, acc.a});
+                    accelerometers.pop_front();
+                }
+                if (!accelerometers.empty())
+                    while (!gyroscopes.empty() && gyroscopes.front().t < t) gyroscopes.pop_front();
+            }
+        }
+        gyroscopes.push_back({t, {x, y, z}});
+        return predict_pose(t);
+    }
+    PoseState track_accelerometer(double t, double x, double y, double z) {
+        if (!gyroscopes.empty() && t >= gyroscopes.front().t) {
+            if (t > gyroscopes.back().t) {
+                while (gyroscopes.size() > 1) gyroscopes.pop_front();
+                accelerometers.push_back({t, {x, y, z}});
+            } else if (t == gyroscopes.back().t) {
+                while (gyroscopes.size() > 1) gyroscopes.pop_front();
+                track_imu({t, gyroscopes.front().w, {x, y, z}});
+            } else {
+                while (t >= gyroscopes[1].t) gyroscopes.pop_front();
+                double lambda = (t - gyroscopes[0].t) / (gyroscopes[1].t - gyroscopes[0].t);
+                V3 w = gyroscopes[0].w + lambda * (gyroscopes[1].w - gyroscopes[0].w);
+                track_imu({t, w, {x, y, z}});
+            }
+        }
+        return predict_pose(t);
+    }
+    PoseState track_camera(std::shared_ptr<HipImage> image) {
+        const Config &c = P.config;
+        auto f = std::make_unique<Frame>();
+        f->id = ++P.ids.frame;
+        f->K = c.K;
+        f->image = image;
+        f->sqrt_inv_cov[0] = c.K.fx / std::sqrt(c.keypoint_noise_cov[0]);
+        f->sqrt_inv_cov[1] = c.K.fy / std::sqrt(c.keypoint_noise_cov[3]);
+        f->camera = {c.q_bc, c.p_bc};
+        f->imu = {c.q_bi, c.p_bi};
+        frames.emplace_back(std::move(f));
+        PoseState out = predict_pose(image->t);
+        if (image->t > latest_timestamp) {
+            latest_pose = out;
+            latest_timestamp = image->t;
+        }
+        return out;
+    }
+    void track_imu(const ImuData &imu) {
+        frontal_imus.push_back(imu);
+        imus.push_back(imu);
+        while (!imus.empty() && !frames.empty()) {
+            if (imus.front().t <= frames.front()->image->t) {
+                frames.front()->preintegration.data.push_back(imus.front());
+                imus.pop_front();
+            } else {
+                std::unique_ptr<Frame> f = std::move(frames.front());
+                frames.pop_front();
+                feature_tracker_work(std::move(f));
+            }
+        }
+    }
+    PoseState predict_pose(double t) {
+        PoseState out;
+        if (ft_latest_state) {
+            auto [st, sp, sm] = ft_latest_state.value();
+            while (!frontal_imus.empty() && frontal_imus.front().t <= st) frontal_imus.pop_front();
+            const V3 gravity{0, 0, -9.80665};
+            for (const ImuData &imu : frontal_imus) {
+                if (imu.t <= t) {
+                    double dt = imu.t - st;
+                    sp.p = sp.p + dt * sm.v + 0.5 * dt * dt * (gravity + sp.q * (imu.a - sm.ba));
+                    sm.v = sm.v + dt * (gravity + sp.q * (imu.a - sm.ba));
+                    sp.q = (sp.q * expmap((imu.w - sm.bg) * dt)).normalized();
+                    st = imu.t;
+                }
+            }
+            out.q = sp.q * P.config.q_bo;
+            out.p = sp.p + sp.q * P.config.p_bo;
+        } else {
+            out.q = Quat{0, 0, 0, 0};
+            out.p = V3{0, 0, 0};
+        }
+        return out;
+    }
+    SysState get_system_state() const { return swt ? SYS_TRACKING : SYS_INITIALIZING; }
+
+    // -------- FeatureTracker::work (core/feature_tracker.cpp:24-153)
+    void feature_tracker_work(std::unique_ptr<Frame> frame) {
+        const Config &c = P.config;
+        hip_check(xrhip_image_preprocess(frame->image->h, c.feature_tracker_clahe_clip_limit,
+                                         (int)c.feature_tracker_clahe_width, (int)c.feature_tracker_clahe_height),
+                  "xrhip_image_preprocess");
+        auto [opt_t, opt_id, opt_pose, opt_motion] = frontend_latest_state;
+        (void)opt_t;
+        bool is_initialized = opt_id != nil();
+        bool swt_tag = !is_initialized || frame->id % c.sliding_window_tracker_frequent == 0;
+        Map *map = ft_map.get();
+        if (map->frame_num() > 0) {
+            if (is_initialized) {
+                size_t oi = map->frame_index_by_id(opt_id);
+                if (oi != nil()) {
+                    Frame *of = map->get_frame(oi);
+                    of->pose = opt_pose;
+                    of->motion = opt_motion;
+                    for (size_t j = oi + 1; j < map->frame_num(); ++j) {
+                        Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
+                        P.integrate(fj->preintegration, fj->image->t, fi->motion.bg, fi->motion.ba, false, false);
+                        predict(fj->preintegration, fi, fj);
+                    }
+                } else {
+                    ft_latest_state.reset();   // "SWT cannot catch up."
+                }
+            }
+            Frame *last = map->get_frame(map->frame_num() - 1);
+            if (!last->preintegration.data.empty()) {
+                if (frame->preintegration.data.empty() ||
+                    (frame->preintegration.data.front().t - last->image->t > 1.0e-5)) {
+                    ImuData imu = last->preintegration.data.back();
+                    imu.t = last->image->t;
+                    frame->preintegration.data.insert(frame->preintegration.data.begin(), imu);
+                }
+            }
+            P.integrate(frame->preintegration, frame->image->t, last->motion.bg, last->motion.ba, false, false);
+            frame_track_keypoints(P, last, frame.get());
+            if (is_initialized) {
+                predict(frame->preintegration, last, frame.get());
+                ft_latest_state = LatestState{frame->image->t, frame->pose, frame->motion};
+            }
+            last->image->release_image_buffer();
+        }
+        if (swt_tag) frame_detect_keypoints(P, frame.get());
+        map->attach_frame(std::move(frame));
+        size_t max_frames = is_initialized ? c.feature_tracker_max_frames : c.feature_tracker_max_init_frames;
+        while (map->frame_num() > max_frames && map->get_frame(0)->id < opt_id) map->erase_frame(0);
+        P.times.frames++;
+        if (swt_tag) frontend_work(map->get_frame(map->frame_num() - 1)->id);
+    }
+
+    // -------- FrontendWorker::work (core/frontend_worker.cpp:28-86)
+    void frontend_work(size_t pending_frame_id) {
+        if (!swt) {
+            init.mirror_keyframe_map(ft_map.get(), pending_frame_id);
+            if ((swt = init.initialize())) {
+                auto [t, pose, motion] = swt->get_latest_state();
+                frontend_latest_state = {t, pending_frame_id, pose, motion};
+            }
+        } else {
+            swt->mirror_frame(ft_map.get(), pending_frame_id);
+            if (swt->track()) {
+                auto [t, pose, motion] = swt->get_latest_state();
+                frontend_latest_state = {t, pending_frame_id, pose, motion};
+            }
+        }
+    }
+
+    struct Gyro {
+        double t;
+        V3 w;
+    };
+    struct Acc {
+        double t;
+        V3 a;
+    };
+    Pipeline P;
+    std::unique_ptr<Map> ft_map;
+    BootstrapInitializer init;
+    std::unique_ptr<SlidingWindowTracker> swt;
+    std::deque<Gyro> gyroscopes;
+    std::deque<Acc> accelerometers;
+    std::deque<ImuData> imus, frontal_imus;
+    std::deque<std::unique_ptr<Frame>> frames;
+    std::optional<LatestState> ft_latest_state;
+    std::tuple<double, size_t, PoseState, MotionState> frontend_latest_state{0.0, nil(), PoseState{}, MotionState{}};
+    PoseState latest_pose;
+    double latest_timestamp = 0;
+};
+
+}   // namespace xrh

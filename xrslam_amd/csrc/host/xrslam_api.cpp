@@ -1,0 +1,242 @@
+// xrslam_api.cpp -- the outer C ABI (include/XRSLAM.h) on top of the host pipeline.
+// Mirrors XRSLAMManager (reference xrslam-interface/src/XRSLAMManager.cpp:85-242) and
+// XRSLAMInternal.cpp:4-90: a process-global instance, deep-copied images, synchronous calls.
+#include "../../../include/XRSLAM.h"
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+
+#include "pipeline.hpp"
+
+namespace {
+
+struct Manager {
+    std::unique_ptr<xrh::System> sys;
+    xrh::Config config;
+    std::shared_ptr<xrh::HipImage> cur_image;
+    std::mutex input_mutex;
+    std::string last_error;
+    std::vector<uint8_t> gray;
+};
+
+Manager &mgr() {
+    static Manager m;
+    return m;
+}
+
+template <class F> void guarded(F &&f) {
+    try {
+        f();
+    } catch (const std::exception &e) {
+        mgr().last_error = e.what();
+        std::fprintf(stderr, "[xrslam_hip] %s\n", e.what());
+    }
+}
+
+void fill_pose(const xrh::PoseState &latest, const xrh::Quat &q_ext, const xrh::V3 &p_ext, double t, XRSLAMPose *pose) {
+    xrh::Quat q = latest.q * q_ext;
+    xrh::V3 p = latest.p + latest.q * p_ext;
+    pose->timestamp = t;
+    pose->quaternion[0] = q.x;
+    pose->quaternion[1] = q.y;
+    pose->quaternion[2] = q.z;
+    pose->quaternion[3] = q.w;
+    pose->translation[0] = p.x;
+    pose->translation[1] = p.y;
+    pose->translation[2] = p.z;
+}
+
+}   // namespace
+
+extern "C" {
+
+int XRSLAMCreate(const char *slam_config_path, const char *device_config_path, const char *, const char *,
+                 void **config) {
+    Manager &m = mgr();
+    int ok = 0;
+    guarded([&] {
+        m.config = xrh::load_config(slam_config_path, device_config_path);
+        m.sys = std::make_unique<xrh::System>(m.config);
+        if (config) *config = static_cast<void *>(&m.config);
+        ok = 1;
+    });
+    return ok;
+}
+
+void XRSLAMPushSensorData(XRSLAMSensorType type, void *data) {
+    Manager &m = mgr();
+    if (!m.sys || !data) return;
+    guarded([&] {
+        switch (type) {
+        case XRSLAM_SENSOR_CAMERA: {
+            auto *im = static_cast<XRSLAMImage *>(data);
+            if (im->camera_id != 0) break;
+            const int cols = (int)m.config.cam_resolution[0], rows = (int)m.config.cam_resolution[1];
+            const uint8_t *src = im->data;
+            int stride = im->stride;
+            if (im->channel == 3 || im->channel == 4) {   // cv::cvtColor BGR(A)2GRAY: (B*1868 + G*9617 + R*4899 + 8192) >> 14
+                m.gray.resize((size_t)cols * rows);
+                for (int y = 0; y < rows; ++y)
+                    for (int x = 0; x < cols; ++x) {
+                        const uint8_t *px = im->data + (size_t)y * im->stride + (size_t)x * im->channel;
+                        m.gray[(size_t)y * cols + x] = (uint8_t)((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14);
+                    }
+                src = m.gray.data();
+                stride = cols;
+            } else if (im->channel != 1) {
+                throw std::runtime_error("Image channel is not supported!");
+            }
+            std::lock_guard<std::mutex> lk(m.input_mutex);
+            m.cur_image = m.sys->P.make_image(src, stride, im->timeStamp, false);
+            break;
+        }
+        case XRSLAM_SENSOR_ACCELERATION: {
+            auto *a = static_cast<XRSLAMAcceleration *>(data);
+            m.sys->track_accelerometer(a->timestamp, a->data[0], a->data[1], a->data[2]);
+            break;
+        }
+        case XRSLAM_SENSOR_GYROSCOPE: {
+            auto *g = static_cast<XRSLAMGyroscope *>(data);
+            m.sys->track_gyroscope(g->timestamp, g->data[0], g->data[1], g->data[2]);
+            break;
+        }
+        default:
+            break;
+        }
+    });
+}
+
+void XRSLAMRunOneFrame() {
+    Manager &m = mgr();
+    if (!m.sys) return;
+    guarded([&] {
+        std::lock_guard<std::mutex> lk(m.input_mutex);
+        if (m.cur_image) m.sys->track_camera(m.cur_image);
+    });
+}
+
+void XRSLAMSetViewer(void *) {}
+
+void XRSLAMGetResult(XRSLAMResultType type, void *out) {
+    Manager &m = mgr();
+    if (!m.sys || !out) return;
+    guarded([&] {
+        switch (type) {
+        case XRSLAM_RESULT_BODY_POSE:
+            fill_pose(m.sys->latest_pose, m.config.q_bi, m.config.p_bi, m.sys->latest_timestamp, static_cast<XRSLAMPose *>(out));
+            break;
+        case XRSLAM_RESULT_CAMERA_POSE:
+            fill_pose(m.sys->latest_pose, m.config.q_bc, m.config.p_bc, m.sys->latest_timestamp, static_cast<XRSLAMPose *>(out));
+            break;
+        case XRSLAM_RESULT_STATE: {
+            auto st = m.sys->get_system_state();
+            *static_cast<XRSLAMState *>(out) = st == xrh::SYS_INITIALIZING ? XRSLAM_STATE_INITIALIZING
+                                               : st == xrh::SYS_TRACKING   ? XRSLAM_STATE_TRACKING_SUCCESS
+                                                                           : XRSLAM_STATE_TRACKING_FAIL;
+            break;
+        }
+        case XRSLAM_RESULT_LANDMARKS: {
+            auto *lm = static_cast<XRSLAMLandmarks *>(out);
+            lm->num_landmarks = 0;
+            lm->landmarks = nullptr;
+            if (m.sys->swt) {
+                xrh::Map *map = m.sys->swt->map.get();
+                std::vector<XRSLAMLandmark> pts;
+                for (size_t i = 0; i < map->track_num(); ++i) {
+                    xrh::Track *t = map->get_track(i);
+                    if (t->tag(xrh::TT_VALID)) {
+                        xrh::V3 p = t->get_landmark_point();
+                        pts.push_back({p.x, p.y, p.z});
+                    }
+                }
+                lm->num_landmarks = (int)pts.size();
+                lm->landmarks = new XRSLAMLandmark[pts.size() + 1];   // caller-owned, like the reference (:207)
+                std::memcpy(lm->landmarks, pts.data(), sizeof(XRSLAMLandmark) * pts.size());
+            }
+            break;
+        }
+        case XRSLAM_RESULT_BIAS: {
+            auto *b = static_cast<XRSLAMIMUBias *>(out);
+            if (m.sys->swt) {
+                auto [t, pose, motion] = m.sys->swt->get_latest_state();
+                (void)t;
+                (void)pose;
+                for (int i = 0; i < 3; ++i) {
+                    b->acc_bias.data[i] = motion.ba[i];
+                    b->gyr_bias.data[i] = motion.bg[i];
+                }
+            }
+            break;
+        }
+        case XRSLAM_RESULT_VERSION: {
+            auto *s = static_cast<XRSLAMStringOutput *>(out);
+            static const char ver[] = "0.1.0";
+            s->str_length = (int)std::strlen(ver);
+            s->data = new char[s->str_length + 5];
+            std::strcpy(s->data, ver);
+            break;
+        }
+        case XRSLAM_INFO_INTRINSICS: {
+            auto *k = static_cast<XRSLAMIntrinsics *>(out);
+            k->fx = m.config.K.fx;
+            k->fy = m.config.K.fy;
+            k->cx = m.config.K.cx;
+            k->cy = m.config.K.cy;
+            break;
+        }
+        default:
+            break;
+        }
+    });
+}
+
+void XRSLAMDestroy() {
+    Manager &m = mgr();
+    guarded([&] {
+        m.cur_image.reset();
+        m.sys.reset();
+    });
+}
+
+void XRSLAMAmdSetInitialState(double t, const double q[4], const double p[3], const double v[3], const double bg[3],
+                              const double ba[3]) {
+    Manager &m = mgr();
+    if (!m.sys) return;
+    xrh::InitialState s;
+    s.t = t;
+    s.pose.q = xrh::Quat{q[0], q[1], q[2], q[3]}.normalized();
+    s.pose.p = {p[0], p[1], p[2]};
+    s.motion.v = {v[0], v[1], v[2]};
+    s.motion.bg = {bg[0], bg[1], bg[2]};
+    s.motion.ba = {ba[0], ba[1], ba[2]};
+    m.sys->init.states.push_back(s);
+}
+
+void XRSLAMAmdPushImageDevice(const void *gray_dev, int stride, double timestamp) {
+    Manager &m = mgr();
+    if (!m.sys) return;
+    guarded([&] {
+        std::lock_guard<std::mutex> lk(m.input_mutex);
+        m.cur_image = m.sys->P.make_image(static_cast<const uint8_t *>(gray_dev), stride, timestamp, true);
+    });
+}
+
+void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out) {
+    Manager &m = mgr();
+    if (!out) return;
+    std::memset(out, 0, sizeof(*out));
+    if (!m.sys) return;
+    const xrh::StageTimes &t = m.sys->P.times;
+    out->frames = t.frames;
+    out->solves = t.solves;
+    out->solve_iterations = t.solve_iterations;
+    out->marginalizations = t.marginalizations;
+    out->keyframes = t.keyframes;
+    out->ba_device_ms = t.ba_device_ms;
+}
+
+const char *XRSLAMAmdLastError(void) { return mgr().last_error.c_str(); }
+
+}   // extern "C"

@@ -1,0 +1,148 @@
+"""The player's call sequence (reference xrslam-pc/player/src/main.cpp:116-169) over the outer C ABI
+(include/XRSLAM.h): at equal timestamps the asynchronous dataset reader yields gyroscope, then
+accelerometer, then camera (IO/async_dataset_reader.cpp:41-48).  Works against any shared object that
+exports the XRSLAM.h symbols (the product library, or the oracle-backed CPU reference build)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+XRSLAM_SENSOR_CAMERA, XRSLAM_SENSOR_ACCELERATION, XRSLAM_SENSOR_GYROSCOPE = 0, 2, 3
+XRSLAM_RESULT_BODY_POSE, XRSLAM_RESULT_STATE = 0, 2
+
+
+class XRSLAMImage(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("timeStamp", C.c_double), ("stride", C.c_int), ("camera_id", C.c_int),
+                ("channel", C.c_int), ("ext", C.c_void_p)]
+
+
+class XRSLAMVec3(C.Structure):       # XRSLAMAcceleration / XRSLAMGyroscope
+    _fields_ = [("data", C.c_double * 3), ("timestamp", C.c_double)]
+
+
+class XRSLAMPose(C.Structure):
+    _fields_ = [("quaternion", C.c_double * 4), ("translation", C.c_double * 3), ("timestamp", C.c_double)]
+
+
+class XRSLAMAmdTimes(C.Structure):
+    _fields_ = [("frames", C.c_long), ("solves", C.c_long), ("solve_iterations", C.c_long),
+                ("marginalizations", C.c_long), ("keyframes", C.c_long), ("ba_device_ms", C.c_double)]
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SLAM_YAML = os.path.join(ROOT, "configs", "euroc_slam.yaml")
+SENSOR_YAML = os.path.join(ROOT, "configs", "euroc_sensor.yaml")
+
+
+def load(lib_path):
+    lib = C.CDLL(lib_path)
+    lib.XRSLAMCreate.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.XRSLAMPushSensorData.argtypes = [C.c_int, C.c_void_p]
+    lib.XRSLAMPushSensorData.restype = None
+    lib.XRSLAMRunOneFrame.restype = None
+    lib.XRSLAMGetResult.argtypes = [C.c_int, C.c_void_p]
+    lib.XRSLAMGetResult.restype = None
+    lib.XRSLAMDestroy.restype = None
+    lib.XRSLAMAmdSetInitialState.argtypes = [C.c_double] + [C.c_void_p] * 5
+    lib.XRSLAMAmdSetInitialState.restype = None
+    lib.XRSLAMAmdPushImageDevice.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    lib.XRSLAMAmdPushImageDevice.restype = None
+    lib.XRSLAMAmdGetTimes.argtypes = [C.POINTER(XRSLAMAmdTimes)]
+    lib.XRSLAMAmdGetTimes.restype = None
+    lib.XRSLAMAmdLastError.restype = C.c_char_p
+    return lib
+
+
+class Session:
+    """One XRSLAM instance (the reference is a process singleton, XRSLAMManager.cpp:6-9)."""
+
+    def __init__(self, lib_path, seq, slam_yaml=SLAM_YAML, sensor_yaml=SENSOR_YAML, device_frames=None,
+                 init_frames=60):
+        self.lib = load(lib_path)
+        self.seq = seq
+        cfg = C.c_void_p()
+        ok = self.lib.XRSLAMCreate(slam_yaml.encode(), sensor_yaml.encode(), b"", b"xrslam_amd", C.byref(cfg))
+        if ok != 1:
+            raise RuntimeError("XRSLAMCreate failed: %s" % self.lib.XRSLAMAmdLastError().decode())
+        st = seq["states"]
+        for i in range(min(init_frames, len(st))):
+            s = np.ascontiguousarray(st[i])
+            q, p, v, bg, ba = [np.ascontiguousarray(s[a:b]) for a, b in ((0, 4), (4, 7), (7, 10), (10, 13), (13, 16))]
+            self.lib.XRSLAMAmdSetInitialState(float(seq["cam_t"][i]), q.ctypes.data, p.ctypes.data, v.ctypes.data,
+                                              bg.ctypes.data, ba.ctypes.data)
+        self.device_frames = device_frames   # (base pointer, bytes per frame, stride) when frames live in HBM
+        self.imu_k = 0
+        self.frame_k = 0
+        self.poses = []
+
+    def _push_imu_until(self, t_limit):
+        imu = self.seq["imu"]
+        while self.imu_k < len(imu) and imu[self.imu_k, 0] <= t_limit + 1e-9:
+            r = imu[self.imu_k]
+            g = XRSLAMVec3((C.c_double * 3)(*r[1:4]), r[0])
+            a = XRSLAMVec3((C.c_double * 3)(*r[4:7]), r[0])
+            self.lib.XRSLAMPushSensorData(XRSLAM_SENSOR_GYROSCOPE, C.byref(g))
+            self.lib.XRSLAMPushSensorData(XRSLAM_SENSOR_ACCELERATION, C.byref(a))
+            self.imu_k += 1
+
+    def step(self):
+        """Feeds everything up to and including the next camera frame; returns False at the end."""
+        if self.frame_k >= len(self.seq["cam_t"]):
+            return False
+        t = float(self.seq["cam_t"][self.frame_k])
+        self._push_imu_until(t)
+        if self.device_frames is not None:
+            base, fbytes, stride = self.device_frames
+            self.lib.XRSLAMAmdPushImageDevice(C.c_void_p(base + self.frame_k * fbytes), stride, t)
+        else:
+            fr = self.seq["frames"][self.frame_k]
+            img = XRSLAMImage(fr.ctypes.data, t, fr.strides[0], 0, 1, None)
+            self.lib.XRSLAMPushSensorData(XRSLAM_SENSOR_CAMERA, C.byref(img))
+        self.lib.XRSLAMRunOneFrame()
+        state = C.c_int(-1)
+        self.lib.XRSLAMGetResult(XRSLAM_RESULT_STATE, C.byref(state))
+        if state.value == 1:
+            pose = XRSLAMPose()
+            self.lib.XRSLAMGetResult(XRSLAM_RESULT_BODY_POSE, C.byref(pose))
+            self.poses.append([pose.timestamp] + list(pose.translation) + list(pose.quaternion))
+        self.frame_k += 1
+        return True
+
+    def flush(self):
+        """Pushes the IMU samples after the last frame so the last queued frame is processed
+        (processing is triggered by the first IMU sample later than the frame, detail.cpp:130-142)."""
+        self._push_imu_until(1e300)
+
+    def times(self):
+        t = XRSLAMAmdTimes()
+        self.lib.XRSLAMAmdGetTimes(C.byref(t))
+        return t
+
+    def error(self):
+        return self.lib.XRSLAMAmdLastError().decode()
+
+    def close(self):
+        self.lib.XRSLAMDestroy()
+
+
+def ate_rmse(poses, seq):
+    """ATE RMSE after SE(3) Umeyama alignment (what `evo_ape tum -a` computes, docs/en/tutorials/euroc_evaluation.md)."""
+    if len(poses) < 3:
+        return float("nan")
+    P = np.array(poses)
+    P = P[np.abs(P[:, 4:8]).sum(1) > 0]      # results before the first tracked frame are the all-zero pose (detail.cpp:165-168)
+    if len(P) < 3:
+        return float("nan")
+    idx = np.searchsorted(seq["cam_t"], P[:, 0] - 1e-6)
+    idx = np.clip(idx, 0, len(seq["cam_t"]) - 1)
+    gt = seq["states"][idx, 4:7]
+    est = P[:, 1:4]
+    mu_e, mu_g = est.mean(0), gt.mean(0)
+    H = (est - mu_e).T @ (gt - mu_g)
+    U, S, Vt = np.linalg.svd(H)
+    D = np.eye(3)
+    if np.linalg.det(Vt.T @ U.T) < 0:
+        D[2, 2] = -1
+    R = Vt.T @ D @ U.T
+    aligned = (R @ (est - mu_e).T).T + mu_g
+    return float(np.sqrt(((aligned - gt) ** 2).sum(1).mean()))

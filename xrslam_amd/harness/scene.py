@@ -1,0 +1,90 @@
+"""Synthetic S1 "EuRoC MH_01-like" stream: a textured box room rendered through the EuRoC cam0 pinhole
+model along the analytic trajectory, with 200 Hz IMU.  Seeded, no external data."""
+import numpy as np
+
+from .trajectory import Trajectory, qmat, qmul, qrot
+
+K_EUROC = (458.654, 457.296, 367.215, 248.375)
+Q_BC = np.array([-7.7071797555374275e-03, 1.0499323370587278e-02, 7.0175280029197162e-01, 7.1230146066895372e-01])
+Q_BC = Q_BC / np.linalg.norm(Q_BC)
+P_BC = np.array([-0.0216401454975, -0.064676986768, 0.00981073058949])
+
+
+def _noise_texture(n, seed, octaves=7, mean=110.0, sigma=45.0):
+    rng = np.random.RandomState(seed)
+    acc = np.zeros((n, n))
+    amp = 1.0
+    for o in range(octaves):
+        g = max(4, n >> (octaves - o))
+        grid = rng.randn(g + 1, g + 1)
+        xs = np.linspace(0, g - 1e-6, n)
+        i0 = xs.astype(int)
+        f = xs - i0
+        rows = grid[i0] * (1 - f)[:, None] + grid[i0 + 1] * f[:, None]
+        acc += amp * (rows[:, i0] * (1 - f)[None, :] + rows[:, i0 + 1] * f[None, :])
+        amp *= 0.8
+    acc = (acc - acc.mean()) / acc.std()
+    return np.clip(mean + sigma * acc, 0, 255)
+
+
+class BoxRoom:
+    def __init__(self, half=(6.0, 6.0, 3.5), texels_per_m=110.0, seed=1):
+        self.half = np.array(half)
+        self.tpm = texels_per_m
+        n = int(np.ceil(2 * max(half) * texels_per_m)) + 2
+        self.tex = np.stack([_noise_texture(n, seed * 10 + k) for k in range(6)])   # face = 2*axis + (positive side)
+        self.n = n
+
+    def render(self, q_wc, p_wc, w=752, h=480, K=K_EUROC):
+        fx, fy, cx, cy = K
+        xs = (np.arange(w) - cx) / fx
+        ys = (np.arange(h) - cy) / fy
+        d_cam = np.stack(np.broadcast_arrays(xs[None, :], ys[:, None], np.ones((h, w))), axis=-1)
+        d = d_cam @ qmat(q_wc).T                       # world ray directions
+        with np.errstate(divide="ignore", invalid="ignore"):
+            side = np.where(d >= 0, 1.0, -1.0)
+            t_axis = (side * self.half - p_wc) / d
+        t_axis = np.where(np.isfinite(t_axis) & (t_axis > 0), t_axis, np.inf)
+        axis = np.argmin(t_axis, axis=-1)
+        t = np.take_along_axis(t_axis, axis[..., None], axis=-1)[..., 0]
+        hit = p_wc + d * t[..., None]
+        face = 2 * axis + (np.take_along_axis(side, axis[..., None], axis=-1)[..., 0] > 0)
+        ua = np.where(axis == 0, 1, 0)                 # in-plane axes
+        va = np.where(axis == 2, 1, 2)
+        u = (np.take_along_axis(hit, ua[..., None], axis=-1)[..., 0] + self.half.max()) * self.tpm
+        v = (np.take_along_axis(hit, va[..., None], axis=-1)[..., 0] + self.half.max()) * self.tpm
+        u = np.clip(u, 0, self.n - 1.001)
+        v = np.clip(v, 0, self.n - 1.001)
+        u0 = u.astype(int)
+        v0 = v.astype(int)
+        fu = u - u0
+        fv = v - v0
+        T = self.tex
+        val = (T[face, v0, u0] * (1 - fu) * (1 - fv) + T[face, v0, u0 + 1] * fu * (1 - fv) + T[face, v0 + 1, u0] * (1 - fu) * fv +
+               T[face, v0 + 1, u0 + 1] * fu * fv)
+        return np.clip(np.rint(val), 0, 255).astype(np.uint8)
+
+
+def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True):
+    """Returns dict(frames uint8 [n,h,w], cam_t [n], imu [m,7] (t, w, a), states [n,16] ground truth body states)."""
+    rng = np.random.RandomState(seed)
+    traj = Trajectory()
+    room = BoxRoom(seed=seed)
+    bg = rng.randn(3) * 1e-3
+    ba = rng.randn(3) * 1e-2
+    ratio = int(round(imu_hz / cam_hz))
+    n_imu = (n_frames - 1) * ratio + ratio + 1
+    imu = np.zeros((n_imu, 7))
+    sg, sa = (1.7e-4 * np.sqrt(imu_hz), 2.0e-3 * np.sqrt(imu_hz)) if noise else (0.0, 0.0)
+    for k in range(n_imu):
+        t = t0 + k / imu_hz
+        wv, av = traj.imu(t, bg, ba)
+        imu[k] = np.concatenate([[t], wv + rng.randn(3) * sg, av + rng.randn(3) * sa])
+    frames = np.zeros((n_frames, h, w), np.uint8)
+    cam_t = t0 + np.arange(n_frames) / cam_hz
+    states = np.zeros((n_frames, 16))
+    for i, t in enumerate(cam_t):
+        q, p = traj.q(t), traj.p(t)
+        states[i] = np.concatenate([q, p, traj.v(t), bg, ba])
+        frames[i] = room.render(qmul(q, Q_BC), p + qrot(q, P_BC), w, h)
+    return dict(frames=frames, cam_t=cam_t, imu=imu, states=states, bg=bg, ba=ba)
