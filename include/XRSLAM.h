@@ -152,6 +152,10 @@ typedef struct XRSLAMAmdTimes {
     double ba_device_ms; /* sum of HIP-event solve times */
 } XRSLAMAmdTimes;
 void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out);
+/* HIP-event profiling of the KLT kernels (off by default) and its accumulated counters; the struct is
+ * xrhip_klt_stats from xrslam_hip.h (passed as void* to keep this header free of that include) */
+void XRSLAMAmdSetProfiling(int enable);
+void XRSLAMAmdGetKltStats(void *xrhip_klt_stats_out, int reset);
 /* last error raised inside the library ("" if none); the reference aborts/throws instead */
 const char *XRSLAMAmdLastError(void);
 

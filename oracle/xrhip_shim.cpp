@@ -110,6 +110,11 @@ int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const dou
     if (n > 0) orc_track_keypoints(cur->pyr, next->pyr, curr_xy, next_xy, has_guess, status, n, nullptr);
     return 0;
 }
+int xrhip_klt_set_profiling(xrhip_klt *, int) { return 0; }
+int xrhip_klt_get_stats(xrhip_klt *, xrhip_klt_stats *out, int) {
+    std::memset(out, 0, sizeof(*out));
+    return 0;
+}
 int xrhip_ba_create(int, int, int, xrhip_ba **out) {
     *out = new xrhip_ba{0};
     return 0;

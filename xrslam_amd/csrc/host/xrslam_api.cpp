@@ -237,6 +237,17 @@ void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out) {
     out->ba_device_ms = t.ba_device_ms;
 }
 
+void XRSLAMAmdSetProfiling(int enable) {
+    Manager &m = mgr();
+    if (m.sys) xrhip_klt_set_profiling(m.sys->P.klt, enable);
+}
+
+void XRSLAMAmdGetKltStats(void *out, int reset) {
+    Manager &m = mgr();
+    if (!m.sys || !out) return;
+    guarded([&] { xrh::hip_check(xrhip_klt_get_stats(m.sys->P.klt, static_cast<xrhip_klt_stats *>(out), reset), "xrhip_klt_get_stats"); });
+}
+
 const char *XRSLAMAmdLastError(void) { return mgr().last_error.c_str(); }
 
 }   // extern "C"

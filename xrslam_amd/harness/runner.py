@@ -50,6 +50,10 @@ def load(lib_path):
     lib.XRSLAMAmdGetTimes.argtypes = [C.POINTER(XRSLAMAmdTimes)]
     lib.XRSLAMAmdGetTimes.restype = None
     lib.XRSLAMAmdLastError.restype = C.c_char_p
+    lib.XRSLAMAmdSetProfiling.argtypes = [C.c_int]
+    lib.XRSLAMAmdSetProfiling.restype = None
+    lib.XRSLAMAmdGetKltStats.argtypes = [C.c_void_p, C.c_int]
+    lib.XRSLAMAmdGetKltStats.restype = None
     return lib
 
 
@@ -117,6 +121,15 @@ class Session:
         t = XRSLAMAmdTimes()
         self.lib.XRSLAMAmdGetTimes(C.byref(t))
         return t
+
+    def set_profiling(self, on):
+        self.lib.XRSLAMAmdSetProfiling(1 if on else 0)
+
+    def klt_stats(self, reset=False):
+        from xrslam_amd.klt import KltStats
+        st = KltStats()
+        self.lib.XRSLAMAmdGetKltStats(C.byref(st), 1 if reset else 0)
+        return st
 
     def error(self):
         return self.lib.XRSLAMAmdLastError().decode()
