@@ -153,6 +153,12 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
         std::vector<int> fill(rotf_start.begin(), rotf_start.end() - 1);
         for (int o = 0; o < MR; ++o) rotf_items[fill[P->rot_tgt[o]]++] = o;
     }
+    std::vector<int> act_idx;
+    for (int a = 0; a < 15 * F; ++a) {
+        const int f = a / 15, k = a % 15;
+        if (k < 6 ? !(P->frame_fix[f] & XRHIP_FIX_POSE) : !(P->frame_fix[f] & XRHIP_FIX_MOTION)) act_idx.push_back(a);
+    }
+    d.na = (int)act_idx.size();
     std::vector<int> imuf(2 * F, -1), priorf(F, -1);
     for (int k = 0; k < NI; ++k) {
         if (imuf[2 * P->imu_j[k]] >= 0 || imuf[2 * P->imu_i[k] + 1] >= 0)
@@ -208,6 +214,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     const size_t o_pit = put(pair_items.data(), sizeof(int) * 4 * M);
     const size_t o_rfs = put(rotf_start.data(), sizeof(int) * (F + 1)), o_rfi = put(rotf_items.data(), sizeof(int) * MR);
     const size_t o_imuf = put(imuf.data(), sizeof(int) * 2 * F), o_prf = put(priorf.data(), sizeof(int) * F);
+    const size_t o_act = put(act_idx.data(), sizeof(int) * act_idx.size());
     const size_t o_ctl = put(&ctl, sizeof(ctl));
     const size_t in_bytes = A.used + 256;
 
@@ -232,6 +239,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     const size_t w_T = carve(D8 * (size_t)d.PF * d.PF), w_S = carve(D8 * (size_t)n * n);
     const size_t w_dD = carve(D8 * d.NV), w_gr = carve(D8 * d.NV), w_gn = carve(D8 * d.NV), w_gs = carve(D8 * d.NV);
     const size_t w_st = carve(D8 * d.NV), w_de = carve(D8 * d.NV), w_part = carve(D8 * 64);
+    const size_t w_Hv = carve(D8 * 36 * (size_t)F * F), w_gv = carve(D8 * 6 * F);
     int rc = ensure_arena(c, in_bytes, w + 256, (size_t)16 * F + L + 8);
     if (rc) return rc;
     for (const Item &it : items)
@@ -271,6 +279,9 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     p.rotf_items = (const int *)(I + o_rfi);
     p.imuf = (const int *)(I + o_imuf);
     p.priorf = (const int *)(I + o_prf);
+    p.act_idx = (const int *)(I + o_act);
+    p.Hv = (double *)(W + w_Hv);
+    p.gv = (double *)(W + w_gv);
     p.orec = (double *)(W + w_orec);
     p.ocost = (double *)(W + w_ocost);
     p.rrec = (double *)(W + w_rrec);
@@ -316,6 +327,7 @@ static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, cons
     if (d.NI) hipLaunchKernelGGL(kb_lin_imu, dim3(d.NI), dim3(64), 0, s, d, p, imu);
     hipLaunchKernelGGL(kb_lin_prior, dim3(1), dim3(256), sizeof(double) * std::max(d.np, 1), s, d, p);
     hipLaunchKernelGGL(kb_landmark, dim3(d.Lp), dim3(64), 0, s, d, p);
+    hipLaunchKernelGGL(kb_assemble_vision, dim3(d.F * d.F), dim3(64), 0, s, d, p);
     hipLaunchKernelGGL(kb_assemble, dim3((d.n * d.n + 255) / 256), dim3(256), 0, s, d, p);
     hipLaunchKernelGGL(kb_sum_cost, dim3(1), dim3(256), 0, s, d, p);
     hipLaunchKernelGGL(kb_gradmax, dim3(1), dim3(256), 0, s, d, p);
@@ -326,11 +338,11 @@ static int launch_solve(xrhip_ba *c, const BaDims &d, const BaPtrs &p) {
     hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);
     const int tiles = d.PF / 16;
     hipLaunchKernelGGL(kb_schur_mfma, dim3(tiles * tiles), dim3(256), 0, s, d, p);
-    size_t lds = sizeof(double) * ((size_t)((d.n + 1) & ~1) + (size_t)d.n * (d.n + 1) / 2);
+    size_t lds = sizeof(double) * ((size_t)((d.na + 1) & ~1) + (size_t)d.na * (d.na + 1) / 2);
     int use_lds = 1;
     if (lds > (size_t)c->lds_limit) {
         use_lds = 0;
-        lds = sizeof(double) * (size_t)((d.n + 1) & ~1);
+        lds = sizeof(double) * (size_t)((d.na + 1) & ~1);
     }
     hipLaunchKernelGGL(kb_solve, dim3(1), dim3(512), lds, s, d, p, use_lds);
     XR_HIP(hipGetLastError());

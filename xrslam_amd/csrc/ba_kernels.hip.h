@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "ba_math.hip.h"
+#include "dense_lds.hip.h"
 
 namespace xrhip {
 
@@ -48,6 +49,7 @@ struct BaDims {
     int NP, np;         // prior frames, 15*NP
     int NV;             // n + L
     int robust;         // 1: CauchyLoss(1) on visual factors (Solver); 0: none (marginalisation)
+    int na;             // number of free frame dofs (size of the reduced system actually factored)
 };
 
 struct BaPtrs {
@@ -72,6 +74,8 @@ struct BaPtrs {
     const int *rotf_start, *rotf_items;   // CSR frame -> rotation factors
     const int *imuf;                 // [F][2]: imu factor with j == f, imu factor with i == f (or -1)
     const int *priorf;               // [F]: index in prior_frames or -1
+    const int *act_idx;              // [na] free frame dofs (indices into [0, 15F)), ascending
+    double *Hv, *gv;                 // [F][F][36] reprojection blocks, [F][6] reprojection gradient
     // linearisation products
     double *orec, *ocost;            // [M][28], [M]
     double *rrec, *rcost;
@@ -210,6 +214,31 @@ __device__ __forceinline__ double imu_cost_eval(const BaPtrs &p, int k, const do
     return 0.5 * c;
 }
 
+// wave-cooperative whitened IMU cost: returns the factor's cost in lane 0 (0 in the other lanes)
+__device__ __forceinline__ double imu_cost_wave(const BaPtrs &p, int k, const double *state, const Ext &imu, int lane) {
+    const int fi = p.imu_i[k], fj = p.imu_j[k];
+    if (p.fix[fi] == 3 && p.fix[fj] == 3) return 0.0;
+    const double *data = p.imu_data + (size_t)k * XRHIP_IMU_DIM;
+    double raw[15];
+    if (lane == 0) {
+        const ImuRec pre = load_imu(data);
+        imu_raw_residual(load_state(state + 16 * fi), load_state(state + 16 * fj), pre,
+                         v3(p.bias_ref[6 * k], p.bias_ref[6 * k + 1], p.bias_ref[6 * k + 2]),
+                         v3(p.bias_ref[6 * k + 3], p.bias_ref[6 * k + 4], p.bias_ref[6 * k + 5]), imu, raw);
+    }
+#pragma unroll
+    for (int i = 0; i < 15; ++i) raw[i] = __shfl(raw[i], 0);
+    double c = 0;
+    if (lane < 15) {
+        const double *S = data + 56 + 15 * lane;
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < 15; ++j) s += S[j] * raw[j];
+        c = 0.5 * s * s;
+    }
+    return wave_sum(c) * (lane == 0 ? 1.0 : 0.0);
+}
+
 // One 64-lane workgroup per IMU factor: lane 0 evaluates the (serial) SO(3) algebra into LDS, then all
 // lanes apply the 15x15 whitening to the residual and both Jacobians.
 __global__ __launch_bounds__(64) void kb_lin_imu(BaDims d, BaPtrs p, Ext imu) {
@@ -276,7 +305,8 @@ __device__ __forceinline__ void prior_delta(const BaPtrs &p, int i, const double
     if (Jq) *Jq = inverse3(right_jacobian(rq));
 }
 
-// prior cost at `state`: 0.5 |S delta + infovec|^2 ; block-wide (any block size), delta staged in `sh` (np doubles)
+// prior cost at `state`: 0.5 |S delta + infovec|^2 ; block-wide (any block size), delta staged in `sh` (np doubles).
+// One wavefront per row of S, lanes striding over the columns (coalesced).
 __device__ __forceinline__ double prior_cost_block(const BaDims &d, const BaPtrs &p, const double *state, double *sh,
                                                    double *scratch, double *r_out) {
     for (int i = threadIdx.x; i < d.NP; i += blockDim.x) {
@@ -285,13 +315,18 @@ __device__ __forceinline__ double prior_cost_block(const BaDims &d, const BaPtrs
         for (int k = 0; k < 15; ++k) sh[15 * i + k] = dl[k];
     }
     __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     double c = 0;
-    for (int i = threadIdx.x; i < d.np; i += blockDim.x) {
-        double s = p.pinfo[i];
+    for (int i = wave; i < d.np; i += nw) {
         const double *row = p.pS + (size_t)i * d.np;
-        for (int j = 0; j < d.np; ++j) s += row[j] * sh[j];
-        if (r_out) r_out[i] = s;
-        c += s * s;
+        double s = 0;
+        for (int j = lane; j < d.np; j += 64) s += row[j] * sh[j];
+        s = wave_sum(s);
+        if (lane == 0) {
+            s += p.pinfo[i];
+            if (r_out) r_out[i] = s;
+            c += s * s;
+        }
     }
     return 0.5 * block_sum(c, scratch);
 }
@@ -307,22 +342,12 @@ __global__ __launch_bounds__(256) void kb_lin_prior(BaDims d, BaPtrs p) {
         double dl[15];
         M3 Jq;
         prior_delta(p, i, p.state, dl, &Jq);
-        for (int k = 0; k < 15; ++k) sh[15 * i + k] = dl[k];
         for (int k = 0; k < 9; ++k) p.pJq[9 * i + k] = Jq.m[k];
     }
+    const double c = prior_cost_block(d, p, p.state, sh, scratch, p.pr);
+    if (threadIdx.x == 0) p.pcost[0] = c;
     __syncthreads();
-    double c = 0;
-    for (int i = threadIdx.x; i < d.np; i += blockDim.x) {
-        double s = p.pinfo[i];
-        const double *row = p.pS + (size_t)i * d.np;
-        for (int j = 0; j < d.np; ++j) s += row[j] * sh[j];
-        p.pr[i] = s;
-        c += s * s;
-    }
-    c = block_sum(c, scratch);
-    if (threadIdx.x == 0) p.pcost[0] = 0.5 * c;
-    __syncthreads();
-    // t = S^T r
+    // t = S^T r  (thread per column: consecutive threads read consecutive addresses)
     for (int j = threadIdx.x; j < d.np; j += blockDim.x) {
         double s = 0;
         for (int i = 0; i < d.np; ++i) s += p.pS[(size_t)i * d.np + j] * p.pr[i];
@@ -393,9 +418,56 @@ __global__ __launch_bounds__(64) void kb_landmark(BaDims d, BaPtrs p) {
 }
 
 // --------------------------------------------------------------------- assembly
-// One thread per element (a,b) of the frame Hessian Hpp (15F x 15F) and, for b == 0, of g.
-// Every contribution list is visited in a fixed order: reprojection pairs (CSR), rotation factors,
-// the two IMU factors adjacent to the frame, the prior.
+// Reprojection blocks: one wavefront per (row frame, column frame) pair.  The lanes stride over the pair's
+// observation list, each accumulating a private 6x6 block (+ 6-vector for the diagonal pair); a fixed
+// butterfly reduction combines them -- "batched small-block JtJ accumulation with wavefront-shuffle reductions".
+__global__ __launch_bounds__(64) void kb_assemble_vision(BaDims d, BaPtrs p) {
+    const int fa = blockIdx.x / d.F, fb = blockIdx.x - fa * d.F, lane = threadIdx.x;
+    const int s0 = p.pair_start[fa * d.F + fb], s1 = p.pair_start[fa * d.F + fb + 1];
+    double h[36], g[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) h[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = 0.0;
+    const bool diag = (fa == fb);
+    for (int it = s0 + lane; it < s1; it += 64) {
+        const int code = p.pair_items[it];
+        const double *rec = p.orec + (size_t)(code >> 1) * OREC;
+        const int ra = (code & 1) ? 12 : 0;
+        const int rb = diag ? ra : ((code & 1) ? 0 : 12);
+        double ja[12], jb[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            ja[i] = rec[ra + i];
+            jb[i] = rec[rb + i];
+        }
+        const double r0 = rec[26], r1 = rec[27];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int b = 0; b < 6; ++b) h[6 * a + b] += ja[a] * jb[b] + ja[6 + a] * jb[6 + b];
+            if (diag) g[a] += ja[a] * r0 + ja[6 + a] * r1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) h[i] = wave_sum(h[i]);
+    if (diag) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g[i] = wave_sum(g[i]);
+    }
+    if (lane == 0) {
+        double *out = p.Hv + (size_t)blockIdx.x * 36;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) out[i] = h[i];
+        if (diag)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) p.gv[6 * fa + i] = g[i];
+    }
+}
+
+// One thread per element (a,b) of the frame Hessian Hpp (15F x 15F) and, for b == 0, of g: adds the
+// reprojection block, rotation priors, the (at most two) IMU factors adjacent to the frame and the prior,
+// always in this fixed order.
 __global__ __launch_bounds__(256) void kb_assemble(BaDims d, BaPtrs p) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= d.n * d.n) return;
@@ -405,27 +477,9 @@ __global__ __launch_bounds__(256) void kb_assemble(BaDims d, BaPtrs p) {
     const bool want_g = (b == 0);
     if (dof_active(p.fix, a) && (dof_active(p.fix, b) || want_g)) {
         const bool bact = dof_active(p.fix, b);
-        // reprojection blocks (pose dofs only)
         if (ka < 6) {
-            if (kb < 6 && bact) {
-                const int s = p.pair_start[fa * d.F + fb], t = p.pair_start[fa * d.F + fb + 1];
-                for (int it = s; it < t; ++it) {
-                    const int code = p.pair_items[it];
-                    const double *rec = p.orec + (size_t)(code >> 1) * OREC;
-                    const int ra = (code & 1) ? 12 : 0;                       // role of the row frame
-                    const int rb = (fa == fb) ? ra : ((code & 1) ? 0 : 12);   // column frame: same or the other role
-                    h += rec[ra + ka] * rec[rb + kb] + rec[ra + 6 + ka] * rec[rb + 6 + kb];
-                }
-            }
-            if (want_g) {
-                const int s = p.pair_start[fa * d.F + fa], t = p.pair_start[fa * d.F + fa + 1];
-                for (int it = s; it < t; ++it) {
-                    const int code = p.pair_items[it];
-                    const double *rec = p.orec + (size_t)(code >> 1) * OREC;
-                    const int ra = (code & 1) ? 12 : 0;
-                    g += rec[ra + ka] * rec[26] + rec[ra + 6 + ka] * rec[27];
-                }
-            }
+            if (kb < 6 && bact) h += p.Hv[(size_t)(fa * d.F + fb) * 36 + 6 * ka + kb];
+            if (want_g) g += p.gv[6 * fa + ka];
             if (ka < 3) {
                 const int s = p.rotf_start[fa], t = p.rotf_start[fa + 1];
                 for (int it = s; it < t; ++it) {
@@ -435,7 +489,7 @@ __global__ __launch_bounds__(256) void kb_assemble(BaDims d, BaPtrs p) {
                 }
             }
         }
-        // IMU factors: k0 has j == fa, k1 has i == fa
+        // IMU factors: side 0 has j == fa, side 1 has i == fa
         for (int side = 0; side < 2; ++side) {
             const int k = p.imuf[2 * fa + side];
             if (k < 0) continue;
@@ -541,144 +595,116 @@ __global__ __launch_bounds__(256) void kb_schur_mfma(BaDims d, BaPtrs p) {
 }
 
 // -------------------------------------------------------------------- the solve
-// full quadratic form v^T Hs v over frames + landmarks (Hs = Jacobi-scaled Hessian); block-wide
+// full quadratic form v^T Hs v over frames + landmarks (Hs = Jacobi-scaled Hessian); block-wide.
+// One wavefront per matrix row with the lanes striding over the columns, so every load is coalesced.
 __device__ __forceinline__ double quad_form(const BaDims &d, const BaPtrs &p, const double *v, double *scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     double acc = 0;
-    for (int a = threadIdx.x; a < d.n; a += blockDim.x) {
+    for (int a = wave; a < d.n; a += nw) {
         const double *row = p.Hpp + (size_t)a * d.n;
         double s = 0;
-        for (int b = 0; b < d.n; ++b) s += row[b] * p.sp[b] * v[b];
-        acc += v[a] * p.sp[a] * s;
+        for (int b = lane; b < d.n; b += 64) s += row[b] * p.sp[b] * v[b];
+        s = wave_sum(s);
+        if (lane == 0) acc += v[a] * p.sp[a] * s;
     }
-    for (int l = threadIdx.x; l < d.L; l += blockDim.x) {
+    for (int l = wave; l < d.L; l += nw) {
         if (!p.lact[l]) continue;
         const double *row = p.Wt + (size_t)l * d.PF;
         const double vl = v[d.n + l] * p.sl[l];
         double s = 0;
-        for (int f = 0; f < d.F; ++f)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s += row[6 * f + k] * p.sp[15 * f + k] * v[15 * f + k];
-        acc += 2.0 * vl * s + vl * vl * p.hll[l];
+        for (int c = lane; c < 6 * d.F; c += 64) {
+            const int f = c / 6, k = c - 6 * f;
+            s += row[c] * p.sp[15 * f + k] * v[15 * f + k];
+        }
+        s = wave_sum(s);
+        if (lane == 0) acc += 2.0 * vl * s + vl * vl * p.hll[l];
     }
     return block_sum(acc, scratch);
 }
 
-XD int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // packed lower triangle, j <= i
-
-// Reduced system + Cholesky + Gauss-Newton / Cauchy quantities.  One workgroup.
-// Dynamic LDS: packed lower triangle of the reduced matrix when it fits (use_lds), plus vectors.
+// Reduced camera system + blocked Cholesky + Gauss-Newton / Cauchy quantities.  One workgroup.
+// Only the `na` free frame dofs enter the factorisation (localize_newframe has 15, refine_window 15 F).
+// Dynamic LDS: rhs [na] + packed lower triangle when it fits (use_lds); otherwise the triangle lives in Sred.
 __global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds) {
     extern __shared__ double lds[];
     __shared__ double scratch[8];
+    __shared__ double Dblk[CH_NB][CH_NB + 1];
     __shared__ int fail;
     BaCtl *c = p.ctl;
-    const int n = d.n, tid = threadIdx.x, nt = blockDim.x;
-    double *y = lds;              // [n] rhs / solution
-    double *A = lds + ((n + 1) & ~1);   // packed lower (LDS) ...
-    if (!use_lds) A = nullptr;
+    const int n = d.n, na = d.na, tid = threadIdx.x, nt = blockDim.x;
+    double *y = lds;                                   // [na] rhs / solution (compact)
+    double *A = use_lds ? lds + ((na + 1) & ~1) : p.Sred;   // packed lower triangle (compact)
     const double mu = c->mu;
-    if (tid == 0) fail = 0;
-    // ---- assemble  S = sp (Hpp - T) sp + mu D^2   (inactive dofs pinned), rhs = sp (gp - W^T (omega gl))
-    for (int e = tid; e < n * n; e += nt) {
-        const int a = e / n, b = e - a * n;
-        if (b > a) continue;
-        const bool act = dof_active(p.fix, a) && dof_active(p.fix, b);
-        double v = 0.0;
-        if (act) {
-            v = p.Hpp[e];
-            const int fa = a / 15, ka = a - 15 * fa, fb = b / 15, kb = b - 15 * fb;
-            if (ka < 6 && kb < 6) v -= p.T[(size_t)(6 * fa + ka) * d.PF + 6 * fb + kb];
-            v *= p.sp[a] * p.sp[b];
-            if (a == b) v += mu * p.diagD[a] * p.diagD[a];
-        } else if (a == b) {
-            v = 1.0;
-        }
-        if (use_lds) A[tri(a, b)] = v;
-        else p.Sred[(size_t)a * n + b] = v;
+    // ---- S = sp (Hpp - T) sp + mu D^2 over the free dofs, rhs = sp (gp - W^T (omega gl))
+    for (int e = tid; e < na * na; e += nt) {
+        const int i = e / na, j = e - i * na;
+        if (j > i) continue;
+        const int a = p.act_idx[i], b = p.act_idx[j];
+        double v = p.Hpp[(size_t)a * n + b];
+        const int fa = a / 15, ka = a - 15 * fa, fb = b / 15, kb = b - 15 * fb;
+        if (ka < 6 && kb < 6) v -= p.T[(size_t)(6 * fa + ka) * d.PF + 6 * fb + kb];
+        v *= p.sp[a] * p.sp[b];
+        if (a == b) v += mu * p.diagD[a] * p.diagD[a];
+        A[tri_idx(i, j)] = v;
     }
-    for (int a = tid; a < n; a += nt) {
-        double v = 0.0;
-        if (dof_active(p.fix, a)) {
-            v = p.gp[a];
+    {
+        const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+        for (int i = wave; i < na; i += nw) {
+            const int a = p.act_idx[i];
             const int fa = a / 15, ka = a - 15 * fa;
-            if (ka < 6) {
-                double s = 0;
-                for (int l = 0; l < d.L; ++l) s += p.Wt[(size_t)l * d.PF + 6 * fa + ka] * (p.omega[l] * p.gl[l]);
-                v -= s;
-            }
-            v *= p.sp[a];
+            double sacc = 0;
+            if (ka < 6)
+                for (int l = lane; l < d.L; l += 64) sacc += p.Wt[(size_t)l * d.PF + 6 * fa + ka] * (p.omega[l] * p.gl[l]);
+            sacc = wave_sum(sacc);
+            if (lane == 0) y[i] = (p.gp[a] - sacc) * p.sp[a];
         }
-        y[a] = v;
     }
     __syncthreads();
-    // ---- Cholesky (left-looking, column by column)
-#define AE(i, j) (use_lds ? A[tri(i, j)] : p.Sred[(size_t)(i)*n + (j)])
-    for (int j = 0; j < n; ++j) {
-        for (int i = j + tid; i < n; i += nt) {
-            double s = AE(i, j);
-            for (int k = 0; k < j; ++k) s -= AE(i, k) * AE(j, k);
-            if (use_lds) A[tri(i, j)] = s;
-            else p.Sred[(size_t)i * n + j] = s;
-        }
-        __syncthreads();
-        const double djj = AE(j, j);
-        if (!(djj > 0.0) || !isfinite(djj)) {
-            if (tid == 0) fail = 1;
-        }
-        __syncthreads();
-        if (fail) break;
-        const double dj = sqrt(djj);
-        for (int i = j + tid; i < n; i += nt) {
-            const double v = (i == j) ? dj : AE(i, j) / dj;
-            if (use_lds) A[tri(i, j)] = v;
-            else p.Sred[(size_t)i * n + j] = v;
-        }
-        __syncthreads();
-    }
-    if (fail) {
+    const bool ok = chol_blocked(A, na, Dblk, &fail);
+    if (!ok) {
         if (tid == 0) c->linear_ok = 0;
         return;
     }
-    // ---- forward / backward substitution
-    for (int j = 0; j < n; ++j) {
-        if (tid == 0) y[j] = y[j] / AE(j, j);
-        __syncthreads();
-        const double yj = y[j];
-        for (int i = j + 1 + tid; i < n; i += nt) y[i] -= AE(i, j) * yj;
-        __syncthreads();
-    }
-    for (int j = n - 1; j >= 0; --j) {
-        if (tid == 0) y[j] = y[j] / AE(j, j);
-        __syncthreads();
-        const double yj = y[j];
-        for (int i = tid; i < j; i += nt) y[i] -= AE(j, i) * yj;
-        __syncthreads();
-    }
-#undef AE
+    trsv_lower(A, na, y);
+    trsv_lower_t(A, na, y);
     // ---- Gauss-Newton step (scaled space), landmark back-substitution, dogleg gradient
-    int bad = 0;
     for (int a = tid; a < n; a += nt) {
-        const double D = p.diagD[a];
-        const double ya = dof_active(p.fix, a) ? y[a] : 0.0;
-        p.gn[a] = -D * ya;
-        p.grad[a] = dof_active(p.fix, a) ? p.gs[a] / D : 0.0;
+        p.gn[a] = 0.0;
+        p.grad[a] = dof_active(p.fix, a) ? p.gs[a] / p.diagD[a] : 0.0;
+        p.delta[a] = 0.0;   // delta doubles as the full-layout y (frame part) for the back-substitution below
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int i = tid; i < na; i += nt) {
+        const int a = p.act_idx[i];
+        const double ya = y[i];
+        p.gn[a] = -p.diagD[a] * ya;
+        p.delta[a] = ya;
         if (!isfinite(ya)) bad = 1;
     }
-    for (int l = tid; l < d.L; l += nt) {
-        double yl = 0.0;
-        const double D = p.diagD[n + l];
-        if (p.lact[l]) {
-            const double s = p.sl[l];
-            const double *row = p.Wt + (size_t)l * d.PF;
-            double w = 0;
-            for (int f = 0; f < d.F; ++f)
-#pragma unroll
-                for (int k = 0; k < 6; ++k) w += row[6 * f + k] * p.sp[15 * f + k] * y[15 * f + k];
-            yl = (s * p.gl[l] - s * w) / (s * s * p.hll[l] + mu * D * D);
-            if (!isfinite(yl)) bad = 1;
+    __syncthreads();
+    {
+        const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+        for (int l = wave; l < d.L; l += nw) {
+            double yl = 0.0;
+            const double D = p.diagD[n + l];
+            if (p.lact[l]) {
+                const double sl = p.sl[l];
+                const double *row = p.Wt + (size_t)l * d.PF;
+                double w = 0;
+                for (int cidx = lane; cidx < 6 * d.F; cidx += 64) {
+                    const int f = cidx / 6, k = cidx - 6 * f;
+                    w += row[cidx] * p.sp[15 * f + k] * p.delta[15 * f + k];
+                }
+                w = wave_sum(w);
+                yl = (sl * p.gl[l] - sl * w) / (sl * sl * p.hll[l] + mu * D * D);
+                if (!isfinite(yl)) bad = 1;
+            }
+            if (lane == 0) {
+                p.gn[n + l] = -D * yl;
+                p.grad[n + l] = p.lact[l] ? p.gs[n + l] / D : 0.0;
+            }
         }
-        p.gn[n + l] = -D * yl;
-        p.grad[n + l] = p.lact[l] ? p.gs[n + l] / D : 0.0;
     }
     if (bad) atomicExch(&fail, 1);
     __syncthreads();
@@ -904,7 +930,10 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
         double cost = 0;
         for (int o = tid; o < d.M; o += nt) cost += obs_eval(d, p, o, p.cand, p.depth_cand, cam, sx, sy, false, nullptr);
         for (int o = tid; o < d.MR; o += nt) cost += rot_eval(d, p, o, p.cand, cam, sx, sy, false, nullptr);
-        for (int k = tid; k < d.NI; k += nt) cost += imu_cost_eval(p, k, p.cand, imu);
+        {   // IMU factors: one wavefront each (lane 0 does the SO(3) algebra, lanes 0..14 the whitening rows)
+            const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+            for (int k = wave; k < d.NI; k += nw) cost += imu_cost_wave(p, k, p.cand, imu, lane);
+        }
         cost = block_sum(cost, scratch);
         if (d.NP > 0) cost += prior_cost_block(d, p, p.cand, sh, scratch, nullptr);
         if (!isfinite(cost)) cost = 1.7976931348623157e308;
