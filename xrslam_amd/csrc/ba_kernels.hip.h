@@ -117,6 +117,24 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
     return s;
 }
 
+// deterministic block-wide sum of N values at once (2 barriers); scratch must hold N * blockDim.x/64 doubles
+template <int N> __device__ __forceinline__ void block_sum_n(double (&v)[N], double *scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < N; ++k) scratch[k * nw + w] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double s = 0;
+        for (int i = 0; i < nw; ++i) s += scratch[k * nw + i];
+        v[k] = s;
+    }
+}
+
 // --------------------------------------------------------------- reprojection factors
 // One thread per observation.  use_cand selects the candidate state (cost only).
 __device__ __forceinline__ double obs_eval(const BaDims &d, const BaPtrs &p, int o, const double *state,
@@ -795,7 +813,7 @@ __device__ __forceinline__ double ambient_norm2(const BaDims &d, const BaPtrs &p
 __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy,
                                               int after_linearisation) {
     extern __shared__ double sh[];   // np doubles for the prior delta
-    __shared__ double scratch[8];
+    __shared__ double scratch[32];
     __shared__ int s_status;
     BaCtl *c = p.ctl;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -822,6 +840,21 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
     }
     bool check_gradient = (mode == 1);   // the iteration that led here was successful
     bool skip_finalize = (mode == 3);
+    // |gradient|, |gauss-newton step| and their inner product stay the same for every trial of this launch
+    double gnorm, gn_norm, gd;
+    {
+        double r3[3] = {0, 0, 0};
+        for (int a = tid; a < d.NV; a += nt) {
+            r3[0] += p.grad[a] * p.grad[a];
+            r3[1] += p.gn[a] * p.gn[a];
+            r3[2] += p.grad[a] * p.gn[a];
+        }
+        block_sum_n<3>(r3, scratch);
+        gnorm = sqrt(r3[0]);
+        gn_norm = sqrt(r3[1]);
+        gd = r3[2];
+        __syncthreads();
+    }
     while (true) {
         // ---- finalize checks + start of the next iteration
         if (tid == 0) {
@@ -861,17 +894,8 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
         check_gradient = false;
         __syncthreads();
         if (s_status != ST_RUNNING) break;
-        // ---- traditional dogleg for the current radius
-        double g2 = 0, n2 = 0, gd = 0;
-        for (int a = tid; a < d.NV; a += nt) {
-            g2 += p.grad[a] * p.grad[a];
-            n2 += p.gn[a] * p.gn[a];
-            gd += p.grad[a] * p.gn[a];
-        }
-        g2 = block_sum(g2, scratch);
-        n2 = block_sum(n2, scratch);
-        gd = block_sum(gd, scratch);
-        const double gnorm = sqrt(g2), gn_norm = sqrt(n2), radius = c->radius, alpha = c->alpha;
+        // ---- traditional dogleg for the current radius (|grad|, |gn|, grad.gn were reduced once per launch)
+        const double radius = c->radius, alpha = c->alpha;
         double ca = 0, cb = 0, step_norm = 0;   // step(scaled by D) = ca * grad + cb * gn
         if (gn_norm <= radius) {
             cb = 1.0;
@@ -890,19 +914,19 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
             cb = beta;
             step_norm = -1.0;
         }
-        double sn2 = 0, sg = 0;
+        double red2[2] = {0, 0};   // |step|^2 (D-scaled), step . gs
         for (int a = tid; a < d.NV; a += nt) {
             const double v = ca * p.grad[a] + cb * p.gn[a];
-            sn2 += v * v;
+            red2[0] += v * v;
             const double st = v / p.diagD[a];
             p.step[a] = st;
-            sg += st * p.gs[a];
+            red2[1] += st * p.gs[a];
             const double sc = a < d.n ? p.sp[a] : p.sl[a - d.n];
             p.delta[a] = st * sc;
         }
-        sn2 = block_sum(sn2, scratch);
-        sg = block_sum(sg, scratch);
-        if (step_norm < 0) step_norm = sqrt(sn2);
+        block_sum_n<2>(red2, scratch);
+        const double sg = red2[1];
+        if (step_norm < 0) step_norm = sqrt(red2[0]);
         __syncthreads();
         const double shs = quad_form(d, p, p.step, scratch);
         const double model_cost_change = -sg - 0.5 * shs;
@@ -927,28 +951,42 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
             state_plus(p.state + 16 * f, p.delta + 15 * f, pose_free(p.fix[f]), motion_free(p.fix[f]), p.cand + 16 * f);
         for (int l = tid; l < d.L; l += nt) p.depth_cand[l] = p.depth[l] + (p.lact[l] ? p.delta[d.n + l] : 0.0);
         __syncthreads();
-        double cost = 0;
-        for (int o = tid; o < d.M; o += nt) cost += obs_eval(d, p, o, p.cand, p.depth_cand, cam, sx, sy, false, nullptr);
-        for (int o = tid; o < d.MR; o += nt) cost += rot_eval(d, p, o, p.cand, cam, sx, sy, false, nullptr);
-        {   // IMU factors: one wavefront each (lane 0 does the SO(3) algebra, lanes 0..14 the whitening rows)
-            const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-            for (int k = wave; k < d.NI; k += nw) cost += imu_cost_wave(p, k, p.cand, imu, lane);
+        for (int i = tid; i < d.NP; i += nt) {   // prior delta at the candidate, staged for the row products
+            double dl[15];
+            prior_delta(p, i, p.cand, dl, nullptr);
+            for (int k = 0; k < 15; ++k) sh[15 * i + k] = dl[k];
         }
-        cost = block_sum(cost, scratch);
-        if (d.NP > 0) cost += prior_cost_block(d, p, p.cand, sh, scratch, nullptr);
-        if (!isfinite(cost)) cost = 1.7976931348623157e308;
-        // ambient step norm |x - candidate|
-        double dn = 0;
+        __syncthreads();
+        double red[2] = {0, 0};   // cost, |x - candidate|^2
+        for (int o = tid; o < d.M; o += nt) red[0] += obs_eval(d, p, o, p.cand, p.depth_cand, cam, sx, sy, false, nullptr);
+        for (int o = tid; o < d.MR; o += nt) red[0] += rot_eval(d, p, o, p.cand, cam, sx, sy, false, nullptr);
+        {   // IMU factors and prior rows: one wavefront each (coalesced)
+            const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+            for (int k = wave; k < d.NI; k += nw) red[0] += imu_cost_wave(p, k, p.cand, imu, lane);
+            for (int i = wave; i < d.np; i += nw) {
+                const double *row = p.pS + (size_t)i * d.np;
+                double s = 0;
+                for (int j = lane; j < d.np; j += 64) s += row[j] * sh[j];
+                s = wave_sum(s);
+                if (lane == 0) {
+                    s += p.pinfo[i];
+                    red[0] += 0.5 * s * s;
+                }
+            }
+        }
         for (int f = tid; f < d.F; f += nt) {
             const double *a = p.state + 16 * f, *b = p.cand + 16 * f;
             if (pose_free(p.fix[f]))
-                for (int k = 0; k < 7; ++k) dn += (a[k] - b[k]) * (a[k] - b[k]);
+                for (int k = 0; k < 7; ++k) red[1] += (a[k] - b[k]) * (a[k] - b[k]);
             if (motion_free(p.fix[f]))
-                for (int k = 7; k < 16; ++k) dn += (a[k] - b[k]) * (a[k] - b[k]);
+                for (int k = 7; k < 16; ++k) red[1] += (a[k] - b[k]) * (a[k] - b[k]);
         }
         for (int l = tid; l < d.L; l += nt)
-            if (p.lact[l]) dn += (p.depth[l] - p.depth_cand[l]) * (p.depth[l] - p.depth_cand[l]);
-        dn = sqrt(block_sum(dn, scratch));
+            if (p.lact[l]) red[1] += (p.depth[l] - p.depth_cand[l]) * (p.depth[l] - p.depth_cand[l]);
+        block_sum_n<2>(red, scratch);
+        double cost = red[0];
+        if (!isfinite(cost)) cost = 1.7976931348623157e308;
+        const double dn = sqrt(red[1]);
         // ---- decisions (uniform across the workgroup)
         const double x_cost = c->x_cost;
         int st = ST_RUNNING;

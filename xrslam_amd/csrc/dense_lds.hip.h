@@ -82,17 +82,25 @@ __device__ __forceinline__ bool chol_blocked(double *A, int n, double (*D)[CH_NB
                 if (c < nb) row[c] = x[c];
         }
         __syncthreads();
-        // ---- (3) trailing update: A[i][k] -= sum_c L[i][j0+c] L[k][j0+c],  jb <= k <= i < n
-        const int m = n - jb;
-        for (int e = tid; e < m * m; e += nt) {
-            const int ii = e / m, kk = e - ii * m;
-            if (kk > ii) continue;
-            const double *ri = A + tri_idx(jb + ii, j0), *rk = A + tri_idx(jb + kk, j0);
-            double s = 0;
+        // ---- (3) trailing update: A[i][k] -= sum_c L[i][j0+c] L[k][j0+c],  jb <= k <= i < n.
+        // One wavefront per row i (its panel row is read once, as an LDS broadcast), lanes over k.
+        {
+            const int nw = nt >> 6;
+            for (int i = jb + wave; i < n; i += nw) {
+                const double *ri = A + tri_idx(i, j0);
+                double li[CH_NB];
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c)
-                if (c < nb) s += ri[c] * rk[c];
-            A[tri_idx(jb + ii, jb + kk)] -= s;
+                for (int c = 0; c < CH_NB; ++c) li[c] = (c < nb) ? ri[c] : 0.0;
+                double *out = A + tri_idx(i, jb);
+                for (int k = jb + lane; k <= i; k += 64) {
+                    const double *rk = A + tri_idx(k, j0);
+                    double s = 0;
+#pragma unroll
+                    for (int c = 0; c < CH_NB; ++c)
+                        if (c < nb) s += li[c] * rk[c];
+                    out[k - jb] -= s;
+                }
+            }
         }
         __syncthreads();
     }

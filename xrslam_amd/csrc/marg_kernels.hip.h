@@ -15,6 +15,7 @@
 //   km_finish      sqrt_info = diag(sqrt(lambda)) V^T, infovec = diag(1/sqrt(lambda)) V^T b' (lambda <= 1e-8 -> 0)
 #pragma once
 #include "ba_kernels.hip.h"
+#include "dense_lds.hip.h"
 
 namespace xrhip {
 
@@ -223,6 +224,66 @@ __global__ __launch_bounds__(1024) void km_jacobi(int R, int G, const double *__
     if (tid == 0) *sweeps_out = sweep;
 }
 
+// Cholesky fast path of "create marginalization factor" (marginalization_factor.h:440-455).  When every
+// eigenvalue of the marginal information matrix A exceeds the reference's 1e-8 floor, no eigen-direction is
+// dropped and ANY factor S with S^T S = A carries the same prior: S = L^T (A = L L^T), infovec = L^-1 b'
+// reproduce Lambda = S^T S and eta = S^T infovec exactly like diag(sqrt(lambda)) V^T would.  The kernel
+// factors A in LDS and bounds lambda_min from above by inverse iteration; the caller falls back to the
+// Jacobi eigen-solver (km_jacobi) when the factorisation fails or the bound is not comfortably above the floor.
+__global__ __launch_bounds__(512) void km_chol(int R, const double *__restrict__ A, const double *__restrict__ bp,
+                                               double *__restrict__ sqrt_info, double *__restrict__ infovec,
+                                               double *__restrict__ lam_est, int *__restrict__ status) {
+    extern __shared__ double lds[];
+    __shared__ double Dblk[CH_NB][CH_NB + 1];
+    __shared__ double scratch[8];
+    __shared__ int fail;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double *x = lds, *y = lds + ((R + 1) & ~1), *Lp = y + ((R + 1) & ~1);
+    for (int e = tid; e < R * R; e += nt) {
+        const int i = e / R, j = e - i * R;
+        if (j <= i) Lp[tri_idx(i, j)] = A[e];
+    }
+    __syncthreads();
+    if (!chol_blocked(Lp, R, Dblk, &fail)) {
+        if (tid == 0) status[2] = 1;
+        return;
+    }
+    for (int i = tid; i < R; i += nt) y[i] = bp[i];
+    __syncthreads();
+    trsv_lower(Lp, R, y);
+    for (int i = tid; i < R; i += nt) infovec[i] = y[i];
+    for (int e = tid; e < R * R; e += nt) {
+        const int i = e / R, j = e - i * R;
+        sqrt_info[e] = (j >= i) ? Lp[tri_idx(j, i)] : 0.0;
+    }
+    // inverse iteration: 1 / |A^-1 x| for unit x is an upper bound of lambda_min that converges to it
+    for (int i = tid; i < R; i += nt) x[i] = 1.0 + 0.5 * sin(1.7 * i + 0.3);
+    __syncthreads();
+    double lam = 0;
+    for (int it = 0; it < 12; ++it) {
+        double n2 = 0;
+        for (int i = tid; i < R; i += nt) n2 += x[i] * x[i];
+        n2 = block_sum(n2, scratch);
+        const double inv = 1.0 / sqrt(n2);
+        for (int i = tid; i < R; i += nt) y[i] = x[i] * inv;
+        __syncthreads();
+        trsv_lower(Lp, R, y);
+        trsv_lower_t(Lp, R, y);
+        double m2 = 0;
+        for (int i = tid; i < R; i += nt) {
+            m2 += y[i] * y[i];
+            x[i] = y[i];
+        }
+        m2 = block_sum(m2, scratch);
+        lam = 1.0 / sqrt(m2);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        lam_est[0] = lam;
+        status[3] = (isfinite(lam) && lam > 1.0e-6) ? 0 : 1;
+    }
+}
+
 // sqrt_info row i = sqrt(lambda_i) v_i^T, infovec_i = v_i . b' / sqrt(lambda_i), eigenvalues <= 1e-8 dropped.
 __global__ __launch_bounds__(64) void km_finish(int R, const double *__restrict__ B, const double *__restrict__ V,
                                                 const double *__restrict__ bp, double *__restrict__ sqrt_info,
@@ -275,6 +336,32 @@ __global__ __launch_bounds__(256) void kp_preintegrate(const PreintJob *__restri
     }
     __syncthreads();
     const V3 bg = v3(job.bg[0], job.bg[1], job.bg[2]), ba = v3(job.ba[0], job.ba[1], job.ba[2]);
+    if (!want_cov && !want_jac) {
+        // the tracker's form (feature_tracker.cpp:55-57,89-91): only delta q/p/v -- one lane, no barriers
+        if (tid == 0) {
+            Q4 q = Q4{0, 0, 0, 1};
+            V3 pv = v3(0, 0, 0), vv = v3(0, 0, 0);
+            double T = 0;
+            for (int n = 0; n < job.sample_count; ++n) {
+                const double *smp = samples + (size_t)(job.sample_begin + n) * 7;
+                const double t1 = (n + 1 < job.sample_count) ? smp[7] : job.t_end;
+                const double dt = t1 - smp[0];
+                const V3 w = v3(smp[1], smp[2], smp[3]) - bg;
+                const V3 a = v3(smp[4], smp[5], smp[6]) - ba;
+                const V3 qa = q_rot(q, a);
+                pv = pv + vv * dt + qa * (0.5 * dt * dt);
+                vv = vv + qa * dt;
+                q = q_normalized(q_mul(q, expmap(w * dt)));
+                T = T + dt;
+            }
+            o[0] = T;
+            o[1] = q.x; o[2] = q.y; o[3] = q.z; o[4] = q.w;
+            o[5] = pv.x; o[6] = pv.y; o[7] = pv.z;
+            o[8] = vv.x; o[9] = vv.y; o[10] = vv.z;
+        }
+        for (int e = 11 + tid; e < XRHIP_IMU_DIM; e += blockDim.x) o[e] = 0.0;
+        return;
+    }
     for (int n = 0; n < job.sample_count; ++n) {
         const double *smp = samples + (size_t)(job.sample_begin + n) * 7;
         const double t1 = (n + 1 < job.sample_count) ? smp[7] : job.t_end;
