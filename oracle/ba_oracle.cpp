@@ -1216,6 +1216,11 @@ int orc_ba_marginalize(const xrhip_marg_problem *M, double *out_sqrt_info, doubl
     for (int i = 0; i < R; ++i)
         for (int j = 0; j < i; ++j) Hr(j, i) = Hr(i, j);
     sym_eigen(Hr, w, V);
+    if (std::getenv("ORC_MARG_TRACE")) {
+        int nsmall = 0;
+        for (int i = 0; i < R; ++i) nsmall += !(w[i] > 1.0e-8);
+        std::fprintf(stderr, "marg R=%d lambda_min=%.3e lambda_2=%.3e lambda_max=%.3e  clamped=%d\n", R, w[0], w[1], w[R - 1], nsmall);
+    }
     for (int i = 0; i < R; ++i) {
         const double lam = w[i] > 1.0e-8 ? w[i] : 0.0;
         const double lam_inv = w[i] > 1.0e-8 ? 1.0 / w[i] : 0.0;

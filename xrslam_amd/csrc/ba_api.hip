@@ -363,6 +363,7 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
     XR_HIP(hipFuncSetAttribute((const void *)kb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)kb_try, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     XR_HIP(hipFuncSetAttribute((const void *)km_chol, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+    XR_HIP(hipFuncSetAttribute((const void *)km_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     // pre-size for the advertised maxima
     size_t in_guess = (size_t)max_obs * 96 + (size_t)max_frames * max_frames * 15 * 15 * 8 + (size_t)max_frames * 3000 + 65536;
     rc = ensure_arena(c, in_guess, in_guess * 4, (size_t)16 * max_frames + max_landmarks + 8);
@@ -622,7 +623,8 @@ int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_s
     const size_t o_Hm = carve(D8 * (size_t)N * N), o_bm = carve(D8 * N), o_T2 = carve(D8 * (size_t)R * 15);
     const size_t o_A = carve(D8 * (size_t)R * R), o_bp = carve(D8 * R), o_B = carve(D8 * (size_t)R * R);
     const size_t o_V = carve(D8 * (size_t)R * R), o_si = carve(D8 * (size_t)R * R), o_iv = carve(D8 * R);
-    const size_t o_st = carve(sizeof(int) * 4), o_lam = carve(D8 * 2);
+    const size_t o_st = carve(sizeof(int) * 4), o_lam = carve(D8 * 2), o_sup = carve(sizeof(int) * (size_t)R);
+    const size_t o_As = carve(D8 * (size_t)R * R), o_bs = carve(D8 * R), o_Ss = carve(D8 * (size_t)R * R), o_ivs = carve(D8 * R);
     rc = ensure_work2(c, w + 256, D8 * ((size_t)R * R + R) + 64);
     if (rc) return rc;
     char *W2 = c->work2;
@@ -642,30 +644,27 @@ int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_s
     hipLaunchKernelGGL(km_complement, dim3((R * R + 255) / 256), dim3(256), 0, s, N, Hm, bm, T2, A, bp);
     double *hs = (double *)c->h_stage;
     int hst[4] = {0, 0, 0, 0};
-    const size_t chol_lds = D8 * (2 * (size_t)((R + 1) & ~1) + (size_t)R * (R + 1) / 2);
-    bool need_jacobi = true;
-    if (chol_lds <= (size_t)c->lds_limit) {
-        // fast path: Cholesky factor as sqrt_info (valid whenever no eigenvalue is at the 1e-8 floor)
-        hipLaunchKernelGGL(km_chol, dim3(1), dim3(512), chol_lds, s, R, A, bp, dsi, div, (double *)(W2 + o_lam), dst);
+    int *dsup = (int *)(W2 + o_sup), *dsn = dst + 1;
+    double *As = (double *)(W2 + o_As), *bs = (double *)(W2 + o_bs), *Ss = (double *)(W2 + o_Ss), *ivs = (double *)(W2 + o_ivs);
+    if (R > 512) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: window too large");
+    const int lds_doubles = c->lds_limit / (int)D8;
+    hipLaunchKernelGGL(km_support, dim3(1), dim3(512), 0, s, R, A, bp, dsup, dsn, As, bs);
+    // fast path: Cholesky factor of the compacted matrix as sqrt_info (valid when no eigenvalue is near the 1e-8 floor)
+    hipLaunchKernelGGL(km_chol, dim3(1), dim3(512), (size_t)c->lds_limit, s, dsn, lds_doubles, As, bs, Ss, ivs,
+                       (double *)(W2 + o_lam), dst);
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, s));
+    XR_HIP(hipStreamSynchronize(s));
+    if (!hst[0] && (hst[2] != 0 || hst[3] != 0)) {
+        hipLaunchKernelGGL(km_jacobi, dim3(1), dim3(1024), (size_t)c->lds_limit, s, dsn, lds_doubles, As, bs, B, V, Ss, ivs,
+                           60, dst + 2);
         XR_HIP(hipGetLastError());
-        XR_HIP(hipMemcpyAsync(hs, dsi, D8 * (size_t)R * R, hipMemcpyDeviceToHost, s));
-        XR_HIP(hipMemcpyAsync(hs + (size_t)R * R, div, D8 * R, hipMemcpyDeviceToHost, s));
-        XR_HIP(hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, s));
-        XR_HIP(hipStreamSynchronize(s));
-        need_jacobi = hst[2] != 0 || hst[3] != 0;
     }
-    if (need_jacobi && !hst[0]) {
-        int G = 8;
-        while (G > 1 && ((R + 1) / 2) * G > 1024) G >>= 1;
-        if (((R + 1) / 2) * G > 1024) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: window too large for the Jacobi kernel");
-        hipLaunchKernelGGL(km_jacobi, dim3(1), dim3(1024), 0, s, R, G, A, B, V, 60, dst + 1);
-        hipLaunchKernelGGL(km_finish, dim3(R), dim3(64), 0, s, R, B, V, bp, dsi, div);
-        XR_HIP(hipGetLastError());
-        XR_HIP(hipMemcpyAsync(hs, dsi, D8 * (size_t)R * R, hipMemcpyDeviceToHost, s));
-        XR_HIP(hipMemcpyAsync(hs + (size_t)R * R, div, D8 * R, hipMemcpyDeviceToHost, s));
-        XR_HIP(hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, s));
-        XR_HIP(hipStreamSynchronize(s));
-    }
+    hipLaunchKernelGGL(km_expand, dim3((R * R + 255) / 256), dim3(256), 0, s, R, dsup, dsn, Ss, ivs, dsi, div);
+    XR_HIP(hipGetLastError());
+    XR_HIP(hipMemcpyAsync(hs, dsi, D8 * (size_t)R * R, hipMemcpyDeviceToHost, s));
+    XR_HIP(hipMemcpyAsync(hs + (size_t)R * R, div, D8 * R, hipMemcpyDeviceToHost, s));
+    XR_HIP(hipStreamSynchronize(s));
     if (hst[0]) return xr_fail(XRHIP_ESTATE, "xrhip_ba_marginalize: singular victim block");
     std::memcpy(out_sqrt_info, hs, D8 * (size_t)R * R);
     std::memcpy(out_infovec, hs + (size_t)R * R, D8 * R);

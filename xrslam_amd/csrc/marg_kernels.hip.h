@@ -144,26 +144,85 @@ __global__ __launch_bounds__(256) void km_complement(int N, const double *__rest
     }
 }
 
-// Parallel one-sided (Hestenes) Jacobi on the symmetric matrix A: B = A V is driven to orthogonal columns by
-// plane rotations applied to column pairs; the R/2 pairs of a round-robin round are disjoint and processed
-// concurrently by G-thread groups.  B, V are column-major R x R in global memory (L2 resident).
-// On exit column i of V is an eigenvector and lambda_i = v_i . b_i.
-__global__ __launch_bounds__(1024) void km_jacobi(int R, int G, const double *__restrict__ A, double *__restrict__ B,
-                                                  double *__restrict__ V, int max_sweeps, int *__restrict__ sweeps_out) {
-    __shared__ int rotated;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int e = tid; e < R * R; e += nt) {
-        const int c = e / R, r = e - c * R;
-        B[e] = A[(size_t)r * R + c];   // column-major copy (A symmetric)
-        V[e] = (r == c) ? 1.0 : 0.0;
+// Support of the marginal information matrix.  Frames that share neither a landmark, an IMU factor nor the old
+// prior with the victim have exactly zero rows/columns in A (no factor touches them), e.g. all velocity/bias
+// dofs of frames that are only connected through vision.  Those rows are zero eigen-directions of the
+// reference's SelfAdjointEigenSolver (eigenvalue 0 <= 1e-8 -> dropped), so the decomposition is done on the
+// compacted matrix and the result is scattered back with zero rows -- identical Lambda = S^T S and eta.
+__global__ __launch_bounds__(512) void km_support(int R, const double *__restrict__ A, const double *__restrict__ bp,
+                                                  int *__restrict__ sup_idx, int *__restrict__ sup_n,
+                                                  double *__restrict__ As, double *__restrict__ bs) {
+    __shared__ int flags[512], pos[512], total;
+    const int tid = threadIdx.x;
+    int f = 0;
+    if (tid < R) {
+        const double *row = A + (size_t)tid * R;
+        for (int j = 0; j < R; ++j)
+            if (row[j] != 0.0) {
+                f = 1;
+                break;
+            }
+    }
+    flags[tid] = f;
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        for (int i = 0; i < R; ++i) {
+            pos[i] = c;
+            if (flags[i]) sup_idx[c++] = i;
+        }
+        total = c;
+        *sup_n = c;
     }
     __syncthreads();
+    const int Rs = total;
+    for (int e = tid; e < Rs * Rs; e += blockDim.x) {
+        const int i = e / Rs, j = e - i * Rs;
+        As[e] = A[(size_t)sup_idx[i] * R + sup_idx[j]];
+    }
+    for (int i = tid; i < Rs; i += blockDim.x) bs[i] = bp[sup_idx[i]];
+}
+
+// scatter the compact factor back: sqrt_info [R x R] (zero outside the support), infovec [R]
+__global__ __launch_bounds__(256) void km_expand(int R, const int *__restrict__ sup_idx, const int *__restrict__ sup_n,
+                                                 const double *__restrict__ Ss, const double *__restrict__ ivs,
+                                                 double *__restrict__ sqrt_info, double *__restrict__ infovec) {
+    const int Rs = *sup_n;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= R * R) return;
+    const int i = e / R, j = e - i * R;
+    // row i of the full factor = row i of the compact factor (rows >= Rs are zero), columns scattered
+    double v = 0.0;
+    if (i < Rs) {
+        // find j in the support (sup_idx ascending): binary search
+        int lo = 0, hi = Rs - 1;
+        while (lo <= hi) {
+            const int mid = (lo + hi) >> 1;
+            const int sj = sup_idx[mid];
+            if (sj == j) {
+                v = Ss[(size_t)i * Rs + mid];
+                break;
+            }
+            if (sj < j) lo = mid + 1;
+            else hi = mid - 1;
+        }
+    }
+    sqrt_info[e] = v;
+    if (j == 0) infovec[i] = (i < Rs) ? ivs[i] : 0.0;
+}
+
+// Parallel one-sided (Hestenes) Jacobi on the symmetric matrix A: B = A V is driven to orthogonal columns by
+// plane rotations applied to column pairs; the R/2 pairs of a round-robin round are disjoint and processed
+// concurrently by G-thread groups.  B, V are column-major R x R (LDS when they fit, else L2-resident global).
+// On exit column i of V is an eigenvector and lambda_i = v_i . b_i.
+__device__ __forceinline__ int jacobi_sweeps(int R, int G, double *B, double *V, int max_sweeps, int *rotated) {
+    const int tid = threadIdx.x;
     const int Rp = R + (R & 1);
     const int pairs = Rp / 2;
     const int k = tid / G, g = tid - k * G;
     int sweep = 0;
     for (; sweep < max_sweeps; ++sweep) {
-        if (tid == 0) rotated = 0;
+        if (tid == 0) *rotated = 0;
         __syncthreads();
         for (int r = 0; r < Rp - 1; ++r) {
             int pi = -1, qi = -1;
@@ -213,15 +272,58 @@ __global__ __launch_bounds__(1024) void km_jacobi(int R, int G, const double *__
                     vp[e] = cs * u - sn * w;
                     vq[e] = sn * u + cs * w;
                 }
-                if (g == 0) rotated = 1;
+                if (g == 0) *rotated = 1;
             }
             __syncthreads();
         }
-        const int any = rotated;
+        const int any = *rotated;
         __syncthreads();
         if (!any) break;
     }
-    if (tid == 0) *sweeps_out = sweep;
+    return sweep;
+}
+
+// Eigen-decomposition of the compacted matrix As (Rs = *sup_n).  use_lds: B and V live in dynamic LDS
+// (2 Rs^2 doubles must fit, checked on the device), otherwise in the global buffers Bg, Vg.
+// Outputs the compact factor: Ss row i = sqrt(lambda_i) v_i^T, ivs_i = v_i . bs / sqrt(lambda_i), lambda <= 1e-8 dropped.
+__global__ __launch_bounds__(1024) void km_jacobi(const int *__restrict__ sup_n, int lds_doubles,
+                                                  const double *__restrict__ As, const double *__restrict__ bs,
+                                                  double *__restrict__ Bg, double *__restrict__ Vg,
+                                                  double *__restrict__ Ss, double *__restrict__ ivs, int max_sweeps,
+                                                  int *__restrict__ sweeps_out) {
+    extern __shared__ double lds[];
+    __shared__ int rotated;
+    const int R = *sup_n;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (R == 0) return;
+    const bool in_lds = 2 * R * R <= lds_doubles;
+    double *B = in_lds ? lds : Bg, *V = in_lds ? lds + (size_t)R * R : Vg;
+    for (int e = tid; e < R * R; e += nt) {
+        const int c = e / R, r = e - c * R;
+        B[e] = As[(size_t)r * R + c];   // column-major copy (A symmetric)
+        V[e] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    int G = 8;
+    while (G > 1 && ((R + 1) / 2) * G > nt) G >>= 1;
+    const int sweeps = jacobi_sweeps(R, G, B, V, max_sweeps, &rotated);
+    if (tid == 0) *sweeps_out = sweeps;
+    // finish: one wavefront per eigenpair
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    for (int i = wave; i < R; i += nw) {
+        const double *v = V + (size_t)i * R, *b = B + (size_t)i * R;
+        double lam = 0, vb = 0;
+        for (int e = lane; e < R; e += 64) {
+            lam += v[e] * b[e];
+            vb += v[e] * bs[e];
+        }
+        lam = wave_sum(lam);
+        vb = wave_sum(vb);
+        const double sl = lam > 1.0e-8 ? sqrt(lam) : 0.0;
+        const double sli = lam > 1.0e-8 ? sqrt(1.0 / lam) : 0.0;
+        for (int e = lane; e < R; e += 64) Ss[(size_t)i * R + e] = sl * v[e];
+        if (lane == 0) ivs[i] = sli * vb;
+    }
 }
 
 // Cholesky fast path of "create marginalization factor" (marginalization_factor.h:440-455).  When every
@@ -230,7 +332,8 @@ __global__ __launch_bounds__(1024) void km_jacobi(int R, int G, const double *__
 // reproduce Lambda = S^T S and eta = S^T infovec exactly like diag(sqrt(lambda)) V^T would.  The kernel
 // factors A in LDS and bounds lambda_min from above by inverse iteration; the caller falls back to the
 // Jacobi eigen-solver (km_jacobi) when the factorisation fails or the bound is not comfortably above the floor.
-__global__ __launch_bounds__(512) void km_chol(int R, const double *__restrict__ A, const double *__restrict__ bp,
+__global__ __launch_bounds__(512) void km_chol(const int *__restrict__ sup_n, int lds_doubles,
+                                               const double *__restrict__ A, const double *__restrict__ bp,
                                                double *__restrict__ sqrt_info, double *__restrict__ infovec,
                                                double *__restrict__ lam_est, int *__restrict__ status) {
     extern __shared__ double lds[];
@@ -238,6 +341,11 @@ __global__ __launch_bounds__(512) void km_chol(int R, const double *__restrict__
     __shared__ double scratch[8];
     __shared__ int fail;
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int R = *sup_n;
+    if (R == 0 || 2 * ((R + 1) & ~1) + R * (R + 1) / 2 > lds_doubles) {
+        if (tid == 0) status[2] = 1;   // does not fit: take the Jacobi path
+        return;
+    }
     double *x = lds, *y = lds + ((R + 1) & ~1), *Lp = y + ((R + 1) & ~1);
     for (int e = tid; e < R * R; e += nt) {
         const int i = e / R, j = e - i * R;
@@ -282,25 +390,6 @@ __global__ __launch_bounds__(512) void km_chol(int R, const double *__restrict__
         lam_est[0] = lam;
         status[3] = (isfinite(lam) && lam > 1.0e-6) ? 0 : 1;
     }
-}
-
-// sqrt_info row i = sqrt(lambda_i) v_i^T, infovec_i = v_i . b' / sqrt(lambda_i), eigenvalues <= 1e-8 dropped.
-__global__ __launch_bounds__(64) void km_finish(int R, const double *__restrict__ B, const double *__restrict__ V,
-                                                const double *__restrict__ bp, double *__restrict__ sqrt_info,
-                                                double *__restrict__ infovec) {
-    const int i = blockIdx.x, lane = threadIdx.x;
-    const double *v = V + (size_t)i * R, *b = B + (size_t)i * R;
-    double lam = 0, vb = 0;
-    for (int e = lane; e < R; e += 64) {
-        lam += v[e] * b[e];
-        vb += v[e] * bp[e];
-    }
-    lam = wave_sum(lam);
-    vb = wave_sum(vb);
-    const double sl = lam > 1.0e-8 ? sqrt(lam) : 0.0;
-    const double sli = lam > 1.0e-8 ? sqrt(1.0 / lam) : 0.0;
-    for (int e = lane; e < R; e += 64) sqrt_info[(size_t)i * R + e] = sl * v[e];
-    if (lane == 0) infovec[i] = sli * vb;
 }
 
 // ------------------------------------------------------------------------------------------------------
