@@ -47,19 +47,14 @@ def main():
         raise SystemExit("--warmup must be >= 40 so that window initialisation (36 frames) is not timed")
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
     from xrslam_amd import _lib
     from xrslam_amd.harness import runner, scene
+    from xrslam_amd.harness.dist import RunGroup
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    group = RunGroup()                      # one process per GPU; "nccl" == RCCL over xGMI
+    rank, local_rank, world = group.rank, group.local_rank, group.world
     _lib.set_device(local_rank)
 
     n_frames = args.warmup + args.steps
@@ -71,8 +66,7 @@ def main():
                           device_frames=(dev.data_ptr(), h * w, w))
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        group.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -94,10 +88,8 @@ def main():
     t_e = sess.times()
     st = sess.klt_stats(reset=False)
     sess.set_profiling(False)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    red = group.reduce_metrics(args.steps, elapsed)      # frames: SUM, wall seconds: MAX over ranks
+    elapsed, total_frames = red["seconds"], red["frames"]
 
     if rank == 0:
         poses = list(sess.poses)
@@ -110,7 +102,7 @@ def main():
         achieved = (lk_bytes / n_launch) / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
         out = {
             "metric": "frames/sec, full per-frame hot path (KLT tracker + sliding-window VI-BA), one sequence per GPU",
-            "value": round(world * args.steps / elapsed, 3),
+            "value": round(total_frames / elapsed, 3),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -159,8 +151,7 @@ def main():
             cpu.close()
         print(json.dumps(out))
     sess.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":
