@@ -124,12 +124,21 @@ def main():
             "stage_kernel_ms": {"preprocess": round(st.ms_preprocess / max(1, st.n_preprocess), 4),
                                 "lk_track": round(lk_ms, 4),
                                 "detect": round(st.ms_detect / max(1, st.n_detect), 4)},
+            "host_wall_ms_per_frame": {k[5:]: round(1e3 * (getattr(t_e, k) - getattr(t_w, k)) / args.steps, 4)
+                                       for k in ("wall_frame", "wall_preprocess", "wall_track", "wall_detect",
+                                                 "wall_preintegrate", "wall_solve", "wall_marginalize")},
             "ate_rmse_m": round(runner.ate_rmse(poses, seq), 5),
             "roofline": {"kernel": "k_lk_track", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_launch": round(lk_bytes / n_launch, 1),
                          "launch_us": round(lk_ms * 1e3, 3)},
         }
+        if os.environ.get("XRSLAM_HIP_LIB"):      # instrumented build variant: report its in-kernel phase timers
+            import ctypes
+            buf = (ctypes.c_longlong * 32)()
+            ctypes.CDLL(_lib.LIB_PATH).xrhip_debug_kprof(buf, 0)
+            out["kprof_ms"] = [round(v / 1e5, 3) for v in buf]    # 100 MHz ticks -> ms (whole run incl. warmup)
+            out["kprof_ms"][19] = int(buf[19])                    # slot 19 counts trust-region trials
         if args.cpu_frames > 40 and world == 1:
             import subprocess
             ref_lib = os.path.join(ROOT, "oracle", "_build", "libxrslam_oracle.so")

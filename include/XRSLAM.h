@@ -150,6 +150,9 @@ void XRSLAMAmdPushImageDevice(const void *gray_dev, int stride, double timestamp
 typedef struct XRSLAMAmdTimes {
     long frames, solves, solve_iterations, marginalizations, keyframes;
     double ba_device_ms; /* sum of HIP-event solve times */
+    /* host wall-clock seconds inside the inner C-ABI calls (preprocess, track, detect, preintegrate, solve,
+     * marginalize) and in the whole per-frame work (FeatureTracker::work incl. the backend) */
+    double wall_preprocess, wall_track, wall_detect, wall_preintegrate, wall_solve, wall_marginalize, wall_frame;
 } XRSLAMAmdTimes;
 void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out);
 /* HIP-event profiling of the KLT kernels (off by default) and its accumulated counters; the struct is

@@ -234,6 +234,9 @@ int xrhip_ba_preintegrate_batch(xrhip_ba *ctx, const double *samples, const int 
 int xrhip_ba_debug_linearize(xrhip_ba *ctx, const xrhip_ba_problem *problem, double *H, double *g, double *hll,
                              double *gl, double *W, double *cost);
 int xrhip_ba_debug_schur(xrhip_ba *ctx, const double *W, const double *w, int L, int P, double *out);
+/* development aid: accumulated in-kernel phase timers (100 MHz ticks) of the BA kernels; all zero unless the
+ * library was built with -DXRHIP_KPROF (csrc/build.sh, XR_VARIANT=kprof) */
+void xrhip_debug_kprof(long long *out32, int reset);
 
 #ifdef __cplusplus
 }

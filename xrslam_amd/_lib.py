@@ -4,7 +4,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libxrslam_hip.so")
+# XRSLAM_HIP_LIB selects an instrumented build variant of the same library (csrc/build.sh XR_VARIANT)
+LIB_PATH = os.environ.get("XRSLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libxrslam_hip.so")
 
 XRHIP_OK = 0
 XRHIP_ENODEVICE = -1

@@ -238,7 +238,8 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     const size_t w_sp = carve(D8 * n), w_sl = carve(D8 * d.Lp), w_om = carve(D8 * d.Lp);
     const size_t w_T = carve(D8 * (size_t)d.PF * d.PF), w_S = carve(D8 * (size_t)n * n);
     const size_t w_dD = carve(D8 * d.NV), w_gr = carve(D8 * d.NV), w_gn = carve(D8 * d.NV), w_gs = carve(D8 * d.NV);
-    const size_t w_st = carve(D8 * d.NV), w_de = carve(D8 * d.NV), w_part = carve(D8 * 64);
+    const size_t w_st = carve(D8 * d.NV), w_de = carve(D8 * d.NV), w_part = carve(D8 * (size_t)(aux_quad_blocks_n(d.n, std::max(d.L, 1)) + 8));
+    const size_t w_wog = carve(D8 * d.PF);
     const size_t w_Hv = carve(D8 * 36 * (size_t)F * F), w_gv = carve(D8 * 6 * F);
     int rc = ensure_arena(c, in_bytes, w + 256, (size_t)16 * F + L + 8);
     if (rc) return rc;
@@ -311,6 +312,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     p.step = (double *)(W + w_st);
     p.delta = (double *)(W + w_de);
     p.partial = (double *)(W + w_part);
+    p.wog = (double *)(W + w_wog);
     p.ctl = (BaCtl *)(I + o_ctl);
     cam.q = Q4{P->cam_q_bc[0], P->cam_q_bc[1], P->cam_q_bc[2], P->cam_q_bc[3]};
     cam.p = V3{P->cam_p_bc[0], P->cam_p_bc[1], P->cam_p_bc[2]};
@@ -338,18 +340,35 @@ static int launch_solve(xrhip_ba *c, const BaDims &d, const BaPtrs &p) {
     hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);
     const int tiles = d.PF / 16;
     hipLaunchKernelGGL(kb_schur_mfma, dim3(tiles * tiles), dim3(256), 0, s, d, p);
-    size_t lds = sizeof(double) * ((size_t)((d.na + 1) & ~1) + (size_t)d.na * (d.na + 1) / 2);
+    hipLaunchKernelGGL(kb_solve_aux, dim3(aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64), dim3(256), 0, s, d, p);
+    // dynamic LDS: rhs [na] + work region = max(packed triangle, gathered frame step of the back-substitution);
+    // systems whose triangle does not fit are factored in the (L2-resident) global buffer Sred instead
+    const size_t tri = (size_t)d.na * (d.na + 1) / 2;
+    const size_t aux = (size_t)d.PF;
+    size_t lds = sizeof(double) * ((size_t)((d.na + 1) & ~1) + std::max(tri, aux));
     int use_lds = 1;
     if (lds > (size_t)c->lds_limit) {
         use_lds = 0;
-        lds = sizeof(double) * (size_t)((d.na + 1) & ~1);
+        lds = sizeof(double) * ((size_t)((d.na + 1) & ~1) + aux);
+        if (lds > (size_t)c->lds_limit) return xr_fail(XRHIP_EOVERFLOW, "xrhip_ba_solve: problem exceeds the LDS work region");
     }
     hipLaunchKernelGGL(kb_solve, dim3(1), dim3(512), lds, s, d, p, use_lds);
     XR_HIP(hipGetLastError());
     return XRHIP_OK;
 }
 
+static long long g_kprof[32];   // accumulated in-kernel phase ticks (all zero unless built with -DXRHIP_KPROF)
+
 extern "C" {
+
+/* development aid: in-kernel phase timers of kb_solve / kb_try accumulated over all solves of the process,
+ * in 100 MHz ticks; only instrumented builds (build.sh -DXRHIP_KPROF) write them */
+void xrhip_debug_kprof(long long *out32, int reset) {
+    for (int i = 0; i < 32; ++i) {
+        if (out32) out32[i] = g_kprof[i];
+        if (reset) g_kprof[i] = 0;
+    }
+}
 
 int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **out) {
     if (!out || max_frames <= 0 || max_landmarks < 0 || max_obs < 0) return xr_fail(XRHIP_EINVAL, "xrhip_ba_create: bad arguments");
@@ -454,6 +473,7 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     float ms = 0.f;
     hipEventElapsedTime(&ms, c->ev0, c->ev1);
     const BaCtl &ctl = *c->h_ctl;
+    for (int i = 0; i < 32; ++i) g_kprof[i] += ctl.prof[i];
     sm.iterations = ctl.iteration;
     sm.successful_steps = ctl.successful_steps;
     sm.termination = ctl.termination;

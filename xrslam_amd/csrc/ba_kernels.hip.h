@@ -24,13 +24,15 @@
 namespace xrhip {
 
 constexpr int OREC = 28;   // per-observation record: Jt(12) Jr(12) jl(2) r(2), robustified
-constexpr int RREC = 8;    // per-rotation-factor record: Jq(6) r(2)
+constexpr int RREC = 8;
+constexpr int QF_ROWS = 8; // landmark rows a wavefront keeps in flight in the back-substitution
 
 struct BaCtl {   // device-resident solver state (one per context)
     double radius, mu;
     double x_cost, cand_cost, minimum_cost;
     double x_norm, gmax, alpha, step_norm;
     double model_cost_change, initial_cost;
+    double q_gg, q_gn, q_nn;   // J-quadratic forms of the scaled gradient / Gauss-Newton directions (see quad_forms)
     int iteration, successful_steps, invalid_steps;
     int reuse;          // DoglegStrategy::reuse_
     int status;         // ST_* below
@@ -39,7 +41,27 @@ struct BaCtl {   // device-resident solver state (one per context)
     int first;          // first linearisation of this solve (Jacobi scales are frozen afterwards)
     int max_iterations;
     int pad;
+    long long prof[32];   // accumulated 100 MHz ticks per kernel phase (only written by -DXRHIP_KPROF builds)
 };
+#ifdef XRHIP_KPROF
+#define KPROF_BEGIN() long long kp_t = wall_clock64()
+#define KPROF(slot)                                                   \
+    do {                                                              \
+        __syncthreads();                                              \
+        if (threadIdx.x == 0) {                                       \
+            const long long kp_n = wall_clock64();                    \
+            p.ctl->prof[slot] += kp_n - kp_t;                         \
+            kp_t = kp_n;                                              \
+        }                                                             \
+    } while (0)
+#else
+#define KPROF_BEGIN() \
+    do {              \
+    } while (0)
+#define KPROF(slot) \
+    do {            \
+    } while (0)
+#endif
 enum { ST_RUNNING = 0, ST_ACCEPTED = 1, ST_RESOLVE = 2, ST_DONE = 3, ST_RESOLVE_INNER = 102 };
 
 struct BaDims {
@@ -87,7 +109,8 @@ struct BaPtrs {
     double *T;                       // [PF][PF]
     double *Sred;                    // [n][n] scratch (global fallback of the Cholesky)
     double *diagD, *grad, *gn, *gs, *step, *delta;   // [NV] each
-    double *partial;                 // cost partial sums
+    double *partial;                 // [aux_quad_blocks] partial sums of Q(g~,g~)
+    double *wog;                     // [PF] W^T (omega gl)
     BaCtl *ctl;
 };
 
@@ -613,31 +636,122 @@ __global__ __launch_bounds__(256) void kb_schur_mfma(BaDims d, BaPtrs p) {
 }
 
 // -------------------------------------------------------------------- the solve
-// full quadratic form v^T Hs v over frames + landmarks (Hs = Jacobi-scaled Hessian); block-wide.
-// One wavefront per matrix row with the lanes striding over the columns, so every load is coalesced.
-__device__ __forceinline__ double quad_form(const BaDims &d, const BaPtrs &p, const double *v, double *scratch) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    double acc = 0;
-    for (int a = wave; a < d.n; a += nw) {
-        const double *row = p.Hpp + (size_t)a * d.n;
-        double s = 0;
-        for (int b = lane; b < d.n; b += 64) s += row[b] * p.sp[b] * v[b];
-        s = wave_sum(s);
-        if (lane == 0) acc += v[a] * p.sp[a] * s;
-    }
-    for (int l = wave; l < d.L; l += nw) {
-        if (!p.lact[l]) continue;
-        const double *row = p.Wt + (size_t)l * d.PF;
-        const double vl = v[d.n + l] * p.sl[l];
-        double s = 0;
-        for (int c = lane; c < 6 * d.F; c += 64) {
-            const int f = c / 6, k = c - 6 * f;
-            s += row[c] * p.sp[15 * f + k] * v[15 * f + k];
+// Dogleg needs three quadratic forms of the Jacobi-scaled Hessian Hs = J^T J (frames + landmarks) per linearisation:
+// with g~ = grad / D = gs / D^2 (steepest descent) and n~ = gn / D (Gauss-Newton, n~ = -y, (Hs + mu D^2) y = gs)
+//   Q(g~,g~)  the Cauchy step length;  and for a dogleg point  step = ca g~ + cb n~
+//   step^T Hs step = ca^2 Q(g~,g~) + 2 ca cb Q(g~,n~) + cb^2 Q(n~,n~).
+// Only Q(g~,g~) needs the matrix; the other two follow from the linear system the Gauss-Newton step solves:
+//   Hs n~ = -gs - mu D^2 n~   =>   Q(g~,n~) = -|grad|^2 - mu (n~ . gs),   Q(n~,n~) = -(n~ . gs) - mu |gn|^2.
+// kb_solve_aux is the wide (multi-workgroup) companion of the single-workgroup kb_solve; it runs before it and
+// does the two passes over the big operands that do not depend on the factorisation:
+//   role 0 (blocks [0, nbq)):       partial sums of Q(g~,g~): 16 frame rows or 32 landmark rows per block
+//   role 1 (blocks [nbq, nbq+nbr)): wog = W^T (omega gl), 64 pose columns per block
+__host__ __device__ __forceinline__ int aux_quad_blocks_n(int n, int L) { return (n + 15) / 16 + (L + 31) / 32; }
+
+__global__ __launch_bounds__(256) void kb_solve_aux(BaDims d, BaPtrs p) {
+    __shared__ double scratch[8];
+    __shared__ double part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = d.n, P6 = 6 * d.F;
+    const int nbf = (n + 15) / 16, nbq = aux_quad_blocks_n(n, d.L);
+    int blk = blockIdx.x;
+    if (blk < nbq) {
+        double acc = 0;
+        if (blk < nbf) {   // frame rows a0 .. a0+3 of this wavefront against all frame columns
+            const int a0 = 16 * blk + 4 * wave;
+            double ga[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = a0 + r;
+                ga[r] = 0.0;
+                if (a < n && dof_active(p.fix, a)) {
+                    const double D = p.diagD[a];
+                    ga[r] = p.sp[a] * (p.gs[a] / (D * D));
+                }
+            }
+            for (int b0 = 0; b0 < n; b0 += 256) {
+                double h[4][4], xb[4];
+#pragma unroll
+                for (int cch = 0; cch < 4; ++cch) {
+                    const int b = b0 + 64 * cch + lane;
+                    xb[cch] = 0.0;
+                    if (b < n && dof_active(p.fix, b)) {
+                        const double D = p.diagD[b];
+                        xb[cch] = p.sp[b] * (p.gs[b] / (D * D));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[cch][r] = (b < n && a0 + r < n) ? p.Hpp[(size_t)(a0 + r) * n + b] : 0.0;
+                }
+#pragma unroll
+                for (int cch = 0; cch < 4; ++cch) {
+                    double t = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t += ga[r] * h[cch][r];
+                    acc += t * xb[cch];
+                }
+            }
+        } else {   // landmark rows: 2 g~_l sl (W_l . u6) + (g~_l sl)^2 hll
+            const int l0 = 32 * (blk - nbf) + 8 * wave;
+            double wg[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) wg[r] = 0.0;
+            for (int c0 = 0; c0 < P6; c0 += 128) {
+                double w[2][8], xc[2];
+#pragma unroll
+                for (int cch = 0; cch < 2; ++cch) {
+                    const int cc = c0 + 64 * cch + lane;
+                    xc[cch] = 0.0;
+                    if (cc < P6) {
+                        const int f = cc / 6, a = 15 * f + (cc - 6 * f);
+                        if (pose_free(p.fix[f])) {
+                            const double D = p.diagD[a];
+                            xc[cch] = p.sp[a] * (p.gs[a] / (D * D));
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        w[cch][r] = (cc < P6 && l0 + r < d.L) ? p.Wt[(size_t)(l0 + r) * d.PF + cc] : 0.0;
+                }
+#pragma unroll
+                for (int cch = 0; cch < 2; ++cch)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) wg[r] += w[cch][r] * xc[cch];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int l = l0 + r;
+                if (l >= d.L || !p.lact[l]) continue;
+                const double D = p.diagD[n + l];
+                const double gl = p.sl[l] * (p.gs[n + l] / (D * D));
+                acc += 2.0 * gl * wg[r];
+                if (lane == 0) acc += gl * gl * p.hll[l];
+            }
         }
-        s = wave_sum(s);
-        if (lane == 0) acc += 2.0 * vl * s + vl * vl * p.hll[l];
+        acc = block_sum(acc, scratch);
+        if (tid == 0) p.partial[blk] = acc;
+        return;
     }
-    return block_sum(acc, scratch);
+    blk -= nbq;
+    {   // wog[c] = sum_l Wt[l][c] omega_l gl_l: 64 columns per block, the four wavefronts split the landmark rows
+        const int cc = 64 * blk + lane;
+        const int per = (d.L + 3) / 4, l0 = wave * per, l1 = min(d.L, l0 + per);
+        double sacc = 0;
+        if (cc < P6)
+            for (int lb = l0; lb < l1; lb += 8) {
+                double wv[8], og[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int l = min(lb + r, l1 - 1);
+                    wv[r] = p.Wt[(size_t)l * d.PF + cc];
+                    og[r] = (lb + r < l1) ? p.omega[l] * p.gl[l] : 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) sacc += wv[r] * og[r];
+            }
+        part[wave][lane] = sacc;
+        __syncthreads();
+        if (wave == 0 && cc < P6) p.wog[cc] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    }
 }
 
 // Reduced camera system + blocked Cholesky + Gauss-Newton / Cauchy quantities.  One workgroup.
@@ -645,14 +759,24 @@ __device__ __forceinline__ double quad_form(const BaDims &d, const BaPtrs &p, co
 // Dynamic LDS: rhs [na] + packed lower triangle when it fits (use_lds); otherwise the triangle lives in Sred.
 __global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds) {
     extern __shared__ double lds[];
-    __shared__ double scratch[8];
+    __shared__ double scratch[32];
     __shared__ double Dblk[CH_NB][CH_NB + 1];
     __shared__ int fail;
     BaCtl *c = p.ctl;
     const int n = d.n, na = d.na, tid = threadIdx.x, nt = blockDim.x;
     double *y = lds;                                   // [na] rhs / solution (compact)
-    double *A = use_lds ? lds + ((na + 1) & ~1) : p.Sred;   // packed lower triangle (compact)
+    double *work = lds + ((na + 1) & ~1);              // LDS work region: the packed triangle, later the gathered frame step
+    double *A = use_lds ? work : p.Sred;               // packed lower triangle (compact)
     const double mu = c->mu;
+    KPROF_BEGIN();
+    for (int i = tid; i < na; i += nt) {   // rhs = sp (gp - W^T (omega gl)); the product comes from kb_solve_aux
+        const int a = p.act_idx[i];
+        const int fa = a / 15, ka = a - 15 * fa;
+        const double sacc = ka < 6 ? p.wog[6 * fa + ka] : 0.0;
+        y[i] = (p.gp[a] - sacc) * p.sp[a];
+    }
+    __syncthreads();
+    KPROF(0);
     // ---- S = sp (Hpp - T) sp + mu D^2 over the free dofs, rhs = sp (gp - W^T (omega gl))
     for (int e = tid; e < na * na; e += nt) {
         const int i = e / na, j = e - i * na;
@@ -665,26 +789,22 @@ __global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds)
         if (a == b) v += mu * p.diagD[a] * p.diagD[a];
         A[tri_idx(i, j)] = v;
     }
-    {
-        const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-        for (int i = wave; i < na; i += nw) {
-            const int a = p.act_idx[i];
-            const int fa = a / 15, ka = a - 15 * fa;
-            double sacc = 0;
-            if (ka < 6)
-                for (int l = lane; l < d.L; l += 64) sacc += p.Wt[(size_t)l * d.PF + 6 * fa + ka] * (p.omega[l] * p.gl[l]);
-            sacc = wave_sum(sacc);
-            if (lane == 0) y[i] = (p.gp[a] - sacc) * p.sp[a];
-        }
-    }
     __syncthreads();
+    KPROF(1);
+#ifdef XRHIP_KPROF
+    const bool ok = chol_blocked(A, na, Dblk, &fail, p.ctl->prof + 24);
+#else
     const bool ok = chol_blocked(A, na, Dblk, &fail);
+#endif
+    KPROF(2);
     if (!ok) {
         if (tid == 0) c->linear_ok = 0;
         return;
     }
     trsv_lower(A, na, y);
+    KPROF(3);
     trsv_lower_t(A, na, y);
+    KPROF(4);
     // ---- Gauss-Newton step (scaled space), landmark back-substitution, dogleg gradient
     for (int a = tid; a < n; a += nt) {
         p.gn[a] = 0.0;
@@ -703,24 +823,51 @@ __global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds)
     __syncthreads();
     {
         const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-        for (int l = wave; l < d.L; l += nw) {
-            double yl = 0.0;
-            const double D = p.diagD[n + l];
-            if (p.lact[l]) {
-                const double sl = p.sl[l];
-                const double *row = p.Wt + (size_t)l * d.PF;
-                double w = 0;
-                for (int cidx = lane; cidx < 6 * d.F; cidx += 64) {
-                    const int f = cidx / 6, k = cidx - 6 * f;
-                    w += row[cidx] * p.sp[15 * f + k] * p.delta[15 * f + k];
+        const int P6 = 6 * d.F;
+        double *x6 = work;   // [P6] scaled frame step gathered to the pose columns (the triangle is dead by now)
+        for (int cidx = tid; cidx < P6; cidx += nt) {
+            const int f = cidx / 6, k = cidx - 6 * f;
+            x6[cidx] = p.sp[15 * f + k] * p.delta[15 * f + k];
+        }
+        __syncthreads();
+        for (int l0 = QF_ROWS * wave; l0 < d.L; l0 += QF_ROWS * nw) {   // QF_ROWS landmark rows per wavefront in flight
+            double w8[QF_ROWS];
+#pragma unroll
+            for (int r = 0; r < QF_ROWS; ++r) w8[r] = 0.0;
+            for (int c0 = 0; c0 < P6; c0 += 128) {
+                double w[2][QF_ROWS];
+#pragma unroll
+                for (int cch = 0; cch < 2; ++cch) {
+                    const int cidx = c0 + 64 * cch + lane;
+#pragma unroll
+                    for (int r = 0; r < QF_ROWS; ++r)
+                        w[cch][r] = (cidx < P6 && l0 + r < d.L) ? p.Wt[(size_t)(l0 + r) * d.PF + cidx] : 0.0;
                 }
-                w = wave_sum(w);
-                yl = (sl * p.gl[l] - sl * w) / (sl * sl * p.hll[l] + mu * D * D);
-                if (!isfinite(yl)) bad = 1;
+#pragma unroll
+                for (int cch = 0; cch < 2; ++cch) {
+                    const int cidx = c0 + 64 * cch + lane;
+                    const double x = cidx < P6 ? x6[cidx] : 0.0;
+#pragma unroll
+                    for (int r = 0; r < QF_ROWS; ++r) w8[r] += w[cch][r] * x;
+                }
             }
-            if (lane == 0) {
-                p.gn[n + l] = -D * yl;
-                p.grad[n + l] = p.lact[l] ? p.gs[n + l] / D : 0.0;
+#pragma unroll
+            for (int r = 0; r < QF_ROWS; ++r) w8[r] = wave_sum(w8[r]);
+#pragma unroll
+            for (int r = 0; r < QF_ROWS; ++r) {
+                const int l = l0 + r;
+                if (l >= d.L) continue;
+                double yl = 0.0;
+                const double D = p.diagD[n + l];
+                if (p.lact[l]) {
+                    const double sl = p.sl[l];
+                    yl = (sl * p.gl[l] - sl * w8[r]) / (sl * sl * p.hll[l] + mu * D * D);
+                    if (!isfinite(yl)) bad = 1;
+                }
+                if (lane == 0) {
+                    p.gn[n + l] = -D * yl;
+                    p.grad[n + l] = p.lact[l] ? p.gs[n + l] / D : 0.0;
+                }
             }
         }
     }
@@ -730,17 +877,25 @@ __global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds)
         if (tid == 0) c->linear_ok = 0;
         return;
     }
-    // ---- Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2 ; step buffer reused for sg = grad / D
-    double g2 = 0;
+    KPROF(5);
+    // ---- Cauchy point alpha = |grad|^2 / Q(g~,g~) and the quadratic forms of the dogleg model (see kb_solve_aux)
+    double r3[3] = {0, 0, 0};   // |grad|^2, n~ . gs, |gn|^2
     for (int a = tid; a < d.NV; a += nt) {
-        p.step[a] = p.grad[a] / p.diagD[a];
-        g2 += p.grad[a] * p.grad[a];
+        const double g = p.grad[a], nn = p.gn[a];
+        r3[0] += g * g;
+        r3[1] += (nn / p.diagD[a]) * p.gs[a];
+        r3[2] += nn * nn;
     }
-    g2 = block_sum(g2, scratch);
-    __syncthreads();
-    const double jg2 = quad_form(d, p, p.step, scratch);
+    block_sum_n<3>(r3, scratch);
+    KPROF(6);
     if (tid == 0) {
-        c->alpha = g2 / jg2;
+        double qgg = 0;
+        const int nbq = aux_quad_blocks_n(d.n, d.L);
+        for (int i = 0; i < nbq; ++i) qgg += p.partial[i];
+        c->alpha = r3[0] / qgg;
+        c->q_gg = qgg;
+        c->q_gn = -r3[0] - mu * r3[1];
+        c->q_nn = -r3[1] - mu * r3[2];
         c->linear_ok = 1;
     }
 }
@@ -824,6 +979,7 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
     // mode 2: after a re-solve caused by an invalid step (x unchanged)
     // mode 3: inner retry of DoglegStrategy::ComputeGaussNewtonStep's mu loop (same iteration)
     const int mode = after_linearisation;
+    KPROF_BEGIN();
     if (mode == 1) {
         // FinalizeIterationAndCheckIfMinimizerCanContinue of the iteration that produced this x:
         // refresh the user state the IMU factors read their bias reference from (StateUpdatingCallback)
@@ -838,6 +994,7 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
         }
         __syncthreads();
     }
+    KPROF(10);
     bool check_gradient = (mode == 1);   // the iteration that led here was successful
     bool skip_finalize = (mode == 3);
     // |gradient|, |gauss-newton step| and their inner product stay the same for every trial of this launch
@@ -855,6 +1012,7 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
         gd = r3[2];
         __syncthreads();
     }
+    KPROF(11);
     while (true) {
         // ---- finalize checks + start of the next iteration
         if (tid == 0) {
@@ -894,6 +1052,7 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
         check_gradient = false;
         __syncthreads();
         if (s_status != ST_RUNNING) break;
+        KPROF(12);
         // ---- traditional dogleg for the current radius (|grad|, |gn|, grad.gn were reduced once per launch)
         const double radius = c->radius, alpha = c->alpha;
         double ca = 0, cb = 0, step_norm = 0;   // step(scaled by D) = ca * grad + cb * gn
@@ -928,7 +1087,9 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
         const double sg = red2[1];
         if (step_norm < 0) step_norm = sqrt(red2[0]);
         __syncthreads();
-        const double shs = quad_form(d, p, p.step, scratch);
+        KPROF(13);
+        const double shs = (ca * ca) * c->q_gg + 2.0 * (ca * cb) * c->q_gn + (cb * cb) * c->q_nn;   // see quad_forms
+        KPROF(14);
         const double model_cost_change = -sg - 0.5 * shs;
         if (!(model_cost_change > 0.0)) {
             if (tid == 0) {
@@ -957,23 +1118,33 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
             for (int k = 0; k < 15; ++k) sh[15 * i + k] = dl[k];
         }
         __syncthreads();
+        KPROF(15);
         double red[2] = {0, 0};   // cost, |x - candidate|^2
         for (int o = tid; o < d.M; o += nt) red[0] += obs_eval(d, p, o, p.cand, p.depth_cand, cam, sx, sy, false, nullptr);
         for (int o = tid; o < d.MR; o += nt) red[0] += rot_eval(d, p, o, p.cand, cam, sx, sy, false, nullptr);
+        KPROF(16);
         {   // IMU factors and prior rows: one wavefront each (coalesced)
             const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
             for (int k = wave; k < d.NI; k += nw) red[0] += imu_cost_wave(p, k, p.cand, imu, lane);
-            for (int i = wave; i < d.np; i += nw) {
-                const double *row = p.pS + (size_t)i * d.np;
-                double s = 0;
-                for (int j = lane; j < d.np; j += 64) s += row[j] * sh[j];
-                s = wave_sum(s);
-                if (lane == 0) {
-                    s += p.pinfo[i];
-                    red[0] += 0.5 * s * s;
+            for (int i0 = 4 * wave; i0 < d.np; i0 += 4 * nw) {   // four prior rows per wavefront in flight
+                double s4[4] = {0, 0, 0, 0};
+                for (int j = lane; j < d.np; j += 64) {
+                    const double x = sh[j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s4[r] += p.pS[(size_t)min(i0 + r, d.np - 1) * d.np + j] * x;
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s4[r] = wave_sum(s4[r]);
+                if (lane == 0)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (i0 + r < d.np) {
+                            const double t = s4[r] + p.pinfo[i0 + r];
+                            red[0] += 0.5 * t * t;
+                        }
             }
         }
+        KPROF(17);
         for (int f = tid; f < d.F; f += nt) {
             const double *a = p.state + 16 * f, *b = p.cand + 16 * f;
             if (pose_free(p.fix[f]))
@@ -987,6 +1158,8 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
         double cost = red[0];
         if (!isfinite(cost)) cost = 1.7976931348623157e308;
         const double dn = sqrt(red[1]);
+        KPROF(18);
+        if (tid == 0) p.ctl->prof[19] += 1;   // trials
         // ---- decisions (uniform across the workgroup)
         const double x_cost = c->x_cost;
         int st = ST_RUNNING;

@@ -3,14 +3,17 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../lib"
-mkdir -p "$OUT" "$HERE/_obj"
+# XR_VARIANT=name builds lib/libxrslam_hip_name.so from _obj_name/ (e.g. XR_VARIANT=kprof build.sh -DXRHIP_KPROF)
+VAR="${XR_VARIANT:+_$XR_VARIANT}"
+OBJ="$HERE/_obj$VAR"
+mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -I$HERE/../../include"
 SRCS="$(ls "$HERE"/*.hip) $(ls "$HERE"/host/*.cpp)"
 OBJS=""
 pids=()
 for s in $SRCS; do
-  b="$(basename "$s")"; o="$HERE/_obj/${b%.*}.o"
+  b="$(basename "$s")"; o="$OBJ/${b%.*}.o"
   OBJS="$OBJS $o"
   if [ ! -f "$o" ] || [ -n "$(find "$HERE" "$HERE/../../include" "$HERE/host" -maxdepth 1 \( -name '*.h' -o -name '*.hpp' -o -name "$(basename "$s")" \) -newer "$o" | head -1)" ]; then
     $HIPCC $FLAGS "$@" -c "$s" -o "$o" &
@@ -18,5 +21,5 @@ for s in $SRCS; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libxrslam_hip.so" $OBJS
-echo "built $OUT/libxrslam_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libxrslam_hip$VAR.so" $OBJS
+echo "built $OUT/libxrslam_hip$VAR.so"

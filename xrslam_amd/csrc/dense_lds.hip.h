@@ -6,7 +6,7 @@
 //   (1) the 16x16 diagonal block is factored by wavefront 0 alone (lane-parallel, wave-synchronous,
 //       no workgroup barrier inside),
 //   (2) the panel below it is solved one row per thread,
-//   (3) the trailing matrix gets a rank-16 update by all threads,
+//   (3) the trailing matrix gets its rank-16 update from the f64 matrix cores (16x16 tiles, one per wavefront),
 // i.e. 3 workgroup barriers per panel instead of 3 per column.  Triangular solves are blocked the same way.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,8 +27,26 @@ __device__ __forceinline__ void wave_sync() {
 // In-place blocked Cholesky of the packed lower triangle A (n x n): on success A holds L.
 // D is a [CH_NB][CH_NB+1] LDS scratch block, s_fail an LDS flag.  All threads of the workgroup must call.
 // Returns false (uniformly) if a non-positive pivot is met.
-__device__ __forceinline__ bool chol_blocked(double *A, int n, double (*D)[CH_NB + 1], int *s_fail) {
+#ifdef XRHIP_KPROF
+#define CHPROF(slot)                                  \
+    do {                                              \
+        if (prof && threadIdx.x == 0) {               \
+            const long long t_now = wall_clock64();   \
+            prof[slot] += t_now - t_prev;             \
+            t_prev = t_now;                           \
+        }                                             \
+    } while (0)
+#else
+#define CHPROF(slot) \
+    do {             \
+    } while (0)
+#endif
+__device__ __forceinline__ bool chol_blocked(double *A, int n, double (*D)[CH_NB + 1], int *s_fail,
+                                             long long *prof = nullptr) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+#ifdef XRHIP_KPROF
+    long long t_prev = wall_clock64();
+#endif
     if (tid == 0) *s_fail = 0;
     __syncthreads();
     for (int j0 = 0; j0 < n; j0 += CH_NB) {
@@ -62,6 +80,7 @@ __device__ __forceinline__ bool chol_blocked(double *A, int n, double (*D)[CH_NB
             }
         }
         __syncthreads();
+        CHPROF(0);
         if (*s_fail) return false;
         const int jb = j0 + nb;
         if (jb >= n) break;
@@ -82,27 +101,38 @@ __device__ __forceinline__ bool chol_blocked(double *A, int n, double (*D)[CH_NB
                 if (c < nb) row[c] = x[c];
         }
         __syncthreads();
-        // ---- (3) trailing update: A[i][k] -= sum_c L[i][j0+c] L[k][j0+c],  jb <= k <= i < n.
-        // One wavefront per row i (its panel row is read once, as an LDS broadcast), lanes over k.
+        CHPROF(1);
+        // ---- (3) trailing update A22 -= P P^T (P = the freshly solved n-jb x 16 panel) on the f64 matrix cores:
+        // 16x16 output tiles of the lower triangle are dealt round-robin to the wavefronts; one tile = four
+        // v_mfma_f64_16x16x4_f64 (k = 16).  Operand layout: A[i][k] from lane (i = lane & 15, k = lane >> 4),
+        // B[k][j] from lane (k = lane >> 4, j = lane & 15), D[(lane >> 4) + 4 r][lane & 15] in register r.
         {
-            const int nw = nt >> 6;
-            for (int i = jb + wave; i < n; i += nw) {
-                const double *ri = A + tri_idx(i, j0);
-                double li[CH_NB];
+            const int nw = nt >> 6, r16 = lane & 15, q = lane >> 4;
+            const int T = (n - jb + 15) >> 4;
+            int t = 0;
+            for (int ti = 0; ti < T; ++ti)
+                for (int tj = 0; tj <= ti; ++tj, ++t) {
+                    if (t % nw != wave) continue;
+                    const int gi = jb + 16 * ti + r16, gk = jb + 16 * tj + r16;
+                    const double *pa = A + tri_idx(min(gi, n - 1), j0) + q;
+                    const double *pb = A + tri_idx(min(gk, n - 1), j0) + q;
+                    const bool va = gi < n, vb = gk < n;
+                    typedef double d4 __attribute__((ext_vector_type(4)));
+                    d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int c = 0; c < CH_NB; ++c) li[c] = (c < nb) ? ri[c] : 0.0;
-                double *out = A + tri_idx(i, jb);
-                for (int k = jb + lane; k <= i; k += 64) {
-                    const double *rk = A + tri_idx(k, j0);
-                    double s = 0;
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const double av = va ? pa[4 * s4] : 0.0, bv = vb ? pb[4 * s4] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    }
 #pragma unroll
-                    for (int c = 0; c < CH_NB; ++c)
-                        if (c < nb) s += li[c] * rk[c];
-                    out[k - jb] -= s;
+                    for (int r = 0; r < 4; ++r) {
+                        const int oi = jb + 16 * ti + q + 4 * r, ok = jb + 16 * tj + r16;
+                        if (oi < n && ok <= oi) A[tri_idx(oi, ok)] -= acc[r];
+                    }
                 }
-            }
         }
         __syncthreads();
+        CHPROF(2);
     }
     return true;
 }

@@ -14,6 +14,7 @@
 // The Initializer (SfM + visual-inertial alignment) is out of scope: the
 // window is bootstrapped from externally supplied initial states (BootstrapInitializer).
 #pragma once
+#include <chrono>
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -41,6 +42,15 @@ struct StageTimes {   // seconds, accumulated (inspection slots feature_tracker_
     double tracker = 0, localize = 0, refine = 0, marginalize = 0, preintegrate = 0;
     long frames = 0, solves = 0, solve_iterations = 0, marginalizations = 0, keyframes = 0;
     double ba_device_ms = 0;
+    // host wall-clock seconds spent inside the C-ABI calls, and in the whole per-frame work
+    double w_upload = 0, w_preprocess = 0, w_track = 0, w_detect = 0, w_preintegrate = 0, w_solve = 0, w_marginalize = 0,
+           w_frame = 0;
+};
+struct WallTimer {   // adds the scope's duration to a StageTimes slot
+    double &slot;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit WallTimer(double &s) : slot(s) {}
+    ~WallTimer() { slot += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
 struct Pipeline {
@@ -106,6 +116,7 @@ struct Pipeline {
             s[4] = d.a.x; s[5] = d.a.y; s[6] = d.a.z;
         }
         const double b1[3] = {bg.x, bg.y, bg.z}, b2[3] = {ba_.x, ba_.y, ba_.z};
+        WallTimer wt_w_preintegrate(times.w_preintegrate);
         hip_check(xrhip_ba_preintegrate(ba, smp.data(), (int)pre.data.size(), t, b1, b2, noise36, jac, cov, pre.rec),
                   "xrhip_ba_preintegrate");
         pre.valid = true;
@@ -145,6 +156,7 @@ inline void frame_detect_keypoints(Pipeline &P, Frame *f) {   // frame.cpp:55-72
     const int maxp = (int)c.feature_tracker_max_keypoint_detection;
     std::vector<double> fresh(2 * (size_t)std::max(maxp, 1));
     int n_new = 0;
+    WallTimer wt_w_detect(P.times.w_detect);
     hip_check(xrhip_image_detect(f->image->h, existing.data(), (int)f->keypoint_num(), maxp,
                                  c.feature_tracker_min_keypoint_distance, fresh.data(), &n_new),
               "xrhip_image_detect");
@@ -173,9 +185,12 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
         has_guess = 1;
     }
     std::vector<uint8_t> st8(std::max<size_t>(n, 1), 0);
-    hip_check(xrhip_image_track(cur->image->h, next->image->h, curr_px.data(), next_px.data(), has_guess, st8.data(),
-                                (int)n),
-              "xrhip_image_track");
+    {
+        WallTimer wt_w_track(P.times.w_track);
+        hip_check(xrhip_image_track(cur->image->h, next->image->h, curr_px.data(), next_px.data(), has_guess,
+                                    st8.data(), (int)n),
+                  "xrhip_image_track");
+    }
     std::vector<char> status(st8.begin(), st8.begin() + n), mask;
     std::vector<V2> cur_h, next_h;
     std::vector<V3> next_bearings;
@@ -351,6 +366,7 @@ class BaBuilder {
         }
         pb.max_iterations = (int)c.solver_iteration_limit;
         xrhip_ba_summary sm;
+        WallTimer wt_w_solve(P_.times.w_solve);
         hip_check(xrhip_ba_solve(P_.ba, &pb, &sm), "xrhip_ba_solve");
         for (int f = 0; f < F; ++f)
             if (fix_[f] != (XRHIP_FIX_POSE | XRHIP_FIX_MOTION)) unpack_state(&state[16 * (size_t)f], frames_[f], fix_[f]);
@@ -513,6 +529,7 @@ inline void marginalize_frame(Pipeline &P, Map *map, size_t index) {   // Map::m
     mp.obs_z_ref = zr.data();
     const size_t R = 15 * (size_t)(K - 1);
     std::vector<double> si(R * R), iv(R), lin(16 * (size_t)(K - 1));
+    WallTimer wt_w_marginalize(P.times.w_marginalize);
     hip_check(xrhip_ba_marginalize(P.ba, &mp, si.data(), iv.data(), lin.data()), "xrhip_ba_marginalize");
     prior->sqrt_info.swap(si);
     prior->infovec.swap(iv);
@@ -1027,10 +1044,14 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
 
     // -------- FeatureTracker::work (core/feature_tracker.cpp:24-153)
     void feature_tracker_work(std::unique_ptr<Frame> frame) {
+        WallTimer wt_frame(P.times.w_frame);
         const Config &c = P.config;
-        hip_check(xrhip_image_preprocess(frame->image->h, c.feature_tracker_clahe_clip_limit,
-                                         (int)c.feature_tracker_clahe_width, (int)c.feature_tracker_clahe_height),
-                  "xrhip_image_preprocess");
+        {
+            WallTimer wt_w_preprocess(P.times.w_preprocess);
+            hip_check(xrhip_image_preprocess(frame->image->h, c.feature_tracker_clahe_clip_limit,
+                                             (int)c.feature_tracker_clahe_width, (int)c.feature_tracker_clahe_height),
+                      "xrhip_image_preprocess");
+        }
         auto [opt_t, opt_id, opt_pose, opt_motion] = frontend_latest_state;
         (void)opt_t;
         bool is_initialized = opt_id != nil();

@@ -235,6 +235,13 @@ void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out) {
     out->marginalizations = t.marginalizations;
     out->keyframes = t.keyframes;
     out->ba_device_ms = t.ba_device_ms;
+    out->wall_preprocess = t.w_preprocess;
+    out->wall_track = t.w_track;
+    out->wall_detect = t.w_detect;
+    out->wall_preintegrate = t.w_preintegrate;
+    out->wall_solve = t.w_solve;
+    out->wall_marginalize = t.w_marginalize;
+    out->wall_frame = t.w_frame;
 }
 
 void XRSLAMAmdSetProfiling(int enable) {

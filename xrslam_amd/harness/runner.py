@@ -26,7 +26,10 @@ class XRSLAMPose(C.Structure):
 
 class XRSLAMAmdTimes(C.Structure):
     _fields_ = [("frames", C.c_long), ("solves", C.c_long), ("solve_iterations", C.c_long),
-                ("marginalizations", C.c_long), ("keyframes", C.c_long), ("ba_device_ms", C.c_double)]
+                ("marginalizations", C.c_long), ("keyframes", C.c_long), ("ba_device_ms", C.c_double),
+                ("wall_preprocess", C.c_double), ("wall_track", C.c_double), ("wall_detect", C.c_double),
+                ("wall_preintegrate", C.c_double), ("wall_solve", C.c_double), ("wall_marginalize", C.c_double),
+                ("wall_frame", C.c_double)]
 
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
