@@ -132,4 +132,14 @@ int xrhip_ba_preintegrate(xrhip_ba *, const double *samples, int n, double t_end
     if (rc) g_err = "preintegrate failed";
     return rc ? XRHIP_ESTATE : 0;
 }
+int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *begin, const int *count,
+                                const double *t_end, const double *bg, const double *ba, int n_jobs,
+                                const double *noise36, int jac, int cov, double *out) {
+    for (int k = 0; k < n_jobs; ++k) {
+        int rc = xrhip_ba_preintegrate(c, samples + 7 * (size_t)begin[k], count[k], t_end[k], bg + 3 * k, ba + 3 * k,
+                                       noise36, jac, cov, out + (size_t)XRHIP_IMU_DIM * k);
+        if (rc) return rc;
+    }
+    return 0;
+}
 }

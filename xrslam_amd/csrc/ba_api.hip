@@ -707,14 +707,19 @@ int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *s
         if (sample_count[k] <= 0 || sample_begin[k] < 0) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: empty IMU segment");
         total = std::max(total, sample_begin[k] + sample_count[k]);
     }
+    // zero-copy: jobs, samples, noise, results and status live in the pinned staging block, which the kernel
+    // addresses directly over the host link -- an integration moves a few hundred bytes in and 2.2 KB out, so
+    // copy-engine round trips (H2D, memset, D2H) would cost several times the kernel itself
     const size_t D8 = sizeof(double);
     const size_t b_jobs = sizeof(PreintJob) * n_jobs, b_smp = D8 * 7 * (size_t)total, b_noise = D8 * 36;
     const size_t o_jobs = 0, o_smp = (b_jobs + 255) & ~size_t(255), o_noise = (o_smp + b_smp + 255) & ~size_t(255);
     const size_t o_out = (o_noise + b_noise + 255) & ~size_t(255), o_st = o_out + D8 * XRHIP_IMU_DIM * (size_t)n_jobs;
     const size_t bytes = o_st + sizeof(int) * n_jobs + 256;
-    int rc = ensure_work2(c, bytes, bytes);
+    int rc = ensure_work2(c, 0, bytes);
     if (rc) return rc;
-    char *H = c->h_stage, *Dv = c->work2;
+    char *H = c->h_stage;
+    char *Dv = nullptr;
+    XR_HIP(hipHostGetDevicePointer((void **)&Dv, H, 0));
     PreintJob *jobs = (PreintJob *)(H + o_jobs);
     for (int k = 0; k < n_jobs; ++k) {
         jobs[k].sample_begin = sample_begin[k];
@@ -729,14 +734,10 @@ int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *s
     std::memcpy(H + o_noise, noise_cov36, b_noise);
     std::memset(H + o_st, 0, sizeof(int) * n_jobs);
     hipStream_t s = c->stream;
-    XR_HIP(hipMemcpyAsync(Dv, H, o_out, hipMemcpyHostToDevice, s));
-    XR_HIP(hipMemsetAsync(Dv + o_st, 0, sizeof(int) * n_jobs, s));
-    hipLaunchKernelGGL(kp_preintegrate, dim3(n_jobs), dim3(256), 0, s, (const PreintJob *)(Dv + o_jobs),
+    hipLaunchKernelGGL(kp_preintegrate, dim3(n_jobs), dim3(64), 0, s, (const PreintJob *)(Dv + o_jobs),
                        (const double *)(Dv + o_smp), (const double *)(Dv + o_noise), compute_jacobian ? 1 : 0,
                        compute_covariance ? 1 : 0, (double *)(Dv + o_out), (int *)(Dv + o_st));
     XR_HIP(hipGetLastError());
-    XR_HIP(hipMemcpyAsync(H + o_out, Dv + o_out, D8 * XRHIP_IMU_DIM * (size_t)n_jobs + sizeof(int) * n_jobs,
-                          hipMemcpyDeviceToHost, s));
     XR_HIP(hipStreamSynchronize(s));
     const int *st = (const int *)(H + o_st);
     for (int k = 0; k < n_jobs; ++k)

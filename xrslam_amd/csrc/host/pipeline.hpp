@@ -122,6 +122,48 @@ struct Pipeline {
         pre.valid = true;
         return true;
     }
+    // several integrations in one launch (refine_window re-integrates every keyframe interval, refine_subwindow
+    // every subframe interval); entries with no IMU data are skipped and reported as false
+    struct IntegrateJob {
+        PreInt *pre;
+        double t;
+        V3 bg, ba;
+    };
+    std::vector<char> integrate_batch(const std::vector<IntegrateJob> &jobs, bool jac, bool cov) {
+        std::vector<char> ok(jobs.size(), 0);
+        std::vector<double> smp, t_end, bgs, bas;
+        std::vector<int> begin, count, which;
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            const PreInt &pre = *jobs[k].pre;
+            if (pre.data.empty()) continue;
+            ok[k] = 1;
+            which.push_back((int)k);
+            begin.push_back((int)(smp.size() / 7));
+            count.push_back((int)pre.data.size());
+            t_end.push_back(jobs[k].t);
+            for (const ImuData &d : pre.data) {
+                const double row[7] = {d.t, d.w.x, d.w.y, d.w.z, d.a.x, d.a.y, d.a.z};
+                smp.insert(smp.end(), row, row + 7);
+            }
+            const double b1[3] = {jobs[k].bg.x, jobs[k].bg.y, jobs[k].bg.z}, b2[3] = {jobs[k].ba.x, jobs[k].ba.y, jobs[k].ba.z};
+            bgs.insert(bgs.end(), b1, b1 + 3);
+            bas.insert(bas.end(), b2, b2 + 3);
+        }
+        if (which.empty()) return ok;
+        std::vector<double> out((size_t)XRHIP_IMU_DIM * which.size());
+        {
+            WallTimer wt_w_preintegrate(times.w_preintegrate);
+            hip_check(xrhip_ba_preintegrate_batch(ba, smp.data(), begin.data(), count.data(), t_end.data(), bgs.data(),
+                                                  bas.data(), (int)which.size(), noise36, jac, cov, out.data()),
+                      "xrhip_ba_preintegrate_batch");
+        }
+        for (size_t i = 0; i < which.size(); ++i) {
+            PreInt &pre = *jobs[which[i]].pre;
+            std::memcpy(pre.rec, &out[(size_t)XRHIP_IMU_DIM * i], sizeof(double) * XRHIP_IMU_DIM);
+            pre.valid = true;
+        }
+        return ok;
+    }
 };
 
 inline HipImage::~HipImage() {
@@ -700,6 +742,7 @@ class SlidingWindowTracker {
                 b.add_reprojection_error(f, j);
             }
         }
+        std::vector<Pipeline::IntegrateJob> kf_jobs;
         for (size_t j = 1; j < map->frame_num(); ++j) {
             Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
             fj->keyframe_preintegration = fj->preintegration;
@@ -708,8 +751,15 @@ class SlidingWindowTracker {
                 for (auto &sf : fi->subframes) extra.insert(extra.end(), sf->preintegration.data.begin(), sf->preintegration.data.end());
                 fj->keyframe_preintegration.data.insert(fj->keyframe_preintegration.data.begin(), extra.begin(), extra.end());
             }
-            if (P_.integrate(fj->keyframe_preintegration, fj->image->t, fi->motion.bg, fi->motion.ba, true, true))
-                b.add_preintegration_error(fi, fj, fj->keyframe_preintegration);
+            kf_jobs.push_back({&fj->keyframe_preintegration, fj->image->t, fi->motion.bg, fi->motion.ba});
+        }
+        {
+            const std::vector<char> ok = P_.integrate_batch(kf_jobs, true, true);
+            for (size_t j = 1; j < map->frame_num(); ++j)
+                if (ok[j - 1]) {
+                    Frame *fj = map->get_frame(j);
+                    b.add_preintegration_error(map->get_frame(j - 1), fj, fj->keyframe_preintegration);
+                }
         }
         b.solve();
         for (size_t k = 0; k < map->track_num(); ++k) {
@@ -750,6 +800,17 @@ class SlidingWindowTracker {
         }
     }
 
+    // (re-)integrate every subframe interval of `frame` with the current biases, one launch
+    void integrate_subframes(Frame *frame) {
+        std::vector<Pipeline::IntegrateJob> jobs;
+        for (size_t i = 0; i < frame->subframes.size(); ++i) {
+            Frame *sf = frame->subframes[i].get();
+            Frame *prev = (i == 0 ? frame : frame->subframes[i - 1].get());
+            jobs.push_back({&sf->preintegration, sf->image->t, prev->motion.bg, prev->motion.ba});
+        }
+        P_.integrate_batch(jobs, true, true);
+    }
+
     void refine_subwindow() {   // :370-465
         Frame *frame = map->get_frame(map->frame_num() - 1);
         if (frame->subframes.empty()) return;
@@ -771,11 +832,11 @@ class SlidingWindowTracker {
             frame->tag(FT_FIX_POSE) = true;
             frame->tag(FT_FIX_MOTION) = true;
             b.add_frame_states(frame);
+            integrate_subframes(frame);
             for (size_t i = 0; i < frame->subframes.size(); ++i) {
                 Frame *sf = frame->subframes[i].get();
                 b.add_frame_states(sf);
                 Frame *prev = (i == 0 ? frame : frame->subframes[i - 1].get());
-                P_.integrate(sf->preintegration, sf->image->t, prev->motion.bg, prev->motion.ba, true, true);
                 b.add_preintegration_error(prev, sf, sf->preintegration);
             }
             Frame *last = frame->subframes.back().get();
@@ -798,11 +859,11 @@ class SlidingWindowTracker {
             frame->tag(FT_FIX_POSE) = true;
             frame->tag(FT_FIX_MOTION) = true;
             b.add_frame_states(frame);
+            integrate_subframes(frame);
             for (size_t i = 0; i < frame->subframes.size(); ++i) {
                 Frame *sf = frame->subframes[i].get();
                 b.add_frame_states(sf);
                 Frame *prev = (i == 0 ? frame : frame->subframes[i - 1].get());
-                P_.integrate(sf->preintegration, sf->image->t, prev->motion.bg, prev->motion.ba, true, true);
                 b.add_preintegration_error(prev, sf, sf->preintegration);
                 for (size_t k = 0; k < sf->keypoint_num(); ++k) {
                     if (Track *t = sf->get_track(k)) {

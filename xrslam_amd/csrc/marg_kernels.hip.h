@@ -52,13 +52,11 @@ __global__ __launch_bounds__(256) void km_permute(BaDims d, BaPtrs p, int victim
     }
 }
 
-// In-LDS inverse of a 15x15 matrix by Gauss-Jordan with partial pivoting; >= 225 threads, all must call.
-// A is destroyed, I receives the inverse.  Returns false (uniformly) if a zero pivot is met.
+// In-LDS inverse of a 15x15 matrix by Gauss-Jordan with partial pivoting; any workgroup size >= 64, all threads
+// must call.  A is destroyed, I receives the inverse.  Returns false (uniformly) if a zero pivot is met.
 __device__ __forceinline__ bool inv15_block(double (*A)[15], double (*I)[15], int *s_piv, int *s_bad) {
-    const int tid = threadIdx.x;
-    const int i = tid / 15, j = tid - 15 * (tid / 15);
-    const bool in = tid < 225;
-    if (in) I[i][j] = (i == j) ? 1.0 : 0.0;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int e = tid; e < 225; e += nt) I[e / 15][e % 15] = (e / 15 == e % 15) ? 1.0 : 0.0;
     if (tid == 0) *s_bad = 0;
     __syncthreads();
     for (int k = 0; k < 15; ++k) {
@@ -86,16 +84,28 @@ __device__ __forceinline__ bool inv15_block(double (*A)[15], double (*I)[15], in
         }
         __syncthreads();
         const double dkk = A[k][k];
-        const double f = in ? A[i][k] : 0.0;
-        __syncthreads();
-        if (in && i == k) {
-            A[k][j] /= dkk;
-            I[k][j] /= dkk;
+        double f[4];   // column k of the rows this thread updates (read before anything changes)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + r * nt;
+            f[r] = e < 225 ? A[e / 15][k] : 0.0;
         }
         __syncthreads();
-        if (in && i != k) {
-            A[i][j] -= f * A[k][j];
-            I[i][j] -= f * I[k][j];
+        if (tid < 15) {
+            A[k][tid] /= dkk;
+            I[k][tid] /= dkk;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + r * nt;
+            if (e < 225) {
+                const int i = e / 15, j = e - 15 * i;
+                if (i != k) {
+                    A[i][j] -= f[r] * A[k][j];
+                    I[i][j] -= f[r] * I[k][j];
+                }
+            }
         }
         __syncthreads();
     }
@@ -393,29 +403,41 @@ __global__ __launch_bounds__(512) void km_chol(const int *__restrict__ sup_n, in
 }
 
 // ------------------------------------------------------------------------------------------------------
-// IMU pre-integration.  One 128-thread workgroup per integration; the 9x9 covariance recursion
-// A Sigma A^T + B Q B^T and the five 3x3 bias Jacobians are spread over the lanes, the SO(3) algebra of each
-// sample is evaluated by lane 0.  Batched: blockIdx.x selects the integration.
+// IMU pre-integration (PreIntegrator::integrate, estimation/preintegrator.cpp:7-100).  One wavefront per
+// integration; blockIdx.x selects the job.  Euler integration is a recurrence over the samples, but most of
+// its arithmetic is not: per chunk of PI_CHUNK samples
+//   P1  lane = sample: bias-corrected rates, expmap(w dt), its transpose matrix E and the right Jacobian Jr
+//   P2  lane 0: the quaternion chain q_{n+1} = normalize(q_n * expmap_n)   (the only transcendental-free serial part)
+//   P3  lane = sample: R_n, R_n hat(a_n), q_n a_n, the 9x9 transition A_n and the noise term G_n = B_n (Q/dt) B_n^T
+//   P4  lane 0: position / velocity chain
+//   P5  lanes = matrix entries: Sigma <- A_n Sigma A_n^T + G_n and the five 3x3 bias Jacobians, sample by sample,
+//       two wavefront-local barriers per sample
+// followed by the 15x15 inverse + Cholesky of the covariance.  Samples and results live in pinned host memory
+// mapped into the device (zero-copy): an integration is a handful of doubles, so a copy engine round trip would
+// cost more than the kernel.
 struct PreintJob {
     int sample_begin, sample_count;   // into samples [.][7] = t, w, a
     double t_end;
     double bg[3], ba[3];
 };
 
-__global__ __launch_bounds__(256) void kp_preintegrate(const PreintJob *__restrict__ jobs,
-                                                       const double *__restrict__ samples,
-                                                       const double *__restrict__ noise36, int want_jac, int want_cov,
-                                                       double *__restrict__ out, int *__restrict__ status) {
-    __shared__ double cov[15][15], Am[9][9], Bm[9][6], Tm[9][9], Um[9][6];
+constexpr int PI_CHUNK = 32;
+
+__global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restrict__ jobs,
+                                                      const double *__restrict__ samples,
+                                                      const double *__restrict__ noise36, int want_jac, int want_cov,
+                                                      double *__restrict__ out, int *__restrict__ status) {
+    __shared__ double cov[15][15], Tm[9][9], inv[15][15];
     __shared__ double Jac[5][9], Jnew[5][9];   // dq_dbg, dp_dbg, dp_dba, dv_dbg, dv_dba
-    __shared__ double dR[9], E[9], Jr[9], Ra[9];
+    __shared__ double sA[PI_CHUNK][81], sG[PI_CHUNK][81];
+    __shared__ double sE[PI_CHUNK][9], sJr[PI_CHUNK][9], sR[PI_CHUNK][9], sRa[PI_CHUNK][9];
+    __shared__ double sEq[PI_CHUNK][4], sQ[PI_CHUNK][4], sQa[PI_CHUNK][3], sDt[PI_CHUNK];
     __shared__ double sq[4], sp3[3], sv3[3], sdt;
-    __shared__ double inv[15][15];
     __shared__ int s_piv, s_bad;
     const PreintJob job = jobs[blockIdx.x];
     const int tid = threadIdx.x;
     double *o = out + (size_t)blockIdx.x * XRHIP_IMU_DIM;
-    for (int e = tid; e < 225; e += blockDim.x) cov[e / 15][e % 15] = 0.0;
+    for (int e = tid; e < 225; e += 64) cov[e / 15][e % 15] = 0.0;
     if (tid < 45) Jac[tid / 9][tid % 9] = 0.0;
     if (tid == 0) {
         sq[0] = sq[1] = sq[2] = 0.0;
@@ -423,130 +445,153 @@ __global__ __launch_bounds__(256) void kp_preintegrate(const PreintJob *__restri
         for (int i = 0; i < 3; ++i) sp3[i] = sv3[i] = 0.0;
         sdt = 0.0;
     }
-    __syncthreads();
     const V3 bg = v3(job.bg[0], job.bg[1], job.bg[2]), ba = v3(job.ba[0], job.ba[1], job.ba[2]);
-    if (!want_cov && !want_jac) {
-        // the tracker's form (feature_tracker.cpp:55-57,89-91): only delta q/p/v -- one lane, no barriers
-        if (tid == 0) {
-            Q4 q = Q4{0, 0, 0, 1};
-            V3 pv = v3(0, 0, 0), vv = v3(0, 0, 0);
-            double T = 0;
-            for (int n = 0; n < job.sample_count; ++n) {
-                const double *smp = samples + (size_t)(job.sample_begin + n) * 7;
-                const double t1 = (n + 1 < job.sample_count) ? smp[7] : job.t_end;
-                const double dt = t1 - smp[0];
-                const V3 w = v3(smp[1], smp[2], smp[3]) - bg;
-                const V3 a = v3(smp[4], smp[5], smp[6]) - ba;
-                const V3 qa = q_rot(q, a);
-                pv = pv + vv * dt + qa * (0.5 * dt * dt);
-                vv = vv + qa * dt;
-                q = q_normalized(q_mul(q, expmap(w * dt)));
-                T = T + dt;
-            }
-            o[0] = T;
-            o[1] = q.x; o[2] = q.y; o[3] = q.z; o[4] = q.w;
-            o[5] = pv.x; o[6] = pv.y; o[7] = pv.z;
-            o[8] = vv.x; o[9] = vv.y; o[10] = vv.z;
-        }
-        for (int e = 11 + tid; e < XRHIP_IMU_DIM; e += blockDim.x) o[e] = 0.0;
-        return;
-    }
-    for (int n = 0; n < job.sample_count; ++n) {
-        const double *smp = samples + (size_t)(job.sample_begin + n) * 7;
-        const double t1 = (n + 1 < job.sample_count) ? smp[7] : job.t_end;
-        const double dt = t1 - smp[0];
-        const V3 w = v3(smp[1], smp[2], smp[3]) - bg;
-        const V3 a = v3(smp[4], smp[5], smp[6]) - ba;
-        if (tid == 0) {
-            const Q4 q = Q4{sq[0], sq[1], sq[2], sq[3]};
-            const M3 R = q_mat(q), Em = q_mat(q_conj(expmap(w * dt))), J = right_jacobian(w * dt), ra = R * hat(a);
-            for (int i = 0; i < 9; ++i) {
-                dR[i] = R.m[i];
-                E[i] = Em.m[i];
-                Jr[i] = J.m[i];
-                Ra[i] = ra.m[i];
-            }
-        }
-        __syncthreads();
-        if (want_cov) {
-            if (tid < 81) {
-                const int i = tid / 9, j = tid % 9;
-                double v = (i == j) ? 1.0 : 0.0;
-                if (i < 3 && j < 3) v = E[3 * i + j];                                  // (ES_Q, ES_Q)
-                if (i >= 6 && j < 3) v = -dt * Ra[3 * (i - 6) + j];                    // (ES_V, ES_Q)
-                if (i >= 3 && i < 6 && j < 3) v = -0.5 * dt * dt * Ra[3 * (i - 3) + j];   // (ES_P, ES_Q)
-                if (i >= 3 && i < 6 && j >= 6) v = (i - 3 == j - 6) ? dt : 0.0;        // (ES_P, ES_V)
-                Am[i][j] = v;
-            }
-            if (tid >= 128 && tid < 128 + 54) {
-                const int e = tid - 128, i = e / 6, j = e % 6;
-                double v = 0.0;
-                if (i < 3 && j < 3) v = dt * Jr[3 * i + j];                            // (ES_Q, bg)
-                if (i >= 6 && j >= 3) v = dt * dR[3 * (i - 6) + (j - 3)];              // (ES_V, ba)
-                if (i >= 3 && i < 6 && j >= 3) v = 0.5 * dt * dt * dR[3 * (i - 3) + (j - 3)];   // (ES_P, ba)
-                Bm[i][j] = v;
-            }
-            __syncthreads();
-            const double inv_dt = 1.0 / fmax(dt, 1.0e-7);
-            if (tid < 81) {
-                const int i = tid / 9, j = tid % 9;
-                double s = 0;
-                for (int k = 0; k < 9; ++k) s += Am[i][k] * cov[k][j];
-                Tm[i][j] = s;
-            }
-            if (tid >= 128 && tid < 128 + 54) {
-                const int e = tid - 128, i = e / 6, j = e % 6;
-                double s = 0;
-                if (j < 3) {
-                    for (int k = 0; k < 3; ++k) s += Bm[i][k] * (noise36[3 * k + j] * inv_dt);
-                } else {
-                    for (int k = 0; k < 3; ++k) s += Bm[i][3 + k] * (noise36[9 + 3 * k + (j - 3)] * inv_dt);
+    double walk = 0.0;   // lanes 46..63: one entry of the two 3x3 bias random-walk blocks
+    __syncthreads();
+    for (int n0 = 0; n0 < job.sample_count; n0 += PI_CHUNK) {
+        const int nc = min(PI_CHUNK, job.sample_count - n0);
+        // ---- P1
+        V3 a = v3(0, 0, 0);
+        double dt = 0.0;
+        if (tid < nc) {
+            const int n = n0 + tid;
+            const double *smp = samples + (size_t)(job.sample_begin + n) * 7;
+            const double t1 = (n + 1 < job.sample_count) ? smp[7] : job.t_end;
+            dt = t1 - smp[0];
+            const V3 w = v3(smp[1], smp[2], smp[3]) - bg;
+            a = v3(smp[4], smp[5], smp[6]) - ba;
+            const Q4 e = expmap(w * dt);
+            sEq[tid][0] = e.x; sEq[tid][1] = e.y; sEq[tid][2] = e.z; sEq[tid][3] = e.w;
+            sDt[tid] = dt;
+            if (want_cov || want_jac) {
+                const M3 Em = q_mat(q_conj(e)), J = right_jacobian(w * dt);
+                for (int i = 0; i < 9; ++i) {
+                    sE[tid][i] = Em.m[i];
+                    sJr[tid][i] = J.m[i];
                 }
-                Um[i][j] = s;
             }
-            __syncthreads();
-            if (tid < 81) {
-                const int i = tid / 9, j = tid % 9;
-                double s = 0;
-                for (int k = 0; k < 9; ++k) s += Tm[i][k] * Am[j][k];
-                double u = 0;
-                for (int k = 0; k < 6; ++k) u += Um[i][k] * Bm[j][k];
-                cov[i][j] = s + u;
-            }
-            if (tid >= 128 && tid < 128 + 18) {
-                const int e = tid - 128, blk = e / 9, i = (e % 9) / 3, j = e % 3;
-                cov[9 + 3 * blk + i][9 + 3 * blk + j] += noise36[18 + 9 * blk + 3 * i + j] * dt;
-            }
-        }
-        if (want_jac && tid < 45) {
-            const int m = tid / 9, i = (tid % 9) / 3, j = tid % 3;
-            double radq = 0, edq = 0;   // (dR hat(a) dq_dbg)_ij and (E dq_dbg)_ij
-            for (int k = 0; k < 3; ++k) {
-                radq += Ra[3 * i + k] * Jac[0][3 * k + j];
-                edq += E[3 * i + k] * Jac[0][3 * k + j];
-            }
-            double v;
-            if (m == 1) v = Jac[1][3 * i + j] + dt * Jac[3][3 * i + j] - 0.5 * dt * dt * radq;        // dp_dbg
-            else if (m == 2) v = Jac[2][3 * i + j] + dt * Jac[4][3 * i + j] - 0.5 * dt * dt * dR[3 * i + j];   // dp_dba
-            else if (m == 3) v = Jac[3][3 * i + j] - dt * radq;                                      // dv_dbg
-            else if (m == 4) v = Jac[4][3 * i + j] - dt * dR[3 * i + j];                             // dv_dba
-            else v = edq - dt * Jr[3 * i + j];                                                       // dq_dbg
-            Jnew[m][3 * i + j] = v;
         }
         __syncthreads();
-        if (want_jac && tid < 45) Jac[tid / 9][tid % 9] = Jnew[tid / 9][tid % 9];
+        // ---- P2
         if (tid == 0) {
-            const Q4 q = Q4{sq[0], sq[1], sq[2], sq[3]};
-            const V3 qa = q_rot(q, a);
-            const V3 pv = v3(sp3[0], sp3[1], sp3[2]), vv = v3(sv3[0], sv3[1], sv3[2]);
-            const V3 pn = pv + vv * dt + qa * (0.5 * dt * dt);
-            const V3 vn = vv + qa * dt;
-            const Q4 qn = q_normalized(q_mul(q, expmap(w * dt)));
-            sdt = sdt + dt;
-            sp3[0] = pn.x; sp3[1] = pn.y; sp3[2] = pn.z;
-            sv3[0] = vn.x; sv3[1] = vn.y; sv3[2] = vn.z;
-            sq[0] = qn.x; sq[1] = qn.y; sq[2] = qn.z; sq[3] = qn.w;
+            Q4 q = Q4{sq[0], sq[1], sq[2], sq[3]};
+            for (int n = 0; n < nc; ++n) {
+                sQ[n][0] = q.x; sQ[n][1] = q.y; sQ[n][2] = q.z; sQ[n][3] = q.w;
+                q = q_normalized(q_mul(q, Q4{sEq[n][0], sEq[n][1], sEq[n][2], sEq[n][3]}));
+            }
+            sq[0] = q.x; sq[1] = q.y; sq[2] = q.z; sq[3] = q.w;
         }
+        __syncthreads();
+        // ---- P3
+        if (tid < nc) {
+            const Q4 q = Q4{sQ[tid][0], sQ[tid][1], sQ[tid][2], sQ[tid][3]};
+            const V3 qa = q_rot(q, a);
+            sQa[tid][0] = qa.x; sQa[tid][1] = qa.y; sQa[tid][2] = qa.z;
+            if (want_cov || want_jac) {
+                const M3 R = q_mat(q), ra = R * hat(a);
+                for (int i = 0; i < 9; ++i) {
+                    sR[tid][i] = R.m[i];
+                    sRa[tid][i] = ra.m[i];
+                }
+                if (want_cov) {
+                    double Bm[9][6];
+                    for (int i = 0; i < 9; ++i)
+                        for (int j = 0; j < 9; ++j) {
+                            double v = (i == j) ? 1.0 : 0.0;
+                            if (i < 3 && j < 3) v = sE[tid][3 * i + j];                                // (ES_Q, ES_Q)
+                            if (i >= 6 && j < 3) v = -dt * ra.m[3 * (i - 6) + j];                      // (ES_V, ES_Q)
+                            if (i >= 3 && i < 6 && j < 3) v = -0.5 * dt * dt * ra.m[3 * (i - 3) + j];  // (ES_P, ES_Q)
+                            if (i >= 3 && i < 6 && j >= 6) v = (i - 3 == j - 6) ? dt : 0.0;            // (ES_P, ES_V)
+                            sA[tid][9 * i + j] = v;
+                        }
+                    for (int i = 0; i < 9; ++i)
+                        for (int j = 0; j < 6; ++j) {
+                            double v = 0.0;
+                            if (i < 3 && j < 3) v = dt * sJr[tid][3 * i + j];                          // (ES_Q, bg)
+                            if (i >= 6 && j >= 3) v = dt * R.m[3 * (i - 6) + (j - 3)];                 // (ES_V, ba)
+                            if (i >= 3 && i < 6 && j >= 3) v = 0.5 * dt * dt * R.m[3 * (i - 3) + (j - 3)];   // (ES_P, ba)
+                            Bm[i][j] = v;
+                        }
+                    const double inv_dt = 1.0 / fmax(dt, 1.0e-7);
+                    double Um[9][6];
+                    for (int i = 0; i < 9; ++i)
+                        for (int j = 0; j < 6; ++j) {
+                            double u = 0;
+                            if (j < 3) {
+                                for (int k = 0; k < 3; ++k) u += Bm[i][k] * (noise36[3 * k + j] * inv_dt);
+                            } else {
+                                for (int k = 0; k < 3; ++k) u += Bm[i][3 + k] * (noise36[9 + 3 * k + (j - 3)] * inv_dt);
+                            }
+                            Um[i][j] = u;
+                        }
+                    for (int i = 0; i < 9; ++i)
+                        for (int j = 0; j < 9; ++j) {
+                            double u = 0;
+                            for (int k = 0; k < 6; ++k) u += Um[i][k] * Bm[j][k];
+                            sG[tid][9 * i + j] = u;
+                        }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P4
+        if (tid == 0) {
+            V3 pv = v3(sp3[0], sp3[1], sp3[2]), vv = v3(sv3[0], sv3[1], sv3[2]);
+            double T = sdt;
+            for (int n = 0; n < nc; ++n) {
+                const double h = sDt[n];
+                const V3 qa = v3(sQa[n][0], sQa[n][1], sQa[n][2]);
+                pv = pv + vv * h + qa * (0.5 * h * h);
+                vv = vv + qa * h;
+                T = T + h;
+            }
+            sp3[0] = pv.x; sp3[1] = pv.y; sp3[2] = pv.z;
+            sv3[0] = vv.x; sv3[1] = vv.y; sv3[2] = vv.z;
+            sdt = T;
+        }
+        // ---- P5
+        if (want_cov || want_jac)
+            for (int n = 0; n < nc; ++n) {
+                const double h = sDt[n];
+                if (want_cov) {
+                    for (int e = tid; e < 81; e += 64) {
+                        const int i = e / 9, j = e - 9 * i;
+                        double s2 = 0;
+                        for (int k = 0; k < 9; ++k) s2 += sA[n][9 * i + k] * cov[k][j];
+                        Tm[i][j] = s2;
+                    }
+                    if (tid >= 46) {
+                        const int e = tid - 46, blk = e / 9, r = e - 9 * blk;
+                        walk += noise36[18 + 9 * blk + r] * h;
+                    }
+                }
+                if (want_jac && tid < 45) {
+                    const int m = tid / 9, i = (tid % 9) / 3, j = tid % 3;
+                    const double *Ra = sRa[n], *E = sE[n], *dR = sR[n], *Jr = sJr[n];
+                    double radq = 0, edq = 0;   // (dR hat(a) dq_dbg)_ij and (E dq_dbg)_ij
+                    for (int k = 0; k < 3; ++k) {
+                        radq += Ra[3 * i + k] * Jac[0][3 * k + j];
+                        edq += E[3 * i + k] * Jac[0][3 * k + j];
+                    }
+                    double v;
+                    if (m == 1) v = Jac[1][3 * i + j] + h * Jac[3][3 * i + j] - 0.5 * h * h * radq;        // dp_dbg
+                    else if (m == 2) v = Jac[2][3 * i + j] + h * Jac[4][3 * i + j] - 0.5 * h * h * dR[3 * i + j];   // dp_dba
+                    else if (m == 3) v = Jac[3][3 * i + j] - h * radq;                                     // dv_dbg
+                    else if (m == 4) v = Jac[4][3 * i + j] - h * dR[3 * i + j];                            // dv_dba
+                    else v = edq - h * Jr[3 * i + j];                                                      // dq_dbg
+                    Jnew[m][3 * i + j] = v;
+                }
+                __syncthreads();
+                if (want_cov)
+                    for (int e = tid; e < 81; e += 64) {
+                        const int i = e / 9, j = e - 9 * i;
+                        double s2 = 0;
+                        for (int k = 0; k < 9; ++k) s2 += Tm[i][k] * sA[n][9 * j + k];
+                        cov[i][j] = s2 + sG[n][9 * i + j];
+                    }
+                if (want_jac && tid < 45) Jac[tid / 9][tid % 9] = Jnew[tid / 9][tid % 9];
+                __syncthreads();
+            }
         __syncthreads();
     }
     // outputs
@@ -560,8 +605,12 @@ __global__ __launch_bounds__(256) void kp_preintegrate(const PreintJob *__restri
     }
     if (tid < 45) o[11 + tid] = Jac[tid / 9][tid % 9];
     if (!want_cov) {
-        for (int e = tid; e < 225; e += blockDim.x) o[56 + e] = 0.0;
+        for (int e = tid; e < 225; e += 64) o[56 + e] = 0.0;
         return;
+    }
+    if (tid >= 46) {
+        const int e = tid - 46, blk = e / 9, r = e - 9 * blk;
+        cov[9 + 3 * blk + r / 3][9 + 3 * blk + r % 3] = walk;
     }
     // sqrt_inv_cov = LLT(cov^-1).matrixL().transpose()
     __syncthreads();
@@ -570,14 +619,14 @@ __global__ __launch_bounds__(256) void kp_preintegrate(const PreintJob *__restri
         return;
     }
     // Cholesky of inv (lower) in place into cov (reused as L)
-    for (int e = tid; e < 225; e += blockDim.x) cov[e / 15][e % 15] = 0.0;
+    for (int e = tid; e < 225; e += 64) cov[e / 15][e % 15] = 0.0;
     __syncthreads();
     for (int j = 0; j < 15; ++j) {
         if (tid < 15 && tid >= j) {
             const int i = tid;
-            double s = inv[i][j];
-            for (int k = 0; k < j; ++k) s -= cov[i][k] * cov[j][k];
-            inv[i][j] = s;   // column j updated in place
+            double s2 = inv[i][j];
+            for (int k = 0; k < j; ++k) s2 -= cov[i][k] * cov[j][k];
+            inv[i][j] = s2;   // column j updated in place
         }
         __syncthreads();
         const double djj = inv[j][j];
@@ -589,7 +638,7 @@ __global__ __launch_bounds__(256) void kp_preintegrate(const PreintJob *__restri
         if (tid < 15 && tid >= j) cov[tid][j] = (tid == j) ? dj : inv[tid][j] / dj;
         __syncthreads();
     }
-    for (int e = tid; e < 225; e += blockDim.x) o[56 + e] = cov[e % 15][e / 15];   // L^T, row-major
+    for (int e = tid; e < 225; e += 64) o[56 + e] = cov[e % 15][e / 15];   // L^T, row-major
 }
 
 }   // namespace xrhip
