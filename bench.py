@@ -127,6 +127,10 @@ def main():
             "host_wall_ms_per_frame": {k[5:]: round(1e3 * (getattr(t_e, k) - getattr(t_w, k)) / args.steps, 4)
                                        for k in ("wall_frame", "wall_preprocess", "wall_track", "wall_detect",
                                                  "wall_preintegrate", "wall_solve", "wall_marginalize")},
+            "host_scope_ms_per_frame": dict(zip(
+                ("ft_track", "ransac_essential", "ransac_rotation", "ft_detect", "mirror_frame", "localize", "manage_keyframe",
+                 "track_landmark", "refine_window", "slide_window", "refine_subwindow"),
+                [round(1e3 * (t_e.wall_scope[i] - t_w.wall_scope[i]) / args.steps, 4) for i in range(11)])),
             "ate_rmse_m": round(runner.ate_rmse(poses, seq), 5),
             "roofline": {"kernel": "k_lk_track", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,

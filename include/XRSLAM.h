@@ -149,10 +149,14 @@ void XRSLAMAmdSetInitialState(double t, const double q[4], const double p[3], co
 void XRSLAMAmdPushImageDevice(const void *gray_dev, int stride, double timestamp);
 typedef struct XRSLAMAmdTimes {
     long frames, solves, solve_iterations, marginalizations, keyframes;
-    double ba_device_ms; /* sum of HIP-event solve times */
+    double ba_device_ms; /* sum of xrhip_ba_summary.ms_solve (staging + kernels + result read-back of every solve) */
     /* host wall-clock seconds inside the inner C-ABI calls (preprocess, track, detect, preintegrate, solve,
      * marginalize) and in the whole per-frame work (FeatureTracker::work incl. the backend) */
     double wall_preprocess, wall_track, wall_detect, wall_preintegrate, wall_solve, wall_marginalize, wall_frame;
+    /* host wall-clock seconds of whole pipeline stages (their device waits included): Frame::track_keypoints,
+     * of which 5-pt RANSAC, 2-pt RANSAC; Frame::detect_keypoints; mirror_frame; localize_newframe; manage_keyframe;
+     * track_landmark; refine_window; slide_window; refine_subwindow; rest reserved */
+    double wall_scope[16];
 } XRSLAMAmdTimes;
 void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out);
 /* HIP-event profiling of the KLT kernels (off by default) and its accumulated counters; the struct is

@@ -181,7 +181,7 @@ typedef struct xrhip_ba_summary {
     int termination;       /* XRHIP_BA_* */
     int usable;            /* Summary::IsSolutionUsable() */
     double initial_cost, final_cost;
-    double ms_solve;       /* HIP-event time of the whole solve on the BA stream */
+    double ms_solve;       /* host wall-clock of the whole solve: staging, every kernel, result mailbox read */
 } xrhip_ba_summary;
 
 /* marginalisation of one frame (CeresMarginalizationFactor::marginalize,

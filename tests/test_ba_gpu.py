@@ -130,6 +130,14 @@ def test_localize_solve_parity(ctx, bo):
     assert sm_h.termination == 0 and sm_h.successful_steps >= 2
 
 
+def test_subwindow_sized_problem_parity(ctx, bo):
+    """refine_subwindow: a fixed keyframe, a few free subframes, reprojection priors only (no free landmark:
+    the Schur complement is empty)."""
+    pd, _ = bs.make_window(K=4, L=60, seed=31, with_prior=False, n_fixed_first=1)
+    pd.landmark_fix[:] = 1
+    _solve_both(ctx, bo, pd, "subwindow")
+
+
 def test_vision_only_and_fixed_frames_parity(ctx, bo):
     pd, _ = bs.make_window(K=6, L=80, seed=5)
     pd.frame_fix[:] = abi.FIX_MOTION

@@ -8,6 +8,8 @@
 #include "marg_kernels.hip.h"
 #include "common.hip.h"
 
+#include <cstdlib>
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -33,7 +35,6 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct xrhip_ba {
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Arena in;         // inputs (uploaded every solve)
     char *work = nullptr;   // device-only workspace
     size_t work_cap = 0;
@@ -41,7 +42,9 @@ struct xrhip_ba {
     size_t work2_cap = 0;
     char *h_stage = nullptr;   // pinned staging for work2 transfers
     size_t h_stage_cap = 0;
-    BaCtl *h_ctl = nullptr;   // pinned
+    BaCtl *h_ctl = nullptr;   // pinned; doubles as the zero-copy mailbox of kb_try
+    int *h_seq = nullptr;     // pinned; sequence number published by kb_try after h_ctl / h_out
+    int seq = 0;
     double *h_out = nullptr;  // pinned readback (states + depths)
     size_t h_out_cap = 0;
     int lds_limit = 150 * 1024;
@@ -159,6 +162,8 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
         if (k < 6 ? !(P->frame_fix[f] & XRHIP_FIX_POSE) : !(P->frame_fix[f] & XRHIP_FIX_MOTION)) act_idx.push_back(a);
     }
     d.na = (int)act_idx.size();
+    d.nla = 0;
+    for (int l = 0; l < L; ++l) d.nla += lact[l] ? 1 : 0;
     std::vector<int> imuf(2 * F, -1), priorf(F, -1);
     for (int k = 0; k < NI; ++k) {
         if (imuf[2 * P->imu_j[k]] >= 0 || imuf[2 * P->imu_i[k] + 1] >= 0)
@@ -314,6 +319,9 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     p.partial = (double *)(W + w_part);
     p.wog = (double *)(W + w_wog);
     p.ctl = (BaCtl *)(I + o_ctl);
+    XR_HIP(hipHostGetDevicePointer((void **)&p.host_ctl, c->h_ctl, 0));
+    XR_HIP(hipHostGetDevicePointer((void **)&p.host_out, c->h_out, 0));
+    XR_HIP(hipHostGetDevicePointer((void **)&p.host_seq, c->h_seq, 0));
     cam.q = Q4{P->cam_q_bc[0], P->cam_q_bc[1], P->cam_q_bc[2], P->cam_q_bc[3]};
     cam.p = V3{P->cam_p_bc[0], P->cam_p_bc[1], P->cam_p_bc[2]};
     imu.q = Q4{P->imu_q_bi[0], P->imu_q_bi[1], P->imu_q_bi[2], P->imu_q_bi[3]};
@@ -321,40 +329,67 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     return XRHIP_OK;
 }
 
+// one linearisation: 3 launches + the cost (and, for the solver, gradient norm + per-solve preparation)
 static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
-                             double sy) {
+                             double sy, bool for_solver) {
     hipStream_t s = c->stream;
-    if (d.M) hipLaunchKernelGGL(kb_lin_obs, dim3((d.M + 255) / 256), dim3(256), 0, s, d, p, cam, sx, sy);
-    if (d.MR) hipLaunchKernelGGL(kb_lin_rot, dim3((d.MR + 255) / 256), dim3(256), 0, s, d, p, cam, sx, sy);
-    if (d.NI) hipLaunchKernelGGL(kb_lin_imu, dim3(d.NI), dim3(64), 0, s, d, p, imu);
-    hipLaunchKernelGGL(kb_lin_prior, dim3(1), dim3(256), sizeof(double) * std::max(d.np, 1), s, d, p);
-    hipLaunchKernelGGL(kb_landmark, dim3(d.Lp), dim3(64), 0, s, d, p);
-    hipLaunchKernelGGL(kb_assemble_vision, dim3(d.F * d.F), dim3(64), 0, s, d, p);
+    hipLaunchKernelGGL(kb_lin_all, dim3(lin_all_blocks(d.M, d.MR, d.NI)), dim3(256), sizeof(double) * std::max(d.np, 1), s, d, p,
+                       cam, imu, sx, sy);
+    hipLaunchKernelGGL(kb_landmark_vision, dim3(d.Lp + d.F * d.F), dim3(64), 0, s, d, p);
     hipLaunchKernelGGL(kb_assemble, dim3((d.n * d.n + 255) / 256), dim3(256), 0, s, d, p);
-    hipLaunchKernelGGL(kb_sum_cost, dim3(1), dim3(256), 0, s, d, p);
-    hipLaunchKernelGGL(kb_gradmax, dim3(1), dim3(256), 0, s, d, p);
+    if (for_solver) hipLaunchKernelGGL(kb_cost_prepare, dim3(1), dim3(256), 0, s, d, p);
+    else hipLaunchKernelGGL(kb_sum_cost, dim3(1), dim3(256), 0, s, d, p);
 }
 
-static int launch_solve(xrhip_ba *c, const BaDims &d, const BaPtrs &p) {
-    hipStream_t s = c->stream;
-    hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);
-    const int tiles = d.PF / 16;
-    hipLaunchKernelGGL(kb_schur_mfma, dim3(tiles * tiles), dim3(256), 0, s, d, p);
-    hipLaunchKernelGGL(kb_solve_aux, dim3(aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64), dim3(256), 0, s, d, p);
-    // dynamic LDS: rhs [na] + work region = max(packed triangle, gathered frame step of the back-substitution);
-    // systems whose triangle does not fit are factored in the (L2-resident) global buffer Sred instead
+// dynamic LDS of kb_solve / solve_block: rhs [na] + work region = max(packed triangle, gathered frame step of the
+// back-substitution); systems whose triangle does not fit `limit` are factored in the global buffer Sred instead
+static int solve_lds(const BaDims &d, size_t limit, size_t *bytes, int *use_lds) {
     const size_t tri = (size_t)d.na * (d.na + 1) / 2;
     const size_t aux = (size_t)d.PF;
     size_t lds = sizeof(double) * ((size_t)((d.na + 1) & ~1) + std::max(tri, aux));
-    int use_lds = 1;
-    if (lds > (size_t)c->lds_limit) {
-        use_lds = 0;
+    *use_lds = 1;
+    if (lds > limit) {
+        *use_lds = 0;
         lds = sizeof(double) * ((size_t)((d.na + 1) & ~1) + aux);
-        if (lds > (size_t)c->lds_limit) return xr_fail(XRHIP_EOVERFLOW, "xrhip_ba_solve: problem exceeds the LDS work region");
+        if (lds > limit) return xr_fail(XRHIP_EOVERFLOW, "xrhip_ba_solve: problem exceeds the LDS work region");
     }
-    hipLaunchKernelGGL(kb_solve, dim3(1), dim3(512), lds, s, d, p, use_lds);
+    *bytes = lds;
+    return XRHIP_OK;
+}
+
+// reduced-system solve + trust-region trials: 2 launches (3 when mu changed without a new linearisation)
+static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
+                            double sy, bool prepare, int mode, int seq) {
+    hipStream_t s = c->stream;
+    if (prepare) hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);
+    const int tiles = d.PF / 16;
+    hipLaunchKernelGGL(kb_schur_aux, dim3(tiles * tiles + aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64), dim3(256), 0, s, d, p);
+    size_t lds = 0;
+    int use_lds = 1;
+    int rcl = solve_lds(d, (size_t)c->lds_limit, &lds, &use_lds);
+    if (rcl) return rcl;
+    lds = std::max(lds, sizeof(double) * (size_t)std::max(d.np, 1));
+    hipLaunchKernelGGL(kb_solve_try, dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq);
     XR_HIP(hipGetLastError());
     return XRHIP_OK;
+}
+
+// Spin on the sequence number kb_try stores (system-scope release) after its results: completion is seen a
+// few microseconds after the kernel's last store, where a blocking hipStreamSynchronize costs 20-30 us.
+// hipStreamQuery is polled now and then so that a faulted kernel turns into an error instead of a hang.
+static int wait_mailbox(xrhip_ba *c, int seq) {
+    volatile int *flag = c->h_seq;
+    for (unsigned long spin = 1;; ++spin) {
+        if (*flag == seq) return XRHIP_OK;
+        if ((spin & 0x3FFF) == 0) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) {
+                if (*flag == seq) return XRHIP_OK;
+                return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: trial kernel retired without publishing its result");
+            }
+            if (q != hipErrorNotReady) return xr_fail(XRHIP_EHIP, "xrhip_ba_solve: stream error while waiting for the trial kernel");
+        }
+    }
 }
 
 static long long g_kprof[32];   // accumulated in-kernel phase ticks (all zero unless built with -DXRHIP_KPROF)
@@ -376,11 +411,10 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
     if (rc) return rc;
     xrhip_ba *c = new xrhip_ba();
     XR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    XR_HIP(hipEventCreate(&c->ev0));
-    XR_HIP(hipEventCreate(&c->ev1));
     XR_HIP(hipHostMalloc(&c->h_ctl, sizeof(BaCtl), hipHostMallocDefault));
-    XR_HIP(hipFuncSetAttribute((const void *)kb_solve, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
-    XR_HIP(hipFuncSetAttribute((const void *)kb_try, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    XR_HIP(hipHostMalloc(&c->h_seq, 64, hipHostMallocDefault));
+    *c->h_seq = 0;
+    XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_chol, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     // pre-size for the advertised maxima
@@ -400,9 +434,8 @@ void xrhip_ba_destroy(xrhip_ba *c) {
     hipFree(c->work2);
     hipHostFree(c->h_stage);
     hipHostFree(c->h_ctl);
+    hipHostFree(c->h_seq);
     hipHostFree(c->h_out);
-    hipEventDestroy(c->ev0);
-    hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -432,48 +465,47 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     BaDims d;
     BaPtrs p;
     Ext cam, imu;
-    XR_HIP(hipEventRecord(c->ev0, c->stream));
+    const auto t_begin = std::chrono::steady_clock::now();
     rc = stage_problem(c, P, d, p, cam, imu);
     if (rc) return rc;
     const double sx = P->sqrt_inv_cov[0], sy = P->sqrt_inv_cov[1];
     hipStream_t s = c->stream;
     if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);
-    launch_linearize(c, d, p, cam, imu, sx, sy);
-    rc = launch_solve(c, d, p);
-    if (rc) return rc;
+    bool done = false, relinearise = true;
     int mode = 1;
-    const size_t try_lds = sizeof(double) * std::max(d.np, 1);
-    for (int guard = 0; guard < 4 * (P->max_iterations + 8); ++guard) {
-        hipLaunchKernelGGL(kb_try, dim3(1), dim3(512), try_lds, s, d, p, cam, imu, sx, sy, mode);
-        XR_HIP(hipGetLastError());
-        XR_HIP(hipMemcpyAsync(c->h_ctl, p.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, s));
-        XR_HIP(hipStreamSynchronize(s));
+    for (int guard = 0; guard < 4 * (P->max_iterations + 8) && !done; ++guard) {
+        const int seq = ++c->seq;
+        if (relinearise) launch_linearize(c, d, p, cam, imu, sx, sy, true);
+        rc = launch_solve_try(c, d, p, cam, imu, sx, sy, !relinearise, mode, seq);
+        if (rc) return rc;
+        rc = wait_mailbox(c, seq);   // no copy, no driver wait: the kernel's last store is the sequence number
+        if (rc) return rc;
         const int st = c->h_ctl->status;
-        if (st == ST_DONE) break;
-        if (st == ST_ACCEPTED) {
-            launch_linearize(c, d, p, cam, imu, sx, sy);
-            rc = launch_solve(c, d, p);
-            if (rc) return rc;
+        if (st == ST_DONE) {
+            done = true;   // the optimised states are already in h_out
+        } else if (st == ST_ACCEPTED) {
+            relinearise = true;
             mode = 1;
         } else if (st == ST_RESOLVE || st == ST_RESOLVE_INNER) {
-            rc = launch_solve(c, d, p);
-            if (rc) return rc;
+            relinearise = false;
             mode = (st == ST_RESOLVE) ? 2 : 3;
         } else {
             return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: unexpected device status");
         }
     }
-    // read back the optimised states (in place, like the reference)
-    XR_HIP(hipMemcpyAsync(c->h_out, p.state, sizeof(double) * 16 * d.F, hipMemcpyDeviceToHost, s));
-    if (d.L) XR_HIP(hipMemcpyAsync(c->h_out + 16 * d.F, p.depth, sizeof(double) * d.L, hipMemcpyDeviceToHost, s));
-    XR_HIP(hipEventRecord(c->ev1, s));
-    XR_HIP(hipStreamSynchronize(s));
+    if (!done) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: trust-region loop did not terminate");
+    // the optimised states (in place, like the reference)
     std::memcpy(P->frame_state, c->h_out, sizeof(double) * 16 * d.F);
     if (d.L) std::memcpy(P->inv_depth, c->h_out + 16 * d.F, sizeof(double) * d.L);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     const BaCtl &ctl = *c->h_ctl;
-    for (int i = 0; i < 32; ++i) g_kprof[i] += ctl.prof[i];
+    {   // development aid: XRHIP_KPROF_MIN_NA restricts the accumulated phase timers to solves of at least that size
+        static const int min_na = std::getenv("XRHIP_KPROF_MIN_NA") ? std::atoi(std::getenv("XRHIP_KPROF_MIN_NA")) : 0;
+        if (d.na >= min_na) {
+            for (int i = 0; i < 32; ++i) g_kprof[i] += ctl.prof[i];
+            g_kprof[31] += 1;   // solves counted
+        }
+    }
     sm.iterations = ctl.iteration;
     sm.successful_steps = ctl.successful_steps;
     sm.termination = ctl.termination;
@@ -503,7 +535,7 @@ int xrhip_ba_debug_linearize(xrhip_ba *c, const xrhip_ba_problem *P, double *H, 
     if (rc) return rc;
     hipStream_t s = c->stream;
     if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);
-    launch_linearize(c, d, p, cam, imu, P->sqrt_inv_cov[0], P->sqrt_inv_cov[1]);
+    launch_linearize(c, d, p, cam, imu, P->sqrt_inv_cov[0], P->sqrt_inv_cov[1], false);
     XR_HIP(hipGetLastError());
     XR_HIP(hipMemcpyAsync(c->h_ctl, p.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, s));
     if (H) XR_HIP(hipMemcpyAsync(H, p.Hpp, sizeof(double) * (size_t)d.n * d.n, hipMemcpyDeviceToHost, s));
@@ -655,7 +687,7 @@ int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_s
     hipStream_t s = c->stream;
     XR_HIP(hipMemsetAsync(dst, 0, sizeof(int) * 4, s));
     if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);
-    launch_linearize(c, d, p, cam, imu, M->sqrt_inv_cov[0], M->sqrt_inv_cov[1]);
+    launch_linearize(c, d, p, cam, imu, M->sqrt_inv_cov[0], M->sqrt_inv_cov[1], false);
     hipLaunchKernelGGL(km_omega, dim3((std::max(d.L, 1) + 255) / 256), dim3(256), 0, s, d, p);
     const int tiles = d.PF / 16;
     hipLaunchKernelGGL(kb_schur_mfma, dim3(tiles * tiles), dim3(256), 0, s, d, p);

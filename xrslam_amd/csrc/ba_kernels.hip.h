@@ -72,6 +72,7 @@ struct BaDims {
     int NV;             // n + L
     int robust;         // 1: CauchyLoss(1) on visual factors (Solver); 0: none (marginalisation)
     int na;             // number of free frame dofs (size of the reduced system actually factored)
+    int nla;            // number of free landmarks (0: no Schur complement, kb_mono skips the landmark phases)
 };
 
 struct BaPtrs {
@@ -111,6 +112,11 @@ struct BaPtrs {
     double *diagD, *grad, *gn, *gs, *step, *delta;   // [NV] each
     double *partial;                 // [aux_quad_blocks] partial sums of Q(g~,g~)
     double *wog;                     // [PF] W^T (omega gl)
+    // zero-copy mailbox in pinned host memory (device-visible addresses): the trial kernel publishes the
+    // control block, on termination the optimised states, and last a sequence number the host spins on
+    BaCtl *host_ctl;
+    double *host_out;                // [16 F + L]
+    int *host_seq;
     BaCtl *ctl;
 };
 
@@ -192,13 +198,15 @@ __device__ __forceinline__ double obs_eval(const BaDims &d, const BaPtrs &p, int
     return d.robust ? 0.5 * log(1.0 + s) : 0.5 * s;
 }
 
-__global__ __launch_bounds__(256) void kb_lin_obs(BaDims d, BaPtrs p, Ext cam, double sx, double sy) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= d.M) return;
+__device__ __forceinline__ void lin_obs_item(const BaDims &d, const BaPtrs &p, const Ext &cam, double sx, double sy, int o) {
     double rec[OREC];
     p.ocost[o] = obs_eval(d, p, o, p.state, p.depth, cam, sx, sy, true, rec);
 #pragma unroll
     for (int i = 0; i < OREC; ++i) p.orec[(size_t)o * OREC + i] = rec[i];
+}
+__global__ __launch_bounds__(256) void kb_lin_obs(BaDims d, BaPtrs p, Ext cam, double sx, double sy) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o < d.M) lin_obs_item(d, p, cam, sx, sy, o);
 }
 
 __device__ __forceinline__ double rot_eval(const BaDims &d, const BaPtrs &p, int o, const double *state,
@@ -224,13 +232,15 @@ __device__ __forceinline__ double rot_eval(const BaDims &d, const BaPtrs &p, int
     return 0.5 * log(1.0 + s);
 }
 
-__global__ __launch_bounds__(256) void kb_lin_rot(BaDims d, BaPtrs p, Ext cam, double sx, double sy) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= d.MR) return;
+__device__ __forceinline__ void lin_rot_item(const BaDims &d, const BaPtrs &p, const Ext &cam, double sx, double sy, int o) {
     double rec[RREC];
     p.rcost[o] = rot_eval(d, p, o, p.state, cam, sx, sy, true, rec);
 #pragma unroll
     for (int i = 0; i < RREC; ++i) p.rrec[(size_t)o * RREC + i] = rec[i];
+}
+__global__ __launch_bounds__(256) void kb_lin_rot(BaDims d, BaPtrs p, Ext cam, double sx, double sy) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o < d.MR) lin_rot_item(d, p, cam, sx, sy, o);
 }
 
 // --------------------------------------------------------------------- IMU factors
@@ -280,11 +290,11 @@ __device__ __forceinline__ double imu_cost_wave(const BaPtrs &p, int k, const do
     return wave_sum(c) * (lane == 0 ? 1.0 : 0.0);
 }
 
-// One 64-lane workgroup per IMU factor: lane 0 evaluates the (serial) SO(3) algebra into LDS, then all
-// lanes apply the 15x15 whitening to the residual and both Jacobians.
-__global__ __launch_bounds__(64) void kb_lin_imu(BaDims d, BaPtrs p, Ext imu) {
-    __shared__ double raw[15], Ji[225], Jj[225];
-    const int k = blockIdx.x, lane = threadIdx.x;
+// One wavefront per IMU factor: lane 0 evaluates the (serial) SO(3) algebra into LDS, then all lanes apply the
+// 15x15 whitening to the residual and both Jacobians.  scr: IMU_SCR doubles of LDS owned by this wavefront.
+constexpr int IMU_SCR = 15 + 225 + 225;
+__device__ __forceinline__ void lin_imu_item(const BaDims &d, const BaPtrs &p, const Ext &imu, int k, int lane, double *scr) {
+    double *raw = scr, *Ji = scr + 15, *Jj = scr + 240;
     const int fi = p.imu_i[k], fj = p.imu_j[k];
     const double *data = p.imu_data + (size_t)k * XRHIP_IMU_DIM;
     const bool active = !(p.fix[fi] == 3 && p.fix[fj] == 3);
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(64) void kb_lin_imu(BaDims d, BaPtrs p, Ext imu) {
         Ji[i] = 0.0;
         Jj[i] = 0.0;
     }
-    __syncthreads();
+    wave_sync();
     if (lane == 0 && active) {
         const FState si = load_state(p.state + 16 * fi), sj = load_state(p.state + 16 * fj);
         const ImuRec pre = load_imu(data);
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(64) void kb_lin_imu(BaDims d, BaPtrs p, Ext imu) {
         for (int i = 0; i < 15; ++i) raw[i] = r15[i];
         imu_raw_jacobians(si, sj, pre, bg0, ba0, imu, v3(r15[0], r15[1], r15[2]), Ji, Jj);
     }
-    __syncthreads();
+    wave_sync();
     const double *S = data + 56;
     double cost = 0.0;
     if (lane < 15) {
@@ -330,6 +340,11 @@ __global__ __launch_bounds__(64) void kb_lin_imu(BaDims d, BaPtrs p, Ext imu) {
         p.imu_Ji[(size_t)225 * k + e] = a;
         p.imu_Jj[(size_t)225 * k + e] = b;
     }
+    wave_sync();   // scr may be reused by the caller for the next factor
+}
+__global__ __launch_bounds__(64) void kb_lin_imu(BaDims d, BaPtrs p, Ext imu) {
+    __shared__ double scr[IMU_SCR];
+    lin_imu_item(d, p, imu, blockIdx.x, threadIdx.x, scr);
 }
 
 // ------------------------------------------------------------------------ prior
@@ -372,9 +387,8 @@ __device__ __forceinline__ double prior_cost_block(const BaDims &d, const BaPtrs
     return 0.5 * block_sum(c, scratch);
 }
 
-__global__ __launch_bounds__(256) void kb_lin_prior(BaDims d, BaPtrs p) {
-    extern __shared__ double sh[];   // np doubles
-    __shared__ double scratch[8];
+// block-wide, any workgroup size; sh: np doubles of LDS, scratch: blockDim/64 doubles
+__device__ __forceinline__ void lin_prior_block(const BaDims &d, const BaPtrs &p, double *sh, double *scratch) {
     if (d.NP == 0) {
         if (threadIdx.x == 0) p.pcost[0] = 0.0;
         return;
@@ -395,6 +409,11 @@ __global__ __launch_bounds__(256) void kb_lin_prior(BaDims d, BaPtrs p) {
         p.pt[j] = s;
     }
 }
+__global__ __launch_bounds__(256) void kb_lin_prior(BaDims d, BaPtrs p) {
+    extern __shared__ double sh[];   // np doubles
+    __shared__ double scratch[8];
+    lin_prior_block(d, p, sh, scratch);
+}
 
 // Lam = S^T S (once per prior upload)
 __global__ __launch_bounds__(256) void kb_prior_lambda(int np, const double *__restrict__ S, double *__restrict__ Lam) {
@@ -409,15 +428,14 @@ __global__ __launch_bounds__(256) void kb_prior_lambda(int np, const double *__r
 // -------------------------------------------------------------------- landmarks
 // One wavefront per landmark: H_ll, g_l and the cross-term row W_l (6 values per observing frame),
 // written as a dense row of Wt [Lp][PF] (zero elsewhere) so the Schur product is a plain MFMA SYRK.
-__global__ __launch_bounds__(64) void kb_landmark(BaDims d, BaPtrs p) {
-    const int l = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void landmark_item(const BaDims &d, const BaPtrs &p, int l, int lane) {
     double *row = p.Wt + (size_t)l * d.PF;
     for (int c = lane; c < d.PF; c += 64) row[c] = 0.0;
     if (l >= d.L) return;
     const int b = p.lm_start[l], e = p.lm_start[l + 1];
     double hll = 0, gl = 0, wr[6] = {0, 0, 0, 0, 0, 0};
     int ref = -1;
-    __syncthreads();
+    wave_sync();
     for (int it = b + lane; it < e + ((64 - (e - b) % 64) % 64); it += 64) {   // uniform trip count for the shuffles
         const bool valid = it < e;
         double wt[6] = {0, 0, 0, 0, 0, 0};
@@ -448,7 +466,8 @@ __global__ __launch_bounds__(64) void kb_landmark(BaDims d, BaPtrs p) {
     int refm = ref;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) refm = max(refm, __shfl_xor(refm, off));
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0);   // the row stores above must have landed before lane 0 adds the reference block
+    wave_sync();
     if (lane == 0) {
         p.hll[l] = hll;
         p.gl[l] = gl;
@@ -457,13 +476,15 @@ __global__ __launch_bounds__(64) void kb_landmark(BaDims d, BaPtrs p) {
             for (int a = 0; a < 6; ++a) row[6 * refm + a] += wr[a];
     }
 }
+__global__ __launch_bounds__(64) void kb_landmark(BaDims d, BaPtrs p) { landmark_item(d, p, blockIdx.x, threadIdx.x); }
 
 // --------------------------------------------------------------------- assembly
 // Reprojection blocks: one wavefront per (row frame, column frame) pair.  The lanes stride over the pair's
 // observation list, each accumulating a private 6x6 block (+ 6-vector for the diagonal pair); a fixed
 // butterfly reduction combines them -- "batched small-block JtJ accumulation with wavefront-shuffle reductions".
-__global__ __launch_bounds__(64) void kb_assemble_vision(BaDims d, BaPtrs p) {
-    const int fa = blockIdx.x / d.F, fb = blockIdx.x - fa * d.F, lane = threadIdx.x;
+__device__ __forceinline__ void assemble_vision_item(const BaDims &d, const BaPtrs &p, int pair, int lane) {
+    const int fa = pair / d.F, fb = pair - fa * d.F;
+    if (!pose_free(p.fix[fa]) || !pose_free(p.fix[fb])) return;   // the block is never read (kb_assemble)
     const int s0 = p.pair_start[fa * d.F + fb], s1 = p.pair_start[fa * d.F + fb + 1];
     double h[36], g[6];
 #pragma unroll
@@ -497,7 +518,7 @@ __global__ __launch_bounds__(64) void kb_assemble_vision(BaDims d, BaPtrs p) {
         for (int i = 0; i < 6; ++i) g[i] = wave_sum(g[i]);
     }
     if (lane == 0) {
-        double *out = p.Hv + (size_t)blockIdx.x * 36;
+        double *out = p.Hv + (size_t)pair * 36;
 #pragma unroll
         for (int i = 0; i < 36; ++i) out[i] = h[i];
         if (diag)
@@ -505,13 +526,12 @@ __global__ __launch_bounds__(64) void kb_assemble_vision(BaDims d, BaPtrs p) {
             for (int i = 0; i < 6; ++i) p.gv[6 * fa + i] = g[i];
     }
 }
+__global__ __launch_bounds__(64) void kb_assemble_vision(BaDims d, BaPtrs p) { assemble_vision_item(d, p, blockIdx.x, threadIdx.x); }
 
 // One thread per element (a,b) of the frame Hessian Hpp (15F x 15F) and, for b == 0, of g: adds the
 // reprojection block, rotation priors, the (at most two) IMU factors adjacent to the frame and the prior,
 // always in this fixed order.
-__global__ __launch_bounds__(256) void kb_assemble(BaDims d, BaPtrs p) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= d.n * d.n) return;
+__device__ __forceinline__ void assemble_item(const BaDims &d, const BaPtrs &p, int e) {
     const int a = e / d.n, b = e - a * d.n;
     const int fa = a / 15, ka = a - 15 * fa, fb = b / 15, kb = b - 15 * fb;
     double h = 0.0, g = 0.0;
@@ -578,10 +598,14 @@ __global__ __launch_bounds__(256) void kb_assemble(BaDims d, BaPtrs p) {
     p.Hpp[e] = h;
     if (want_g) p.gp[a] = g;
 }
+__global__ __launch_bounds__(256) void kb_assemble(BaDims d, BaPtrs p) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < d.n * d.n) assemble_item(d, p, e);
+}
 
 // ------------------------------------------------------------------ preparation
 // Jacobi scales (first linearisation only), dogleg diagonal, scaled gradient, landmark Schur weights.
-__global__ __launch_bounds__(256) void kb_prepare(BaDims d, BaPtrs p) {
+__device__ __forceinline__ void prepare_block(const BaDims &d, const BaPtrs &p) {
     const BaCtl *c = p.ctl;
     const double mu = c->mu;
     for (int a = threadIdx.x; a < d.n; a += blockDim.x) {
@@ -592,7 +616,7 @@ __global__ __launch_bounds__(256) void kb_prepare(BaDims d, BaPtrs p) {
         p.gs[a] = s * p.gp[a];
     }
     for (int l = threadIdx.x; l < d.L; l += blockDim.x) {
-        const double h = p.hll[l];
+        const double h = p.lact[l] ? p.hll[l] : 0.0;   // constant landmarks take no part; keep their scales finite
         if (c->first) p.sl[l] = 1.0 / (1.0 + sqrt(h));
         const double s = p.sl[l];
         const double D = sqrt(fmin(fmax(s * s * h, 1e-6), 1e32));
@@ -601,6 +625,7 @@ __global__ __launch_bounds__(256) void kb_prepare(BaDims d, BaPtrs p) {
         p.omega[l] = p.lact[l] ? 1.0 / (h + mu * D * D / (s * s)) : 0.0;
     }
 }
+__global__ __launch_bounds__(256) void kb_prepare(BaDims d, BaPtrs p) { prepare_block(d, p); }
 
 // ------------------------------------------------------------------- MFMA Schur
 // T = W^T diag(omega) W, i.e. H_pl H_ll'^-1 H_lp of the reduced camera system, on the f64 matrix
@@ -610,10 +635,10 @@ __global__ __launch_bounds__(256) void kb_prepare(BaDims d, BaPtrs p) {
 // D: col = lane&15, row = (lane>>4) + 4*reg.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void kb_schur_mfma(BaDims d, BaPtrs p) {
+__device__ __forceinline__ void schur_tile_block(const BaDims &d, const BaPtrs &p, int tile) {
     __shared__ double red[4][256];
     const int tiles = d.PF / 16;
-    const int ti = blockIdx.x / tiles, tj = blockIdx.x - ti * tiles;
+    const int ti = tile / tiles, tj = tile - ti * tiles;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kq = d.Lp / 4;   // landmarks per wavefront (multiple of 4)
     const int k0 = wave * kq;
@@ -634,6 +659,7 @@ __global__ __launch_bounds__(256) void kb_schur_mfma(BaDims d, BaPtrs p) {
     const int row = e >> 4, col = e & 15;
     p.T[(size_t)(16 * ti + row) * d.PF + 16 * tj + col] = s;
 }
+__global__ __launch_bounds__(256) void kb_schur_mfma(BaDims d, BaPtrs p) { schur_tile_block(d, p, blockIdx.x); }
 
 // -------------------------------------------------------------------- the solve
 // Dogleg needs three quadratic forms of the Jacobi-scaled Hessian Hs = J^T J (frames + landmarks) per linearisation:
@@ -648,13 +674,12 @@ __global__ __launch_bounds__(256) void kb_schur_mfma(BaDims d, BaPtrs p) {
 //   role 1 (blocks [nbq, nbq+nbr)): wog = W^T (omega gl), 64 pose columns per block
 __host__ __device__ __forceinline__ int aux_quad_blocks_n(int n, int L) { return (n + 15) / 16 + (L + 31) / 32; }
 
-__global__ __launch_bounds__(256) void kb_solve_aux(BaDims d, BaPtrs p) {
+__device__ __forceinline__ void solve_aux_block(const BaDims &d, const BaPtrs &p, int blk) {
     __shared__ double scratch[8];
     __shared__ double part[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = d.n, P6 = 6 * d.F;
     const int nbf = (n + 15) / 16, nbq = aux_quad_blocks_n(n, d.L);
-    int blk = blockIdx.x;
     if (blk < nbq) {
         double acc = 0;
         if (blk < nbf) {   // frame rows a0 .. a0+3 of this wavefront against all frame columns
@@ -753,12 +778,17 @@ __global__ __launch_bounds__(256) void kb_solve_aux(BaDims d, BaPtrs p) {
         if (wave == 0 && cc < P6) p.wog[cc] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
     }
 }
+// Schur tiles and the solve's auxiliary passes in one launch: [tiles^2 | aux blocks]
+__global__ __launch_bounds__(256) void kb_schur_aux(BaDims d, BaPtrs p) {
+    const int t2 = (d.PF / 16) * (d.PF / 16);
+    if ((int)blockIdx.x < t2) schur_tile_block(d, p, blockIdx.x);
+    else solve_aux_block(d, p, (int)blockIdx.x - t2);
+}
 
 // Reduced camera system + blocked Cholesky + Gauss-Newton / Cauchy quantities.  One workgroup.
 // Only the `na` free frame dofs enter the factorisation (localize_newframe has 15, refine_window 15 F).
 // Dynamic LDS: rhs [na] + packed lower triangle when it fits (use_lds); otherwise the triangle lives in Sred.
-__global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds) {
-    extern __shared__ double lds[];
+__device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, int use_lds, double *lds) {
     __shared__ double scratch[32];
     __shared__ double Dblk[CH_NB][CH_NB + 1];
     __shared__ int fail;
@@ -772,7 +802,7 @@ __global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds)
     for (int i = tid; i < na; i += nt) {   // rhs = sp (gp - W^T (omega gl)); the product comes from kb_solve_aux
         const int a = p.act_idx[i];
         const int fa = a / 15, ka = a - 15 * fa;
-        const double sacc = ka < 6 ? p.wog[6 * fa + ka] : 0.0;
+        const double sacc = (d.nla && ka < 6) ? p.wog[6 * fa + ka] : 0.0;
         y[i] = (p.gp[a] - sacc) * p.sp[a];
     }
     __syncthreads();
@@ -784,7 +814,7 @@ __global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds)
         const int a = p.act_idx[i], b = p.act_idx[j];
         double v = p.Hpp[(size_t)a * n + b];
         const int fa = a / 15, ka = a - 15 * fa, fb = b / 15, kb = b - 15 * fb;
-        if (ka < 6 && kb < 6) v -= p.T[(size_t)(6 * fa + ka) * d.PF + 6 * fb + kb];
+        if (d.nla && ka < 6 && kb < 6) v -= p.T[(size_t)(6 * fa + ka) * d.PF + 6 * fb + kb];
         v *= p.sp[a] * p.sp[b];
         if (a == b) v += mu * p.diagD[a] * p.diagD[a];
         A[tri_idx(i, j)] = v;
@@ -834,7 +864,7 @@ __global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds)
             double w8[QF_ROWS];
 #pragma unroll
             for (int r = 0; r < QF_ROWS; ++r) w8[r] = 0.0;
-            for (int c0 = 0; c0 < P6; c0 += 128) {
+            for (int c0 = 0; c0 < (d.nla ? P6 : 0); c0 += 128) {
                 double w[2][QF_ROWS];
 #pragma unroll
                 for (int cch = 0; cch < 2; ++cch) {
@@ -899,10 +929,13 @@ __global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds)
         c->linear_ok = 1;
     }
 }
+__global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds) {
+    extern __shared__ double lds[];
+    solve_block(d, p, use_lds, lds);
+}
 
 // gradient_max_norm = |x - Plus(x, -g)|_inf in ambient coordinates (TrustRegionMinimizer::EvaluateGradientAndJacobian)
-__global__ __launch_bounds__(256) void kb_gradmax(BaDims d, BaPtrs p) {
-    __shared__ double red[256];
+__device__ __forceinline__ void gradmax_block(const BaDims &d, const BaPtrs &p, double *scratch) {   // scratch: blockDim/64 doubles
     double m = 0;
     for (int f = threadIdx.x; f < d.F; f += blockDim.x) {
         double neg[15], out[16];
@@ -913,18 +946,26 @@ __global__ __launch_bounds__(256) void kb_gradmax(BaDims d, BaPtrs p) {
     }
     for (int l = threadIdx.x; l < d.L; l += blockDim.x)
         if (p.lact[l]) m = fmax(m, fabs(p.gl[l]));
-    red[threadIdx.x] = m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
-        __syncthreads();
+    if (lane == 0) scratch[w] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0;
+        for (int i = 0; i < nw; ++i) r = fmax(r, scratch[i]);
+        p.ctl->gmax = r;
     }
-    if (threadIdx.x == 0) p.ctl->gmax = red[0];
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void kb_gradmax(BaDims d, BaPtrs p) {
+    __shared__ double scratch[8];
+    gradmax_block(d, p, scratch);
 }
 
 // total cost at `state` (x) from the per-factor costs written by the linearisation kernels
-__global__ __launch_bounds__(256) void kb_sum_cost(BaDims d, BaPtrs p) {
-    __shared__ double scratch[8];
+__device__ __forceinline__ void sum_cost_block(const BaDims &d, const BaPtrs &p, double *scratch) {
     double c = 0;
     for (int o = threadIdx.x; o < d.M; o += blockDim.x) c += p.ocost[o];
     for (int o = threadIdx.x; o < d.MR; o += blockDim.x) c += p.rcost[o];
@@ -939,6 +980,10 @@ __global__ __launch_bounds__(256) void kb_sum_cost(BaDims d, BaPtrs p) {
             ctl->minimum_cost = c;
         }
     }
+}
+__global__ __launch_bounds__(256) void kb_sum_cost(BaDims d, BaPtrs p) {
+    __shared__ double scratch[8];
+    sum_cost_block(d, p, scratch);
 }
 
 // ambient norm of the active parameter blocks of `state`/`depth`; block-wide
@@ -965,9 +1010,9 @@ __device__ __forceinline__ double ambient_norm2(const BaDims &d, const BaPtrs &p
 //   ST_RESOLVE   the step was invalid -> mu was increased, host re-solves the linear system
 //   ST_DONE      the minimiser terminated
 // `after_linearisation` = this launch directly follows a (re)linearisation or re-solve.
-__global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy,
-                                              int after_linearisation) {
-    extern __shared__ double sh[];   // np doubles for the prior delta
+__device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
+                                         double sy, int after_linearisation, int seq, bool publish_always, double *sh) {
+    // sh: np doubles of LDS for the prior delta
     __shared__ double scratch[32];
     __shared__ int s_status;
     BaCtl *c = p.ctl;
@@ -1207,7 +1252,88 @@ __global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext i
         }
         __syncthreads();
     }
-    if (tid == 0) c->status = s_status;
+    // ---- publish to the host mailbox
+    if (s_status == ST_DONE) {
+        for (int e = tid; e < 16 * d.F; e += nt) p.host_out[e] = p.state[e];
+        for (int l = tid; l < d.L; l += nt) p.host_out[16 * d.F + l] = p.depth[l];
+        __threadfence_system();
+    }
+    __syncthreads();
+    const int status = s_status;
+    if (tid == 0) {
+        c->status = status;
+        if (publish_always || status == ST_DONE) {
+            const long long *src = reinterpret_cast<const long long *>(c);
+            long long *dst = reinterpret_cast<long long *>(p.host_ctl);
+            for (unsigned i = 0; i < sizeof(BaCtl) / sizeof(long long); ++i) dst[i] = src[i];
+            __threadfence_system();
+            *reinterpret_cast<volatile int *>(p.host_seq) = seq;
+        }
+    }
+    __syncthreads();
+    return status;
+}
+__global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy,
+                                              int after_linearisation, int seq) {
+    extern __shared__ double sh[];   // np doubles for the prior delta
+    try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, true, sh);
+}
+
+// ------------------------------------------------------------------ fused launches
+// A kernel on this device costs ~4-5 us of dispatch + drain however little it does, and the phases of one
+// trust-region round are small; independent phases therefore share a launch (block ranges select the role), and
+// consecutive single-workgroup phases run back to back in one kernel.
+
+// all four factor families at once: [obs | rot | imu (4 factors per block) | prior (1 block)]
+__global__ __launch_bounds__(256) void kb_lin_all(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy) {
+    extern __shared__ double sh[];   // np doubles (prior role)
+    __shared__ double scr[4][IMU_SCR];
+    __shared__ double scratch[8];
+    const int nbo = (d.M + 255) / 256, nbr = (d.MR + 255) / 256, nbi = (d.NI + 3) / 4;
+    int blk = blockIdx.x;
+    if (blk < nbo) {
+        const int o = blk * 256 + threadIdx.x;
+        if (o < d.M) lin_obs_item(d, p, cam, sx, sy, o);
+        return;
+    }
+    blk -= nbo;
+    if (blk < nbr) {
+        const int o = blk * 256 + threadIdx.x;
+        if (o < d.MR) lin_rot_item(d, p, cam, sx, sy, o);
+        return;
+    }
+    blk -= nbr;
+    if (blk < nbi) {
+        const int wave = threadIdx.x >> 6, k = 4 * blk + wave;
+        if (k < d.NI) lin_imu_item(d, p, imu, k, threadIdx.x & 63, scr[wave]);
+        return;
+    }
+    lin_prior_block(d, p, sh, scratch);
+}
+__host__ __device__ __forceinline__ int lin_all_blocks(int M, int MR, int NI) { return (M + 255) / 256 + (MR + 255) / 256 + (NI + 3) / 4 + 1; }
+
+// per-landmark rows and per-frame-pair reprojection blocks: [Lp landmarks | F*F pairs], one wavefront each
+__global__ __launch_bounds__(64) void kb_landmark_vision(BaDims d, BaPtrs p) {
+    if ((int)blockIdx.x < d.Lp) landmark_item(d, p, blockIdx.x, threadIdx.x);
+    else assemble_vision_item(d, p, blockIdx.x - d.Lp, threadIdx.x);
+}
+
+// total cost, gradient max-norm and the per-solve preparation, one workgroup
+__global__ __launch_bounds__(256) void kb_cost_prepare(BaDims d, BaPtrs p) {
+    __shared__ double scratch[8];
+    sum_cost_block(d, p, scratch);
+    __syncthreads();
+    gradmax_block(d, p, scratch);
+    prepare_block(d, p);
+}
+
+// reduced-system solve followed by the trust-region trials, one workgroup
+__global__ __launch_bounds__(512) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int use_lds,
+                                                    int after_linearisation, int seq) {
+    extern __shared__ double lds[];   // max(solve_block's region, np doubles)
+    solve_block(d, p, use_lds, lds);
+    __syncthreads();
+    try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, true, lds);
 }
 
 }   // namespace xrhip

@@ -45,7 +45,11 @@ struct StageTimes {   // seconds, accumulated (inspection slots feature_tracker_
     // host wall-clock seconds spent inside the C-ABI calls, and in the whole per-frame work
     double w_upload = 0, w_preprocess = 0, w_track = 0, w_detect = 0, w_preintegrate = 0, w_solve = 0, w_marginalize = 0,
            w_frame = 0;
+    // host wall-clock seconds of whole pipeline stages (device waits included), see SC_* below
+    double scope[16] = {0};
 };
+enum { SC_FT_TRACK = 0, SC_RANSAC_E, SC_RANSAC_R, SC_FT_DETECT, SC_MIRROR, SC_LOCALIZE, SC_MANAGE_KF, SC_TRACK_LANDMARK,
+       SC_REFINE_WINDOW, SC_SLIDE_WINDOW, SC_REFINE_SUBWINDOW, SC_COUNT };
 struct WallTimer {   // adds the scope's duration to a StageTimes slot
     double &slot;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -188,6 +192,7 @@ inline void predict(const PreInt &pre, const Frame *o, Frame *n) {
 
 // ------------------------------------------------------------------------------------- Frame ops
 inline void frame_detect_keypoints(Pipeline &P, Frame *f) {   // frame.cpp:55-72 + opencv_image.cpp:38-73
+    WallTimer sc_t(P.times.scope[SC_FT_DETECT]);
     const Config &c = P.config;
     std::vector<double> existing(2 * f->keypoint_num());
     for (size_t i = 0; i < f->keypoint_num(); ++i) {
@@ -206,6 +211,7 @@ inline void frame_detect_keypoints(Pipeline &P, Frame *f) {   // frame.cpp:55-72
 }
 
 inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // frame.cpp:74-174
+    WallTimer sc_t(P.times.scope[SC_FT_TRACK]);
     const Config &c = P.config;
     const size_t n = cur->keypoint_num();
     std::vector<double> curr_px(2 * n), next_px(2 * n);
@@ -243,10 +249,17 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
         next_h.push_back({nb.x / nb.z, nb.y / nb.z});
         next_bearings.push_back(nb);
     }
-    find_essential_matrix(cur_h, next_h, mask, 1.0);
+    {
+        WallTimer sc_e(P.times.scope[SC_RANSAC_E]);
+        find_essential_matrix(cur_h, next_h, mask, 1.0);
+    }
     for (size_t i = 0; i < status.size() && i < mask.size(); ++i)
         if (!mask[i]) status[i] = 0;
-    M3 R = find_rotation_matrix(cur->bearings, next_bearings, mask, (M_PI / 180.0) * c.rotation_ransac_threshold);
+    M3 R;
+    {
+        WallTimer sc_r(P.times.scope[SC_RANSAC_R]);
+        R = find_rotation_matrix(cur->bearings, next_bearings, mask, (M_PI / 180.0) * c.rotation_ransac_threshold);
+    }
     std::vector<double> angles;
     for (size_t i = 0; i < mask.size(); ++i)
         if (mask[i]) angles.push_back(std::acos(dot(R * cur->bearings[i], next_bearings[i])) * 180 / M_PI);
@@ -599,6 +612,7 @@ class SlidingWindowTracker {
     }
 
     void mirror_frame(Map *ft_map, size_t frame_id) {   // sliding_window_tracker.cpp:31-80
+        WallTimer sc_t(P_.times.scope[SC_MIRROR]);
         Frame *keyframe = map->get_frame(map->frame_num() - 1);
         Frame *new_i = keyframe;
         if (!keyframe->subframes.empty()) new_i = keyframe->subframes.back().get();
@@ -642,6 +656,7 @@ class SlidingWindowTracker {
     }
 
     void localize_newframe() {   // :119-143
+        WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
         BaBuilder b(P_);
         Frame *fi = map->get_frame(map->frame_num() - 2);
         if (!fi->subframes.empty()) fi = fi->subframes.back().get();
@@ -655,6 +670,7 @@ class SlidingWindowTracker {
     }
 
     bool manage_keyframe() {   // :145-223
+        WallTimer sc_t(P_.times.scope[SC_MANAGE_KF]);
         const Config &c = P_.config;
         Frame *kf_i = map->get_frame(map->frame_num() - 2);
         Frame *nf_j = map->get_frame(map->frame_num() - 1);
@@ -696,6 +712,7 @@ class SlidingWindowTracker {
     }
 
     void track_landmark() {   // :225-245
+        WallTimer sc_t(P_.times.scope[SC_TRACK_LANDMARK]);
         Frame *nf = map->get_frame(map->frame_num() - 1);
         for (size_t k = 0; k < nf->keypoint_num(); ++k) {
             if (Track *t = nf->get_track(k)) {
@@ -716,6 +733,7 @@ class SlidingWindowTracker {
     }
 
     void refine_window() {   // :247-358
+        WallTimer sc_t(P_.times.scope[SC_REFINE_WINDOW]);
         BaBuilder b(P_);
         if (!map->marginalization_factor) map->marginalization_factor = create_marginalization_factor(map.get());
         for (size_t i = 0; i < map->frame_num(); ++i) b.add_frame_states(map->get_frame(i));
@@ -793,6 +811,7 @@ class SlidingWindowTracker {
     }
 
     void slide_window() {   // :360-368
+        WallTimer sc_t(P_.times.scope[SC_SLIDE_WINDOW]);
         while (map->frame_num() > P_.config.sliding_window_size) {
             Frame *f = map->get_frame(0);
             for (auto &sf : f->subframes) map->untrack_frame(sf.get());
@@ -812,6 +831,7 @@ class SlidingWindowTracker {
     }
 
     void refine_subwindow() {   // :370-465
+        WallTimer sc_t(P_.times.scope[SC_REFINE_SUBWINDOW]);
         Frame *frame = map->get_frame(map->frame_num() - 1);
         if (frame->subframes.empty()) return;
         if (frame->subframes[0]->tag(FT_NO_TRANSLATION)) {

@@ -242,6 +242,7 @@ void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out) {
     out->wall_solve = t.w_solve;
     out->wall_marginalize = t.w_marginalize;
     out->wall_frame = t.w_frame;
+    for (int i = 0; i < 16; ++i) out->wall_scope[i] = t.scope[i];
 }
 
 void XRSLAMAmdSetProfiling(int enable) {

@@ -29,7 +29,7 @@ class XRSLAMAmdTimes(C.Structure):
                 ("marginalizations", C.c_long), ("keyframes", C.c_long), ("ba_device_ms", C.c_double),
                 ("wall_preprocess", C.c_double), ("wall_track", C.c_double), ("wall_detect", C.c_double),
                 ("wall_preintegrate", C.c_double), ("wall_solve", C.c_double), ("wall_marginalize", C.c_double),
-                ("wall_frame", C.c_double)]
+                ("wall_frame", C.c_double), ("wall_scope", C.c_double * 16)]
 
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
