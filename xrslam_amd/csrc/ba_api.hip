@@ -231,7 +231,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
         return off;
     };
     const size_t D8 = sizeof(double);
-    const size_t w_cand = carve(D8 * 16 * F), w_dcand = carve(D8 * L);
+    const size_t w_cand = carve(D8 * 16 * F * TRY_B), w_dcand = carve(D8 * L * TRY_B);
     const size_t w_pLam = carve(D8 * (size_t)np * np);
     const size_t w_orec = carve(D8 * OREC * M), w_ocost = carve(D8 * M);
     const size_t w_rrec = carve(D8 * RREC * MR), w_rcost = carve(D8 * MR);
@@ -243,7 +243,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     const size_t w_sp = carve(D8 * n), w_sl = carve(D8 * d.Lp), w_om = carve(D8 * d.Lp);
     const size_t w_T = carve(D8 * (size_t)d.PF * d.PF), w_S = carve(D8 * (size_t)n * n);
     const size_t w_dD = carve(D8 * d.NV), w_gr = carve(D8 * d.NV), w_gn = carve(D8 * d.NV), w_gs = carve(D8 * d.NV);
-    const size_t w_st = carve(D8 * d.NV), w_de = carve(D8 * d.NV), w_part = carve(D8 * (size_t)(aux_quad_blocks_n(d.n, std::max(d.L, 1)) + 8));
+    const size_t w_st = carve(D8 * d.NV), w_de = carve(D8 * d.NV * TRY_B), w_part = carve(D8 * (size_t)(aux_quad_blocks_n(d.n, std::max(d.L, 1)) + 8));
     const size_t w_wog = carve(D8 * d.PF);
     const size_t w_Hv = carve(D8 * 36 * (size_t)F * F), w_gv = carve(D8 * 6 * F);
     int rc = ensure_arena(c, in_bytes, w + 256, (size_t)16 * F + L + 8);
@@ -368,7 +368,7 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
     int use_lds = 1;
     int rcl = solve_lds(d, (size_t)c->lds_limit, &lds, &use_lds);
     if (rcl) return rcl;
-    lds = std::max(lds, sizeof(double) * (size_t)std::max(d.np, 1));
+    lds = std::max(lds, sizeof(double) * (size_t)std::max(TRY_B * (d.np + 15 * d.NI), 1));
     hipLaunchKernelGGL(kb_solve_try, dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq);
     XR_HIP(hipGetLastError());
     return XRHIP_OK;
@@ -466,8 +466,12 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     BaPtrs p;
     Ext cam, imu;
     const auto t_begin = std::chrono::steady_clock::now();
-    rc = stage_problem(c, P, d, p, cam, imu);
+    {
+        HostProfScope hp(8, "ba_solve: stage_problem");
+        rc = stage_problem(c, P, d, p, cam, imu);
+    }
     if (rc) return rc;
+    HostProfScope hp_rounds(9, "ba_solve: rounds (launch+wait)");
     const double sx = P->sqrt_inv_cov[0], sy = P->sqrt_inv_cov[1];
     hipStream_t s = c->stream;
     if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);

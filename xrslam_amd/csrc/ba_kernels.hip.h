@@ -25,6 +25,7 @@ namespace xrhip {
 
 constexpr int OREC = 28;   // per-observation record: Jt(12) Jr(12) jl(2) r(2), robustified
 constexpr int RREC = 8;
+constexpr int TRY_B = 4;   // trust-region trials costed per sweep after a rejection
 constexpr int QF_ROWS = 8; // landmark rows a wavefront keeps in flight in the back-substitution
 
 struct BaCtl {   // device-resident solver state (one per context)
@@ -77,9 +78,9 @@ struct BaDims {
 
 struct BaPtrs {
     // problem
-    double *state, *cand;            // [F][16]
+    double *state, *cand;            // [F][16], [TRY_B][F][16]
     const uint8_t *fix;              // [F]
-    double *depth, *depth_cand;      // [L]
+    double *depth, *depth_cand;      // [L], [TRY_B][L]
     const uint8_t *lact;             // [L] landmark is a free parameter
     const int *obs_tgt, *obs_ref, *obs_lm;
     const double *obs_zt, *obs_zr;
@@ -1012,9 +1013,8 @@ __device__ __forceinline__ double ambient_norm2(const BaDims &d, const BaPtrs &p
 // `after_linearisation` = this launch directly follows a (re)linearisation or re-solve.
 __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
                                          double sy, int after_linearisation, int seq, bool publish_always, double *sh) {
-    // sh: np doubles of LDS for the prior delta
-    __shared__ double scratch[32];
-    __shared__ int s_status;
+    // sh: LDS, TRY_B * np doubles for the prior deltas of the candidates + TRY_B * NI * 15 for the raw IMU residuals
+    __shared__ double scratch[2 * TRY_B * 8];
     BaCtl *c = p.ctl;
     const int tid = threadIdx.x, nt = blockDim.x;
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
@@ -1040,8 +1040,6 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
         __syncthreads();
     }
     KPROF(10);
-    bool check_gradient = (mode == 1);   // the iteration that led here was successful
-    bool skip_finalize = (mode == 3);
     // |gradient|, |gauss-newton step| and their inner product stay the same for every trial of this launch
     double gnorm, gn_norm, gd;
     {
@@ -1058,208 +1056,312 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
         __syncthreads();
     }
     KPROF(11);
-    while (true) {
-        // ---- finalize checks + start of the next iteration
-        if (tid == 0) {
-            int st = ST_RUNNING;
-            if (!skip_finalize) {
-                if (c->iteration >= c->max_iterations) {
-                    c->termination = XRHIP_BA_NO_CONVERGENCE;
-                    st = ST_DONE;
-                } else if (check_gradient && c->gmax <= gradient_tolerance) {
-                    c->termination = XRHIP_BA_CONVERGENCE;
-                    st = ST_DONE;
-                } else if (c->radius <= min_radius) {
-                    c->termination = XRHIP_BA_CONVERGENCE;
-                    st = ST_DONE;
-                }
-                if (st == ST_RUNNING) c->iteration += 1;
+    // Every thread keeps its own copy of the minimiser's scalars and runs the (uniform) decision logic itself;
+    // thread 0 writes them back on exit.  No barrier or LDS flag is needed to agree on the outcome.
+    int iteration = c->iteration, invalid_steps = c->invalid_steps, successful_steps = c->successful_steps;
+    int reuse = c->reuse, termination = c->termination, status = ST_RUNNING;
+    double radius = c->radius, mu = c->mu, cand_cost = c->cand_cost, last_step_norm = c->step_norm;
+    const int max_iterations = c->max_iterations, linear_ok = c->linear_ok;
+    const double gmax = c->gmax, x_cost = c->x_cost, x_norm = c->x_norm, alpha = c->alpha;
+    const double q_gg = c->q_gg, q_gn = c->q_gn, q_nn = c->q_nn;
+    bool check_gradient = (mode == 1);   // the iteration that led here was successful
+    bool skip_finalize = (mode == 3);
+    // Trials are evaluated in batches: after a rejection the next radii are known (radius / 2, / 4, ...), so the
+    // next TRY_B candidates are costed in ONE sweep over the factors and the decisions replayed in order -- the
+    // sweep is latency-bound, extra candidates are nearly free.  The first trial of a launch is usually accepted
+    // and goes alone.
+    int B = 1;
+    while (status == ST_RUNNING) {
+        // ---- FinalizeIterationAndCheckIfMinimizerCanContinue + start of the next iteration (first trial of the batch)
+        if (!skip_finalize) {
+            if (iteration >= max_iterations) {
+                termination = XRHIP_BA_NO_CONVERGENCE;
+                status = ST_DONE;
+            } else if (check_gradient && gmax <= gradient_tolerance) {
+                termination = XRHIP_BA_CONVERGENCE;
+                status = ST_DONE;
+            } else if (radius <= min_radius) {
+                termination = XRHIP_BA_CONVERGENCE;
+                status = ST_DONE;
             }
-            if (st == ST_RUNNING && !c->linear_ok) {
-                if (c->mu * 10.0 < 1.0) {
-                    c->mu *= 10.0;           // ComputeGaussNewtonStep: retry with a larger mu, same iteration
-                    st = ST_RESOLVE_INNER;
+            if (status == ST_RUNNING) iteration += 1;
+        }
+        if (status == ST_RUNNING && !linear_ok) {
+            if (mu * 10.0 < 1.0) {
+                mu *= 10.0;           // ComputeGaussNewtonStep: retry with a larger mu, same iteration
+                status = ST_RESOLVE_INNER;
+            } else {
+                invalid_steps += 1;   // LINEAR_SOLVER_FAILURE -> invalid step
+                if (invalid_steps >= 5) {
+                    termination = XRHIP_BA_FAILURE;
+                    status = ST_DONE;
                 } else {
-                    c->invalid_steps += 1;   // LINEAR_SOLVER_FAILURE -> invalid step
-                    if (c->invalid_steps >= 5) {
-                        c->termination = XRHIP_BA_FAILURE;
-                        st = ST_DONE;
-                    } else {
-                        c->mu *= 10.0;
-                        c->reuse = 0;
-                        st = ST_RESOLVE;
-                    }
+                    mu *= 10.0;
+                    reuse = 0;
+                    status = ST_RESOLVE;
                 }
             }
-            s_status = st;
         }
         skip_finalize = false;
         check_gradient = false;
-        __syncthreads();
-        if (s_status != ST_RUNNING) break;
+        if (status != ST_RUNNING) break;
         KPROF(12);
-        // ---- traditional dogleg for the current radius (|grad|, |gn|, grad.gn were reduced once per launch)
-        const double radius = c->radius, alpha = c->alpha;
-        double ca = 0, cb = 0, step_norm = 0;   // step(scaled by D) = ca * grad + cb * gn
-        if (gn_norm <= radius) {
-            cb = 1.0;
-            step_norm = gn_norm;
-        } else if (gnorm * alpha >= radius) {
-            ca = -(radius / gnorm);
-            step_norm = radius;
-        } else {
-            const double b_dot_a = -alpha * gd;
-            const double a_sq = pow(alpha * gnorm, 2.0);
-            const double bma_sq = a_sq - 2 * b_dot_a + pow(gn_norm, 2);
-            const double cc = b_dot_a - a_sq;
-            const double dd = sqrt(cc * cc + bma_sq * (pow(radius, 2.0) - a_sq));
-            const double beta = (cc <= 0) ? (dd - cc) / bma_sq : (radius * radius - a_sq) / (dd + cc);
-            ca = -alpha * (1.0 - beta);
-            cb = beta;
-            step_norm = -1.0;
+        // ---- traditional dogleg points for radius, radius/2, ...: step (scaled by D) = ca grad + cb gn
+        double ca[TRY_B], cb[TRY_B], step_norm[TRY_B];
+#pragma unroll
+        for (int k = 0; k < TRY_B; ++k) {
+            const double rk = radius * (1.0 / (double)(1 << k));   // exact
+            ca[k] = 0.0;
+            cb[k] = 0.0;
+            if (gn_norm <= rk) {
+                cb[k] = 1.0;
+                step_norm[k] = gn_norm;
+            } else if (gnorm * alpha >= rk) {
+                ca[k] = -(rk / gnorm);
+                step_norm[k] = rk;
+            } else {
+                const double b_dot_a = -alpha * gd;
+                const double a_sq = pow(alpha * gnorm, 2.0);
+                const double bma_sq = a_sq - 2 * b_dot_a + pow(gn_norm, 2);
+                const double cc = b_dot_a - a_sq;
+                const double dd = sqrt(cc * cc + bma_sq * (pow(rk, 2.0) - a_sq));
+                const double beta = (cc <= 0) ? (dd - cc) / bma_sq : (rk * rk - a_sq) / (dd + cc);
+                ca[k] = -alpha * (1.0 - beta);
+                cb[k] = beta;
+                step_norm[k] = -1.0;
+            }
         }
-        double red2[2] = {0, 0};   // |step|^2 (D-scaled), step . gs
+        double red2[2 * TRY_B];   // per candidate: |step|^2 (D-scaled), step . gs
+#pragma unroll
+        for (int k = 0; k < 2 * TRY_B; ++k) red2[k] = 0.0;
         for (int a = tid; a < d.NV; a += nt) {
-            const double v = ca * p.grad[a] + cb * p.gn[a];
-            red2[0] += v * v;
-            const double st = v / p.diagD[a];
-            p.step[a] = st;
-            red2[1] += st * p.gs[a];
+            const double g = p.grad[a], gnv = p.gn[a], D = p.diagD[a], gsa = p.gs[a];
             const double sc = a < d.n ? p.sp[a] : p.sl[a - d.n];
-            p.delta[a] = st * sc;
+#pragma unroll
+            for (int k = 0; k < TRY_B; ++k)
+                if (k < B) {
+                    const double v = ca[k] * g + cb[k] * gnv;
+                    red2[2 * k] += v * v;
+                    const double st = v / D;
+                    red2[2 * k + 1] += st * gsa;
+                    p.delta[(size_t)k * d.NV + a] = st * sc;
+                }
         }
-        block_sum_n<2>(red2, scratch);
-        const double sg = red2[1];
-        if (step_norm < 0) step_norm = sqrt(red2[0]);
+        block_sum_n<2 * TRY_B>(red2, scratch);
+        double model_cost_change[TRY_B];
+#pragma unroll
+        for (int k = 0; k < TRY_B; ++k) {
+            if (step_norm[k] < 0) step_norm[k] = sqrt(red2[2 * k]);
+            const double shs = (ca[k] * ca[k]) * q_gg + 2.0 * (ca[k] * cb[k]) * q_gn + (cb[k] * cb[k]) * q_nn;   // see kb_solve_aux
+            model_cost_change[k] = -red2[2 * k + 1] - 0.5 * shs;
+        }
         __syncthreads();
         KPROF(13);
-        const double shs = (ca * ca) * c->q_gg + 2.0 * (ca * cb) * c->q_gn + (cb * cb) * c->q_nn;   // see quad_forms
-        KPROF(14);
-        const double model_cost_change = -sg - 0.5 * shs;
-        if (!(model_cost_change > 0.0)) {
-            if (tid == 0) {
-                c->invalid_steps += 1;
-                if (c->invalid_steps >= 5) {
-                    c->termination = XRHIP_BA_FAILURE;
-                    c->status = ST_DONE;
-                    s_status = ST_DONE;
-                } else {
-                    c->mu *= 10.0;   // StepIsInvalid
-                    c->reuse = 0;
-                    s_status = ST_RESOLVE;
-                }
-            }
-            __syncthreads();
-            break;
+        // ---- candidate points and their costs
+        for (int e = tid; e < B * d.F; e += nt) {
+            const int k = e / d.F, f = e - k * d.F;
+            state_plus(p.state + 16 * f, p.delta + (size_t)k * d.NV + 15 * f, pose_free(p.fix[f]), motion_free(p.fix[f]),
+                       p.cand + (size_t)k * 16 * d.F + 16 * f);
         }
-        // ---- candidate point and its cost
-        for (int f = tid; f < d.F; f += nt)
-            state_plus(p.state + 16 * f, p.delta + 15 * f, pose_free(p.fix[f]), motion_free(p.fix[f]), p.cand + 16 * f);
-        for (int l = tid; l < d.L; l += nt) p.depth_cand[l] = p.depth[l] + (p.lact[l] ? p.delta[d.n + l] : 0.0);
+        for (int e = tid; e < B * d.L; e += nt) {
+            const int k = e / d.L, l = e - k * d.L;
+            p.depth_cand[(size_t)k * d.L + l] = p.depth[l] + (p.lact[l] ? p.delta[(size_t)k * d.NV + d.n + l] : 0.0);
+        }
         __syncthreads();
-        for (int i = tid; i < d.NP; i += nt) {   // prior delta at the candidate, staged for the row products
+        for (int e = tid; e < B * d.NP; e += nt) {   // prior delta at the candidates, staged for the row products
+            const int k = e / d.NP, i = e - k * d.NP;
             double dl[15];
-            prior_delta(p, i, p.cand, dl, nullptr);
-            for (int k = 0; k < 15; ++k) sh[15 * i + k] = dl[k];
+            prior_delta(p, i, p.cand + (size_t)k * 16 * d.F, dl, nullptr);
+            for (int q = 0; q < 15; ++q) sh[k * d.np + 15 * i + q] = dl[q];
         }
         __syncthreads();
         KPROF(15);
-        double red[2] = {0, 0};   // cost, |x - candidate|^2
-        for (int o = tid; o < d.M; o += nt) red[0] += obs_eval(d, p, o, p.cand, p.depth_cand, cam, sx, sy, false, nullptr);
-        for (int o = tid; o < d.MR; o += nt) red[0] += rot_eval(d, p, o, p.cand, cam, sx, sy, false, nullptr);
-        KPROF(16);
-        {   // IMU factors and prior rows: one wavefront each (coalesced)
-            const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-            for (int k = wave; k < d.NI; k += nw) red[0] += imu_cost_wave(p, k, p.cand, imu, lane);
-            for (int i0 = 4 * wave; i0 < d.np; i0 += 4 * nw) {   // four prior rows per wavefront in flight
-                double s4[4] = {0, 0, 0, 0};
-                for (int j = lane; j < d.np; j += 64) {
-                    const double x = sh[j];
+        double red[2 * TRY_B];   // per candidate: cost, |x - candidate|^2
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s4[r] += p.pS[(size_t)min(i0 + r, d.np - 1) * d.np + j] * x;
+        for (int k = 0; k < 2 * TRY_B; ++k) red[k] = 0.0;
+        for (int o = tid; o < d.M; o += nt)
+#pragma unroll
+            for (int k = 0; k < TRY_B; ++k)
+                if (k < B)
+                    red[2 * k] += obs_eval(d, p, o, p.cand + (size_t)k * 16 * d.F, p.depth_cand + (size_t)k * d.L, cam, sx, sy,
+                                           false, nullptr);
+        for (int o = tid; o < d.MR; o += nt)
+#pragma unroll
+            for (int k = 0; k < TRY_B; ++k)
+                if (k < B) red[2 * k] += rot_eval(d, p, o, p.cand + (size_t)k * 16 * d.F, cam, sx, sy, false, nullptr);
+        KPROF(16);
+        {   // IMU factors: the SO(3)-heavy raw residual is a long serial chain, so every (factor, candidate) pair gets
+            // its own lane (all pairs advance in lockstep); the 15x15 whitening then runs one row per thread
+            double *raw = sh + TRY_B * d.np;   // [B * NI][15]
+            for (int e = tid; e < B * d.NI; e += nt) {
+                const int k = e / d.NI, f = e - k * d.NI;
+                const int fi = p.imu_i[f], fj = p.imu_j[f];
+                double r15[15];
+                if (p.fix[fi] == 3 && p.fix[fj] == 3) {
+                    for (int q = 0; q < 15; ++q) r15[q] = 0.0;
+                } else {
+                    const double *st = p.cand + (size_t)k * 16 * d.F;
+                    imu_raw_residual(load_state(st + 16 * fi), load_state(st + 16 * fj), load_imu(p.imu_data + (size_t)f * XRHIP_IMU_DIM),
+                                     v3(p.bias_ref[6 * f], p.bias_ref[6 * f + 1], p.bias_ref[6 * f + 2]),
+                                     v3(p.bias_ref[6 * f + 3], p.bias_ref[6 * f + 4], p.bias_ref[6 * f + 5]), imu, r15);
+                }
+                for (int q = 0; q < 15; ++q) raw[15 * e + q] = r15[q];
+            }
+            __syncthreads();
+            for (int it = tid; it < B * d.NI * 15; it += nt) {
+                const int e = it / 15, i = it - 15 * e, k = e / d.NI, f = e - k * d.NI;
+                const double *S = p.imu_data + (size_t)f * XRHIP_IMU_DIM + 56 + 15 * i;
+                double acc = 0;
+#pragma unroll
+                for (int j = 0; j < 15; ++j) acc += S[j] * raw[15 * e + j];
+                const double cst = 0.5 * acc * acc;
+#pragma unroll
+                for (int q = 0; q < TRY_B; ++q)
+                    if (q == k) red[2 * q] += cst;
+            }
+            const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+            for (int i0 = 4 * wave; i0 < d.np; i0 += 4 * nw) {
+                double s4[TRY_B][4];
+#pragma unroll
+                for (int k = 0; k < TRY_B; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s4[k][r] = 0.0;
+                for (int j = lane; j < d.np; j += 64) {
+                    double row[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) row[r] = p.pS[(size_t)min(i0 + r, d.np - 1) * d.np + j];
+#pragma unroll
+                    for (int k = 0; k < TRY_B; ++k)
+                        if (k < B) {
+                            const double x = sh[k * d.np + j];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s4[k][r] += row[r] * x;
+                        }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s4[r] = wave_sum(s4[r]);
-                if (lane == 0)
+                for (int k = 0; k < TRY_B; ++k)
+                    if (k < B) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (i0 + r < d.np) {
-                            const double t = s4[r] + p.pinfo[i0 + r];
-                            red[0] += 0.5 * t * t;
-                        }
+                        for (int r = 0; r < 4; ++r) s4[k][r] = wave_sum(s4[k][r]);
+                        if (lane == 0)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (i0 + r < d.np) {
+                                    const double t = s4[k][r] + p.pinfo[i0 + r];
+                                    red[2 * k] += 0.5 * t * t;
+                                }
+                    }
             }
         }
         KPROF(17);
-        for (int f = tid; f < d.F; f += nt) {
-            const double *a = p.state + 16 * f, *b = p.cand + 16 * f;
+        for (int e = tid; e < B * d.F; e += nt) {
+            const int k = e / d.F, f = e - k * d.F;
+            const double *a = p.state + 16 * f, *b = p.cand + (size_t)k * 16 * d.F + 16 * f;
+            double acc = 0;
             if (pose_free(p.fix[f]))
-                for (int k = 0; k < 7; ++k) red[1] += (a[k] - b[k]) * (a[k] - b[k]);
+                for (int q = 0; q < 7; ++q) acc += (a[q] - b[q]) * (a[q] - b[q]);
             if (motion_free(p.fix[f]))
-                for (int k = 7; k < 16; ++k) red[1] += (a[k] - b[k]) * (a[k] - b[k]);
+                for (int q = 7; q < 16; ++q) acc += (a[q] - b[q]) * (a[q] - b[q]);
+#pragma unroll
+            for (int q = 0; q < TRY_B; ++q)
+                if (q == k) red[2 * q + 1] += acc;
         }
-        for (int l = tid; l < d.L; l += nt)
-            if (p.lact[l]) red[1] += (p.depth[l] - p.depth_cand[l]) * (p.depth[l] - p.depth_cand[l]);
-        block_sum_n<2>(red, scratch);
-        double cost = red[0];
-        if (!isfinite(cost)) cost = 1.7976931348623157e308;
-        const double dn = sqrt(red[1]);
+        for (int e = tid; e < B * d.L; e += nt) {
+            const int k = e / d.L, l = e - k * d.L;
+            if (!p.lact[l]) continue;
+            const double df = p.depth[l] - p.depth_cand[(size_t)k * d.L + l];
+#pragma unroll
+            for (int q = 0; q < TRY_B; ++q)
+                if (q == k) red[2 * q + 1] += df * df;
+        }
+        block_sum_n<2 * TRY_B>(red, scratch);
         KPROF(18);
-        if (tid == 0) p.ctl->prof[19] += 1;   // trials
-        // ---- decisions (uniform across the workgroup)
-        const double x_cost = c->x_cost;
-        int st = ST_RUNNING;
-        bool accept = false;
-        double relative_decrease = 0;
-        if (dn <= parameter_tolerance * (c->x_norm + parameter_tolerance)) {
-            st = ST_DONE;
-        } else if (fabs(x_cost - cost) <= function_tolerance * x_cost) {
-            st = ST_DONE;
-        } else {
-            relative_decrease = (x_cost - cost) / model_cost_change;
-            accept = relative_decrease > min_relative_decrease;
-        }
-        __syncthreads();
-        if (st == ST_DONE) {
-            if (tid == 0) {
-                c->termination = XRHIP_BA_CONVERGENCE;
-                s_status = ST_DONE;
+        // ---- replay the decisions in order (uniform across the workgroup)
+        int accepted = -1;
+#pragma unroll
+        for (int k = 0; k < TRY_B; ++k) {
+            if (k >= B || status != ST_RUNNING || accepted >= 0) continue;
+            if (k > 0) {   // the finalize step of the rejected trial before this one
+                if (iteration >= max_iterations) {
+                    termination = XRHIP_BA_NO_CONVERGENCE;
+                    status = ST_DONE;
+                } else if (radius <= min_radius) {
+                    termination = XRHIP_BA_CONVERGENCE;
+                    status = ST_DONE;
+                }
+                if (status != ST_RUNNING) continue;
+                iteration += 1;
             }
-            __syncthreads();
-            break;
-        }
-        if (accept) {
-            for (int e = tid; e < 16 * d.F; e += nt) p.state[e] = p.cand[e];
-            for (int l = tid; l < d.L; l += nt) p.depth[l] = p.depth_cand[l];
-            if (tid == 0) {
-                c->invalid_steps = 0;
-                c->successful_steps += 1;
-                if (relative_decrease < 0.25) c->radius *= 0.5;
-                if (relative_decrease > 0.75) c->radius = fmax(c->radius, 3.0 * step_norm);
-                c->radius = fmin(c->radius, max_radius);
-                c->mu = fmax(1e-8, 2.0 * c->mu / 10.0);
-                c->reuse = 0;
-                c->cand_cost = cost;
-                c->step_norm = step_norm;
-                s_status = ST_ACCEPTED;
+#ifdef XRHIP_KPROF
+            if (tid == 0) p.ctl->prof[19] += 1;   // trials
+#endif
+            if (!(model_cost_change[k] > 0.0)) {
+                invalid_steps += 1;
+                if (invalid_steps >= 5) {
+                    termination = XRHIP_BA_FAILURE;
+                    status = ST_DONE;
+                } else {
+                    mu *= 10.0;   // StepIsInvalid
+                    reuse = 0;
+                    status = ST_RESOLVE;
+                }
+                continue;
             }
-            __syncthreads();
-            break;
+            double cost = red[2 * k];
+            if (!isfinite(cost)) cost = 1.7976931348623157e308;
+            const double dn = sqrt(red[2 * k + 1]);
+            if (dn <= parameter_tolerance * (x_norm + parameter_tolerance) ||
+                fabs(x_cost - cost) <= function_tolerance * x_cost) {
+                termination = XRHIP_BA_CONVERGENCE;
+                status = ST_DONE;
+                continue;
+            }
+            const double relative_decrease = (x_cost - cost) / model_cost_change[k];
+            if (relative_decrease > min_relative_decrease) {
+                accepted = k;
+                invalid_steps = 0;
+                successful_steps += 1;
+                if (relative_decrease < 0.25) radius *= 0.5;
+                if (relative_decrease > 0.75) radius = fmax(radius, 3.0 * step_norm[k]);
+                radius = fmin(radius, max_radius);
+                mu = fmax(1e-8, 2.0 * mu / 10.0);
+                reuse = 0;
+                cand_cost = cost;
+                last_step_norm = step_norm[k];
+                status = ST_ACCEPTED;
+                continue;
+            }
+            invalid_steps = 0;
+            radius *= 0.5;   // StepRejected
+            reuse = 1;
         }
-        if (tid == 0) {
-            c->invalid_steps = 0;
-            c->radius *= 0.5;   // StepRejected
-            c->reuse = 1;
+        if (accepted >= 0) {
+            const double *cs = p.cand + (size_t)accepted * 16 * d.F, *cd = p.depth_cand + (size_t)accepted * d.L;
+            for (int e = tid; e < 16 * d.F; e += nt) p.state[e] = cs[e];
+            for (int l = tid; l < d.L; l += nt) p.depth[l] = cd[l];
         }
-        __syncthreads();
+        __syncthreads();   // candidates / deltas are rewritten by the next batch
+        B = TRY_B;
     }
+    if (tid == 0) {
+        c->iteration = iteration;
+        c->invalid_steps = invalid_steps;
+        c->successful_steps = successful_steps;
+        c->reuse = reuse;
+        c->termination = termination;
+        c->radius = radius;
+        c->mu = mu;
+        c->cand_cost = cand_cost;
+        c->step_norm = last_step_norm;
+    }
+    __syncthreads();
     // ---- publish to the host mailbox
-    if (s_status == ST_DONE) {
+    if (status == ST_DONE) {
         for (int e = tid; e < 16 * d.F; e += nt) p.host_out[e] = p.state[e];
         for (int l = tid; l < d.L; l += nt) p.host_out[16 * d.F + l] = p.depth[l];
         __threadfence_system();
     }
     __syncthreads();
-    const int status = s_status;
     if (tid == 0) {
         c->status = status;
         if (publish_always || status == ST_DONE) {

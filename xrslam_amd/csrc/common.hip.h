@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "hostprof.hpp"
+
 #include <cstdio>
 #include <cstring>
 
@@ -43,6 +45,7 @@ inline int xr_require_device() {
     }
     return XRHIP_OK;
 }
+
 
 }   // namespace xrhip
 

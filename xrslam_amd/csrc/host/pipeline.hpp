@@ -26,6 +26,7 @@
 #include <unordered_set>
 
 #include "../host_select.hpp"
+#include "../hostprof.hpp"
 #include "config.hpp"
 #include "map.hpp"
 
@@ -239,6 +240,8 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
                                     st8.data(), (int)n),
                   "xrhip_image_track");
     }
+    xrhip::HostProfScope hp_post(4, "ft_track: after LK (all)");
+    xrhip::HostProfScope *hp_a = new xrhip::HostProfScope(5, "ft_track: bearings");
     std::vector<char> status(st8.begin(), st8.begin() + n), mask;
     std::vector<V2> cur_h, next_h;
     std::vector<V3> next_bearings;
@@ -249,6 +252,7 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
         next_h.push_back({nb.x / nb.z, nb.y / nb.z});
         next_bearings.push_back(nb);
     }
+    delete hp_a;
     {
         WallTimer sc_e(P.times.scope[SC_RANSAC_E]);
         find_essential_matrix(cur_h, next_h, mask, 1.0);
@@ -260,6 +264,7 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
         WallTimer sc_r(P.times.scope[SC_RANSAC_R]);
         R = find_rotation_matrix(cur->bearings, next_bearings, mask, (M_PI / 180.0) * c.rotation_ransac_threshold);
     }
+    xrhip::HostProfScope hp_b(6, "ft_track: angles+poisson+append");
     std::vector<double> angles;
     for (size_t i = 0; i < mask.size(); ++i)
         if (mask[i]) angles.push_back(std::acos(dot(R * cur->bearings[i], next_bearings[i])) * 180 / M_PI);
@@ -369,6 +374,7 @@ class BaBuilder {
     void add_marginalization(MargPrior *m) { prior_ = m; }
 
     bool solve(double *elapsed_device_ms = nullptr) {
+        xrhip::HostProfScope hp_s(10, "BaBuilder::solve (all)");
         const Config &c = P_.config;
         const int F = (int)frames_.size(), L = (int)tracks_.size();
         std::vector<double> state(16 * (size_t)F), depth(std::max(L, 1));
@@ -612,6 +618,7 @@ class SlidingWindowTracker {
     }
 
     void mirror_frame(Map *ft_map, size_t frame_id) {   // sliding_window_tracker.cpp:31-80
+        xrhip::HostProfScope hp_m(7, "mirror_frame");
         WallTimer sc_t(P_.times.scope[SC_MIRROR]);
         Frame *keyframe = map->get_frame(map->frame_num() - 1);
         Frame *new_i = keyframe;
@@ -1125,6 +1132,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
 
     // -------- FeatureTracker::work (core/feature_tracker.cpp:24-153)
     void feature_tracker_work(std::unique_ptr<Frame> frame) {
+        xrhip::HostProfScope hp_f(11, "feature_tracker_work (all)");
         WallTimer wt_frame(P.times.w_frame);
         const Config &c = P.config;
         {

@@ -1,0 +1,35 @@
+// hostprof.hpp -- development aid: named host wall-clock accumulators (no HIP dependency).
+// XRHIP_HOSTPROF=1 makes xrhip_klt_destroy / XRSLAMDestroy dump them to stderr.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+namespace xrhip {
+
+struct HostProf {
+    static constexpr int N = 24;
+    double sec[N] = {0};
+    long calls[N] = {0};
+    const char *name[N] = {nullptr};
+};
+inline HostProf g_hostprof;
+struct HostProfScope {
+    int slot;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    HostProfScope(int s, const char *name) : slot(s) { g_hostprof.name[s] = name; }
+    ~HostProfScope() {
+        g_hostprof.sec[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        g_hostprof.calls[slot] += 1;
+    }
+};
+inline void hostprof_dump() {
+    if (!std::getenv("XRHIP_HOSTPROF")) return;
+    for (int i = 0; i < HostProf::N; ++i)
+        if (g_hostprof.name[i])
+            std::fprintf(stderr, "[hostprof] %-28s calls %7ld  total %9.3f ms  avg %8.2f us\n", g_hostprof.name[i],
+                         g_hostprof.calls[i], 1e3 * g_hostprof.sec[i], 1e6 * g_hostprof.sec[i] / std::max(1L, g_hostprof.calls[i]));
+}
+
+}   // namespace xrhip

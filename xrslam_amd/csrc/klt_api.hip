@@ -178,6 +178,7 @@ int xrhip_klt_create(int width, int height, int max_points, xrhip_klt **out) {
 
 void xrhip_klt_destroy(xrhip_klt *c) {
     if (!c) return;
+    hostprof_dump();
     hipStreamSynchronize(c->stream);
     hipFree(c->lut);
     hipFree(c->resp);
@@ -348,6 +349,8 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
     xrhip_klt *c = im->ctx;
     const int w = c->w, h = c->h;
     ProfScope prof(c, CAT_DETECT);
+    HostProfScope hp_all(0, "detect: whole call");
+    HostProfScope *hp_gpu = new HostProfScope(1, "detect: launch+D2H waits");
     int rc = run_harris(im);
     if (rc) return rc;
     hipLaunchKernelGGL(k_harris_nms, dim3((w + 63) / 64, (h + 15) / 16), dim3(256), 0, c->stream, c->resp, w, h,
@@ -362,6 +365,8 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
         XR_HIP(hipMemcpyAsync(c->h_cand, c->cand, sizeof(HarrisCand) * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
         XR_HIP(hipStreamSynchronize(c->stream));
     }
+    delete hp_gpu;
+    HostProfScope hp_sel(2, "detect: host selection");
     // total order: response desc, then linear index desc (cv greaterThanPtr).  The greedy
     // spacing pass usually stops after a few hundred candidates (max_points corners), so the
     // order is produced lazily from a heap instead of sorting all candidates.
@@ -408,6 +413,7 @@ int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const dou
     if (!cur->have_pyramid || !next->have_pyramid)
         return xr_fail(XRHIP_ESTATE, "xrhip_image_track: preprocess() has not run on both images");
     if (n == 0) return XRHIP_OK;
+    HostProfScope hp_trk(3, "track: whole call");
     xrhip_klt *c = cur->ctx;
     int rc = ensure_points(c, n);
     if (rc) return rc;
