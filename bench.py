@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (MI355X_MICROARCH.md)
 SLAM_YAML = os.path.join(ROOT, "configs", "bench_slam_150.yaml")
 SENSOR_YAML = os.path.join(ROOT, "configs", "euroc_sensor.yaml")
 
@@ -75,6 +76,7 @@ def main():
         raise SystemExit("warmup failed: " + sess.error())
     t_w = sess.times()
     sess.klt_stats(reset=True)
+    sess.ba_stats(reset=True)
     if not args.no_profile:
         sess.set_profiling(True)
     barrier()
@@ -87,6 +89,7 @@ def main():
         raise SystemExit("timed region failed: " + sess.error())
     t_e = sess.times()
     st = sess.klt_stats(reset=False)
+    bst = sess.ba_stats(reset=False)
     sess.set_profiling(False)
     red = group.reduce_metrics(args.steps, elapsed)      # frames: SUM, wall seconds: MAX over ranks
     elapsed, total_frames = red["seconds"], red["frames"]
@@ -100,6 +103,7 @@ def main():
         lk_bytes = 2420.0 * st.lk_templates + 484.0 * st.lk_iterations     # SURVEY.md section 8d, B_lk
         lk_ms = st.ms_track / n_launch
         achieved = (lk_bytes / n_launch) / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
+        ba_tflops = bst.flops_solve_try / (bst.ms_solve_try * 1e-3) / 1e12 if bst.ms_solve_try > 0 else 0.0
         out = {
             "metric": "frames/sec, full per-frame hot path (KLT tracker + sliding-window VI-BA), one sequence per GPU",
             "value": round(total_frames / elapsed, 3),
@@ -132,10 +136,18 @@ def main():
                  "track_landmark", "refine_window", "slide_window", "refine_subwindow"),
                 [round(1e3 * (t_e.wall_scope[i] - t_w.wall_scope[i]) / args.steps, 4) for i in range(11)])),
             "ate_rmse_m": round(runner.ate_rmse(poses, seq), 5),
-            "roofline": {"kernel": "k_lk_track", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "algorithmic_bytes_per_launch": round(lk_bytes / n_launch, 1),
-                         "launch_us": round(lk_ms * 1e3, 3)},
+            # dominant kernel by total time (profiles/): kb_solve_try = reduced-system Cholesky (f64 MFMA trailing
+            # updates) + trust-region trial costing, one workgroup per launch; flops = algorithmic
+            "roofline": {"kernel": "kb_solve_try", "bound": "mfma", "achieved": round(ba_tflops, 6),
+                         "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ba_tflops / F64_MFMA_PEAK_TFLOPS, 8),
+                         "traffic": None,
+                         "algorithmic_flops_per_launch": round(bst.flops_solve_try / max(1, bst.n_timed), 1),
+                         "launch_us": round(1e3 * bst.ms_solve_try / max(1, bst.n_timed), 3),
+                         "launches": int(bst.n_timed), "trials": int(bst.n_trials)},
+            "roofline_lk": {"kernel": "k_lk_track", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                            "algorithmic_bytes_per_launch": round(lk_bytes / n_launch, 1),
+                            "launch_us": round(lk_ms * 1e3, 3)},
         }
         if os.environ.get("XRSLAM_HIP_LIB"):      # instrumented build variant: report its in-kernel phase timers
             import ctypes

@@ -163,6 +163,8 @@ void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out);
  * xrhip_klt_stats from xrslam_hip.h (passed as void* to keep this header free of that include) */
 void XRSLAMAmdSetProfiling(int enable);
 void XRSLAMAmdGetKltStats(void *xrhip_klt_stats_out, int reset);
+/* same for the BA context: xrhip_ba_stats from xrslam_hip.h (XRSLAMAmdSetProfiling switches both) */
+void XRSLAMAmdGetBaStats(void *xrhip_ba_stats_out, int reset);
 /* last error raised inside the library ("" if none); the reference aborts/throws instead */
 const char *XRSLAMAmdLastError(void);
 

@@ -212,6 +212,19 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
 void xrhip_ba_destroy(xrhip_ba *ctx);
 /* replaces: Solver::solve() over a problem assembled with add_frame_states/add_track_states/add_factor */
 int xrhip_ba_solve(xrhip_ba *ctx, const xrhip_ba_problem *problem, xrhip_ba_summary *summary);
+
+/* HIP-event profiling of the dominant BA kernel (kb_solve_try: reduced-system Cholesky + trust-region trials),
+ * off by default.  flops = algorithmic work of the launches:
+ * na^3/3 + 2 na^2 per launch + (450 M + 3000 NI + 2 np^2) per trial costed. */
+typedef struct xrhip_ba_stats {
+    long n_solve_try;        /* launches */
+    long n_trials;           /* trust-region trials evaluated by them */
+    double ms_solve_try;     /* sum of HIP-event durations (only launches made while profiling was on) */
+    long n_timed;            /* launches that contributed to ms_solve_try */
+    double flops_solve_try;  /* algorithmic flops of the timed launches */
+} xrhip_ba_stats;
+int xrhip_ba_set_profiling(xrhip_ba *ctx, int enable);
+int xrhip_ba_get_stats(xrhip_ba *ctx, xrhip_ba_stats *out, int reset);
 /* replaces: MarginalizationFactor::marginalize(index).  Outputs the new prior over the n_frames-1
  * remaining frames (map order): sqrt_info [(15(n-1))^2], infovec [15(n-1)], lin [(n-1)][16]. */
 int xrhip_ba_marginalize(xrhip_ba *ctx, const xrhip_marg_problem *problem, double *out_sqrt_info,

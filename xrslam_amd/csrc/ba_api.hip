@@ -45,6 +45,16 @@ struct xrhip_ba {
     BaCtl *h_ctl = nullptr;   // pinned; doubles as the zero-copy mailbox of kb_try
     int *h_seq = nullptr;     // pinned; sequence number published by kb_try after h_ctl / h_out
     int seq = 0;
+    // optional HIP-event profiling of kb_solve_try
+    bool profiling = false;
+    struct Timed {
+        hipEvent_t e0, e1;
+        double flops_fixed, flops_per_trial;
+        int iter_before;
+    };
+    std::vector<Timed> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    xrhip_ba_stats stats = {0, 0, 0.0, 0, 0.0};
     double *h_out = nullptr;  // pinned readback (states + depths)
     size_t h_out_cap = 0;
     int lds_limit = 150 * 1024;
@@ -369,8 +379,27 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
     int rcl = solve_lds(d, (size_t)c->lds_limit, &lds, &use_lds);
     if (rcl) return rcl;
     lds = std::max(lds, sizeof(double) * (size_t)std::max(TRY_B * (d.np + 15 * d.NI), 1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling) {
+        if (!c->free_events.empty()) {
+            e0 = c->free_events.back().first;
+            e1 = c->free_events.back().second;
+            c->free_events.pop_back();
+        } else {
+            XR_HIP(hipEventCreate(&e0));
+            XR_HIP(hipEventCreate(&e1));
+        }
+        XR_HIP(hipEventRecord(e0, s));
+    }
     hipLaunchKernelGGL(kb_solve_try, dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq);
     XR_HIP(hipGetLastError());
+    if (c->profiling) {
+        XR_HIP(hipEventRecord(e1, s));
+        const double na = d.na;
+        c->pending.push_back({e0, e1, na * na * na / 3.0 + 2.0 * na * na,
+                              450.0 * d.M + 3000.0 * d.NI + 2.0 * (double)d.np * d.np, -1});
+    }
+    c->stats.n_solve_try++;
     return XRHIP_OK;
 }
 
@@ -395,6 +424,34 @@ static int wait_mailbox(xrhip_ba *c, int seq) {
 static long long g_kprof[32];   // accumulated in-kernel phase ticks (all zero unless built with -DXRHIP_KPROF)
 
 extern "C" {
+
+static void ba_resolve_pending(xrhip_ba *c) {
+    for (auto &t : c->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
+            c->stats.ms_solve_try += ms;
+            c->stats.n_timed += 1;
+            c->stats.flops_solve_try += t.flops_fixed + t.flops_per_trial * std::max(t.iter_before, 0);
+        }
+        c->free_events.push_back({t.e0, t.e1});
+    }
+    c->pending.clear();
+}
+
+int xrhip_ba_set_profiling(xrhip_ba *c, int enable) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_set_profiling: null context");
+    if (!enable) ba_resolve_pending(c);
+    c->profiling = enable != 0;
+    return XRHIP_OK;
+}
+
+int xrhip_ba_get_stats(xrhip_ba *c, xrhip_ba_stats *out, int reset) {
+    if (!c || !out) return xr_fail(XRHIP_EINVAL, "xrhip_ba_get_stats: null argument");
+    ba_resolve_pending(c);
+    *out = c->stats;
+    if (reset) c->stats = {0, 0, 0.0, 0, 0.0};
+    return XRHIP_OK;
+}
 
 /* development aid: in-kernel phase timers of kb_solve / kb_try accumulated over all solves of the process,
  * in 100 MHz ticks; only instrumented builds (build.sh -DXRHIP_KPROF) write them */
@@ -435,6 +492,11 @@ void xrhip_ba_destroy(xrhip_ba *c) {
     hipHostFree(c->h_stage);
     hipHostFree(c->h_ctl);
     hipHostFree(c->h_seq);
+    ba_resolve_pending(c);
+    for (auto &e : c->free_events) {
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
+    }
     hipHostFree(c->h_out);
     hipStreamDestroy(c->stream);
     delete c;
@@ -476,7 +538,7 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     hipStream_t s = c->stream;
     if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);
     bool done = false, relinearise = true;
-    int mode = 1;
+    int mode = 1, iter_seen = 0;
     for (int guard = 0; guard < 4 * (P->max_iterations + 8) && !done; ++guard) {
         const int seq = ++c->seq;
         if (relinearise) launch_linearize(c, d, p, cam, imu, sx, sy, true);
@@ -484,6 +546,13 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
         if (rc) return rc;
         rc = wait_mailbox(c, seq);   // no copy, no driver wait: the kernel's last store is the sequence number
         if (rc) return rc;
+        {   // trials this launch costed = trust-region iterations it advanced
+            const int it_now = c->h_ctl->iteration;
+            const int trials = std::max(0, it_now - iter_seen);
+            iter_seen = it_now;
+            c->stats.n_trials += trials;
+            if (c->profiling && !c->pending.empty()) c->pending.back().iter_before = trials;
+        }
         const int st = c->h_ctl->status;
         if (st == ST_DONE) {
             done = true;   // the optimised states are already in h_out

@@ -247,7 +247,16 @@ void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out) {
 
 void XRSLAMAmdSetProfiling(int enable) {
     Manager &m = mgr();
-    if (m.sys) xrhip_klt_set_profiling(m.sys->P.klt, enable);
+    if (m.sys) {
+        xrhip_klt_set_profiling(m.sys->P.klt, enable);
+        xrhip_ba_set_profiling(m.sys->P.ba, enable);
+    }
+}
+
+void XRSLAMAmdGetBaStats(void *out, int reset) {
+    Manager &m = mgr();
+    if (!m.sys || !out) return;
+    guarded([&] { xrh::hip_check(xrhip_ba_get_stats(m.sys->P.ba, static_cast<xrhip_ba_stats *>(out), reset), "xrhip_ba_get_stats"); });
 }
 
 void XRSLAMAmdGetKltStats(void *out, int reset) {

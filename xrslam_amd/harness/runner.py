@@ -24,6 +24,11 @@ class XRSLAMPose(C.Structure):
     _fields_ = [("quaternion", C.c_double * 4), ("translation", C.c_double * 3), ("timestamp", C.c_double)]
 
 
+class BaStats(C.Structure):   # xrhip_ba_stats (include/xrslam_hip.h)
+    _fields_ = [("n_solve_try", C.c_long), ("n_trials", C.c_long), ("ms_solve_try", C.c_double), ("n_timed", C.c_long),
+                ("flops_solve_try", C.c_double)]
+
+
 class XRSLAMAmdTimes(C.Structure):
     _fields_ = [("frames", C.c_long), ("solves", C.c_long), ("solve_iterations", C.c_long),
                 ("marginalizations", C.c_long), ("keyframes", C.c_long), ("ba_device_ms", C.c_double),
@@ -132,6 +137,11 @@ class Session:
         from xrslam_amd.klt import KltStats
         st = KltStats()
         self.lib.XRSLAMAmdGetKltStats(C.byref(st), 1 if reset else 0)
+        return st
+
+    def ba_stats(self, reset=False):
+        st = BaStats()
+        self.lib.XRSLAMAmdGetBaStats(C.byref(st), 1 if reset else 0)
         return st
 
     def error(self):
