@@ -104,6 +104,15 @@ def main():
         lk_ms = st.ms_track / n_launch
         achieved = (lk_bytes / n_launch) / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
         ba_tflops = bst.flops_solve_try / (bst.ms_solve_try * 1e-3) / 1e12 if bst.ms_solve_try > 0 else 0.0
+        # HBM-side bytes per launch: PMC counters cannot be read in-process; they come from the committed rocprofv3
+        # --pmc passes of this same command (profiles/r01_pmc_traffic.md says how they were collected)
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            traffic = {k: round(1024.0 * (v["fetch_kb"] + v["write_kb"]), 1) for k, v in pmc.items()}
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "frames/sec, full per-frame hot path (KLT tracker + sliding-window VI-BA), one sequence per GPU",
             "value": round(total_frames / elapsed, 3),
@@ -140,12 +149,12 @@ def main():
             # updates) + trust-region trial costing, one workgroup per launch; flops = algorithmic
             "roofline": {"kernel": "kb_solve_try", "bound": "mfma", "achieved": round(ba_tflops, 6),
                          "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ba_tflops / F64_MFMA_PEAK_TFLOPS, 8),
-                         "traffic": None,
+                         "traffic": traffic.get("kb_solve_try"),
                          "algorithmic_flops_per_launch": round(bst.flops_solve_try / max(1, bst.n_timed), 1),
                          "launch_us": round(1e3 * bst.ms_solve_try / max(1, bst.n_timed), 3),
                          "launches": int(bst.n_timed), "trials": int(bst.n_trials)},
             "roofline_lk": {"kernel": "k_lk_track", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic.get("k_lk_track"),
                             "algorithmic_bytes_per_launch": round(lk_bytes / n_launch, 1),
                             "launch_us": round(lk_ms * 1e3, 3)},
         }
