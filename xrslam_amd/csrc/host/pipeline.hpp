@@ -281,7 +281,7 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
         by_length.emplace_back(i, t->keypoint_num());
     }
     std::sort(by_length.begin(), by_length.end(), [](const auto &a, const auto &b) { return a.second > b.second; });
-    xrhip::PoissonDisk2 filter(c.feature_tracker_min_keypoint_distance);
+    xrhip::PoissonDisk2 filter(c.feature_tracker_min_keypoint_distance, (int)c.cam_resolution[0], (int)c.cam_resolution[1]);
     for (auto &[ki, len] : by_length) {
         (void)len;
         Track *t = cur->get_track(ki);

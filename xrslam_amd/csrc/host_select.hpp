@@ -21,11 +21,19 @@ namespace xrhip {
 // decides which cells are consulted.
 class PoissonDisk2 {
   public:
-    explicit PoissonDisk2(double radius)
-        : r2_(radius * radius), cell_(radius / std::sqrt(2.0)), span_((int)std::ceil(std::sqrt(2.0))) {}
+    // width/height (pixels) size a dense cell array for the image area plus a margin; points outside it (never
+    // produced by the tracker, but legal) fall back to a hash map, so results do not depend on the bounds given.
+    explicit PoissonDisk2(double radius, int width = 0, int height = 0)
+        : r2_(radius * radius), cell_(radius / std::sqrt(2.0)), span_((int)std::ceil(std::sqrt(2.0))) {
+        if (width > 0 && height > 0) {
+            gw_ = (int)std::floor(width / cell_) + 1 + 2 * kMargin;
+            gh_ = (int)std::floor(height / cell_) + 1 + 2 * kMargin;
+            dense_.assign((size_t)gw_ * gh_, -1);
+        }
+    }
 
     void preset(double x, double y) {
-        grid_[key(ix(x), ix(y))] = (int)pts_.size() / 2;
+        slot(ix(x), ix(y)) = (int)pts_.size() / 2;
         pts_.push_back(x);
         pts_.push_back(y);
     }
@@ -40,9 +48,9 @@ class PoissonDisk2 {
                 x_it = bx;
                 ++y_it;
             }
-            auto it = grid_.find(key(x_it, y_it));
-            if (it != grid_.end()) {
-                const double dx = x - pts_[2 * it->second], dy = y - pts_[2 * it->second + 1];
+            const int at = lookup(x_it, y_it);
+            if (at >= 0) {
+                const double dx = x - pts_[2 * at], dy = y - pts_[2 * at + 1];
                 if (dx * dx + dy * dy < r2_) return false;
             }
         }
@@ -56,12 +64,25 @@ class PoissonDisk2 {
     }
 
   private:
+    static constexpr int kMargin = 4;
     int ix(double v) const { return (int)std::floor(v / cell_); }
     static int64_t key(int a, int b) { return ((int64_t)a << 32) ^ (uint32_t)b; }
+    bool inside(int a, int b) const { return a >= -kMargin && b >= -kMargin && a < gw_ - kMargin && b < gh_ - kMargin; }
+    int lookup(int a, int b) const {
+        if (inside(a, b)) return dense_[(size_t)(b + kMargin) * gw_ + (a + kMargin)];
+        auto it = sparse_.find(key(a, b));
+        return it == sparse_.end() ? -1 : it->second;
+    }
+    int &slot(int a, int b) {
+        if (inside(a, b)) return dense_[(size_t)(b + kMargin) * gw_ + (a + kMargin)];
+        return sparse_[key(a, b)];
+    }
     double r2_, cell_;
     int span_;
+    int gw_ = 0, gh_ = 0;
     std::vector<double> pts_;
-    std::unordered_map<int64_t, int> grid_;
+    std::vector<int> dense_;
+    std::unordered_map<int64_t, int> sparse_;
 };
 
 // goodFeaturesToTrack's greedy spacing.  `next(idx)` yields candidate linear

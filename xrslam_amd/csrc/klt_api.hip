@@ -42,6 +42,10 @@ struct xrhip_klt {
     int cand_cap = 0;
     HarrisCand *h_cand = nullptr;    // pinned
     int *h_count = nullptr;          // pinned (2 ints)
+    HarrisCand *h_top = nullptr;     // pinned, device-mapped: the strongest candidates (k_harris_select)
+    SelectHeader *h_sel = nullptr;   // pinned, device-mapped
+    int top_cap = 4096;
+    int sel_seq = 0;
     // track scratch
     int pts_cap = 0;
     double2 *d_curr = nullptr, *d_next = nullptr;
@@ -167,6 +171,9 @@ int xrhip_klt_create(int width, int height, int max_points, xrhip_klt **out) {
     XR_HIP(hipMalloc(&c->cand, sizeof(HarrisCand) * (size_t)c->cand_cap));
     XR_HIP(hipHostMalloc(&c->h_cand, sizeof(HarrisCand) * (size_t)c->cand_cap, hipHostMallocDefault));
     XR_HIP(hipHostMalloc(&c->h_count, sizeof(int) * 2, hipHostMallocDefault));
+    XR_HIP(hipHostMalloc(&c->h_top, sizeof(HarrisCand) * (size_t)c->top_cap, hipHostMallocDefault));
+    XR_HIP(hipHostMalloc(&c->h_sel, sizeof(SelectHeader), hipHostMallocDefault));
+    std::memset(c->h_sel, 0, sizeof(SelectHeader));
     XR_HIP(hipMalloc(&c->d_counters, sizeof(LkCounters)));
     XR_HIP(hipMemset(c->d_counters, 0, sizeof(LkCounters)));
     XR_HIP(hipHostMalloc(&c->h_counters, sizeof(LkCounters), hipHostMallocDefault));
@@ -186,6 +193,8 @@ void xrhip_klt_destroy(xrhip_klt *c) {
     hipFree(c->cand);
     hipHostFree(c->h_cand);
     hipHostFree(c->h_count);
+    hipHostFree(c->h_top);
+    hipHostFree(c->h_sel);
     hipFree(c->d_curr);
     hipFree(c->d_next);
     hipFree(c->d_status);
@@ -356,41 +365,66 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
     hipLaunchKernelGGL(k_harris_nms, dim3((w + 63) / 64, (h + 15) / 16), dim3(256), 0, c->stream, c->resp, w, h,
                        c->max_key, 1.0e-3, c->cand, c->cand_count, c->cand_cap);
     XR_HIP(hipGetLastError());
+    // the strongest candidates + header arrive in pinned memory without a copy; spin on the sequence number
+    HarrisCand *d_top = nullptr;
+    SelectHeader *d_sel = nullptr;
+    XR_HIP(hipHostGetDevicePointer((void **)&d_top, c->h_top, 0));
+    XR_HIP(hipHostGetDevicePointer((void **)&d_sel, c->h_sel, 0));
+    const int seq = ++c->sel_seq;
+    hipLaunchKernelGGL(k_harris_select, dim3(1), dim3(1024), 0, c->stream, c->cand, c->cand_count, c->cand_cap, c->max_key,
+                       1.0e-3, d_top, c->top_cap, d_sel, seq);
+    XR_HIP(hipGetLastError());
     prof.finish();
-    XR_HIP(hipMemcpyAsync(c->h_count, c->max_key, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
-    XR_HIP(hipStreamSynchronize(c->stream));
-    const int nc = c->h_count[1];
-    if (nc > c->cand_cap) return xr_fail(XRHIP_EOVERFLOW, "xrhip_image_detect: corner candidate buffer overflow");
-    if (nc > 0) {
-        XR_HIP(hipMemcpyAsync(c->h_cand, c->cand, sizeof(HarrisCand) * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
-        XR_HIP(hipStreamSynchronize(c->stream));
+    {
+        volatile int *flag = &c->h_sel->seq;
+        for (unsigned long spin = 1; *flag != seq; ++spin)
+            if ((spin & 0x3FFF) == 0) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess && *flag != seq) return xr_fail(XRHIP_ESTATE, "xrhip_image_detect: selection kernel did not publish");
+                if (q != hipSuccess && q != hipErrorNotReady) return xr_fail(XRHIP_EHIP, "xrhip_image_detect: stream error");
+            }
     }
+    const int nc = c->h_sel->n_candidates, n_top = c->h_sel->n_top;
+    if (nc > c->cand_cap) return xr_fail(XRHIP_EOVERFLOW, "xrhip_image_detect: corner candidate buffer overflow");
     delete hp_gpu;
     HostProfScope hp_sel(2, "detect: host selection");
-    // total order: response desc, then linear index desc (cv greaterThanPtr).  The greedy
-    // spacing pass usually stops after a few hundred candidates (max_points corners), so the
-    // order is produced lazily from a heap instead of sorting all candidates.
+    // total order: response desc, then linear index desc (cv greaterThanPtr).  The greedy spacing pass usually
+    // stops after a few hundred candidates (max_points corners), so the order is produced lazily from a heap.
     auto before = [](const HarrisCand &a, const HarrisCand &b) {   // a is visited before b
         if (a.v > b.v) return true;
         if (a.v < b.v) return false;
         return a.idx > b.idx;
     };
     auto heap_less = [&](const HarrisCand &a, const HarrisCand &b) { return before(b, a); };
-    HarrisCand *hb = c->h_cand, *he = c->h_cand + nc;
-    std::make_heap(hb, he, heap_less);
     // GFTTDetector(max_points, 1e-3, 20, 3, harris) -- minDistance is the literal 20 of opencv_image.cpp:186
-    std::vector<int> corners = greedy_min_distance(
-        [&](int &idx) {
-            if (hb == he) return false;
-            std::pop_heap(hb, he, heap_less);
-            --he;
-            idx = he->idx;
-            return true;
-        },
-        w, h, 20.0, max_points);
+    auto select_from = [&](HarrisCand *hb, HarrisCand *he) {
+        std::make_heap(hb, he, heap_less);
+        return greedy_min_distance(
+            [&](int &idx) {
+                if (hb == he) return false;
+                std::pop_heap(hb, he, heap_less);
+                --he;
+                idx = he->idx;
+                return true;
+            },
+            w, h, 20.0, max_points);
+    };
+    std::vector<int> corners;
+    bool need_all = n_top > c->top_cap;
+    if (!need_all) {
+        corners = select_from(c->h_top, c->h_top + n_top);
+        // the pass ran out of strong candidates before it had max_points corners: the weaker ones matter after all
+        need_all = n_top < nc && (max_points <= 0 || (int)corners.size() < max_points);
+    }
+    if (need_all) {
+        HostProfScope hp_fb(12, "detect: full candidate list fallback");
+        XR_HIP(hipMemcpyAsync(c->h_cand, c->cand, sizeof(HarrisCand) * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
+        XR_HIP(hipStreamSynchronize(c->stream));
+        corners = select_from(c->h_cand, c->h_cand + nc);
+    }
     int n = 0;
     if (!corners.empty()) {
-        PoissonDisk2 filter(min_distance);
+        PoissonDisk2 filter(min_distance, w, h);
         for (int i = 0; i < n_exist; ++i) filter.preset(existing_xy[2 * i], existing_xy[2 * i + 1]);
         for (int idx : corners) {
             const double x = (double)(float)(idx % w), y = (double)(float)(idx / w);

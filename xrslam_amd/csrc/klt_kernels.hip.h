@@ -308,6 +308,77 @@ __global__ __launch_bounds__(256) void k_harris_nms(const float *__restrict__ re
     }
 }
 
+// The host's greedy spacing pass visits candidates in (response desc, index desc) order and normally stops
+// after a few hundred of the ~10^4 NMS survivors.  This kernel hands it a superset of the SEL_K strongest:
+// responses are binned linearly between the quality threshold and the maximum (monotone in the response), the
+// bin boundary that keeps >= SEL_K candidates is found, and everything at or above it is written -- together
+// with a header and, last, a sequence number -- straight into pinned host memory.  One workgroup.
+constexpr int SEL_BINS = 4096;
+constexpr int SEL_K = 1024;
+struct SelectHeader {
+    int n_candidates;   // all NMS survivors
+    int n_top;          // candidates at or above the boundary bin (may exceed the capacity of the top block)
+    int boundary_bin;
+    int seq;            // written last
+};
+
+__global__ __launch_bounds__(1024) void k_harris_select(const HarrisCand *__restrict__ cand, const int *__restrict__ count,
+                                                        int capacity, const int *__restrict__ max_key, double quality,
+                                                        HarrisCand *top_out, int top_cap, SelectHeader *hdr, int seq) {
+    __shared__ unsigned hist[SEL_BINS];
+    __shared__ unsigned part[64];
+    __shared__ int s_bin, s_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nc = min(*count, capacity);
+    const float maxv = float_from_key(*max_key);
+    const float thr = (float)((double)maxv * quality);
+    const float scale = (maxv > thr) ? (float)SEL_BINS / (maxv - thr) : 0.f;
+    for (int i = tid; i < SEL_BINS; i += 1024) hist[i] = 0;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int i = tid; i < nc; i += 1024) {
+        const int q = min(SEL_BINS - 1, max(0, (int)((cand[i].v - thr) * scale)));
+        atomicAdd(&hist[q], 1u);
+    }
+    __syncthreads();
+    // boundary = largest bin b with count(bins >= b) >= SEL_K (0 when there are fewer candidates)
+    if (tid < 64) {
+        unsigned sum = 0;
+        for (int b = 0; b < SEL_BINS / 64; ++b) sum += hist[tid * (SEL_BINS / 64) + b];
+        part[tid] = sum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned above = 0;
+        int g = 63;
+        while (g > 0 && above + part[g] < (unsigned)SEL_K) above += part[g--];
+        int b = g * (SEL_BINS / 64) + (SEL_BINS / 64) - 1;
+        while (b > g * (SEL_BINS / 64) && above + hist[b] < (unsigned)SEL_K) above += hist[b--];
+        if (above + hist[b] < (unsigned)SEL_K) b = 0;   // fewer than SEL_K candidates in total: keep all
+        s_bin = b;
+    }
+    __syncthreads();
+    const int bin = s_bin;
+    for (int i = tid; i < nc; i += 1024) {
+        const HarrisCand cd = cand[i];
+        const int q = min(SEL_BINS - 1, max(0, (int)((cd.v - thr) * scale)));
+        if (q >= bin) {
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < top_cap) top_out[pos] = cd;
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        hdr->n_candidates = *count;
+        hdr->n_top = s_n;
+        hdr->boundary_bin = bin;
+        __threadfence_system();
+        *reinterpret_cast<volatile int *>(&hdr->seq) = seq;
+    }
+    (void)lane;
+}
+
 // ----------------------------------------------------------------------- LK
 constexpr int LK_SLOTS = 7;   // ceil(441 / 64)
 constexpr int LK_W_BITS = 14;
