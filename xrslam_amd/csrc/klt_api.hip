@@ -48,6 +48,13 @@ struct xrhip_klt {
     int sel_seq = 0;
     // track scratch
     int pts_cap = 0;
+    // zero-copy point block of xrhip_image_track (pinned, device-mapped): curr | next | status, + completion mailbox
+    char *h_pts = nullptr;
+    int h_pts_cap = 0;
+    unsigned *d_done = nullptr;      // device counter of finished wavefronts (monotonic)
+    unsigned done_base = 0;
+    int *h_trk_seq = nullptr;        // pinned
+    int trk_seq = 0;
     double2 *d_curr = nullptr, *d_next = nullptr;
     uint8_t *d_status = nullptr;
     float2 *d_fprev = nullptr, *d_fnext = nullptr;
@@ -172,6 +179,10 @@ int xrhip_klt_create(int width, int height, int max_points, xrhip_klt **out) {
     XR_HIP(hipHostMalloc(&c->h_cand, sizeof(HarrisCand) * (size_t)c->cand_cap, hipHostMallocDefault));
     XR_HIP(hipHostMalloc(&c->h_count, sizeof(int) * 2, hipHostMallocDefault));
     XR_HIP(hipHostMalloc(&c->h_top, sizeof(HarrisCand) * (size_t)c->top_cap, hipHostMallocDefault));
+    XR_HIP(hipHostMalloc(&c->h_trk_seq, 64, hipHostMallocDefault));
+    *c->h_trk_seq = 0;
+    XR_HIP(hipMalloc(&c->d_done, sizeof(unsigned)));
+    XR_HIP(hipMemset(c->d_done, 0, sizeof(unsigned)));
     XR_HIP(hipHostMalloc(&c->h_sel, sizeof(SelectHeader), hipHostMallocDefault));
     std::memset(c->h_sel, 0, sizeof(SelectHeader));
     XR_HIP(hipMalloc(&c->d_counters, sizeof(LkCounters)));
@@ -194,6 +205,9 @@ void xrhip_klt_destroy(xrhip_klt *c) {
     hipHostFree(c->h_cand);
     hipHostFree(c->h_count);
     hipHostFree(c->h_top);
+    hipHostFree(c->h_trk_seq);
+    hipHostFree(c->h_pts);
+    hipFree(c->d_done);
     hipHostFree(c->h_sel);
     hipFree(c->d_curr);
     hipFree(c->d_next);
@@ -451,25 +465,47 @@ int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const dou
     xrhip_klt *c = cur->ctx;
     int rc = ensure_points(c, n);
     if (rc) return rc;
-    XR_HIP(hipMemcpyAsync(c->d_curr, curr_xy, sizeof(double2) * n, hipMemcpyHostToDevice, c->stream));
-    if (has_guess)
-        XR_HIP(hipMemcpyAsync(c->d_next, next_xy_inout, sizeof(double2) * n, hipMemcpyHostToDevice, c->stream));
+    if (n > c->h_pts_cap) {
+        if (c->h_pts) hipHostFree(c->h_pts);
+        c->h_pts = nullptr;
+        const int cap = std::max(n, std::max(512, 2 * c->h_pts_cap));
+        XR_HIP(hipHostMalloc(&c->h_pts, (size_t)cap * (2 * sizeof(double2) + 1) + 64, hipHostMallocDefault));
+        c->h_pts_cap = cap;
+    }
+    double2 *h_curr = (double2 *)c->h_pts, *h_next = h_curr + c->h_pts_cap;
+    uint8_t *h_status = (uint8_t *)(h_next + c->h_pts_cap);
+    std::memcpy(h_curr, curr_xy, sizeof(double2) * n);
+    if (has_guess) std::memcpy(h_next, next_xy_inout, sizeof(double2) * n);
+    char *d_pts = nullptr;
+    int *d_seq = nullptr;
+    XR_HIP(hipHostGetDevicePointer((void **)&d_pts, c->h_pts, 0));
+    XR_HIP(hipHostGetDevicePointer((void **)&d_seq, c->h_trk_seq, 0));
+    double2 *dv_curr = (double2 *)d_pts, *dv_next = dv_curr + c->h_pts_cap;
+    uint8_t *dv_status = (uint8_t *)(dv_next + c->h_pts_cap);
     PyrView A = make_view(cur), B = make_view(next);
     ProfScope prof(c, CAT_TRACK);
-    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, c->stream, A, B, c->d_curr, c->d_next, has_guess ? 1 : 0,
-                       c->d_status, n, c->profiling ? c->d_counters : (LkCounters *)nullptr);
+    const int seq = ++c->trk_seq;
+    c->done_base += (unsigned)n;
+    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, c->stream, A, B, dv_curr, dv_next, has_guess ? 1 : 0, dv_status, n,
+                       c->profiling ? c->d_counters : (LkCounters *)nullptr, c->d_done, c->done_base, d_seq, seq);
     XR_HIP(hipGetLastError());
     prof.finish();
     c->stats.lk_points += n;
+    {
+        volatile int *flag = c->h_trk_seq;
+        for (unsigned long spin = 1; *flag != seq; ++spin)
+            if ((spin & 0x3FFF) == 0) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess && *flag != seq) return xr_fail(XRHIP_ESTATE, "xrhip_image_track: kernel retired without publishing");
+                if (q != hipSuccess && q != hipErrorNotReady) return xr_fail(XRHIP_EHIP, "xrhip_image_track: stream error");
+            }
+    }
     // results: status first, positions only where status != 0 (reference semantics)
-    std::vector<double> tmp(2 * (size_t)n);
-    XR_HIP(hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
-    XR_HIP(hipMemcpyAsync(tmp.data(), c->d_next, sizeof(double2) * n, hipMemcpyDeviceToHost, c->stream));
-    XR_HIP(hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; ++i) {
+        status[i] = h_status[i];
         if (status[i]) {
-            next_xy_inout[2 * i] = tmp[2 * i];
-            next_xy_inout[2 * i + 1] = tmp[2 * i + 1];
+            next_xy_inout[2 * i] = h_next[i].x;
+            next_xy_inout[2 * i + 1] = h_next[i].y;
         }
     }
     return XRHIP_OK;

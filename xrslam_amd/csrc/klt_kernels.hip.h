@@ -546,10 +546,15 @@ __device__ __forceinline__ void lk_lane_layout(int lane, int (&wx)[LK_SLOTS], in
 
 // OpenCvImage::track_keypoints: forward LK, border/displacement gates, backward
 // LK, 0.5 px round-trip check -- fused, one wavefront per keypoint.
+// curr / next_io / status_out may live in pinned host memory (zero-copy): the points of a frame are a few KB, so
+// the kernel reads and writes them over the host link itself.  done / done_target / host_seq implement the
+// completion mailbox: every wavefront publishes its result (system-scope fence), bumps `done`, and the one that
+// reaches done_target stores `seq` where the host is spinning.
 __global__ __launch_bounds__(64) void k_lk_track(PyrView A, PyrView B, const double2 *__restrict__ curr,
                                                  double2 *__restrict__ next_io, int has_guess,
                                                  uint8_t *__restrict__ status_out, int n,
-                                                 LkCounters *__restrict__ counters) {
+                                                 LkCounters *__restrict__ counters, unsigned *done, unsigned done_target,
+                                                 int *host_seq, int seq) {
     const int pt = blockIdx.x;
     if (pt >= n) return;
     const int lane = threadIdx.x;
@@ -586,6 +591,13 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrView A, PyrView B, const dou
         if (counters) {
             atomicAdd(&counters->templates, (unsigned long long)n_templates);
             atomicAdd(&counters->iterations, (unsigned long long)n_iters);
+        }
+        if (done) {
+            __threadfence_system();
+            if (atomicAdd(done, 1u) + 1u == done_target) {
+                __threadfence_system();
+                *reinterpret_cast<volatile int *>(host_seq) = seq;
+            }
         }
     }
 }
