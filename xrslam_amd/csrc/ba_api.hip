@@ -351,17 +351,17 @@ static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, cons
     else hipLaunchKernelGGL(kb_sum_cost, dim3(1), dim3(256), 0, s, d, p);
 }
 
-// dynamic LDS of kb_solve / solve_block: rhs [na] + work region = max(packed triangle, gathered frame step of the
-// back-substitution); systems whose triangle does not fit `limit` are factored in the global buffer Sred instead
+// dynamic LDS of solve_block: work region = max(packed triangle incl. the rhs row that rides along, gathered
+// frame step of the back-substitution); systems whose triangle does not fit `limit` are factored in the global
+// buffer Sred instead
 static int solve_lds(const BaDims &d, size_t limit, size_t *bytes, int *use_lds) {
-    const size_t tri = (size_t)d.na * (d.na + 1) / 2;
+    const size_t tri = (size_t)(d.na + 1) * (d.na + 2) / 2;
     const size_t aux = (size_t)d.PF;
-    size_t lds = sizeof(double) * ((size_t)((d.na + 1) & ~1) + std::max(tri, aux));
+    size_t lds = sizeof(double) * std::max(tri, aux);
     *use_lds = 1;
     if (lds > limit) {
         *use_lds = 0;
-        lds = sizeof(double) * ((size_t)((d.na + 1) & ~1) + aux);
-        if (lds > limit) return xr_fail(XRHIP_EOVERFLOW, "xrhip_ba_solve: problem exceeds the LDS work region");
+        lds = sizeof(double) * aux;
     }
     *bytes = lds;
     return XRHIP_OK;

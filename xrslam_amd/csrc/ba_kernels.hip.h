@@ -795,9 +795,9 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
     __shared__ int fail;
     BaCtl *c = p.ctl;
     const int n = d.n, na = d.na, tid = threadIdx.x, nt = blockDim.x;
-    double *y = lds;                                   // [na] rhs / solution (compact)
-    double *work = lds + ((na + 1) & ~1);              // LDS work region: the packed triangle, later the gathered frame step
-    double *A = use_lds ? work : p.Sred;               // packed lower triangle (compact)
+    double *work = lds;                                // LDS work region: the packed triangle, later the gathered frame step
+    double *A = use_lds ? work : p.Sred;               // packed lower triangle (compact) + the rhs as its row `na`
+    double *y = A + tri_idx(na, 0);                    // [na] rhs -> L^-1 rhs (by the factorisation) -> solution
     const double mu = c->mu;
     KPROF_BEGIN();
     for (int i = tid; i < na; i += nt) {   // rhs = sp (gp - W^T (omega gl)); the product comes from kb_solve_aux
@@ -823,16 +823,15 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
     __syncthreads();
     KPROF(1);
 #ifdef XRHIP_KPROF
-    const bool ok = chol_blocked(A, na, Dblk, &fail, p.ctl->prof + 24);
+    const bool ok = chol_blocked(A, na, na + 1, Dblk, &fail, p.ctl->prof + 24);   // the rhs row rides along
 #else
-    const bool ok = chol_blocked(A, na, Dblk, &fail);
+    const bool ok = chol_blocked(A, na, na + 1, Dblk, &fail);
 #endif
     KPROF(2);
     if (!ok) {
         if (tid == 0) c->linear_ok = 0;
         return;
     }
-    trsv_lower(A, na, y);
     KPROF(3);
     trsv_lower_t(A, na, y);
     KPROF(4);
@@ -852,7 +851,12 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
         if (!isfinite(ya)) bad = 1;
     }
     __syncthreads();
-    {
+    if (!d.nla) {   // every landmark is held constant (localize_newframe, refine_subwindow): nothing to back-substitute
+        for (int l = tid; l < d.L; l += nt) {
+            p.gn[n + l] = 0.0;
+            p.grad[n + l] = 0.0;
+        }
+    } else {
         const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
         const int P6 = 6 * d.F;
         double *x6 = work;   // [P6] scaled frame step gathered to the pose columns (the triangle is dead by now)
@@ -865,7 +869,7 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
             double w8[QF_ROWS];
 #pragma unroll
             for (int r = 0; r < QF_ROWS; ++r) w8[r] = 0.0;
-            for (int c0 = 0; c0 < (d.nla ? P6 : 0); c0 += 128) {
+            for (int c0 = 0; c0 < P6; c0 += 128) {
                 double w[2][QF_ROWS];
 #pragma unroll
                 for (int cch = 0; cch < 2; ++cch) {

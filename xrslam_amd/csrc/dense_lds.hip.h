@@ -1,13 +1,15 @@
 // dense_lds.hip.h -- workgroup-cooperative dense SPD kernels on a packed lower-triangular matrix that
 // lives in LDS (or, for systems that exceed the 160 KB LDS of a CU, in an L2-resident global buffer).
 //
-// Used by the reduced-camera-system solve of the bundle adjustment (kb_solve) and by the Cholesky
+// Used by the reduced-camera-system solve of the bundle adjustment (solve_block) and by the Cholesky
 // fast path of the marginalisation (km_chol).  Right-looking blocked Cholesky with 16-wide panels:
-//   (1) the 16x16 diagonal block is factored by wavefront 0 alone (lane-parallel, wave-synchronous,
-//       no workgroup barrier inside),
-//   (2) the panel below it is solved one row per thread,
-//   (3) the trailing matrix gets its rank-16 update from the f64 matrix cores (16x16 tiles, one per wavefront),
-// i.e. 3 workgroup barriers per panel instead of 3 per column.  Triangular solves are blocked the same way.
+//   (1) the 16x16 diagonal block is factored AND inverted by wavefront 0 entirely in registers: lane l owns
+//       row l, values cross lanes through v_readlane -- no LDS round trip, no barrier on the serial chain;
+//   (2) the panel below it is multiplied by the inverse on the f64 matrix cores (16-row tiles);
+//   (3) the trailing matrix gets its rank-16 update from the matrix cores as well (16x16 tiles),
+// i.e. 3 workgroup barriers per panel.  A right-hand side can ride along as an extra row of the matrix
+// (nrows = n + 1): when the factorisation ends that row holds L^-1 rhs, so no forward solve is needed.
+// The triangular solves run the 16x16 diagonal systems in registers the same way.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,9 +26,13 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// In-place blocked Cholesky of the packed lower triangle A (n x n): on success A holds L.
-// D is a [CH_NB][CH_NB+1] LDS scratch block, s_fail an LDS flag.  All threads of the workgroup must call.
-// Returns false (uniformly) if a non-positive pivot is met.
+// value of `v` in lane `src` (wave-uniform index), broadcast to every lane
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 #ifdef XRHIP_KPROF
 #define CHPROF(slot)                                  \
     do {                                              \
@@ -41,9 +47,61 @@ __device__ __forceinline__ void wave_sync() {
     do {             \
     } while (0)
 #endif
-__device__ __forceinline__ bool chol_blocked(double *A, int n, double (*D)[CH_NB + 1], int *s_fail,
+
+typedef double chol_d4 __attribute__((ext_vector_type(4)));
+
+// Wavefront 0 only.  Factors the nb x nb diagonal block at (j0, j0) of the packed matrix A in place (A gets L)
+// and leaves L^-1 (lower triangular, zero above the diagonal, identity-padded to 16x16) in Dinv.
+// Returns false (uniformly over the wavefront) on a non-positive pivot.
+__device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double (*Dinv)[CH_NB + 1], int lane) {
+    double x[CH_NB];   // row `lane` of the block; rows >= nb are identity rows
+#pragma unroll
+    for (int k = 0; k < CH_NB; ++k) x[k] = (lane < nb && k <= lane) ? A[tri_idx(j0 + lane, j0 + k)] : ((k == lane) ? 1.0 : 0.0);
+    double dinv[CH_NB];
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) {
+        double dcc = lane_bcast(x[c], c);
+        if (!(dcc > 0.0) || !isfinite(dcc)) {
+            ok = false;
+            dcc = 1.0;
+        }
+        const double dd = sqrt(dcc);
+        dinv[c] = 1.0 / dd;
+        x[c] = (lane == c) ? dd : x[c] * dinv[c];
+#pragma unroll
+        for (int k = c + 1; k < CH_NB; ++k) {
+            const double lkc = lane_bcast(x[c], k);   // L[k][c]
+            x[k] -= x[c] * lkc;                        // meaningful for lane >= k (lower triangle)
+        }
+    }
+    // column `lane` of L^-1 by forward substitution: xi[r] = Linv[r][lane]
+    double xi[CH_NB];
+#pragma unroll
+    for (int r = 0; r < CH_NB; ++r) {
+        double acc = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) acc -= lane_bcast(x[k], r) * xi[k];   // L[r][k] * Linv[k][lane]
+        xi[r] = (r < lane) ? 0.0 : acc * dinv[r];
+    }
+    if (lane < CH_NB) {
+#pragma unroll
+        for (int r = 0; r < CH_NB; ++r) Dinv[r][lane] = xi[r];
+#pragma unroll
+        for (int k = 0; k < CH_NB; ++k)
+            if (lane < nb && k <= lane) A[tri_idx(j0 + lane, j0 + k)] = x[k];
+    }
+    return ok;
+}
+
+// In-place blocked Cholesky of the packed lower triangle A (n x n): on success A holds L.  Rows n .. nrows-1
+// (nrows >= n, packed right behind the matrix) are carried along as right-hand sides: they end up holding
+// L^-1 rhs.  Dinv is a [CH_NB][CH_NB+1] LDS scratch block, s_fail an LDS flag.  All threads of the workgroup
+// must call.  Returns false (uniformly) if a non-positive pivot is met.
+__device__ __forceinline__ bool chol_blocked(double *A, int n, int nrows, double (*Dinv)[CH_NB + 1], int *s_fail,
                                              long long *prof = nullptr) {
-    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
 #ifdef XRHIP_KPROF
     long long t_prev = wall_clock64();
 #endif
@@ -51,83 +109,65 @@ __device__ __forceinline__ bool chol_blocked(double *A, int n, double (*D)[CH_NB
     __syncthreads();
     for (int j0 = 0; j0 < n; j0 += CH_NB) {
         const int nb = min(CH_NB, n - j0);
-        // ---- (1) diagonal block, wavefront 0
+        // ---- (1) diagonal block: factor + invert, wavefront 0, registers only
         if (wave == 0) {
-            for (int p = lane; p < CH_NB * CH_NB; p += 64) {
-                const int r = p >> 4, k = p & 15;
-                if (r < nb && k <= r) D[r][k] = A[tri_idx(j0 + r, j0 + k)];
-            }
-            wave_sync();
-            for (int c = 0; c < nb; ++c) {
-                const double dcc = D[c][c];
-                if (!(dcc > 0.0) || !isfinite(dcc)) {
-                    if (lane == 0) *s_fail = 1;
-                    break;
-                }
-                const double dd = sqrt(dcc);
-                if (lane > c && lane < nb) D[lane][c] = D[lane][c] / dd;
-                if (lane == c) D[c][c] = dd;
-                wave_sync();
-                for (int p = lane; p < CH_NB * CH_NB; p += 64) {
-                    const int r = p >> 4, k = p & 15;
-                    if (k > c && r >= k && r < nb) D[r][k] -= D[r][c] * D[k][c];
-                }
-                wave_sync();
-            }
-            for (int p = lane; p < CH_NB * CH_NB; p += 64) {
-                const int r = p >> 4, k = p & 15;
-                if (r < nb && k <= r) A[tri_idx(j0 + r, j0 + k)] = D[r][k];
-            }
+            if (!chol_diag_wave(A, j0, nb, Dinv, lane) && lane == 0) *s_fail = 1;
         }
         __syncthreads();
         CHPROF(0);
         if (*s_fail) return false;
         const int jb = j0 + nb;
-        if (jb >= n) break;
-        // ---- (2) panel solve: row i of the panel, x = A[i][j0..j0+nb) * Ldd^-T
-        for (int i = jb + tid; i < n; i += nt) {
-            double x[CH_NB];
-            double *row = A + tri_idx(i, j0);
+        if (jb >= nrows) break;
+        // ---- (2) panel: X = P Linv^T for the rows below the block, 16-row tiles on the matrix cores.
+        // A[i][k] from lane (i = lane & 15, k = lane >> 4), B[k][j] = Linv[j][k] from lane (k = lane >> 4, j = lane & 15).
+        {
+            const int T = (nrows - jb + 15) >> 4;
+            for (int t = wave; t < T; t += nw) {
+                const int gi = jb + 16 * t + r16;
+                const bool va = gi < nrows;
+                const double *pa = A + tri_idx(min(gi, nrows - 1), j0) + q;
+                chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) {
-                if (c < nb) {
-                    double s = row[c];
-                    for (int k = 0; k < c; ++k) s -= x[k] * D[c][k];
-                    x[c] = s / D[c][c];
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int kcol = 4 * s4 + q;
+                    const double av = (va && kcol < nb) ? pa[4 * s4] : 0.0;
+                    const double bv = Dinv[r16][kcol];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+                // D[(lane >> 4) + 4 r][lane & 15]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int oi = jb + 16 * t + q + 4 * r;
+                    if (oi < nrows && r16 < nb) A[tri_idx(oi, j0 + r16)] = acc[r];
                 }
             }
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c)
-                if (c < nb) row[c] = x[c];
         }
         __syncthreads();
         CHPROF(1);
-        // ---- (3) trailing update A22 -= P P^T (P = the freshly solved n-jb x 16 panel) on the f64 matrix cores:
-        // 16x16 output tiles of the lower triangle are dealt round-robin to the wavefronts; one tile = four
-        // v_mfma_f64_16x16x4_f64 (k = 16).  Operand layout: A[i][k] from lane (i = lane & 15, k = lane >> 4),
-        // B[k][j] from lane (k = lane >> 4, j = lane & 15), D[(lane >> 4) + 4 r][lane & 15] in register r.
+        // ---- (3) trailing update A22 -= P P^T: 16x16 tiles of the lower triangle (and of the rhs rows), one
+        // tile = four v_mfma_f64_16x16x4_f64 (k = 16)
         {
-            const int nw = nt >> 6, r16 = lane & 15, q = lane >> 4;
-            const int T = (n - jb + 15) >> 4;
+            const int T = (nrows - jb + 15) >> 4;
             int t = 0;
             for (int ti = 0; ti < T; ++ti)
                 for (int tj = 0; tj <= ti; ++tj, ++t) {
                     if (t % nw != wave) continue;
+                    if (jb + 16 * tj >= n) continue;   // rhs rows have no columns of their own
                     const int gi = jb + 16 * ti + r16, gk = jb + 16 * tj + r16;
-                    const double *pa = A + tri_idx(min(gi, n - 1), j0) + q;
+                    const double *pa = A + tri_idx(min(gi, nrows - 1), j0) + q;
                     const double *pb = A + tri_idx(min(gk, n - 1), j0) + q;
-                    const bool va = gi < n, vb = gk < n;
-                    typedef double d4 __attribute__((ext_vector_type(4)));
-                    d4 acc = {0.0, 0.0, 0.0, 0.0};
+                    const bool va = gi < nrows, vb = gk < n;
+                    chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
-                        const double av = va ? pa[4 * s4] : 0.0, bv = vb ? pb[4 * s4] : 0.0;
+                        const bool vk = 4 * s4 + q < nb;
+                        const double av = (va && vk) ? pa[4 * s4] : 0.0, bv = (vb && vk) ? pb[4 * s4] : 0.0;
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int oi = jb + 16 * ti + q + 4 * r, ok = jb + 16 * tj + r16;
-                        if (oi < n && ok <= oi) A[tri_idx(oi, ok)] -= acc[r];
+                        if (oi < nrows && ok < n && ok <= oi) A[tri_idx(oi, ok)] -= acc[r];
                     }
                 }
         }
@@ -137,46 +177,63 @@ __device__ __forceinline__ bool chol_blocked(double *A, int n, double (*D)[CH_NB
     return true;
 }
 
-// y <- L^-1 y  (forward) with L packed lower in A.  All threads must call.
+// y <- L^-1 y  (forward) with L packed lower in A.  All threads must call.  The 16x16 diagonal systems are
+// solved by wavefront 0 in registers (lane k owns row k of the block and y[j0 + k]).
 __device__ __forceinline__ void trsv_lower(const double *A, int n, double *y) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
     for (int j0 = 0; j0 < n; j0 += CH_NB) {
         const int nb = min(CH_NB, n - j0);
         if (wave == 0) {
-            for (int c = 0; c < nb; ++c) {
-                const double yc = y[j0 + c] / A[tri_idx(j0 + c, j0 + c)];
-                wave_sync();
-                if (lane == c) y[j0 + c] = yc;
-                if (lane > c && lane < nb) y[j0 + lane] -= A[tri_idx(j0 + lane, j0 + c)] * yc;
-                wave_sync();
+            double row[CH_NB], dl = 1.0;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) {
+                row[c] = (lane < nb && c <= lane) ? A[tri_idx(j0 + lane, j0 + c)] : ((c == lane) ? 1.0 : 0.0);
+                if (c == lane) dl = row[c];
             }
+            const double dinv = 1.0 / dl;
+            double r = (lane < nb) ? y[j0 + lane] : 0.0;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) {
+                const double xc = lane_bcast(r, c) * lane_bcast(dinv, c);
+                if (lane == c) r = xc;
+                else if (lane > c) r -= row[c] * xc;
+            }
+            if (lane < nb) y[j0 + lane] = r;
         }
         __syncthreads();
         const int jb = j0 + nb;
         for (int i = jb + tid; i < n; i += nt) {
-            const double *row = A + tri_idx(i, j0);
+            const double *rowp = A + tri_idx(i, j0);
             double s = 0;
-            for (int c = 0; c < nb; ++c) s += row[c] * y[j0 + c];
+            for (int c = 0; c < nb; ++c) s += rowp[c] * y[j0 + c];
             y[i] -= s;
         }
         __syncthreads();
     }
 }
 
-// y <- L^-T y  (backward).  All threads must call.
+// y <- L^-T y  (backward).  All threads must call.  Lane k of wavefront 0 owns column k of the diagonal block.
 __device__ __forceinline__ void trsv_lower_t(const double *A, int n, double *y) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int last = ((n - 1) / CH_NB) * CH_NB;
     for (int j0 = last; j0 >= 0; j0 -= CH_NB) {
         const int nb = min(CH_NB, n - j0);
         if (wave == 0) {
-            for (int c = nb - 1; c >= 0; --c) {
-                const double yc = y[j0 + c] / A[tri_idx(j0 + c, j0 + c)];
-                wave_sync();
-                if (lane == c) y[j0 + c] = yc;
-                if (lane < c) y[j0 + lane] -= A[tri_idx(j0 + c, j0 + lane)] * yc;
-                wave_sync();
+            double col[CH_NB], dl = 1.0;   // col[c] = L[j0 + c][j0 + lane], c >= lane
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) {
+                col[c] = (c < nb && lane <= c) ? A[tri_idx(j0 + c, j0 + lane)] : ((c == lane) ? 1.0 : 0.0);
+                if (c == lane) dl = col[c];
             }
+            const double dinv = 1.0 / dl;
+            double r = (lane < nb) ? y[j0 + lane] : 0.0;
+#pragma unroll
+            for (int c = CH_NB - 1; c >= 0; --c) {
+                const double xc = lane_bcast(r, c) * lane_bcast(dinv, c);
+                if (lane == c) r = xc;
+                else if (lane < c) r -= col[c] * xc;
+            }
+            if (lane < nb) y[j0 + lane] = r;
         }
         __syncthreads();
         for (int i = tid; i < j0; i += nt) {

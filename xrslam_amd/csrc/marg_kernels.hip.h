@@ -362,7 +362,7 @@ __global__ __launch_bounds__(512) void km_chol(const int *__restrict__ sup_n, in
         if (j <= i) Lp[tri_idx(i, j)] = A[e];
     }
     __syncthreads();
-    if (!chol_blocked(Lp, R, Dblk, &fail)) {
+    if (!chol_blocked(Lp, R, R, Dblk, &fail)) {
         if (tid == 0) status[2] = 1;
         return;
     }
