@@ -174,6 +174,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     d.na = (int)act_idx.size();
     d.nla = 0;
     for (int l = 0; l < L; ++l) d.nla += lact[l] ? 1 : 0;
+    d.lm_rows = d.Lp;   // xrhip_ba_solve drops the landmark rows when no landmark is free
     std::vector<int> imuf(2 * F, -1), priorf(F, -1);
     for (int k = 0; k < NI; ++k) {
         if (imuf[2 * P->imu_j[k]] >= 0 || imuf[2 * P->imu_i[k] + 1] >= 0)
@@ -345,7 +346,7 @@ static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, cons
     hipStream_t s = c->stream;
     hipLaunchKernelGGL(kb_lin_all, dim3(lin_all_blocks(d.M, d.MR, d.NI)), dim3(256), sizeof(double) * std::max(d.np, 1), s, d, p,
                        cam, imu, sx, sy);
-    hipLaunchKernelGGL(kb_landmark_vision, dim3(d.Lp + d.F * d.F), dim3(64), 0, s, d, p);
+    hipLaunchKernelGGL(kb_landmark_vision, dim3(d.lm_rows + d.F * d.F), dim3(64), 0, s, d, p);
     hipLaunchKernelGGL(kb_assemble, dim3((d.n * d.n + 255) / 256), dim3(256), 0, s, d, p);
     if (for_solver) hipLaunchKernelGGL(kb_cost_prepare, dim3(1), dim3(256), 0, s, d, p);
     else hipLaunchKernelGGL(kb_sum_cost, dim3(1), dim3(256), 0, s, d, p);
@@ -373,7 +374,9 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
     hipStream_t s = c->stream;
     if (prepare) hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);
     const int tiles = d.PF / 16;
-    hipLaunchKernelGGL(kb_schur_aux, dim3(tiles * tiles + aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64), dim3(256), 0, s, d, p);
+    hipLaunchKernelGGL(kb_schur_aux, dim3(d.nla ? tiles * tiles + aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64
+                                                : aux_quad_blocks_n(d.n, d.L)),
+                       dim3(256), 0, s, d, p);
     size_t lds = 0;
     int use_lds = 1;
     int rcl = solve_lds(d, (size_t)c->lds_limit, &lds, &use_lds);
@@ -534,6 +537,7 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     }
     if (rc) return rc;
     HostProfScope hp_rounds(9, "ba_solve: rounds (launch+wait)");
+    if (!d.nla) d.lm_rows = 0;
     const double sx = P->sqrt_inv_cov[0], sy = P->sqrt_inv_cov[1];
     hipStream_t s = c->stream;
     if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);

@@ -73,7 +73,8 @@ struct BaDims {
     int NV;             // n + L
     int robust;         // 1: CauchyLoss(1) on visual factors (Solver); 0: none (marginalisation)
     int na;             // number of free frame dofs (size of the reduced system actually factored)
-    int nla;            // number of free landmarks (0: no Schur complement, kb_mono skips the landmark phases)
+    int nla;            // number of free landmarks (0: no Schur complement)
+    int lm_rows;        // landmark rows kb_landmark_vision builds: Lp, or 0 when the solver has no free landmark
 };
 
 struct BaPtrs {
@@ -780,8 +781,9 @@ __device__ __forceinline__ void solve_aux_block(const BaDims &d, const BaPtrs &p
     }
 }
 // Schur tiles and the solve's auxiliary passes in one launch: [tiles^2 | aux blocks]
+// (without free landmarks there is no Schur complement and no W^T (omega gl): only the quadratic-form blocks run)
 __global__ __launch_bounds__(256) void kb_schur_aux(BaDims d, BaPtrs p) {
-    const int t2 = (d.PF / 16) * (d.PF / 16);
+    const int t2 = d.nla ? (d.PF / 16) * (d.PF / 16) : 0;
     if ((int)blockIdx.x < t2) schur_tile_block(d, p, blockIdx.x);
     else solve_aux_block(d, p, (int)blockIdx.x - t2);
 }
@@ -1419,9 +1421,11 @@ __global__ __launch_bounds__(256) void kb_lin_all(BaDims d, BaPtrs p, Ext cam, E
 __host__ __device__ __forceinline__ int lin_all_blocks(int M, int MR, int NI) { return (M + 255) / 256 + (MR + 255) / 256 + (NI + 3) / 4 + 1; }
 
 // per-landmark rows and per-frame-pair reprojection blocks: [Lp landmarks | F*F pairs], one wavefront each
+// (no landmark rows are needed when every landmark is constant: nla == 0)
 __global__ __launch_bounds__(64) void kb_landmark_vision(BaDims d, BaPtrs p) {
-    if ((int)blockIdx.x < d.Lp) landmark_item(d, p, blockIdx.x, threadIdx.x);
-    else assemble_vision_item(d, p, blockIdx.x - d.Lp, threadIdx.x);
+    const int lp = d.lm_rows;
+    if ((int)blockIdx.x < lp) landmark_item(d, p, blockIdx.x, threadIdx.x);
+    else assemble_vision_item(d, p, blockIdx.x - lp, threadIdx.x);
 }
 
 // total cost, gradient max-norm and the per-solve preparation, one workgroup
