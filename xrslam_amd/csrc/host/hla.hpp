@@ -132,6 +132,12 @@ inline void jacobi_svd(const Dense &A_in, std::vector<double> &s, Dense &V, Dens
     Dense A = A_in;
     V = Dense(n, n);
     for (int i = 0; i < n; ++i) V(i, i) = 1.0;
+    double fro2 = 0.0;
+    for (double v : A.a) fro2 += v * v;
+    // a column whose norm has dropped below 1e-15 |A|_F is a converged null-space direction: rotating it further
+    // only chases rounding noise (rank-deficient inputs -- the 5x9 epipolar system, a 2-point covariance -- would
+    // otherwise burn every sweep on such columns)
+    const double null2 = 1e-30 * fro2;
     for (int sweep = 0; sweep < 60; ++sweep) {
         bool rotated = false;
         for (int p = 0; p < n - 1; ++p)
@@ -142,7 +148,7 @@ inline void jacobi_svd(const Dense &A_in, std::vector<double> &s, Dense &V, Dens
                     be += A(i, q) * A(i, q);
                     ga += A(i, p) * A(i, q);
                 }
-                if (ga == 0.0 || std::fabs(ga) <= 1e-16 * std::sqrt(al * be)) continue;
+                if (ga == 0.0 || std::fabs(ga) <= 1e-16 * std::sqrt(al * be) || std::min(al, be) <= null2) continue;
                 rotated = true;
                 double zeta = (be - al) / (2.0 * ga);
                 double t = 1.0 / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
