@@ -425,7 +425,7 @@ constexpr int PI_CHUNK = 32;
 
 __global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restrict__ jobs,
                                                       const double *__restrict__ samples,
-                                                      const double *__restrict__ noise36, int want_jac, int want_cov,
+                                                      const double *__restrict__ noise_host, int want_jac, int want_cov,
                                                       double *__restrict__ out, int *__restrict__ status) {
     __shared__ double cov[15][15], Tm[9][9], inv[15][15];
     __shared__ double Jac[5][9], Jnew[5][9];   // dq_dbg, dp_dbg, dp_dba, dv_dbg, dv_dba
@@ -433,9 +433,11 @@ __global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restric
     __shared__ double sE[PI_CHUNK][9], sJr[PI_CHUNK][9], sR[PI_CHUNK][9], sRa[PI_CHUNK][9];
     __shared__ double sEq[PI_CHUNK][4], sQ[PI_CHUNK][4], sQa[PI_CHUNK][3], sDt[PI_CHUNK];
     __shared__ double sq[4], sp3[3], sv3[3], sdt;
-    __shared__ int s_piv, s_bad;
+    __shared__ double Dinv[CH_NB][CH_NB + 1];
+    __shared__ double noise36[36];   // the inputs live in pinned host memory: fetch each of them exactly once
     const PreintJob job = jobs[blockIdx.x];
     const int tid = threadIdx.x;
+    if (tid < 36) noise36[tid] = noise_host[tid];
     double *o = out + (size_t)blockIdx.x * XRHIP_IMU_DIM;
     for (int e = tid; e < 225; e += 64) cov[e / 15][e % 15] = 0.0;
     if (tid < 45) Jac[tid / 9][tid % 9] = 0.0;
@@ -554,10 +556,14 @@ __global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restric
             for (int n = 0; n < nc; ++n) {
                 const double h = sDt[n];
                 if (want_cov) {
+                    // Tm = A cov with A = [E 0 0; P I dt I; V 0 I] (3x3 blocks): three products with the rotation
+                    // rows of cov plus the identity / dt terms, in the order of the dense row sum
                     for (int e = tid; e < 81; e += 64) {
                         const int i = e / 9, j = e - 9 * i;
-                        double s2 = 0;
-                        for (int k = 0; k < 9; ++k) s2 += sA[n][9 * i + k] * cov[k][j];
+                        const double *a = sA[n] + 9 * i;
+                        double s2 = (a[0] * cov[0][j] + a[1] * cov[1][j]) + a[2] * cov[2][j];
+                        if (i >= 3 && i < 6) s2 = (s2 + cov[i][j]) + h * cov[i + 3][j];
+                        else if (i >= 6) s2 = s2 + cov[i][j];
                         Tm[i][j] = s2;
                     }
                     if (tid >= 46) {
@@ -582,13 +588,21 @@ __global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restric
                     Jnew[m][3 * i + j] = v;
                 }
                 __syncthreads();
-                if (want_cov)
-                    for (int e = tid; e < 81; e += 64) {
-                        const int i = e / 9, j = e - 9 * i;
-                        double s2 = 0;
-                        for (int k = 0; k < 9; ++k) s2 += Tm[i][k] * sA[n][9 * j + k];
-                        cov[i][j] = s2 + sG[n][9 * i + j];
+                if (want_cov && tid < 45) {
+                    // cov = Tm A^T + G, lower triangle only (one entry per lane), mirrored
+                    int i = 0, j = tid;
+                    while (j > i) {   // tid -> (i, j <= i) of the 9x9 lower triangle
+                        j -= i + 1;
+                        ++i;
                     }
+                    const double *a = sA[n] + 9 * j;   // row j of A
+                    double s2 = (Tm[i][0] * a[0] + Tm[i][1] * a[1]) + Tm[i][2] * a[2];
+                    if (j >= 3 && j < 6) s2 = (s2 + Tm[i][j]) + Tm[i][j + 3] * h;
+                    else if (j >= 6) s2 = s2 + Tm[i][j];
+                    s2 += sG[n][9 * i + j];
+                    cov[i][j] = s2;
+                    cov[j][i] = s2;
+                }
                 if (want_jac && tid < 45) Jac[tid / 9][tid % 9] = Jnew[tid / 9][tid % 9];
                 __syncthreads();
             }
@@ -612,33 +626,31 @@ __global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restric
         const int e = tid - 46, blk = e / 9, r = e - 9 * blk;
         cov[9 + 3 * blk + r / 3][9 + 3 * blk + r % 3] = walk;
     }
-    // sqrt_inv_cov = LLT(cov^-1).matrixL().transpose()
+    // sqrt_inv_cov = LLT(cov^-1).matrixL().transpose().  With J the index reversal and J cov J = Lr Lr^T,
+    // cov^-1 = (J Lr^-T J)(J Lr^-1 J) and J Lr^-T J is lower triangular with a positive diagonal, i.e. it IS that
+    // Cholesky factor: sqrt_inv_cov = J Lr^-1 J.  One register-resident 15x15 factorisation + triangular inverse
+    // (chol_diag_wave) instead of a pivoted Gauss-Jordan inverse followed by a Cholesky.
     __syncthreads();
-    if (!inv15_block(cov, inv, &s_piv, &s_bad)) {
-        if (tid == 0) status[blockIdx.x] = 2;
+    double *Pr = &inv[0][0];   // packed lower triangle of J cov J
+    for (int e = tid; e < 120; e += 64) {
+        int i = 0, j = e;
+        while (j > i) {
+            j -= i + 1;
+            ++i;
+        }
+        Pr[tri_idx(i, j)] = cov[14 - i][14 - j];
+    }
+    __syncthreads();
+    const bool pd = chol_diag_wave(Pr, 0, 15, Dinv, tid);
+    __syncthreads();
+    if (!pd) {
+        if (tid == 0) status[blockIdx.x] = 3;
         return;
     }
-    // Cholesky of inv (lower) in place into cov (reused as L)
-    for (int e = tid; e < 225; e += 64) cov[e / 15][e % 15] = 0.0;
-    __syncthreads();
-    for (int j = 0; j < 15; ++j) {
-        if (tid < 15 && tid >= j) {
-            const int i = tid;
-            double s2 = inv[i][j];
-            for (int k = 0; k < j; ++k) s2 -= cov[i][k] * cov[j][k];
-            inv[i][j] = s2;   // column j updated in place
-        }
-        __syncthreads();
-        const double djj = inv[j][j];
-        if (!(djj > 0.0)) {
-            if (tid == 0) status[blockIdx.x] = 3;
-            return;
-        }
-        const double dj = sqrt(djj);
-        if (tid < 15 && tid >= j) cov[tid][j] = (tid == j) ? dj : inv[tid][j] / dj;
-        __syncthreads();
+    for (int e = tid; e < 225; e += 64) {
+        const int i = e / 15, j = e - 15 * i;
+        o[56 + e] = (j >= i) ? Dinv[14 - i][14 - j] : 0.0;   // upper triangular, row-major
     }
-    for (int e = tid; e < 225; e += 64) o[56 + e] = cov[e % 15][e / 15];   // L^T, row-major
 }
 
 }   // namespace xrhip
