@@ -1119,6 +1119,8 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
             const double rk = radius * (1.0 / (double)(1 << k));   // exact
             ca[k] = 0.0;
             cb[k] = 0.0;
+            step_norm[k] = 0.0;
+            if (k >= B) continue;
             if (gn_norm <= rk) {
                 cb[k] = 1.0;
                 step_norm[k] = gn_norm;
@@ -1126,11 +1128,12 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
                 ca[k] = -(rk / gnorm);
                 step_norm[k] = rk;
             } else {
+                // (DoglegStrategy::ComputeTraditionalDoglegStep writes these squares as pow(x, 2.0))
                 const double b_dot_a = -alpha * gd;
-                const double a_sq = pow(alpha * gnorm, 2.0);
-                const double bma_sq = a_sq - 2 * b_dot_a + pow(gn_norm, 2);
+                const double a_sq = (alpha * gnorm) * (alpha * gnorm);
+                const double bma_sq = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
                 const double cc = b_dot_a - a_sq;
-                const double dd = sqrt(cc * cc + bma_sq * (pow(rk, 2.0) - a_sq));
+                const double dd = sqrt(cc * cc + bma_sq * (rk * rk - a_sq));
                 const double beta = (cc <= 0) ? (dd - cc) / bma_sq : (rk * rk - a_sq) / (dd + cc);
                 ca[k] = -alpha * (1.0 - beta);
                 cb[k] = beta;
@@ -1153,7 +1156,14 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
                     p.delta[(size_t)k * d.NV + a] = st * sc;
                 }
         }
-        block_sum_n<2 * TRY_B>(red2, scratch);
+        if (B == 1) {
+            double r1[2] = {red2[0], red2[1]};
+            block_sum_n<2>(r1, scratch);
+            red2[0] = r1[0];
+            red2[1] = r1[1];
+        } else {
+            block_sum_n<2 * TRY_B>(red2, scratch);
+        }
         double model_cost_change[TRY_B];
 #pragma unroll
         for (int k = 0; k < TRY_B; ++k) {
@@ -1280,7 +1290,14 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
             for (int q = 0; q < TRY_B; ++q)
                 if (q == k) red[2 * q + 1] += df * df;
         }
-        block_sum_n<2 * TRY_B>(red, scratch);
+        if (B == 1) {
+            double r1[2] = {red[0], red[1]};
+            block_sum_n<2>(r1, scratch);
+            red[0] = r1[0];
+            red[1] = r1[1];
+        } else {
+            block_sum_n<2 * TRY_B>(red, scratch);
+        }
         KPROF(18);
         // ---- replay the decisions in order (uniform across the workgroup)
         int accepted = -1;
