@@ -81,6 +81,10 @@ int xrhip_image_release(xrhip_image *img);
  * (xrslam.h:155-157, opencv_image.cpp:38-73).  `existing_xy` = n_exist (x,y)
  * doubles already tracked; new points are written to out_xy (capacity
  * max_points pairs) and *n_out.  Synchronous (returns host data). */
+/* Optional hint: xrhip_image_detect will be called on `img`.  Its Harris pass (which does not depend on the
+ * tracking result) is then queued right behind the next xrhip_image_track launch that has `img` as its target,
+ * so that it runs while the host digests the tracks.  Without the hint detect() launches the pass itself. */
+int xrhip_image_prefetch_detect(xrhip_image *img);
 int xrhip_image_detect(xrhip_image *img, const double *existing_xy, int n_exist, int max_points,
                        double min_distance, double *out_xy, int *n_out);
 

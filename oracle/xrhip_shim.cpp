@@ -91,6 +91,7 @@ int xrhip_image_release(xrhip_image *im) {
     im->have_raw = im->have_pyr = false;
     return 0;
 }
+int xrhip_image_prefetch_detect(xrhip_image *) { return 0; }
 int xrhip_image_detect(xrhip_image *im, const double *existing, int n_exist, int max_points, double min_dist,
                        double *out_xy, int *n_out) {
     if (!im->have_pyr) {

@@ -1172,6 +1172,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
                 }
             }
             P.integrate(frame->preintegration, frame->image->t, last->motion.bg, last->motion.ba, false, false);
+            if (swt_tag) hip_check(xrhip_image_prefetch_detect(frame->image->h), "xrhip_image_prefetch_detect");
             frame_track_keypoints(P, last, frame.get());
             if (is_initialized) {
                 predict(frame->preintegration, last, frame.get());

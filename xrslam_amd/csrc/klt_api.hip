@@ -77,6 +77,8 @@ struct xrhip_image {
     uint8_t *raw = nullptr;    // w*h, unpadded upload target (CLAHE input)
     bool have_raw = false;
     bool have_pyramid = false;
+    bool want_detect = false;   // xrhip_image_prefetch_detect: queue the Harris pass behind the next tracking launch
+    int detect_seq = 0;         // != 0: the Harris pass of this image is in flight / done under that sequence number
     LevelBuf lv[KLT_LEVELS];
 };
 
@@ -273,6 +275,8 @@ int xrhip_image_upload(xrhip_image *im, const uint8_t *gray, int stride) {
     XR_HIP(hipStreamSynchronize(c->stream));
     im->have_raw = true;
     im->have_pyramid = false;
+    im->want_detect = false;
+    im->detect_seq = 0;
     return XRHIP_OK;
 }
 
@@ -282,6 +286,8 @@ int xrhip_image_upload_device(xrhip_image *im, const void *gray_dev, int stride)
     XR_HIP(hipMemcpy2DAsync(im->raw, c->w, gray_dev, stride, c->w, c->h, hipMemcpyDeviceToDevice, c->stream));
     im->have_raw = true;
     im->have_pyramid = false;
+    im->want_detect = false;
+    im->detect_seq = 0;
     return XRHIP_OK;
 }
 
@@ -364,22 +370,17 @@ static int run_harris(xrhip_image *im) {
     return XRHIP_OK;
 }
 
-int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, int max_points, double min_distance,
-                       double *out_xy, int *n_out) {
-    if (!im || !out_xy || !n_out || n_exist < 0 || (n_exist > 0 && !existing_xy))
-        return xr_fail(XRHIP_EINVAL, "xrhip_image_detect: bad arguments");
-    if (!im->have_pyramid) return xr_fail(XRHIP_ESTATE, "xrhip_image_detect: preprocess() has not run");
+// Harris response, NMS and strongest-candidate selection of `im`, asynchronous; results land in the pinned top
+// block / header under a fresh sequence number (one detection in flight per context)
+static int launch_detect(xrhip_image *im) {
     xrhip_klt *c = im->ctx;
     const int w = c->w, h = c->h;
     ProfScope prof(c, CAT_DETECT);
-    HostProfScope hp_all(0, "detect: whole call");
-    HostProfScope *hp_gpu = new HostProfScope(1, "detect: launch+D2H waits");
     int rc = run_harris(im);
     if (rc) return rc;
     hipLaunchKernelGGL(k_harris_nms, dim3((w + 63) / 64, (h + 15) / 16), dim3(256), 0, c->stream, c->resp, w, h,
                        c->max_key, 1.0e-3, c->cand, c->cand_count, c->cand_cap);
     XR_HIP(hipGetLastError());
-    // the strongest candidates + header arrive in pinned memory without a copy; spin on the sequence number
     HarrisCand *d_top = nullptr;
     SelectHeader *d_sel = nullptr;
     XR_HIP(hipHostGetDevicePointer((void **)&d_top, c->h_top, 0));
@@ -389,6 +390,32 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
                        1.0e-3, d_top, c->top_cap, d_sel, seq);
     XR_HIP(hipGetLastError());
     prof.finish();
+    im->detect_seq = seq;
+    return XRHIP_OK;
+}
+
+int xrhip_image_prefetch_detect(xrhip_image *im) {
+    if (!im) return xr_fail(XRHIP_EINVAL, "xrhip_image_prefetch_detect: null image");
+    im->want_detect = true;
+    return XRHIP_OK;
+}
+
+int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, int max_points, double min_distance,
+                       double *out_xy, int *n_out) {
+    if (!im || !out_xy || !n_out || n_exist < 0 || (n_exist > 0 && !existing_xy))
+        return xr_fail(XRHIP_EINVAL, "xrhip_image_detect: bad arguments");
+    if (!im->have_pyramid) return xr_fail(XRHIP_ESTATE, "xrhip_image_detect: preprocess() has not run");
+    xrhip_klt *c = im->ctx;
+    const int w = c->w, h = c->h;
+    HostProfScope hp_all(0, "detect: whole call");
+    HostProfScope *hp_gpu = new HostProfScope(1, "detect: launch+D2H waits");
+    if (!im->detect_seq) {
+        int rc = launch_detect(im);
+        if (rc) return rc;
+    }
+    const int seq = im->detect_seq;
+    im->detect_seq = 0;
+    im->want_detect = false;
     {
         volatile int *flag = &c->h_sel->seq;
         for (unsigned long spin = 1; *flag != seq; ++spin)
@@ -491,6 +518,12 @@ int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const dou
     XR_HIP(hipGetLastError());
     prof.finish();
     c->stats.lk_points += n;
+    // the Harris pass of `next` does not depend on the tracking result: queue it now so that it runs while the host
+    // digests the tracks (the wait below is on the tracking kernel's own mailbox, not on the stream)
+    if (next->want_detect && !next->detect_seq) {
+        rc = launch_detect(const_cast<xrhip_image *>(next));
+        if (rc) return rc;
+    }
     {
         volatile int *flag = c->h_trk_seq;
         for (unsigned long spin = 1; *flag != seq; ++spin)
