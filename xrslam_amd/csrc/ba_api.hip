@@ -261,7 +261,14 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     if (rc) return rc;
     for (const Item &it : items)
         if (it.bytes) std::memcpy(A.host + it.off, it.src, it.bytes);
-    XR_HIP(hipMemcpyAsync(A.dev, A.host, in_bytes, hipMemcpyHostToDevice, c->stream));
+    {
+        char *host_dev = nullptr;   // device-visible address of the pinned staging block
+        XR_HIP(hipHostGetDevicePointer((void **)&host_dev, A.host, 0));
+        const size_t n16 = (in_bytes + 15) / 16;
+        const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 128);
+        hipLaunchKernelGGL(kb_stage, dim3(blocks), dim3(256), 0, c->stream, (const uint4 *)host_dev, (uint4 *)A.dev, n16);
+        XR_HIP(hipGetLastError());
+    }
 
     char *I = A.dev, *W = c->work;
     p.state = (double *)(I + o_state);

@@ -1463,4 +1463,11 @@ __global__ __launch_bounds__(512) void kb_solve_try(BaDims d, BaPtrs p, Ext cam,
     try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, true, lds);
 }
 
+// The staged problem (a few tens of KB) is pulled from the pinned host arena by the device itself, 16 bytes per
+// lane: a kernel in the solve's own stream starts within a few microseconds, where a copy-engine transfer adds
+// its scheduling latency in front of the first linearisation.
+__global__ __launch_bounds__(256) void kb_stage(const uint4 *__restrict__ src_host, uint4 *__restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src_host[i];
+}
+
 }   // namespace xrhip
