@@ -1,7 +1,7 @@
 // ba_api.hip -- C ABI of the bundle adjustment (include/xrslam_hip.h, plug point #2).
 // Host side of xrslam::Solver for gfx950: packs the factor graph into one device arena,
 // builds the gather indices, and drives the kernel sequence of ba_kernels.hip.h.  The
-// trust-region trial loop runs on the device (kb_try); the host only intervenes when a new
+// trust-region trial loop runs on the device (kb_solve_try); the host only intervenes when a new
 // linearisation or a re-solve of the linear system is needed.
 #include "../../include/xrslam_hip.h"
 #include "ba_kernels.hip.h"
@@ -42,8 +42,8 @@ struct xrhip_ba {
     size_t work2_cap = 0;
     char *h_stage = nullptr;   // pinned staging for work2 transfers
     size_t h_stage_cap = 0;
-    BaCtl *h_ctl = nullptr;   // pinned; doubles as the zero-copy mailbox of kb_try
-    int *h_seq = nullptr;     // pinned; sequence number published by kb_try after h_ctl / h_out
+    BaCtl *h_ctl = nullptr;   // pinned; doubles as the zero-copy mailbox of kb_solve_try
+    int *h_seq = nullptr;     // pinned; sequence number published by kb_solve_try after h_ctl / h_out
     int seq = 0;
     // optional HIP-event profiling of kb_solve_try
     bool profiling = false;
@@ -256,6 +256,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     const size_t w_dD = carve(D8 * d.NV), w_gr = carve(D8 * d.NV), w_gn = carve(D8 * d.NV), w_gs = carve(D8 * d.NV);
     const size_t w_st = carve(D8 * d.NV), w_de = carve(D8 * d.NV * TRY_B), w_part = carve(D8 * (size_t)(aux_quad_blocks_n(d.n, std::max(d.L, 1)) + 8));
     const size_t w_wog = carve(D8 * d.PF);
+    const size_t w_wide = carve(D8 * WIDE_G * 4 * WIDE_B);
     const size_t w_Hv = carve(D8 * 36 * (size_t)F * F), w_gv = carve(D8 * 6 * F);
     int rc = ensure_arena(c, in_bytes, w + 256, (size_t)16 * F + L + 8);
     if (rc) return rc;
@@ -336,6 +337,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     p.delta = (double *)(W + w_de);
     p.partial = (double *)(W + w_part);
     p.wog = (double *)(W + w_wog);
+    p.wide_part = (double *)(W + w_wide);
     p.ctl = (BaCtl *)(I + o_ctl);
     XR_HIP(hipHostGetDevicePointer((void **)&p.host_ctl, c->h_ctl, 0));
     XR_HIP(hipHostGetDevicePointer((void **)&p.host_out, c->h_out, 0));
@@ -375,6 +377,10 @@ static int solve_lds(const BaDims &d, size_t limit, size_t *bytes, int *use_lds)
     return XRHIP_OK;
 }
 
+// Large problems hand a run of rejected trials to kb_trials_wide (the whole chip costs 8 candidates per launch);
+// for small ones the round trip would cost more than looping inside kb_solve_try.
+static bool wide_trials(const BaDims &d) { return d.M >= 256 && d.F <= 32; }
+
 // reduced-system solve + trust-region trials: 2 launches (3 when mu changed without a new linearisation)
 static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
                             double sy, bool prepare, int mode, int seq) {
@@ -401,7 +407,8 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
         }
         XR_HIP(hipEventRecord(e0, s));
     }
-    hipLaunchKernelGGL(kb_solve_try, dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq);
+    hipLaunchKernelGGL(kb_solve_try, dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
+                       wide_trials(d) ? 1 : 0);
     XR_HIP(hipGetLastError());
     if (c->profiling) {
         XR_HIP(hipEventRecord(e1, s));
@@ -413,7 +420,7 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
     return XRHIP_OK;
 }
 
-// Spin on the sequence number kb_try stores (system-scope release) after its results: completion is seen a
+// Spin on the sequence number kb_solve_try stores (system-scope release) after its results: completion is seen a
 // few microseconds after the kernel's last store, where a blocking hipStreamSynchronize costs 20-30 us.
 // hipStreamQuery is polled now and then so that a faulted kernel turns into an error instead of a hang.
 static int wait_mailbox(xrhip_ba *c, int seq) {
@@ -463,7 +470,7 @@ int xrhip_ba_get_stats(xrhip_ba *c, xrhip_ba_stats *out, int reset) {
     return XRHIP_OK;
 }
 
-/* development aid: in-kernel phase timers of kb_solve / kb_try accumulated over all solves of the process,
+/* development aid: in-kernel phase timers of kb_solve_try accumulated over all solves of the process,
  * in 100 MHz ticks; only instrumented builds (build.sh -DXRHIP_KPROF) write them */
 void xrhip_debug_kprof(long long *out32, int reset) {
     for (int i = 0; i < 32; ++i) {
@@ -564,7 +571,19 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
             c->stats.n_trials += trials;
             if (c->profiling && !c->pending.empty()) c->pending.back().iter_before = trials;
         }
-        const int st = c->h_ctl->status;
+        int st = c->h_ctl->status;
+        for (int wguard = 0; st == ST_NEED_TRIALS && wguard < 64; ++wguard) {   // run of rejected trials, 8 per launch
+            const int wseq = ++c->seq;
+            const size_t wlds = sizeof(double) * (size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np);
+            hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, s, d, p, cam, imu, sx, sy, wseq);
+            XR_HIP(hipGetLastError());
+            rc = wait_mailbox(c, wseq);
+            if (rc) return rc;
+            const int it_now = c->h_ctl->iteration;
+            c->stats.n_trials += std::max(0, it_now - iter_seen);
+            iter_seen = it_now;
+            st = c->h_ctl->status;
+        }
         if (st == ST_DONE) {
             done = true;   // the optimised states are already in h_out
         } else if (st == ST_ACCEPTED) {

@@ -5,14 +5,14 @@
 // evaluation of the factor set, CauchyLoss correction, Jacobi scaling, Schur elimination of
 // the inverse-depth blocks, the reduced-system Cholesky and the traditional dogleg loop.
 //
-// Data flow per linearisation (all f64, everything stays in HBM/L2 between kernels):
-//   kb_lin_obs / kb_lin_rot / kb_lin_imu / kb_lin_prior   per-factor residuals + Jacobians
-//   kb_landmark     per-landmark (one wavefront each): H_ll, g_l and the dense cross-term row W_l
-//   kb_assemble     deterministic gather of all factor blocks into the (15F)^2 frame Hessian
-//   kb_prepare      Jacobi scales, dogleg diagonal, landmark Schur weights
-//   kb_schur_mfma   T = W^T diag(omega) W on the f64 matrix cores (v_mfma_f64_16x16x4_f64)
-//   kb_solve        reduced system, LDS-resident packed Cholesky, Gauss-Newton + Cauchy data
-//   kb_try          trust-region trials (dogleg point, candidate cost, accept/reject) on-device
+// Launches of one trust-region round (all f64, everything stays in HBM/L2 between kernels):
+//   kb_lin_all           per-factor residuals + Jacobians of all four factor families
+//   kb_landmark_vision   per-landmark H_ll, g_l, dense cross-term row W_l; per-frame-pair reprojection blocks
+//   kb_assemble          deterministic gather of all factor blocks into the (15F)^2 frame Hessian
+//   kb_cost_prepare      cost, gradient norm, Jacobi scales, dogleg diagonal, landmark Schur weights
+//   kb_schur_aux         T = W^T diag(omega) W on the f64 matrix cores + the solve's wide auxiliary passes
+//   kb_solve_try         reduced system, LDS-resident blocked Cholesky, dogleg data, trust-region trials
+// The bodies are __device__ functions (..._item: one thread / wavefront per item, ..._block: one workgroup).
 // Summation orders are fixed (no floating-point atomics), so results are run-to-run identical.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -25,7 +25,9 @@ namespace xrhip {
 
 constexpr int OREC = 28;   // per-observation record: Jt(12) Jr(12) jl(2) r(2), robustified
 constexpr int RREC = 8;
-constexpr int TRY_B = 4;   // trust-region trials costed per sweep after a rejection
+constexpr int TRY_B = 4;   // trust-region trials costed per sweep after a rejection (inside kb_solve_try)
+constexpr int WIDE_B = 8;  // ... per kb_trials_wide launch
+constexpr int WIDE_G = 32; // workgroups of kb_trials_wide
 constexpr int QF_ROWS = 8; // landmark rows a wavefront keeps in flight in the back-substitution
 
 struct BaCtl {   // device-resident solver state (one per context)
@@ -33,7 +35,8 @@ struct BaCtl {   // device-resident solver state (one per context)
     double x_cost, cand_cost, minimum_cost;
     double x_norm, gmax, alpha, step_norm;
     double model_cost_change, initial_cost;
-    double q_gg, q_gn, q_nn;   // J-quadratic forms of the scaled gradient / Gauss-Newton directions (see quad_forms)
+    double q_gg, q_gn, q_nn;   // J-quadratic forms of the scaled gradient / Gauss-Newton directions (see kb_schur_aux)
+    double gnorm, gn_norm, gd; // |grad|, |gn|, grad.gn of the current linearisation (kept for kb_trials_wide)
     int iteration, successful_steps, invalid_steps;
     int reuse;          // DoglegStrategy::reuse_
     int status;         // ST_* below
@@ -41,7 +44,7 @@ struct BaCtl {   // device-resident solver state (one per context)
     int linear_ok;      // result of the last kb_solve
     int first;          // first linearisation of this solve (Jacobi scales are frozen afterwards)
     int max_iterations;
-    int pad;
+    unsigned wide_ticket;   // blocks of the running kb_trials_wide launch that have delivered their partial sums
     long long prof[32];   // accumulated 100 MHz ticks per kernel phase (only written by -DXRHIP_KPROF builds)
 };
 #ifdef XRHIP_KPROF
@@ -63,7 +66,7 @@ struct BaCtl {   // device-resident solver state (one per context)
     do {            \
     } while (0)
 #endif
-enum { ST_RUNNING = 0, ST_ACCEPTED = 1, ST_RESOLVE = 2, ST_DONE = 3, ST_RESOLVE_INNER = 102 };
+enum { ST_RUNNING = 0, ST_ACCEPTED = 1, ST_RESOLVE = 2, ST_DONE = 3, ST_NEED_TRIALS = 4, ST_RESOLVE_INNER = 102 };
 
 struct BaDims {
     int F, n, PF;       // frames, 15F, pose dims padded to 16
@@ -114,6 +117,7 @@ struct BaPtrs {
     double *diagD, *grad, *gn, *gs, *step, *delta;   // [NV] each
     double *partial;                 // [aux_quad_blocks] partial sums of Q(g~,g~)
     double *wog;                     // [PF] W^T (omega gl)
+    double *wide_part;               // [WIDE_G][4 WIDE_B] per-block partial sums of kb_trials_wide
     // zero-copy mailbox in pinned host memory (device-visible addresses): the trial kernel publishes the
     // control block, on termination the optimised states, and last a sequence number the host spins on
     BaCtl *host_ctl;
@@ -168,6 +172,20 @@ template <int N> __device__ __forceinline__ void block_sum_n(double (&v)[N], dou
 
 // --------------------------------------------------------------- reprojection factors
 // One thread per observation.  use_cand selects the candidate state (cost only).
+// cost only, with the landmark's inverse depth given by value (kb_trials_wide forms candidates on the fly)
+__device__ __forceinline__ double obs_cost_at(const BaDims &d, const BaPtrs &p, int o, const double *state, double inv_depth,
+                                              const Ext &cam, double sx, double sy) {
+    const int ft = p.obs_tgt[o], fr = p.obs_ref[o], l = p.obs_lm[o];
+    if (!pose_free(p.fix[ft]) && !pose_free(p.fix[fr]) && !p.lact[l]) return 0.0;
+    const FState st = load_state(state + 16 * ft), sr = load_state(state + 16 * fr);
+    const V3 zt = v3(p.obs_zt[3 * o], p.obs_zt[3 * o + 1], p.obs_zt[3 * o + 2]);
+    const V3 zr = v3(p.obs_zr[3 * o], p.obs_zr[3 * o + 1], p.obs_zr[3 * o + 2]);
+    double r[2];
+    eval_reprojection(st, sr, inv_depth, zt, zr, cam, sx, sy, r, false, nullptr, nullptr, nullptr);
+    const double s2 = r[0] * r[0] + r[1] * r[1];
+    return d.robust ? 0.5 * log(1.0 + s2) : 0.5 * s2;
+}
+
 __device__ __forceinline__ double obs_eval(const BaDims &d, const BaPtrs &p, int o, const double *state,
                                            const double *depth, const Ext &cam, double sx, double sy, bool want_j,
                                            double *rec) {
@@ -206,10 +224,6 @@ __device__ __forceinline__ void lin_obs_item(const BaDims &d, const BaPtrs &p, c
 #pragma unroll
     for (int i = 0; i < OREC; ++i) p.orec[(size_t)o * OREC + i] = rec[i];
 }
-__global__ __launch_bounds__(256) void kb_lin_obs(BaDims d, BaPtrs p, Ext cam, double sx, double sy) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o < d.M) lin_obs_item(d, p, cam, sx, sy, o);
-}
 
 __device__ __forceinline__ double rot_eval(const BaDims &d, const BaPtrs &p, int o, const double *state,
                                            const Ext &cam, double sx, double sy, bool want_j, double *rec) {
@@ -239,10 +253,6 @@ __device__ __forceinline__ void lin_rot_item(const BaDims &d, const BaPtrs &p, c
     p.rcost[o] = rot_eval(d, p, o, p.state, cam, sx, sy, true, rec);
 #pragma unroll
     for (int i = 0; i < RREC; ++i) p.rrec[(size_t)o * RREC + i] = rec[i];
-}
-__global__ __launch_bounds__(256) void kb_lin_rot(BaDims d, BaPtrs p, Ext cam, double sx, double sy) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o < d.MR) lin_rot_item(d, p, cam, sx, sy, o);
 }
 
 // --------------------------------------------------------------------- IMU factors
@@ -344,10 +354,6 @@ __device__ __forceinline__ void lin_imu_item(const BaDims &d, const BaPtrs &p, c
     }
     wave_sync();   // scr may be reused by the caller for the next factor
 }
-__global__ __launch_bounds__(64) void kb_lin_imu(BaDims d, BaPtrs p, Ext imu) {
-    __shared__ double scr[IMU_SCR];
-    lin_imu_item(d, p, imu, blockIdx.x, threadIdx.x, scr);
-}
 
 // ------------------------------------------------------------------------ prior
 // delta and Jr^-1 of prior frame i at `state`
@@ -411,11 +417,6 @@ __device__ __forceinline__ void lin_prior_block(const BaDims &d, const BaPtrs &p
         p.pt[j] = s;
     }
 }
-__global__ __launch_bounds__(256) void kb_lin_prior(BaDims d, BaPtrs p) {
-    extern __shared__ double sh[];   // np doubles
-    __shared__ double scratch[8];
-    lin_prior_block(d, p, sh, scratch);
-}
 
 // Lam = S^T S (once per prior upload)
 __global__ __launch_bounds__(256) void kb_prior_lambda(int np, const double *__restrict__ S, double *__restrict__ Lam) {
@@ -478,7 +479,6 @@ __device__ __forceinline__ void landmark_item(const BaDims &d, const BaPtrs &p, 
             for (int a = 0; a < 6; ++a) row[6 * refm + a] += wr[a];
     }
 }
-__global__ __launch_bounds__(64) void kb_landmark(BaDims d, BaPtrs p) { landmark_item(d, p, blockIdx.x, threadIdx.x); }
 
 // --------------------------------------------------------------------- assembly
 // Reprojection blocks: one wavefront per (row frame, column frame) pair.  The lanes stride over the pair's
@@ -528,7 +528,6 @@ __device__ __forceinline__ void assemble_vision_item(const BaDims &d, const BaPt
             for (int i = 0; i < 6; ++i) p.gv[6 * fa + i] = g[i];
     }
 }
-__global__ __launch_bounds__(64) void kb_assemble_vision(BaDims d, BaPtrs p) { assemble_vision_item(d, p, blockIdx.x, threadIdx.x); }
 
 // One thread per element (a,b) of the frame Hessian Hpp (15F x 15F) and, for b == 0, of g: adds the
 // reprojection block, rotation priors, the (at most two) IMU factors adjacent to the frame and the prior,
@@ -936,10 +935,6 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
         c->linear_ok = 1;
     }
 }
-__global__ __launch_bounds__(512) void kb_solve(BaDims d, BaPtrs p, int use_lds) {
-    extern __shared__ double lds[];
-    solve_block(d, p, use_lds, lds);
-}
 
 // gradient_max_norm = |x - Plus(x, -g)|_inf in ambient coordinates (TrustRegionMinimizer::EvaluateGradientAndJacobian)
 __device__ __forceinline__ void gradmax_block(const BaDims &d, const BaPtrs &p, double *scratch) {   // scratch: blockDim/64 doubles
@@ -965,10 +960,6 @@ __device__ __forceinline__ void gradmax_block(const BaDims &d, const BaPtrs &p, 
         p.ctl->gmax = r;
     }
     __syncthreads();
-}
-__global__ __launch_bounds__(256) void kb_gradmax(BaDims d, BaPtrs p) {
-    __shared__ double scratch[8];
-    gradmax_block(d, p, scratch);
 }
 
 // total cost at `state` (x) from the per-factor costs written by the linearisation kernels
@@ -1009,6 +1000,193 @@ __device__ __forceinline__ double ambient_norm2(const BaDims &d, const BaPtrs &p
     return block_sum(s, scratch);
 }
 
+// ------------------------------------------------------------------- trial logic
+// TrustRegionMinimizer's scalars.  Every thread keeps its own copy and runs the (uniform) decision logic itself;
+// thread 0 writes them back.  Shared by the in-kernel trial loop (try_block) and by kb_trials_wide.
+struct TrialScalars {
+    int iteration, invalid_steps, successful_steps, reuse, termination, status, max_iterations, linear_ok;
+    double radius, mu, cand_cost, last_step_norm;
+    double gmax, x_cost, x_norm, alpha, q_gg, q_gn, q_nn, gnorm, gn_norm, gd;
+};
+constexpr double TR_FUNCTION_TOLERANCE = 1e-6, TR_GRADIENT_TOLERANCE = 1e-10, TR_PARAMETER_TOLERANCE = 1e-8;
+constexpr double TR_MIN_RELATIVE_DECREASE = 1e-3, TR_MIN_RADIUS = 1e-32, TR_MAX_RADIUS = 1e16;
+
+__device__ __forceinline__ void trial_load(const BaCtl *c, TrialScalars &t) {
+    t.iteration = c->iteration;
+    t.invalid_steps = c->invalid_steps;
+    t.successful_steps = c->successful_steps;
+    t.reuse = c->reuse;
+    t.termination = c->termination;
+    t.status = ST_RUNNING;
+    t.max_iterations = c->max_iterations;
+    t.linear_ok = c->linear_ok;
+    t.radius = c->radius;
+    t.mu = c->mu;
+    t.cand_cost = c->cand_cost;
+    t.last_step_norm = c->step_norm;
+    t.gmax = c->gmax;
+    t.x_cost = c->x_cost;
+    t.x_norm = c->x_norm;
+    t.alpha = c->alpha;
+    t.q_gg = c->q_gg;
+    t.q_gn = c->q_gn;
+    t.q_nn = c->q_nn;
+    t.gnorm = c->gnorm;
+    t.gn_norm = c->gn_norm;
+    t.gd = c->gd;
+}
+__device__ __forceinline__ void trial_store(BaCtl *c, const TrialScalars &t) {   // one thread
+    c->iteration = t.iteration;
+    c->invalid_steps = t.invalid_steps;
+    c->successful_steps = t.successful_steps;
+    c->reuse = t.reuse;
+    c->termination = t.termination;
+    c->radius = t.radius;
+    c->mu = t.mu;
+    c->cand_cost = t.cand_cost;
+    c->step_norm = t.last_step_norm;
+}
+
+// FinalizeIterationAndCheckIfMinimizerCanContinue + start of the next iteration, for the first trial of a launch
+__device__ __forceinline__ void trial_begin(TrialScalars &t, bool skip_finalize, bool check_gradient) {
+    if (!skip_finalize) {
+        if (t.iteration >= t.max_iterations) {
+            t.termination = XRHIP_BA_NO_CONVERGENCE;
+            t.status = ST_DONE;
+        } else if (check_gradient && t.gmax <= TR_GRADIENT_TOLERANCE) {
+            t.termination = XRHIP_BA_CONVERGENCE;
+            t.status = ST_DONE;
+        } else if (t.radius <= TR_MIN_RADIUS) {
+            t.termination = XRHIP_BA_CONVERGENCE;
+            t.status = ST_DONE;
+        }
+        if (t.status == ST_RUNNING) t.iteration += 1;
+    }
+    if (t.status == ST_RUNNING && !t.linear_ok) {
+        if (t.mu * 10.0 < 1.0) {
+            t.mu *= 10.0;           // ComputeGaussNewtonStep: retry with a larger mu, same iteration
+            t.status = ST_RESOLVE_INNER;
+        } else {
+            t.invalid_steps += 1;   // LINEAR_SOLVER_FAILURE -> invalid step
+            if (t.invalid_steps >= 5) {
+                t.termination = XRHIP_BA_FAILURE;
+                t.status = ST_DONE;
+            } else {
+                t.mu *= 10.0;
+                t.reuse = 0;
+                t.status = ST_RESOLVE;
+            }
+        }
+    }
+}
+
+// traditional dogleg point for trust-region radius rk: step (scaled by D) = ca grad + cb gn.
+// step_norm < 0: the interpolated case, the caller supplies |step| from its reduction.
+__device__ __forceinline__ void dogleg_point(const TrialScalars &t, double rk, double &ca, double &cb, double &step_norm) {
+    ca = 0.0;
+    cb = 0.0;
+    if (t.gn_norm <= rk) {
+        cb = 1.0;
+        step_norm = t.gn_norm;
+    } else if (t.gnorm * t.alpha >= rk) {
+        ca = -(rk / t.gnorm);
+        step_norm = rk;
+    } else {
+        // (DoglegStrategy::ComputeTraditionalDoglegStep writes these squares as pow(x, 2.0))
+        const double b_dot_a = -t.alpha * t.gd;
+        const double a_sq = (t.alpha * t.gnorm) * (t.alpha * t.gnorm);
+        const double bma_sq = a_sq - 2 * b_dot_a + t.gn_norm * t.gn_norm;
+        const double cc = b_dot_a - a_sq;
+        const double dd = sqrt(cc * cc + bma_sq * (rk * rk - a_sq));
+        const double beta = (cc <= 0) ? (dd - cc) / bma_sq : (rk * rk - a_sq) / (dd + cc);
+        ca = -t.alpha * (1.0 - beta);
+        cb = beta;
+        step_norm = -1.0;
+    }
+}
+__device__ __forceinline__ double dogleg_model_change(const TrialScalars &t, double ca, double cb, double step_dot_gs) {
+    const double shs = (ca * ca) * t.q_gg + 2.0 * (ca * cb) * t.q_gn + (cb * cb) * t.q_nn;   // see kb_schur_aux
+    return -step_dot_gs - 0.5 * shs;
+}
+
+// Decision for trial k of a batch whose predecessors were all rejected (k > 0 first replays their finalize step).
+// Returns true when the candidate is accepted; t.status != ST_RUNNING ends the batch.
+__device__ __forceinline__ bool trial_decide(TrialScalars &t, int k, double model_cost_change, double cost, double dn2,
+                                             double step_norm) {
+    if (k > 0) {
+        if (t.iteration >= t.max_iterations) {
+            t.termination = XRHIP_BA_NO_CONVERGENCE;
+            t.status = ST_DONE;
+        } else if (t.radius <= TR_MIN_RADIUS) {
+            t.termination = XRHIP_BA_CONVERGENCE;
+            t.status = ST_DONE;
+        }
+        if (t.status != ST_RUNNING) return false;
+        t.iteration += 1;
+    }
+    if (!(model_cost_change > 0.0)) {
+        t.invalid_steps += 1;
+        if (t.invalid_steps >= 5) {
+            t.termination = XRHIP_BA_FAILURE;
+            t.status = ST_DONE;
+        } else {
+            t.mu *= 10.0;   // StepIsInvalid
+            t.reuse = 0;
+            t.status = ST_RESOLVE;
+        }
+        return false;
+    }
+    if (!isfinite(cost)) cost = 1.7976931348623157e308;
+    const double dn = sqrt(dn2);
+    if (dn <= TR_PARAMETER_TOLERANCE * (t.x_norm + TR_PARAMETER_TOLERANCE) ||
+        fabs(t.x_cost - cost) <= TR_FUNCTION_TOLERANCE * t.x_cost) {
+        t.termination = XRHIP_BA_CONVERGENCE;
+        t.status = ST_DONE;
+        return false;
+    }
+    const double relative_decrease = (t.x_cost - cost) / model_cost_change;
+    if (relative_decrease > TR_MIN_RELATIVE_DECREASE) {
+        t.invalid_steps = 0;
+        t.successful_steps += 1;
+        if (relative_decrease < 0.25) t.radius *= 0.5;
+        if (relative_decrease > 0.75) t.radius = fmax(t.radius, 3.0 * step_norm);
+        t.radius = fmin(t.radius, TR_MAX_RADIUS);
+        t.mu = fmax(1e-8, 2.0 * t.mu / 10.0);
+        t.reuse = 0;
+        t.cand_cost = cost;
+        t.last_step_norm = step_norm;
+        t.status = ST_ACCEPTED;
+        return true;
+    }
+    t.invalid_steps = 0;
+    t.radius *= 0.5;   // StepRejected
+    t.reuse = 1;
+    return false;
+}
+
+// Publish the result of a trial launch into the host mailbox: control block, on termination the optimised
+// states, last the sequence number.  Block-wide.
+__device__ __forceinline__ void publish_block(const BaDims &d, const BaPtrs &p, int status, int seq, bool always) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (status == ST_DONE) {
+        for (int e = tid; e < 16 * d.F; e += nt) p.host_out[e] = p.state[e];
+        for (int l = tid; l < d.L; l += nt) p.host_out[16 * d.F + l] = p.depth[l];
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (tid == 0) {
+        p.ctl->status = status;
+        if (always || status == ST_DONE) {
+            const long long *src = reinterpret_cast<const long long *>(p.ctl);
+            long long *dst = reinterpret_cast<long long *>(p.host_ctl);
+            for (unsigned i = 0; i < sizeof(BaCtl) / sizeof(long long); ++i) dst[i] = src[i];
+            __threadfence_system();
+            *reinterpret_cast<volatile int *>(p.host_seq) = seq;
+        }
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------- trial loop
 // TrustRegionMinimizer's per-iteration logic for as long as no new linearisation is needed:
 // dogleg point for the current radius, model cost change, candidate = Plus(x, delta), candidate
@@ -1018,13 +1196,12 @@ __device__ __forceinline__ double ambient_norm2(const BaDims &d, const BaPtrs &p
 //   ST_DONE      the minimiser terminated
 // `after_linearisation` = this launch directly follows a (re)linearisation or re-solve.
 __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
-                                         double sy, int after_linearisation, int seq, bool publish_always, double *sh) {
+                                         double sy, int after_linearisation, int seq, bool wide_after_first, double *sh) {
     // sh: LDS, TRY_B * np doubles for the prior deltas of the candidates + TRY_B * NI * 15 for the raw IMU residuals
+    // wide_after_first: if the first trial is rejected, hand the following ones to kb_trials_wide (ST_NEED_TRIALS)
     __shared__ double scratch[2 * TRY_B * 8];
     BaCtl *c = p.ctl;
     const int tid = threadIdx.x, nt = blockDim.x;
-    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
-    const double min_relative_decrease = 1e-3, min_radius = 1e-32, max_radius = 1e16;
 
     // mode 1: directly after a (re)linearisation at a new x (initial point or accepted step)
     // mode 2: after a re-solve caused by an invalid step (x unchanged)
@@ -1035,8 +1212,8 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
         // FinalizeIterationAndCheckIfMinimizerCanContinue of the iteration that produced this x:
         // refresh the user state the IMU factors read their bias reference from (StateUpdatingCallback)
         for (int k = tid; k < d.NI; k += nt) {
-            const double *s = p.state + 16 * p.imu_i[k];
-            for (int i = 0; i < 6; ++i) p.bias_ref[6 * k + i] = s[10 + i];
+            const double *st = p.state + 16 * p.imu_i[k];
+            for (int i = 0; i < 6; ++i) p.bias_ref[6 * k + i] = st[10 + i];
         }
         const double xn2 = ambient_norm2(d, p, p.state, p.depth, scratch);
         if (tid == 0) {
@@ -1046,8 +1223,7 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
         __syncthreads();
     }
     KPROF(10);
-    // |gradient|, |gauss-newton step| and their inner product stay the same for every trial of this launch
-    double gnorm, gn_norm, gd;
+    // |gradient|, |gauss-newton step| and their inner product stay the same for every trial of this linearisation
     {
         double r3[3] = {0, 0, 0};
         for (int a = tid; a < d.NV; a += nt) {
@@ -1056,89 +1232,36 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
             r3[2] += p.grad[a] * p.gn[a];
         }
         block_sum_n<3>(r3, scratch);
-        gnorm = sqrt(r3[0]);
-        gn_norm = sqrt(r3[1]);
-        gd = r3[2];
+        if (tid == 0) {
+            c->gnorm = sqrt(r3[0]);
+            c->gn_norm = sqrt(r3[1]);
+            c->gd = r3[2];
+        }
         __syncthreads();
     }
     KPROF(11);
-    // Every thread keeps its own copy of the minimiser's scalars and runs the (uniform) decision logic itself;
-    // thread 0 writes them back on exit.  No barrier or LDS flag is needed to agree on the outcome.
-    int iteration = c->iteration, invalid_steps = c->invalid_steps, successful_steps = c->successful_steps;
-    int reuse = c->reuse, termination = c->termination, status = ST_RUNNING;
-    double radius = c->radius, mu = c->mu, cand_cost = c->cand_cost, last_step_norm = c->step_norm;
-    const int max_iterations = c->max_iterations, linear_ok = c->linear_ok;
-    const double gmax = c->gmax, x_cost = c->x_cost, x_norm = c->x_norm, alpha = c->alpha;
-    const double q_gg = c->q_gg, q_gn = c->q_gn, q_nn = c->q_nn;
+    TrialScalars t;
+    trial_load(c, t);
     bool check_gradient = (mode == 1);   // the iteration that led here was successful
     bool skip_finalize = (mode == 3);
     // Trials are evaluated in batches: after a rejection the next radii are known (radius / 2, / 4, ...), so the
-    // next TRY_B candidates are costed in ONE sweep over the factors and the decisions replayed in order -- the
-    // sweep is latency-bound, extra candidates are nearly free.  The first trial of a launch is usually accepted
-    // and goes alone.
+    // next TRY_B candidates are costed in ONE sweep over the factors and the decisions replayed in order.  The
+    // first trial of a launch is usually accepted and goes alone.
     int B = 1;
-    while (status == ST_RUNNING) {
-        // ---- FinalizeIterationAndCheckIfMinimizerCanContinue + start of the next iteration (first trial of the batch)
-        if (!skip_finalize) {
-            if (iteration >= max_iterations) {
-                termination = XRHIP_BA_NO_CONVERGENCE;
-                status = ST_DONE;
-            } else if (check_gradient && gmax <= gradient_tolerance) {
-                termination = XRHIP_BA_CONVERGENCE;
-                status = ST_DONE;
-            } else if (radius <= min_radius) {
-                termination = XRHIP_BA_CONVERGENCE;
-                status = ST_DONE;
-            }
-            if (status == ST_RUNNING) iteration += 1;
-        }
-        if (status == ST_RUNNING && !linear_ok) {
-            if (mu * 10.0 < 1.0) {
-                mu *= 10.0;           // ComputeGaussNewtonStep: retry with a larger mu, same iteration
-                status = ST_RESOLVE_INNER;
-            } else {
-                invalid_steps += 1;   // LINEAR_SOLVER_FAILURE -> invalid step
-                if (invalid_steps >= 5) {
-                    termination = XRHIP_BA_FAILURE;
-                    status = ST_DONE;
-                } else {
-                    mu *= 10.0;
-                    reuse = 0;
-                    status = ST_RESOLVE;
-                }
-            }
-        }
+    while (t.status == ST_RUNNING) {
+        trial_begin(t, skip_finalize, check_gradient);
         skip_finalize = false;
         check_gradient = false;
-        if (status != ST_RUNNING) break;
+        if (t.status != ST_RUNNING) break;
         KPROF(12);
         // ---- traditional dogleg points for radius, radius/2, ...: step (scaled by D) = ca grad + cb gn
         double ca[TRY_B], cb[TRY_B], step_norm[TRY_B];
 #pragma unroll
         for (int k = 0; k < TRY_B; ++k) {
-            const double rk = radius * (1.0 / (double)(1 << k));   // exact
             ca[k] = 0.0;
             cb[k] = 0.0;
             step_norm[k] = 0.0;
-            if (k >= B) continue;
-            if (gn_norm <= rk) {
-                cb[k] = 1.0;
-                step_norm[k] = gn_norm;
-            } else if (gnorm * alpha >= rk) {
-                ca[k] = -(rk / gnorm);
-                step_norm[k] = rk;
-            } else {
-                // (DoglegStrategy::ComputeTraditionalDoglegStep writes these squares as pow(x, 2.0))
-                const double b_dot_a = -alpha * gd;
-                const double a_sq = (alpha * gnorm) * (alpha * gnorm);
-                const double bma_sq = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
-                const double cc = b_dot_a - a_sq;
-                const double dd = sqrt(cc * cc + bma_sq * (rk * rk - a_sq));
-                const double beta = (cc <= 0) ? (dd - cc) / bma_sq : (rk * rk - a_sq) / (dd + cc);
-                ca[k] = -alpha * (1.0 - beta);
-                cb[k] = beta;
-                step_norm[k] = -1.0;
-            }
+            if (k < B) dogleg_point(t, t.radius * (1.0 / (double)(1 << k)), ca[k], cb[k], step_norm[k]);
         }
         double red2[2 * TRY_B];   // per candidate: |step|^2 (D-scaled), step . gs
 #pragma unroll
@@ -1168,8 +1291,7 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
 #pragma unroll
         for (int k = 0; k < TRY_B; ++k) {
             if (step_norm[k] < 0) step_norm[k] = sqrt(red2[2 * k]);
-            const double shs = (ca[k] * ca[k]) * q_gg + 2.0 * (ca[k] * cb[k]) * q_gn + (cb[k] * cb[k]) * q_nn;   // see kb_solve_aux
-            model_cost_change[k] = -red2[2 * k + 1] - 0.5 * shs;
+            model_cost_change[k] = dogleg_model_change(t, ca[k], cb[k], red2[2 * k + 1]);
         }
         __syncthreads();
         KPROF(13);
@@ -1303,60 +1425,11 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
         int accepted = -1;
 #pragma unroll
         for (int k = 0; k < TRY_B; ++k) {
-            if (k >= B || status != ST_RUNNING || accepted >= 0) continue;
-            if (k > 0) {   // the finalize step of the rejected trial before this one
-                if (iteration >= max_iterations) {
-                    termination = XRHIP_BA_NO_CONVERGENCE;
-                    status = ST_DONE;
-                } else if (radius <= min_radius) {
-                    termination = XRHIP_BA_CONVERGENCE;
-                    status = ST_DONE;
-                }
-                if (status != ST_RUNNING) continue;
-                iteration += 1;
-            }
+            if (k >= B || t.status != ST_RUNNING) continue;
 #ifdef XRHIP_KPROF
             if (tid == 0) p.ctl->prof[19] += 1;   // trials
 #endif
-            if (!(model_cost_change[k] > 0.0)) {
-                invalid_steps += 1;
-                if (invalid_steps >= 5) {
-                    termination = XRHIP_BA_FAILURE;
-                    status = ST_DONE;
-                } else {
-                    mu *= 10.0;   // StepIsInvalid
-                    reuse = 0;
-                    status = ST_RESOLVE;
-                }
-                continue;
-            }
-            double cost = red[2 * k];
-            if (!isfinite(cost)) cost = 1.7976931348623157e308;
-            const double dn = sqrt(red[2 * k + 1]);
-            if (dn <= parameter_tolerance * (x_norm + parameter_tolerance) ||
-                fabs(x_cost - cost) <= function_tolerance * x_cost) {
-                termination = XRHIP_BA_CONVERGENCE;
-                status = ST_DONE;
-                continue;
-            }
-            const double relative_decrease = (x_cost - cost) / model_cost_change[k];
-            if (relative_decrease > min_relative_decrease) {
-                accepted = k;
-                invalid_steps = 0;
-                successful_steps += 1;
-                if (relative_decrease < 0.25) radius *= 0.5;
-                if (relative_decrease > 0.75) radius = fmax(radius, 3.0 * step_norm[k]);
-                radius = fmin(radius, max_radius);
-                mu = fmax(1e-8, 2.0 * mu / 10.0);
-                reuse = 0;
-                cand_cost = cost;
-                last_step_norm = step_norm[k];
-                status = ST_ACCEPTED;
-                continue;
-            }
-            invalid_steps = 0;
-            radius *= 0.5;   // StepRejected
-            reuse = 1;
+            if (trial_decide(t, k, model_cost_change[k], red[2 * k], red[2 * k + 1], step_norm[k])) accepted = k;
         }
         if (accepted >= 0) {
             const double *cs = p.cand + (size_t)accepted * 16 * d.F, *cd = p.depth_cand + (size_t)accepted * d.L;
@@ -1364,44 +1437,13 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
             for (int l = tid; l < d.L; l += nt) p.depth[l] = cd[l];
         }
         __syncthreads();   // candidates / deltas are rewritten by the next batch
+        if (t.status == ST_RUNNING && wide_after_first) t.status = ST_NEED_TRIALS;
         B = TRY_B;
     }
-    if (tid == 0) {
-        c->iteration = iteration;
-        c->invalid_steps = invalid_steps;
-        c->successful_steps = successful_steps;
-        c->reuse = reuse;
-        c->termination = termination;
-        c->radius = radius;
-        c->mu = mu;
-        c->cand_cost = cand_cost;
-        c->step_norm = last_step_norm;
-    }
+    if (tid == 0) trial_store(c, t);
     __syncthreads();
-    // ---- publish to the host mailbox
-    if (status == ST_DONE) {
-        for (int e = tid; e < 16 * d.F; e += nt) p.host_out[e] = p.state[e];
-        for (int l = tid; l < d.L; l += nt) p.host_out[16 * d.F + l] = p.depth[l];
-        __threadfence_system();
-    }
-    __syncthreads();
-    if (tid == 0) {
-        c->status = status;
-        if (publish_always || status == ST_DONE) {
-            const long long *src = reinterpret_cast<const long long *>(c);
-            long long *dst = reinterpret_cast<long long *>(p.host_ctl);
-            for (unsigned i = 0; i < sizeof(BaCtl) / sizeof(long long); ++i) dst[i] = src[i];
-            __threadfence_system();
-            *reinterpret_cast<volatile int *>(p.host_seq) = seq;
-        }
-    }
-    __syncthreads();
-    return status;
-}
-__global__ __launch_bounds__(512) void kb_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy,
-                                              int after_linearisation, int seq) {
-    extern __shared__ double sh[];   // np doubles for the prior delta
-    try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, true, sh);
+    publish_block(d, p, t.status, seq, true);
+    return t.status;
 }
 
 // ------------------------------------------------------------------ fused launches
@@ -1455,12 +1497,185 @@ __global__ __launch_bounds__(256) void kb_cost_prepare(BaDims d, BaPtrs p) {
 }
 
 // reduced-system solve followed by the trust-region trials, one workgroup
+// wide_trials: a rejected first trial hands over to kb_trials_wide (large problems) instead of looping in here
 __global__ __launch_bounds__(512) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int use_lds,
-                                                    int after_linearisation, int seq) {
-    extern __shared__ double lds[];   // max(solve_block's region, np doubles)
+                                                    int after_linearisation, int seq, int wide_trials) {
+    extern __shared__ double lds[];   // max(solve_block's region, try_block's staging)
     solve_block(d, p, use_lds, lds);
     __syncthreads();
-    try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, true, lds);
+    try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, wide_trials != 0, lds);
+}
+
+// The rejected-trial tail of a large solve on the whole chip.  After a rejection the next radii are radius/2,
+// radius/4, ...: WIDE_B candidates are costed by WIDE_G workgroups, each taking a slice of the factors (the small
+// candidate states are recomputed per workgroup in LDS); per-block partial sums go to global memory, and the last
+// block to arrive adds them up in block order, replays the accept / reject decisions exactly like try_block,
+// applies an accepted step and publishes to the host mailbox.  ST_NEED_TRIALS = all WIDE_B rejected, launch again.
+// Dynamic LDS: WIDE_B * (16 F + np) doubles.
+__global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int seq) {
+    extern __shared__ double wl[];
+    __shared__ double scratch[4 * WIDE_B * 4];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int blk = blockIdx.x, G = gridDim.x;
+    const int n = d.n;
+    double *cand = wl;                           // [WIDE_B][F][16]
+    double *pd = wl + (size_t)WIDE_B * 16 * d.F;   // [WIDE_B][np]
+    BaCtl *c = p.ctl;
+    TrialScalars t;
+    trial_load(c, t);
+    // the batch continues a run of rejections: trial 0 replays the finalize step of its rejected predecessor
+    double ca[WIDE_B], cb[WIDE_B], step_norm[WIDE_B];
+#pragma unroll
+    for (int k = 0; k < WIDE_B; ++k) dogleg_point(t, t.radius * (1.0 / (double)(1 << k)), ca[k], cb[k], step_norm[k]);
+    // ---- candidate frame states (every block, LDS) and prior deltas
+    for (int e = tid; e < WIDE_B * d.F; e += nt) {
+        const int k = e / d.F, f = e - k * d.F;
+        double dl[15];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) {
+            const int a = 15 * f + q;
+            double cak = 0, cbk = 0;
+#pragma unroll
+            for (int kk = 0; kk < WIDE_B; ++kk)
+                if (kk == k) {
+                    cak = ca[kk];
+                    cbk = cb[kk];
+                }
+            dl[q] = ((cak * p.grad[a] + cbk * p.gn[a]) / p.diagD[a]) * p.sp[a];
+        }
+        state_plus(p.state + 16 * f, dl, pose_free(p.fix[f]), motion_free(p.fix[f]), cand + (size_t)(k * d.F + f) * 16);
+    }
+    __syncthreads();
+    for (int e = tid; e < WIDE_B * d.NP; e += nt) {
+        const int k = e / d.NP, i = e - k * d.NP;
+        double dl[15];
+        prior_delta(p, i, cand + (size_t)k * 16 * d.F, dl, nullptr);
+        for (int q = 0; q < 15; ++q) pd[k * d.np + 15 * i + q] = dl[q];
+    }
+    __syncthreads();
+    // ---- this block's slice of the sums: per candidate cost, |x - cand|^2, |step|^2, step . gs
+    double acc[4 * WIDE_B];
+#pragma unroll
+    for (int q = 0; q < 4 * WIDE_B; ++q) acc[q] = 0.0;
+    const int gtid = blk * nt + tid, gnt = G * nt;
+    for (int a = gtid; a < d.NV; a += gnt) {   // step norms / gradient products, landmark part of |x - cand|^2
+        const double g = p.grad[a], gnv = p.gn[a], D = p.diagD[a], gsa = p.gs[a];
+        const bool lm = a >= n;
+        const double sl = lm ? p.sl[a - n] : 0.0;
+        const bool act = lm && p.lact[a - n];
+#pragma unroll
+        for (int k = 0; k < WIDE_B; ++k) {
+            const double v = ca[k] * g + cb[k] * gnv;
+            acc[4 * k + 2] += v * v;
+            const double st = v / D;
+            acc[4 * k + 3] += st * gsa;
+            if (act) {   // |depth - candidate depth|^2 from the stored values, like try_block
+                const double dep = p.depth[a - n];
+                const double df = dep - (dep + st * sl);
+                acc[4 * k + 1] += df * df;
+            }
+        }
+    }
+    if (blk == 0)
+        for (int e = tid; e < WIDE_B * d.F; e += nt) {
+            const int k = e / d.F, f = e - k * d.F;
+            const double *a = p.state + 16 * f, *b = cand + (size_t)(k * d.F + f) * 16;
+            double s2 = 0;
+            if (pose_free(p.fix[f]))
+                for (int q = 0; q < 7; ++q) s2 += (a[q] - b[q]) * (a[q] - b[q]);
+            if (motion_free(p.fix[f]))
+                for (int q = 7; q < 16; ++q) s2 += (a[q] - b[q]) * (a[q] - b[q]);
+#pragma unroll
+            for (int kk = 0; kk < WIDE_B; ++kk)
+                if (kk == k) acc[4 * kk + 1] += s2;
+        }
+    for (int o = gtid; o < d.M; o += gnt) {   // reprojection factors
+        const int l = p.obs_lm[o];
+        const double dep = p.depth[l], g = p.grad[n + l], gnv = p.gn[n + l], Dl = p.diagD[n + l], sl = p.sl[l];
+        const bool act = p.lact[l] != 0;
+#pragma unroll
+        for (int k = 0; k < WIDE_B; ++k) {
+            const double dk = act ? dep + ((ca[k] * g + cb[k] * gnv) / Dl) * sl : dep;
+            acc[4 * k] += obs_cost_at(d, p, o, cand + (size_t)k * 16 * d.F, dk, cam, sx, sy);
+        }
+    }
+    for (int o = gtid; o < d.MR; o += gnt)
+#pragma unroll
+        for (int k = 0; k < WIDE_B; ++k) acc[4 * k] += rot_eval(d, p, o, cand + (size_t)k * 16 * d.F, cam, sx, sy, false, nullptr);
+    for (int e = gtid; e < WIDE_B * d.NI; e += gnt) {   // IMU factors: raw residual + 15x15 whitening per (factor, candidate)
+        const int k = e / d.NI, f = e - k * d.NI;
+        const double cst = imu_cost_eval(p, f, cand + (size_t)k * 16 * d.F, imu);
+#pragma unroll
+        for (int kk = 0; kk < WIDE_B; ++kk)
+            if (kk == k) acc[4 * kk] += cst;
+    }
+    for (int i = blk * nw + wave; i < d.np; i += G * nw) {   // prior rows: one wavefront per row, every candidate
+        double sr[WIDE_B];
+#pragma unroll
+        for (int k = 0; k < WIDE_B; ++k) sr[k] = 0.0;
+        for (int j = lane; j < d.np; j += 64) {
+            const double sij = p.pS[(size_t)i * d.np + j];
+#pragma unroll
+            for (int k = 0; k < WIDE_B; ++k) sr[k] += sij * pd[k * d.np + j];
+        }
+#pragma unroll
+        for (int k = 0; k < WIDE_B; ++k) {
+            const double r = wave_sum(sr[k]) + p.pinfo[i];
+            if (lane == 0) acc[4 * k] += 0.5 * r * r;
+        }
+    }
+    // ---- block partial sums -> global; the last block to finish reduces and decides
+    block_sum_n<4 * WIDE_B>(acc, scratch);
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 4 * WIDE_B; ++q) p.wide_part[(size_t)blk * 4 * WIDE_B + q] = acc[q];
+        __threadfence();
+        const unsigned ticket = atomicAdd(&c->wide_ticket, 1u);
+        s_last = (ticket == (unsigned)G - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double tot[4 * WIDE_B];
+#pragma unroll
+    for (int q = 0; q < 4 * WIDE_B; ++q) {
+        double s2 = 0;
+        for (int b = 0; b < G; ++b) s2 += p.wide_part[(size_t)b * 4 * WIDE_B + q];   // fixed order
+        tot[q] = s2;
+    }
+    int accepted = -1;
+#pragma unroll
+    for (int k = 0; k < WIDE_B; ++k) {
+        if (t.status != ST_RUNNING) continue;
+        if (step_norm[k] < 0) step_norm[k] = sqrt(tot[4 * k + 2]);
+        const double mcc = dogleg_model_change(t, ca[k], cb[k], tot[4 * k + 3]);
+        // as the continuation of a rejection run every trial of the batch, the first included, starts with the
+        // finalize step of its rejected predecessor (k + 1 > 0)
+#ifdef XRHIP_KPROF
+        if (tid == 0) p.ctl->prof[19] += 1;
+#endif
+        if (trial_decide(t, k + 1, mcc, tot[4 * k], tot[4 * k + 1], step_norm[k])) accepted = k;
+    }
+    if (accepted >= 0) {
+        for (int e = tid; e < 16 * d.F; e += nt) p.state[e] = cand[(size_t)accepted * 16 * d.F + e];
+        double cak = 0, cbk = 0;
+#pragma unroll
+        for (int kk = 0; kk < WIDE_B; ++kk)
+            if (kk == accepted) {
+                cak = ca[kk];
+                cbk = cb[kk];
+            }
+        for (int l = tid; l < d.L; l += nt)
+            if (p.lact[l]) p.depth[l] = p.depth[l] + ((cak * p.grad[n + l] + cbk * p.gn[n + l]) / p.diagD[n + l]) * p.sl[l];
+    }
+    if (t.status == ST_RUNNING) t.status = ST_NEED_TRIALS;
+    if (tid == 0) {
+        trial_store(c, t);
+        c->wide_ticket = 0;
+    }
+    __syncthreads();
+    publish_block(d, p, t.status, seq, true);
 }
 
 // The staged problem (a few tens of KB) is pulled from the pinned host arena by the device itself, 16 bytes per
