@@ -1590,20 +1590,33 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
             for (int kk = 0; kk < WIDE_B; ++kk)
                 if (kk == k) acc[4 * kk + 1] += s2;
         }
-    for (int o = gtid; o < d.M; o += gnt) {   // reprojection factors
+    for (int e = gtid; e < WIDE_B * d.M; e += gnt) {   // reprojection factors: one (factor, candidate) pair per thread
+        const int k = e / d.M, o = e - k * d.M;
         const int l = p.obs_lm[o];
-        const double dep = p.depth[l], g = p.grad[n + l], gnv = p.gn[n + l], Dl = p.diagD[n + l], sl = p.sl[l];
-        const bool act = p.lact[l] != 0;
+        double cak = 0, cbk = 0;
 #pragma unroll
-        for (int k = 0; k < WIDE_B; ++k) {
-            const double dk = act ? dep + ((ca[k] * g + cb[k] * gnv) / Dl) * sl : dep;
-            acc[4 * k] += obs_cost_at(d, p, o, cand + (size_t)k * 16 * d.F, dk, cam, sx, sy);
-        }
+        for (int kk = 0; kk < WIDE_B; ++kk)
+            if (kk == k) {
+                cak = ca[kk];
+                cbk = cb[kk];
+            }
+        const double dep = p.depth[l];
+        const double dk = p.lact[l] ? dep + ((cak * p.grad[n + l] + cbk * p.gn[n + l]) / p.diagD[n + l]) * p.sl[l] : dep;
+        const double cst = obs_cost_at(d, p, o, cand + (size_t)k * 16 * d.F, dk, cam, sx, sy);
+#pragma unroll
+        for (int kk = 0; kk < WIDE_B; ++kk)
+            if (kk == k) acc[4 * kk] += cst;
     }
-    for (int o = gtid; o < d.MR; o += gnt)
+    for (int e = gtid; e < WIDE_B * d.MR; e += gnt) {
+        const int k = e / d.MR, o = e - k * d.MR;
+        const double cst = rot_eval(d, p, o, cand + (size_t)k * 16 * d.F, cam, sx, sy, false, nullptr);
 #pragma unroll
-        for (int k = 0; k < WIDE_B; ++k) acc[4 * k] += rot_eval(d, p, o, cand + (size_t)k * 16 * d.F, cam, sx, sy, false, nullptr);
-    for (int e = gtid; e < WIDE_B * d.NI; e += gnt) {   // IMU factors: raw residual + 15x15 whitening per (factor, candidate)
+        for (int kk = 0; kk < WIDE_B; ++kk)
+            if (kk == k) acc[4 * kk] += cst;
+    }
+    // IMU factors: raw residual + 15x15 whitening per (factor, candidate), taken by the blocks from the far end of the
+    // grid so that they do not pile onto the threads that already hold a reprojection pair
+    for (int e = (G * nt - 1 - gtid); e < WIDE_B * d.NI; e += gnt) {
         const int k = e / d.NI, f = e - k * d.NI;
         const double cst = imu_cost_eval(p, f, cand + (size_t)k * 16 * d.F, imu);
 #pragma unroll
@@ -1637,13 +1650,15 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
     __syncthreads();
     if (!s_last) return;
     __threadfence();
+    if (tid < 4 * WIDE_B) {
+        double s2 = 0;
+        for (int b = 0; b < G; ++b) s2 += p.wide_part[(size_t)b * 4 * WIDE_B + tid];   // fixed order
+        scratch[tid] = s2;
+    }
+    __syncthreads();
     double tot[4 * WIDE_B];
 #pragma unroll
-    for (int q = 0; q < 4 * WIDE_B; ++q) {
-        double s2 = 0;
-        for (int b = 0; b < G; ++b) s2 += p.wide_part[(size_t)b * 4 * WIDE_B + q];   // fixed order
-        tot[q] = s2;
-    }
+    for (int q = 0; q < 4 * WIDE_B; ++q) tot[q] = scratch[q];
     int accepted = -1;
 #pragma unroll
     for (int k = 0; k < WIDE_B; ++k) {
