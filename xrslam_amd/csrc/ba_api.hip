@@ -604,7 +604,8 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     const BaCtl &ctl = *c->h_ctl;
     {   // development aid: XRHIP_KPROF_MIN_NA restricts the accumulated phase timers to solves of at least that size
         static const int min_na = std::getenv("XRHIP_KPROF_MIN_NA") ? std::atoi(std::getenv("XRHIP_KPROF_MIN_NA")) : 0;
-        if (d.na >= min_na) {
+        static const int max_na = std::getenv("XRHIP_KPROF_MAX_NA") ? std::atoi(std::getenv("XRHIP_KPROF_MAX_NA")) : 1 << 30;
+        if (d.na >= min_na && d.na <= max_na) {
             for (int i = 0; i < 32; ++i) g_kprof[i] += ctl.prof[i];
             g_kprof[31] += 1;   // solves counted
         }

@@ -52,8 +52,11 @@ typedef double chol_d4 __attribute__((ext_vector_type(4)));
 
 // Wavefront 0 only.  Factors the nb x nb diagonal block at (j0, j0) of the packed matrix A in place (A gets L)
 // and leaves L^-1 (lower triangular, zero above the diagonal, identity-padded to 16x16) in Dinv.
+// If `rhs` is given (the LAST panel of a system with one right-hand-side row), the inverse is not needed: the
+// row segment rhs[j0 .. j0+nb) is forward-substituted in registers instead and Dinv is left untouched.
 // Returns false (uniformly over the wavefront) on a non-positive pivot.
-__device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double (*Dinv)[CH_NB + 1], int lane) {
+__device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double (*Dinv)[CH_NB + 1], int lane,
+                                               double *rhs = nullptr) {
     double x[CH_NB];   // row `lane` of the block; rows >= nb are identity rows
 #pragma unroll
     for (int k = 0; k < CH_NB; ++k) x[k] = (lane < nb && k <= lane) ? A[tri_idx(j0 + lane, j0 + k)] : ((k == lane) ? 1.0 : 0.0);
@@ -74,6 +77,22 @@ __device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double
             const double lkc = lane_bcast(x[c], k);   // L[k][c]
             x[k] -= x[c] * lkc;                        // meaningful for lane >= k (lower triangle)
         }
+    }
+    if (rhs) {
+        double r = (lane < nb) ? rhs[j0 + lane] : 0.0;
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) {
+            const double xc = lane_bcast(r, c) * dinv[c];
+            if (lane == c) r = xc;
+            else if (lane > c) r -= x[c] * xc;   // L[lane][c]
+        }
+        if (lane < nb) {
+            rhs[j0 + lane] = r;
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k)
+                if (k <= lane) A[tri_idx(j0 + lane, j0 + k)] = x[k];
+        }
+        return ok;
     }
     // column `lane` of L^-1 by forward substitution: xi[r] = Linv[r][lane]
     double xi[CH_NB];
@@ -109,15 +128,17 @@ __device__ __forceinline__ bool chol_blocked(double *A, int n, int nrows, double
     __syncthreads();
     for (int j0 = 0; j0 < n; j0 += CH_NB) {
         const int nb = min(CH_NB, n - j0);
-        // ---- (1) diagonal block: factor + invert, wavefront 0, registers only
+        // ---- (1) diagonal block: factor + invert, wavefront 0, registers only.  The last panel of a system with a
+        // single rhs row needs no inverse: that row is substituted in the same registers.
+        const int jb = j0 + nb;
+        const bool last_with_rhs = (jb >= n) && (nrows == n + 1);
         if (wave == 0) {
-            if (!chol_diag_wave(A, j0, nb, Dinv, lane) && lane == 0) *s_fail = 1;
+            if (!chol_diag_wave(A, j0, nb, Dinv, lane, last_with_rhs ? A + tri_idx(n, 0) : nullptr) && lane == 0) *s_fail = 1;
         }
         __syncthreads();
         CHPROF(0);
         if (*s_fail) return false;
-        const int jb = j0 + nb;
-        if (jb >= nrows) break;
+        if (jb >= nrows || last_with_rhs) break;
         // ---- (2) panel: X = P Linv^T for the rows below the block, 16-row tiles on the matrix cores.
         // A[i][k] from lane (i = lane & 15, k = lane >> 4), B[k][j] = Linv[j][k] from lane (k = lane >> 4, j = lane & 15).
         {
