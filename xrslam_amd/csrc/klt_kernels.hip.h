@@ -385,10 +385,32 @@ constexpr int LK_W_BITS = 14;
 
 __device__ __forceinline__ int lk_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
+// Exact wavefront-wide sum of a 64-bit integer, result in every lane.  DPP data movement (row_shr 1/2/4/8 scan
+// inside each row of 16 lanes, row_bcast:15 / row_bcast:31 across the rows, v_readlane of lane 63) instead of six
+// ds_bpermute round trips: the reductions sit on the serial path of every LK iteration.
+// (Tried and dropped: staging a 34x34 search region of the target level in LDS per level -- the iteration's taps are
+// L1 hits already, the staging pass cost more than it saved: 74 -> 102 us per launch.)
+__device__ __forceinline__ long long dpp_shifted_i64(long long v, const int step) {
+    int lo = (int)(v & 0xffffffffLL), hi = (int)(v >> 32);
+    switch (step) {   // dpp_ctrl, row_mask and bank_mask must be compile-time constants
+    case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false); break;   // row_shr:1
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, false); break;   // row_shr:2
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, false); break;   // row_shr:4
+    case 3: lo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, false); break;   // row_shr:8
+    case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, false); break;   // row_bcast:15 -> rows 1, 3
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, false); break;  // row_bcast:31 -> rows 2, 3
+    }
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += dpp_shifted_i64(v, 0);
+    v += dpp_shifted_i64(v, 1);
+    v += dpp_shifted_i64(v, 2);
+    v += dpp_shifted_i64(v, 3);
+    v += dpp_shifted_i64(v, 4);
+    v += dpp_shifted_i64(v, 5);
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffLL), 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return ((long long)hi << 32) | (unsigned int)lo;
 }
 
 struct LkCounters {
