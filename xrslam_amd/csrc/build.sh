@@ -23,3 +23,12 @@ done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libxrslam_hip$VAR.so" $OBJS
 echo "built $OUT/libxrslam_hip$VAR.so"
+# headless EuRoC player (host only: XRSLAM.h + zlib), links the library just built
+if [ -z "$VAR" ]; then
+  BIN="$HERE/../bin"; mkdir -p "$BIN"
+  P="$HERE/player/xrslam_player.cpp"
+  if [ ! -f "$BIN/xrslam-player" ] || [ -n "$(find "$HERE/player" "$HERE/host" "$HERE/../../include" -maxdepth 1 -newer "$BIN/xrslam-player" | head -1)" ] || [ "$OUT/libxrslam_hip.so" -nt "$BIN/xrslam-player" ]; then
+    g++ -O2 -std=c++17 -Wall -I"$HERE/../../include" -I"$HERE/player" "$P" -o "$BIN/xrslam-player" -L"$OUT" -lxrslam_hip -lz -Wl,-rpath,'$ORIGIN/../lib'
+    echo "built $BIN/xrslam-player"
+  fi
+fi
