@@ -22,8 +22,11 @@ def seq():
     return scene.make_sequence(n_frames=N_FRAMES, seed=1)
 
 
-def _run(lib_path, seq):
-    s = runner.Session(lib_path, seq)
+STRESS_YAML = os.path.join(ROOT, "configs", "stress_slam_300.yaml")
+
+
+def _run(lib_path, seq, slam_yaml=None):
+    s = runner.Session(lib_path, seq, slam_yaml=slam_yaml) if slam_yaml else runner.Session(lib_path, seq)
     while s.step():
         assert not s.error(), s.error()
     s.flush()
@@ -68,5 +71,23 @@ def test_gpu_pipeline_matches_cpu_reference(seq, oracle_run):
     assert counts_h == counts_o                   # identical discrete decisions
     assert poses_h.shape == poses_o.shape
     np.testing.assert_allclose(poses_h[:, 0], poses_o[:, 0], rtol=0, atol=0)
+    np.testing.assert_allclose(poses_h[:, 1:], poses_o[:, 1:], rtol=1e-4, atol=1e-6)
+    assert runner.ate_rmse(list(poses_h), seq) < 0.03
+
+
+@pytest.mark.gpu
+def test_gpu_pipeline_matches_cpu_reference_stress_config():
+    """BASELINE config 3 (300 features, 15-keyframe window): the reduced system outgrows the LDS triangle (the
+    factorisation runs in the global buffer), marginalisation starts once 15 keyframes are in the window."""
+    from xrslam_amd import _lib
+    if not os.path.exists(ORACLE_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    seq = scene.make_sequence(n_frames=100, seed=3)
+    poses_o, counts_o = _run(ORACLE_LIB, seq, STRESS_YAML)
+    poses_h, counts_h = _run(_lib.LIB_PATH, seq, STRESS_YAML)
+    assert counts_h == counts_o
+    assert counts_o[4] >= 8 and counts_o[3] >= 1          # keyframes, marginalisations
+    assert poses_h.shape == poses_o.shape
     np.testing.assert_allclose(poses_h[:, 1:], poses_o[:, 1:], rtol=1e-4, atol=1e-6)
     assert runner.ate_rmse(list(poses_h), seq) < 0.03
