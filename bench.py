@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=90,
                     help="frames of the bounded CPU-reference sample (0 = skip); the first 36 only seed the window")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the KLT kernels")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl == RCCL); 'gloo' lets two "
+                    "ranks share one GPU when the multi-process path is exercised on a single-GPU box")
     args = ap.parse_args()
     if args.warmup < 40:
         raise SystemExit("--warmup must be >= 40 so that window initialisation (36 frames) is not timed")
@@ -53,10 +55,11 @@ def main():
     from xrslam_amd import _lib
     from xrslam_amd.harness import runner, scene
     from xrslam_amd.harness.dist import RunGroup
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    group = RunGroup()                      # one process per GPU; "nccl" == RCCL over xGMI
+    device_index = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()   # == LOCAL_RANK on a full node
+    torch.cuda.set_device(device_index)
+    group = RunGroup(backend=args.backend)  # one process per GPU; "nccl" == RCCL over xGMI
     rank, local_rank, world = group.rank, group.local_rank, group.world
-    _lib.set_device(local_rank)
+    _lib.set_device(device_index)
 
     n_frames = args.warmup + args.steps
     seq = scene.make_sequence(n_frames=n_frames + 1, seed=1 + rank)
