@@ -407,8 +407,12 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
         }
         XR_HIP(hipEventRecord(e0, s));
     }
-    hipLaunchKernelGGL(kb_solve_try, dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
-                       wide_trials(d) ? 1 : 0);
+    if (d.M + d.MR <= 320 && d.na <= 64)
+        hipLaunchKernelGGL(kb_solve_try<256>, dim3(1), dim3(256), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
+                           wide_trials(d) ? 1 : 0);
+    else
+        hipLaunchKernelGGL(kb_solve_try<512>, dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
+                           wide_trials(d) ? 1 : 0);
     XR_HIP(hipGetLastError());
     if (c->profiling) {
         XR_HIP(hipEventRecord(e1, s));
@@ -488,7 +492,8 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
     XR_HIP(hipHostMalloc(&c->h_ctl, sizeof(BaCtl), hipHostMallocDefault));
     XR_HIP(hipHostMalloc(&c->h_seq, 64, hipHostMallocDefault));
     *c->h_seq = 0;
-    XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+    XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<512>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+    XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<256>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_chol, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     // pre-size for the advertised maxima

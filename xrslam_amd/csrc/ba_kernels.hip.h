@@ -1498,8 +1498,12 @@ __global__ __launch_bounds__(256) void kb_cost_prepare(BaDims d, BaPtrs p) {
 
 // reduced-system solve followed by the trust-region trials, one workgroup
 // wide_trials: a rejected first trial hands over to kb_trials_wide (large problems) instead of looping in here
-__global__ __launch_bounds__(512) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int use_lds,
-                                                    int after_linearisation, int seq, int wide_trials) {
+// NT = workgroup size.  The trial code holds whole IMU records and reprojection chains in registers: at 512 threads
+// (256 VGPRs each) it spills ~190 registers to scratch memory, at 256 threads it gets 512 registers and spills
+// nothing -- small problems (one observation per thread either way) run the 256-thread instance.
+template <int NT>
+__global__ __launch_bounds__(NT) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int use_lds,
+                                                   int after_linearisation, int seq, int wide_trials) {
     extern __shared__ double lds[];   // max(solve_block's region, try_block's staging)
     solve_block(d, p, use_lds, lds);
     __syncthreads();
