@@ -116,6 +116,7 @@ typedef struct xrhip_klt_stats {
     long long lk_templates;    /* (dir,point,level) templates extracted */
     long long lk_iterations;   /* LK iterations executed */
     long long lk_points;       /* points submitted to track */
+    long long detect_full_list;   /* detections that fell back from the strongest-candidate block to the full list */
 } xrhip_klt_stats;
 int xrhip_klt_set_profiling(xrhip_klt *ctx, int enable);
 int xrhip_klt_get_stats(xrhip_klt *ctx, xrhip_klt_stats *out, int reset);

@@ -111,6 +111,34 @@ def test_detect_and_track_parity_synthetic(mods, w, h, n, seed):
     np.testing.assert_array_equal(kp2_h, kp2_o)
 
 
+def test_detect_paths_prefetch_and_full_list_fallback(mods):
+    """The corner pass has three routes to the same answer: launched by detect(), prefetched behind a tracking launch,
+    and -- when the greedy spacing pass exhausts the strongest candidates before it has max_points corners -- the
+    fallback to the full candidate list.  All must equal the oracle."""
+    ko, klt = mods
+    w, h = 752, 480
+    g = np.full((h, w), 110, np.uint8)
+    g[90:390, 200:500] = noise_image(300, 300, seed=77)          # > 1024 NMS survivors packed into 300 x 300 px
+    g2 = warp_affine(g, np.eye(2), np.array([1.5, 0.5]))
+    ctx, HA, HB, OA, OB = _pair(ko, klt, g, g2)
+    want = OA.detect_keypoints(np.zeros((0, 2)), 1000, 20.0)      # asks for more corners than 20 px spacing allows
+    before = ctx.stats().detect_full_list
+    got = HA.detect_keypoints(np.zeros((0, 2)), 1000, 20.0)
+    np.testing.assert_array_equal(got, want)
+    assert 50 < len(want) < 400
+    assert ctx.stats().detect_full_list == before + 1           # the fallback route really ran
+    # prefetch: B's Harris pass rides behind the A -> B tracking launch
+    kp = want[:100]
+    HB.prefetch_detect()
+    nx_h, st_h = HA.track_keypoints(HB, kp, None)
+    nx_o, st_o = OA.track_keypoints(OB, kp, None)
+    np.testing.assert_array_equal(st_h, st_o)
+    np.testing.assert_array_equal(nx_h, nx_o)
+    np.testing.assert_array_equal(HB.detect_keypoints(nx_o[st_o > 0], 150, 20.0), OB.detect_keypoints(nx_o[st_o > 0], 150, 20.0))
+    # and again without a hint on the same image: same result
+    np.testing.assert_array_equal(HB.detect_keypoints(nx_o[st_o > 0], 150, 20.0), OB.detect_keypoints(nx_o[st_o > 0], 150, 20.0))
+
+
 def test_plain_lk_parity_including_failures(mods):
     ko, klt = mods
     g = noise_image(752, 480, seed=41)

@@ -459,6 +459,7 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
     }
     if (need_all) {
         HostProfScope hp_fb(12, "detect: full candidate list fallback");
+        c->stats.detect_full_list += 1;
         XR_HIP(hipMemcpyAsync(c->h_cand, c->cand, sizeof(HarrisCand) * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
         XR_HIP(hipStreamSynchronize(c->stream));
         corners = select_from(c->h_cand, c->h_cand + nc);

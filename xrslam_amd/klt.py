@@ -12,7 +12,8 @@ from ._lib import check
 class KltStats(C.Structure):
     _fields_ = [("ms_preprocess", C.c_double), ("ms_track", C.c_double), ("ms_detect", C.c_double),
                 ("n_preprocess", C.c_longlong), ("n_track", C.c_longlong), ("n_detect", C.c_longlong),
-                ("lk_templates", C.c_longlong), ("lk_iterations", C.c_longlong), ("lk_points", C.c_longlong)]
+                ("lk_templates", C.c_longlong), ("lk_iterations", C.c_longlong), ("lk_points", C.c_longlong),
+                ("detect_full_list", C.c_longlong)]
 
 
 def _p(a):
@@ -134,6 +135,10 @@ class HipImage:
 
     def release_image_buffer(self):
         check(L().xrhip_image_release(self._h))
+
+    def prefetch_detect(self):
+        """Hint: detect_keypoints will follow; the Harris pass is queued behind the next tracking launch onto this image."""
+        check(L().xrhip_image_prefetch_detect(self._h))
 
     def detect_keypoints(self, existing, max_points, min_dist):
         existing = np.ascontiguousarray(existing, dtype=np.float64).reshape(-1, 2)
