@@ -131,6 +131,44 @@ struct FrameIdLess {
     bool operator()(const Frame *a, const Frame *b) const { return a->id < b->id; }
 };
 
+// The observation list of a track (reference: std::map<Frame*, size_t, compare<Frame*>>, track.h).  A track is seen
+// in a dozen frames at most, so the ordered map is a flat vector sorted by frame id: same iteration order and
+// interface subset, no node allocation per observation (tracks gain ~150 observations per frame).
+class FrameRefs {
+  public:
+    using value_type = std::pair<Frame *, size_t>;
+    using const_iterator = std::vector<value_type>::const_iterator;
+    const_iterator begin() const { return v_.begin(); }
+    const_iterator end() const { return v_.end(); }
+    size_t size() const { return v_.size(); }
+    bool empty() const { return v_.empty(); }
+    const_iterator find(Frame *f) const {
+        auto it = lower(f);
+        return (it != v_.end() && !FrameIdLess()(f, it->first)) ? it : v_.end();
+    }
+    size_t count(Frame *f) const { return find(f) != v_.end() ? 1 : 0; }
+    size_t at(Frame *f) const {
+        auto it = find(f);
+        if (it == v_.end()) throw std::out_of_range("FrameRefs::at");
+        return it->second;
+    }
+    size_t &operator[](Frame *f) {
+        auto it = v_.begin() + (lower(f) - v_.begin());
+        if (it == v_.end() || FrameIdLess()(f, it->first)) it = v_.insert(it, value_type(f, 0));
+        return it->second;
+    }
+    void erase(Frame *f) {
+        auto it = find(f);
+        if (it != v_.end()) v_.erase(v_.begin() + (it - v_.begin()));
+    }
+
+  private:
+    const_iterator lower(Frame *f) const {
+        return std::lower_bound(v_.begin(), v_.end(), f, [](const value_type &a, Frame *b) { return FrameIdLess()(a.first, b); });
+    }
+    std::vector<value_type> v_;
+};
+
 struct LandmarkState {
     double inv_depth = 0, reprojection_error = 0;
 };
@@ -143,7 +181,7 @@ class Track {
     Map *map = nullptr;
     LandmarkState landmark;
     size_t m_life = 0;
-    std::map<Frame *, size_t, FrameIdLess> keypoint_refs;
+    FrameRefs keypoint_refs;
 
     bool &tag(TrackTag t) { return tags[t]; }
     bool tag(TrackTag t) const { return tags[t]; }
