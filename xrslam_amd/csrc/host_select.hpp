@@ -101,7 +101,9 @@ inline std::vector<int> greedy_min_distance(NextFn next, int w, int h, double mi
     }
     const int cell = (int)std::lrint(min_distance);
     const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
-    std::vector<std::vector<int>> grid((size_t)gw * gh);
+    // cell -> chain of accepted corners (newest first); the spacing test does not depend on the visiting order
+    std::vector<int> head((size_t)gw * gh, -1), next_in_cell;
+    next_in_cell.reserve(max_corners > 0 ? (size_t)max_corners : 256);
     const double md2 = min_distance * min_distance;
     while (next(idx)) {
         const int y = idx / w, x = idx - y * w;
@@ -111,7 +113,8 @@ inline std::vector<int> greedy_min_distance(NextFn next, int w, int h, double mi
         bool good = true;
         for (int yy = y1; yy <= y2 && good; ++yy)
             for (int xx = x1; xx <= x2 && good; ++xx)
-                for (int other : grid[(size_t)yy * gw + xx]) {
+                for (int k = head[(size_t)yy * gw + xx]; k >= 0; k = next_in_cell[k]) {
+                    const int other = out[k];
                     const float dx = (float)(x - other % w), dy = (float)(y - other / w);
                     if ((double)(dx * dx + dy * dy) < md2) {
                         good = false;
@@ -119,7 +122,8 @@ inline std::vector<int> greedy_min_distance(NextFn next, int w, int h, double mi
                     }
                 }
         if (good) {
-            grid[(size_t)yc * gw + xc].push_back(idx);
+            next_in_cell.push_back(head[(size_t)yc * gw + xc]);
+            head[(size_t)yc * gw + xc] = (int)out.size();
             out.push_back(idx);
             if (max_corners > 0 && (int)out.size() == max_corners) break;
         }
