@@ -80,6 +80,8 @@ struct IdSource {
 class Frame {
   public:
     size_t id = 0;
+    unsigned long ba_gen = 0;   // problem-assembly scratch (BaBuilder): generation stamp and index in that problem
+    int ba_index = -1;
     bool tags[FT_COUNT] = {false, false, false, false};
     Map *map = nullptr;
     Intrinsics K;
@@ -176,6 +178,8 @@ struct LandmarkState {
 class Track {
   public:
     size_t id = 0;
+    unsigned long ba_gen = 0;   // see Frame::ba_gen
+    int ba_index = -1;
     bool tags[TT_COUNT] = {false, false, false, false, true, false, false};   // TT_STATIC set (track.cpp:8)
     size_t map_index = 0;
     Map *map = nullptr;

@@ -66,6 +66,7 @@ struct Pipeline {
     std::vector<xrhip_image *> image_pool;
     double noise36[36];
     StageTimes times;
+    unsigned long ba_generation = 0;   // BaBuilder instances stamp frames / tracks with it
 
     explicit Pipeline(const Config &c) : config(c) {
         hip_check(xrhip_klt_create((int)c.cam_resolution[0], (int)c.cam_resolution[1],
@@ -305,36 +306,42 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
 // runs xrhip_ba_solve; states are written back in place.
 class BaBuilder {
   public:
-    explicit BaBuilder(Pipeline &P) : P_(P) {}
+    // Frame / track -> problem index: stamped on the object with this builder's generation number instead of a
+    // hash map (a problem touches ~150 tracks; two problems per frame)
+    explicit BaBuilder(Pipeline &P) : P_(P), gen_(++P.ba_generation) {
+        obs_tgt_.reserve(2048);
+        obs_ref_.reserve(2048);
+        obs_lm_.reserve(2048);
+        obs_zt_.reserve(3 * 2048);
+        obs_zr_.reserve(3 * 2048);
+        tracks_.reserve(512);
+        lfix_.reserve(512);
+    }
     int frame_index(Frame *f, bool as_parameter, bool with_motion = true) {
-        auto it = fidx_.find(f);
-        if (it == fidx_.end()) {
-            int i = (int)frames_.size();
-            fidx_[f] = i;
+        if (f->ba_gen != gen_) {
+            f->ba_gen = gen_;
+            f->ba_index = (int)frames_.size();
             frames_.push_back(f);
             fix_.push_back(XRHIP_FIX_POSE | XRHIP_FIX_MOTION);
-            it = fidx_.find(f);
         }
         if (as_parameter) {
             uint8_t fx = 0;
             if (f->tag(FT_FIX_POSE)) fx |= XRHIP_FIX_POSE;
             if (!with_motion || f->tag(FT_FIX_MOTION)) fx |= XRHIP_FIX_MOTION;
-            fix_[it->second] = fx;
+            fix_[f->ba_index] = fx;
         }
-        return it->second;
+        return f->ba_index;
     }
     void add_frame_states(Frame *f, bool with_motion = true) { frame_index(f, true, with_motion); }
     int landmark_index(Track *t, bool as_parameter) {
-        auto it = lidx_.find(t);
-        if (it == lidx_.end()) {
-            int i = (int)tracks_.size();
-            lidx_[t] = i;
+        if (t->ba_gen != gen_) {
+            t->ba_gen = gen_;
+            t->ba_index = (int)tracks_.size();
             tracks_.push_back(t);
             lfix_.push_back(1);
-            it = lidx_.find(t);
         }
-        if (as_parameter) lfix_[it->second] = 0;
-        return it->second;
+        if (as_parameter) lfix_[t->ba_index] = 0;
+        return t->ba_index;
     }
     void add_track_states(Track *t) { landmark_index(t, true); }
     // ReprojectionErrorFactor (parameters: tgt pose, ref pose, inverse depth)
@@ -480,8 +487,7 @@ class BaBuilder {
         push3(obs_zr_, zr);
     }
     Pipeline &P_;
-    std::unordered_map<Frame *, int> fidx_;
-    std::unordered_map<Track *, int> lidx_;
+    unsigned long gen_;
     std::vector<Frame *> frames_;
     std::vector<Track *> tracks_;
     std::vector<uint8_t> fix_, lfix_;
