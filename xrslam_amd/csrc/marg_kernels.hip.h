@@ -374,31 +374,55 @@ __global__ __launch_bounds__(512) void km_chol(const int *__restrict__ sup_n, in
         const int i = e / R, j = e - i * R;
         sqrt_info[e] = (j >= i) ? Lp[tri_idx(j, i)] : 0.0;
     }
-    // inverse iteration: 1 / |A^-1 x| for unit x is an upper bound of lambda_min that converges to it
-    for (int i = tid; i < R; i += nt) x[i] = 1.0 + 0.5 * sin(1.7 * i + 0.3);
-    __syncthreads();
+    // Guard of the fast path: every eigenvalue must lie above the reference's 1e-8 clamp.  When a second triangle
+    // fits in LDS the bound is rigorous and cheap: trace(A^-1) = |L^-1|_F^2 = sum 1/lambda_i >= 1/lambda_min, so
+    // lambda_min >= 1 / trace(A^-1); column j of L^-1 is a forward substitution done by thread j.  Otherwise fall
+    // back to inverse iteration (1 / |A^-1 x| for unit x is an upper bound of lambda_min that converges to it) and
+    // demand a 100x margin.
     double lam = 0;
-    for (int it = 0; it < 12; ++it) {
-        double n2 = 0;
-        for (int i = tid; i < R; i += nt) n2 += x[i] * x[i];
-        n2 = block_sum(n2, scratch);
-        const double inv = 1.0 / sqrt(n2);
-        for (int i = tid; i < R; i += nt) y[i] = x[i] * inv;
-        __syncthreads();
-        trsv_lower(Lp, R, y);
-        trsv_lower_t(Lp, R, y);
-        double m2 = 0;
-        for (int i = tid; i < R; i += nt) {
-            m2 += y[i] * y[i];
-            x[i] = y[i];
+    bool rigorous = false;
+    if (2 * ((R + 1) & ~1) + R * (R + 1) <= lds_doubles) {
+        rigorous = true;
+        double *X = Lp + R * (R + 1) / 2;   // column-major packed: column j holds rows j .. R-1
+        double tr = 0;
+        for (int j = tid; j < R; j += nt) {
+            double *xc = X + (size_t)j * R - (size_t)j * (j - 1) / 2 - j;   // xc[i], i >= j
+            for (int i = j; i < R; ++i) {
+                double sacc = (i == j) ? 1.0 : 0.0;
+                const double *Li = Lp + tri_idx(i, 0);
+                for (int k = j; k < i; ++k) sacc -= Li[k] * xc[k];
+                const double v = sacc / Li[i];
+                xc[i] = v;
+                tr += v * v;
+            }
         }
-        m2 = block_sum(m2, scratch);
-        lam = 1.0 / sqrt(m2);
+        tr = block_sum(tr, scratch);
+        lam = 1.0 / tr;
+    } else {
+        for (int i = tid; i < R; i += nt) x[i] = 1.0 + 0.5 * sin(1.7 * i + 0.3);
         __syncthreads();
+        for (int it = 0; it < 12; ++it) {
+            double n2 = 0;
+            for (int i = tid; i < R; i += nt) n2 += x[i] * x[i];
+            n2 = block_sum(n2, scratch);
+            const double inv = 1.0 / sqrt(n2);
+            for (int i = tid; i < R; i += nt) y[i] = x[i] * inv;
+            __syncthreads();
+            trsv_lower(Lp, R, y);
+            trsv_lower_t(Lp, R, y);
+            double m2 = 0;
+            for (int i = tid; i < R; i += nt) {
+                m2 += y[i] * y[i];
+                x[i] = y[i];
+            }
+            m2 = block_sum(m2, scratch);
+            lam = 1.0 / sqrt(m2);
+            __syncthreads();
+        }
     }
     if (tid == 0) {
         lam_est[0] = lam;
-        status[3] = (isfinite(lam) && lam > 1.0e-6) ? 0 : 1;
+        status[3] = (isfinite(lam) && lam > (rigorous ? 1.0e-8 : 1.0e-6)) ? 0 : 1;
     }
 }
 
