@@ -800,6 +800,7 @@ int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_s
     hipLaunchKernelGGL(km_omega, dim3((std::max(d.L, 1) + 255) / 256), dim3(256), 0, s, d, p);
     const int tiles = d.PF / 16;
     hipLaunchKernelGGL(kb_schur_mfma, dim3(tiles * tiles), dim3(256), 0, s, d, p);
+    hipLaunchKernelGGL(km_wog, dim3((6 * d.F + 63) / 64), dim3(256), 0, s, d, p);
     hipLaunchKernelGGL(km_permute, dim3((N * N + 255) / 256), dim3(256), 0, s, d, p, M->victim, Hm, bm);
     hipLaunchKernelGGL(km_victim, dim3(1), dim3(256), 0, s, N, Hm, T2, dst);
     hipLaunchKernelGGL(km_complement, dim3((R * R + 255) / 256), dim3(256), 0, s, N, Hm, bm, T2, A, bp);

@@ -28,6 +28,9 @@ __global__ __launch_bounds__(256) void km_omega(BaDims d, BaPtrs p) {
 }
 
 // Hm [N x N] (N = 15K) = permuted (Hpp - T on the pose dofs); bm = permuted (gp - W^T (gl/hll)).
+// wog = W^T (omega gl): the wide column pass of kb_schur_aux (role 1) on its own
+__global__ __launch_bounds__(256) void km_wog(BaDims d, BaPtrs p) { solve_aux_block(d, p, aux_quad_blocks_n(d.n, d.L) + (int)blockIdx.x); }
+
 __global__ __launch_bounds__(256) void km_permute(BaDims d, BaPtrs p, int victim, double *__restrict__ Hm,
                                                   double *__restrict__ bm) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -41,15 +44,7 @@ __global__ __launch_bounds__(256) void km_permute(BaDims d, BaPtrs p, int victim
     if (ka < 6 && kb < 6) v -= p.T[(size_t)(6 * fa + ka) * d.PF + 6 * fb + kb];
     const int pa = 15 * pfa + ka, pb = 15 * pfb + kb;
     Hm[(size_t)pa * n + pb] = v;
-    if (b == 0) {
-        double g = p.gp[a];
-        if (ka < 6) {
-            double s = 0;
-            for (int l = 0; l < d.L; ++l) s += p.Wt[(size_t)l * d.PF + 6 * fa + ka] * (p.omega[l] * p.gl[l]);
-            g -= s;
-        }
-        bm[pa] = g;
-    }
+    if (b == 0) bm[pa] = p.gp[a] - (ka < 6 ? p.wog[6 * fa + ka] : 0.0);   // wog = W^T (omega gl), from km_wog
 }
 
 // In-LDS inverse of a 15x15 matrix by Gauss-Jordan with partial pivoting; any workgroup size >= 64, all threads
@@ -163,17 +158,15 @@ __global__ __launch_bounds__(512) void km_support(int R, const double *__restric
                                                   int *__restrict__ sup_idx, int *__restrict__ sup_n,
                                                   double *__restrict__ As, double *__restrict__ bs) {
     __shared__ int flags[512], pos[512], total;
-    const int tid = threadIdx.x;
-    int f = 0;
-    if (tid < R) {
-        const double *row = A + (size_t)tid * R;
-        for (int j = 0; j < R; ++j)
-            if (row[j] != 0.0) {
-                f = 1;
-                break;
-            }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    flags[tid] = 0;
+    __syncthreads();
+    for (int i = wave; i < R; i += nw) {   // one wavefront per row, lanes across the columns
+        const double *row = A + (size_t)i * R;
+        int nz = 0;
+        for (int j = lane; j < R; j += 64) nz |= (row[j] != 0.0) ? 1 : 0;
+        if (__any(nz) && lane == 0) flags[i] = 1;
     }
-    flags[tid] = f;
     __syncthreads();
     if (tid == 0) {
         int c = 0;
