@@ -172,6 +172,8 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
         if (k < 6 ? !(P->frame_fix[f] & XRHIP_FIX_POSE) : !(P->frame_fix[f] & XRHIP_FIX_MOTION)) act_idx.push_back(a);
     }
     d.na = (int)act_idx.size();
+    std::vector<int> act_inv((size_t)15 * F, -1);
+    for (size_t i = 0; i < act_idx.size(); ++i) act_inv[act_idx[i]] = (int)i;
     d.nla = 0;
     for (int l = 0; l < L; ++l) d.nla += lact[l] ? 1 : 0;
     d.lm_rows = d.Lp;   // xrhip_ba_solve drops the landmark rows when no landmark is free
@@ -231,6 +233,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     const size_t o_rfs = put(rotf_start.data(), sizeof(int) * (F + 1)), o_rfi = put(rotf_items.data(), sizeof(int) * MR);
     const size_t o_imuf = put(imuf.data(), sizeof(int) * 2 * F), o_prf = put(priorf.data(), sizeof(int) * F);
     const size_t o_act = put(act_idx.data(), sizeof(int) * act_idx.size());
+    const size_t o_ainv = put(act_inv.data(), sizeof(int) * act_inv.size());
     const size_t o_ctl = put(&ctl, sizeof(ctl));
     const size_t in_bytes = A.used + 256;
 
@@ -305,6 +308,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     p.imuf = (const int *)(I + o_imuf);
     p.priorf = (const int *)(I + o_prf);
     p.act_idx = (const int *)(I + o_act);
+    p.act_inv = (const int *)(I + o_ainv);
     p.Hv = (double *)(W + w_Hv);
     p.gv = (double *)(W + w_gv);
     p.orec = (double *)(W + w_orec);
@@ -387,8 +391,9 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
     hipStream_t s = c->stream;
     if (prepare) hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);
     const int tiles = d.PF / 16;
-    hipLaunchKernelGGL(kb_schur_aux, dim3(d.nla ? tiles * tiles + aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64
-                                                : aux_quad_blocks_n(d.n, d.L)),
+    const int nrest = (d.na * d.na + 255) / 256;   // blocks that write the Schur-free entries of the reduced system
+    hipLaunchKernelGGL(kb_schur_aux, dim3(nrest + (d.nla ? tiles * tiles + aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64
+                                                        : aux_quad_blocks_n(d.n, d.L))),
                        dim3(256), 0, s, d, p);
     size_t lds = 0;
     int use_lds = 1;

@@ -103,6 +103,7 @@ struct BaPtrs {
     const int *imuf;                 // [F][2]: imu factor with j == f, imu factor with i == f (or -1)
     const int *priorf;               // [F]: index in prior_frames or -1
     const int *act_idx;              // [na] free frame dofs (indices into [0, 15F)), ascending
+    const int *act_inv;              // [15F] inverse of act_idx (-1: dof is constant)
     double *Hv, *gv;                 // [F][F][36] reprojection blocks, [F][6] reprojection gradient
     // linearisation products
     double *orec, *ocost;            // [M][28], [M]
@@ -636,7 +637,9 @@ __global__ __launch_bounds__(256) void kb_prepare(BaDims d, BaPtrs p) { prepare_
 // D: col = lane&15, row = (lane>>4) + 4*reg.
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void schur_tile_block(const BaDims &d, const BaPtrs &p, int tile) {
+// emit_s: also write the pose-pose entries of the reduced system  S = sp (Hpp - T) sp + mu D^2  (lower triangle,
+// packed over the active dofs) into Sred -- the solve kernel then only copies a contiguous block into LDS.
+__device__ __forceinline__ void schur_tile_block(const BaDims &d, const BaPtrs &p, int tile, bool emit_s = false) {
     __shared__ double red[4][256];
     const int tiles = d.PF / 16;
     const int ti = tile / tiles, tj = tile - ti * tiles;
@@ -659,6 +662,31 @@ __device__ __forceinline__ void schur_tile_block(const BaDims &d, const BaPtrs &
     const double s = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
     const int row = e >> 4, col = e & 15;
     p.T[(size_t)(16 * ti + row) * d.PF + 16 * tj + col] = s;
+    if (emit_s) {
+        const int pa = 16 * ti + row, pb = 16 * tj + col;
+        if (pa < 6 * d.F && pb < 6 * d.F) {
+            const int a = 15 * (pa / 6) + pa % 6, b = 15 * (pb / 6) + pb % 6;
+            const int ia = p.act_inv[a], ib = p.act_inv[b];
+            if (ia >= 0 && ib >= 0 && ib <= ia) {
+                double v = (p.Hpp[(size_t)a * d.n + b] - s) * (p.sp[a] * p.sp[b]);
+                if (a == b) v += p.ctl->mu * p.diagD[a] * p.diagD[a];
+                p.Sred[tri_idx(ia, ib)] = v;
+            }
+        }
+    }
+}
+// the entries of S that carry no Schur term (a velocity / bias dof on either side, or no free landmark at all)
+__device__ __forceinline__ void reduced_rest_block(const BaDims &d, const BaPtrs &p, int blk) {
+    const int e = blk * 256 + (int)threadIdx.x;
+    if (e >= d.na * d.na) return;
+    const int i = e / d.na, j = e - i * d.na;
+    if (j > i) return;
+    const int a = p.act_idx[i], b = p.act_idx[j];
+    const int ka = a % 15, kb = b % 15;
+    if (d.nla && ka < 6 && kb < 6) return;   // written by the Schur tile that owns it
+    double v = p.Hpp[(size_t)a * d.n + b] * (p.sp[a] * p.sp[b]);
+    if (a == b) v += p.ctl->mu * p.diagD[a] * p.diagD[a];
+    p.Sred[tri_idx(i, j)] = v;
 }
 __global__ __launch_bounds__(256) void kb_schur_mfma(BaDims d, BaPtrs p) { schur_tile_block(d, p, blockIdx.x); }
 
@@ -781,10 +809,21 @@ __device__ __forceinline__ void solve_aux_block(const BaDims &d, const BaPtrs &p
 }
 // Schur tiles and the solve's auxiliary passes in one launch: [tiles^2 | aux blocks]
 // (without free landmarks there is no Schur complement and no W^T (omega gl): only the quadratic-form blocks run)
+// layout of the grid: [Schur tiles | rest of S | aux blocks]
 __global__ __launch_bounds__(256) void kb_schur_aux(BaDims d, BaPtrs p) {
     const int t2 = d.nla ? (d.PF / 16) * (d.PF / 16) : 0;
-    if ((int)blockIdx.x < t2) schur_tile_block(d, p, blockIdx.x);
-    else solve_aux_block(d, p, (int)blockIdx.x - t2);
+    const int nrest = (d.na * d.na + 255) / 256;
+    int blk = blockIdx.x;
+    if (blk < t2) {
+        schur_tile_block(d, p, blk, true);
+        return;
+    }
+    blk -= t2;
+    if (blk < nrest) {
+        reduced_rest_block(d, p, blk);
+        return;
+    }
+    solve_aux_block(d, p, blk - nrest);
 }
 
 // Reduced camera system + blocked Cholesky + Gauss-Newton / Cauchy quantities.  One workgroup.
@@ -809,18 +848,9 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
     }
     __syncthreads();
     KPROF(0);
-    // ---- S = sp (Hpp - T) sp + mu D^2 over the free dofs, rhs = sp (gp - W^T (omega gl))
-    for (int e = tid; e < na * na; e += nt) {
-        const int i = e / na, j = e - i * na;
-        if (j > i) continue;
-        const int a = p.act_idx[i], b = p.act_idx[j];
-        double v = p.Hpp[(size_t)a * n + b];
-        const int fa = a / 15, ka = a - 15 * fa, fb = b / 15, kb = b - 15 * fb;
-        if (d.nla && ka < 6 && kb < 6) v -= p.T[(size_t)(6 * fa + ka) * d.PF + 6 * fb + kb];
-        v *= p.sp[a] * p.sp[b];
-        if (a == b) v += mu * p.diagD[a] * p.diagD[a];
-        A[tri_idx(i, j)] = v;
-    }
+    // ---- S = sp (Hpp - T) sp + mu D^2 over the free dofs was written by kb_schur_aux as a packed triangle in Sred
+    if (use_lds)
+        for (int e = tid; e < na * (na + 1) / 2; e += nt) A[e] = p.Sred[e];
     __syncthreads();
     KPROF(1);
 #ifdef XRHIP_KPROF
