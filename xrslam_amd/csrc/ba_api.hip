@@ -564,7 +564,7 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     if (!d.nla) d.lm_rows = 0;
     const double sx = P->sqrt_inv_cov[0], sy = P->sqrt_inv_cov[1];
     hipStream_t s = c->stream;
-    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);
+    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16)), dim3(256), 0, s, d.np, p.pS, p.pLam);
     bool done = false, relinearise = true;
     int mode = 1, iter_seen = 0;
     for (int guard = 0; guard < 4 * (P->max_iterations + 8) && !done; ++guard) {
@@ -648,7 +648,7 @@ int xrhip_ba_debug_linearize(xrhip_ba *c, const xrhip_ba_problem *P, double *H, 
     rc = stage_problem(c, P, d, p, cam, imu);
     if (rc) return rc;
     hipStream_t s = c->stream;
-    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);
+    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16)), dim3(256), 0, s, d.np, p.pS, p.pLam);
     launch_linearize(c, d, p, cam, imu, P->sqrt_inv_cov[0], P->sqrt_inv_cov[1], false);
     XR_HIP(hipGetLastError());
     XR_HIP(hipMemcpyAsync(c->h_ctl, p.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, s));
@@ -800,7 +800,7 @@ int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_s
     int *dst = (int *)(W2 + o_st);
     hipStream_t s = c->stream;
     XR_HIP(hipMemsetAsync(dst, 0, sizeof(int) * 4, s));
-    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3((d.np * d.np + 255) / 256), dim3(256), 0, s, d.np, p.pS, p.pLam);
+    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16)), dim3(256), 0, s, d.np, p.pS, p.pLam);
     launch_linearize(c, d, p, cam, imu, M->sqrt_inv_cov[0], M->sqrt_inv_cov[1], false);
     hipLaunchKernelGGL(km_omega, dim3((std::max(d.L, 1) + 255) / 256), dim3(256), 0, s, d, p);
     const int tiles = d.PF / 16;

@@ -419,14 +419,31 @@ __device__ __forceinline__ void lin_prior_block(const BaDims &d, const BaPtrs &p
     }
 }
 
-// Lam = S^T S (once per prior upload)
+// Lam = S^T S (once per solve with a prior) on the f64 matrix cores: one workgroup per 16x16 tile of Lam, the four
+// wavefronts split the contraction (rows of S) and combine in LDS in a fixed order.
 __global__ __launch_bounds__(256) void kb_prior_lambda(int np, const double *__restrict__ S, double *__restrict__ Lam) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= np * np) return;
-    const int a = e / np, b = e - a * np;
-    double s = 0;
-    for (int i = 0; i < np; ++i) s += S[(size_t)i * np + a] * S[(size_t)i * np + b];
-    Lam[e] = s;
+    __shared__ double red[4][256];
+    const int tiles = (np + 15) / 16;
+    const int ti = blockIdx.x / tiles, tj = blockIdx.x - ti * tiles;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 15, kk = lane >> 4;
+    const int kq = (((np + 3) / 4 + 3) / 4) * 4;   // contraction rows per wavefront, multiple of 4
+    const int ca = 16 * ti + i, cb = 16 * tj + i;
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k = wave * kq; k < (wave + 1) * kq; k += 4) {
+        const int r = k + kk;
+        const double a = (r < np && ca < np) ? S[(size_t)r * np + ca] : 0.0;
+        const double b = (r < np && cb < np) ? S[(size_t)r * np + cb] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(kk + 4 * r) * 16 + i] = acc[r];
+    __syncthreads();
+    const int e = threadIdx.x;
+    const double v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    const int row = 16 * ti + (e >> 4), col = 16 * tj + (e & 15);
+    if (row < np && col < np) Lam[(size_t)row * np + col] = v;
 }
 
 // -------------------------------------------------------------------- landmarks
