@@ -382,16 +382,23 @@ __device__ __forceinline__ double prior_cost_block(const BaDims &d, const BaPtrs
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     double c = 0;
-    for (int i = wave; i < d.np; i += nw) {
-        const double *row = p.pS + (size_t)i * d.np;
-        double s = 0;
-        for (int j = lane; j < d.np; j += 64) s += row[j] * sh[j];
-        s = wave_sum(s);
-        if (lane == 0) {
-            s += p.pinfo[i];
-            if (r_out) r_out[i] = s;
-            c += s * s;
+    for (int i0 = 4 * wave; i0 < d.np; i0 += 4 * nw) {   // four rows per wavefront in flight
+        double s4[4] = {0, 0, 0, 0};
+        for (int j = lane; j < d.np; j += 64) {
+            const double x = sh[j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s4[r] += p.pS[(size_t)min(i0 + r, d.np - 1) * d.np + j] * x;
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s4[r] = wave_sum(s4[r]);
+        if (lane == 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (i0 + r < d.np) {
+                    const double t = s4[r] + p.pinfo[i0 + r];
+                    if (r_out) r_out[i0 + r] = t;
+                    c += t * t;
+                }
     }
     return 0.5 * block_sum(c, scratch);
 }
@@ -411,10 +418,20 @@ __device__ __forceinline__ void lin_prior_block(const BaDims &d, const BaPtrs &p
     const double c = prior_cost_block(d, p, p.state, sh, scratch, p.pr);
     if (threadIdx.x == 0) p.pcost[0] = c;
     __syncthreads();
-    // t = S^T r  (thread per column: consecutive threads read consecutive addresses)
+    // t = S^T r  (thread per column: consecutive threads read consecutive addresses; eight rows per round trip)
     for (int j = threadIdx.x; j < d.np; j += blockDim.x) {
         double s = 0;
-        for (int i = 0; i < d.np; ++i) s += p.pS[(size_t)i * d.np + j] * p.pr[i];
+        for (int i0 = 0; i0 < d.np; i0 += 8) {
+            double v[8], r8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = min(i0 + q, d.np - 1);
+                v[q] = p.pS[(size_t)i * d.np + j];
+                r8[q] = (i0 + q < d.np) ? p.pr[i] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q] * r8[q];
+        }
         p.pt[j] = s;
     }
 }
