@@ -568,61 +568,73 @@ __global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restric
             sv3[0] = vv.x; sv3[1] = vv.y; sv3[2] = vv.z;
             sdt = T;
         }
-        // ---- P5
-        if (want_cov || want_jac)
+        // ---- P5 (all lane -> matrix-entry mappings are loop invariants, computed before the sample loop)
+        if (want_cov || want_jac) {
+            // Tm = A cov: entries e0 = tid and (for tid < 17) e1 = tid + 64 of the 9x9 product
+            const int i0 = tid / 9, j0 = tid - 9 * i0;
+            const int e1 = tid + 64, i1 = e1 / 9, j1 = e1 - 9 * i1;
+            const bool has1 = e1 < 81;
+            // cov = Tm A^T + G: lower-triangle entry (li, lj <= li) for tid < 45
+            int li = 0, lj = tid;
+            while (lj > li) {
+                lj -= li + 1;
+                ++li;
+            }
+            const bool low = tid < 45;
+            const int wb = (tid - 46) / 9, wr = (tid - 46) - 9 * wb;
+            const double wnoise = (tid >= 46) ? noise36[18 + 9 * wb + wr] : 0.0;
+            const int jm = tid / 9, ji = (tid % 9) / 3, jj = tid % 3;
             for (int n = 0; n < nc; ++n) {
                 const double h = sDt[n];
+                const double *An = sA[n];
                 if (want_cov) {
-                    // Tm = A cov with A = [E 0 0; P I dt I; V 0 I] (3x3 blocks): three products with the rotation
-                    // rows of cov plus the identity / dt terms, in the order of the dense row sum
-                    for (int e = tid; e < 81; e += 64) {
-                        const int i = e / 9, j = e - 9 * i;
-                        const double *a = sA[n] + 9 * i;
-                        double s2 = (a[0] * cov[0][j] + a[1] * cov[1][j]) + a[2] * cov[2][j];
-                        if (i >= 3 && i < 6) s2 = (s2 + cov[i][j]) + h * cov[i + 3][j];
-                        else if (i >= 6) s2 = s2 + cov[i][j];
-                        Tm[i][j] = s2;
+                    // A = [E 0 0; P I dt I; V 0 I] (3x3 blocks): three products with the rotation rows of cov plus the
+                    // identity / dt terms, in the order of the dense row sum
+                    {
+                        const double *a = An + 9 * i0;
+                        double s2 = (a[0] * cov[0][j0] + a[1] * cov[1][j0]) + a[2] * cov[2][j0];
+                        if (i0 >= 3 && i0 < 6) s2 = (s2 + cov[i0][j0]) + h * cov[i0 + 3][j0];
+                        else if (i0 >= 6) s2 = s2 + cov[i0][j0];
+                        Tm[i0][j0] = s2;
                     }
-                    if (tid >= 46) {
-                        const int e = tid - 46, blk = e / 9, r = e - 9 * blk;
-                        walk += noise36[18 + 9 * blk + r] * h;
+                    if (has1) {
+                        const double *a = An + 9 * i1;
+                        double s2 = (a[0] * cov[0][j1] + a[1] * cov[1][j1]) + a[2] * cov[2][j1];
+                        if (i1 >= 3 && i1 < 6) s2 = (s2 + cov[i1][j1]) + h * cov[i1 + 3][j1];
+                        else if (i1 >= 6) s2 = s2 + cov[i1][j1];
+                        Tm[i1][j1] = s2;
                     }
+                    walk += wnoise * h;
                 }
-                if (want_jac && tid < 45) {
-                    const int m = tid / 9, i = (tid % 9) / 3, j = tid % 3;
+                if (want_jac && low) {
                     const double *Ra = sRa[n], *E = sE[n], *dR = sR[n], *Jr = sJr[n];
                     double radq = 0, edq = 0;   // (dR hat(a) dq_dbg)_ij and (E dq_dbg)_ij
                     for (int k = 0; k < 3; ++k) {
-                        radq += Ra[3 * i + k] * Jac[0][3 * k + j];
-                        edq += E[3 * i + k] * Jac[0][3 * k + j];
+                        radq += Ra[3 * ji + k] * Jac[0][3 * k + jj];
+                        edq += E[3 * ji + k] * Jac[0][3 * k + jj];
                     }
                     double v;
-                    if (m == 1) v = Jac[1][3 * i + j] + h * Jac[3][3 * i + j] - 0.5 * h * h * radq;        // dp_dbg
-                    else if (m == 2) v = Jac[2][3 * i + j] + h * Jac[4][3 * i + j] - 0.5 * h * h * dR[3 * i + j];   // dp_dba
-                    else if (m == 3) v = Jac[3][3 * i + j] - h * radq;                                     // dv_dbg
-                    else if (m == 4) v = Jac[4][3 * i + j] - h * dR[3 * i + j];                            // dv_dba
-                    else v = edq - h * Jr[3 * i + j];                                                      // dq_dbg
-                    Jnew[m][3 * i + j] = v;
+                    if (jm == 1) v = Jac[1][3 * ji + jj] + h * Jac[3][3 * ji + jj] - 0.5 * h * h * radq;        // dp_dbg
+                    else if (jm == 2) v = Jac[2][3 * ji + jj] + h * Jac[4][3 * ji + jj] - 0.5 * h * h * dR[3 * ji + jj];   // dp_dba
+                    else if (jm == 3) v = Jac[3][3 * ji + jj] - h * radq;                                       // dv_dbg
+                    else if (jm == 4) v = Jac[4][3 * ji + jj] - h * dR[3 * ji + jj];                            // dv_dba
+                    else v = edq - h * Jr[3 * ji + jj];                                                         // dq_dbg
+                    Jnew[jm][3 * ji + jj] = v;
                 }
                 __syncthreads();
-                if (want_cov && tid < 45) {
-                    // cov = Tm A^T + G, lower triangle only (one entry per lane), mirrored
-                    int i = 0, j = tid;
-                    while (j > i) {   // tid -> (i, j <= i) of the 9x9 lower triangle
-                        j -= i + 1;
-                        ++i;
-                    }
-                    const double *a = sA[n] + 9 * j;   // row j of A
-                    double s2 = (Tm[i][0] * a[0] + Tm[i][1] * a[1]) + Tm[i][2] * a[2];
-                    if (j >= 3 && j < 6) s2 = (s2 + Tm[i][j]) + Tm[i][j + 3] * h;
-                    else if (j >= 6) s2 = s2 + Tm[i][j];
-                    s2 += sG[n][9 * i + j];
-                    cov[i][j] = s2;
-                    cov[j][i] = s2;
+                if (want_cov && low) {
+                    const double *a = An + 9 * lj;   // row lj of A
+                    double s2 = (Tm[li][0] * a[0] + Tm[li][1] * a[1]) + Tm[li][2] * a[2];
+                    if (lj >= 3 && lj < 6) s2 = (s2 + Tm[li][lj]) + Tm[li][lj + 3] * h;
+                    else if (lj >= 6) s2 = s2 + Tm[li][lj];
+                    s2 += sG[n][9 * li + lj];
+                    cov[li][lj] = s2;
+                    cov[lj][li] = s2;
                 }
-                if (want_jac && tid < 45) Jac[tid / 9][tid % 9] = Jnew[tid / 9][tid % 9];
+                if (want_jac && low) Jac[jm][3 * ji + jj] = Jnew[jm][3 * ji + jj];
                 __syncthreads();
             }
+        }
         __syncthreads();
     }
     // outputs
