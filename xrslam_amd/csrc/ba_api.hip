@@ -353,6 +353,9 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     return XRHIP_OK;
 }
 
+// small problems without a free landmark: assembly, preparation and the reduced system in one workgroup (kb_small_mid)
+static bool small_mid(const BaDims &d) { return d.nla == 0 && d.na <= 16; }   // measured: beyond one free frame the wide launches win
+
 // one linearisation: 3 launches + the cost (and, for the solver, gradient norm + per-solve preparation)
 static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
                              double sy, bool for_solver) {
@@ -360,6 +363,7 @@ static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, cons
     hipLaunchKernelGGL(kb_lin_all, dim3(lin_all_blocks(d.M, d.MR, d.NI)), dim3(256), sizeof(double) * std::max(d.np, 1), s, d, p,
                        cam, imu, sx, sy);
     hipLaunchKernelGGL(kb_landmark_vision, dim3(d.lm_rows + d.F * d.F), dim3(64), 0, s, d, p);
+    if (for_solver && small_mid(d)) return;   // kb_small_mid (launch_solve_try) assembles what the solve reads
     hipLaunchKernelGGL(kb_assemble, dim3((d.n * d.n + 255) / 256), dim3(256), 0, s, d, p);
     if (for_solver) hipLaunchKernelGGL(kb_cost_prepare, dim3(1), dim3(256), 0, s, d, p);
     else hipLaunchKernelGGL(kb_sum_cost, dim3(1), dim3(256), 0, s, d, p);
@@ -389,12 +393,15 @@ static bool wide_trials(const BaDims &d) { return d.M >= 256 && d.F <= 32; }
 static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
                             double sy, bool prepare, int mode, int seq) {
     hipStream_t s = c->stream;
-    if (prepare) hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);
+    const bool mid = small_mid(d);
+    if (mid) hipLaunchKernelGGL(kb_small_mid, dim3(1), dim3(256), 0, s, d, p, prepare ? 0 : 1);
+    if (!mid && prepare) hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);
     const int tiles = d.PF / 16;
     const int nrest = (d.na * d.na + 255) / 256;   // blocks that write the Schur-free entries of the reduced system
-    hipLaunchKernelGGL(kb_schur_aux, dim3(nrest + (d.nla ? tiles * tiles + aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64
-                                                        : aux_quad_blocks_n(d.n, d.L))),
-                       dim3(256), 0, s, d, p);
+    if (!mid)
+        hipLaunchKernelGGL(kb_schur_aux, dim3(nrest + (d.nla ? tiles * tiles + aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64
+                                                            : aux_quad_blocks_n(d.n, d.L))),
+                           dim3(256), 0, s, d, p);
     size_t lds = 0;
     int use_lds = 1;
     int rcl = solve_lds(d, (size_t)c->lds_limit, &lds, &use_lds);

@@ -1761,6 +1761,51 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
     publish_block(d, p, t.status, seq, true);
 }
 
+// Small problems without a free landmark (localize_newframe, refine_subwindow: a handful of free dofs): the three
+// launches between the frame-pair blocks and the solve -- Hessian assembly, cost / gradient norm / preparation, the
+// reduced system + Cauchy quadratic form -- are one workgroup's worth of work and run back to back here.
+// Only what the solve reads is assembled: the active x active entries (+ the gradient), zero diagonals elsewhere.
+__global__ __launch_bounds__(256) void kb_small_mid(BaDims d, BaPtrs p, int relinearised) {
+    __shared__ double scratch[8];
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int n = d.n, na = d.na;
+    if (relinearised) {
+        const bool col0_active = dof_active(p.fix, 0);
+        for (int e = tid; e < na * (na + 1); e += nt) {
+            const int i = e / (na + 1), j = e - i * (na + 1);
+            if (j == na && col0_active) continue;   // the gradient entry rides on column 0, already visited
+            assemble_item(d, p, p.act_idx[i] * n + (j < na ? p.act_idx[j] : 0));
+        }
+        for (int a = tid; a < n; a += nt)
+            if (!dof_active(p.fix, a)) {
+                p.Hpp[(size_t)a * n + a] = 0.0;
+                p.gp[a] = 0.0;
+            }
+        __syncthreads();
+        sum_cost_block(d, p, scratch);
+        __syncthreads();
+        gradmax_block(d, p, scratch);
+    }
+    prepare_block(d, p);
+    __syncthreads();
+    for (int blk = 0; blk * 256 < na * na; ++blk) reduced_rest_block(d, p, blk);
+    double acc = 0;   // Q(g~,g~) over the active dofs (see kb_schur_aux)
+    for (int i = wave; i < na; i += nw) {
+        const int a = p.act_idx[i];
+        const double Da = p.diagD[a], ga = p.sp[a] * (p.gs[a] / (Da * Da));
+        double t = 0;
+        for (int j = lane; j < na; j += 64) {
+            const int b = p.act_idx[j];
+            const double Db = p.diagD[b];
+            t += p.Hpp[(size_t)a * n + b] * (p.sp[b] * (p.gs[b] / (Db * Db)));
+        }
+        acc += ga * t;
+    }
+    acc = block_sum(acc, scratch);
+    const int nbq = aux_quad_blocks_n(n, d.L);
+    for (int i = tid; i < nbq; i += nt) p.partial[i] = (i == 0) ? acc : 0.0;
+}
+
 // The staged problem (a few tens of KB) is pulled from the pinned host arena by the device itself, 16 bytes per
 // lane: a kernel in the solve's own stream starts within a few microseconds, where a copy-engine transfer adds
 // its scheduling latency in front of the first linearisation.
