@@ -388,6 +388,8 @@ static int solve_lds(const BaDims &d, size_t limit, size_t *bytes, int *use_lds)
 // Large problems hand a run of rejected trials to kb_trials_wide (the whole chip costs 8 candidates per launch);
 // for small ones the round trip would cost more than looping inside kb_solve_try.
 static bool wide_trials(const BaDims &d) { return d.M >= 256 && d.F <= 32; }
+// ... and window-sized problems (refine_window) cost even their first trial there, queued right behind the solve
+static bool wide_first(const BaDims &d) { return wide_trials(d) && d.M >= 600 && d.na >= 90; }
 
 // reduced-system solve + trust-region trials: 2 launches (3 when mu changed without a new linearisation)
 static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
@@ -424,8 +426,13 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
                            wide_trials(d) ? 1 : 0);
     else
         hipLaunchKernelGGL(kb_solve_try<512>, dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
-                           wide_trials(d) ? 1 : 0);
+                           wide_first(d) ? 2 : (wide_trials(d) ? 1 : 0));
     XR_HIP(hipGetLastError());
+    if (wide_first(d)) {   // the first trial batch rides right behind the solve: no host round trip in between
+        const size_t wlds = sizeof(double) * (size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np);
+        hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, s, d, p, cam, imu, sx, sy, seq, 1, mode);
+        XR_HIP(hipGetLastError());
+    }
     if (c->profiling) {
         XR_HIP(hipEventRecord(e1, s));
         const double na = d.na;
@@ -592,7 +599,7 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
         for (int wguard = 0; st == ST_NEED_TRIALS && wguard < 64; ++wguard) {   // run of rejected trials, 8 per launch
             const int wseq = ++c->seq;
             const size_t wlds = sizeof(double) * (size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np);
-            hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, s, d, p, cam, imu, sx, sy, wseq);
+            hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, s, d, p, cam, imu, sx, sy, wseq, 0, 0);
             XR_HIP(hipGetLastError());
             rc = wait_mailbox(c, wseq);
             if (rc) return rc;

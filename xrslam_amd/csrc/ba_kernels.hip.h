@@ -1260,7 +1260,8 @@ __device__ __forceinline__ void publish_block(const BaDims &d, const BaPtrs &p, 
 //   ST_DONE      the minimiser terminated
 // `after_linearisation` = this launch directly follows a (re)linearisation or re-solve.
 __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
-                                         double sy, int after_linearisation, int seq, bool wide_after_first, double *sh) {
+                                         double sy, int after_linearisation, int seq, bool wide_after_first, double *sh,
+                                         bool prep_only = false) {
     // sh: LDS, TRY_B * np doubles for the prior deltas of the candidates + TRY_B * NI * 15 for the raw IMU residuals
     // wide_after_first: if the first trial is rejected, hand the following ones to kb_trials_wide (ST_NEED_TRIALS)
     __shared__ double scratch[2 * TRY_B * 8];
@@ -1304,6 +1305,9 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
         __syncthreads();
     }
     KPROF(11);
+    // prep_only: large problems cost every trial, the first included, on the whole chip (kb_trials_wide is already
+    // queued behind this kernel); nothing is published from here
+    if (prep_only) return ST_NEED_TRIALS;
     TrialScalars t;
     trial_load(c, t);
     bool check_gradient = (mode == 1);   // the iteration that led here was successful
@@ -1561,7 +1565,8 @@ __global__ __launch_bounds__(256) void kb_cost_prepare(BaDims d, BaPtrs p) {
 }
 
 // reduced-system solve followed by the trust-region trials, one workgroup
-// wide_trials: a rejected first trial hands over to kb_trials_wide (large problems) instead of looping in here
+// wide_trials: 1 = a rejected first trial hands over to kb_trials_wide instead of looping in here; 2 = every trial,
+// the first included, is costed by kb_trials_wide (queued behind this kernel by the host)
 // NT = workgroup size.  The trial code holds whole IMU records and reprojection chains in registers: at 512 threads
 // (256 VGPRs each) it spills ~190 registers to scratch memory, at 256 threads it gets 512 registers and spills
 // nothing -- small problems (one observation per thread either way) run the 256-thread instance.
@@ -1571,7 +1576,7 @@ __global__ __launch_bounds__(NT) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, 
     extern __shared__ double lds[];   // max(solve_block's region, try_block's staging)
     solve_block(d, p, use_lds, lds);
     __syncthreads();
-    try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, wide_trials != 0, lds);
+    try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, wide_trials != 0, lds, wide_trials == 2);
 }
 
 // The rejected-trial tail of a large solve on the whole chip.  After a rejection the next radii are radius/2,
@@ -1580,7 +1585,10 @@ __global__ __launch_bounds__(NT) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, 
 // block to arrive adds them up in block order, replays the accept / reject decisions exactly like try_block,
 // applies an accepted step and publishes to the host mailbox.  ST_NEED_TRIALS = all WIDE_B rejected, launch again.
 // Dynamic LDS: WIDE_B * (16 F + np) doubles.
-__global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int seq) {
+// first != 0: this launch carries the first trial after a solve (mode = the solve's after_linearisation flag), so it
+// starts with the minimiser's finalize / start-of-iteration step instead of continuing a run of rejections.
+__global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int seq,
+                                                      int first, int mode) {
     extern __shared__ double wl[];
     __shared__ double scratch[4 * WIDE_B * 4];
     __shared__ int s_last;
@@ -1592,7 +1600,18 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
     BaCtl *c = p.ctl;
     TrialScalars t;
     trial_load(c, t);
-    // the batch continues a run of rejections: trial 0 replays the finalize step of its rejected predecessor
+    if (first) {
+        trial_begin(t, mode == 3, mode == 1);
+        if (t.status != ST_RUNNING) {   // terminated / re-solve requested before any trial: every block agrees
+            if (blk == 0) {
+                if (tid == 0) trial_store(c, t);
+                __syncthreads();
+                publish_block(d, p, t.status, seq, true);
+            }
+            return;
+        }
+    }
+    // otherwise the batch continues a run of rejections: trial 0 replays the finalize step of its rejected predecessor
     double ca[WIDE_B], cb[WIDE_B], step_norm[WIDE_B];
 #pragma unroll
     for (int k = 0; k < WIDE_B; ++k) dogleg_point(t, t.radius * (1.0 / (double)(1 << k)), ca[k], cb[k], step_norm[k]);
@@ -1738,7 +1757,7 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
 #ifdef XRHIP_KPROF
         if (tid == 0) p.ctl->prof[19] += 1;
 #endif
-        if (trial_decide(t, k + 1, mcc, tot[4 * k], tot[4 * k + 1], step_norm[k])) accepted = k;
+        if (trial_decide(t, first ? k : k + 1, mcc, tot[4 * k], tot[4 * k + 1], step_norm[k])) accepted = k;
     }
     if (accepted >= 0) {
         for (int e = tid; e < 16 * d.F; e += nt) p.state[e] = cand[(size_t)accepted * 16 * d.F + e];
