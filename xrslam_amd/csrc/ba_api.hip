@@ -421,7 +421,7 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
         }
         XR_HIP(hipEventRecord(e0, s));
     }
-    if (d.M + d.MR <= 320 && d.na <= 64)
+    if (d.M + d.MR <= 640 && d.na <= 64)
         hipLaunchKernelGGL(kb_solve_try<256>, dim3(1), dim3(256), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
                            wide_trials(d) ? 1 : 0);
     else
