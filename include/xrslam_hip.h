@@ -247,6 +247,14 @@ int xrhip_ba_preintegrate_batch(xrhip_ba *ctx, const double *samples, const int 
                                 int n_jobs, const double *noise_cov36, int compute_jacobian, int compute_covariance,
                                 double *out);
 
+/* asynchronous form of the batch: _begin queues the integrations and returns, _end waits for them and copies the
+ * records out.  One batch in flight per context; no other call on the context may use the staging block in between
+ * (xrhip_ba_marginalize does; xrhip_ba_solve does not). */
+int xrhip_ba_preintegrate_begin(xrhip_ba *ctx, const double *samples, const int *sample_begin, const int *sample_count,
+                                const double *t_end, const double *bg, const double *ba, int n_jobs,
+                                const double *noise_cov36, int compute_jacobian, int compute_covariance);
+int xrhip_ba_preintegrate_end(xrhip_ba *ctx, double *out);
+
 /* parity/testing aids (not part of the reference interface): the unreduced normal equations of one
  * linearisation, and the MFMA Schur product kernel on arbitrary inputs. */
 int xrhip_ba_debug_linearize(xrhip_ba *ctx, const xrhip_ba_problem *problem, double *H, double *g, double *hll,

@@ -148,4 +148,18 @@ int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *b
     }
     return 0;
 }
+// asynchronous form: the CPU reference computes at _begin and hands the records over at _end
+static std::vector<double> g_preint_out;
+static int g_preint_rc = 0;
+int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *begin, const int *count, const double *t_end,
+                                const double *bg, const double *ba, int n_jobs, const double *noise36, int jac, int cov) {
+    g_preint_out.assign((size_t)XRHIP_IMU_DIM * n_jobs, 0.0);
+    g_preint_rc = xrhip_ba_preintegrate_batch(c, samples, begin, count, t_end, bg, ba, n_jobs, noise36, jac, cov, g_preint_out.data());
+    return 0;
+}
+int xrhip_ba_preintegrate_end(xrhip_ba *, double *out) {
+    if (g_preint_rc) return g_preint_rc;
+    std::memcpy(out, g_preint_out.data(), sizeof(double) * g_preint_out.size());
+    return 0;
+}
 }

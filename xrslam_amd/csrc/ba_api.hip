@@ -45,6 +45,8 @@ struct xrhip_ba {
     BaCtl *h_ctl = nullptr;   // pinned; doubles as the zero-copy mailbox of kb_solve_try
     int *h_seq = nullptr;     // pinned; sequence number published by kb_solve_try after h_ctl / h_out
     int seq = 0;
+    int preint_pending = 0;            // jobs of the pre-integration batch in flight (begin/end), 0 = none
+    size_t preint_o_out = 0, preint_o_st = 0;
     // optional HIP-event profiling of kb_solve_try
     bool profiling = false;
     struct Timed {
@@ -858,11 +860,12 @@ int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_s
     return XRHIP_OK;
 }
 
-int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *sample_begin, const int *sample_count,
+int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *sample_begin, const int *sample_count,
                                 const double *t_end, const double *bg, const double *ba, int n_jobs,
-                                const double *noise_cov36, int compute_jacobian, int compute_covariance, double *out) {
-    if (!c || !samples || !sample_begin || !sample_count || !t_end || !bg || !ba || !noise_cov36 || !out || n_jobs <= 0)
+                                const double *noise_cov36, int compute_jacobian, int compute_covariance) {
+    if (!c || !samples || !sample_begin || !sample_count || !t_end || !bg || !ba || !noise_cov36 || n_jobs <= 0)
         return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: bad arguments");
+    if (c->preint_pending) return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate_begin: a batch is already in flight");
     int total = 0;
     for (int k = 0; k < n_jobs; ++k) {
         if (sample_count[k] <= 0 || sample_begin[k] < 0) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: empty IMU segment");
@@ -870,7 +873,8 @@ int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *s
     }
     // zero-copy: jobs, samples, noise, results and status live in the pinned staging block, which the kernel
     // addresses directly over the host link -- an integration moves a few hundred bytes in and 2.2 KB out, so
-    // copy-engine round trips (H2D, memset, D2H) would cost several times the kernel itself
+    // copy-engine round trips (H2D, memset, D2H) would cost several times the kernel itself.  Each job's status word
+    // is its completion mailbox.
     const size_t D8 = sizeof(double);
     const size_t b_jobs = sizeof(PreintJob) * n_jobs, b_smp = D8 * 7 * (size_t)total, b_noise = D8 * 36;
     const size_t o_jobs = 0, o_smp = (b_jobs + 255) & ~size_t(255), o_noise = (o_smp + b_smp + 255) & ~size_t(255);
@@ -899,12 +903,40 @@ int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *s
                        (const double *)(Dv + o_smp), (const double *)(Dv + o_noise), compute_jacobian ? 1 : 0,
                        compute_covariance ? 1 : 0, (double *)(Dv + o_out), (int *)(Dv + o_st));
     XR_HIP(hipGetLastError());
-    XR_HIP(hipStreamSynchronize(s));
-    const int *st = (const int *)(H + o_st);
-    for (int k = 0; k < n_jobs; ++k)
-        if (st[k]) return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate: covariance is not positive definite");
-    std::memcpy(out, H + o_out, D8 * XRHIP_IMU_DIM * (size_t)n_jobs);
+    c->preint_pending = n_jobs;
+    c->preint_o_out = o_out;
+    c->preint_o_st = o_st;
     return XRHIP_OK;
+}
+
+int xrhip_ba_preintegrate_end(xrhip_ba *c, double *out) {
+    if (!c || !out) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_end: bad arguments");
+    if (!c->preint_pending) return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate_end: nothing in flight");
+    const int n_jobs = c->preint_pending;
+    c->preint_pending = 0;
+    char *H = c->h_stage;
+    volatile int *st = (volatile int *)(H + c->preint_o_st);
+    for (int k = 0; k < n_jobs; ++k)
+        for (unsigned long spin = 1; st[k] == 0; ++spin)
+            if ((spin & 0x3FFF) == 0) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess && st[k] == 0) return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate: kernel retired without publishing");
+                if (q != hipSuccess && q != hipErrorNotReady) return xr_fail(XRHIP_EHIP, "xrhip_ba_preintegrate: stream error");
+            }
+    for (int k = 0; k < n_jobs; ++k)
+        if (st[k] != 1) return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate: covariance is not positive definite");
+    std::memcpy(out, H + c->preint_o_out, sizeof(double) * XRHIP_IMU_DIM * (size_t)n_jobs);
+    return XRHIP_OK;
+}
+
+int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *sample_begin, const int *sample_count,
+                                const double *t_end, const double *bg, const double *ba, int n_jobs,
+                                const double *noise_cov36, int compute_jacobian, int compute_covariance, double *out) {
+    if (!out) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: bad arguments");
+    int rc = xrhip_ba_preintegrate_begin(c, samples, sample_begin, sample_count, t_end, bg, ba, n_jobs, noise_cov36,
+                                         compute_jacobian, compute_covariance);
+    if (rc) return rc;
+    return xrhip_ba_preintegrate_end(c, out);
 }
 
 int xrhip_ba_preintegrate(xrhip_ba *c, const double *samples, int n, double t_end, const double *bg, const double *ba,

@@ -128,6 +128,29 @@ struct Pipeline {
         pre.valid = true;
         return true;
     }
+    // asynchronous form for one interval: integrate_begin queues the kernel, integrate_end waits and stores the record
+    bool integrate_begin(const std::vector<ImuData> &data, double t, const V3 &bg, const V3 &ba_, bool jac, bool cov) {
+        if (data.empty()) return false;
+        std::vector<double> smp(data.size() * 7);
+        for (size_t i = 0; i < data.size(); ++i) {
+            const ImuData &d = data[i];
+            double *s = &smp[7 * i];
+            s[0] = d.t;
+            s[1] = d.w.x; s[2] = d.w.y; s[3] = d.w.z;
+            s[4] = d.a.x; s[5] = d.a.y; s[6] = d.a.z;
+        }
+        const double b1[3] = {bg.x, bg.y, bg.z}, b2[3] = {ba_.x, ba_.y, ba_.z};
+        const int begin = 0, count = (int)data.size();
+        WallTimer wt_w_preintegrate(times.w_preintegrate);
+        hip_check(xrhip_ba_preintegrate_begin(ba, smp.data(), &begin, &count, &t, b1, b2, 1, noise36, jac, cov),
+                  "xrhip_ba_preintegrate_begin");
+        return true;
+    }
+    void integrate_end(PreInt &pre) {
+        WallTimer wt_w_preintegrate(times.w_preintegrate);
+        hip_check(xrhip_ba_preintegrate_end(ba, pre.rec), "xrhip_ba_preintegrate_end");
+        pre.valid = true;
+    }
     // several integrations in one launch (refine_window re-integrates every keyframe interval, refine_subwindow
     // every subframe interval); entries with no IMU data are skipped and reported as false
     struct IntegrateJob {
@@ -638,6 +661,9 @@ class SlidingWindowTracker {
             const std::vector<ImuData> &od = ft_map->get_frame(index)->preintegration.data;
             nd.insert(nd.begin(), od.begin(), od.end());
         }
+        // the pre-integration of the new interval only needs its IMU samples and the biases of the last window frame:
+        // queue it now, it runs on the device while the track links are copied below
+        const bool integrating = P_.integrate_begin(nd, curr->image->t, new_i->motion.bg, new_i->motion.ba, true, true);
         map->attach_frame(curr->clone());
         Frame *new_j = map->get_frame(map->frame_num() - 1);
         for (size_t ki = 0; ki < old_i->keypoint_num(); ++ki) {
@@ -651,7 +677,7 @@ class SlidingWindowTracker {
             }
         }
         map->prune_tracks([](const Track *t) { return t->tag(TT_TRASH) && !t->tag(TT_STATIC); });
-        P_.integrate(new_j->preintegration, new_j->image->t, new_i->motion.bg, new_i->motion.ba, true, true);
+        if (integrating) P_.integrate_end(new_j->preintegration);
         predict(new_j->preintegration, new_i, new_j);
     }
 

@@ -440,6 +440,14 @@ struct PreintJob {
 
 constexpr int PI_CHUNK = 32;
 
+// completion mailbox: the job's status word (pinned host memory) is its last store -- 1 = record complete,
+// 3 = covariance not positive definite; the host spins on it instead of synchronising the stream
+__device__ __forceinline__ void preint_publish(int *status, int code) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *reinterpret_cast<volatile int *>(status + blockIdx.x) = code;
+}
+
 __global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restrict__ jobs,
                                                       const double *__restrict__ samples,
                                                       const double *__restrict__ noise_host, int want_jac, int want_cov,
@@ -649,6 +657,7 @@ __global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restric
     if (tid < 45) o[11 + tid] = Jac[tid / 9][tid % 9];
     if (!want_cov) {
         for (int e = tid; e < 225; e += 64) o[56 + e] = 0.0;
+        preint_publish(status, 1);
         return;
     }
     if (tid >= 46) {
@@ -673,13 +682,14 @@ __global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restric
     const bool pd = chol_diag_wave(Pr, 0, 15, Dinv, tid);
     __syncthreads();
     if (!pd) {
-        if (tid == 0) status[blockIdx.x] = 3;
+        preint_publish(status, 3);
         return;
     }
     for (int e = tid; e < 225; e += 64) {
         const int i = e / 15, j = e - 15 * i;
         o[56 + e] = (j >= i) ? Dinv[14 - i][14 - j] : 0.0;   // upper triangular, row-major
     }
+    preint_publish(status, 1);
 }
 
 }   // namespace xrhip
