@@ -87,15 +87,30 @@ class Session:
         self.frame_k = 0
         self.poses = []
 
-    def _push_imu_until(self, t_limit):
+    def _imu_structs(self):
+        """The sensor structs of the whole sequence, built once (the player reads them from a file the same way);
+        pushing a sample is then a single foreign call."""
         imu = self.seq["imu"]
-        while self.imu_k < len(imu) and imu[self.imu_k, 0] <= t_limit + 1e-9:
-            r = imu[self.imu_k]
-            g = XRSLAMVec3((C.c_double * 3)(*r[1:4]), r[0])
-            a = XRSLAMVec3((C.c_double * 3)(*r[4:7]), r[0])
-            self.lib.XRSLAMPushSensorData(XRSLAM_SENSOR_GYROSCOPE, C.byref(g))
-            self.lib.XRSLAMPushSensorData(XRSLAM_SENSOR_ACCELERATION, C.byref(a))
-            self.imu_k += 1
+        n = len(imu)
+        gy, ac = (XRSLAMVec3 * n)(), (XRSLAMVec3 * n)()
+        for k in range(n):
+            r = imu[k]
+            gy[k].data[0], gy[k].data[1], gy[k].data[2], gy[k].timestamp = r[1], r[2], r[3], r[0]
+            ac[k].data[0], ac[k].data[1], ac[k].data[2], ac[k].timestamp = r[4], r[5], r[6], r[0]
+        self._gy, self._ac = gy, ac
+        self._imu_t = [float(v) for v in imu[:, 0]]
+
+    def _push_imu_until(self, t_limit):
+        if not hasattr(self, "_gy"):
+            self._imu_structs()
+        push, gy, ac, ts, n = self.lib.XRSLAMPushSensorData, self._gy, self._ac, self._imu_t, len(self._imu_t)
+        k = self.imu_k
+        lim = t_limit + 1e-9
+        while k < n and ts[k] <= lim:
+            push(XRSLAM_SENSOR_GYROSCOPE, C.byref(gy[k]))
+            push(XRSLAM_SENSOR_ACCELERATION, C.byref(ac[k]))
+            k += 1
+        self.imu_k = k
 
     def step(self):
         """Feeds everything up to and including the next camera frame; returns False at the end."""
