@@ -453,7 +453,18 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
     std::vector<int> corners;
     bool need_all = n_top > c->top_cap;
     if (!need_all) {
-        corners = select_from(c->h_top, c->h_top + n_top);
+        if (c->h_sel->sorted) {   // already in visiting order: walk it
+            const HarrisCand *it = c->h_top, *end = c->h_top + n_top;
+            corners = greedy_min_distance(
+                [&](int &idx) {
+                    if (it == end) return false;
+                    idx = (it++)->idx;
+                    return true;
+                },
+                w, h, 20.0, max_points);
+        } else {
+            corners = select_from(c->h_top, c->h_top + n_top);
+        }
         // the pass ran out of strong candidates before it had max_points corners: the weaker ones matter after all
         need_all = n_top < nc && (max_points <= 0 || (int)corners.size() < max_points);
     }

@@ -314,11 +314,13 @@ __global__ __launch_bounds__(256) void k_harris_nms(const float *__restrict__ re
 // bin boundary that keeps >= SEL_K candidates is found, and everything at or above it is written -- together
 // with a header and, last, a sequence number -- straight into pinned host memory.  One workgroup.
 constexpr int SEL_BINS = 4096;
-constexpr int SEL_K = 1024;
+constexpr int SEL_K = 896;    // a few more than the ~400 the spacing pass usually visits; <= 1024 keeps the sort at 1024 entries
+constexpr int SEL_SORT = 2048;   // selected candidates that fit the LDS sort (SEL_BINS * 4 bytes = SEL_SORT * 8 bytes)
 struct SelectHeader {
     int n_candidates;   // all NMS survivors
     int n_top;          // candidates at or above the boundary bin (may exceed the capacity of the top block)
     int boundary_bin;
+    int sorted;         // the top block is in visiting order (response desc, index desc)
     int seq;            // written last
 };
 
@@ -359,20 +361,57 @@ __global__ __launch_bounds__(1024) void k_harris_select(const HarrisCand *__rest
     }
     __syncthreads();
     const int bin = s_bin;
+    // the histogram is dead: its LDS now collects the selected candidates (SEL_SORT of them fit)
+    HarrisCand *sel = reinterpret_cast<HarrisCand *>(hist);
     for (int i = tid; i < nc; i += 1024) {
         const HarrisCand cd = cand[i];
         const int q = min(SEL_BINS - 1, max(0, (int)((cd.v - thr) * scale)));
         if (q >= bin) {
             const int pos = atomicAdd(&s_n, 1);
-            if (pos < top_cap) top_out[pos] = cd;
+            if (pos < SEL_SORT) sel[pos] = cd;
+            else if (pos < top_cap) top_out[pos] = cd;
         }
+    }
+    __syncthreads();
+    const int n_top = s_n;
+    int sorted = 0;
+    if (n_top <= SEL_SORT && n_top <= top_cap) {
+        // bitonic sort into the visiting order of the greedy spacing pass: response descending, then index descending
+        // (the kernel runs while the host digests the tracks, so the sort is free)
+        const int ns = n_top <= 1024 ? 1024 : SEL_SORT;   // sort size: next power of two
+        for (int i = n_top + tid; i < ns; i += 1024) {
+            sel[i].v = -1.0f;   // responses above the threshold are positive: padding sorts last
+            sel[i].idx = -1;
+        }
+        __syncthreads();
+        for (int k = 2; k <= ns; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < ns; i += 1024) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const HarrisCand a = sel[i], b = sel[l];
+                        const bool a_first = (a.v > b.v) || (a.v == b.v && a.idx > b.idx);
+                        const bool up = (i & k) == 0;
+                        if (up ? !a_first : a_first) {
+                            sel[i] = b;
+                            sel[l] = a;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < n_top; i += 1024) top_out[i] = sel[i];
+        sorted = 1;
+    } else {
+        for (int i = tid; i < min(n_top, min(SEL_SORT, top_cap)); i += 1024) top_out[i] = sel[i];
     }
     __threadfence_system();
     __syncthreads();
     if (tid == 0) {
         hdr->n_candidates = *count;
-        hdr->n_top = s_n;
+        hdr->n_top = n_top;
         hdr->boundary_bin = bin;
+        hdr->sorted = sorted;
         __threadfence_system();
         *reinterpret_cast<volatile int *>(&hdr->seq) = seq;
     }
