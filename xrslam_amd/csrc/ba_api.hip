@@ -839,6 +839,9 @@ int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_s
     XR_HIP(hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, s));
     XR_HIP(hipStreamSynchronize(s));
     if (!hst[0] && (hst[2] != 0 || hst[3] != 0)) {
+        if (std::getenv("XRHIP_HOSTPROF"))
+            std::fprintf(stderr, "[hostprof] marginalisation falls back to the eigen path: cholesky %s, guard %s, lambda bound %g, support %d of %d\n",
+                         hst[2] ? "failed" : "ok", hst[3] ? "failed" : "ok", 0.0, hst[1], R);
         hipLaunchKernelGGL(km_jacobi, dim3(1), dim3(1024), (size_t)c->lds_limit, s, dsn, lds_doubles, As, bs, B, V, Ss, ivs,
                            60, dst + 2);
         XR_HIP(hipGetLastError());
