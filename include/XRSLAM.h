@@ -8,9 +8,8 @@
  * against libxrslam_hip.so unchanged.  Implementation: xrslam_amd/csrc/host/xrslam_api.cpp.
  *
  * Differences, all additive:
- *   - the XRSLAMAmd* entry points at the bottom (bootstrap states, device-resident
- *     images, stage timers) -- the reference's Initializer is out of scope
- *      so the window is seeded through XRSLAMAmdSetInitialState;
+ *   - the XRSLAMAmd* entry points at the bottom (optional externally supplied initial
+ *     states, device-resident images, stage timers, initialiser report);
  *   - XRSLAMFeatures is declared for C++ only, like the reference (it holds a std::vector).
  */
 #ifndef XRSLAM_AMD_XRSLAM_H
@@ -142,7 +141,9 @@ void XRSLAMGetResult(XRSLAMResultType result_type, void *result_data);
 void XRSLAMDestroy();
 
 /* ---- additive MI355X entry points ---- */
-/* seed state for the bootstrap initialiser: body pose/velocity/biases at image time t (q: x y z w) */
+/* Optional: body pose/velocity/biases at image time t (q: x y z w).  While any such state is registered the
+ * first window is seeded from them (poses of its 8 keyframes) instead of SfM + IMU alignment
+ * (core/initializer.cpp:158-571); with none registered the library initialises itself like the reference. */
 void XRSLAMAmdSetInitialState(double t, const double q[4], const double p[3], const double v[3],
                               const double bg[3], const double ba[3]);
 /* like XRSLAM_SENSOR_CAMERA but `gray_dev` is an 8-bit single-channel image already resident in HBM */
@@ -155,7 +156,8 @@ typedef struct XRSLAMAmdTimes {
     double wall_preprocess, wall_track, wall_detect, wall_preintegrate, wall_solve, wall_marginalize, wall_frame;
     /* host wall-clock seconds of whole pipeline stages (their device waits included): Frame::track_keypoints,
      * of which 5-pt RANSAC, 2-pt RANSAC; Frame::detect_keypoints; mirror_frame; localize_newframe; manage_keyframe;
-     * track_landmark; refine_window; slide_window; refine_subwindow; rest reserved */
+     * track_landmark; refine_window; slide_window; refine_subwindow; initialiser (SfM + alignment attempts);
+     * rest reserved */
     double wall_scope[16];
 } XRSLAMAmdTimes;
 void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out);
@@ -165,6 +167,15 @@ void XRSLAMAmdSetProfiling(int enable);
 void XRSLAMAmdGetKltStats(void *xrhip_klt_stats_out, int reset);
 /* same for the BA context: xrhip_ba_stats from xrslam_hip.h (XRSLAMAmdSetProfiling switches both) */
 void XRSLAMAmdGetBaStats(void *xrhip_ba_stats_out, int reset);
+/* What the initialiser (core/initializer.cpp) did so far: attempts that reached SfM, whether the last one
+ * succeeded, which of the eight (R, T) hypotheses won its triangulation vote, and the IMU alignment it produced
+ * (metric scale of the unit-baseline SfM map, gravity in the SfM frame, gyroscope bias). */
+typedef struct XRSLAMAmdInitReport {
+    long attempts, successes;
+    int sfm_candidate, sfm_triangulated;
+    double scale, gravity[3], bg[3];
+} XRSLAMAmdInitReport;
+void XRSLAMAmdGetInitReport(XRSLAMAmdInitReport *out);
 /* last error raised inside the library ("" if none); the reference aborts/throws instead */
 const char *XRSLAMAmdLastError(void);
 

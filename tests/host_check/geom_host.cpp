@@ -108,3 +108,86 @@ int gh_load_config(const char *slam, const char *dev, double *out64) {
     }
 }
 }
+
+// ------------------------------------------------------------------------------ two_view.hpp
+#include "../../xrslam_amd/csrc/host/two_view.hpp"
+extern "C" {
+void gh_homography_4pt(const double *p1, const double *p2, double *H9) {
+    std::array<V2, 4> a, b;
+    for (int i = 0; i < 4; ++i) {
+        a[i] = {p1[2 * i], p1[2 * i + 1]};
+        b[i] = {p2[2 * i], p2[2 * i + 1]};
+    }
+    M3 H = solve_homography_4pt(a, b);
+    std::memcpy(H9, H.m, sizeof(H.m));
+}
+int gh_find_homography(const double *p1, const double *p2, int n, double thr, int seed, char *mask, double *H9) {
+    std::vector<V2> a(n), b(n);
+    for (int i = 0; i < n; ++i) {
+        a[i] = {p1[2 * i], p1[2 * i + 1]};
+        b[i] = {p2[2 * i], p2[2 * i + 1]};
+    }
+    std::vector<char> m;
+    M3 H = find_homography_matrix(a, b, m, thr, 0.999, 1000, seed);
+    std::memcpy(H9, H.m, sizeof(H.m));
+    int cnt = 0;
+    for (size_t i = 0; i < m.size(); ++i) cnt += (mask[i] = m[i]);
+    return cnt;
+}
+int gh_decompose_homography(const double *H9, double *R18, double *T6, double *n6) {
+    M3 H, R1, R2;
+    std::memcpy(H.m, H9, sizeof(H.m));
+    V3 T1, T2, n1, n2;
+    bool ok = decompose_homography(H, R1, R2, T1, T2, n1, n2);
+    std::memcpy(R18, R1.m, sizeof(R1.m));
+    std::memcpy(R18 + 9, R2.m, sizeof(R2.m));
+    for (int k = 0; k < 3; ++k) {
+        T6[k] = T1[k]; T6[3 + k] = T2[k];
+        n6[k] = n1[k]; n6[3 + k] = n2[k];
+    }
+    return ok ? 1 : 0;
+}
+void gh_decompose_essential(const double *E9, double *R18, double *T3) {
+    M3 E, R1, R2;
+    std::memcpy(E.m, E9, sizeof(E.m));
+    V3 T;
+    decompose_essential(E, R1, R2, T);
+    std::memcpy(R18, R1.m, sizeof(R1.m));
+    std::memcpy(R18 + 9, R2.m, sizeof(R2.m));
+    for (int k = 0; k < 3; ++k) T3[k] = T[k];
+}
+void gh_lstsq(const double *A, const double *b, int m, int n, double *x) {
+    Dense D(m, n);
+    std::memcpy(D.a.data(), A, sizeof(double) * m * n);
+    std::vector<double> r = lstsq_qr(D, std::vector<double>(b, b + m));
+    std::memcpy(x, r.data(), sizeof(double) * n);
+}
+void gh_svd_solve3(const double *A9, const double *b3, double *x3) {
+    M3 A;
+    std::memcpy(A.m, A9, sizeof(A.m));
+    V3 x = svd_solve3(A, V3{b3[0], b3[1], b3[2]});
+    for (int k = 0; k < 3; ++k) x3[k] = x[k];
+}
+void gh_quat_from_matrix(const double *R9, double *q4) {
+    M3 R;
+    std::memcpy(R.m, R9, sizeof(R.m));
+    Quat q = quat_from_matrix(R);
+    q4[0] = q.x; q4[1] = q.y; q4[2] = q.z; q4[3] = q.w;
+}
+void gh_from_two_vectors(const double *a3, const double *b3, double *q4) {
+    Quat q = quat_from_two_vectors(V3{a3[0], a3[1], a3[2]}, V3{b3[0], b3[1], b3[2]});
+    q4[0] = q.x; q4[1] = q.y; q4[2] = q.z; q4[3] = q.w;
+}
+void gh_logmap(const double *q4, double *w3) {
+    V3 w = logmap(Quat{q4[0], q4[1], q4[2], q4[3]});
+    for (int k = 0; k < 3; ++k) w3[k] = w[k];
+}
+void gh_s2_basis(const double *x3, double *b6) {
+    V3 b1, b2;
+    s2_tangential_basis(V3{x3[0], x3[1], x3[2]}, b1, b2);
+    for (int k = 0; k < 3; ++k) {
+        b6[k] = b1[k];
+        b6[3 + k] = b2[k];
+    }
+}
+}

@@ -91,3 +91,75 @@ def test_gpu_pipeline_matches_cpu_reference_stress_config():
     assert poses_h.shape == poses_o.shape
     np.testing.assert_allclose(poses_h[:, 1:], poses_o[:, 1:], rtol=1e-4, atol=1e-6)
     assert runner.ate_rmse(list(poses_h), seq) < 0.03
+
+
+# ------------------------------------------------------------------------- self-initialisation
+# No external initial states: the window comes from the library's own SfM + IMU alignment (core/initializer.cpp).
+# The stream is the figure-eight at half speed, so that the first-to-last keyframe baseline (~0.7 m) passes the
+# reference's scale gate  0.001 <= scale <= 1  (initializer.cpp:391,397; the SfM map has unit baseline).
+N_INIT_FRAMES = 80
+
+
+def _run_self_init(lib_path, seq):
+    s = runner.Session(lib_path, seq, init_frames=0)
+    while s.step():
+        assert not s.error(), s.error()
+    s.flush()
+    t = s.times()
+    counts = (t.frames, t.solves, t.solve_iterations, t.marginalizations, t.keyframes)
+    rep = s.init_report()
+    report = dict(attempts=rep.attempts, successes=rep.successes, candidate=rep.sfm_candidate,
+                  triangulated=rep.sfm_triangulated, scale=rep.scale, gravity=np.array(rep.gravity[:]),
+                  bg=np.array(rep.bg[:]))
+    poses = np.array(s.poses)
+    s.close()
+    return poses, counts, report
+
+
+@pytest.fixture(scope="module")
+def init_seq():
+    from xrslam_amd.harness.trajectory import Trajectory
+    return scene.make_sequence(n_frames=N_INIT_FRAMES, seed=1, traj=Trajectory(amp=1.5, speed=0.3))
+
+
+@pytest.fixture(scope="module")
+def oracle_self_init(init_seq):
+    if not os.path.exists(ORACLE_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return _run_self_init(ORACLE_LIB, init_seq)
+
+
+def test_cpu_reference_pipeline_initialises_itself(init_seq, oracle_self_init):
+    poses, counts, rep = oracle_self_init
+    assert counts[0] == N_INIT_FRAMES
+    assert rep["successes"] == 1 and 1 <= rep["attempts"] <= 12
+    assert rep["candidate"] >= 4                        # a general (non-planar) view: an essential-matrix hypothesis
+    assert rep["triangulated"] >= 50
+    ok = poses[np.abs(poses[:, 4:8]).sum(1) > 0]
+    assert len(ok) >= N_INIT_FRAMES - 36 - rep["attempts"] - 1     # first window needs 36 frames
+    # metric scale: the SfM map has unit baseline between the first and the last of the 8 keyframes
+    st, cam_t = init_seq["states"], init_seq["cam_t"]
+    first = int(np.searchsorted(cam_t, ok[0, 0] - 1e-6)) - 35
+    baseline = np.linalg.norm(st[first + 35, 4:7] - st[first, 4:7])
+    assert abs(rep["scale"] / baseline - 1) < 0.1
+    assert abs(np.linalg.norm(rep["gravity"]) - 9.80665) < 1e-9
+    assert np.abs(rep["bg"] - init_seq["bg"]).max() < 2e-3
+    # trajectory: gravity-aligned frame with free yaw/origin -> compare after SE(3) alignment, no scale freedom
+    assert runner.ate_rmse(list(poses), init_seq) < 0.04
+
+
+@pytest.mark.gpu
+def test_gpu_pipeline_initialises_itself_like_cpu_reference(init_seq, oracle_self_init):
+    from xrslam_amd import _lib
+    poses_o, counts_o, rep_o = oracle_self_init
+    poses_h, counts_h, rep_h = _run_self_init(_lib.LIB_PATH, init_seq)
+    assert (rep_h["attempts"], rep_h["successes"], rep_h["candidate"], rep_h["triangulated"]) == \
+        (rep_o["attempts"], rep_o["successes"], rep_o["candidate"], rep_o["triangulated"])
+    np.testing.assert_allclose(rep_h["scale"], rep_o["scale"], rtol=1e-6)
+    np.testing.assert_allclose(rep_h["gravity"], rep_o["gravity"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rep_h["bg"], rep_o["bg"], rtol=0, atol=1e-8)
+    assert counts_h == counts_o
+    assert poses_h.shape == poses_o.shape
+    np.testing.assert_allclose(poses_h[:, 1:], poses_o[:, 1:], rtol=1e-4, atol=1e-6)
+    assert runner.ate_rmse(list(poses_h), init_seq) < 0.04

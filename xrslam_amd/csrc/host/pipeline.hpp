@@ -29,6 +29,7 @@
 #include "../hostprof.hpp"
 #include "config.hpp"
 #include "map.hpp"
+#include "two_view.hpp"
 
 namespace xrh {
 
@@ -50,7 +51,7 @@ struct StageTimes {   // seconds, accumulated (inspection slots feature_tracker_
     double scope[16] = {0};
 };
 enum { SC_FT_TRACK = 0, SC_RANSAC_E, SC_RANSAC_R, SC_FT_DETECT, SC_MIRROR, SC_LOCALIZE, SC_MANAGE_KF, SC_TRACK_LANDMARK,
-       SC_REFINE_WINDOW, SC_SLIDE_WINDOW, SC_REFINE_SUBWINDOW, SC_COUNT };
+       SC_REFINE_WINDOW, SC_SLIDE_WINDOW, SC_REFINE_SUBWINDOW, SC_INITIALIZE, SC_COUNT };
 struct WallTimer {   // adds the scope's duration to a StageTimes slot
     double &slot;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -403,9 +404,28 @@ class BaBuilder {
     }
     void add_marginalization(MargPrior *m) { prior_ = m; }
 
+    size_t factor_num() const { return obs_tgt_.size() + rot_tgt_.size() + imu_i_.size() + (prior_ ? 1 : 0); }
+    // Parameter blocks that no factor touches are not part of the program Ceres minimises (it drops them while
+    // building the reduced program): a free pose / motion nobody references is passed as a constant.
+    void drop_unreferenced_blocks() {
+        const size_t F = frames_.size();
+        std::vector<char> pose_used(F, 0), motion_used(F, 0);
+        for (size_t o = 0; o < obs_tgt_.size(); ++o) pose_used[obs_tgt_[o]] = pose_used[obs_ref_[o]] = 1;
+        for (size_t o = 0; o < rot_tgt_.size(); ++o) pose_used[rot_tgt_[o]] = pose_used[rot_ref_[o]] = 1;
+        for (size_t o = 0; o < imu_i_.size(); ++o)
+            pose_used[imu_i_[o]] = pose_used[imu_j_[o]] = motion_used[imu_i_[o]] = motion_used[imu_j_[o]] = 1;
+        if (prior_)
+            for (Frame *f : prior_->frames)
+                if (f->ba_gen == gen_) pose_used[f->ba_index] = motion_used[f->ba_index] = 1;
+        for (size_t f = 0; f < F; ++f) {
+            if (!pose_used[f]) fix_[f] |= XRHIP_FIX_POSE;
+            if (!motion_used[f]) fix_[f] |= XRHIP_FIX_MOTION;
+        }
+    }
     bool solve(double *elapsed_device_ms = nullptr) {
         xrhip::HostProfScope hp_s(10, "BaBuilder::solve (all)");
         const Config &c = P_.config;
+        drop_unreferenced_blocks();
         const int F = (int)frames_.size(), L = (int)tracks_.size();
         std::vector<double> state(16 * (size_t)F), depth(std::max(L, 1));
         for (int f = 0; f < F; ++f) pack_state(frames_[f], &state[16 * (size_t)f]);
@@ -951,19 +971,20 @@ class SlidingWindowTracker {
     std::unique_ptr<Map> map;
 };
 
-// ---------------------------------------------------------------------------- bootstrap initialiser
-// Stand-in for Initializer (core/initializer.cpp:22-571, out of scope): same keyframe mirroring
-// (:22-76) and the same final bundle adjustment / keyframe tagging as Initializer::initialize (:78-140),
-// but poses, velocities and biases come from externally supplied states instead of SfM + IMU alignment.
+// ------------------------------------------------------------------------------------ initialiser
+// Initializer (core/initializer.cpp:22-571): keyframe mirroring (:22-76), two-view + PnP + BA structure from
+// motion (:158-384), gyroscope bias / gravity / scale / velocity alignment (:386-571) and the final
+// visual-inertial bundle adjustment (:78-140).  When initial states were supplied from outside
+// (XRSLAMAmdSetInitialState) they replace SfM + alignment; everything else is the same code.
 struct InitialState {
     double t;
     PoseState pose;
     MotionState motion;
 };
 
-class BootstrapInitializer {
+class Initializer {
   public:
-    explicit BootstrapInitializer(Pipeline &P) : P_(P) {}
+    explicit Initializer(Pipeline &P) : P_(P) {}
     std::vector<InitialState> states;   // sorted by time
 
     void mirror_keyframe_map(Map *ft_map, size_t init_frame_id) {
@@ -1002,50 +1023,29 @@ class BootstrapInitializer {
 
     std::unique_ptr<SlidingWindowTracker> initialize() {
         if (!map) return nullptr;
-        for (size_t i = 0; i < map->frame_num(); ++i) {
-            Frame *f = map->get_frame(i);
-            const InitialState *s = lookup(f->image->t);
-            if (!s) return nullptr;
-            f->pose = s->pose;
-            f->motion = s->motion;
+        if (!states.empty()) {
+            if (!apply_external_states()) return nullptr;
+        } else {
+            WallTimer sc_t(P_.times.scope[SC_INITIALIZE]);
+            attempts++;
+            const bool verbose = std::getenv("XRSLAM_AMD_DEBUG_INIT") != nullptr;
+            const bool ok_sfm = init_sfm();
+            if (verbose)
+                std::fprintf(stderr, "[init] sfm %d: hypothesis %d, %zu triangulated, %zu tracks\n", (int)ok_sfm,
+                             sfm_candidate, sfm_triangulated, map->track_num());
+            if (!ok_sfm) return nullptr;
+            const bool ok_imu = init_imu();
+            if (verbose)
+                std::fprintf(stderr, "[init] imu %d: scale %g gravity %g %g %g bg %g %g %g\n", (int)ok_imu, scale, gravity.x,
+                             gravity.y, gravity.z, bg.x, bg.y, bg.z);
+            if (!ok_imu) return nullptr;
+            successes++;
         }
-        size_t ok = 0;
-        for (size_t k = 0; k < map->track_num(); ++k) {
-            Track *t = map->get_track(k);
-            if (auto p = t->triangulate()) {
-                t->set_landmark_point(p.value());
-                t->tag(TT_TRIANGULATED) = true;
-                t->tag(TT_VALID) = true;
-                t->tag(TT_STATIC) = true;
-                ok++;
-            } else {
-                t->landmark.inv_depth = -1.0;
-                t->tag(TT_VALID) = false;
-            }
-        }
-        if (ok < P_.config.initializer_min_landmarks) return nullptr;
         map->get_frame(0)->tag(FT_FIX_POSE) = true;
         BaBuilder b(P_);
         for (size_t i = 0; i < map->frame_num(); ++i) b.add_frame_states(map->get_frame(i));
-        std::unordered_set<Track *> visited;
-        for (size_t i = 0; i < map->frame_num(); ++i) {
-            Frame *f = map->get_frame(i);
-            for (size_t j = 0; j < f->keypoint_num(); ++j) {
-                Track *t = f->get_track(j);
-                if (!t || !t->tag(TT_VALID) || visited.count(t)) continue;
-                visited.insert(t);
-                b.add_track_states(t);
-            }
-        }
-        for (size_t i = 0; i < map->frame_num(); ++i) {
-            Frame *f = map->get_frame(i);
-            for (size_t j = 0; j < f->keypoint_num(); ++j) {
-                Track *t = f->get_track(j);
-                if (!t || !t->all_tagged({TT_VALID, TT_TRIANGULATED})) continue;
-                if (f == t->first_frame()) continue;
-                b.add_reprojection_error(f, j);
-            }
-        }
+        add_valid_tracks(b);
+        add_reprojection_factors(b);
         for (size_t j = 1; j < map->frame_num(); ++j) {
             Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
             if (P_.integrate(fj->preintegration, fj->image->t, fi->motion.bg, fi->motion.ba, true, true))
@@ -1057,6 +1057,323 @@ class BootstrapInitializer {
         return swt;
     }
 
+    // quantities of the last IMU alignment (also read by tests)
+    V3 bg, ba, gravity;
+    double scale = 1;
+    std::vector<V3> velocities;
+    long attempts = 0, successes = 0;   // initialise() calls that reached SfM / that produced a window
+    int sfm_candidate = -1;             // which of the 8 (R, T) hypotheses won the triangulation vote
+    size_t sfm_triangulated = 0;
+
+  private:
+    static constexpr int kRansacSeed = 648;   // Config::random() (config.cpp:66)
+    static constexpr double kGravityNominal = 9.80665;
+
+    bool apply_external_states() {
+        for (size_t i = 0; i < map->frame_num(); ++i) {
+            Frame *f = map->get_frame(i);
+            const InitialState *s = lookup(f->image->t);
+            if (!s) return false;
+            f->pose = s->pose;
+            f->motion = s->motion;
+        }
+        return retriangulate() >= P_.config.initializer_min_landmarks;
+    }
+
+    // every track is re-triangulated from the current poses; the ones that fail become invalid (:548-568)
+    size_t retriangulate() {
+        size_t ok = 0;
+        for (size_t k = 0; k < map->track_num(); ++k) {
+            Track *t = map->get_track(k);
+            if (auto p = t->triangulate()) {
+                t->set_landmark_point(p.value());
+                t->tag(TT_VALID) = true;
+                t->tag(TT_TRIANGULATED) = true;
+                ok++;
+            } else {
+                t->tag(TT_VALID) = false;
+            }
+        }
+        return ok;
+    }
+
+    void add_valid_tracks(BaBuilder &b) {
+        std::unordered_set<Track *> visited;
+        for (size_t i = 0; i < map->frame_num(); ++i) {
+            Frame *f = map->get_frame(i);
+            for (size_t j = 0; j < f->keypoint_num(); ++j) {
+                Track *t = f->get_track(j);
+                if (!t || !t->tag(TT_VALID) || visited.count(t)) continue;
+                visited.insert(t);
+                b.add_track_states(t);
+            }
+        }
+    }
+    void add_reprojection_factors(BaBuilder &b) {
+        for (size_t i = 0; i < map->frame_num(); ++i) {
+            Frame *f = map->get_frame(i);
+            for (size_t j = 0; j < f->keypoint_num(); ++j) {
+                Track *t = f->get_track(j);
+                if (!t || !t->all_tagged({TT_VALID, TT_TRIANGULATED})) continue;
+                if (f == t->first_frame()) continue;
+                b.add_reprojection_error(f, j);
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- structure from motion (:158-384)
+    bool init_sfm() {
+        const Config &c = P_.config;
+        Frame *fi = map->get_frame(0), *fj = map->get_frame(map->frame_num() - 1);
+        std::vector<V2> pi, pj;
+        std::vector<std::pair<size_t, size_t>> matches;
+        double parallax = 0;
+        for (size_t ki = 0; ki < fi->keypoint_num(); ++ki) {
+            Track *t = fi->get_track(ki);
+            if (!t) continue;
+            size_t kj = t->get_keypoint_index(fj);
+            if (kj == nil()) continue;
+            const V3 &a = fi->get_keypoint(ki), &bq = fj->get_keypoint(kj);
+            pi.push_back({a.x / a.z, a.y / a.z});
+            pj.push_back({bq.x / bq.z, bq.y / bq.z});
+            matches.emplace_back(ki, kj);
+            V2 ua = apply_k(a, fi->K), ub = apply_k(bq, fj->K);
+            parallax += std::hypot(ua.x - ub.x, ua.y - ub.y);
+        }
+        const int common = (int)matches.size();
+        if (common < (int)c.initializer_min_matches) return false;
+        parallax /= std::max(common, 1);
+        if (parallax < c.initializer_min_parallax) return false;
+
+        // eight (R, T) hypotheses: two homography decompositions and the essential twisted pair, each with +-T
+        std::vector<M3> Rs;
+        std::vector<V3> Ts;
+        std::vector<char> mask;
+        M3 RH1, RH2, RE1, RE2;
+        V3 TH1, TH2, nH1, nH2, TE;
+        M3 H = find_homography_matrix(pi, pj, mask, 0.7 / fi->K.fx, 0.999, 1000, kRansacSeed);
+        if (!decompose_homography(H, RH1, RH2, TH1, TH2, nH1, nH2)) return false;   // pure rotation
+        TH1 = normalized(TH1);
+        TH2 = normalized(TH2);
+        Rs.insert(Rs.end(), {RH1, RH1, RH2, RH2});
+        Ts.insert(Ts.end(), {TH1, -TH1, TH2, -TH2});
+        M3 E = find_essential_matrix(pi, pj, mask, 0.7 / fi->K.fx, 0.999, 1000, kRansacSeed);
+        decompose_essential(E, RE1, RE2, TE);
+        TE = normalized(TE);
+        Rs.insert(Rs.end(), {RE1, RE1, RE2, RE2});
+        Ts.insert(Ts.end(), {TE, -TE, TE, -TE});
+
+        const size_t n = pi.size();
+        std::vector<std::vector<V3>> pts(Rs.size());
+        std::vector<std::vector<char>> status(Rs.size());
+        std::vector<size_t> counts(Rs.size(), 0);
+        std::vector<double> scores(Rs.size(), 0.0);
+        size_t best = 0;
+        for (size_t h = 0; h < Rs.size(); ++h) {
+            pts[h].resize(n);
+            status[h].assign(n, 0);
+            P34 P1{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}}, P2;
+            for (int r = 0; r < 3; ++r) {
+                for (int cc = 0; cc < 3; ++cc) P2.m[4 * r + cc] = Rs[h](r, cc);
+                P2.m[4 * r + 3] = Ts[h][r];
+            }
+            for (size_t k = 0; k < n; ++k) {
+                auto q = triangulate_point(P1, P2, V3{pi[k].x, pi[k].y, 1.0}, V3{pj[k].x, pj[k].y, 1.0});
+                V3 q1{q[0], q[1], q[2]};
+                V3 q2 = Rs[h] * q1 + Ts[h] * q[3];
+                if (q1.z * q[3] > 0 && q2.z * q[3] > 0 && q1.z / q[3] < 100 && q2.z / q[3] < 100) {
+                    pts[h][k] = q1 / q[3];
+                    status[h][k] = 1;
+                    counts[h]++;
+                    const double ax = q1.x / q1.z - pi[k].x, ay = q1.y / q1.z - pi[k].y;
+                    const double bx = q2.x / q2.z - pj[k].x, by = q2.y / q2.z - pj[k].y;
+                    scores[h] += 0.5 * ((ax * ax + ay * ay) + (bx * bx + by * by));
+                }
+            }
+            // the vote as the reference casts it (:254-260): a better score wins among well-triangulated
+            // hypotheses, otherwise more points win
+            if (counts[h] > c.initializer_min_triangulation && scores[h] < scores[best]) best = h;
+            else if (counts[h] > counts[best]) best = h;
+        }
+        sfm_candidate = (int)best;
+        sfm_triangulated = counts[best];
+        if (counts[best] < c.initializer_min_triangulation) return false;
+
+        PoseState pose;
+        pose.q = Quat{0, 0, 0, 1};
+        pose.p = V3{0, 0, 0};
+        fi->set_pose(fi->camera, pose);
+        M3 Rt = transpose(Rs[best]);
+        pose.q = quat_from_matrix(Rt);
+        pose.p = -(Rt * Ts[best]);
+        fj->set_pose(fj->camera, pose);
+        for (size_t k = 0; k < n; ++k) {
+            if (!status[best][k]) continue;
+            Track *t = fi->get_track(matches[k].first);
+            t->set_landmark_point(pts[best][k]);
+            t->tag(TT_VALID) = true;
+            t->tag(TT_TRIANGULATED) = true;
+        }
+
+        // the frames in between: pose-only adjustment against the two-view landmarks, seeded with the previous pose
+        for (size_t j = 1; j + 1 < map->frame_num(); ++j) {
+            Frame *prev = map->get_frame(j - 1), *cur = map->get_frame(j);
+            cur->set_pose(cur->camera, prev->get_pose(prev->camera));
+            BaBuilder b(P_);
+            b.add_frame_states(cur);
+            for (size_t k = 0; k < cur->keypoint_num(); ++k) {
+                Track *t = cur->get_track(k);
+                if (!t || !t->has_keypoint(map->get_frame(0))) continue;
+                if (t->tag(TT_VALID) && t->tag(TT_TRIANGULATED)) b.add_reprojection_prior(cur, k);
+            }
+            if (b.factor_num() > 0) b.solve();
+        }
+
+        for (size_t k = 0; k < map->track_num(); ++k) {
+            Track *t = map->get_track(k);
+            if (t->tag(TT_VALID)) continue;
+            if (auto p = t->triangulate()) {
+                t->set_landmark_point(p.value());
+                t->tag(TT_VALID) = true;
+                t->tag(TT_TRIANGULATED) = true;
+            }
+        }
+
+        map->get_frame(0)->tag(FT_FIX_POSE) = true;
+        BaBuilder b(P_);
+        for (size_t i = 0; i < map->frame_num(); ++i) b.add_frame_states(map->get_frame(i), false);
+        add_valid_tracks(b);
+        add_reprojection_factors(b);
+        if (!b.solve()) return false;
+        // landmark.reprojection_error is never written by the reference, so its "> 3.0" clause never fires (:376-380)
+        map->prune_tracks([](const Track *t) { return !t->tag(TT_VALID) || t->landmark.reprojection_error > 3.0; });
+        return true;
+    }
+
+    // -------------------------------------------------------------------- IMU alignment (:386-571)
+    bool init_imu() {
+        bg = ba = gravity = V3{0, 0, 0};
+        scale = 1;
+        velocities.assign(map->frame_num(), V3{0, 0, 0});
+        solve_gyro_bias();
+        solve_gravity_scale_velocity();
+        if (scale < 0.001 || scale > 1.0) return false;
+        if (!P_.config.initializer_refine_imu) return apply_init();
+        refine_scale_velocity_via_gravity();
+        if (scale < 0.001 || scale > 1.0) return false;
+        return apply_init();
+    }
+
+    void preintegrate() {
+        std::vector<Pipeline::IntegrateJob> jobs;
+        for (size_t j = 1; j < map->frame_num(); ++j) {
+            Frame *f = map->get_frame(j);
+            jobs.push_back({&f->preintegration, f->image->t, bg, ba});
+        }
+        P_.integrate_batch(jobs, true, false);
+    }
+
+    void solve_gyro_bias() {   // sum over intervals of |log((q_i dq)^-1 q_j) - dq_dbg bg|^2
+        preintegrate();
+        M3 A;
+        V3 rhs{0, 0, 0};
+        for (size_t j = 1; j < map->frame_num(); ++j) {
+            const Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
+            const PoseState pi = fi->get_pose(fi->imu), pj = fj->get_pose(fj->imu);
+            M3 J;
+            for (int k = 0; k < 9; ++k) J.m[k] = fj->preintegration.rec[11 + k];   // dq_dbg
+            M3 Jt = transpose(J);
+            M3 JtJ = Jt * J;
+            for (int k = 0; k < 9; ++k) A.m[k] += JtJ.m[k];
+            rhs = rhs + Jt * logmap((pi.q * fj->preintegration.dq()).conjugate() * pj.q);
+        }
+        bg = svd_solve3(A, rhs);
+    }
+
+    // rows per interval (i, j = i+1), unknowns [g | s | v_0 .. v_{N-1}] (or [dg(2) | s | v] with the gravity
+    // direction restricted to its tangent plane):
+    //   -dt^2/2 g + s (pc_j - pc_i) - dt v_i      = q_i dp + (q_j - q_i) p_bc
+    //   -dt g               - v_i + v_j           = q_i dv
+    void fill_alignment(Dense &A, std::vector<double> &rhs, bool tangent) {
+        const int N = (int)map->frame_num(), g_cols = tangent ? 2 : 3, s_col = g_cols, v0 = g_cols + 1;
+        A = Dense((N - 1) * 6, g_cols + 1 + 3 * N);
+        rhs.assign((size_t)(N - 1) * 6, 0.0);
+        V3 t1, t2;
+        if (tangent) s2_tangential_basis(gravity, t1, t2);
+        for (int j = 1; j < N; ++j) {
+            const int i = j - 1;
+            const Frame *fi = map->get_frame(i), *fj = map->get_frame(j);
+            const PreInt &d = fj->preintegration;
+            const double dt = d.dt();
+            const PoseState ci = fi->get_pose(fi->camera), cj = fj->get_pose(fj->camera);
+            const V3 dpc = cj.p - ci.p;
+            V3 bp = fi->pose.q * d.dp() + (fj->pose.q * fj->camera.p_cs - fi->pose.q * fi->camera.p_cs);
+            V3 bv = fi->pose.q * d.dv();
+            if (tangent) {
+                bp = bp + gravity * (0.5 * dt * dt);
+                bv = bv + gravity * dt;
+            }
+            for (int r = 0; r < 3; ++r) {
+                if (tangent) {
+                    A(i * 6 + r, 0) = -0.5 * dt * dt * t1[r];
+                    A(i * 6 + r, 1) = -0.5 * dt * dt * t2[r];
+                    A(i * 6 + 3 + r, 0) = -dt * t1[r];
+                    A(i * 6 + 3 + r, 1) = -dt * t2[r];
+                } else {
+                    A(i * 6 + r, r) = -0.5 * dt * dt;
+                    A(i * 6 + 3 + r, r) = -dt;
+                }
+                A(i * 6 + r, s_col) = dpc[r];
+                A(i * 6 + r, v0 + i * 3 + r) = -dt;
+                A(i * 6 + 3 + r, v0 + i * 3 + r) = -1.0;
+                A(i * 6 + 3 + r, v0 + j * 3 + r) = 1.0;
+                rhs[i * 6 + r] = bp[r];
+                rhs[i * 6 + 3 + r] = bv[r];
+            }
+        }
+    }
+
+    void solve_gravity_scale_velocity() {
+        preintegrate();
+        Dense A;
+        std::vector<double> rhs;
+        fill_alignment(A, rhs, false);
+        std::vector<double> x = lstsq_qr(A, rhs);
+        gravity = normalized(V3{x[0], x[1], x[2]}) * kGravityNominal;
+        scale = x[3];
+        for (size_t i = 0; i < map->frame_num(); ++i) velocities[i] = V3{x[4 + 3 * i], x[5 + 3 * i], x[6 + 3 * i]};
+    }
+
+    void refine_scale_velocity_via_gravity() {   // one damped step of the gravity direction on the sphere |g| = 9.80665
+        const double damp = 0.1;
+        preintegrate();
+        Dense A;
+        std::vector<double> rhs;
+        fill_alignment(A, rhs, true);
+        std::vector<double> x = lstsq_qr(A, rhs);
+        V3 t1, t2;
+        s2_tangential_basis(gravity, t1, t2);
+        gravity = normalized(gravity + (t1 * x[0] + t2 * x[1]) * damp) * kGravityNominal;
+        scale = x[2];
+        for (size_t i = 0; i < map->frame_num(); ++i) velocities[i] = V3{x[3 + 3 * i], x[4 + 3 * i], x[5 + 3 * i]};
+    }
+
+    bool apply_init() {   // rotate gravity onto -z, apply the metric scale, set velocities and the gyroscope bias
+        Quat q = quat_from_two_vectors(gravity, V3{0, 0, -kGravityNominal});
+        for (size_t i = 0; i < map->frame_num(); ++i) {
+            Frame *f = map->get_frame(i);
+            PoseState ip = f->get_pose(f->imu);
+            ip.q = q * ip.q;
+            ip.p = (q * ip.p) * scale;
+            f->set_pose(f->imu, ip);
+            f->motion.v = q * velocities[i];
+            f->motion.bg = bg;
+            f->motion.ba = ba;
+        }
+        return retriangulate() >= P_.config.initializer_min_landmarks;
+    }
+
+  public:
     Pipeline &P_;
     std::unique_ptr<Map> map;
 };
@@ -1247,7 +1564,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
     };
     Pipeline P;
     std::unique_ptr<Map> ft_map;
-    BootstrapInitializer init;
+    Initializer init;
     std::unique_ptr<SlidingWindowTracker> swt;
     std::deque<Gyro> gyroscopes;
     std::deque<Acc> accelerometers;

@@ -265,6 +265,21 @@ void XRSLAMAmdGetKltStats(void *out, int reset) {
     guarded([&] { xrh::hip_check(xrhip_klt_get_stats(m.sys->P.klt, static_cast<xrhip_klt_stats *>(out), reset), "xrhip_klt_get_stats"); });
 }
 
+void XRSLAMAmdGetInitReport(XRSLAMAmdInitReport *out) {
+    Manager &m = mgr();
+    if (!m.sys || !out) return;
+    const xrh::Initializer &in = m.sys->init;
+    out->attempts = in.attempts;
+    out->successes = in.successes;
+    out->sfm_candidate = in.sfm_candidate;
+    out->sfm_triangulated = (int)in.sfm_triangulated;
+    out->scale = in.scale;
+    for (int k = 0; k < 3; ++k) {
+        out->gravity[k] = in.gravity[k];
+        out->bg[k] = in.bg[k];
+    }
+}
+
 const char *XRSLAMAmdLastError(void) { return mgr().last_error.c_str(); }
 
 }   // extern "C"

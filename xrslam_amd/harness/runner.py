@@ -37,6 +37,12 @@ class XRSLAMAmdTimes(C.Structure):
                 ("wall_frame", C.c_double), ("wall_scope", C.c_double * 16)]
 
 
+class XRSLAMAmdInitReport(C.Structure):
+    _fields_ = [("attempts", C.c_long), ("successes", C.c_long), ("sfm_candidate", C.c_int),
+                ("sfm_triangulated", C.c_int), ("scale", C.c_double), ("gravity", C.c_double * 3),
+                ("bg", C.c_double * 3)]
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SLAM_YAML = os.path.join(ROOT, "configs", "euroc_slam.yaml")
 SENSOR_YAML = os.path.join(ROOT, "configs", "euroc_sensor.yaml")
@@ -58,6 +64,8 @@ def load(lib_path):
     lib.XRSLAMAmdGetTimes.argtypes = [C.POINTER(XRSLAMAmdTimes)]
     lib.XRSLAMAmdGetTimes.restype = None
     lib.XRSLAMAmdLastError.restype = C.c_char_p
+    lib.XRSLAMAmdGetInitReport.argtypes = [C.POINTER(XRSLAMAmdInitReport)]
+    lib.XRSLAMAmdGetInitReport.restype = None
     lib.XRSLAMAmdSetProfiling.argtypes = [C.c_int]
     lib.XRSLAMAmdSetProfiling.restype = None
     lib.XRSLAMAmdGetKltStats.argtypes = [C.c_void_p, C.c_int]
@@ -158,6 +166,11 @@ class Session:
         st = BaStats()
         self.lib.XRSLAMAmdGetBaStats(C.byref(st), 1 if reset else 0)
         return st
+
+    def init_report(self):
+        r = XRSLAMAmdInitReport()
+        self.lib.XRSLAMAmdGetInitReport(C.byref(r))
+        return r
 
     def error(self):
         return self.lib.XRSLAMAmdLastError().decode()

@@ -65,10 +65,10 @@ class BoxRoom:
         return np.clip(np.rint(val), 0, 255).astype(np.uint8)
 
 
-def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True):
+def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True, traj=None):
     """Returns dict(frames uint8 [n,h,w], cam_t [n], imu [m,7] (t, w, a), states [n,16] ground truth body states)."""
     rng = np.random.RandomState(seed)
-    traj = Trajectory()
+    traj = traj or Trajectory()
     room = BoxRoom(seed=seed)
     bg = rng.randn(3) * 1e-3
     ba = rng.randn(3) * 1e-2
