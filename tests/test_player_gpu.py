@@ -21,11 +21,11 @@ def test_player_tracks_a_synthetic_euroc_directory(tmp_path):
     root = euroc.write_euroc(seq, str(tmp_path / "mav0"))
     out = str(tmp_path / "traj.tum")
     cmd = [PLAYER, "--slam", os.path.join(ROOT, "configs", "bench_slam_150.yaml"), "--device",
-           os.path.join(ROOT, "configs", "euroc_sensor.yaml"), "--euroc", root, "--out", out, "--no-undistort"]
+           os.path.join(ROOT, "configs", "euroc_sensor.yaml"), "--euroc", root, "--out", out, "--no-undistort", "--bootstrap-frames", "60"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res["error"] == "" and res["frames"] == 100 and res["bootstrap_states"] == 60
+    assert res["error"] == "" and res["frames"] == 100 and res["bootstrap_states"] == 60 and res["init_attempts"] == 0
     assert res["tracked"] >= 50                       # the first 36 frames seed the window
     assert 0 <= res["ate_rmse_m"] < 0.03
     rows = np.loadtxt(out)
@@ -45,3 +45,21 @@ def test_player_tracks_a_synthetic_euroc_directory(tmp_path):
     assert n >= 50
     # time stamps went through a ns text round trip, so agreement is close but not bitwise
     assert np.abs(ref[-n:, 1:4] - rows[-n:, 1:4]).max() < 5e-3
+
+
+def test_player_initialises_itself(tmp_path):
+    """Default mode, as the reference's player runs: no ground truth is handed to the library."""
+    from xrslam_amd.harness import euroc, scene
+    from xrslam_amd.harness.trajectory import Trajectory
+    seq = scene.make_sequence(n_frames=90, seed=1, traj=Trajectory(amp=1.5, speed=0.3))
+    root = euroc.write_euroc(seq, str(tmp_path / "mav0"))
+    out = str(tmp_path / "traj.tum")
+    cmd = [PLAYER, "--slam", os.path.join(ROOT, "configs", "euroc_slam.yaml"), "--device",
+           os.path.join(ROOT, "configs", "euroc_sensor.yaml"), "--euroc", root, "--out", out, "--no-undistort"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["error"] == "" and res["frames"] == 90 and res["bootstrap_states"] == 0
+    assert 1 <= res["init_attempts"] <= 12 and 0.5 < res["init_scale"] < 1.0
+    assert res["tracked"] >= 40
+    assert 0 <= res["ate_rmse_m"] < 0.04
