@@ -183,6 +183,14 @@ def test_large_window_uses_global_cholesky_path(ctx, bo):
     _solve_both(ctx, bo, pd, "k16")
 
 
+def test_config5_sized_window(ctx, bo):
+    """BASELINE config 5: 600 features, 20-keyframe window plus the new frame (315 frame unknowns, ~8000 observations)."""
+    pd, _ = bs.make_window(K=21, L=600, seed=4)
+    assert len(pd.obs_lm) > 6000
+    sm_o, sm_h = _solve_both(ctx, bo, pd, "k21")
+    assert sm_h.final_cost < sm_h.initial_cost
+
+
 def _marg_problem(pd, victim=0):
     seen = set(pd.obs_lm[(pd.obs_ref == victim) | (pd.obs_tgt == victim)])
     sel = np.array([l in seen for l in pd.obs_lm])
@@ -195,7 +203,7 @@ def _marg_problem(pd, victim=0):
                                pd.inv_depth, obs)
 
 
-@pytest.mark.parametrize("K,Ln,seed", [(11, 150, 21), (6, 80, 22), (16, 300, 23)])
+@pytest.mark.parametrize("K,Ln,seed", [(11, 150, 21), (6, 80, 22), (16, 300, 23), (21, 600, 24)])
 def test_marginalization_parity(ctx, bo, K, Ln, seed):
     """sqrt_info / infovec are only defined up to an orthogonal transform of the eigenbasis, so parity is
     asserted on the invariants the solver consumes: Lambda = S^T S and eta = S^T infovec."""

@@ -93,6 +93,35 @@ def test_gpu_pipeline_matches_cpu_reference_stress_config():
     assert runner.ate_rmse(list(poses_h), seq) < 0.03
 
 
+@pytest.mark.gpu
+def test_gpu_pipeline_matches_cpu_reference_config5():
+    """BASELINE config 5: synthetic 1280x720 stream, 600 features, 20-keyframe window.  90 frames grow the window to
+    ~13 keyframes x ~600 landmarks (the marginalisation of a 21-frame window is covered by tests/test_ba_gpu.py)."""
+    from xrslam_amd import _lib
+    if not os.path.exists(ORACLE_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    slam, sensor = os.path.join(ROOT, "configs", "large_slam_600.yaml"), os.path.join(ROOT, "configs", "large_sensor_1280.yaml")
+    seq = scene.make_sequence(n_frames=90, seed=9, w=1280, h=720, K=(780.0, 778.0, 640.0, 360.0))
+
+    def run(lib_path):
+        s = runner.Session(lib_path, seq, slam_yaml=slam, sensor_yaml=sensor)
+        while s.step():
+            assert not s.error(), s.error()
+        s.flush()
+        t = s.times()
+        out = np.array(s.poses), (t.frames, t.solves, t.solve_iterations, t.marginalizations, t.keyframes)
+        s.close()
+        return out
+
+    poses_o, counts_o = run(ORACLE_LIB)
+    poses_h, counts_h = run(_lib.LIB_PATH)
+    assert counts_h == counts_o and counts_o[4] >= 10
+    assert poses_h.shape == poses_o.shape
+    np.testing.assert_allclose(poses_h[:, 1:], poses_o[:, 1:], rtol=1e-4, atol=1e-6)
+    assert runner.ate_rmse(list(poses_h), seq) < 0.03
+
+
 # ------------------------------------------------------------------------- self-initialisation (SURVEY 8f-f3)
 # No external initial states: the window comes from the library's own SfM + IMU alignment (core/initializer.cpp).
 # The stream is the figure-eight at half speed, so that the first-to-last keyframe baseline (~0.7 m) passes the

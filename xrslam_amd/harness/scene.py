@@ -65,7 +65,7 @@ class BoxRoom:
         return np.clip(np.rint(val), 0, 255).astype(np.uint8)
 
 
-def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True, traj=None):
+def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True, traj=None, K=K_EUROC):
     """Returns dict(frames uint8 [n,h,w], cam_t [n], imu [m,7] (t, w, a), states [n,16] ground truth body states)."""
     rng = np.random.RandomState(seed)
     traj = traj or Trajectory()
@@ -86,5 +86,5 @@ def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0,
     for i, t in enumerate(cam_t):
         q, p = traj.q(t), traj.p(t)
         states[i] = np.concatenate([q, p, traj.v(t), bg, ba])
-        frames[i] = room.render(qmul(q, Q_BC), p + qrot(q, P_BC), w, h)
+        frames[i] = room.render(qmul(q, Q_BC), p + qrot(q, P_BC), w, h, K)
     return dict(frames=frames, cam_t=cam_t, imu=imu, states=states, bg=bg, ba=ba)
