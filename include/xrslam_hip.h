@@ -227,6 +227,7 @@ typedef struct xrhip_ba_stats {
     double ms_solve_try;     /* sum of HIP-event durations (only launches made while profiling was on) */
     long n_timed;            /* launches that contributed to ms_solve_try */
     double flops_solve_try;  /* algorithmic flops of the timed launches */
+    long n_tiny;             /* solves that ran as ONE launch (kb_tiny: no free landmark, a few free frames); not in the above */
 } xrhip_ba_stats;
 int xrhip_ba_set_profiling(xrhip_ba *ctx, int enable);
 int xrhip_ba_get_stats(xrhip_ba *ctx, xrhip_ba_stats *out, int reset);

@@ -56,7 +56,8 @@ struct xrhip_ba {
     };
     std::vector<Timed> pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
-    xrhip_ba_stats stats = {0, 0, 0.0, 0, 0.0};
+    xrhip_ba_stats stats = {0, 0, 0.0, 0, 0.0, 0};
+    const TinyArgs *tiny_args = nullptr;   // device address of the staged argument block (kb_tiny)
     double *h_out = nullptr;  // pinned readback (states + depths)
     size_t h_out_cap = 0;
     int lds_limit = 150 * 1024;
@@ -237,6 +238,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     const size_t o_act = put(act_idx.data(), sizeof(int) * act_idx.size());
     const size_t o_ainv = put(act_inv.data(), sizeof(int) * act_inv.size());
     const size_t o_ctl = put(&ctl, sizeof(ctl));
+    const size_t o_args = put(nullptr, sizeof(TinyArgs));   // filled below, once the device addresses are known
     const size_t in_bytes = A.used + 256;
 
     // ---- workspace layout (device only)
@@ -266,15 +268,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     int rc = ensure_arena(c, in_bytes, w + 256, (size_t)16 * F + L + 8);
     if (rc) return rc;
     for (const Item &it : items)
-        if (it.bytes) std::memcpy(A.host + it.off, it.src, it.bytes);
-    {
-        char *host_dev = nullptr;   // device-visible address of the pinned staging block
-        XR_HIP(hipHostGetDevicePointer((void **)&host_dev, A.host, 0));
-        const size_t n16 = (in_bytes + 15) / 16;
-        const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 128);
-        hipLaunchKernelGGL(kb_stage, dim3(blocks), dim3(256), 0, c->stream, (const uint4 *)host_dev, (uint4 *)A.dev, n16);
-        XR_HIP(hipGetLastError());
-    }
+        if (it.bytes && it.src) std::memcpy(A.host + it.off, it.src, it.bytes);
 
     char *I = A.dev, *W = c->work;
     p.state = (double *)(I + o_state);
@@ -352,10 +346,35 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     cam.p = V3{P->cam_p_bc[0], P->cam_p_bc[1], P->cam_p_bc[2]};
     imu.q = Q4{P->imu_q_bi[0], P->imu_q_bi[1], P->imu_q_bi[2], P->imu_q_bi[3]};
     imu.p = V3{P->imu_p_bi[0], P->imu_p_bi[1], P->imu_p_bi[2]};
+    {   // the argument block of the single-launch solve travels with the problem
+        TinyArgs *ta = reinterpret_cast<TinyArgs *>(A.host + o_args);
+        ta->d = d;
+        ta->p = p;
+        ta->cam = cam;
+        ta->imu = imu;
+        ta->sx = P->sqrt_inv_cov[0];
+        ta->sy = P->sqrt_inv_cov[1];
+        c->tiny_args = reinterpret_cast<const TinyArgs *>(I + o_args);
+    }
+    {
+        char *host_dev = nullptr;   // device-visible address of the pinned staging block
+        XR_HIP(hipHostGetDevicePointer((void **)&host_dev, A.host, 0));
+        const size_t n16 = (in_bytes + 15) / 16;
+        const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 128);
+        hipLaunchKernelGGL(kb_stage, dim3(blocks), dim3(256), 0, c->stream, (const uint4 *)host_dev, (uint4 *)A.dev, n16);
+        XR_HIP(hipGetLastError());
+    }
     return XRHIP_OK;
 }
 
 // small problems without a free landmark: assembly, preparation and the reduced system in one workgroup (kb_small_mid)
+// no free landmark and a single free frame (localize_newframe, the initialiser's PnP): the whole solve runs inside
+// one launch (kb_tiny).  Measured: with several free frames (refine_subwindow, na = 30..60) the one-workgroup
+// assembly of the active block costs more than the launches and round trips it saves (0.243 vs 0.225 ms per frame).
+static bool tiny(const BaDims &d) {
+    static const bool off = std::getenv("XRHIP_NO_TINY") != nullptr;   // development switch: force the multi-launch path
+    return !off && d.nla == 0 && d.na <= 16 && d.M + d.MR <= 640;
+}
 static bool small_mid(const BaDims &d) { return d.nla == 0 && d.na <= 16; }   // measured: beyond one free frame the wide launches win
 
 // one linearisation: 3 launches + the cost (and, for the solver, gradient norm + per-solve preparation)
@@ -491,7 +510,7 @@ int xrhip_ba_get_stats(xrhip_ba *c, xrhip_ba_stats *out, int reset) {
     if (!c || !out) return xr_fail(XRHIP_EINVAL, "xrhip_ba_get_stats: null argument");
     ba_resolve_pending(c);
     *out = c->stats;
-    if (reset) c->stats = {0, 0, 0.0, 0, 0.0};
+    if (reset) c->stats = {0, 0, 0.0, 0, 0.0, 0};
     return XRHIP_OK;
 }
 
@@ -583,6 +602,21 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16)), dim3(256), 0, s, d.np, p.pS, p.pLam);
     bool done = false, relinearise = true;
     int mode = 1, iter_seen = 0;
+    if (tiny(d)) {   // the whole trust-region loop in one launch (kb_tiny)
+        const int seq = ++c->seq;
+        size_t lds = 0;
+        int use_lds = 1;
+        rc = solve_lds(d, (size_t)c->lds_limit, &lds, &use_lds);
+        if (rc) return rc;
+        lds = std::max(lds, sizeof(double) * (size_t)std::max(TRY_B * (d.np + 15 * d.NI), 1));
+        hipLaunchKernelGGL(kb_tiny, dim3(1), dim3(256), lds, s, c->tiny_args, use_lds, seq, 4 * (P->max_iterations + 8));
+        XR_HIP(hipGetLastError());
+        rc = wait_mailbox(c, seq);
+        if (rc) return rc;
+        if (c->h_ctl->status != ST_DONE) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: trust-region loop did not terminate");
+        c->stats.n_tiny++;
+        done = true;
+    }
     for (int guard = 0; guard < 4 * (P->max_iterations + 8) && !done; ++guard) {
         const int seq = ++c->seq;
         if (relinearise) launch_linearize(c, d, p, cam, imu, sx, sy, true);

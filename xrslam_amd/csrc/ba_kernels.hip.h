@@ -1261,7 +1261,7 @@ __device__ __forceinline__ void publish_block(const BaDims &d, const BaPtrs &p, 
 // `after_linearisation` = this launch directly follows a (re)linearisation or re-solve.
 __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
                                          double sy, int after_linearisation, int seq, bool wide_after_first, double *sh,
-                                         bool prep_only = false) {
+                                         bool prep_only = false, bool publish_always = true) {
     // sh: LDS, TRY_B * np doubles for the prior deltas of the candidates + TRY_B * NI * 15 for the raw IMU residuals
     // wide_after_first: if the first trial is rejected, hand the following ones to kb_trials_wide (ST_NEED_TRIALS)
     __shared__ double scratch[2 * TRY_B * 8];
@@ -1510,7 +1510,7 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
     }
     if (tid == 0) trial_store(c, t);
     __syncthreads();
-    publish_block(d, p, t.status, seq, true);
+    publish_block(d, p, t.status, seq, publish_always);
     return t.status;
 }
 
@@ -1784,8 +1784,7 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
 // launches between the frame-pair blocks and the solve -- Hessian assembly, cost / gradient norm / preparation, the
 // reduced system + Cauchy quadratic form -- are one workgroup's worth of work and run back to back here.
 // Only what the solve reads is assembled: the active x active entries (+ the gradient), zero diagonals elsewhere.
-__global__ __launch_bounds__(256) void kb_small_mid(BaDims d, BaPtrs p, int relinearised) {
-    __shared__ double scratch[8];
+__device__ __forceinline__ void small_mid_block(const BaDims &d, const BaPtrs &p, int relinearised, double *scratch) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     const int n = d.n, na = d.na;
     if (relinearised) {
@@ -1823,6 +1822,105 @@ __global__ __launch_bounds__(256) void kb_small_mid(BaDims d, BaPtrs p, int reli
     acc = block_sum(acc, scratch);
     const int nbq = aux_quad_blocks_n(n, d.L);
     for (int i = tid; i < nbq; i += nt) p.partial[i] = (i == 0) ? acc : 0.0;
+}
+
+__global__ __launch_bounds__(256) void kb_small_mid(BaDims d, BaPtrs p, int relinearised) {
+    __shared__ double scratch[8];
+    small_mid_block(d, p, relinearised, scratch);
+}
+
+// A whole solve in ONE launch for problems without free landmarks (localize_newframe, refine_subwindow, the
+// initialiser's PnP): a handful of free frames, <= a few hundred constant-landmark observations, the IMU factors
+// between them.  One workgroup runs the trust-region loop itself -- linearise, assemble the active block, prepare,
+// factor, trials -- with the same device bodies the multi-launch path uses, and publishes once, when the minimiser
+// terminates.  Saves 5 launches and one host round trip per round.
+// Dynamic LDS: max(solve_block's region, try_block's staging, np doubles for the prior).
+// The argument block lives in device memory (it is staged with the problem): the loop below keeps very little of it
+// in registers, where by-value kernel arguments would pin ~250 scalar registers across every phase.
+struct TinyArgs {
+    BaDims d;
+    BaPtrs p;
+    Ext cam, imu;
+    double sx, sy;
+};
+__global__ __launch_bounds__(256) void kb_tiny(const TinyArgs *__restrict__ args, int use_lds, int seq, int max_rounds) {
+    const BaDims &d = args->d;
+    const BaPtrs &p = args->p;
+    const Ext &cam = args->cam, &imu = args->imu;
+    const double sx = args->sx, sy = args->sy;
+    extern __shared__ double lds[];
+    __shared__ double scr[4][IMU_SCR];
+    __shared__ double scratch[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_next;
+    __shared__ int s_free[64], s_nfree;   // frames with a free pose: only their pairs carry a reprojection block
+    if (tid == 0) {
+        int nf = 0;
+        for (int f = 0; f < d.F; ++f)
+            if (pose_free(p.fix[f]) && nf < 64) s_free[nf++] = f;
+        s_nfree = nf;
+    }
+    __syncthreads();
+    bool relin = true;
+    int mode = 1, st = ST_RUNNING;
+    for (int round = 0; round < max_rounds; ++round) {
+        KPROF_BEGIN();
+        if (relin) {
+            // the IMU factors (a long serial chain on one lane each) take the first wavefronts; the others work
+            // through the observations meanwhile, 64 at a time from a shared counter, and are joined by the IMU
+            // wavefronts as those finish
+            if (tid == 0) s_next = 0;
+            __syncthreads();
+            for (int k = wave; k < d.NI; k += 4) lin_imu_item(d, p, imu, k, lane, scr[wave]);
+            for (;;) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_next, 64);
+                base = __shfl(base, 0);
+                if (base >= d.M + d.MR) break;
+                const int o = base + lane;
+                if (o < d.M) lin_obs_item(d, p, cam, sx, sy, o);
+                else if (o < d.M + d.MR) lin_rot_item(d, p, cam, sx, sy, o - d.M);
+            }
+            KPROF(20);
+            lin_prior_block(d, p, lds, scratch);
+            __syncthreads();
+            KPROF(21);
+            for (int it = wave; it < s_nfree * s_nfree; it += 4)
+                assemble_vision_item(d, p, s_free[it / s_nfree] * d.F + s_free[it % s_nfree], lane);
+            __syncthreads();
+            KPROF(22);
+        }
+        small_mid_block(d, p, relin ? 1 : 0, scratch);
+        __syncthreads();
+        KPROF(23);
+        solve_block(d, p, use_lds, lds);
+        __syncthreads();
+        KPROF(25);
+        st = try_block(d, p, cam, imu, sx, sy, mode, seq, false, lds, false, false);
+        KPROF(26);
+#ifdef XRHIP_KPROF
+        if (tid == 0) p.ctl->prof[27] += 1;   // rounds
+#endif
+        if (st == ST_DONE) return;
+        if (st == ST_ACCEPTED) {
+            relin = true;
+            mode = 1;
+        } else if (st == ST_RESOLVE || st == ST_RESOLVE_INNER) {
+            relin = false;
+            mode = (st == ST_RESOLVE) ? 2 : 3;
+        } else {
+            break;
+        }
+    }
+    // not terminated within the round budget (or an unexpected status): tell the host, which reports an error
+    if (tid == 0) {
+        p.ctl->status = st == ST_DONE ? ST_DONE : -1;
+        const long long *src = reinterpret_cast<const long long *>(p.ctl);
+        long long *dst = reinterpret_cast<long long *>(p.host_ctl);
+        for (unsigned i = 0; i < sizeof(BaCtl) / sizeof(long long); ++i) dst[i] = src[i];
+        __threadfence_system();
+        *reinterpret_cast<volatile int *>(p.host_seq) = seq;
+    }
 }
 
 // The staged problem (a few tens of KB) is pulled from the pinned host arena by the device itself, 16 bytes per

@@ -26,7 +26,7 @@ class XRSLAMPose(C.Structure):
 
 class BaStats(C.Structure):   # xrhip_ba_stats (include/xrslam_hip.h)
     _fields_ = [("n_solve_try", C.c_long), ("n_trials", C.c_long), ("ms_solve_try", C.c_double), ("n_timed", C.c_long),
-                ("flops_solve_try", C.c_double)]
+                ("flops_solve_try", C.c_double), ("n_tiny", C.c_long)]
 
 
 class XRSLAMAmdTimes(C.Structure):
