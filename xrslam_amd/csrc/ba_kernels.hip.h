@@ -324,7 +324,7 @@ __device__ __forceinline__ void lin_imu_item(const BaDims &d, const BaPtrs &p, c
         double r15[15];
         imu_raw_residual(si, sj, pre, bg0, ba0, imu, r15);
         for (int i = 0; i < 15; ++i) raw[i] = r15[i];
-        imu_raw_jacobians(si, sj, pre, bg0, ba0, imu, v3(r15[0], r15[1], r15[2]), Ji, Jj);
+        imu_raw_jacobians(si, sj, pre, bg0, ba0, imu, v3(r15[0], r15[1], r15[2]), Ji, Jj, p.fix[fi] != 3, p.fix[fj] != 3);
     }
     wave_sync();
     const double *S = data + 56;
@@ -342,13 +342,13 @@ __device__ __forceinline__ void lin_imu_item(const BaDims &d, const BaPtrs &p, c
         const int i = e / 15, c = e - 15 * i;
         double a = 0, b = 0;
         if (active) {
-            for (int j = 0; j < 15; ++j) {
-                a += S[15 * i + j] * Ji[15 * j + c];
-                b += S[15 * i + j] * Jj[15 * j + c];
-            }
             // constant blocks contribute no columns
-            if (!(c < 6 ? pose_free(p.fix[fi]) : motion_free(p.fix[fi]))) a = 0.0;
-            if (!(c < 6 ? pose_free(p.fix[fj]) : motion_free(p.fix[fj]))) b = 0.0;
+            const bool col_i = c < 6 ? pose_free(p.fix[fi]) : motion_free(p.fix[fi]);
+            const bool col_j = c < 6 ? pose_free(p.fix[fj]) : motion_free(p.fix[fj]);
+            if (col_i)
+                for (int j = 0; j < 15; ++j) a += S[15 * i + j] * Ji[15 * j + c];
+            if (col_j)
+                for (int j = 0; j < 15; ++j) b += S[15 * i + j] * Jj[15 * j + c];
         }
         p.imu_Ji[(size_t)225 * k + e] = a;
         p.imu_Jj[(size_t)225 * k + e] = b;

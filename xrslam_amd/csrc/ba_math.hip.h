@@ -366,8 +366,9 @@ XD void put33(double *J, int r0, int c0, const M3 &b) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) J[15 * (r0 + i) + c0 + j] = b.m[3 * i + j];
 }
+// need_i / need_j: a side whose frame is constant is left untouched (the caller zeroes it)
 XD void imu_raw_jacobians(const FState &fi, const FState &fj, const ImuRec &pre, V3 bg0, V3 ba0, const Ext &imu,
-                          V3 rq, double *Ji, double *Jj) {
+                          V3 rq, double *Ji, double *Jj, bool need_i = true, bool need_j = true) {
     const V3 gravity = v3(0.0, 0.0, -9.80665);
     const Q4 q_i = q_mul(fi.q, imu.q);
     const Q4 q_j = q_mul(fj.q, imu.q);
@@ -378,6 +379,15 @@ XD void imu_raw_jacobians(const FState &fi, const FState &fj, const ImuRec &pre,
     const M3 Rqi_t = q_mat(q_conj(q_i));
     const M3 Rimu_t = q_mat(q_conj(imu.q));
     const M3 I3 = m3_identity();
+    if (need_j) {
+        put33(Jj, 0, 0, Jr_inv * Rimu_t);
+        put33(Jj, 3, 0, -(Rqi_t * q_mat(fj.q) * hat(imu.p)));
+        put33(Jj, 3, 3, Rqi_t);
+        put33(Jj, 6, 6, Rqi_t);
+        put33(Jj, 9, 9, I3);
+        put33(Jj, 12, 12, I3);
+    }
+    if (!need_i) return;
     put33(Ji, 0, 0, -(Jr_inv * q_mat(q_conj(q_j)) * q_mat(fi.q)));
     put33(Ji, 3, 0, Rimu_t * hat(q_rot(q_conj(fi.q), p_j - fi.p - fi.v * dt - gravity * (0.5 * dt * dt))));
     put33(Ji, 6, 0, Rimu_t * hat(q_rot(q_conj(fi.q), fj.v - fi.v - gravity * dt)));
@@ -391,12 +401,6 @@ XD void imu_raw_jacobians(const FState &fi, const FState &fj, const ImuRec &pre,
     put33(Ji, 3, 12, -pre.dp_dba);
     put33(Ji, 6, 12, -pre.dv_dba);
     put33(Ji, 12, 12, -I3);
-    put33(Jj, 0, 0, Jr_inv * Rimu_t);
-    put33(Jj, 3, 0, -(Rqi_t * q_mat(fj.q) * hat(imu.p)));
-    put33(Jj, 3, 3, Rqi_t);
-    put33(Jj, 6, 6, Rqi_t);
-    put33(Jj, 9, 9, I3);
-    put33(Jj, 12, 12, I3);
 }
 
 // QuaternionParameterization::Plus + additive blocks; d15 = (dq3, dp, dv, dbg, dba); mask bit0: pose free, bit1: motion free
