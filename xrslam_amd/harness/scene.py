@@ -35,11 +35,25 @@ class BoxRoom:
         self.tex = np.stack([_noise_texture(n, seed * 10 + k) for k in range(6)])   # face = 2*axis + (positive side)
         self.n = n
 
-    def render(self, q_wc, p_wc, w=752, h=480, K=K_EUROC):
+    def render(self, q_wc, p_wc, w=752, h=480, K=K_EUROC, dist=None):
+        """dist = (k1, k2, p1, p2): the image is what a radial-tangential lens would record (each pixel's ray is the
+        undistorted direction whose distorted projection lands on that pixel)."""
         fx, fy, cx, cy = K
         xs = (np.arange(w) - cx) / fx
         ys = (np.arange(h) - cy) / fy
-        d_cam = np.stack(np.broadcast_arrays(xs[None, :], ys[:, None], np.ones((h, w))), axis=-1)
+        gx, gy = np.broadcast_arrays(xs[None, :], ys[:, None])
+        if dist is not None:
+            k1, k2, p1, p2 = dist
+            xd, yd = gx, gy
+            x, y = xd.copy(), yd.copy()
+            for _ in range(12):                        # fixed-point inversion of the distortion model
+                r2 = x * x + y * y
+                kr = 1 + (k2 * r2 + k1) * r2
+                dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+                dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+                x, y = (xd - dx) / kr, (yd - dy) / kr
+            gx, gy = x, y
+        d_cam = np.stack([gx, gy, np.ones((h, w))], axis=-1)
         d = d_cam @ qmat(q_wc).T                       # world ray directions
         with np.errstate(divide="ignore", invalid="ignore"):
             side = np.where(d >= 0, 1.0, -1.0)
@@ -65,7 +79,7 @@ class BoxRoom:
         return np.clip(np.rint(val), 0, 255).astype(np.uint8)
 
 
-def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True, traj=None, K=K_EUROC):
+def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True, traj=None, K=K_EUROC, dist=None):
     """Returns dict(frames uint8 [n,h,w], cam_t [n], imu [m,7] (t, w, a), states [n,16] ground truth body states)."""
     rng = np.random.RandomState(seed)
     traj = traj or Trajectory()
@@ -86,5 +100,5 @@ def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0,
     for i, t in enumerate(cam_t):
         q, p = traj.q(t), traj.p(t)
         states[i] = np.concatenate([q, p, traj.v(t), bg, ba])
-        frames[i] = room.render(qmul(q, Q_BC), p + qrot(q, P_BC), w, h, K)
+        frames[i] = room.render(qmul(q, Q_BC), p + qrot(q, P_BC), w, h, K, dist)
     return dict(frames=frames, cam_t=cam_t, imu=imu, states=states, bg=bg, ba=ba)
