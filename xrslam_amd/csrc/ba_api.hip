@@ -370,10 +370,11 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
 // small problems without a free landmark: assembly, preparation and the reduced system in one workgroup (kb_small_mid)
 // no free landmark and a single free frame (localize_newframe, the initialiser's PnP): the whole solve runs inside
 // one launch (kb_tiny).  Measured: with several free frames (refine_subwindow, na = 30..60) the one-workgroup
-// assembly of the active block costs more than the launches and round trips it saves (0.243 vs 0.225 ms per frame).
+// assembly of the active block (26 of its 41 us: ~60 dependent-latency loads per entry, 8 entries per thread) costs more
+// than the launches and round trips it saves (0.243 vs 0.215 ms per frame; index tables in LDS did not change that).
 static bool tiny(const BaDims &d) {
     static const bool off = std::getenv("XRHIP_NO_TINY") != nullptr;   // development switch: force the multi-launch path
-    return !off && d.nla == 0 && d.na <= 16 && d.M + d.MR <= 640;
+    return !off && d.nla == 0 && d.na <= 16 && d.M + d.MR <= 640 && d.F <= 64;   // kb_tiny lists the free frames in s_free[64]
 }
 static bool small_mid(const BaDims &d) { return d.nla == 0 && d.na <= 16; }   // measured: beyond one free frame the wide launches win
 

@@ -523,6 +523,11 @@ __device__ __forceinline__ void assemble_vision_item(const BaDims &d, const BaPt
     const int fa = pair / d.F, fb = pair - fa * d.F;
     if (!pose_free(p.fix[fa]) || !pose_free(p.fix[fb])) return;   // the block is never read (kb_assemble)
     const int s0 = p.pair_start[fa * d.F + fb], s1 = p.pair_start[fa * d.F + fb + 1];
+    if (s0 == s1) {   // no shared observation (always the case off the diagonal when the landmarks' reference frames are constant)
+        if (lane < 36) p.Hv[(size_t)pair * 36 + lane] = 0.0;
+        if (fa == fb && lane < 6) p.gv[6 * fa + lane] = 0.0;
+        return;
+    }
     double h[36], g[6];
 #pragma unroll
     for (int i = 0; i < 36; ++i) h[i] = 0.0;
