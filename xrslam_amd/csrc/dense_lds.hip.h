@@ -117,6 +117,33 @@ __device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double
 // (nrows >= n, packed right behind the matrix) are carried along as right-hand sides: they end up holding
 // L^-1 rhs.  Dinv is a [CH_NB][CH_NB+1] LDS scratch block, s_fail an LDS flag.  All threads of the workgroup
 // must call.  Returns false (uniformly) if a non-positive pivot is met.
+//
+// One panel of lookahead: the 16x16 diagonal factorisation is a serial chain on ONE wavefront (~6 us) and used to
+// leave the others idle, followed by a trailing update (~4 us at 150 unknowns) that left nothing for the next
+// diagonal block to overlap with.  Now wavefront 0 updates the next diagonal tile (and, before the last panel, the
+// right-hand-side tile that block needs) first and factors it while the other wavefronts finish the trailing update.
+// Every tile is computed exactly as before, only by a different wavefront: results are bitwise unchanged.
+__device__ __forceinline__ void chol_trailing_tile(double *A, int n, int nrows, int j0, int nb, int jb, int ti, int tj,
+                                                   int r16, int q) {
+    // A22 tile (ti, tj) -= P_ti P_tj^T, one tile = four v_mfma_f64_16x16x4_f64 (k = 16)
+    const int gi = jb + 16 * ti + r16, gk = jb + 16 * tj + r16;
+    const double *pa = A + tri_idx(min(gi, nrows - 1), j0) + q;
+    const double *pb = A + tri_idx(min(gk, n - 1), j0) + q;
+    const bool va = gi < nrows, vb = gk < n;
+    chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const bool vk = 4 * s4 + q < nb;
+        const double av = (va && vk) ? pa[4 * s4] : 0.0, bv = (vb && vk) ? pb[4 * s4] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oi = jb + 16 * ti + q + 4 * r, ok = jb + 16 * tj + r16;
+        if (oi < nrows && ok < n && ok <= oi) A[tri_idx(oi, ok)] -= acc[r];
+    }
+}
+
 __device__ __forceinline__ bool chol_blocked(double *A, int n, int nrows, double (*Dinv)[CH_NB + 1], int *s_fail,
                                              long long *prof = nullptr) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
@@ -126,74 +153,76 @@ __device__ __forceinline__ bool chol_blocked(double *A, int n, int nrows, double
 #endif
     if (tid == 0) *s_fail = 0;
     __syncthreads();
+    double *rhs = A + tri_idx(n, 0);
+    // ---- (1) diagonal block: factor + invert, wavefront 0, registers only.  The last panel of a system with a
+    // single rhs row needs no inverse: that row is substituted in the same registers.
+    if (n > 0 && wave == 0) {
+        const int nb0 = min(CH_NB, n);
+        const bool lwr0 = (nb0 >= n) && (nrows == n + 1);
+        if (!chol_diag_wave(A, 0, nb0, Dinv, lane, lwr0 ? rhs : nullptr) && lane == 0) *s_fail = 1;
+    }
+    __syncthreads();
+    CHPROF(0);
+    if (*s_fail) return false;
     for (int j0 = 0; j0 < n; j0 += CH_NB) {
         const int nb = min(CH_NB, n - j0);
-        // ---- (1) diagonal block: factor + invert, wavefront 0, registers only.  The last panel of a system with a
-        // single rhs row needs no inverse: that row is substituted in the same registers.
         const int jb = j0 + nb;
         const bool last_with_rhs = (jb >= n) && (nrows == n + 1);
-        if (wave == 0) {
-            if (!chol_diag_wave(A, j0, nb, Dinv, lane, last_with_rhs ? A + tri_idx(n, 0) : nullptr) && lane == 0) *s_fail = 1;
-        }
-        __syncthreads();
-        CHPROF(0);
-        if (*s_fail) return false;
         if (jb >= nrows || last_with_rhs) break;
         // ---- (2) panel: X = P Linv^T for the rows below the block, 16-row tiles on the matrix cores.
         // A[i][k] from lane (i = lane & 15, k = lane >> 4), B[k][j] = Linv[j][k] from lane (k = lane >> 4, j = lane & 15).
-        {
-            const int T = (nrows - jb + 15) >> 4;
-            for (int t = wave; t < T; t += nw) {
-                const int gi = jb + 16 * t + r16;
-                const bool va = gi < nrows;
-                const double *pa = A + tri_idx(min(gi, nrows - 1), j0) + q;
-                chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const int T = (nrows - jb + 15) >> 4;
+        for (int t = wave; t < T; t += nw) {
+            const int gi = jb + 16 * t + r16;
+            const bool va = gi < nrows;
+            const double *pa = A + tri_idx(min(gi, nrows - 1), j0) + q;
+            chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int kcol = 4 * s4 + q;
-                    const double av = (va && kcol < nb) ? pa[4 * s4] : 0.0;
-                    const double bv = Dinv[r16][kcol];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                }
-                // D[(lane >> 4) + 4 r][lane & 15]
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int kcol = 4 * s4 + q;
+                const double av = (va && kcol < nb) ? pa[4 * s4] : 0.0;
+                const double bv = Dinv[r16][kcol];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+            // D[(lane >> 4) + 4 r][lane & 15]
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int oi = jb + 16 * t + q + 4 * r;
-                    if (oi < nrows && r16 < nb) A[tri_idx(oi, j0 + r16)] = acc[r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int oi = jb + 16 * t + q + 4 * r;
+                if (oi < nrows && r16 < nb) A[tri_idx(oi, j0 + r16)] = acc[r];
             }
         }
         __syncthreads();
         CHPROF(1);
-        // ---- (3) trailing update A22 -= P P^T: 16x16 tiles of the lower triangle (and of the rhs rows), one
-        // tile = four v_mfma_f64_16x16x4_f64 (k = 16)
-        {
-            const int T = (nrows - jb + 15) >> 4;
+        // ---- (3) trailing update A22 -= P P^T over the 16x16 tiles of the lower triangle (and of the rhs rows),
+        // overlapped with (1) of the next panel
+        const bool has_next = jb < n;
+        const int nb1 = has_next ? min(CH_NB, n - jb) : 0;
+        const bool lwr1 = has_next && (jb + nb1 >= n) && (nrows == n + 1);
+        const int rhs_ti = (n - jb) >> 4;            // tile row that holds row n (the first rhs row)
+        const bool look = has_next && nw > 1;        // wavefront 0 leaves the bulk of the tiles to the others
+        if (look && wave == 0) {
+            chol_trailing_tile(A, n, nrows, j0, nb, jb, 0, 0, r16, q);
+            if (lwr1 && rhs_ti != 0) chol_trailing_tile(A, n, nrows, j0, nb, jb, rhs_ti, 0, r16, q);
+            __threadfence_block();   // other lanes of this wavefront read those entries next (A may be in global memory)
+            if (!chol_diag_wave(A, jb, nb1, Dinv, lane, lwr1 ? rhs : nullptr) && lane == 0) *s_fail = 1;
+        } else {
+            const int workers = look ? nw - 1 : nw, me = look ? wave - 1 : wave;
             int t = 0;
             for (int ti = 0; ti < T; ++ti)
-                for (int tj = 0; tj <= ti; ++tj, ++t) {
-                    if (t % nw != wave) continue;
+                for (int tj = 0; tj <= ti; ++tj) {
                     if (jb + 16 * tj >= n) continue;   // rhs rows have no columns of their own
-                    const int gi = jb + 16 * ti + r16, gk = jb + 16 * tj + r16;
-                    const double *pa = A + tri_idx(min(gi, nrows - 1), j0) + q;
-                    const double *pb = A + tri_idx(min(gk, n - 1), j0) + q;
-                    const bool va = gi < nrows, vb = gk < n;
-                    chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const bool vk = 4 * s4 + q < nb;
-                        const double av = (va && vk) ? pa[4 * s4] : 0.0, bv = (vb && vk) ? pb[4 * s4] : 0.0;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int oi = jb + 16 * ti + q + 4 * r, ok = jb + 16 * tj + r16;
-                        if (oi < nrows && ok < n && ok <= oi) A[tri_idx(oi, ok)] -= acc[r];
-                    }
+                    if (look && tj == 0 && (ti == 0 || (lwr1 && ti == rhs_ti))) continue;   // wavefront 0's tiles
+                    if (t++ % workers != me) continue;
+                    chol_trailing_tile(A, n, nrows, j0, nb, jb, ti, tj, r16, q);
                 }
         }
         __syncthreads();
+        if (has_next && !look) {   // single-wavefront workgroups: no overlap to be had
+            if (!chol_diag_wave(A, jb, nb1, Dinv, lane, lwr1 ? rhs : nullptr) && lane == 0) *s_fail = 1;
+            __syncthreads();
+        }
         CHPROF(2);
+        if (*s_fail) return false;
     }
     return true;
 }
