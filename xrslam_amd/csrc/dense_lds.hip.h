@@ -69,8 +69,24 @@ __device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double
             ok = false;
             dcc = 1.0;
         }
-        const double dd = sqrt(dcc);
-        dinv[c] = 1.0 / dd;
+        // sqrt(d) and 1/sqrt(d) together from the hardware reciprocal square root (v_rsq_f64, ~27 bits) and two coupled
+        // Newton steps -- the library sqrt followed by a division is ~3x as long, and this sits on the serial chain of
+        // every panel.  Pivots here are O(1) after Jacobi scaling (1e30 at most, in the marginalisation): no denormals.
+        double dd, hh;
+        {
+            const double r0 = __builtin_amdgcn_rsq(dcc);
+            dd = dcc * r0;
+            hh = 0.5 * r0;
+            double e = fma(-hh, dd, 0.5);
+            dd = fma(dd, e, dd);
+            hh = fma(hh, e, hh);
+            e = fma(-hh, dd, 0.5);
+            dd = fma(dd, e, dd);
+            hh = fma(hh, e, hh);
+            const double res = fma(-dd, dd, dcc);
+            dd = fma(res, hh, dd);
+        }
+        dinv[c] = hh + hh;
         x[c] = (lane == c) ? dd : x[c] * dinv[c];
 #pragma unroll
         for (int k = c + 1; k < CH_NB; ++k) {
