@@ -1858,6 +1858,7 @@ __global__ __launch_bounds__(256) void kb_tiny(const TinyArgs *__restrict__ args
     __shared__ double scratch[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ int s_next;
+    __shared__ double s_vis[4][27];
     __shared__ int s_free[64], s_nfree;   // frames with a free pose: only their pairs carry a reprojection block
     if (tid == 0) {
         int nf = 0;
@@ -1890,8 +1891,48 @@ __global__ __launch_bounds__(256) void kb_tiny(const TinyArgs *__restrict__ args
             lin_prior_block(d, p, lds, scratch);
             __syncthreads();
             KPROF(21);
-            for (int it = wave; it < s_nfree * s_nfree; it += 4)
-                assemble_vision_item(d, p, s_free[it / s_nfree] * d.F + s_free[it % s_nfree], lane);
+            if (s_nfree == 1) {
+                // the one 6x6 reprojection block (f, f): its observations are shared out over all four wavefronts
+                // (assemble_vision_item would leave three of them idle); upper triangle + gradient = 27 sums
+                const int f = s_free[0], pair = f * d.F + f;
+                const int s0 = p.pair_start[pair], s1 = p.pair_start[pair + 1];
+                double acc[27];
+#pragma unroll
+                for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+                for (int it = s0 + tid; it < s1; it += 256) {
+                    const int code = p.pair_items[it];
+                    const double *rec = p.orec + (size_t)(code >> 1) * OREC + ((code & 1) ? 12 : 0);
+                    double j[12];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) j[i] = rec[i];
+                    const double *rr = p.orec + (size_t)(code >> 1) * OREC + 26;
+                    const double r0 = rr[0], r1 = rr[1];
+                    int e = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                        for (int b = a; b < 6; ++b) acc[e++] += j[a] * j[b] + j[6 + a] * j[6 + b];
+                        acc[21 + a] += j[a] * r0 + j[6 + a] * r1;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
+                if (lane == 0)
+#pragma unroll
+                    for (int i = 0; i < 27; ++i) s_vis[wave][i] = acc[i];
+                __syncthreads();
+                if (tid < 36) {
+                    const int a = tid / 6, b = tid - 6 * a, lo = a < b ? a : b, hi = a < b ? b : a;
+                    const int e = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);   // index in the row-major upper triangle
+                    p.Hv[(size_t)pair * 36 + tid] = (s_vis[0][e] + s_vis[1][e]) + (s_vis[2][e] + s_vis[3][e]);
+                } else if (tid < 42) {
+                    const int a = tid - 36;
+                    p.gv[6 * f + a] = (s_vis[0][21 + a] + s_vis[1][21 + a]) + (s_vis[2][21 + a] + s_vis[3][21 + a]);
+                }
+            } else {
+                for (int it = wave; it < s_nfree * s_nfree; it += 4)
+                    assemble_vision_item(d, p, s_free[it / s_nfree] * d.F + s_free[it % s_nfree], lane);
+            }
             __syncthreads();
             KPROF(22);
         }
