@@ -160,14 +160,22 @@ struct Pipeline {
         V3 bg, ba;
     };
     std::vector<char> integrate_batch(const std::vector<IntegrateJob> &jobs, bool jac, bool cov) {
+        std::vector<char> ok = integrate_batch_begin(jobs, jac, cov);
+        integrate_batch_end();
+        return ok;
+    }
+    // asynchronous form: _begin queues the launch and returns which jobs had samples, _end waits and stores the records.
+    // Between the two the caller assembles the problem that will read them (BaBuilder copies records at solve time).
+    std::vector<char> integrate_batch_begin(const std::vector<IntegrateJob> &jobs, bool jac, bool cov) {
         std::vector<char> ok(jobs.size(), 0);
         std::vector<double> smp, t_end, bgs, bas;
-        std::vector<int> begin, count, which;
+        std::vector<int> begin, count;
+        pending_pre_.clear();
         for (size_t k = 0; k < jobs.size(); ++k) {
             const PreInt &pre = *jobs[k].pre;
             if (pre.data.empty()) continue;
             ok[k] = 1;
-            which.push_back((int)k);
+            pending_pre_.push_back(jobs[k].pre);
             begin.push_back((int)(smp.size() / 7));
             count.push_back((int)pre.data.size());
             t_end.push_back(jobs[k].t);
@@ -179,21 +187,27 @@ struct Pipeline {
             bgs.insert(bgs.end(), b1, b1 + 3);
             bas.insert(bas.end(), b2, b2 + 3);
         }
-        if (which.empty()) return ok;
-        std::vector<double> out((size_t)XRHIP_IMU_DIM * which.size());
-        {
-            WallTimer wt_w_preintegrate(times.w_preintegrate);
-            hip_check(xrhip_ba_preintegrate_batch(ba, smp.data(), begin.data(), count.data(), t_end.data(), bgs.data(),
-                                                  bas.data(), (int)which.size(), noise36, jac, cov, out.data()),
-                      "xrhip_ba_preintegrate_batch");
-        }
-        for (size_t i = 0; i < which.size(); ++i) {
-            PreInt &pre = *jobs[which[i]].pre;
-            std::memcpy(pre.rec, &out[(size_t)XRHIP_IMU_DIM * i], sizeof(double) * XRHIP_IMU_DIM);
-            pre.valid = true;
-        }
+        if (pending_pre_.empty()) return ok;
+        WallTimer wt_w_preintegrate(times.w_preintegrate);
+        hip_check(xrhip_ba_preintegrate_begin(ba, smp.data(), begin.data(), count.data(), t_end.data(), bgs.data(), bas.data(),
+                                              (int)pending_pre_.size(), noise36, jac, cov),
+                  "xrhip_ba_preintegrate_begin");
         return ok;
     }
+    void integrate_batch_end() {
+        if (pending_pre_.empty()) return;
+        std::vector<double> out((size_t)XRHIP_IMU_DIM * pending_pre_.size());
+        {
+            WallTimer wt_w_preintegrate(times.w_preintegrate);
+            hip_check(xrhip_ba_preintegrate_end(ba, out.data()), "xrhip_ba_preintegrate_end");
+        }
+        for (size_t i = 0; i < pending_pre_.size(); ++i) {
+            std::memcpy(pending_pre_[i]->rec, &out[(size_t)XRHIP_IMU_DIM * i], sizeof(double) * XRHIP_IMU_DIM);
+            pending_pre_[i]->valid = true;
+        }
+        pending_pre_.clear();
+    }
+    std::vector<PreInt *> pending_pre_;
 };
 
 inline HipImage::~HipImage() {
@@ -395,12 +409,12 @@ class BaBuilder {
     void add_preintegration_error(Frame *fi, Frame *fj, const PreInt &pre) {
         imu_i_.push_back(frame_index(fi, false));
         imu_j_.push_back(frame_index(fj, false));
-        imu_data_.insert(imu_data_.end(), pre.rec, pre.rec + XRHIP_IMU_DIM);
+        imu_pre_.push_back(&pre);
     }
     void add_preintegration_prior(Frame *fi, Frame *fj, const PreInt &pre) {
         imu_i_.push_back(const_frame(fi));
         imu_j_.push_back(frame_index(fj, false));
-        imu_data_.insert(imu_data_.end(), pre.rec, pre.rec + XRHIP_IMU_DIM);
+        imu_pre_.push_back(&pre);
     }
     void add_marginalization(MargPrior *m) { prior_ = m; }
 
@@ -463,6 +477,11 @@ class BaBuilder {
         pb.n_imu = (int)imu_i_.size();
         pb.imu_i = imu_i_.data();
         pb.imu_j = imu_j_.data();
+        // the pre-integration records are read here, not when the factor was added: a batch integration started before
+        // the assembly (Pipeline::integrate_batch_begin) only has to be finished by now
+        imu_data_.resize((size_t)XRHIP_IMU_DIM * imu_pre_.size());
+        for (size_t k = 0; k < imu_pre_.size(); ++k)
+            std::memcpy(&imu_data_[(size_t)XRHIP_IMU_DIM * k], imu_pre_[k]->rec, sizeof(double) * XRHIP_IMU_DIM);
         pb.imu_data = imu_data_.data();
         std::vector<int> pframes;
         if (prior_) {
@@ -536,6 +555,7 @@ class BaBuilder {
     std::vector<uint8_t> fix_, lfix_;
     std::vector<int> obs_tgt_, obs_ref_, obs_lm_, rot_tgt_, rot_ref_, imu_i_, imu_j_;
     std::vector<double> obs_zt_, obs_zr_, rot_zt_, rot_zr_, imu_data_;
+    std::vector<const PreInt *> imu_pre_;
     MargPrior *prior_ = nullptr;
 };
 
@@ -795,6 +815,20 @@ class SlidingWindowTracker {
         WallTimer sc_t(P_.times.scope[SC_REFINE_WINDOW]);
         BaBuilder b(P_);
         if (!map->marginalization_factor) map->marginalization_factor = create_marginalization_factor(map.get());
+        // the keyframe intervals are re-integrated at the current biases: queued now, the device works on them while the
+        // host walks the tracks below; the records are read when the problem is handed over (BaBuilder::solve)
+        std::vector<Pipeline::IntegrateJob> kf_jobs;
+        for (size_t j = 1; j < map->frame_num(); ++j) {
+            Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
+            fj->keyframe_preintegration = fj->preintegration;
+            if (!fi->subframes.empty()) {
+                std::vector<ImuData> extra;
+                for (auto &sf : fi->subframes) extra.insert(extra.end(), sf->preintegration.data.begin(), sf->preintegration.data.end());
+                fj->keyframe_preintegration.data.insert(fj->keyframe_preintegration.data.begin(), extra.begin(), extra.end());
+            }
+            kf_jobs.push_back({&fj->keyframe_preintegration, fj->image->t, fi->motion.bg, fi->motion.ba});
+        }
+        const std::vector<char> ok = P_.integrate_batch_begin(kf_jobs, true, true);
         for (size_t i = 0; i < map->frame_num(); ++i) b.add_frame_states(map->get_frame(i));
         std::unordered_set<Track *> visited;
         for (size_t i = 0; i < map->frame_num(); ++i) {
@@ -819,25 +853,14 @@ class SlidingWindowTracker {
                 b.add_reprojection_error(f, j);
             }
         }
-        std::vector<Pipeline::IntegrateJob> kf_jobs;
-        for (size_t j = 1; j < map->frame_num(); ++j) {
-            Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
-            fj->keyframe_preintegration = fj->preintegration;
-            if (!fi->subframes.empty()) {
-                std::vector<ImuData> extra;
-                for (auto &sf : fi->subframes) extra.insert(extra.end(), sf->preintegration.data.begin(), sf->preintegration.data.end());
-                fj->keyframe_preintegration.data.insert(fj->keyframe_preintegration.data.begin(), extra.begin(), extra.end());
-            }
-            kf_jobs.push_back({&fj->keyframe_preintegration, fj->image->t, fi->motion.bg, fi->motion.ba});
-        }
         {
-            const std::vector<char> ok = P_.integrate_batch(kf_jobs, true, true);
             for (size_t j = 1; j < map->frame_num(); ++j)
                 if (ok[j - 1]) {
                     Frame *fj = map->get_frame(j);
                     b.add_preintegration_error(map->get_frame(j - 1), fj, fj->keyframe_preintegration);
                 }
         }
+        P_.integrate_batch_end();
         b.solve();
         for (size_t k = 0; k < map->track_num(); ++k) {
             Track *t = map->get_track(k);
@@ -879,14 +902,14 @@ class SlidingWindowTracker {
     }
 
     // (re-)integrate every subframe interval of `frame` with the current biases, one launch
-    void integrate_subframes(Frame *frame) {
+    void integrate_subframes_begin(Frame *frame) {   // finished by Pipeline::integrate_batch_end before the solve
         std::vector<Pipeline::IntegrateJob> jobs;
         for (size_t i = 0; i < frame->subframes.size(); ++i) {
             Frame *sf = frame->subframes[i].get();
             Frame *prev = (i == 0 ? frame : frame->subframes[i - 1].get());
             jobs.push_back({&sf->preintegration, sf->image->t, prev->motion.bg, prev->motion.ba});
         }
-        P_.integrate_batch(jobs, true, true);
+        P_.integrate_batch_begin(jobs, true, true);
     }
 
     void refine_subwindow() {   // :370-465
@@ -911,7 +934,7 @@ class SlidingWindowTracker {
             frame->tag(FT_FIX_POSE) = true;
             frame->tag(FT_FIX_MOTION) = true;
             b.add_frame_states(frame);
-            integrate_subframes(frame);
+            integrate_subframes_begin(frame);
             for (size_t i = 0; i < frame->subframes.size(); ++i) {
                 Frame *sf = frame->subframes[i].get();
                 b.add_frame_states(sf);
@@ -930,6 +953,7 @@ class SlidingWindowTracker {
                     }
                 }
             }
+            P_.integrate_batch_end();
             b.solve();
             frame->tag(FT_FIX_POSE) = false;
             frame->tag(FT_FIX_MOTION) = false;
@@ -938,7 +962,7 @@ class SlidingWindowTracker {
             frame->tag(FT_FIX_POSE) = true;
             frame->tag(FT_FIX_MOTION) = true;
             b.add_frame_states(frame);
-            integrate_subframes(frame);
+            integrate_subframes_begin(frame);
             for (size_t i = 0; i < frame->subframes.size(); ++i) {
                 Frame *sf = frame->subframes[i].get();
                 b.add_frame_states(sf);
@@ -955,6 +979,7 @@ class SlidingWindowTracker {
                     }
                 }
             }
+            P_.integrate_batch_end();
             b.solve();
             frame->tag(FT_FIX_POSE) = false;
             frame->tag(FT_FIX_MOTION) = false;
