@@ -235,6 +235,11 @@ int xrhip_ba_get_stats(xrhip_ba *ctx, xrhip_ba_stats *out, int reset);
  * remaining frames (map order): sqrt_info [(15(n-1))^2], infovec [15(n-1)], lin [(n-1)][16]. */
 int xrhip_ba_marginalize(xrhip_ba *ctx, const xrhip_marg_problem *problem, double *out_sqrt_info,
                          double *out_infovec, double *out_lin);
+/* asynchronous form: _begin stages the problem and queues all of its device work, _end waits and returns the prior.
+ * One marginalisation in flight per context, and no other call on that context in between (give the marginalisation a
+ * context of its own -- its stream then runs beside the tracker and the solves of the next frame). */
+int xrhip_ba_marginalize_begin(xrhip_ba *ctx, const xrhip_marg_problem *problem);
+int xrhip_ba_marginalize_end(xrhip_ba *ctx, double *out_sqrt_info, double *out_infovec, double *out_lin);
 /* replaces: PreIntegrator::integrate(t, bg, ba, compute_jacobian, compute_covariance)
  * (preintegrator.cpp:78-100).  samples: [n][7] = t, w(3), a(3); noise: cov_w, cov_a, cov_bg, cov_ba as
  * 3x3 row-major (36 doubles).  out: XRHIP_IMU_DIM doubles. */

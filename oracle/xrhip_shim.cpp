@@ -162,4 +162,22 @@ int xrhip_ba_preintegrate_end(xrhip_ba *, double *out) {
     std::memcpy(out, g_preint_out.data(), sizeof(double) * g_preint_out.size());
     return 0;
 }
+// same for the marginalisation
+static std::vector<double> g_marg_si, g_marg_iv, g_marg_lin;
+static int g_marg_rc = 0;
+int xrhip_ba_marginalize_begin(xrhip_ba *c, const xrhip_marg_problem *M) {
+    const size_t R = 15 * (size_t)(M->n_frames - 1);
+    g_marg_si.assign(R * R, 0.0);
+    g_marg_iv.assign(R, 0.0);
+    g_marg_lin.assign(16 * (size_t)(M->n_frames - 1), 0.0);
+    g_marg_rc = xrhip_ba_marginalize(c, M, g_marg_si.data(), g_marg_iv.data(), g_marg_lin.data());
+    return 0;
+}
+int xrhip_ba_marginalize_end(xrhip_ba *, double *si, double *iv, double *lin) {
+    if (g_marg_rc) return g_marg_rc;
+    std::memcpy(si, g_marg_si.data(), sizeof(double) * g_marg_si.size());
+    std::memcpy(iv, g_marg_iv.data(), sizeof(double) * g_marg_iv.size());
+    std::memcpy(lin, g_marg_lin.data(), sizeof(double) * g_marg_lin.size());
+    return 0;
+}
 }

@@ -232,6 +232,26 @@ def test_marginalization_parity(ctx, bo, K, Ln, seed):
     _solve_both(ctx, bo, p2, "after_marg%d" % seed, rtol=1e-6)
 
 
+def test_marginalization_begin_end_equals_the_blocking_call(ctx):
+    """The asynchronous pair queues the same kernels on the context's stream; solves on ANOTHER context may run in
+    between (the pipeline gives the marginalisation a context of its own)."""
+    from xrslam_amd import ba
+    other = ba.BaContext()
+    pd, _ = bs.make_window(K=11, L=150, seed=21)
+    md = _marg_problem(pd)
+    si0, iv0, lin0 = ctx.marginalize(md)
+    ctx.marginalize_begin(md)
+    pd2, _ = bs.make_localize(seed=2)
+    sm = other.solve(pd2)                       # unrelated work on a second context while the first one is busy
+    assert sm.usable
+    si1, iv1, lin1 = ctx.marginalize_end()
+    np.testing.assert_array_equal(si1, si0)
+    np.testing.assert_array_equal(iv1, iv0)
+    np.testing.assert_array_equal(lin1, lin0)
+    with pytest.raises(Exception):
+        ctx.marginalize_end()                   # nothing in flight any more
+
+
 def test_preintegration_parity(ctx, bo):
     pd, truth = bs.make_window(K=5, L=20, seed=31)
     for k, smp in enumerate(truth["samples"]):

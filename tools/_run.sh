@@ -1,4 +1,4 @@
-timeout 900 python -m pytest tests/test_pipeline.py tests/test_player_gpu.py -m gpu -x -q 2>&1 | tail -3
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 for i in 1 2 3; do
   timeout 300 python bench.py 2>/dev/null | tail -1 > /tmp/b.json
   python3 -c "

@@ -20,6 +20,9 @@ def L():
         lib.xrhip_ba_solve.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary)]
         if hasattr(lib, "xrhip_ba_marginalize"):
             lib.xrhip_ba_marginalize.argtypes = [vp, C.POINTER(abi.MargProblem), vp, vp, vp]
+        if hasattr(lib, "xrhip_ba_marginalize_begin"):
+            lib.xrhip_ba_marginalize_begin.argtypes = [vp, C.POINTER(abi.MargProblem)]
+            lib.xrhip_ba_marginalize_end.argtypes = [vp, vp, vp, vp]
         if hasattr(lib, "xrhip_ba_preintegrate"):
             lib.xrhip_ba_preintegrate.argtypes = [vp, vp, C.c_int, C.c_double, vp, vp, vp, C.c_int, C.c_int, vp]
         lib.xrhip_ba_debug_linearize.argtypes = [vp, C.POINTER(abi.BaProblem), vp, vp, vp, vp, vp, vp]
@@ -66,6 +69,20 @@ class BaContext:
         iv = np.zeros(n)
         lin = np.zeros((k, 16))
         check(L().xrhip_ba_marginalize(self._h, C.byref(s), _p(si), _p(iv), _p(lin)))
+        return si, iv, lin
+
+    def marginalize_begin(self, md):
+        """Queues the marginalisation (xrhip_ba_marginalize_begin); marginalize_end() returns its result."""
+        self._marg_k = len(md.frame_state) - 1
+        check(L().xrhip_ba_marginalize_begin(self._h, C.byref(md.struct())))
+
+    def marginalize_end(self):
+        k = self._marg_k
+        n = 15 * k
+        si = np.zeros((n, n))
+        iv = np.zeros(n)
+        lin = np.zeros((k, 16))
+        check(L().xrhip_ba_marginalize_end(self._h, _p(si), _p(iv), _p(lin)))
         return si, iv, lin
 
     def preintegrate(self, samples, t_end, bg, ba, noise36, jac=True, cov=True):

@@ -45,6 +45,13 @@ struct xrhip_ba {
     BaCtl *h_ctl = nullptr;   // pinned; doubles as the zero-copy mailbox of kb_solve_try
     int *h_seq = nullptr;     // pinned; sequence number published by kb_solve_try after h_ctl / h_out
     int seq = 0;
+    struct MargPending {   // a marginalisation queued by marg_launch and not yet collected
+        bool pending = false;
+        int K = 0, victim = 0, R = 0;
+        std::vector<double> lin;
+        int *dst = nullptr, *dsup = nullptr;
+        double *As = nullptr, *bs = nullptr, *B = nullptr, *V = nullptr, *Ss = nullptr, *ivs = nullptr, *dsi = nullptr, *div = nullptr;
+    } marg;
     int preint_pending = 0;            // jobs of the pre-integration batch in flight (begin/end), 0 = none
     size_t preint_o_out = 0, preint_o_st = 0;
     // optional HIP-event profiling of kb_solve_try
@@ -781,9 +788,11 @@ static int ensure_work2(xrhip_ba *c, size_t dev_bytes, size_t host_bytes) {
 
 extern "C" {
 
-int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_sqrt_info, double *out_infovec,
-                         double *out_lin) {
-    if (!c || !M || !out_sqrt_info || !out_infovec || !out_lin) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: null argument");
+// Marginalisation in two halves.  marg_launch stages the problem and queues EVERY kernel and copy of the Cholesky
+// path (the common one) without waiting; marg_collect waits, re-does the tail through the eigen-solver if the device
+// reported that the Cholesky path does not apply, and hands the prior out.
+static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
+    if (c->marg.pending) return xr_fail(XRHIP_ESTATE, "xrhip_ba_marginalize: a marginalisation is already in flight");
     if (M->n_frames < 2 || M->victim < 0 || M->victim >= M->n_frames)
         return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: bad frame count / victim");
     // express the marginalisation's linearisation as a BA problem with every block free and no robust loss
@@ -842,7 +851,7 @@ int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_s
     const size_t o_V = carve(D8 * (size_t)R * R), o_si = carve(D8 * (size_t)R * R), o_iv = carve(D8 * R);
     const size_t o_st = carve(sizeof(int) * 4), o_lam = carve(D8 * 2), o_sup = carve(sizeof(int) * (size_t)R);
     const size_t o_As = carve(D8 * (size_t)R * R), o_bs = carve(D8 * R), o_Ss = carve(D8 * (size_t)R * R), o_ivs = carve(D8 * R);
-    rc = ensure_work2(c, w + 256, D8 * ((size_t)R * R + R) + 64);
+    rc = ensure_work2(c, w + 256, D8 * ((size_t)R * R + R) + 64 + sizeof(int) * 4);
     if (rc) return rc;
     char *W2 = c->work2;
     double *Hm = (double *)(W2 + o_Hm), *bm = (double *)(W2 + o_bm), *T2 = (double *)(W2 + o_T2);
@@ -861,7 +870,6 @@ int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_s
     hipLaunchKernelGGL(km_victim, dim3(1), dim3(256), 0, s, N, Hm, T2, dst);
     hipLaunchKernelGGL(km_complement, dim3((R * R + 255) / 256), dim3(256), 0, s, N, Hm, bm, T2, A, bp);
     double *hs = (double *)c->h_stage;
-    int hst[4] = {0, 0, 0, 0};
     int *dsup = (int *)(W2 + o_sup), *dsn = dst + 1;
     double *As = (double *)(W2 + o_As), *bs = (double *)(W2 + o_bs), *Ss = (double *)(W2 + o_Ss), *ivs = (double *)(W2 + o_ivs);
     if (R > 512) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: window too large");
@@ -871,31 +879,84 @@ int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_s
     hipLaunchKernelGGL(km_chol, dim3(1), dim3(512), (size_t)c->lds_limit, s, dsn, lds_doubles, As, bs, Ss, ivs,
                        (double *)(W2 + o_lam), dst);
     XR_HIP(hipGetLastError());
-    XR_HIP(hipMemcpyAsync(hst, dst, sizeof(hst), hipMemcpyDeviceToHost, s));
-    XR_HIP(hipStreamSynchronize(s));
-    if (!hst[0] && (hst[2] != 0 || hst[3] != 0)) {
-        if (std::getenv("XRHIP_HOSTPROF"))
-            std::fprintf(stderr, "[hostprof] marginalisation falls back to the eigen path: cholesky %s, guard %s, lambda bound %g, support %d of %d\n",
-                         hst[2] ? "failed" : "ok", hst[3] ? "failed" : "ok", 0.0, hst[1], R);
-        hipLaunchKernelGGL(km_jacobi, dim3(1), dim3(1024), (size_t)c->lds_limit, s, dsn, lds_doubles, As, bs, B, V, Ss, ivs,
-                           60, dst + 2);
-        XR_HIP(hipGetLastError());
-    }
+    // optimistic tail: expand the Cholesky factor and copy everything out; status words last
     hipLaunchKernelGGL(km_expand, dim3((R * R + 255) / 256), dim3(256), 0, s, R, dsup, dsn, Ss, ivs, dsi, div);
     XR_HIP(hipGetLastError());
     XR_HIP(hipMemcpyAsync(hs, dsi, D8 * (size_t)R * R, hipMemcpyDeviceToHost, s));
     XR_HIP(hipMemcpyAsync(hs + (size_t)R * R, div, D8 * R, hipMemcpyDeviceToHost, s));
+    XR_HIP(hipMemcpyAsync(hs + (size_t)R * R + R, dst, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    xrhip_ba::MargPending &mp = c->marg;
+    mp.pending = true;
+    mp.K = K;
+    mp.victim = M->victim;
+    mp.R = R;
+    mp.lin.assign(M->frame_state, M->frame_state + 16 * (size_t)K);
+    mp.dst = dst;
+    mp.dsup = dsup;
+    mp.As = As;
+    mp.bs = bs;
+    mp.B = B;
+    mp.V = V;
+    mp.Ss = Ss;
+    mp.ivs = ivs;
+    mp.dsi = dsi;
+    mp.div = div;
+    return XRHIP_OK;
+}
+
+static int marg_collect(xrhip_ba *c, double *out_sqrt_info, double *out_infovec, double *out_lin) {
+    xrhip_ba::MargPending &mp = c->marg;
+    if (!mp.pending) return xr_fail(XRHIP_ESTATE, "xrhip_ba_marginalize_end: nothing in flight");
+    mp.pending = false;
+    hipStream_t s = c->stream;
+    const size_t D8 = sizeof(double);
+    const int R = mp.R, K = mp.K;
+    double *hs = (double *)c->h_stage;
     XR_HIP(hipStreamSynchronize(s));
+    int hst[4];
+    std::memcpy(hst, hs + (size_t)R * R + R, sizeof(hst));
     if (hst[0]) return xr_fail(XRHIP_ESTATE, "xrhip_ba_marginalize: singular victim block");
+    if (hst[2] != 0 || hst[3] != 0) {
+        if (std::getenv("XRHIP_HOSTPROF"))
+            std::fprintf(stderr, "[hostprof] marginalisation falls back to the eigen path: cholesky %s, guard %s, support %d of %d\n",
+                         hst[2] ? "failed" : "ok", hst[3] ? "failed" : "ok", hst[1], R);
+        const int lds_doubles = c->lds_limit / (int)D8;
+        int *dsn = mp.dst + 1;
+        hipLaunchKernelGGL(km_jacobi, dim3(1), dim3(1024), (size_t)c->lds_limit, s, dsn, lds_doubles, mp.As, mp.bs, mp.B, mp.V, mp.Ss,
+                           mp.ivs, 60, mp.dst + 2);
+        hipLaunchKernelGGL(km_expand, dim3((R * R + 255) / 256), dim3(256), 0, s, R, mp.dsup, dsn, mp.Ss, mp.ivs, mp.dsi, mp.div);
+        XR_HIP(hipGetLastError());
+        XR_HIP(hipMemcpyAsync(hs, mp.dsi, D8 * (size_t)R * R, hipMemcpyDeviceToHost, s));
+        XR_HIP(hipMemcpyAsync(hs + (size_t)R * R, mp.div, D8 * R, hipMemcpyDeviceToHost, s));
+        XR_HIP(hipStreamSynchronize(s));
+    }
     std::memcpy(out_sqrt_info, hs, D8 * (size_t)R * R);
     std::memcpy(out_infovec, hs + (size_t)R * R, D8 * R);
     int j = 0;
     for (int i = 0; i < K; ++i) {
-        if (i == M->victim) continue;
-        std::memcpy(out_lin + 16 * (size_t)j, M->frame_state + 16 * (size_t)i, D8 * 16);
+        if (i == mp.victim) continue;
+        std::memcpy(out_lin + 16 * (size_t)j, mp.lin.data() + 16 * (size_t)i, D8 * 16);
         ++j;
     }
     return XRHIP_OK;
+}
+
+int xrhip_ba_marginalize(xrhip_ba *c, const xrhip_marg_problem *M, double *out_sqrt_info, double *out_infovec,
+                         double *out_lin) {
+    if (!c || !M || !out_sqrt_info || !out_infovec || !out_lin) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: null argument");
+    int rc = marg_launch(c, M);
+    if (rc) return rc;
+    return marg_collect(c, out_sqrt_info, out_infovec, out_lin);
+}
+
+int xrhip_ba_marginalize_begin(xrhip_ba *c, const xrhip_marg_problem *M) {
+    if (!c || !M) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize_begin: null argument");
+    return marg_launch(c, M);
+}
+
+int xrhip_ba_marginalize_end(xrhip_ba *c, double *out_sqrt_info, double *out_infovec, double *out_lin) {
+    if (!c || !out_sqrt_info || !out_infovec || !out_lin) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize_end: null argument");
+    return marg_collect(c, out_sqrt_info, out_infovec, out_lin);
 }
 
 int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *sample_begin, const int *sample_count,

@@ -229,6 +229,9 @@ struct MargPrior {
     std::vector<double> lin;         // [n][16]
     std::vector<double> sqrt_info;   // [15n][15n]
     std::vector<double> infovec;     // [15n]
+    // A marginalisation has been queued on the device and its result (lin, sqrt_info, infovec for the frames above)
+    // has not been fetched yet: resolve_marginalization() does, before anything reads the three arrays.
+    bool pending = false;
 };
 
 class Map {

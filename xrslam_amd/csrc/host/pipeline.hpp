@@ -63,6 +63,7 @@ struct Pipeline {
     Config config;
     xrhip_klt *klt = nullptr;
     xrhip_ba *ba = nullptr;
+    xrhip_ba *ba_marg = nullptr;   // marginalisation has a context (buffers, stream) of its own: it runs beside the next frame
     IdSource ids;
     std::vector<xrhip_image *> image_pool;
     double noise36[36];
@@ -74,6 +75,7 @@ struct Pipeline {
                                    (int)c.feature_tracker_max_keypoint_detection, &klt),
                   "xrhip_klt_create");
         hip_check(xrhip_ba_create(32, 2048, 16384, &ba), "xrhip_ba_create");
+        hip_check(xrhip_ba_create(32, 2048, 16384, &ba_marg), "xrhip_ba_create");
         for (int i = 0; i < 9; ++i) {
             noise36[i] = c.cov_g[i];
             noise36[9 + i] = c.cov_a[i];
@@ -84,6 +86,7 @@ struct Pipeline {
     ~Pipeline() {
         for (xrhip_image *im : image_pool) xrhip_image_destroy(im);
         if (ba) xrhip_ba_destroy(ba);
+        if (ba_marg) xrhip_ba_destroy(ba_marg);
         if (klt) xrhip_klt_destroy(klt);
     }
     xrhip_image *acquire_image() {
@@ -339,6 +342,23 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
     }
 }
 
+// Fetches the result of the marginalisation queued by marginalize_frame (it runs on its own context / stream while the
+// next frames are tracked and localised); called before the prior is read: by the next window solve, by the next
+// marginalisation, at shutdown.
+inline void resolve_marginalization(Pipeline &P, MargPrior *prior) {
+    if (!prior || !prior->pending) return;
+    const size_t n = prior->frames.size(), R = 15 * n;
+    std::vector<double> si(R * R), iv(R), lin(16 * n);
+    {
+        WallTimer wt_w_marginalize(P.times.w_marginalize);
+        hip_check(xrhip_ba_marginalize_end(P.ba_marg, si.data(), iv.data(), lin.data()), "xrhip_ba_marginalize_end");
+    }
+    prior->sqrt_info.swap(si);
+    prior->infovec.swap(iv);
+    prior->lin.swap(lin);
+    prior->pending = false;
+}
+
 // ------------------------------------------------------------------------------- BA problem assembly
 // Collects frames / tracks the way Solver::add_frame_states / add_track_states / add_factor do and
 // runs xrhip_ba_solve; states are written back in place.
@@ -485,6 +505,7 @@ class BaBuilder {
         pb.imu_data = imu_data_.data();
         std::vector<int> pframes;
         if (prior_) {
+            resolve_marginalization(P_, prior_);
             for (Frame *f : prior_->frames) pframes.push_back(frame_index(f, false));
             // frame_index may have appended constant frames: refresh the arrays that depend on F
             if ((int)frames_.size() != F) throw std::logic_error("prior frame is not part of the problem");
@@ -579,6 +600,7 @@ inline std::unique_ptr<MargPrior> create_marginalization_factor(Map *map) {
 inline void marginalize_frame(Pipeline &P, Map *map, size_t index) {   // Map::marginalize_frame (map.cpp:51-63)
     MargPrior *prior = map->marginalization_factor.get();
     if (!prior) throw std::logic_error("marginalization_factor is not initialized yet");
+    resolve_marginalization(P, prior);   // the previous result is this one's input
     const int K = (int)map->frame_num();
     std::unordered_map<Frame *, int> fidx;
     std::vector<double> state(16 * (size_t)K);
@@ -657,13 +679,11 @@ inline void marginalize_frame(Pipeline &P, Map *map, size_t index) {   // Map::m
     mp.obs_lm = ol.data();
     mp.obs_z_tgt = zt.data();
     mp.obs_z_ref = zr.data();
-    const size_t R = 15 * (size_t)(K - 1);
-    std::vector<double> si(R * R), iv(R), lin(16 * (size_t)(K - 1));
-    WallTimer wt_w_marginalize(P.times.w_marginalize);
-    hip_check(xrhip_ba_marginalize(P.ba, &mp, si.data(), iv.data(), lin.data()), "xrhip_ba_marginalize");
-    prior->sqrt_info.swap(si);
-    prior->infovec.swap(iv);
-    prior->lin.swap(lin);
+    {   // queued on the marginalisation's own context; the new sqrt_info / infovec / lin are fetched on first use
+        WallTimer wt_w_marginalize(P.times.w_marginalize);
+        hip_check(xrhip_ba_marginalize_begin(P.ba_marg, &mp), "xrhip_ba_marginalize_begin");
+    }
+    prior->pending = true;
     prior->frames.clear();
     for (int i = 0; i < K; ++i)
         if ((size_t)i != index) prior->frames.push_back(map->get_frame(i));
