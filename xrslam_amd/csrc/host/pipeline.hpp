@@ -706,6 +706,41 @@ class SlidingWindowTracker {
         }
     }
 
+    // Early start of mirror_frame's pre-integration for a frame that is about to be tracked (not yet in ft_map): the
+    // samples between the last window frame and `incoming`, at the biases of the last window frame.
+    void mirror_prepare(Map *ft_map, Frame *incoming) {
+        cancel_prepared();
+        Frame *keyframe = map->get_frame(map->frame_num() - 1);
+        Frame *new_i = keyframe->subframes.empty() ? keyframe : keyframe->subframes.back().get();
+        const size_t idx_i = ft_map->frame_index_by_id(new_i->id);
+        if (idx_i == nil()) return;
+        std::vector<ImuData> nd = incoming->preintegration.data;
+        for (size_t index = ft_map->frame_num() - 1; index > idx_i; --index) {
+            const std::vector<ImuData> &od = ft_map->get_frame(index)->preintegration.data;
+            nd.insert(nd.begin(), od.begin(), od.end());
+        }
+        prepared_ = P_.integrate_begin(nd, incoming->image->t, new_i->motion.bg, new_i->motion.ba, true, true);
+        prepared_id_ = incoming->id;
+        prepared_from_ = new_i->id;
+        prepared_samples_ = nd.size();
+    }
+    void cancel_prepared() {   // a queued integration nobody will collect must still be drained
+        if (prepared_id_ != nil() && prepared_) {
+            PreInt scratch;
+            P_.integrate_end(scratch);
+        }
+        prepared_id_ = nil();
+        prepared_ = false;
+    }
+    ~SlidingWindowTracker() {
+        try {
+            cancel_prepared();
+        } catch (...) {
+        }
+    }
+    size_t prepared_id_ = nil(), prepared_from_ = nil(), prepared_samples_ = 0;
+    bool prepared_ = false;
+
     void mirror_frame(Map *ft_map, size_t frame_id) {   // sliding_window_tracker.cpp:31-80
         xrhip::HostProfScope hp_m(7, "mirror_frame");
         WallTimer sc_t(P_.times.scope[SC_MIRROR]);
@@ -713,7 +748,10 @@ class SlidingWindowTracker {
         Frame *new_i = keyframe;
         if (!keyframe->subframes.empty()) new_i = keyframe->subframes.back().get();
         size_t idx_i = ft_map->frame_index_by_id(new_i->id), idx_j = ft_map->frame_index_by_id(frame_id);
-        if (idx_i == nil() || idx_j == nil()) return;
+        if (idx_i == nil() || idx_j == nil()) {
+            cancel_prepared();
+            return;
+        }
         Frame *old_i = ft_map->get_frame(idx_i), *old_j = ft_map->get_frame(idx_j);
         std::unique_ptr<Frame> curr = old_j->clone();
         std::vector<ImuData> &nd = curr->preintegration.data;
@@ -722,8 +760,16 @@ class SlidingWindowTracker {
             nd.insert(nd.begin(), od.begin(), od.end());
         }
         // the pre-integration of the new interval only needs its IMU samples and the biases of the last window frame:
-        // queue it now, it runs on the device while the track links are copied below
-        const bool integrating = P_.integrate_begin(nd, curr->image->t, new_i->motion.bg, new_i->motion.ba, true, true);
+        // mirror_prepare queued it when the frame entered the tracker (it has been running beside the LK kernel);
+        // otherwise it is queued now and runs while the track links are copied below
+        bool integrating;
+        if (prepared_id_ == frame_id && prepared_from_ == new_i->id && prepared_samples_ == nd.size()) {
+            integrating = prepared_;
+            prepared_id_ = nil();
+        } else {
+            cancel_prepared();
+            integrating = P_.integrate_begin(nd, curr->image->t, new_i->motion.bg, new_i->motion.ba, true, true);
+        }
         map->attach_frame(curr->clone());
         Frame *new_j = map->get_frame(map->frame_num() - 1);
         for (size_t ki = 0; ki < old_i->keypoint_num(); ++ki) {
@@ -1529,12 +1575,17 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
         xrhip::HostProfScope hp_f(11, "feature_tracker_work (all)");
         WallTimer wt_frame(P.times.w_frame);
         const Config &c = P.config;
-        {
+        // CLAHE / pyramid / gradients of the new image depend on nothing else: their launches are issued while the
+        // pre-integration of the new interval runs on the BA stream (below), or right away when there is none to wait for
+        bool preprocessed = false;
+        auto preprocess = [&] {
+            if (preprocessed) return;
+            preprocessed = true;
             WallTimer wt_w_preprocess(P.times.w_preprocess);
             hip_check(xrhip_image_preprocess(frame->image->h, c.feature_tracker_clahe_clip_limit,
                                              (int)c.feature_tracker_clahe_width, (int)c.feature_tracker_clahe_height),
                       "xrhip_image_preprocess");
-        }
+        };
         auto [opt_t, opt_id, opt_pose, opt_motion] = frontend_latest_state;
         (void)opt_t;
         bool is_initialized = opt_id != nil();
@@ -1565,8 +1616,15 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
                     frame->preintegration.data.insert(frame->preintegration.data.begin(), imu);
                 }
             }
-            P.integrate(frame->preintegration, frame->image->t, last->motion.bg, last->motion.ba, false, false);
+            if (P.integrate_begin(frame->preintegration.data, frame->image->t, last->motion.bg, last->motion.ba, false, false)) {
+                preprocess();
+                P.integrate_end(frame->preintegration);
+            }
+            preprocess();
             if (swt_tag) hip_check(xrhip_image_prefetch_detect(frame->image->h), "xrhip_image_prefetch_detect");
+            // the backend will pre-integrate the same interval with Jacobians and covariance when it mirrors this frame:
+            // queued now, it runs beside the LK kernel and the RANSAC gates instead of in front of localize_newframe
+            if (swt && swt_tag && is_initialized) swt->mirror_prepare(map, frame.get());
             frame_track_keypoints(P, last, frame.get());
             if (is_initialized) {
                 predict(frame->preintegration, last, frame.get());
@@ -1574,6 +1632,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
             }
             last->image->release_image_buffer();
         }
+        preprocess();
         if (swt_tag) frame_detect_keypoints(P, frame.get());
         map->attach_frame(std::move(frame));
         size_t max_frames = is_initialized ? c.feature_tracker_max_frames : c.feature_tracker_max_init_frames;
