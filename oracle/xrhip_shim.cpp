@@ -38,7 +38,10 @@ struct xrhip_image {
     bool have_raw, have_pyr;
 };
 struct xrhip_ba {
-    int dummy;
+    int unused = 0;
+    // results of the asynchronous forms, per context like the product (computed at _begin, handed over at _end)
+    std::vector<double> preint_out, marg_si, marg_iv, marg_lin;
+    int preint_rc = 0, marg_rc = 0;
 };
 
 static thread_local std::string g_err;
@@ -117,7 +120,7 @@ int xrhip_klt_get_stats(xrhip_klt *, xrhip_klt_stats *out, int) {
     return 0;
 }
 int xrhip_ba_create(int, int, int, xrhip_ba **out) {
-    *out = new xrhip_ba{0};
+    *out = new xrhip_ba();
     return 0;
 }
 void xrhip_ba_destroy(xrhip_ba *c) { delete c; }
@@ -149,35 +152,31 @@ int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *b
     return 0;
 }
 // asynchronous form: the CPU reference computes at _begin and hands the records over at _end
-static std::vector<double> g_preint_out;
-static int g_preint_rc = 0;
 int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *begin, const int *count, const double *t_end,
                                 const double *bg, const double *ba, int n_jobs, const double *noise36, int jac, int cov) {
-    g_preint_out.assign((size_t)XRHIP_IMU_DIM * n_jobs, 0.0);
-    g_preint_rc = xrhip_ba_preintegrate_batch(c, samples, begin, count, t_end, bg, ba, n_jobs, noise36, jac, cov, g_preint_out.data());
+    c->preint_out.assign((size_t)XRHIP_IMU_DIM * n_jobs, 0.0);
+    c->preint_rc = xrhip_ba_preintegrate_batch(c, samples, begin, count, t_end, bg, ba, n_jobs, noise36, jac, cov, c->preint_out.data());
     return 0;
 }
-int xrhip_ba_preintegrate_end(xrhip_ba *, double *out) {
-    if (g_preint_rc) return g_preint_rc;
-    std::memcpy(out, g_preint_out.data(), sizeof(double) * g_preint_out.size());
+int xrhip_ba_preintegrate_end(xrhip_ba *c, double *out) {
+    if (c->preint_rc) return c->preint_rc;
+    std::memcpy(out, c->preint_out.data(), sizeof(double) * c->preint_out.size());
     return 0;
 }
 // same for the marginalisation
-static std::vector<double> g_marg_si, g_marg_iv, g_marg_lin;
-static int g_marg_rc = 0;
 int xrhip_ba_marginalize_begin(xrhip_ba *c, const xrhip_marg_problem *M) {
     const size_t R = 15 * (size_t)(M->n_frames - 1);
-    g_marg_si.assign(R * R, 0.0);
-    g_marg_iv.assign(R, 0.0);
-    g_marg_lin.assign(16 * (size_t)(M->n_frames - 1), 0.0);
-    g_marg_rc = xrhip_ba_marginalize(c, M, g_marg_si.data(), g_marg_iv.data(), g_marg_lin.data());
+    c->marg_si.assign(R * R, 0.0);
+    c->marg_iv.assign(R, 0.0);
+    c->marg_lin.assign(16 * (size_t)(M->n_frames - 1), 0.0);
+    c->marg_rc = xrhip_ba_marginalize(c, M, c->marg_si.data(), c->marg_iv.data(), c->marg_lin.data());
     return 0;
 }
-int xrhip_ba_marginalize_end(xrhip_ba *, double *si, double *iv, double *lin) {
-    if (g_marg_rc) return g_marg_rc;
-    std::memcpy(si, g_marg_si.data(), sizeof(double) * g_marg_si.size());
-    std::memcpy(iv, g_marg_iv.data(), sizeof(double) * g_marg_iv.size());
-    std::memcpy(lin, g_marg_lin.data(), sizeof(double) * g_marg_lin.size());
+int xrhip_ba_marginalize_end(xrhip_ba *c, double *si, double *iv, double *lin) {
+    if (c->marg_rc) return c->marg_rc;
+    std::memcpy(si, c->marg_si.data(), sizeof(double) * c->marg_si.size());
+    std::memcpy(iv, c->marg_iv.data(), sizeof(double) * c->marg_iv.size());
+    std::memcpy(lin, c->marg_lin.data(), sizeof(double) * c->marg_lin.size());
     return 0;
 }
 }

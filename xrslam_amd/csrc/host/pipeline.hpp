@@ -64,6 +64,7 @@ struct Pipeline {
     xrhip_klt *klt = nullptr;
     xrhip_ba *ba = nullptr;
     xrhip_ba *ba_marg = nullptr;   // marginalisation has a context (buffers, stream) of its own: it runs beside the next frame
+    xrhip_ba *ba_aux = nullptr;    // speculative pre-integration batches (started a frame ahead), same reason
     IdSource ids;
     std::vector<xrhip_image *> image_pool;
     double noise36[36];
@@ -76,6 +77,7 @@ struct Pipeline {
                   "xrhip_klt_create");
         hip_check(xrhip_ba_create(32, 2048, 16384, &ba), "xrhip_ba_create");
         hip_check(xrhip_ba_create(32, 2048, 16384, &ba_marg), "xrhip_ba_create");
+        hip_check(xrhip_ba_create(32, 2048, 16384, &ba_aux), "xrhip_ba_create");
         for (int i = 0; i < 9; ++i) {
             noise36[i] = c.cov_g[i];
             noise36[9 + i] = c.cov_a[i];
@@ -87,6 +89,7 @@ struct Pipeline {
         for (xrhip_image *im : image_pool) xrhip_image_destroy(im);
         if (ba) xrhip_ba_destroy(ba);
         if (ba_marg) xrhip_ba_destroy(ba_marg);
+        if (ba_aux) xrhip_ba_destroy(ba_aux);
         if (klt) xrhip_klt_destroy(klt);
     }
     xrhip_image *acquire_image() {
@@ -170,15 +173,37 @@ struct Pipeline {
     // asynchronous form: _begin queues the launch and returns which jobs had samples, _end waits and stores the records.
     // Between the two the caller assembles the problem that will read them (BaBuilder copies records at solve time).
     std::vector<char> integrate_batch_begin(const std::vector<IntegrateJob> &jobs, bool jac, bool cov) {
+        return batch_begin(ba, pending_pre_, jobs, jac, cov);
+    }
+    void integrate_batch_end() {
+        if (pending_pre_.empty()) return;
+        std::vector<double> out = batch_collect(ba, pending_pre_.size());
+        for (size_t i = 0; i < pending_pre_.size(); ++i) {
+            std::memcpy(pending_pre_[i]->rec, &out[(size_t)XRHIP_IMU_DIM * i], sizeof(double) * XRHIP_IMU_DIM);
+            pending_pre_[i]->valid = true;
+        }
+        pending_pre_.clear();
+    }
+    // the same on the auxiliary context, for batches whose results may or may not be wanted later: the records come back
+    // as one array (jobs without samples are skipped), nothing is written into the PreInt objects
+    size_t aux_batch_begin(const std::vector<IntegrateJob> &jobs, bool jac, bool cov) {
+        std::vector<PreInt *> which;
+        batch_begin(ba_aux, which, jobs, jac, cov);
+        return which.size();
+    }
+    std::vector<double> aux_batch_collect(size_t n_jobs) { return n_jobs ? batch_collect(ba_aux, n_jobs) : std::vector<double>(); }
+
+    std::vector<char> batch_begin(xrhip_ba *ctx, std::vector<PreInt *> &pending, const std::vector<IntegrateJob> &jobs, bool jac,
+                                  bool cov) {
         std::vector<char> ok(jobs.size(), 0);
         std::vector<double> smp, t_end, bgs, bas;
         std::vector<int> begin, count;
-        pending_pre_.clear();
+        pending.clear();
         for (size_t k = 0; k < jobs.size(); ++k) {
             const PreInt &pre = *jobs[k].pre;
             if (pre.data.empty()) continue;
             ok[k] = 1;
-            pending_pre_.push_back(jobs[k].pre);
+            pending.push_back(jobs[k].pre);
             begin.push_back((int)(smp.size() / 7));
             count.push_back((int)pre.data.size());
             t_end.push_back(jobs[k].t);
@@ -190,25 +215,18 @@ struct Pipeline {
             bgs.insert(bgs.end(), b1, b1 + 3);
             bas.insert(bas.end(), b2, b2 + 3);
         }
-        if (pending_pre_.empty()) return ok;
+        if (pending.empty()) return ok;
         WallTimer wt_w_preintegrate(times.w_preintegrate);
-        hip_check(xrhip_ba_preintegrate_begin(ba, smp.data(), begin.data(), count.data(), t_end.data(), bgs.data(), bas.data(),
-                                              (int)pending_pre_.size(), noise36, jac, cov),
+        hip_check(xrhip_ba_preintegrate_begin(ctx, smp.data(), begin.data(), count.data(), t_end.data(), bgs.data(), bas.data(),
+                                              (int)pending.size(), noise36, jac, cov),
                   "xrhip_ba_preintegrate_begin");
         return ok;
     }
-    void integrate_batch_end() {
-        if (pending_pre_.empty()) return;
-        std::vector<double> out((size_t)XRHIP_IMU_DIM * pending_pre_.size());
-        {
-            WallTimer wt_w_preintegrate(times.w_preintegrate);
-            hip_check(xrhip_ba_preintegrate_end(ba, out.data()), "xrhip_ba_preintegrate_end");
-        }
-        for (size_t i = 0; i < pending_pre_.size(); ++i) {
-            std::memcpy(pending_pre_[i]->rec, &out[(size_t)XRHIP_IMU_DIM * i], sizeof(double) * XRHIP_IMU_DIM);
-            pending_pre_[i]->valid = true;
-        }
-        pending_pre_.clear();
+    std::vector<double> batch_collect(xrhip_ba *ctx, size_t n_jobs) {
+        std::vector<double> out((size_t)XRHIP_IMU_DIM * n_jobs);
+        WallTimer wt_w_preintegrate(times.w_preintegrate);
+        hip_check(xrhip_ba_preintegrate_end(ctx, out.data()), "xrhip_ba_preintegrate_end");
+        return out;
     }
     std::vector<PreInt *> pending_pre_;
 };
@@ -735,8 +753,12 @@ class SlidingWindowTracker {
     ~SlidingWindowTracker() {
         try {
             cancel_prepared();
+            drain_speculation();
         } catch (...) {
         }
+        if (std::getenv("XRHIP_HOSTPROF"))
+            std::fprintf(stderr, "[hostprof] subframe re-integrations: %ld speculated, %ld taken from mirror_frame, %ld computed in place\n",
+                         spec_hits_, memo_hits_, spec_misses_);
     }
     size_t prepared_id_ = nil(), prepared_from_ = nil(), prepared_samples_ = 0;
     bool prepared_ = false;
@@ -783,7 +805,15 @@ class SlidingWindowTracker {
             }
         }
         map->prune_tracks([](const Track *t) { return t->tag(TT_TRASH) && !t->tag(TT_STATIC); });
-        if (integrating) P_.integrate_end(new_j->preintegration);
+        if (integrating) {
+            P_.integrate_end(new_j->preintegration);
+            memo_id_ = new_j->id;
+            memo_samples_ = new_j->preintegration.data.size();
+            memo_bg_ = new_i->motion.bg;
+            memo_ba_ = new_i->motion.ba;
+        } else {
+            memo_id_ = nil();
+        }
         predict(new_j->preintegration, new_i, new_j);
     }
 
@@ -797,6 +827,7 @@ class SlidingWindowTracker {
         } else {
             refine_subwindow();
         }
+        speculate_subframes();
         return true;
     }
 
@@ -968,12 +999,83 @@ class SlidingWindowTracker {
     }
 
     // (re-)integrate every subframe interval of `frame` with the current biases, one launch
+    // A subframe interval is re-integrated whenever the biases it starts from have moved -- after every solve.  Nothing
+    // else of the next frame enters those integrations, so they are queued (auxiliary context) as soon as this frame's
+    // solve has returned and run beside the next frame's tracker; refine_subwindow then only has to integrate what the
+    // speculation did not cover.  A job is reused only if frame, end time, sample count and both biases are identical
+    // to what was queued: same kernel, same inputs, bitwise the same record.
+    struct SpecJob {
+        Frame *sf;
+        size_t id, samples;
+        double t;
+        V3 bg, ba;
+    };
+    static bool same3(const V3 &a, const V3 &b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+    static bool speculation_enabled() {
+        static const bool off = std::getenv("XRSLAM_AMD_NO_SPECULATION") != nullptr;   // development switch
+        return !off;
+    }
+    long spec_hits_ = 0, memo_hits_ = 0, spec_misses_ = 0;
+    void speculate_subframes() {
+        drain_speculation();
+        if (!speculation_enabled()) return;
+        Frame *frame = map->get_frame(map->frame_num() - 1);
+        if (frame->subframes.empty()) return;
+        std::vector<Pipeline::IntegrateJob> jobs;
+        for (size_t i = 0; i < frame->subframes.size(); ++i) {
+            Frame *sf = frame->subframes[i].get();
+            if (sf->preintegration.data.empty()) continue;
+            Frame *prev = (i == 0 ? frame : frame->subframes[i - 1].get());
+            jobs.push_back({&sf->preintegration, sf->image->t, prev->motion.bg, prev->motion.ba});
+            spec_.push_back({sf, sf->id, sf->preintegration.data.size(), sf->image->t, prev->motion.bg, prev->motion.ba});
+        }
+        spec_jobs_ = P_.aux_batch_begin(jobs, true, true);
+    }
+    void drain_speculation() {
+        if (spec_jobs_) P_.aux_batch_collect(spec_jobs_);
+        spec_jobs_ = 0;
+        spec_.clear();
+    }
+    std::vector<SpecJob> spec_;
+    size_t spec_jobs_ = 0;
+    // what mirror_frame integrated for the frame it added (Jacobians and covariance included)
+    size_t memo_id_ = nil(), memo_samples_ = 0;
+    V3 memo_bg_, memo_ba_;
+
     void integrate_subframes_begin(Frame *frame) {   // finished by Pipeline::integrate_batch_end before the solve
+        std::vector<double> spec_rec;
+        std::vector<SpecJob> spec;
+        if (spec_jobs_) {
+            spec_rec = P_.aux_batch_collect(spec_jobs_);
+            spec.swap(spec_);
+            spec_jobs_ = 0;
+        }
         std::vector<Pipeline::IntegrateJob> jobs;
         for (size_t i = 0; i < frame->subframes.size(); ++i) {
             Frame *sf = frame->subframes[i].get();
             Frame *prev = (i == 0 ? frame : frame->subframes[i - 1].get());
-            jobs.push_back({&sf->preintegration, sf->image->t, prev->motion.bg, prev->motion.ba});
+            const V3 &bg = prev->motion.bg, &ba = prev->motion.ba;
+            const size_t ns = sf->preintegration.data.size();
+            bool have = false;
+            for (size_t k = 0; k < spec.size() && !have; ++k) {
+                const SpecJob &j = spec[k];
+                if (j.sf == sf && j.id == sf->id && j.samples == ns && j.t == sf->image->t && same3(j.bg, bg) && same3(j.ba, ba)) {
+                    std::memcpy(sf->preintegration.rec, &spec_rec[(size_t)XRHIP_IMU_DIM * k], sizeof(double) * XRHIP_IMU_DIM);
+                    sf->preintegration.valid = true;
+                    have = true;
+                    spec_hits_++;
+                }
+            }
+            // the frame mirror_frame has just added was integrated there, from the same samples at the same biases
+            if (!have && speculation_enabled() && sf->id == memo_id_ && ns == memo_samples_ && ns > 0 && sf->preintegration.valid &&
+                same3(memo_bg_, bg) && same3(memo_ba_, ba)) {
+                have = true;
+                memo_hits_++;
+            }
+            if (!have) {
+                jobs.push_back({&sf->preintegration, sf->image->t, bg, ba});
+                spec_misses_++;
+            }
         }
         P_.integrate_batch_begin(jobs, true, true);
     }
