@@ -157,7 +157,8 @@ typedef struct XRSLAMAmdTimes {
     /* host wall-clock seconds of whole pipeline stages (their device waits included): Frame::track_keypoints,
      * of which 5-pt RANSAC, 2-pt RANSAC; Frame::detect_keypoints; mirror_frame; localize_newframe; manage_keyframe;
      * track_landmark; refine_window; slide_window; refine_subwindow; initialiser (SfM + alignment attempts);
-     * rest reserved */
+     * [12], [13] are COUNTS of the RD-VIO filter (parsac.parsac_flag): frames on which judge_track_status separated a
+     * dynamic group, landmark observations it tagged as outliers; rest reserved */
     double wall_scope[16];
 } XRSLAMAmdTimes;
 void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out);

@@ -191,3 +191,55 @@ void gh_s2_basis(const double *x3, double *b6) {
     }
 }
 }
+
+// ------------------------------------------------------------------------------ parsac.hpp / epnp.hpp
+#include "../../xrslam_amd/csrc/host/parsac.hpp"
+extern "C" {
+void gh_epnp(const double *X, const double *x, int n, double *R9, double *t3) {
+    std::vector<V3> Xs(n);
+    std::vector<V2> xs(n);
+    for (int i = 0; i < n; ++i) {
+        Xs[i] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+        xs[i] = {x[2 * i], x[2 * i + 1]};
+    }
+    Pose34 p = solve_pnp_epnp(Xs.data(), xs.data(), n);
+    std::memcpy(R9, p.R.m, sizeof(p.R.m));
+    for (int k = 0; k < 3; ++k) t3[k] = p.t[k];
+}
+// one persistent state per process, like the function-local statics of the reference
+static ParsacState g_parsac;
+void gh_parsac_reset() { g_parsac = ParsacState(); }
+int gh_pnp_parsac_imu(const double *X, const double *x, const long *lens, int n, const double *R9, const double *t3, double dyn,
+                      double thr, char *mask, double *Rout, double *tout) {
+    std::vector<V3> Xs(n);
+    std::vector<V2> xs(n);
+    std::vector<size_t> ls(n);
+    for (int i = 0; i < n; ++i) {
+        Xs[i] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+        xs[i] = {x[2 * i], x[2 * i + 1]};
+        ls[i] = (size_t)lens[i];
+    }
+    M3 R;
+    std::memcpy(R.m, R9, sizeof(R.m));
+    std::vector<char> m;
+    Pose34 p = find_pnp_matrix_parsac_imu(g_parsac, Xs, xs, ls, R, V3{t3[0], t3[1], t3[2]}, dyn, 1.0, m, thr);
+    int cnt = 0;
+    for (size_t i = 0; i < m.size(); ++i) cnt += (mask[i] = m[i]);
+    std::memcpy(Rout, p.R.m, sizeof(p.R.m));
+    for (int k = 0; k < 3; ++k) tout[k] = p.t[k];
+    return cnt;
+}
+int gh_essential_parsac(const double *p1, const double *p2, int n, double thr, char *mask, double *E9) {
+    std::vector<V2> a(n), b(n);
+    for (int i = 0; i < n; ++i) {
+        a[i] = {p1[2 * i], p1[2 * i + 1]};
+        b[i] = {p2[2 * i], p2[2 * i + 1]};
+    }
+    std::vector<char> m;
+    M3 E = find_essential_matrix_parsac(g_parsac, a, b, m, thr);
+    std::memcpy(E9, E.m, sizeof(E.m));
+    int cnt = 0;
+    for (size_t i = 0; i < m.size(); ++i) cnt += (mask[i] = m[i]);
+    return cnt;
+}
+}

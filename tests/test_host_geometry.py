@@ -17,7 +17,7 @@ OUT = os.path.join(ROOT, "tests", "host_check", "_build", "libgeom_host.so")
 
 @pytest.fixture(scope="module")
 def gh():
-    deps = [SRC] + [os.path.join(ROOT, "xrslam_amd", "csrc", "host", f) for f in ("hla.hpp", "geometry.hpp", "config.hpp", "two_view.hpp")]
+    deps = [SRC] + [os.path.join(ROOT, "xrslam_amd", "csrc", "host", f) for f in ("hla.hpp", "geometry.hpp", "config.hpp", "two_view.hpp", "epnp.hpp", "parsac.hpp")]
     if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", SRC, "-o", OUT])

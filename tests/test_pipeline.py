@@ -192,3 +192,57 @@ def test_gpu_pipeline_initialises_itself_like_cpu_reference(init_seq, oracle_sel
     assert poses_h.shape == poses_o.shape
     np.testing.assert_allclose(poses_h[:, 1:], poses_o[:, 1:], rtol=1e-4, atol=1e-6)
     assert runner.ate_rmse(list(poses_h), init_seq) < 0.04
+
+
+# ------------------------------------------------------------------- RD-VIO dynamic-object rejection
+RDVIO_YAML = os.path.join(ROOT, "configs", "rdvio_slam_150.yaml")
+BENCH_YAML = os.path.join(ROOT, "configs", "bench_slam_150.yaml")
+
+
+def _moving_object(t):
+    """a 0.9 x 0.9 x 0.4 m textured box swinging between the camera and the ceiling it looks at"""
+    return np.array([-1.4 + 0.5 * np.sin(1.2 * t), 0.35 * np.cos(0.9 * t), 2.0]), np.array([0.45, 0.45, 0.2])
+
+
+def _run_rd(lib_path, seq, yaml):
+    s = runner.Session(lib_path, seq, slam_yaml=yaml)
+    while s.step():
+        assert not s.error(), s.error()
+    s.flush()
+    t = s.times()
+    out = np.array(s.poses), (t.frames, t.solves, t.solve_iterations, t.marginalizations, t.keyframes), (t.wall_scope[12], t.wall_scope[13])
+    s.close()
+    return out
+
+
+@pytest.fixture(scope="module")
+def dynamic_seq():
+    return scene.make_sequence(n_frames=100, seed=1, moving_object=_moving_object)
+
+
+@pytest.fixture(scope="module")
+def oracle_rd(dynamic_seq):
+    if not os.path.exists(ORACLE_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return _run_rd(ORACLE_LIB, dynamic_seq, RDVIO_YAML)
+
+
+def test_cpu_reference_pipeline_with_dynamic_object_rejection(dynamic_seq, oracle_rd):
+    poses, counts, (judged, tagged) = oracle_rd
+    assert counts[0] == 100
+    assert judged >= 1 and tagged >= 20            # the filter separated a dynamic group on some frames
+    assert runner.ate_rmse(list(poses), dynamic_seq) < 0.03
+    poses0, counts0, rd0 = _run_rd(ORACLE_LIB, dynamic_seq, BENCH_YAML)
+    assert rd0 == (0.0, 0.0)                        # off by default
+    assert poses0.shape == poses.shape and np.abs(poses0[:, 1:] - poses[:, 1:]).max() > 0      # and it does change the solves
+
+
+@pytest.mark.gpu
+def test_gpu_pipeline_with_dynamic_object_rejection_matches_cpu_reference(dynamic_seq, oracle_rd):
+    from xrslam_amd import _lib
+    poses_o, counts_o, rd_o = oracle_rd
+    poses_h, counts_h, rd_h = _run_rd(_lib.LIB_PATH, dynamic_seq, RDVIO_YAML)
+    assert rd_h == rd_o and counts_h == counts_o
+    assert poses_h.shape == poses_o.shape
+    np.testing.assert_allclose(poses_h[:, 1:], poses_o[:, 1:], rtol=1e-4, atol=1e-6)

@@ -50,6 +50,8 @@ struct Config {
     double solver_time_limit = 1.0e6;
     double rotation_misalignment_threshold = 0.1, rotation_ransac_threshold = 10;
     bool parsac_flag = false;
+    double parsac_dynamic_probability = 0.0, parsac_threshold = 3.0, parsac_norm_scale = 1.0;   // config.cpp:70-74 (unused by the tracker, like there)
+    size_t parsac_keyframe_check_size = 3;
 };
 
 class ConfigError : public std::runtime_error {
@@ -209,6 +211,10 @@ inline Config load_config(const std::string &slam_path, const std::string &devic
     num("rotation.misalignment_threshold", c.rotation_misalignment_threshold);
     num("rotation.ransac_threshold", c.rotation_ransac_threshold);
     boo("parsac.parsac_flag", c.parsac_flag);
+    num("parsac.dynamic_probability", c.parsac_dynamic_probability);
+    num("parsac.threshold", c.parsac_threshold);
+    num("parsac.norm_scale", c.parsac_norm_scale);
+    siz("parsac.keyframe_check_size", c.parsac_keyframe_check_size);
     return c;
 }
 

@@ -29,6 +29,7 @@
 #include "../hostprof.hpp"
 #include "config.hpp"
 #include "map.hpp"
+#include "parsac.hpp"
 #include "two_view.hpp"
 
 namespace xrh {
@@ -51,7 +52,7 @@ struct StageTimes {   // seconds, accumulated (inspection slots feature_tracker_
     double scope[16] = {0};
 };
 enum { SC_FT_TRACK = 0, SC_RANSAC_E, SC_RANSAC_R, SC_FT_DETECT, SC_MIRROR, SC_LOCALIZE, SC_MANAGE_KF, SC_TRACK_LANDMARK,
-       SC_REFINE_WINDOW, SC_SLIDE_WINDOW, SC_REFINE_SUBWINDOW, SC_INITIALIZE, SC_COUNT };
+       SC_REFINE_WINDOW, SC_SLIDE_WINDOW, SC_REFINE_SUBWINDOW, SC_INITIALIZE, SC_RD_JUDGED, SC_RD_OUTLIERS, SC_COUNT };
 struct WallTimer {   // adds the scope's duration to a StageTimes slot
     double &slot;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -765,6 +766,7 @@ class SlidingWindowTracker {
 
     void mirror_frame(Map *ft_map, size_t frame_id) {   // sliding_window_tracker.cpp:31-80
         xrhip::HostProfScope hp_m(7, "mirror_frame");
+        feature_tracking_map_ = ft_map;
         WallTimer sc_t(P_.times.scope[SC_MIRROR]);
         Frame *keyframe = map->get_frame(map->frame_num() - 1);
         Frame *new_i = keyframe;
@@ -817,7 +819,10 @@ class SlidingWindowTracker {
         predict(new_j->preintegration, new_i, new_j);
     }
 
-    bool track() {   // :82-117 (parsac_flag is false)
+    bool track() {   // :82-117
+        if (P_.config.parsac_flag) {
+            if (judge_track_status()) update_track_status();
+        }
         localize_newframe();
         if (manage_keyframe()) {
             P_.times.keyframes++;
@@ -830,6 +835,154 @@ class SlidingWindowTracker {
         speculate_subframes();
         return true;
     }
+
+    // ------------------------------------------------------------------ RD-VIO dynamic-object rejection (:523-790)
+    // Only runs with parsac.parsac_flag (off in the shipped configurations).  judge_track_status marks the landmarks
+    // whose reprojection disagrees with the IMU-aided PnP consensus as TT_OUTLIER / not TT_STATIC, which removes their
+    // factors from the solves below; update_track_status runs the 2D-2D PARSAC check against the last keyframes.
+    struct Rt {
+        M3 R = M3::identity();
+        V3 t;
+    };
+    static Rt rt_mul(const Rt &a, const Rt &b) { return {a.R * b.R, a.R * b.t + a.t}; }
+    static Rt rt_inv(const Rt &a) {
+        const M3 Rt_ = transpose(a.R);
+        return {Rt_, -(Rt_ * a.t)};
+    }
+    static void predict_RT(Frame *fi, Frame *fj, M3 &R, V3 &t) {   // :549-575, literally (both extrinsics enter)
+        const Rt Pwc{to_matrix(fi->camera.q_cs), fi->camera.p_cs}, PwI{to_matrix(fi->imu.q_cs), fi->imu.p_cs};
+        const Rt Pwi{to_matrix(fi->pose.q), fi->pose.p}, Pwj{to_matrix(fj->pose.q), fj->pose.p};
+        const Rt Pji = rt_mul(rt_inv(Pwj), Pwi);
+        const Rt P = rt_mul(rt_mul(rt_mul(rt_mul(rt_inv(Pwc), PwI), Pji), rt_inv(PwI)), Pwc);
+        R = P.R;
+        t = P.t;
+    }
+    static double epipolar_dist(const M3 &F, V2 a, V2 b) {   // :490-495
+        const V3 l = F * V3{a.x, a.y, 1.0};
+        return std::fabs(b.x * l.x + b.y * l.y + l.z) / std::sqrt(l.x * l.x + l.y * l.y);
+    }
+    static M3 k_inverse(const Intrinsics &K) {
+        M3 m;
+        m(0, 0) = 1.0 / K.fx;
+        m(0, 2) = -K.cx / K.fx;
+        m(1, 1) = 1.0 / K.fy;
+        m(1, 2) = -K.cy / K.fy;
+        m(2, 2) = 1.0;
+        return m;
+    }
+
+    bool judge_track_status() {   // :577-739
+        Frame *curr = map->get_frame(map->frame_num() - 1);
+        Frame *keyframe = map->get_frame(map->frame_num() - 2);
+        Frame *last = keyframe->subframes.empty() ? keyframe : keyframe->subframes.back().get();
+        P_.integrate(curr->preintegration, curr->image->t, last->motion.bg, last->motion.ba, true, true);
+        predict(curr->preintegration, last, curr);
+        std::vector<V2> P2D;
+        std::vector<V3> P3D;
+        std::vector<size_t> lens;
+        std::vector<int> index(curr->keypoint_num(), -1);
+        for (size_t k = 0; k < curr->keypoint_num(); ++k)
+            if (Track *t = curr->get_track(k))
+                if (t->all_tagged({TT_VALID, TT_TRIANGULATED})) {
+                    const V3 &b = curr->get_keypoint(k);
+                    P2D.push_back({b.x / b.z, b.y / b.z});
+                    P3D.push_back(t->get_landmark_point());
+                    lens.push_back(t->m_life);
+                    index[k] = (int)P3D.size() - 1;
+                }
+        if (P2D.size() < 20) return false;
+        const PoseState pose = curr->get_pose(curr->camera);
+        const M3 Rcw = to_matrix(pose.q.conjugate());
+        const V3 tcw = -(pose.q.conjugate() * pose.p);
+        std::vector<char> mask;
+        find_pnp_matrix_parsac_imu(parsac_, P3D, P2D, lens, Rcw, tcw, 0.20, 1.0, mask, 1.0 / curr->K.fx);
+        M3 R;
+        V3 t;
+        predict_RT(keyframe, curr, R, t);
+        M3 tx;
+        tx(0, 1) = -t.z; tx(0, 2) = t.y; tx(1, 0) = t.z; tx(1, 2) = -t.x; tx(2, 0) = -t.y; tx(2, 1) = t.x;
+        const M3 F = transpose(k_inverse(keyframe->K)) * (tx * R) * k_inverse(curr->K);
+        const M3 Ft = transpose(F);
+        std::vector<double> d_in, d_out;
+        for (size_t i = 0; i < curr->keypoint_num(); ++i) {
+            if (index[i] == -1) continue;
+            const size_t j = curr->get_track(i)->get_keypoint_index(keyframe);
+            if (j == nil()) continue;
+            const V2 p1 = apply_k(keyframe->get_keypoint(j), keyframe->K), p2 = apply_k(curr->get_keypoint(i), curr->K);
+            const double err = epipolar_dist(F, p1, p2) + epipolar_dist(Ft, p2, p1);
+            (mask[index[i]] ? d_in : d_out).push_back(err);
+        }
+        if (d_in.size() < 20 || d_out.size() < 20) return false;
+        std::sort(d_in.begin(), d_in.end());
+        std::sort(d_out.begin(), d_out.end());
+        const double th1 = d_in[size_t(d_in.size() * 0.5)], th2 = d_out[size_t(d_out.size() * 0.5)];
+        if (th2 < th1 * 2) return false;   // the two groups are not separated: ambiguous
+        parsac_th_ = (th1 + th2) / 2;
+        for (size_t k = 0; k < curr->keypoint_num(); ++k)
+            if (Track *tr = curr->get_track(k))
+                if (index[k] != -1) {
+                    const bool inlier = mask[index[k]] != 0;
+                    tr->tag(TT_OUTLIER) = !inlier;
+                    tr->tag(TT_STATIC) = inlier;
+                    if (!inlier) P_.times.scope[SC_RD_OUTLIERS] += 1.0;
+                }
+        P_.times.scope[SC_RD_JUDGED] += 1.0;
+        return true;
+    }
+
+    bool filter_parsac_2d2d(Frame *fi, Frame *fj, std::vector<char> &mask, std::vector<size_t> &pts_to_index) {   // :523-547
+        std::vector<V2> p1, p2;
+        for (size_t ki = 0; ki < fi->keypoint_num(); ++ki)
+            if (Track *t = fi->get_track(ki)) {
+                const size_t kj = t->get_keypoint_index(fj);
+                if (kj == 0 || kj == nil()) continue;   // `if (size_t kj = ...)` in the reference also drops index 0
+                const V3 &a = fi->get_keypoint(ki), &b = fj->get_keypoint(kj);
+                p1.push_back({a.x / a.z, a.y / a.z});
+                p2.push_back({b.x / b.z, b.y / b.z});
+                pts_to_index.push_back(kj);
+            }
+        if (p1.size() < 10) return false;
+        find_essential_matrix_parsac(parsac_, p1, p2, mask, parsac_th_ / fi->K.fx);
+        return true;
+    }
+
+    void update_track_status() {   // :741-788
+        Frame *curr = map->get_frame(map->frame_num() - 1);
+        if (!feature_tracking_map_) return;
+        const size_t fidx = feature_tracking_map_->frame_index_by_id(curr->id);
+        if (fidx == nil()) return;
+        Frame *old_frame = feature_tracking_map_->get_frame(fidx);
+        std::vector<size_t> outlier_cnts(curr->keypoint_num(), 0), matches_cnts(curr->keypoint_num(), 0);
+        const size_t last = map->frame_num() - 1;
+        const size_t start = std::min(last, std::max(last - P_.config.parsac_keyframe_check_size, size_t(0)));   // unsigned, like the reference
+        for (size_t i = start; i < last; ++i) {
+            std::vector<char> mask;
+            std::vector<size_t> to_index;
+            if (filter_parsac_2d2d(map->get_frame(i), curr, mask, to_index))
+                for (size_t j = 0; j < mask.size(); ++j) {
+                    if (!mask[j]) outlier_cnts[to_index[j]] += 1;
+                    matches_cnts[to_index[j]] += 1;
+                }
+        }
+        // The reference looks the window's track up in the FEATURE TRACKER's frame (a different map: the lookup never
+        // succeeds), so the demotion below is unreachable there as well; kept for the day that lookup is fixed upstream.
+        for (size_t i = 0; i < curr->keypoint_num(); ++i)
+            if (Track *ct = curr->get_track(i)) {
+                const size_t j = ct->get_keypoint_index(old_frame);
+                if (j == 0 || j == nil()) continue;
+                Track *ot = old_frame->get_track(j);
+                if (!ot) continue;
+                const size_t outlier_th = map->frame_num() / 2;
+                if (outlier_cnts[i] > outlier_th / 2 && outlier_cnts[i] > 0.8 * matches_cnts[i]) ct->tag(TT_STATIC) = false;
+                if (!ot->tag(TT_STATIC) || !ct->tag(TT_STATIC)) {
+                    ct->tag(TT_STATIC) = false;
+                    ot->tag(TT_STATIC) = false;
+                }
+            }
+    }
+    ParsacState parsac_;
+    double parsac_th_ = 0.0;
+    Map *feature_tracking_map_ = nullptr;
 
     void localize_newframe() {   // :119-143
         WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);

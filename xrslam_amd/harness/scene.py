@@ -35,7 +35,7 @@ class BoxRoom:
         self.tex = np.stack([_noise_texture(n, seed * 10 + k) for k in range(6)])   # face = 2*axis + (positive side)
         self.n = n
 
-    def render(self, q_wc, p_wc, w=752, h=480, K=K_EUROC, dist=None):
+    def render(self, q_wc, p_wc, w=752, h=480, K=K_EUROC, dist=None, obj=None):
         """dist = (k1, k2, p1, p2): the image is what a radial-tangential lens would record (each pixel's ray is the
         undistorted direction whose distorted projection lands on that pixel)."""
         fx, fy, cx, cy = K
@@ -76,10 +76,39 @@ class BoxRoom:
         T = self.tex
         val = (T[face, v0, u0] * (1 - fu) * (1 - fv) + T[face, v0, u0 + 1] * fu * (1 - fv) + T[face, v0 + 1, u0] * (1 - fu) * fv +
                T[face, v0 + 1, u0 + 1] * fu * fv)
+        if obj is not None:
+            val = self._paint_object(val, p_wc, d, t, obj)
         return np.clip(np.rint(val), 0, 255).astype(np.uint8)
 
+    def _paint_object(self, val, p_wc, d, t_room, obj):
+        """A textured cuboid (centre, half extents) in front of the walls: the moving object of the RD-VIO tests."""
+        c, hs = np.asarray(obj[0], float), np.asarray(obj[1], float)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t1 = (c - hs - p_wc) / d
+            t2 = (c + hs - p_wc) / d
+        tn, tf = np.minimum(t1, t2), np.maximum(t1, t2)
+        t_in, t_out = np.nanmax(tn, axis=-1), np.nanmin(tf, axis=-1)
+        hit_box = (t_in < t_out) & (t_in > 0) & (t_in < t_room)
+        if not hit_box.any():
+            return val
+        axis = np.argmax(tn, axis=-1)
+        hit = p_wc + d * t_in[..., None] - c                       # in the object's frame: texture sticks to it
+        ua = np.where(axis == 0, 1, 0)
+        va = np.where(axis == 2, 1, 2)
+        u = (np.take_along_axis(hit, ua[..., None], axis=-1)[..., 0] + 2.0) * self.tpm
+        v = (np.take_along_axis(hit, va[..., None], axis=-1)[..., 0] + 2.0) * self.tpm
+        u = np.clip(u, 0, self.n - 1.001)
+        v = np.clip(v, 0, self.n - 1.001)
+        u0, v0 = u.astype(int), v.astype(int)
+        fu, fv = u - u0, v - v0
+        To = np.roll(self.tex, 977, axis=2)
+        face = (axis + 3) % 6
+        vo = (To[face, v0, u0] * (1 - fu) * (1 - fv) + To[face, v0, u0 + 1] * fu * (1 - fv) + To[face, v0 + 1, u0] * (1 - fu) * fv +
+              To[face, v0 + 1, u0 + 1] * fu * fv)
+        return np.where(hit_box, vo, val)
 
-def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True, traj=None, K=K_EUROC, dist=None):
+
+def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True, traj=None, K=K_EUROC, dist=None, moving_object=None):
     """Returns dict(frames uint8 [n,h,w], cam_t [n], imu [m,7] (t, w, a), states [n,16] ground truth body states)."""
     rng = np.random.RandomState(seed)
     traj = traj or Trajectory()
@@ -100,5 +129,8 @@ def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0,
     for i, t in enumerate(cam_t):
         q, p = traj.q(t), traj.p(t)
         states[i] = np.concatenate([q, p, traj.v(t), bg, ba])
-        frames[i] = room.render(qmul(q, Q_BC), p + qrot(q, P_BC), w, h, K, dist)
+        obj = None
+        if moving_object is not None:   # callable t -> (centre, half extents), or None when absent
+            obj = moving_object(t)
+        frames[i] = room.render(qmul(q, Q_BC), p + qrot(q, P_BC), w, h, K, dist, obj)
     return dict(frames=frames, cam_t=cam_t, imu=imu, states=states, bg=bg, ba=ba)
