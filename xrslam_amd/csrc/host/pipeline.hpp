@@ -11,8 +11,10 @@
 //   Solver facade (problem assembly)                      estimation/solver.cpp:84-173
 // PC semantics: threading off, every worker runs inline in the caller.
 // All arithmetic of the hot path is delegated to xrhip_* (KLT, pre-integration, BA, marginalisation).
-// The Initializer (SfM + visual-inertial alignment) is out of scope: the
-// window is bootstrapped from externally supplied initial states (BootstrapInitializer).
+//   Initializer (SfM + visual-inertial alignment)         core/initializer.cpp:22-571   (geometry: two_view.hpp)
+//   RD-VIO outlier filters (judge / update_track_status)  core/sliding_window_tracker.cpp:523-790   (parsac.hpp, epnp.hpp)
+// Work that does not depend on the rest of the frame is queued early on streams of its own (marginalisation,
+// re-integrations, image preprocessing): DESIGN.md section 4.5.
 #pragma once
 #include <chrono>
 #include <algorithm>
