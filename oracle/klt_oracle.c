@@ -68,6 +68,14 @@ static inline int reflect101(int i, int n) {
 static inline int cv_round_f(float v) { return (int)lrintf(v); }   /* cvRound: round-half-even */
 static inline int cv_floor_f(float v) { return (int)floorf(v); }
 
+/* Row / tile / point loops below are independent per iteration; they run on
+ * g_threads OpenMP threads (default 1 = the reference-faithful single core; the
+ * CPU baseline of bench.py also reports a multi-threaded figure because OpenCV's
+ * parallel_for_ would spread the same loops).  Results do not depend on it. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return g_threads; }
+
 /* ------------------------------------------------------------------ CLAHE */
 /* cv::CLAHE_Impl::apply, 8-bit, tiles must divide the image (EuRoC sizes do;
  * otherwise OpenCV pads with REFLECT_101, restated below as well). */
@@ -101,6 +109,7 @@ int orc_clahe(const uint8_t *src, int w, int h, int sstride, double clip_limit,
         if (clip < 1) clip = 1;
     }
     uint8_t *lut = (uint8_t *)malloc((size_t)tiles_x * tiles_y * hist_size);
+#pragma omp parallel for collapse(2) num_threads(g_threads)
     for (int ty = 0; ty < tiles_y; ++ty) {
         for (int tx = 0; tx < tiles_x; ++tx) {
             int hist[256];
@@ -137,6 +146,7 @@ int orc_clahe(const uint8_t *src, int w, int h, int sstride, double clip_limit,
     }
     /* interpolation body */
     const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+#pragma omp parallel for num_threads(g_threads)
     for (int y = 0; y < h; ++y) {
         float tyf = y * inv_th - 0.5f;
         int ty1 = cv_floor_f(tyf);
@@ -185,6 +195,7 @@ static inline int16_t *lv_der(const OrcLevel *L, int x, int y) {
 
 static void level_fill_border(OrcLevel *L) {
     /* copyMakeBorder(..., BORDER_REFLECT_101) for the image, zeros for derivs */
+#pragma omp parallel for num_threads(g_threads)
     for (int y = -L->pad; y < L->h + L->pad; ++y) {
         int sy = reflect101(y, L->h);
         for (int x = -L->pad; x < L->w + L->pad; ++x) {
@@ -197,7 +208,10 @@ static void level_fill_border(OrcLevel *L) {
 /* cv::pyrDown, CV_8U, 5-tap [1 4 6 4 1], (sum+128)>>8, BORDER_REFLECT_101 */
 static void pyr_down(const OrcLevel *S, OrcLevel *D) {
     int sw = S->w, sh = S->h;
+#pragma omp parallel num_threads(g_threads)
+    {
     int *rows = (int *)malloc(sizeof(int) * 5 * D->w);
+#pragma omp for
     for (int y = 0; y < D->h; ++y) {
         for (int k = 0; k < 5; ++k) {
             int sy = reflect101(2 * y - 2 + k, sh);
@@ -215,12 +229,14 @@ static void pyr_down(const OrcLevel *S, OrcLevel *D) {
         }
     }
     free(rows);
+    }
 }
 
 /* cv::detail calcSharrDeriv (lkpyramid.cpp): 3/10/3 Scharr, unnormalised, int16,
  * image edges by reflect-101 on the level itself (not on the padded buffer). */
 static void scharr_deriv(OrcLevel *L) {
     int w = L->w, h = L->h;
+#pragma omp parallel for num_threads(g_threads)
     for (int y = 0; y < h; ++y) {
         const uint8_t *r0 = lv_img(L, 0, y > 0 ? y - 1 : (h > 1 ? 1 : 0));
         const uint8_t *r1 = lv_img(L, 0, y);
@@ -324,13 +340,17 @@ void orc_lk(const OrcPyramid *A, const OrcPyramid *B, const float *prev_pts, flo
     const float half = (win - 1) * 0.5f;
     int levels1 = A->nlevels - 1;
     if (max_level > levels1) max_level = levels1;
-    int16_t *Ibuf = (int16_t *)malloc(sizeof(int16_t) * win * win * 3);
-    int16_t *dIbuf = Ibuf + win * win;
     for (int i = 0; i < n; ++i) status[i] = 1;
+    long long n_templates = 0, n_iters = 0;
 
     for (int level = max_level; level >= 0; --level) {
         const OrcLevel *I = &A->lv[level];
         const OrcLevel *J = &B->lv[level];
+#pragma omp parallel num_threads(g_threads) reduction(+ : n_templates, n_iters)
+        {
+        int16_t *Ibuf = (int16_t *)malloc(sizeof(int16_t) * win * win * 3);
+        int16_t *dIbuf = Ibuf + win * win;
+#pragma omp for schedule(dynamic, 4)
         for (int pt = 0; pt < n; ++pt) {
             float px = prev_pts[2 * pt] * (float)(1. / (1 << level));
             float py = prev_pts[2 * pt + 1] * (float)(1. / (1 << level));
@@ -375,7 +395,7 @@ void orc_lk(const OrcPyramid *A, const OrcPyramid *B, const float *prev_pts, flo
                     sA22 += (int64_t)iyval * iyval;
                 }
             }
-            if (stats) stats->templates++;
+            n_templates++;
             float A11 = (float)sA11 * FLT_SCALE;
             float A12 = (float)sA12 * FLT_SCALE;
             float A22 = (float)sA22 * FLT_SCALE;
@@ -411,7 +431,7 @@ void orc_lk(const OrcPyramid *A, const OrcPyramid *B, const float *prev_pts, flo
                         sb2 += (int64_t)diff * dIbuf[2 * (y * win + x) + 1];
                     }
                 }
-                if (stats) stats->iters++;
+                n_iters++;
                 float b1 = (float)sb1 * FLT_SCALE;
                 float b2 = (float)sb2 * FLT_SCALE;
                 float dx = (A12 * b2 - A22 * b1) * D;
@@ -430,8 +450,13 @@ void orc_lk(const OrcPyramid *A, const OrcPyramid *B, const float *prev_pts, flo
                 pdy = dy;
             }
         }
+        free(Ibuf);
+        }
     }
-    free(Ibuf);
+    if (stats) {
+        stats->templates += n_templates;
+        stats->iters += n_iters;
+    }
 }
 
 /* OpenCvImage::track_keypoints (opencv_image.cpp:75-154).
@@ -481,6 +506,7 @@ void orc_track_keypoints(const OrcPyramid *A, const OrcPyramid *B, const double 
 /* cv::cornerHarris(src 8U, blockSize 3, ksize 3, k) with exact integer window sums. */
 void orc_harris_response(const uint8_t *img, int w, int h, int stride, double k, float *resp) {
     int *dxy = (int *)malloc(sizeof(int) * 2 * (size_t)w * h);
+#pragma omp parallel for num_threads(g_threads)
     for (int y = 0; y < h; ++y) {
         const uint8_t *r0 = img + (size_t)reflect101(y - 1, h) * stride;
         const uint8_t *r1 = img + (size_t)y * stride;
@@ -497,6 +523,7 @@ void orc_harris_response(const uint8_t *img, int w, int h, int stride, double k,
     scale *= 255.0;
     scale = 1.0 / scale;
     const float s2 = (float)(scale * scale);
+#pragma omp parallel for num_threads(g_threads)
     for (int y = 0; y < h; ++y) {
         for (int x = 0; x < w; ++x) {
             int sxx = 0, sxy = 0, syy = 0;
@@ -535,13 +562,16 @@ int orc_gftt(const uint8_t *img, int w, int h, int stride, int max_corners, doub
     float *eig = (float *)malloc(sizeof(float) * (size_t)w * h);
     orc_harris_response(img, w, h, stride, k, eig);
     float maxv = eig[0];
-    for (size_t i = 1; i < (size_t)w * h; ++i)
+#pragma omp parallel for num_threads(g_threads) reduction(max : maxv)
+    for (long i = 1; i < (long)w * h; ++i)
         if (eig[i] > maxv) maxv = eig[i];
     float thr = (float)((double)maxv * quality);
-    for (size_t i = 0; i < (size_t)w * h; ++i)
+#pragma omp parallel for num_threads(g_threads)
+    for (long i = 0; i < (long)w * h; ++i)
         if (!(eig[i] > thr)) eig[i] = 0.f;
-    Cand *c = (Cand *)malloc(sizeof(Cand) * (size_t)w * h);
-    int nc = 0;
+    /* local maxima of the 3x3 dilation, flagged per row, then collected in scan order */
+    uint8_t *flag = (uint8_t *)calloc((size_t)w * h, 1);
+#pragma omp parallel for num_threads(g_threads)
     for (int y = 1; y < h - 1; ++y) {
         for (int x = 1; x < w - 1; ++x) {
             float v = eig[(size_t)y * w + x];
@@ -552,13 +582,20 @@ int orc_gftt(const uint8_t *img, int w, int h, int stride, int max_corners, doub
                     float u = eig[(size_t)(y + j) * w + x + i];
                     if (u > m) m = u;
                 }
-            if (v == m) {
-                c[nc].v = v;
-                c[nc].idx = y * w + x;
-                nc++;
-            }
+            if (v == m) flag[(size_t)y * w + x] = 1;
         }
     }
+    int nc = 0;
+    for (size_t i = 0; i < (size_t)w * h; ++i) nc += flag[i];
+    Cand *c = (Cand *)malloc(sizeof(Cand) * (size_t)(nc > 0 ? nc : 1));
+    nc = 0;
+    for (size_t i = 0; i < (size_t)w * h; ++i)
+        if (flag[i]) {
+            c[nc].v = eig[i];
+            c[nc].idx = (int)i;
+            nc++;
+        }
+    free(flag);
     qsort(c, nc, sizeof(Cand), cand_cmp);
     int ncorners = 0;
     if (min_distance >= 1) {

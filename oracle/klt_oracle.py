@@ -44,6 +44,8 @@ def _load():
     lib.orc_detect_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                          C.c_double, C.c_void_p]
     lib.orc_poisson_select.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+    lib.orc_set_threads.argtypes = [C.c_int]
+    lib.orc_get_threads.restype = C.c_int
     del u8p
     return lib
 
@@ -172,3 +174,12 @@ def poisson_select(pts, radius):
     if len(pts):
         lib().orc_poisson_select(_p(pts), len(pts), float(radius), _p(keep))
     return keep
+
+
+def set_threads(n):
+    """OpenMP threads of the row / tile / point loops (default 1); results do not depend on it."""
+    lib().orc_set_threads(int(n))
+
+
+def get_threads():
+    return lib().orc_get_threads()

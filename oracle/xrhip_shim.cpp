@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "../include/xrslam_hip.h"
@@ -21,6 +22,7 @@ int orc_detect_keypoints(const uint8_t *img, int w, int h, int stride, const dou
                          int max_points, double min_dist, double *out_xy);
 void orc_track_keypoints(const OrcPyramid *A, const OrcPyramid *B, const double *curr, double *next_inout, int has_guess,
                          uint8_t *status, int n, void *stats);
+void orc_set_threads(int n);
 // oracle/ba_oracle.cpp
 int orc_ba_solve(const xrhip_ba_problem *P, xrhip_ba_summary *summary);
 int orc_ba_marginalize(const xrhip_marg_problem *M, double *out_sqrt_info, double *out_infovec, double *out_lin);
@@ -53,6 +55,9 @@ int xrhip_device_count(void) { return 0; }
 int xrhip_set_device(int) { return 0; }
 
 int xrhip_klt_create(int width, int height, int, xrhip_klt **out) {
+    // XR_ORACLE_THREADS: threads of the image / point loops (OpenCV's parallel_for_ in the reference); the solver stays
+    // single-threaded like the reference's num_threads = 1 (estimation/solver.cpp:185)
+    if (const char *e = getenv("XR_ORACLE_THREADS")) orc_set_threads(atoi(e));
     *out = new xrhip_klt{width, height};
     return 0;
 }

@@ -179,3 +179,33 @@ def test_poisson_select_matches_bruteforce_semantics():
     # permissive) approximation of a strict 20 px exclusion -- exactly like the reference
     assert d.min() > 20.0 / np.sqrt(2.0) - 1e-9
     assert keep[0] == 1
+
+
+def test_results_do_not_depend_on_thread_count(golden_pair):
+    """The oracle's image / point loops may run on several OpenMP threads (bench.py's cpu_baseline_mt leg):
+    every iteration is independent, so planes, corners, positions and LK counters are identical."""
+    a, b = golden_pair
+
+    def run():
+        A, B = ko.OracleImage(a), ko.OracleImage(b)
+        A.preprocess(6.0, 8, 8)
+        B.preprocess(6.0, 8, 8)
+        kp = A.detect_keypoints(np.zeros((0, 2)), 200, 20.0)
+        st = ko.LkStats()
+        nx, status = A.track_keypoints(B, kp, kp.copy(), stats=st)
+        planes = [A.level(l, padded=True) for l in range(4)]
+        return kp, nx, status, (st.iters, st.templates), planes
+
+    assert ko.get_threads() == 1
+    one = run()
+    try:
+        ko.set_threads(4)
+        four = run()
+    finally:
+        ko.set_threads(1)
+    for x, y in zip(one[:3], four[:3]):
+        np.testing.assert_array_equal(x, y)
+    assert one[3] == four[3]
+    for (i1, d1), (i4, d4) in zip(one[4], four[4]):
+        np.testing.assert_array_equal(i1, i4)
+        np.testing.assert_array_equal(d1, d4)
