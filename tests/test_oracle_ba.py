@@ -332,3 +332,52 @@ def test_solver_trivial_and_fixed_problems():
     sm = bo.solve(pd)
     assert sm.iterations == 0 and sm.usable
     np.testing.assert_array_equal(pd.frame_state, before)
+
+
+def test_se3_cost_function_pattern():
+    """Mirror of the reference's only estimation unit test (xrslam-test/test/src/test_se3_cost_function.cpp:10-93):
+    the toy factor r = p1 - (q*p2 + p) over a quaternion block with QuaternionParameterization
+    (estimation/ceres/quaternion_parameterization.h:12-18: Plus = (q * expmap(dq)).normalized(), identity lift) and
+    its hand-written Jacobians dr/ddq = R(q) hat(p2), dr/dp = -I, validated like CostFunctionValidator
+    (cost_function_validator.h:22-26,289-367: forward differences through Plus, fd_epsilon 1e-9, tolerance 2e-6) before
+    and after a solve.  The quaternion Plus is the oracle's (orc_state_plus), so the test pins the oracle's
+    right-multiplicative update convention to the one the reference's test checks.  Inputs are seeded (the reference
+    draws them from an unseeded std::random_device, so it holds no golden numbers)."""
+    rng = np.random.default_rng(20240924)
+    hat = lambda v: np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+    def plus(q, p, d6):
+        st = np.zeros(16)
+        st[0:4], st[4:7] = q, p
+        d = np.zeros(15)
+        d[0:3], d[3:6] = d6[0:3], d6[3:6]
+        out = bo.state_plus(st, d)
+        return out[0:4], out[4:7]
+
+    def validate(q, p, p1, p2):
+        r0 = p1 - (bs.qrot(q, p2) + p)
+        J = np.hstack([bs.qmat(q) @ hat(p2), -np.eye(3)])
+        Jfd = np.zeros((3, 6))
+        for i in range(6):
+            d = np.zeros(6)
+            d[i] = 1.0e-9
+            qi, pi = plus(q, p, d)
+            Jfd[:, i] = ((p1 - (bs.qrot(qi, p2) + pi)) - r0) / 1.0e-9
+        return np.abs(J - Jfd).max(), r0, J
+
+    for _ in range(20):
+        p2 = rng.uniform(-1, 1, 3)
+        ax, ay, az = rng.uniform(-1, 1, 3) * np.pi
+        q = bs.qmul(bs.qmul(bs.qexp(np.array([ax, 0, 0])), bs.qexp(np.array([0, ay, 0]))), bs.qexp(np.array([0, 0, az])))
+        p = rng.uniform(-1, 1, 3)
+        p1 = bs.qrot(q, p2) + p + rng.uniform(-1, 1, 3) * 0.1
+        err, r, J = validate(q, p, p1, p2)
+        assert err < 2.0e-6
+        for _it in range(50):       # Gauss-Newton on the 3-residual / 6-dof problem (minimum-norm step)
+            q, p = plus(q, p, np.linalg.lstsq(J, -r, rcond=None)[0])
+            err, r, J = validate(q, p, p1, p2)
+            if np.abs(r).max() < 1e-14:
+                break
+        assert np.abs(r).max() < 1e-12          # an exact fit exists (6 dof, 3 residuals)
+        assert abs(np.linalg.norm(q) - 1.0) < 1e-15
+        assert err < 2.0e-6
