@@ -35,6 +35,12 @@ def undistort(gray, K4, D4):
     v = fy * yd + cy
     iu = np.rint(u * INTER_TAB_SIZE).astype(np.int64)
     iv = np.rint(v * INTER_TAB_SIZE).astype(np.int64)
+    return _remap_fixed(gray, iu, iv)
+
+
+def _remap_fixed(gray, iu, iv):
+    """cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) on 1/32-pixel fixed-point coordinates (CV_16SC2 + CV_16UC1 maps)."""
+    h, w = gray.shape
     sx = (iu >> INTER_BITS).astype(np.int64)
     sy = (iv >> INTER_BITS).astype(np.int64)
     ax = (iu & (INTER_TAB_SIZE - 1)).astype(np.int64)
@@ -53,3 +59,43 @@ def undistort(gray, K4, D4):
     acc = tap(sy, sx) * w00 + tap(sy, sx + 1) * w01 + tap(sy + 1, sx) * w10 + tap(sy + 1, sx + 1) * w11
     out = (acc + (1 << (INTER_REMAP_COEF_BITS - 1))) >> INTER_REMAP_COEF_BITS
     return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def undistort_model(gray, K4, D, model):
+    """numpy restatement of xrslam::extra::ImageUndistorter (xrslam-extra/include/xrslam/extra/image_undistorter.h:14-92),
+    used by the reference's TUM-VI reader with model "equidistant" (xrslam-pc/player/src/IO/tum_dataset_reader.cpp:67-76):
+    distort_pixel() per pixel in double, float32 maps, cv::convertMaps(CV_16SC2) -- cvRound(float * 32) with int16
+    saturation of the integer part -- then the same fixed-point remap as above."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    fx, fy, cx, cy = [float(v) for v in K4]
+    D = [float(v) for v in D]
+    j = np.arange(w, dtype=np.float64)[None, :] + np.zeros((h, 1))
+    i = np.arange(h, dtype=np.float64)[:, None] + np.zeros((1, w))
+    x = (j - cx) / fx
+    y = (i - cy) / fy
+    if model == "radtan":
+        k3 = D[4] if len(D) > 4 else 0.0
+        r2 = x * x + y * y
+        r4 = r2 * r2
+        r6 = r4 * r2
+        kr = 1.0 + D[0] * r2 + D[1] * r4 + k3 * r6
+        u = fx * (x * kr + 2.0 * D[2] * x * y + D[3] * (r2 + 2.0 * x * x)) + cx
+        v = fy * (y * kr + 2.0 * D[3] * x * y + D[2] * (r2 + 2.0 * y * y)) + cy
+    elif model == "equidistant":
+        r = np.sqrt(x * x + y * y)
+        th = np.arctan(r)
+        th2 = th * th
+        th4 = th2 * th2
+        thd = th * (1 + D[0] * th2 + D[1] * th4 + D[2] * (th2 * th4) + D[3] * (th4 * th4))
+        sc = np.where(r > 1e-8, thd / np.where(r > 0, r, 1.0), 1.0)
+        u = np.where(r < 1e-10, j, fx * (x * sc) + cx)
+        v = np.where(r < 1e-10, i, fy * (y * sc) + cy)
+    else:
+        raise ValueError("unknown model: " + model)
+    iu = np.rint(u.astype(np.float32) * np.float32(INTER_TAB_SIZE)).astype(np.int64)
+    iv = np.rint(v.astype(np.float32) * np.float32(INTER_TAB_SIZE)).astype(np.int64)
+    # the integer part is stored as int16 (saturate_cast<short>); the fraction survives
+    iu = (np.clip(iu >> INTER_BITS, -32768, 32767) << INTER_BITS) | (iu & (INTER_TAB_SIZE - 1))
+    iv = (np.clip(iv >> INTER_BITS, -32768, 32767) << INTER_BITS) | (iv & (INTER_TAB_SIZE - 1))
+    return _remap_fixed(gray, iu, iv)

@@ -25,6 +25,18 @@ void ph_undistort(const unsigned char *src, int w, int h, const double *K4, cons
     u.apply(src, w, dst, w);
 }
 
+// the reference's ImageUndistorter maps ("radtan" / "equidistant"); returns 1 for an unknown model
+int ph_undistort_model(const unsigned char *src, int w, int h, const double *K4, const double *D, int nd, const char *model,
+                       unsigned char *dst) {
+    try {
+        Undistorter u(w, h, K4, std::vector<double>(D, D + nd), model);
+        u.apply(src, w, dst, w);
+        return 0;
+    } catch (const std::exception &) {
+        return 1;
+    }
+}
+
 // event order of a directory: writes up to cap (type, index) pairs, returns the number of events
 long ph_merge(const char *root, double camera_offset, int *types, long *index, double *times, long cap) {
     const std::vector<CameraRow> cam = load_camera_csv(std::string(root) + "/cam0/data.csv");
@@ -67,6 +79,19 @@ void ph_tum_line(double t, const double *p, const double *q, char *out, long cap
     FILE *f = fmemopen(out, (size_t)cap, "w");
     write_tum_pose(f, t, p, q);
     std::fclose(f);
+}
+
+void ph_csv_line(double t, const double *p, const double *q, char *out, long cap) {
+    FILE *f = fmemopen(out, (size_t)cap, "w");
+    write_csv_pose(f, t, p, q);
+    std::fclose(f);
+}
+
+// 0: no known scheme, 1: euroc, 2: tum; the directory goes to `path`
+int ph_split_url(const char *url, char *path, long cap) {
+    const auto [scheme, dir] = split_dataset_url(url);
+    std::snprintf(path, (size_t)cap, "%s", dir.c_str());
+    return scheme == "euroc" ? 1 : scheme == "tum" ? 2 : 0;
 }
 
 }   // extern "C"

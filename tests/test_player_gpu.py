@@ -20,8 +20,11 @@ def test_player_tracks_a_synthetic_euroc_directory(tmp_path):
     seq = scene.make_sequence(n_frames=100, seed=5)
     root = euroc.write_euroc(seq, str(tmp_path / "mav0"))
     out = str(tmp_path / "traj.tum")
-    cmd = [PLAYER, "--slam", os.path.join(ROOT, "configs", "bench_slam_150.yaml"), "--device",
-           os.path.join(ROOT, "configs", "euroc_sensor.yaml"), "--euroc", root, "--out", out, "--no-undistort", "--bootstrap-frames", "60"]
+    csv = str(tmp_path / "traj.csv")
+    # the reference player's own command line (main.cpp:57-79) plus our two extras
+    cmd = [PLAYER, "-sc", os.path.join(ROOT, "configs", "bench_slam_150.yaml"), "-dc",
+           os.path.join(ROOT, "configs", "euroc_sensor.yaml"), "--tum", out, "--csv", csv, "-p", "--no-undistort",
+           "--bootstrap-frames", "60", "euroc://" + root]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
@@ -32,6 +35,7 @@ def test_player_tracks_a_synthetic_euroc_directory(tmp_path):
     assert rows.shape == (res["tracked"], 8)
     assert np.all(np.diff(rows[:, 0]) > 0)
     np.testing.assert_allclose(np.linalg.norm(rows[:, 4:8], axis=1), 1.0, atol=1e-6)
+    np.testing.assert_array_equal(np.loadtxt(csv, delimiter=","), rows)       # CSV writer: same fields, comma separated
     # the same stream through the ctypes harness (device-independent host pushes): same trajectory
     from xrslam_amd import _lib
     from xrslam_amd.harness import runner

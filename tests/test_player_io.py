@@ -1,5 +1,6 @@
 """CPU tests of the headless player's I/O (xrslam_amd/csrc/player/euroc_io.hpp):
-PNG decode, radial-tangential undistortion, ASL/EuRoC CSV parsing, event order, TUM output, ATE."""
+PNG decode, radial-tangential undistortion, the TUM-VI reader's equidistant undistortion, ASL/EuRoC CSV parsing,
+event order, TUM / CSV output, ATE, and the command line the reference's player accepts."""
 import ctypes as C
 import os
 import subprocess
@@ -29,6 +30,9 @@ def ph():
     lib.ph_tum_line.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_char_p, C.c_long]
     lib.ph_decode_png.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
     lib.ph_undistort.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ph_undistort_model.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p]
+    lib.ph_csv_line.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_char_p, C.c_long]
+    lib.ph_split_url.argtypes = [C.c_char_p, C.c_char_p, C.c_long]
     return lib
 
 
@@ -139,3 +143,71 @@ def test_tum_line_and_ate(ph):
     assert 0.005 < got < 0.03
     if want_ate is not None and np.isfinite(want_ate):
         assert abs(got - want_ate) < 1e-9
+
+
+def test_model_undistorter_matches_the_oracle_restatement(ph):
+    """xrslam::extra::ImageUndistorter (image_undistorter.h:14-92), the TUM-VI reader's undistortion
+    (tum_dataset_reader.cpp:67-76): equidistant and radtan maps against the numpy restatement."""
+    from oracle import undistort as ou
+    rng = np.random.RandomState(5)
+    img = rng.randint(0, 256, (128, 128)).astype(np.uint8)
+    # TUM-VI cam0 (512x512: fx 190.98, fy 190.97, cx 254.93, cy 256.90; k1..k4) scaled to 128x128
+    K = np.array([190.978 / 4, 190.973 / 4, 254.932 / 4, 256.897 / 4])
+    D = np.array([0.0034823894022493434, 0.0007150348452162257, -0.0020532361418706202, 0.00020293673591811182])
+    out = np.zeros_like(img)
+    assert ph.ph_undistort_model(_p(img), 128, 128, _p(K), _p(D), 4, b"equidistant", _p(out)) == 0
+    np.testing.assert_array_equal(out, ou.undistort_model(img, K, D, "equidistant"))
+    assert np.count_nonzero(out != img) > img.size // 2          # a fisheye map is far from the identity
+    # the principal point maps to itself (r < 1e-10 branch): put it on a pixel centre
+    Kc = np.array([48.0, 48.0, 64.0, 64.0])
+    assert ph.ph_undistort_model(_p(img), 128, 128, _p(Kc), _p(D), 4, b"equidistant", _p(out)) == 0
+    np.testing.assert_array_equal(out, ou.undistort_model(img, Kc, D, "equidistant"))
+    assert out[64, 64] == img[64, 64]
+    # radtan with the optional k3
+    D5 = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.01])
+    K2 = np.array([458.654 / 6, 457.296 / 6, 367.215 / 6, 248.375 / 6])
+    img2 = rng.randint(0, 256, (80, 125)).astype(np.uint8)
+    out2 = np.zeros_like(img2)
+    for d in (D5, D5[:4]):
+        assert ph.ph_undistort_model(_p(img2), 125, 80, _p(K2), _p(np.ascontiguousarray(d)), len(d), b"radtan", _p(out2)) == 0
+        np.testing.assert_array_equal(out2, ou.undistort_model(img2, K2, d, "radtan"))
+    # zero coefficients: both models are the identity map
+    for model in (b"radtan", b"equidistant"):
+        assert ph.ph_undistort_model(_p(img), 128, 128, _p(K), _p(np.zeros(4)), 4, model, _p(out)) == 0
+        if model == b"radtan":
+            np.testing.assert_array_equal(out, img)
+    assert ph.ph_undistort_model(_p(img), 128, 128, _p(K), _p(D), 4, b"fov", _p(out)) == 1    # "unknown model" throws
+
+
+def test_csv_line_and_dataset_urls(ph):
+    buf = C.create_string_buffer(512)
+    p = np.array([1.5, -2.25, 3.0]); q = np.array([0.0, 0.0, 0.6, 0.8])
+    ph.ph_csv_line(1403636579.763555584, _p(p), _p(q), buf, 512)
+    want = "%.18e,%.9e,%.9e,%.9e,%.7e,%.7e,%.7e,%.7e\n" % ((1403636579.763555584,) + tuple(p) + tuple(q))
+    assert buf.value.decode() == want                    # trajectory_writer.h:46-52
+    path = C.create_string_buffer(256)
+    assert ph.ph_split_url(b"euroc:///data/MH_01_easy/mav0", path, 256) == 1 and path.value == b"/data/MH_01_easy/mav0"
+    assert ph.ph_split_url(b"tum://room1/mav0", path, 256) == 2 and path.value == b"room1/mav0"
+    assert ph.ph_split_url(b"/data/MH_01_easy/mav0", path, 256) == 0          # dataset_reader.cpp:17-34: no reader
+    assert ph.ph_split_url(b"eur", path, 256) == 0
+
+
+PLAYER = os.path.join(ROOT, "xrslam_amd", "bin", "xrslam-player")
+
+
+@pytest.mark.skipif(not os.path.exists(PLAYER), reason="player not built (run __graft_entry__.build())")
+def test_player_accepts_the_reference_command_line(tmp_path):
+    """xrslam-pc/player/src/main.cpp:57-79: -sc / -dc / -lc / --tum / --csv / -p and a positional euroc:// or tum://
+    input.  No device is needed up to the point where the data set is opened."""
+    slam, dev = os.path.join(ROOT, "configs", "euroc_slam.yaml"), os.path.join(ROOT, "configs", "euroc_sensor.yaml")
+    run = lambda *a: subprocess.run([PLAYER, *a], capture_output=True, text=True)
+    r = run()
+    assert r.returncode == 2 and "usage" in r.stderr
+    r = run("-sc", slam, "-dc", dev, "-p", str(tmp_path))                 # no scheme: the reference finds no reader
+    assert r.returncode == 1 and 'Cannot open "%s"' % tmp_path in r.stderr
+    for url in ("euroc://" + str(tmp_path), "tum://" + str(tmp_path)):
+        r = run("--slamconfig", slam, "--deviceconfig", dev, "--license", "none", "--tum", str(tmp_path / "t.tum"),
+                "--csv", str(tmp_path / "t.csv"), "--play", url)
+        assert r.returncode == 1 and "no camera or IMU data under %s" % tmp_path in r.stderr
+    r = run("-sc", slam, "-dc", dev, "-q", "euroc://x")
+    assert r.returncode == 2 and "unknown argument -q" in r.stderr

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../host/hla.hpp"
@@ -279,6 +280,44 @@ class Undistorter {
                 e.ay = (int)(iv & 31);
             }
     }
+    // xrslam::extra::ImageUndistorter (xrslam-extra/include/xrslam/extra/image_undistorter.h:14-92), the map the
+    // reference's TUM-VI reader builds (tum_dataset_reader.cpp:67-76, model "equidistant"; "radtan" also defined
+    // there with D = k1 k2 p1 p2 [k3]): distort_pixel() in double, stored as float32 maps, cv::convertMaps to the
+    // 1/32-pixel fixed-point form (the product with INTER_TAB_SIZE is a float product), then the same remap.
+    Undistorter(int w, int h, const double K4[4], const std::vector<double> &D, const std::string &model)
+        : w_(w), h_(h), map_((size_t)w * h) {
+        if (model != "radtan" && model != "equidistant") throw std::runtime_error("unknown model: " + model);
+        if (D.size() < 4) throw std::runtime_error("distortion model needs at least 4 coefficients");
+        const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+        for (int i = 0; i < h; ++i)
+            for (int j = 0; j < w; ++j) {
+                const double x = (j - cx) / fx, y = (i - cy) / fy;
+                double u = j, v = i;
+                if (model == "radtan") {
+                    const double k3 = D.size() > 4 ? D[4] : 0.0;
+                    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+                    const double kr = 1.0 + D[0] * r2 + D[1] * r4 + k3 * r6;
+                    u = fx * (x * kr + 2.0 * D[2] * x * y + D[3] * (r2 + 2.0 * x * x)) + cx;
+                    v = fy * (y * kr + 2.0 * D[3] * x * y + D[2] * (r2 + 2.0 * y * y)) + cy;
+                } else {
+                    const double r = std::sqrt(x * x + y * y);
+                    if (r >= 1e-10) {   // the principal point maps to itself
+                        const double th = std::atan(r), th2 = th * th, th4 = th2 * th2, th6 = th2 * th4, th8 = th4 * th4;
+                        const double thd = th * (1 + D[0] * th2 + D[1] * th4 + D[2] * th6 + D[3] * th8);
+                        const double sc = (r > 1e-8) ? thd / r : 1.0;
+                        u = fx * (x * sc) + cx;
+                        v = fy * (y * sc) + cy;
+                    }
+                }
+                const long iu = std::lrintf((float)u * 32.0f), iv = std::lrintf((float)v * 32.0f);
+                Entry &e = map_[(size_t)i * w + j];
+                // convertMaps stores the integer part as int16 (saturating)
+                e.sx = (int)std::min(32767L, std::max(-32768L, iu >> 5));
+                e.sy = (int)std::min(32767L, std::max(-32768L, iv >> 5));
+                e.ax = (int)(iu & 31);
+                e.ay = (int)(iv & 31);
+            }
+    }
     void apply(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride) const {
         for (int i = 0; i < h_; ++i)
             for (int j = 0; j < w_; ++j) {
@@ -307,6 +346,22 @@ class Undistorter {
 // ------------------------------------------------------------------------------------------------- TUM
 inline void write_tum_pose(FILE *f, double t, const double p[3], const double q_xyzw[4]) {
     std::fprintf(f, "%.18e %.9e %.9e %.9e %.7e %.7e %.7e %.7e\n", t, p[0], p[1], p[2], q_xyzw[0], q_xyzw[1], q_xyzw[2], q_xyzw[3]);
+}
+
+// CsvTrajectoryWriter::write_pose (IO/trajectory_writer.h:46-52): the same fields, comma separated
+inline void write_csv_pose(FILE *f, double t, const double p[3], const double q_xyzw[4]) {
+    std::fprintf(f, "%.18e,%.9e,%.9e,%.9e,%.7e,%.7e,%.7e,%.7e\n", t, p[0], p[1], p[2], q_xyzw[0], q_xyzw[1], q_xyzw[2], q_xyzw[3]);
+}
+
+// DatasetReader::create_reader (IO/dataset_reader.cpp:17-34): "euroc://<dir>" or "tum://<dir>"; returns the scheme
+// ("euroc" / "tum") and the directory, or an empty scheme for anything else (the reference then prints
+// 'Cannot open "<input>"' and fails)
+inline std::pair<std::string, std::string> split_dataset_url(const std::string &url) {
+    for (const char *scheme : {"euroc", "tum"}) {
+        const std::string prefix = std::string(scheme) + "://";
+        if (url.compare(0, prefix.size(), prefix) == 0) return {scheme, url.substr(prefix.size())};
+    }
+    return {"", url};
 }
 
 // ------------------------------------------------------------------------------------------------- ATE

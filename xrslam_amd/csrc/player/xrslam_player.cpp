@@ -8,6 +8,15 @@
 //   xrslam-player --slam configs/euroc_slam.yaml --device configs/euroc_sensor.yaml --euroc <dir>/mav0
 //                 [--out traj.tum] [--bootstrap-frames N] [--max-frames N] [--no-undistort]
 //
+// The reference player's own command line (main.cpp:57-79) is accepted as well, so its invocations carry over:
+//
+//   xrslam-player -sc configs/euroc_slam.yaml -dc configs/euroc_sensor.yaml [-lc license] [--tum traj.tum]
+//                 [--csv traj.csv] [-p] euroc://<dir>/mav0 | tum://<dir>/mav0
+//
+// (-p / --play and the license are accepted and ignored: there is no viewer to start.)  `tum://` is the reference's
+// TUM-VI reader (IO/tum_dataset_reader.cpp): same ASL directory layout, images undistorted with the equidistant
+// (fisheye) model of xrslam::extra::ImageUndistorter instead of cv::undistort.
+//
 // By default the library initialises itself (SfM + IMU alignment, like the reference).  With --bootstrap-frames N
 // the first N camera frames are instead seeded from state_groundtruth_estimate0 through XRSLAMAmdSetInitialState
 // (N >= 36 covers the first window), which takes the initialiser out of an accuracy / throughput comparison.
@@ -40,18 +49,37 @@ static const TruthRow *nearest_truth(const std::vector<TruthRow> &gt, double t, 
 int main(int argc, char **argv) {
     std::map<std::string, std::string> opt;
     bool undistort = true;
+    // the reference's option names (main.cpp:57-71) map onto ours
+    const std::map<std::string, std::string> alias = {{"-sc", "slam"}, {"--slamconfig", "slam"}, {"-dc", "device"},
+                                                      {"--deviceconfig", "device"}, {"-lc", "license"}, {"--license", "license"},
+                                                      {"--tum", "out"}};
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--no-undistort") undistort = false;
+        else if (a == "-p" || a == "--play") continue;
+        else if (alias.count(a) && i + 1 < argc) opt[alias.at(a)] = argv[++i];
         else if (a.rfind("--", 0) == 0 && i + 1 < argc) opt[a.substr(2)] = argv[++i];
+        else if (a[0] != '-' && !opt.count("input")) opt["input"] = a;
         else {
             std::fprintf(stderr, "unknown argument %s\n", a.c_str());
             return 2;
         }
     }
+    std::string model = "cv_undistort";   // EurocDatasetReader::read_image: cv::undistort, radial-tangential
+    if (opt.count("input")) {
+        const auto [scheme, path] = split_dataset_url(opt["input"]);
+        if (scheme.empty()) {
+            std::fprintf(stderr, "Cannot open \"%s\"\n", opt["input"].c_str());   // main.cpp:99-103
+            return 1;
+        }
+        opt["euroc"] = path;
+        if (scheme == "tum") model = "equidistant";
+    }
     if (!opt.count("slam") || !opt.count("device") || !opt.count("euroc")) {
         std::fprintf(stderr, "usage: xrslam-player --slam cfg.yaml --device sensor.yaml --euroc <dir>/mav0 [--out traj.tum] "
-                             "[--bootstrap-frames N] [--max-frames N] [--no-undistort]\n");
+                             "[--csv traj.csv] [--bootstrap-frames N] [--max-frames N] [--no-undistort]\n"
+                             "   or: xrslam-player -sc cfg.yaml -dc sensor.yaml [--tum traj.tum] [--csv traj.csv] [-p] "
+                             "euroc://<dir>/mav0 | tum://<dir>/mav0\n");
         return 2;
     }
     const std::string root = opt["euroc"];
@@ -90,6 +118,11 @@ int main(int argc, char **argv) {
         }
     }
     FILE *out = opt.count("out") ? std::fopen(opt["out"].c_str(), "w") : nullptr;
+    FILE *csv = opt.count("csv") ? std::fopen(opt["csv"].c_str(), "w") : nullptr;
+    if ((opt.count("out") && !out) || (opt.count("csv") && !csv)) {
+        std::fprintf(stderr, "Cannot open file\n");   // trajectory_writer.h:37,62
+        return 1;
+    }
     const double K4[4] = {cfg.K.fx, cfg.K.fy, cfg.K.cx, cfg.K.cy};
     std::unique_ptr<Undistorter> und;
     std::vector<uint8_t> rectified;
@@ -121,7 +154,10 @@ int main(int argc, char **argv) {
             }
             const uint8_t *pixels = img.px.data();
             if (undistort && cfg.cam_distortion_flag) {
-                if (!und) und.reset(new Undistorter(img.w, img.h, K4, cfg.cam_distortion));
+                if (!und) {
+                    if (model == "cv_undistort") und.reset(new Undistorter(img.w, img.h, K4, cfg.cam_distortion));
+                    else und.reset(new Undistorter(img.w, img.h, K4, std::vector<double>(cfg.cam_distortion, cfg.cam_distortion + 4), model));
+                }
                 rectified.resize((size_t)img.w * img.h);
                 und->apply(img.px.data(), img.w, rectified.data(), img.w);
                 pixels = rectified.data();
@@ -148,6 +184,7 @@ int main(int argc, char **argv) {
                     if (pose.timestamp > 0 && valid) {
                         ++tracked;
                         if (out) write_tum_pose(out, pose.timestamp, pose.translation, pose.quaternion);
+                        if (csv) write_csv_pose(csv, pose.timestamp, pose.translation, pose.quaternion);
                         if (const TruthRow *g = nearest_truth(gt, pose.timestamp, 2.6e-3)) {
                             est.push_back({pose.translation[0], pose.translation[1], pose.translation[2]});
                             ref.push_back({g->p[0], g->p[1], g->p[2]});
@@ -160,6 +197,7 @@ int main(int argc, char **argv) {
     }
     const double busy = std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_begin).count() - io_seconds;
     if (out) std::fclose(out);
+    if (csv) std::fclose(csv);
     const char *err = XRSLAMAmdLastError();
     XRSLAMAmdInitReport rep;
     std::memset(&rep, 0, sizeof(rep));
