@@ -240,7 +240,7 @@ int xrhip_image_create(xrhip_klt *c, xrhip_image **out) {
         LevelBuf &L = im->lv[l];
         L.w = w;
         L.h = h;
-        L.istride = (KLT_PADX + w + KLT_PAD + 63) / 64 * 64;
+        L.istride = (KLT_PADX + w + KLT_PAD + 3 + 63) / 64 * 64;   // + 3: k_lk_track stages rows as whole dwords
         L.rows = h + 2 * KLT_PAD;
         XR_HIP(hipMalloc(&L.img_base, (size_t)L.rows * L.istride));
         XR_HIP(hipMalloc(&L.der_base, sizeof(short2) * (size_t)L.rows * L.istride));

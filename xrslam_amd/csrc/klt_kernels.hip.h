@@ -15,8 +15,11 @@
 //
 // Execution model: wave64.  LK runs one wavefront per keypoint, the 21x21
 // window is spread over the 64 lanes (7 pixels per lane, template held in
-// registers), and the 2x2 normal-equation sums are reduced with cross-lane
-// butterflies -- no LDS, no barriers, no atomics in the iteration loop.
+// registers), the search neighbourhood of the second image is staged in LDS
+// once per pyramid level (whole dwords, coalesced), and the 2x2 normal-equation
+// sums are reduced with cross-lane butterflies -- no atomics and no branch per
+// pixel slot in the iteration loop, so the seven gathers of a step are in
+// flight together.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -421,6 +424,17 @@ __global__ __launch_bounds__(1024) void k_harris_select(const HarrisCand *__rest
 // ----------------------------------------------------------------------- LK
 constexpr int LK_SLOTS = 7;   // ceil(441 / 64)
 constexpr int LK_W_BITS = 14;
+// Search neighbourhood of the second image staged in LDS once per pyramid level: the 22x22 footprint of the window
+// (21 + 1 for the bilinear taps) plus LK_TILE_R pixels on every side of the level's starting position, the left edge
+// moved down to a 4-byte boundary (so rows are fetched as whole dwords, coalesced).  An iteration whose footprint
+// leaves the tile reads global memory instead -- same bytes, same arithmetic.
+constexpr bool LK_STAGE_J = true;
+constexpr int LK_TILE_R = 5;
+constexpr int LK_TILE_W = 36;               // 22 + 2 * LK_TILE_R + up to 3 pixels of alignment slack, in dwords: 9
+constexpr int LK_TILE_W4 = LK_TILE_W / 4;
+constexpr int LK_TILE_H = 22 + 2 * LK_TILE_R;
+constexpr int LK_TILE_DWORDS = LK_TILE_H * LK_TILE_W4;
+constexpr int LK_TILE_LOADS = (LK_TILE_DWORDS + 63) / 64;   // dwords per lane
 
 __device__ __forceinline__ int lk_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
@@ -464,7 +478,7 @@ struct LkCounters {
 __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, float px0, float py0, float &nx_io,
                                           float &ny_io, const int (&wx)[LK_SLOTS], const int (&wy)[LK_SLOTS],
                                           const bool (&wvalid)[LK_SLOTS], unsigned &n_templates,
-                                          unsigned &n_iters) {
+                                          unsigned &n_iters, uint32_t *tile) {
     const float FLT_SCALE = 1.f / (1 << 20);
     const float half = (KLT_WIN - 1) * 0.5f;
     const double epsilon = 0.01 * 0.01;
@@ -485,6 +499,29 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
         }
         outx = nx;
         outy = ny;
+        // fetch the search neighbourhood of the level's starting position (wave-uniform control flow: one wavefront
+        // per workgroup); issued before the template gather so that both round trips overlap
+        bool staged = false;
+        int tx0 = 0, ty0 = 0;
+        uint32_t tile_regs[LK_TILE_LOADS];
+        if (LK_STAGE_J) {
+            const int inx0 = (int)floorf(nx - half), iny0 = (int)floorf(ny - half);
+            if (inx0 >= -KLT_WIN && inx0 < J.w && iny0 >= -KLT_WIN && iny0 < J.h) {
+                tx0 = inx0 - LK_TILE_R;
+                ty0 = iny0 - LK_TILE_R;
+                tx0 -= (int)(reinterpret_cast<uintptr_t>(J.img + tx0) & 3);   // row strides are multiples of 64 bytes
+#pragma unroll
+                for (int k = 0; k < LK_TILE_LOADS; ++k) {
+                    const int idx = min((int)threadIdx.x + 64 * k, LK_TILE_DWORDS - 1);
+                    const int r = idx / LK_TILE_W4, c4 = idx - r * LK_TILE_W4;
+                    // rows / dwords outside the padded plane are never part of a valid footprint: clamp the address
+                    const int y = min(max(ty0 + r, -KLT_PAD), J.h + KLT_PAD - 1);
+                    const int x = min(max(tx0 + 4 * c4, -KLT_PADX), J.istride - KLT_PADX - 4);
+                    tile_regs[k] = *reinterpret_cast<const uint32_t *>(J.img + (ptrdiff_t)y * J.istride + x);
+                }
+                staged = true;
+            }
+        }
         px -= half;
         py -= half;
         const int ipx = (int)floorf(px), ipy = (int)floorf(py);
@@ -499,31 +536,29 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
         int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
         int Iv[LK_SLOTS], Ix[LK_SLOTS], Iy[LK_SLOTS];
         long long sA11 = 0, sA12 = 0, sA22 = 0;
+        // Branch-free over the slots: a lane without a pixel in slot s (lk_lane_layout points it at window pixel 0)
+        // loads like the others and its template entries are zeroed afterwards, so the gathers of all seven slots are
+        // in flight together instead of one dependent round trip per slot.
 #pragma unroll
         for (int s = 0; s < LK_SLOTS; ++s) {
-            Iv[s] = 0;
-            Ix[s] = 0;
-            Iy[s] = 0;
-            if (wvalid[s]) {
-                const uint8_t *s0 = I.img + (ptrdiff_t)(ipy + wy[s]) * I.istride + (ipx + wx[s]);
-                const uint8_t *s1 = s0 + I.istride;
-                const short2 *d0 = I.der + (ptrdiff_t)(ipy + wy[s]) * I.pstride + (ipx + wx[s]);
-                const short2 *d1 = d0 + I.pstride;
-                short2 g00 = d0[0], g01 = d0[1], g10 = d1[0], g11 = d1[1];
-                int ival = lk_descale(s0[0] * iw00 + s0[1] * iw01 + s1[0] * iw10 + s1[1] * iw11, LK_W_BITS - 5);
-                int ixval = lk_descale(g00.x * iw00 + g01.x * iw01 + g10.x * iw10 + g11.x * iw11, LK_W_BITS);
-                int iyval = lk_descale(g00.y * iw00 + g01.y * iw01 + g10.y * iw10 + g11.y * iw11, LK_W_BITS);
-                // OpenCV stores these as int16 (Iptr/dIptr are short)
-                ival = (short)ival;
-                ixval = (short)ixval;
-                iyval = (short)iyval;
-                Iv[s] = ival;
-                Ix[s] = ixval;
-                Iy[s] = iyval;
-                sA11 += (long long)(ixval * ixval);
-                sA12 += (long long)(ixval * iyval);
-                sA22 += (long long)(iyval * iyval);
-            }
+            const uint8_t *s0 = I.img + (ptrdiff_t)(ipy + wy[s]) * I.istride + (ipx + wx[s]);
+            const uint8_t *s1 = s0 + I.istride;
+            const short2 *d0 = I.der + (ptrdiff_t)(ipy + wy[s]) * I.pstride + (ipx + wx[s]);
+            const short2 *d1 = d0 + I.pstride;
+            short2 g00 = d0[0], g01 = d0[1], g10 = d1[0], g11 = d1[1];
+            int ival = lk_descale(s0[0] * iw00 + s0[1] * iw01 + s1[0] * iw10 + s1[1] * iw11, LK_W_BITS - 5);
+            int ixval = lk_descale(g00.x * iw00 + g01.x * iw01 + g10.x * iw10 + g11.x * iw11, LK_W_BITS);
+            int iyval = lk_descale(g00.y * iw00 + g01.y * iw01 + g10.y * iw10 + g11.y * iw11, LK_W_BITS);
+            // OpenCV stores these as int16 (Iptr/dIptr are short)
+            ival = wvalid[s] ? (int)(short)ival : 0;
+            ixval = wvalid[s] ? (int)(short)ixval : 0;
+            iyval = wvalid[s] ? (int)(short)iyval : 0;
+            Iv[s] = ival;
+            Ix[s] = ixval;
+            Iy[s] = iyval;
+            sA11 += (long long)(ixval * ixval);
+            sA12 += (long long)(ixval * iyval);
+            sA22 += (long long)(iyval * iyval);
         }
         sA11 = wave_sum_i64(sA11);
         sA12 = wave_sum_i64(sA12);
@@ -542,6 +577,16 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
         D = 1.f / D;
         nx -= half;
         ny -= half;
+        // the neighbourhood fetched at the top of the level goes to LDS now (its latency ran under the template work)
+        if (staged) {
+            __syncthreads();   // readers of the previous level's tile are done
+#pragma unroll
+            for (int k = 0; k < LK_TILE_LOADS; ++k) {
+                const int idx = (int)threadIdx.x + 64 * k;
+                if (idx < LK_TILE_DWORDS) tile[idx] = tile_regs[k];
+            }
+            __syncthreads();
+        }
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < 30; ++j) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
@@ -556,9 +601,25 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
             iw10 = __float2int_rn((1.f - a) * b * (1 << LK_W_BITS));
             iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
             long long sb1 = 0, sb2 = 0;
+            const int rx = inx - tx0, ry = iny - ty0;
+            if (staged && rx >= 0 && rx <= LK_TILE_W - 22 && ry >= 0 && ry <= LK_TILE_H - 22) {
+                // LDS-qualified pointer: keeps these reads ds_read (the compiler otherwise sinks the last slot of this
+                // branch and of the global-memory branch below into one block of flat loads -- a second round trip)
+                typedef const __attribute__((address_space(3))) uint8_t *lds_bytes;
+                const lds_bytes t = (lds_bytes)tile + ry * LK_TILE_W + rx;
+                // (a lane without a pixel in slot s holds Ix = Iy = 0 there: its products vanish, no branch needed)
 #pragma unroll
-            for (int s = 0; s < LK_SLOTS; ++s) {
-                if (wvalid[s]) {
+                for (int s = 0; s < LK_SLOTS; ++s) {
+                    const lds_bytes j0 = t + wy[s] * LK_TILE_W + wx[s];
+                    const lds_bytes j1 = j0 + LK_TILE_W;
+                    int diff =
+                        lk_descale(j0[0] * iw00 + j0[1] * iw01 + j1[0] * iw10 + j1[1] * iw11, LK_W_BITS - 5) - Iv[s];
+                    sb1 += (long long)(diff * Ix[s]);
+                    sb2 += (long long)(diff * Iy[s]);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < LK_SLOTS; ++s) {
                     const uint8_t *j0 = J.img + (ptrdiff_t)(iny + wy[s]) * J.istride + (inx + wx[s]);
                     const uint8_t *j1 = j0 + J.istride;
                     int diff =
@@ -631,7 +692,8 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrView A, PyrView B, const dou
         ny = (float)g.y;
     }
     unsigned n_templates = 0, n_iters = 0;
-    int status = lk_one_way(A, B, cx, cy, nx, ny, wx, wy, wvalid, n_templates, n_iters);
+    __shared__ uint32_t tile[LK_TILE_DWORDS];
+    int status = lk_one_way(A, B, cx, cy, nx, ny, wx, wy, wvalid, n_templates, n_iters, tile);
     const int cols = A.lv[0].w, rows = A.lv[0].h;
     if (nx < 20 || nx >= cols - 20 || ny < 20 || ny >= rows - 20) status = 0;
     if (status) {
@@ -641,7 +703,7 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrView A, PyrView B, const dou
     }
     if (status) {
         float rx = cx, ry = cy;
-        int st2 = lk_one_way(B, A, nx, ny, rx, ry, wx, wy, wvalid, n_templates, n_iters);
+        int st2 = lk_one_way(B, A, nx, ny, rx, ry, wx, wy, wvalid, n_templates, n_iters, tile);
         const float dx = cx - rx, dy = cy - ry;
         const double nrm = sqrt((double)dx * (double)dx + (double)dy * (double)dy);
         if (!st2 || nrm > 0.5) status = 0;
@@ -676,7 +738,8 @@ __global__ __launch_bounds__(64) void k_lk_plain(PyrView A, PyrView B, const flo
     const float2 p = prev[pt];
     float2 q = next_io[pt];
     unsigned a = 0, b = 0;
-    int status = lk_one_way(A, B, p.x, p.y, q.x, q.y, wx, wy, wvalid, a, b);
+    __shared__ uint32_t tile[LK_TILE_DWORDS];
+    int status = lk_one_way(A, B, p.x, p.y, q.x, q.y, wx, wy, wvalid, a, b, tile);
     if (lane == 0) {
         status_out[pt] = (uint8_t)status;
         next_io[pt] = q;
