@@ -466,6 +466,17 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
+// Bilinear taps: pixel (8 bit) or Scharr derivative (int16) times a 14-bit fixed-point weight (0 .. 2^14, the fourth
+// one 2^14 minus the others, so -1 at worst).  Both factors fit 24 signed bits, the product is exact, and
+// v_mul_i32_i24 issues at full rate where the general 32-bit v_mul_lo_u32 takes four passes.
+// (Written as the instruction itself: the compiler rewrites __mul24 into a general multiply where it rescales the
+// weights for the derivative taps.)
+__device__ __forceinline__ int lk_tap(int sample, int weight) {
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(sample), "v"(weight));
+    return r;
+}
+
 struct LkCounters {
     unsigned long long templates;
     unsigned long long iterations;
@@ -546,9 +557,12 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
             const short2 *d0 = I.der + (ptrdiff_t)(ipy + wy[s]) * I.pstride + (ipx + wx[s]);
             const short2 *d1 = d0 + I.pstride;
             short2 g00 = d0[0], g01 = d0[1], g10 = d1[0], g11 = d1[1];
-            int ival = lk_descale(s0[0] * iw00 + s0[1] * iw01 + s1[0] * iw10 + s1[1] * iw11, LK_W_BITS - 5);
-            int ixval = lk_descale(g00.x * iw00 + g01.x * iw01 + g10.x * iw10 + g11.x * iw11, LK_W_BITS);
-            int iyval = lk_descale(g00.y * iw00 + g01.y * iw01 + g10.y * iw10 + g11.y * iw11, LK_W_BITS);
+            int ival = lk_descale(lk_tap(s0[0], iw00) + lk_tap(s0[1], iw01) + lk_tap(s1[0], iw10) + lk_tap(s1[1], iw11),
+                                  LK_W_BITS - 5);
+            int ixval = lk_descale(lk_tap(g00.x, iw00) + lk_tap(g01.x, iw01) + lk_tap(g10.x, iw10) + lk_tap(g11.x, iw11),
+                                   LK_W_BITS);
+            int iyval = lk_descale(lk_tap(g00.y, iw00) + lk_tap(g01.y, iw01) + lk_tap(g10.y, iw10) + lk_tap(g11.y, iw11),
+                                   LK_W_BITS);
             // OpenCV stores these as int16 (Iptr/dIptr are short)
             ival = wvalid[s] ? (int)(short)ival : 0;
             ixval = wvalid[s] ? (int)(short)ixval : 0;
@@ -612,8 +626,8 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
                 for (int s = 0; s < LK_SLOTS; ++s) {
                     const lds_bytes j0 = t + wy[s] * LK_TILE_W + wx[s];
                     const lds_bytes j1 = j0 + LK_TILE_W;
-                    int diff =
-                        lk_descale(j0[0] * iw00 + j0[1] * iw01 + j1[0] * iw10 + j1[1] * iw11, LK_W_BITS - 5) - Iv[s];
+                    int diff = lk_descale(lk_tap(j0[0], iw00) + lk_tap(j0[1], iw01) + lk_tap(j1[0], iw10) + lk_tap(j1[1], iw11),
+                                          LK_W_BITS - 5) - Iv[s];
                     sb1 += (long long)(diff * Ix[s]);
                     sb2 += (long long)(diff * Iy[s]);
                 }
@@ -622,8 +636,8 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
                 for (int s = 0; s < LK_SLOTS; ++s) {
                     const uint8_t *j0 = J.img + (ptrdiff_t)(iny + wy[s]) * J.istride + (inx + wx[s]);
                     const uint8_t *j1 = j0 + J.istride;
-                    int diff =
-                        lk_descale(j0[0] * iw00 + j0[1] * iw01 + j1[0] * iw10 + j1[1] * iw11, LK_W_BITS - 5) - Iv[s];
+                    int diff = lk_descale(lk_tap(j0[0], iw00) + lk_tap(j0[1], iw01) + lk_tap(j1[0], iw10) + lk_tap(j1[1], iw11),
+                                          LK_W_BITS - 5) - Iv[s];
                     sb1 += (long long)(diff * Ix[s]);
                     sb2 += (long long)(diff * Iy[s]);
                 }
