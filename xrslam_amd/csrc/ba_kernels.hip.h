@@ -80,51 +80,75 @@ struct BaDims {
     int lm_rows;        // landmark rows kb_landmark_vision builds: Lp, or 0 when the solver has no free landmark
 };
 
+// Pointers of the argument blocks.  Kernels that receive BaPtrs by value see global-address-space pointers (the
+// compiler knows that kernel arguments point to global memory); kb_tiny reads its argument block from device memory
+// and got generic pointers -- every access a FLAT instruction, which counts against vmcnt AND lgkmcnt, so a wait for
+// a cross-lane shuffle also waits for all loads in flight (ISA of v17: 1217 flat_load/flat_store in kb_tiny, 0 global).
+// With -DXRHIP_GLOBAL_PTRS the members are wrappers around address-space-1 pointers, from
+// which the compiler infers global loads / stores everywhere; without it they are plain pointers (the default build:
+// the variant could not be timed on a GPU in round 1).
+#ifdef XRHIP_GLOBAL_PTRS
+template <class T> struct gptr {
+    // stored WITH its address space: a load of this member yields a global pointer, and the single cast to a generic
+    // one below is what address-space inference starts from (a generic -> global -> generic cast pair on a plain
+    // member is folded away before the inference runs, and an assumption "neither LDS nor scratch" was not picked up)
+    __attribute__((address_space(1))) T *raw;
+    __host__ __device__ __forceinline__ operator T *() const { return (T *)raw; }
+    __host__ __device__ __forceinline__ T *operator->() const { return (T *)raw; }
+    __host__ __device__ __forceinline__ gptr &operator=(T *p) {
+        raw = (__attribute__((address_space(1))) T *)p;
+        return *this;
+    }
+};
+#else
+template <class T> using gptr = T *;
+#endif
+
 struct BaPtrs {
     // problem
-    double *state, *cand;            // [F][16], [TRY_B][F][16]
-    const uint8_t *fix;              // [F]
-    double *depth, *depth_cand;      // [L], [TRY_B][L]
-    const uint8_t *lact;             // [L] landmark is a free parameter
-    const int *obs_tgt, *obs_ref, *obs_lm;
-    const double *obs_zt, *obs_zr;
-    const int *rot_tgt, *rot_ref;
-    const double *rot_zt, *rot_zr;
-    const int *imu_i, *imu_j;
-    const double *imu_data;
-    double *bias_ref;                // [NI][6]
-    const int *prior_frames;
-    const double *pS, *pinfo, *plin;
-    double *pLam;                    // S^T S
+    gptr<double> state, cand;            // [F][16], [TRY_B][F][16]
+    gptr<const uint8_t> fix;              // [F]
+    gptr<double> depth, depth_cand;      // [L], [TRY_B][L]
+    gptr<const uint8_t> lact;             // [L] landmark is a free parameter
+    gptr<const int> obs_tgt, obs_ref, obs_lm;
+    gptr<const double> obs_zt, obs_zr;
+    gptr<const int> rot_tgt, rot_ref;
+    gptr<const double> rot_zt, rot_zr;
+    gptr<const int> imu_i, imu_j;
+    gptr<const double> imu_data;
+    gptr<double> bias_ref;                // [NI][6]
+    gptr<const int> prior_frames;
+    gptr<const double> pS, pinfo, plin;
+    gptr<double> pLam;                    // S^T S
     // index structures (built on the host)
-    const int *lm_start, *lm_obs;    // CSR landmark -> observations
-    const int *pair_start, *pair_items;   // CSR (row frame, col frame) -> (obs << 1 | role)
-    const int *rotf_start, *rotf_items;   // CSR frame -> rotation factors
-    const int *imuf;                 // [F][2]: imu factor with j == f, imu factor with i == f (or -1)
-    const int *priorf;               // [F]: index in prior_frames or -1
-    const int *act_idx;              // [na] free frame dofs (indices into [0, 15F)), ascending
-    const int *act_inv;              // [15F] inverse of act_idx (-1: dof is constant)
-    double *Hv, *gv;                 // [F][F][36] reprojection blocks, [F][6] reprojection gradient
+    gptr<const int> lm_start, lm_obs;    // CSR landmark -> observations
+    gptr<const int> pair_start, pair_items;   // CSR (row frame, col frame) -> (obs << 1 | role)
+    gptr<const int> rotf_start, rotf_items;   // CSR frame -> rotation factors
+    gptr<const int> imuf;                 // [F][2]: imu factor with j == f, imu factor with i == f (or -1)
+    gptr<const int> priorf;               // [F]: index in prior_frames or -1
+    gptr<const int> act_idx;              // [na] free frame dofs (indices into [0, 15F)), ascending
+    gptr<const int> act_inv;              // [15F] inverse of act_idx (-1: dof is constant)
+    gptr<double> Hv, gv;                 // [F][F][36] reprojection blocks, [F][6] reprojection gradient
     // linearisation products
-    double *orec, *ocost;            // [M][28], [M]
-    double *rrec, *rcost;
-    double *imu_r, *imu_Ji, *imu_Jj, *imu_cost;   // [NI][15], [NI][225] x2, [NI]
-    double *pr, *pt, *pJq, *pcost;   // prior residual [np], S^T r [np], Jr^-1 [NP][9], cost [1]
-    double *Hpp, *gp;                // [n][n], [n]   unscaled frame Hessian / gradient
-    double *hll, *gl, *Wt;           // [L], [L], [Lp][PF]
-    double *sp, *sl, *omega;         // Jacobi scales [n], [L]; Schur weights [L]
-    double *T;                       // [PF][PF]
-    double *Sred;                    // [n][n] scratch (global fallback of the Cholesky)
-    double *diagD, *grad, *gn, *gs, *step, *delta;   // [NV] each
-    double *partial;                 // [aux_quad_blocks] partial sums of Q(g~,g~)
-    double *wog;                     // [PF] W^T (omega gl)
-    double *wide_part;               // [WIDE_G][4 WIDE_B] per-block partial sums of kb_trials_wide
+    gptr<double> orec, ocost;            // [M][28], [M]
+    gptr<double> rrec, rcost;
+    gptr<double> imu_r, imu_Ji, imu_Jj, imu_cost;   // [NI][15], [NI][225] x2, [NI]
+    gptr<double> pr, pt, pJq, pcost;   // prior residual [np], S^T r [np], Jr^-1 [NP][9], cost [1]
+    gptr<double> Hpp, gp;                // [n][n], [n]   unscaled frame Hessian / gradient
+    gptr<double> hll, gl, Wt;           // [L], [L], [Lp][PF]
+    gptr<double> sp, sl, omega;         // Jacobi scales [n], [L]; Schur weights [L]
+    gptr<double> T;                       // [PF][PF]
+    gptr<double> Sred;                    // [n][n] scratch (global fallback of the Cholesky)
+    gptr<double> diagD, grad, gn, gs, step, delta;   // [NV] each
+    gptr<double> partial;                 // [aux_quad_blocks] partial sums of Q(g~,g~)
+    gptr<double> wog;                     // [PF] W^T (omega gl)
+    gptr<double> wide_part;               // [WIDE_G][4 WIDE_B] per-block partial sums of kb_trials_wide
     // zero-copy mailbox in pinned host memory (device-visible addresses): the trial kernel publishes the
     // control block, on termination the optimised states, and last a sequence number the host spins on
-    BaCtl *host_ctl;
-    double *host_out;                // [16 F + L]
-    int *host_seq;
-    BaCtl *ctl;
+    gptr<BaCtl> host_ctl;
+    gptr<double> host_out;                // [16 F + L]
+    gptr<int> host_seq;
+    gptr<BaCtl> ctl;
 };
 
 XD bool pose_free(uint8_t fix) { return !(fix & 1); }
@@ -874,6 +898,67 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
     __shared__ int fail;
     BaCtl *c = p.ctl;
     const int n = d.n, na = d.na, tid = threadIdx.x, nt = blockDim.x;
+#ifdef XRHIP_GLOBAL_PTRS
+    double *work = lds;                                // LDS work region: the packed triangle, later the gathered frame step
+    const double mu = c->mu;
+    KPROF_BEGIN();
+    int bad = 0;
+    // The factorisation works on `A`: the packed lower triangle (compact) + the rhs as its row `na`, in LDS when it
+    // fits, else in Sred.  As ONE pointer (`use_lds ? work : p.Sred`) it is a generic one and every access of the
+    // Cholesky / substitution chain becomes a FLAT instruction even when it goes to LDS (ISA of v17: 244 flat_load /
+    // flat_store in kb_solve_try); here the stage is instantiated once per memory, so the LDS instance reads and
+    // writes with ds_* instructions (the #else branch is the default build's text, one generic pointer).  Returns false when the factorisation failed.
+    auto factor_stage = [&](double *A) __attribute__((always_inline)) -> bool {
+        double *y = A + tri_idx(na, 0);                    // [na] rhs -> L^-1 rhs (by the factorisation) -> solution
+        for (int i = tid; i < na; i += nt) {   // rhs = sp (gp - W^T (omega gl)); the product comes from kb_solve_aux
+            const int a = p.act_idx[i];
+            const int fa = a / 15, ka = a - 15 * fa;
+            const double sacc = (d.nla && ka < 6) ? p.wog[6 * fa + ka] : 0.0;
+            y[i] = (p.gp[a] - sacc) * p.sp[a];
+        }
+        __syncthreads();
+        KPROF(0);
+        // ---- S = sp (Hpp - T) sp + mu D^2 over the free dofs was written by kb_schur_aux as a packed triangle in Sred
+        if (use_lds)
+            for (int e = tid; e < na * (na + 1) / 2; e += nt) A[e] = p.Sred[e];
+        __syncthreads();
+        KPROF(1);
+#ifdef XRHIP_KPROF
+        const bool ok = chol_blocked(A, na, na + 1, Dblk, &fail, p.ctl->prof + 24);   // the rhs row rides along
+#else
+        const bool ok = chol_blocked(A, na, na + 1, Dblk, &fail);
+#endif
+        KPROF(2);
+        if (!ok) {
+            if (tid == 0) c->linear_ok = 0;
+            return false;
+        }
+        KPROF(3);
+        trsv_lower_t(A, na, y);
+        KPROF(4);
+        // ---- Gauss-Newton step (scaled space), landmark back-substitution, dogleg gradient
+        for (int a = tid; a < n; a += nt) {
+            p.gn[a] = 0.0;
+            p.grad[a] = dof_active(p.fix, a) ? p.gs[a] / p.diagD[a] : 0.0;
+            p.delta[a] = 0.0;   // delta doubles as the full-layout y (frame part) for the back-substitution below
+        }
+        __syncthreads();
+        for (int i = tid; i < na; i += nt) {
+            const int a = p.act_idx[i];
+            const double ya = y[i];
+            p.gn[a] = -p.diagD[a] * ya;
+            p.delta[a] = ya;
+            if (!isfinite(ya)) bad = 1;
+        }
+        __syncthreads();
+        return true;
+    };
+    if (use_lds) {
+        if (!factor_stage(work)) return;
+    } else {
+        if (!factor_stage(static_cast<double *>(p.Sred))) return;
+    }
+#else
     double *work = lds;                                // LDS work region: the packed triangle, later the gathered frame step
     double *A = use_lds ? work : p.Sred;               // packed lower triangle (compact) + the rhs as its row `na`
     double *y = A + tri_idx(na, 0);                    // [na] rhs -> L^-1 rhs (by the factorisation) -> solution
@@ -921,6 +1006,7 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
         if (!isfinite(ya)) bad = 1;
     }
     __syncthreads();
+#endif
     if (!d.nla) {   // every landmark is held constant (localize_newframe, refine_subwindow): nothing to back-substitute
         for (int l = tid; l < d.L; l += nt) {
             p.gn[n + l] = 0.0;
@@ -1246,11 +1332,11 @@ __device__ __forceinline__ void publish_block(const BaDims &d, const BaPtrs &p, 
     if (tid == 0) {
         p.ctl->status = status;
         if (always || status == ST_DONE) {
-            const long long *src = reinterpret_cast<const long long *>(p.ctl);
-            long long *dst = reinterpret_cast<long long *>(p.host_ctl);
+            const long long *src = reinterpret_cast<const long long *>(static_cast<BaCtl *>(p.ctl));
+            long long *dst = reinterpret_cast<long long *>(static_cast<BaCtl *>(p.host_ctl));
             for (unsigned i = 0; i < sizeof(BaCtl) / sizeof(long long); ++i) dst[i] = src[i];
             __threadfence_system();
-            *reinterpret_cast<volatile int *>(p.host_seq) = seq;
+            *reinterpret_cast<volatile int *>(static_cast<int *>(p.host_seq)) = seq;
         }
     }
     __syncthreads();
@@ -1961,11 +2047,11 @@ __global__ __launch_bounds__(256) void kb_tiny(const TinyArgs *__restrict__ args
     // not terminated within the round budget (or an unexpected status): tell the host, which reports an error
     if (tid == 0) {
         p.ctl->status = st == ST_DONE ? ST_DONE : -1;
-        const long long *src = reinterpret_cast<const long long *>(p.ctl);
-        long long *dst = reinterpret_cast<long long *>(p.host_ctl);
+        const long long *src = reinterpret_cast<const long long *>(static_cast<BaCtl *>(p.ctl));
+        long long *dst = reinterpret_cast<long long *>(static_cast<BaCtl *>(p.host_ctl));
         for (unsigned i = 0; i < sizeof(BaCtl) / sizeof(long long); ++i) dst[i] = src[i];
         __threadfence_system();
-        *reinterpret_cast<volatile int *>(p.host_seq) = seq;
+        *reinterpret_cast<volatile int *>(static_cast<int *>(p.host_seq)) = seq;
     }
 }
 
