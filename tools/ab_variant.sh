@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of a build variant against the default library on a GPU box:
 #   tools/ab_variant.sh gptr -DXRHIP_GLOBAL_PTRS
+#   tools/ab_variant.sh dpp -DXRHIP_DPP_SUM
+#   tools/ab_variant.sh both -DXRHIP_GLOBAL_PTRS -DXRHIP_DPP_SUM
 # builds lib/libxrslam_hip_<name>.so (if missing), runs the BA / pipeline / KLT parity tests against it and then
 # bench.py three times per library, alternating (run-to-run spread on one box is about 1 %).
 set -euo pipefail

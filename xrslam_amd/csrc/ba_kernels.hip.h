@@ -158,11 +158,32 @@ XD bool dof_active(const uint8_t *fix, int a) {   // a in [0, 15F)
     return k < 6 ? pose_free(fix[f]) : motion_free(fix[f]);
 }
 
+#ifdef XRHIP_DPP_SUM
+// The partner value of lane (i ^ off) through a DPP move for the butterfly stages that DPP can express -- off 8 is a
+// rotation by 8 inside a row of 16 lanes (row_ror:8), off 2 and 1 are quad permutations -- instead of a round trip over
+// the LDS crossbar (ds_bpermute, two per double).  Same partners, same order of additions: the sums keep their bits.
+template <int CTRL> __device__ __forceinline__ double dpp_move_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += __shfl_xor(v, 32);
+    v += __shfl_xor(v, 16);
+    v += dpp_move_f64<0x128>(v);   // row_ror:8            == lane ^ 8
+    v += __shfl_xor(v, 4);
+    v += dpp_move_f64<0x4e>(v);    // quad_perm:[2,3,0,1]  == lane ^ 2
+    v += dpp_move_f64<0xb1>(v);    // quad_perm:[1,0,3,2]  == lane ^ 1
+    return v;
+}
+#else
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
+#endif
 
 // deterministic block-wide sum (fixed tree); scratch must hold blockDim.x/64 doubles
 __device__ __forceinline__ double block_sum(double v, double *scratch) {
