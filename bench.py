@@ -113,13 +113,14 @@ def main():
         achieved = (lk_bytes / n_launch) / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
         ba_tflops = bst.flops_solve_try / (bst.ms_solve_try * 1e-3) / 1e12 if bst.ms_solve_try > 0 else 0.0
         # HBM-side bytes per launch: PMC counters cannot be read in-process; they come from the committed rocprofv3
-        # --pmc passes of this same command (profiles/r01_pmc_traffic.md says how they were collected)
+        # --pmc passes of this same command (profiles/r*_pmc_traffic.md says how they were collected)
         traffic = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            import glob
+            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as fh:   # newest round
                 pmc = json.load(fh)
             traffic = {k: round(1024.0 * (v["fetch_kb"] + v["write_kb"]), 1) for k, v in pmc.items()}
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, IndexError):
             pass
         out = {
             "metric": "frames/sec, full per-frame hot path (KLT tracker + sliding-window VI-BA), one sequence per GPU",

@@ -5,8 +5,10 @@ On the GPU box (one gpurun call; PMC passes are separate runs without any other 
     rocprofv3 --kernel-trace --memory-copy-trace --stats -d $R/gpurun_out/prof_TAG -o full -- python $R/bench.py --steps 100 --warmup 40 --cpu-frames 0 --no-profile
     for C in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_TAG/$C -o pmc -- python $R/bench.py --steps 60 --warmup 40 --cpu-frames 0 --no-profile; done
     python $R/bench.py > $R/gpurun_out/bench_TAG.json
-Here:
+(tools/gpu_profile.sh TAG is that command sequence.)  Here:
     python tools/make_profile_summary.py TAG v13 "one-line description of this version"
+XR_ROUND (default r01) is the prefix of the files written under profiles/ (r02 in round 2, ...); the PMC header text is
+taken from the newest existing r*_pmc_traffic.md.
 """
 import collections
 import csv
@@ -17,6 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, ver, desc = sys.argv[1], sys.argv[2], sys.argv[3]
+rnd = os.environ.get("XR_ROUND", "r01")
 go = os.path.join(ROOT, "gpurun_out")
 
 c = sqlite3.connect(os.path.join(go, "prof_%s" % tag, "full_results.db"))
@@ -32,18 +35,18 @@ total = sum(t for t, _ in tot.values())
 b = open(os.path.join(go, "bench_%s.json" % tag)).read().strip().splitlines()[-1]
 bj = json.loads(b)
 frames = 140
-lines = ["# round 1, full pipeline %s (%s)" % (ver, desc), "",
+lines = ["# round %d, full pipeline %s (%s)" % (int(rnd[1:]), ver, desc), "",
          "`rocprofv3 --kernel-trace --memory-copy-trace --stats -- python bench.py --steps 100 --warmup 40 --cpu-frames 0 --no-profile` on one MI355X",
          "(gfx950, ROCm 7.2); kernel-trace statistics from the results database.", "",
          "Total kernel time %.2f ms over %d frames (%.3f ms / frame); default `python bench.py` on the same box: %.1f frames/s, "
-         "%.4f ms/frame, %.4f ms/BA-iteration, CPU reference %.1f frames/s on 1 core (`r01_full_%s_bench.json`)." %
+         "%.4f ms/frame, %.4f ms/BA-iteration, CPU reference %.1f frames/s on 1 core (`" + rnd + "_full_%s_bench.json`)." %
          (total / 1e6, frames, total / 1e6 / frames, bj["value"], bj["ms_per_step"], bj["ms_per_ba_iteration"],
-          bj["cpu_baseline"]["value"], ver), "",
+          bj.get("cpu_baseline", {}).get("value", float("nan")), ver), "",
          "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
 for k, (t, n) in sorted(tot.items(), key=lambda x: -x[1][0]):
     lines.append("| `%s` | %d | %.2f | %.2f | %.1f |" % (k, n, t / 1e6, t / 1e3 / n, 100 * t / total))
-open(os.path.join(ROOT, "profiles", "r01_full_%s_kernel_stats.md" % ver), "w").write("\n".join(lines) + "\n")
-open(os.path.join(ROOT, "profiles", "r01_full_%s_bench.json" % ver), "w").write(b + "\n")
+open(os.path.join(ROOT, "profiles", "%s_full_%s_kernel_stats.md" % (rnd, ver)), "w").write("\n".join(lines) + "\n")
+open(os.path.join(ROOT, "profiles", "%s_full_%s_bench.json" % (rnd, ver)), "w").write(b + "\n")
 
 pmc_dir = os.path.join(go, "pmc_%s" % tag)
 if os.path.isdir(pmc_dir):
@@ -63,8 +66,9 @@ if os.path.isdir(pmc_dir):
         res[C] = agg
     names = sorted(res["FETCH_SIZE"], key=lambda n: -res["FETCH_SIZE"][n][0])
     out = {}
-    md = os.path.join(ROOT, "profiles", "r01_pmc_traffic.md")
-    head = open(md).read().split("| kernel |")[0]
+    import glob
+    md = os.path.join(ROOT, "profiles", "%s_pmc_traffic.md" % rnd)
+    head = open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.md")))[-1]).read().split("| kernel |")[0]
     head += "| kernel | launches | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch |\n|---|---|---|---|\n"
     for n in names:
         f = res["FETCH_SIZE"][n]
@@ -73,7 +77,7 @@ if os.path.isdir(pmc_dir):
         out[n] = {"launches": f[1], "fetch_kb": round(fk, 2), "write_kb": round(wk, 2)}
         head += "| `%s` | %d | %.1f | %.1f |\n" % (n, f[1], fk, wk)
     open(md, "w").write(head)
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd), "w"), indent=1)
 print("\n".join(lines[5:22]))
 print(bj["roofline"])
 print(bj["roofline_lk"])
