@@ -60,3 +60,20 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle|#\s*include[^\n]*oracle|liboracle|-[LlI][^\n ]*oracle", t, flags=re.M):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_experimental_build_flags_still_compile():
+    """The build variants prepared for A/B runs (-DXRHIP_GLOBAL_PTRS, -DXRHIP_DPP_SUM, with and
+    without the in-kernel phase timers) must keep passing the front end for host and device, or they rot unnoticed
+    while only the default configuration is built."""
+    import subprocess
+    src = os.path.join(ROOT, "xrslam_amd", "csrc", "ba_api.hip")
+    for flags in (["-DXRHIP_GLOBAL_PTRS", "-DXRHIP_DPP_SUM"], ["-DXRHIP_GLOBAL_PTRS", "-DXRHIP_DPP_SUM", "-DXRHIP_KPROF"]):
+        p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-fsyntax-only",
+                            "-Wno-unused-value", "-Wno-unused-result", "-Wno-unused-command-line-argument"] + flags + [src],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-3000:]
