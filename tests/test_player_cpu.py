@@ -64,3 +64,25 @@ def test_cpu_reference_player_rectifies_and_stops_at_max_frames(player, tmp_path
     assert res["error"] == "" and res["frames"] == 55 and res["tracked"] >= 15
     assert 0 <= res["ate_rmse_m"] < 0.03
     assert res["io_ms_per_frame"] > 0                 # PNG decode + undistortion are accounted separately
+
+
+def test_cpu_reference_player_tum_reader_rectifies_a_fisheye_stream(player, tmp_path):
+    """`tum://` (IO/tum_dataset_reader.cpp): same ASL layout, frames rectified with the equidistant model of
+    xrslam::extra::ImageUndistorter.  The synthetic camera records through that fisheye model; rectified, the stream
+    tracks like a pinhole one, unrectified it must do clearly worse."""
+    from xrslam_amd.harness import euroc, scene
+    coeffs = (0.0034823894022493434, 0.0007150348452162257, -0.0020532361418706202, 0.00020293673591811182)   # TUM-VI cam0
+    seq = scene.make_sequence(n_frames=60, seed=6, dist=("equidistant",) + coeffs)
+    root = euroc.write_euroc(seq, str(tmp_path / "mav0"))
+    sensor = tmp_path / "fisheye_sensor.yaml"
+    text = open(SENSOR).read()
+    lines = text.splitlines()
+    i = next(n for n, ln in enumerate(lines) if ln.strip().startswith("distortion:"))
+    lines[i] = lines[i][:lines[i].index("distortion:")] + "distortion: [%r, %r, %r, %r]" % coeffs
+    sensor.write_text("\n".join(lines) + "\n")
+    base = [player, "-sc", SLAM, "-dc", str(sensor), "--bootstrap-frames", "60"]
+    res = _run(base + ["tum://" + root])
+    assert res["error"] == "" and res["frames"] == 60 and res["tracked"] >= 15
+    assert 0 <= res["ate_rmse_m"] < 0.03
+    res2 = _run(base + ["--no-undistort", "tum://" + root])
+    assert not (0 <= res2["ate_rmse_m"] < 2 * res["ate_rmse_m"])

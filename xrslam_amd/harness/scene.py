@@ -37,12 +37,26 @@ class BoxRoom:
 
     def render(self, q_wc, p_wc, w=752, h=480, K=K_EUROC, dist=None, obj=None):
         """dist = (k1, k2, p1, p2): the image is what a radial-tangential lens would record (each pixel's ray is the
-        undistorted direction whose distorted projection lands on that pixel)."""
+        undistorted direction whose distorted projection lands on that pixel); dist = ("equidistant", k1, k2, k3, k4):
+        what a fisheye lens of the equidistant model would record."""
         fx, fy, cx, cy = K
         xs = (np.arange(w) - cx) / fx
         ys = (np.arange(h) - cy) / fy
         gx, gy = np.broadcast_arrays(xs[None, :], ys[:, None])
-        if dist is not None:
+        if dist is not None and len(dist) == 5 and dist[0] == "equidistant":
+            # ("equidistant", k1, k2, k3, k4): the fisheye model of the reference's TUM-VI reader
+            # (xrslam-extra/include/xrslam/extra/image_undistorter.h:67-84): r_d = theta (1 + k1 theta^2 + ... + k4 theta^8)
+            k1, k2, k3, k4 = dist[1:]
+            rd = np.sqrt(gx * gx + gy * gy)
+            th = rd.copy()
+            for _ in range(20):                        # Newton on theta_d(theta) = r_d
+                t2 = th * th
+                f = th * (1 + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4)))) - rd
+                df = 1 + t2 * (3 * k1 + t2 * (5 * k2 + t2 * (7 * k3 + t2 * 9 * k4)))
+                th = th - f / df
+            sc = np.where(rd > 1e-12, np.tan(th) / np.where(rd > 1e-12, rd, 1.0), 1.0)
+            gx, gy = gx * sc, gy * sc
+        elif dist is not None:
             k1, k2, p1, p2 = dist
             xd, yd = gx, gy
             x, y = xd.copy(), yd.copy()
