@@ -77,4 +77,5 @@ def test_slam_keys_are_optional(lib, tmp_path):
     empty.write_text("%YAML:1.0\n---\n")
     ok, err, _ = _create(lib, str(empty), SENSOR)
     assert ok == 1, err
+    assert err == ""                                  # a successful create clears the error of the failed ones above
     lib.XRSLAMDestroy()

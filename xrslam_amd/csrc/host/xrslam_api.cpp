@@ -56,6 +56,7 @@ int XRSLAMCreate(const char *slam_config_path, const char *device_config_path, c
                  void **config) {
     Manager &m = mgr();
     int ok = 0;
+    m.last_error.clear();   // XRSLAMAmdLastError speaks about the instance being created, not about an earlier one
     guarded([&] {
         m.config = xrh::load_config(slam_config_path, device_config_path);
         m.sys = std::make_unique<xrh::System>(m.config);
