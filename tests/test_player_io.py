@@ -57,6 +57,12 @@ def test_png_decoder_matches_pil(ph, tmp_path):
         path = str(tmp_path / ("g%d.png" % k))
         Image.fromarray(arr).save(path, **kw)
         np.testing.assert_array_equal(_decode(ph, path), arr)
+    # 16-bit grey (TUM-VI): the high byte, like cv::imread(IMREAD_GRAYSCALE) / png_set_strip_16
+    deep = (rng.randint(0, 65536, (33, 47)).astype(np.uint16) & 0xFFF0) + (np.add.outer(np.arange(33), np.arange(47)) % 16).astype(np.uint16)
+    path = str(tmp_path / "g16.png")
+    Image.fromarray(deep).save(path)
+    assert Image.open(path).mode in ("I;16", "I;16B", "I")
+    np.testing.assert_array_equal(_decode(ph, path), (deep >> 8).astype(np.uint8))
     rgb = rng.randint(0, 256, (40, 50, 3)).astype(np.uint8)
     path = str(tmp_path / "rgb.png")
     Image.fromarray(rgb).save(path)

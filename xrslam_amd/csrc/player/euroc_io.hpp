@@ -196,14 +196,19 @@ inline GrayImage decode_png(const std::vector<uint8_t> &file) {
         }
         pos += 12 + len;
     }
-    if (w <= 0 || h <= 0 || depth != 8 || interlace != 0) throw std::runtime_error("png: only 8-bit non-interlaced images");
+    // 16-bit samples (TUM-VI frames) are reduced to their high byte: cv::imread(IMREAD_GRAYSCALE) asks libpng to strip
+    // them to 8 bits (png_set_strip_16) before any colour conversion
+    if (w <= 0 || h <= 0 || (depth != 8 && depth != 16) || interlace != 0)
+        throw std::runtime_error("png: only 8- or 16-bit non-interlaced images");
     int ch = 0;
     if (ctype == 0) ch = 1;
     else if (ctype == 2) ch = 3;
     else if (ctype == 4) ch = 2;
     else if (ctype == 6) ch = 4;
     else throw std::runtime_error("png: unsupported colour type");
-    const size_t stride = (size_t)w * ch;
+    const int bps = depth / 8;            // bytes per sample (big-endian)
+    const int bpp = ch * bps;             // bytes per pixel: the distance the PNG filters look back
+    const size_t stride = (size_t)w * bpp;
     std::vector<uint8_t> raw((stride + 1) * (size_t)h);
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, zdata.data(), (uLong)zdata.size()) != Z_OK || out_len != raw.size())
@@ -217,7 +222,7 @@ inline GrayImage decode_png(const std::vector<uint8_t> &file) {
         const uint8_t *line = &raw[(stride + 1) * (size_t)y];
         const int filter = line[0];
         for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= (size_t)ch ? cur[i - ch] : 0, b = prev[i], c = i >= (size_t)ch ? prev[i - ch] : 0;
+            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
             int pred = 0;
             if (filter == 1) pred = a;
             else if (filter == 2) pred = b;
@@ -232,8 +237,9 @@ inline GrayImage decode_png(const std::vector<uint8_t> &file) {
         }
         uint8_t *dst = &img.px[(size_t)y * w];
         for (int x = 0; x < w; ++x) {
-            if (ch <= 2) dst[x] = cur[(size_t)x * ch];
-            else dst[x] = (uint8_t)((cur[(size_t)x * ch] * 4899 + cur[(size_t)x * ch + 1] * 9617 + cur[(size_t)x * ch + 2] * 1868 + 8192) >> 14);
+            const uint8_t *px = &cur[(size_t)x * bpp];
+            if (ch <= 2) dst[x] = px[0];
+            else dst[x] = (uint8_t)((px[0] * 4899 + px[bps] * 9617 + px[2 * bps] * 1868 + 8192) >> 14);
         }
         prev.swap(cur);
     }
