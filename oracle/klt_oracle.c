@@ -20,8 +20,10 @@
  * LKTrackerInvoker / calcSharrDeriv, pyramids.cpp pyrDown 8U, clahe.cpp,
  * corner.cpp cornerHarris, featureselect.cpp goodFeaturesToTrack).
  *
- * Pinned against the reference's own known answers (tests/test_oracle_golden.py):
- *   xrslam-test/test/src/test_feature_track.cpp:41,55,64  (164 / !NO_TRANSLATION / 161).
+ * Pinned against the reference's own known answers (tests/test_oracle_klt.py,
+ * test_reference_known_answers and ..._at_frame_level):
+ *   xrslam-test/test/src/test_feature_track.cpp:41,55,64  (164 / !NO_TRANSLATION / 161)
+ * -- reproduced exactly, with the test's cv::undistort restated in oracle/undistort.py.
  *
  * Deliberate, documented deviations from a particular OpenCV *build* (whose
  * float summation order is SIMD/build specific anyway):

@@ -12,14 +12,33 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with `pytest -m gpu` via gpurun)")
 
 
+def _pair(name):
+    import numpy as np
+    d = np.load(os.path.join(ROOT, "tests", "golden", name))
+    return d["a"], d["b"]
+
+
 @pytest.fixture(scope="session")
 def golden_pair():
-    import numpy as np
-    d = np.load(os.path.join(ROOT, "tests", "golden", "euroc_pair.npz"))
-    return d["a"], d["b"]
+    """The reference's two test frames, undistorted by the restatement that reproduces its known answers exactly
+    (tests/golden/make_golden.py, oracle/undistort.py)."""
+    return _pair("euroc_pair.npz")
 
 
 @pytest.fixture(scope="session")
 def klt_expected():
     import numpy as np
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "klt_expected.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_pair_v1():
+    """The same frames with the undistortion map rounded straight from the double (36 pixels differ): a second real
+    image pair for the HIP-vs-oracle parity test."""
+    return _pair("euroc_pair_v1.npz")
+
+
+@pytest.fixture(scope="session")
+def klt_expected_v1():
+    import numpy as np
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "klt_expected_v1.npz")))

@@ -263,8 +263,8 @@ inline std::vector<uint8_t> read_file(const std::string &path) {
 }
 
 // -------------------------------------------------------------------------------------- undistortion
-// cv::undistort(src, dst, K, D) for the radial-tangential model (k1, k2, p1, p2): inverse map in double, rounded to
-// 1/32-pixel fixed point, bilinear remap with 15-bit weights, constant-0 border.  K and D pass through float32
+// cv::undistort(src, dst, K, D) for the radial-tangential model (k1, k2, p1, p2): inverse map in double, rounded
+// through float32 to 1/32-pixel fixed point, bilinear remap with 15-bit weights, constant-0 border.  K and D pass through float32
 // because the reference builds CV_32F matrices.  The map only depends on (K, D, size) and is cached.
 class Undistorter {
   public:
@@ -278,7 +278,10 @@ class Undistorter {
                 const double kr = 1 + ((0.0 * r2 + k2) * r2 + k1) * r2;
                 const double xd = x * kr + p1 * xy2 + p2 * (r2 + 2 * x2);
                 const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * xy2;
-                const long long iu = std::llrint((fx * xd + cx) * 32.0), iv = std::llrint((fy * yd + cy) * 32.0);
+                // the source position passes through float32 before the 1/32-pixel rounding (cvRound(float * 32.f), like
+                // cv::convertMaps): this form -- not the rounding straight from the double -- reproduces the known answers
+                // of the reference's test_feature_track on its two EuRoC frames (oracle/undistort.py)
+                const long long iu = std::lrintf((float)(fx * xd + cx) * 32.0f), iv = std::lrintf((float)(fy * yd + cy) * 32.0f);
                 Entry &e = map_[(size_t)i * w + j];
                 e.sx = (int)(iu >> 5);
                 e.sy = (int)(iv >> 5);
