@@ -38,8 +38,8 @@ frames = 140
 lines = ["# round %d, full pipeline %s (%s)" % (int(rnd[1:]), ver, desc), "",
          "`rocprofv3 --kernel-trace --memory-copy-trace --stats -- python bench.py --steps 100 --warmup 40 --cpu-frames 0 --no-profile` on one MI355X",
          "(gfx950, ROCm 7.2); kernel-trace statistics from the results database.", "",
-         "Total kernel time %.2f ms over %d frames (%.3f ms / frame); default `python bench.py` on the same box: %.1f frames/s, "
-         "%.4f ms/frame, %.4f ms/BA-iteration, CPU reference %.1f frames/s on 1 core (`" + rnd + "_full_%s_bench.json`)." %
+         ("Total kernel time %.2f ms over %d frames (%.3f ms / frame); default `python bench.py` on the same box: %.1f frames/s, "
+          "%.4f ms/frame, %.4f ms/BA-iteration, CPU reference %.1f frames/s on 1 core (`" + rnd + "_full_%s_bench.json`).") %
          (total / 1e6, frames, total / 1e6 / frames, bj["value"], bj["ms_per_step"], bj["ms_per_ba_iteration"],
           bj.get("cpu_baseline", {}).get("value", float("nan")), ver), "",
          "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
@@ -81,3 +81,51 @@ if os.path.isdir(pmc_dir):
 print("\n".join(lines[5:22]))
 print(bj["roofline"])
 print(bj["roofline_lk"])
+
+# MFMA utilisation pass (SQ counters, own run): per kernel the f64 MFMA work the counters saw against the time the kernel
+# took.  SQ_INSTS_VALU_MFMA_MOPS_F64 counts units of 512 flop (a v_mfma_f64_16x16x4_f64 is 4 units);
+# SQ_VALU_MFMA_BUSY_CYCLES are cycles a SIMD's matrix pipe was busy, summed over the chip.
+mf = os.path.join(pmc_dir, "MFMA", "pmc_counter_collection.csv")
+if not os.path.exists(mf):
+    mf = os.path.join(pmc_dir, "MFMA_ALT", "pmc_counter_collection.csv")
+if os.path.exists(mf):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen = set()
+    with open(mf) as f:
+        for r in csv.DictReader(f):
+            n = r["Kernel_Name"].split("(")[0].replace("xrhip::", "")
+            if n.startswith("void "):
+                n = n[5:]
+            agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
+            key = (r["Dispatch_Id"], n)
+            if key not in seen:
+                seen.add(key)
+                agg[n]["_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                agg[n]["_launches"] += 1
+    peaks = {}
+    try:
+        peaks = json.load(open(os.path.join(go, "peaks_%s.json" % tag)))
+        json.dump(peaks, open(os.path.join(ROOT, "profiles", "%s_peaks.json" % rnd), "w"))
+    except (OSError, ValueError):
+        pass
+    pk = peaks.get("mfma_f64_16x16x4_tflops", 78.6)
+    clock_ghz, simds = peaks.get("clock_mhz", 2400) / 1e3, peaks.get("cus", 256) * 4
+    L = ["# round %d: f64 MFMA utilisation per kernel (%s)" % (int(rnd[1:]), ver), "",
+         "`rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace` (own pass, no other",
+         "trace domain) of `python bench.py --steps 60 --warmup 40 --cpu-frames 0 --no-profile`.  flop = MOPS_F64 x 512; TFLOP/s = flop / kernel",
+         "duration of the same pass; `of peak` against the f64 MFMA micro-kernel measured on the same box (%.1f TFLOP/s, `tools/peaks.hip`;" % pk,
+         "vendor figure 78.6); `pipe busy` = SQ_VALU_MFMA_BUSY_CYCLES / (duration x %.1f GHz x %d SIMDs)." % (clock_ghz, simds), "",
+         "| kernel | launches | avg us | MFMA flop / launch | TFLOP/s | of measured peak | pipe busy |", "|---|---|---|---|---|---|---|"]
+    out = {}
+    for n, a in sorted(agg.items(), key=lambda x: -x[1].get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0)):
+        mops = a.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
+        if mops <= 0:
+            continue
+        fl, ns, nl = mops * 512.0, a["_ns"], a["_launches"]
+        tf = fl / ns / 1e3
+        busy = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (ns * clock_ghz * simds)
+        out[n] = {"launches": int(nl), "avg_us": round(ns / nl / 1e3, 2), "mfma_flop_per_launch": round(fl / nl, 1),
+                  "tflops": round(tf, 5), "frac_of_measured_peak": round(tf / pk, 7), "pipe_busy": round(busy, 7)}
+        L.append("| `%s` | %d | %.2f | %.3g | %.4f | %.2e | %.2e |" % (n, nl, ns / nl / 1e3, fl / nl, tf, tf / pk, busy))
+    open(os.path.join(ROOT, "profiles", "%s_mfma_util_%s.md" % (rnd, ver)), "w").write("\n".join(L) + "\n")
+    json.dump(out, open(os.path.join(ROOT, "profiles", "%s_mfma_util.json" % rnd), "w"), indent=1)

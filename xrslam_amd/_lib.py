@@ -22,12 +22,10 @@ class XrhipError(RuntimeError):
         self.code = code
 
 
-def build(force=False):
-    """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.check_call([os.path.join(_HERE, "csrc", "build.sh")])
-    else:
-        subprocess.check_call([os.path.join(_HERE, "csrc", "build.sh")])
+def build():
+    """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU).  build.sh is incremental: it recompiles
+    only the translation units whose sources or headers are newer than their objects."""
+    subprocess.check_call([os.path.join(_HERE, "csrc", "build.sh")])
     return LIB_PATH
 
 

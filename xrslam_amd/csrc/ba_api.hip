@@ -450,12 +450,14 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
         }
         XR_HIP(hipEventRecord(e0, s));
     }
-    if (d.M + d.MR <= 640 && d.na <= 64)
-        hipLaunchKernelGGL(kb_solve_try<256>, dim3(1), dim3(256), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
+    if (wide_first(d))
+        hipLaunchKernelGGL((kb_solve_try<512, true>), dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq, 2);
+    else if (d.M + d.MR <= 640 && d.na <= 64)
+        hipLaunchKernelGGL((kb_solve_try<256, false>), dim3(1), dim3(256), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
                            wide_trials(d) ? 1 : 0);
     else
-        hipLaunchKernelGGL(kb_solve_try<512>, dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
-                           wide_first(d) ? 2 : (wide_trials(d) ? 1 : 0));
+        hipLaunchKernelGGL((kb_solve_try<512, false>), dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
+                           wide_trials(d) ? 1 : 0);
     XR_HIP(hipGetLastError());
     if (wide_first(d)) {   // the first trial batch rides right behind the solve: no host round trip in between
         const size_t wlds = sizeof(double) * (size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np);
@@ -540,8 +542,9 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
     XR_HIP(hipHostMalloc(&c->h_ctl, sizeof(BaCtl), hipHostMallocDefault));
     XR_HIP(hipHostMalloc(&c->h_seq, 64, hipHostMallocDefault));
     *c->h_seq = 0;
-    XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<512>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
-    XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<256>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+    XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+    XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+    XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_chol, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     // pre-size for the advertised maxima
@@ -839,6 +842,7 @@ static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     if (rc) return rc;
     d.robust = 0;
     const int N = d.n, R = N - 15;
+    if (R > 512) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: window too large");   // before anything is queued
     const size_t D8 = sizeof(double);
     size_t w = 0;
     auto carve = [&](size_t bytes) {
@@ -872,7 +876,6 @@ static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     double *hs = (double *)c->h_stage;
     int *dsup = (int *)(W2 + o_sup), *dsn = dst + 1;
     double *As = (double *)(W2 + o_As), *bs = (double *)(W2 + o_bs), *Ss = (double *)(W2 + o_Ss), *ivs = (double *)(W2 + o_ivs);
-    if (R > 512) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: window too large");
     const int lds_doubles = c->lds_limit / (int)D8;
     hipLaunchKernelGGL(km_support, dim3(1), dim3(512), 0, s, R, A, bp, dsup, dsn, As, bs);
     // fast path: Cholesky factor of the compacted matrix as sqrt_info (valid when no eigenvalue is near the 1e-8 floor)
@@ -964,7 +967,12 @@ int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *s
                                 const double *noise_cov36, int compute_jacobian, int compute_covariance) {
     if (!c || !samples || !sample_begin || !sample_count || !t_end || !bg || !ba || !noise_cov36 || n_jobs <= 0)
         return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: bad arguments");
-    if (c->preint_pending) return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate_begin: a batch is already in flight");
+    if (c->preint_pending) {
+        // a batch nobody collected (its owner unwound on an error between begin and end): the staging block it writes
+        // to is about to be reused, so wait for its kernel and forget it instead of refusing every later frame
+        XR_HIP(hipStreamSynchronize(c->stream));
+        c->preint_pending = 0;
+    }
     int total = 0;
     for (int k = 0; k < n_jobs; ++k) {
         if (sample_count[k] <= 0 || sample_begin[k] < 0) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: empty IMU segment");

@@ -82,12 +82,10 @@ struct BaDims {
 
 // Pointers of the argument blocks.  Kernels that receive BaPtrs by value see global-address-space pointers (the
 // compiler knows that kernel arguments point to global memory); kb_tiny reads its argument block from device memory
-// and got generic pointers -- every access a FLAT instruction, which counts against vmcnt AND lgkmcnt, so a wait for
-// a cross-lane shuffle also waits for all loads in flight (ISA of v17: 1217 flat_load/flat_store in kb_tiny, 0 global).
-// With -DXRHIP_GLOBAL_PTRS the members are wrappers around address-space-1 pointers, from
-// which the compiler infers global loads / stores everywhere; without it they are plain pointers (the default build:
-// the variant could not be timed on a GPU in round 1).
-#ifdef XRHIP_GLOBAL_PTRS
+// and would get generic pointers -- every access a FLAT instruction, which counts against vmcnt AND lgkmcnt, so a wait
+// for a cross-lane shuffle also waits for all loads in flight (1217 flat_load/flat_store in kb_tiny, 0 global).
+// The members are therefore wrappers around address-space-1 pointers, from which the compiler infers global loads /
+// stores everywhere (A/B on MI355X, profiles/r02_ab_variants.md: localize_newframe 0.180 -> 0.173 ms per frame).
 template <class T> struct gptr {
     // stored WITH its address space: a load of this member yields a global pointer, and the single cast to a generic
     // one below is what address-space inference starts from (a generic -> global -> generic cast pair on a plain
@@ -100,9 +98,6 @@ template <class T> struct gptr {
         return *this;
     }
 };
-#else
-template <class T> using gptr = T *;
-#endif
 
 struct BaPtrs {
     // problem
@@ -158,32 +153,11 @@ XD bool dof_active(const uint8_t *fix, int a) {   // a in [0, 15F)
     return k < 6 ? pose_free(fix[f]) : motion_free(fix[f]);
 }
 
-#ifdef XRHIP_DPP_SUM
-// The partner value of lane (i ^ off) through a DPP move for the butterfly stages that DPP can express -- off 8 is a
-// rotation by 8 inside a row of 16 lanes (row_ror:8), off 2 and 1 are quad permutations -- instead of a round trip over
-// the LDS crossbar (ds_bpermute, two per double).  Same partners, same order of additions: the sums keep their bits.
-template <int CTRL> __device__ __forceinline__ double dpp_move_f64(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ double wave_sum(double v) {
-    v += __shfl_xor(v, 32);
-    v += __shfl_xor(v, 16);
-    v += dpp_move_f64<0x128>(v);   // row_ror:8            == lane ^ 8
-    v += __shfl_xor(v, 4);
-    v += dpp_move_f64<0x4e>(v);    // quad_perm:[2,3,0,1]  == lane ^ 2
-    v += dpp_move_f64<0xb1>(v);    // quad_perm:[1,0,3,2]  == lane ^ 1
-    return v;
-}
-#else
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
-#endif
 
 // deterministic block-wide sum (fixed tree); scratch must hold blockDim.x/64 doubles
 __device__ __forceinline__ double block_sum(double v, double *scratch) {
@@ -919,7 +893,6 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
     __shared__ int fail;
     BaCtl *c = p.ctl;
     const int n = d.n, na = d.na, tid = threadIdx.x, nt = blockDim.x;
-#ifdef XRHIP_GLOBAL_PTRS
     double *work = lds;                                // LDS work region: the packed triangle, later the gathered frame step
     const double mu = c->mu;
     KPROF_BEGIN();
@@ -928,7 +901,7 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
     // fits, else in Sred.  As ONE pointer (`use_lds ? work : p.Sred`) it is a generic one and every access of the
     // Cholesky / substitution chain becomes a FLAT instruction even when it goes to LDS (ISA of v17: 244 flat_load /
     // flat_store in kb_solve_try); here the stage is instantiated once per memory, so the LDS instance reads and
-    // writes with ds_* instructions (the #else branch is the default build's text, one generic pointer).  Returns false when the factorisation failed.
+    // writes with ds_* instructions.  Returns false when the factorisation failed.
     auto factor_stage = [&](double *A) __attribute__((always_inline)) -> bool {
         double *y = A + tri_idx(na, 0);                    // [na] rhs -> L^-1 rhs (by the factorisation) -> solution
         for (int i = tid; i < na; i += nt) {   // rhs = sp (gp - W^T (omega gl)); the product comes from kb_solve_aux
@@ -979,55 +952,6 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
     } else {
         if (!factor_stage(static_cast<double *>(p.Sred))) return;
     }
-#else
-    double *work = lds;                                // LDS work region: the packed triangle, later the gathered frame step
-    double *A = use_lds ? work : p.Sred;               // packed lower triangle (compact) + the rhs as its row `na`
-    double *y = A + tri_idx(na, 0);                    // [na] rhs -> L^-1 rhs (by the factorisation) -> solution
-    const double mu = c->mu;
-    KPROF_BEGIN();
-    for (int i = tid; i < na; i += nt) {   // rhs = sp (gp - W^T (omega gl)); the product comes from kb_solve_aux
-        const int a = p.act_idx[i];
-        const int fa = a / 15, ka = a - 15 * fa;
-        const double sacc = (d.nla && ka < 6) ? p.wog[6 * fa + ka] : 0.0;
-        y[i] = (p.gp[a] - sacc) * p.sp[a];
-    }
-    __syncthreads();
-    KPROF(0);
-    // ---- S = sp (Hpp - T) sp + mu D^2 over the free dofs was written by kb_schur_aux as a packed triangle in Sred
-    if (use_lds)
-        for (int e = tid; e < na * (na + 1) / 2; e += nt) A[e] = p.Sred[e];
-    __syncthreads();
-    KPROF(1);
-#ifdef XRHIP_KPROF
-    const bool ok = chol_blocked(A, na, na + 1, Dblk, &fail, p.ctl->prof + 24);   // the rhs row rides along
-#else
-    const bool ok = chol_blocked(A, na, na + 1, Dblk, &fail);
-#endif
-    KPROF(2);
-    if (!ok) {
-        if (tid == 0) c->linear_ok = 0;
-        return;
-    }
-    KPROF(3);
-    trsv_lower_t(A, na, y);
-    KPROF(4);
-    // ---- Gauss-Newton step (scaled space), landmark back-substitution, dogleg gradient
-    for (int a = tid; a < n; a += nt) {
-        p.gn[a] = 0.0;
-        p.grad[a] = dof_active(p.fix, a) ? p.gs[a] / p.diagD[a] : 0.0;
-        p.delta[a] = 0.0;   // delta doubles as the full-layout y (frame part) for the back-substitution below
-    }
-    __syncthreads();
-    int bad = 0;
-    for (int i = tid; i < na; i += nt) {
-        const int a = p.act_idx[i];
-        const double ya = y[i];
-        p.gn[a] = -p.diagD[a] * ya;
-        p.delta[a] = ya;
-        if (!isfinite(ya)) bad = 1;
-    }
-    __syncthreads();
-#endif
     if (!d.nla) {   // every landmark is held constant (localize_newframe, refine_subwindow): nothing to back-substitute
         for (int l = tid; l < d.L; l += nt) {
             p.gn[n + l] = 0.0;
@@ -1682,13 +1606,16 @@ __global__ __launch_bounds__(256) void kb_cost_prepare(BaDims d, BaPtrs p) {
 // NT = workgroup size.  The trial code holds whole IMU records and reprojection chains in registers: at 512 threads
 // (256 VGPRs each) it spills ~190 registers to scratch memory, at 256 threads it gets 512 registers and spills
 // nothing -- small problems (one observation per thread either way) run the 256-thread instance.
-template <int NT>
+// PREP = true is the wide_trials == 2 instance: the trial code is not even compiled in, so the factorisation of a
+// window-sized system runs in a 512-thread kernel without the ~190 spilled registers the trial loop costs there.
+template <int NT, bool PREP>
 __global__ __launch_bounds__(NT) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int use_lds,
                                                    int after_linearisation, int seq, int wide_trials) {
     extern __shared__ double lds[];   // max(solve_block's region, try_block's staging)
     solve_block(d, p, use_lds, lds);
     __syncthreads();
-    try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, wide_trials != 0, lds, wide_trials == 2);
+    if (PREP) try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, true, lds, true);
+    else try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, wide_trials != 0, lds, false);
 }
 
 // The rejected-trial tail of a large solve on the whole chip.  After a rejection the next radii are radius/2,

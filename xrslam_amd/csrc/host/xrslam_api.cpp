@@ -58,6 +58,12 @@ int XRSLAMCreate(const char *slam_config_path, const char *device_config_path, c
     int ok = 0;
     m.last_error.clear();   // XRSLAMAmdLastError speaks about the instance being created, not about an earlier one
     guarded([&] {
+        {   // a second Create without Destroy: drop the previous instance first, in XRSLAMDestroy's order -- the pending
+            // image returns its device buffer to the Pipeline that owns it, which must still be alive at that point
+            std::lock_guard<std::mutex> lk(m.input_mutex);
+            m.cur_image.reset();
+            m.sys.reset();
+        }
         m.config = xrh::load_config(slam_config_path, device_config_path);
         m.sys = std::make_unique<xrh::System>(m.config);
         if (config) *config = static_cast<void *>(&m.config);
