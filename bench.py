@@ -2,6 +2,8 @@
 """bench.py -- frames/sec + ms/BA-iteration of the XRSLAM per-frame hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W        (one JSON line on rank 0)
+  python bench.py --workload {s1,s2,s3,s4}             (default s1 == BASELINE config 2; the others are extra lines)
+  python bench.py --sequences-per-gpu S                (S independent sequences on each GPU, one host thread each)
 
 A "step" is one camera frame of one sequence pushed through the whole hot path behind the
 reference's C API (include/XRSLAM.h, the player's call sequence of xrslam-pc/player/src/main.cpp:116-169):
@@ -10,19 +12,28 @@ XRSLAMGetResult.  Inside: CLAHE + LK pyramid + Scharr, IMU pre-integration, forw
 5-pt/2-pt RANSAC gates, Harris re-detection, localize_newframe solve, keyframe policy, landmark
 triangulation, refine_window / refine_subwindow dogleg solves, marginalisation.
 
-Workload (config.workload): synthetic S1 "EuRoC MH_01-like" stream: 752x480 (the
-real EuRoC cam0 size; BASELINE.json's 640x480 is a known discrepancy, SURVEY.md top table), 20 Hz camera /
-200 Hz IMU, 150 features, 10-keyframe window (BASELINE config 2), seeded box-room scene.  The first 36
-frames of a stream only seed the window (initial states supplied from the ground truth, so that every run
+Workloads (config.workload):
+  s1  synthetic "EuRoC MH_01-like" stream: 752x480 (the real EuRoC cam0 size; BASELINE.json's 640x480 is a known
+      discrepancy, SURVEY.md top table), 20 Hz camera / 200 Hz IMU, 150 features, 10-keyframe window (BASELINE config 2)
+  s2  "V1_03-like" stress stream: faster motion, 300 features, 15-keyframe window (BASELINE config 3)
+  s3  1280x720 stream, 600 features, 20-keyframe window (BASELINE config 5)
+  s4  BA micro-bench: the frozen refine_window problems of tests/golden/ba_snapshots/ replayed through xrhip_ba_solve
+      (a "step" is one whole solve; value = solves/s, ms_per_ba_iteration is the figure of interest)
+The first 36 frames of a stream only seed the window (initial states supplied from the ground truth, so that every run
 measures the same steady-state path): they are never timed -- with --warmup W < 40 the missing 40 - W frames
 run as an untimed pre-roll in front of the W warmup steps (config.untimed_preroll_frames).
+`value` is measured with frames resident in HBM; `host_image_path` repeats a bounded number of frames through the
+reference-shaped XRSLAM_SENSOR_CAMERA call (host image, uploaded inside the timed call) on the same stream.
 One independent sequence per GPU: no data-path collective, only a barrier and a MAX
-reduction of the wall time over RCCL.
+reduction of the wall time over RCCL.  --sequences-per-gpu S puts S sequences on every GPU (instance-scoped entry points,
+XRSLAMAmdInstance*): `value` is then the aggregate over all sequences of all GPUs.
 """
 import argparse
+import glob
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -33,8 +44,79 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (MI355X_MICROARCH.md)
-SLAM_YAML = os.path.join(ROOT, "configs", "bench_slam_150.yaml")
-SENSOR_YAML = os.path.join(ROOT, "configs", "euroc_sensor.yaml")
+CFG = os.path.join(ROOT, "configs")
+WORKLOADS = {
+    "s1": dict(slam="bench_slam_150.yaml", sensor="euroc_sensor.yaml", w=752, h=480, K=None, traj=None, features=150, window=10,
+               text="S1 EuRoC-MH_01-like synthetic stream, 752x480 @20 Hz + 200 Hz IMU, 150 features, 10-keyframe window, "
+                    "30-iteration dogleg cap (BASELINE config 2)"),
+    "s2": dict(slam="stress_slam_300.yaml", sensor="euroc_sensor.yaml", w=752, h=480, K=None,
+               traj=dict(amp=1.5, speed=1.0, rot=0.8), features=300, window=15,
+               text="S2 EuRoC-V1_03-like synthetic stress stream (1.5 m/s, 60 deg/s peaks), 752x480 @20 Hz + 200 Hz IMU, "
+                    "300 features, 15-keyframe window (BASELINE config 3)"),
+    "s3": dict(slam="large_slam_600.yaml", sensor="large_sensor_1280.yaml", w=1280, h=720, K=(780.0, 778.0, 640.0, 360.0), traj=None,
+               features=600, window=20,
+               text="S3 synthetic 1280x720 stream @20 Hz + 200 Hz IMU, 600 features, 20-keyframe window (BASELINE config 5)"),
+}
+
+
+def newest_profile(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_extras(kernel_rev):
+    """Measured peaks of the MI355X the profiles were taken on (tools/peaks.hip) and the HBM-side traffic of the
+    committed rocprofv3 --pmc passes -- the latter only when those passes ran the kernels this library carries."""
+    peaks = newest_profile("r*_peaks.json") or {}
+    pmc = newest_profile("r*_pmc_traffic.json") or {}
+    traffic, note = {}, "no committed PMC pass"
+    if pmc:
+        rev = pmc.get("_kernel_rev")
+        if rev == kernel_rev:
+            traffic = {k: round(1024.0 * (v["fetch_kb"] + v["write_kb"]), 1) for k, v in pmc.items() if isinstance(v, dict)}
+            note = "profiles/ PMC passes of kernel revision " + str(rev)
+        else:
+            note = "committed PMC passes are of kernel revision %s, this library is %s: not shown" % (rev, kernel_rev)
+    return peaks, traffic, note
+
+
+def bench_s4(args, out_common):
+    """S4: frozen refine_window problems replayed through the C ABI of plug point #2."""
+    from xrslam_amd import ba
+    from tests import ba_snapshots
+    snaps = ba_snapshots.load_all()
+    if not snaps:
+        raise SystemExit("no BA snapshots under tests/golden/ba_snapshots/")
+    ctx = ba.BaContext(max_frames=32, max_landmarks=2048, max_obs=16384)
+    reps = max(1, args.steps)
+    per = []
+    for name, pd, exp in snaps:
+        for _ in range(max(1, args.warmup // 10)):
+            ctx.solve(pd.copy())
+        t0 = time.perf_counter()
+        it = 0
+        for _ in range(reps):
+            it += ctx.solve(pd.copy()).iterations
+        dt = time.perf_counter() - t0
+        per.append(dict(snapshot=name, frames=len(pd.frame_state), landmarks=len(pd.inv_depth), observations=len(pd.obs_tgt),
+                        iterations_per_solve=it / reps, ms_per_solve=round(1e3 * dt / reps, 4),
+                        ms_per_ba_iteration=round(1e3 * dt / max(1, it), 5)))
+    tot_ms = sum(p["ms_per_solve"] for p in per)
+    out = dict(out_common)
+    out.update({"metric": "BA solves/sec on frozen refine_window snapshots (S4 micro-bench)", "value": round(1e3 * len(per) / tot_ms, 3),
+                "unit": "solves/s", "steps": reps, "warmup": args.warmup, "ms_per_step": round(tot_ms / len(per), 4),
+                "dtype": "f64 BA", "data": "frozen problems dumped from the synthetic S1/S2/S3 streams (tests/golden/ba_snapshots)",
+                "config": {"workload": "S4 frozen refine_window snapshots replayed through xrhip_ba_solve", "snapshots": len(per)},
+                "ms_per_ba_iteration": round(sum(p["ms_per_ba_iteration"] * p["iterations_per_solve"] for p in per) /
+                                             max(1e-9, sum(p["iterations_per_solve"] for p in per)), 5),
+                "snapshots": per})
+    print(json.dumps(out))
 
 
 def main():
@@ -42,14 +124,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="s1", choices=["s1", "s2", "s3", "s4"])
+    ap.add_argument("--sequences-per-gpu", type=int, default=1,
+                    help="independent sequences per GPU, one host thread each (instance-scoped entry points)")
     ap.add_argument("--cpu-frames", type=int, default=240,
                     help="frames of the bounded CPU-reference sample (0 = skip); the first 36 only seed the window")
+    ap.add_argument("--host-frames", type=int, default=60,
+                    help="frames of the extra leg through the reference-shaped host-image call (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the KLT kernels")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl == RCCL); 'gloo' lets two "
                     "ranks share one GPU when the multi-process path is exercised on a single-GPU box")
     args = ap.parse_args()
-    if args.steps < 1 or args.warmup < 0:
-        raise SystemExit("--steps must be >= 1 and --warmup >= 0")
+    if args.steps < 1 or args.warmup < 0 or args.sequences_per_gpu < 1:
+        raise SystemExit("--steps must be >= 1, --warmup >= 0, --sequences-per-gpu >= 1")
+    S = args.sequences_per_gpu
+    if S > 1:   # every instance owns four HIP streams; the runtime multiplexes streams over this many hardware queues
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(4 * S, 24)))
     # the first 36 frames of a stream only seed the sliding window (no pose, no solve): they never fall into the timed
     # region -- a warmup shorter than 40 steps is preceded by the missing frames as an untimed pre-roll
     preroll = max(0, 40 - args.warmup)
@@ -60,46 +150,94 @@ def main():
     from xrslam_amd import _lib
     from xrslam_amd.harness import runner, scene
     from xrslam_amd.harness.dist import RunGroup
+    from xrslam_amd.harness.trajectory import Trajectory
     device_index = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()   # == LOCAL_RANK on a full node
     torch.cuda.set_device(device_index)
     group = RunGroup(backend=args.backend)  # one process per GPU; "nccl" == RCCL over xGMI
-    rank, local_rank, world = group.rank, group.local_rank, group.world
+    rank, world = group.rank, group.world
     _lib.set_device(device_index)
+    kernel_rev = _lib.kernel_revision()
+    peaks, traffic, traffic_note = roofline_extras(kernel_rev)
+    common = {"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "kernel_rev": kernel_rev}
 
-    n_frames = preroll + args.warmup + args.steps
-    seq = scene.make_sequence(n_frames=n_frames + 1, seed=1 + rank)
-    dev = torch.from_numpy(seq["frames"]).cuda()     # inputs resident in HBM before the timed region
+    if args.workload == "s4":
+        if rank == 0:
+            bench_s4(args, common)
+        group.close()
+        return
+
+    wl = WORKLOADS[args.workload]
+    slam_yaml, sensor_yaml = os.path.join(CFG, wl["slam"]), os.path.join(CFG, wl["sensor"])
+    host_frames = args.host_frames if (S == 1 and world == 1) else 0
+    n_frames = preroll + args.warmup + args.steps + host_frames
+    seq_kw = dict(w=wl["w"], h=wl["h"])
+    if wl["K"]:
+        seq_kw["K"] = wl["K"]
+    sessions, keep = [], []
+    for i in range(S):
+        kw = dict(seq_kw)
+        if wl["traj"]:
+            kw["traj"] = Trajectory(**wl["traj"])
+        seq = scene.make_sequence(n_frames=n_frames + 1, seed=1 + rank * S + i, **kw)
+        dev = torch.from_numpy(seq["frames"]).cuda()     # inputs resident in HBM before the timed region
+        keep.append(dev)
+        h, w = seq["frames"].shape[1:]
+        sessions.append(runner.Session(_lib.LIB_PATH, seq, slam_yaml=slam_yaml, sensor_yaml=sensor_yaml,
+                                       device_frames=(dev.data_ptr(), h * w, w), instance=(S > 1)))
     torch.cuda.synchronize()
-    h, w = seq["frames"].shape[1:]
-    sess = runner.Session(_lib.LIB_PATH, seq, slam_yaml=SLAM_YAML, sensor_yaml=SENSOR_YAML,
-                          device_frames=(dev.data_ptr(), h * w, w))
+    sess, seq = sessions[0], sessions[0].seq
 
     def barrier():
         group.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(preroll + args.warmup):
-        sess.step()
-    if sess.error():
-        raise SystemExit("warmup failed: " + sess.error())
+    def run_all(n):
+        """n frames on every session: inline for one, one host thread per sequence otherwise (the foreign calls release
+        the interpreter lock, so the sequences' host work and device waits overlap)."""
+        if S == 1:
+            for _ in range(n):
+                sess.step()
+            return
+        errs = []
+
+        def work(s):
+            try:
+                for _ in range(n):
+                    s.step()
+            except Exception as e:   # noqa: BLE001
+                errs.append(repr(e))
+        th = [threading.Thread(target=work, args=(s,)) for s in sessions]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise SystemExit("sequence thread failed: " + errs[0])
+
+    run_all(preroll + args.warmup)
+    for s in sessions:
+        if s.error():
+            raise SystemExit("warmup failed: " + s.error())
     t_w = sess.times()
-    sess.klt_stats(reset=True)
-    sess.ba_stats(reset=True)
-    if not args.no_profile:
-        sess.set_profiling(True)
+    for s in sessions:
+        s.klt_stats(reset=True)
+        s.ba_stats(reset=True)
+        if not args.no_profile:
+            s.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sess.step()
+    run_all(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if sess.error():
-        raise SystemExit("timed region failed: " + sess.error())
+    for s in sessions:
+        if s.error():
+            raise SystemExit("timed region failed: " + s.error())
     t_e = sess.times()
     st = sess.klt_stats(reset=False)
     bst = sess.ba_stats(reset=False)
-    sess.set_profiling(False)
-    red = group.reduce_metrics(args.steps, elapsed)      # frames: SUM, wall seconds: MAX over ranks
+    for s in sessions:
+        s.set_profiling(False)
+    red = group.reduce_metrics(args.steps * S, elapsed)      # frames: SUM, wall seconds: MAX over ranks
     elapsed, total_frames = red["seconds"], red["frames"]
 
     if rank == 0:
@@ -112,32 +250,20 @@ def main():
         lk_ms = st.ms_track / n_launch
         achieved = (lk_bytes / n_launch) / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
         ba_tflops = bst.flops_solve_try / (bst.ms_solve_try * 1e-3) / 1e12 if bst.ms_solve_try > 0 else 0.0
-        # HBM-side bytes per launch: PMC counters cannot be read in-process; they come from the committed rocprofv3
-        # --pmc passes of this same command (profiles/r*_pmc_traffic.md says how they were collected)
-        traffic = {}
-        try:
-            import glob
-            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as fh:   # newest round
-                pmc = json.load(fh)
-            traffic = {k: round(1024.0 * (v["fetch_kb"] + v["write_kb"]), 1) for k, v in pmc.items()}
-        except (OSError, ValueError, KeyError, IndexError):
-            pass
-        out = {
-            "metric": "frames/sec, full per-frame hot path (KLT tracker + sliding-window VI-BA), one sequence per GPU",
+        hbm_meas, mfma_meas = peaks.get("stream_read_gbs"), peaks.get("mfma_f64_16x16x4_tflops")
+        out = dict(common)
+        out.update({
+            "metric": "frames/sec, full per-frame hot path (KLT tracker + sliding-window VI-BA), %s per GPU"
+                      % ("one sequence" if S == 1 else "%d sequences" % S),
             "value": round(total_frames / elapsed, 3),
             "unit": "frames/s",
-            "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
             "dtype": "u8/i16 images, f32 LK with exact i64 reductions, f64 BA",
             "data": "synthetic",
-            "config": {"workload": "S1 EuRoC-MH_01-like synthetic stream, 752x480 @20 Hz + 200 Hz IMU, 150 features, "
-                                   "10-keyframe window, 30-iteration dogleg cap (BASELINE config 2)",
-                       "features": 150, "window_keyframes": 10, "sequences_per_gpu": 1, "untimed_preroll_frames": preroll},
+            "config": {"workload": wl["text"], "features": wl["features"], "window_keyframes": wl["window"],
+                       "sequences_per_gpu": S, "untimed_preroll_frames": preroll},
             "ms_per_ba_iteration": round(ba_ms / iters, 4),
             "ba": {"solves_per_frame": round(solves / args.steps, 3), "iterations_per_solve": round(iters / solves, 2),
                    "device_ms_per_solve": round(ba_ms / solves, 4),
@@ -154,26 +280,42 @@ def main():
                  "track_landmark", "refine_window", "slide_window", "refine_subwindow"),
                 [round(1e3 * (t_e.wall_scope[i] - t_w.wall_scope[i]) / args.steps, 4) for i in range(11)])),
             "ate_rmse_m": (lambda a: round(a, 5) if a == a else None)(runner.ate_rmse(poses, seq)),   # None with < 3 poses
-            # dominant kernel by total time (profiles/): kb_solve_try = reduced-system Cholesky (f64 MFMA trailing
-            # updates) + trust-region trial costing, one workgroup per launch; flops = algorithmic
+            # dominant single kernel by total time (profiles/): kb_solve_try = reduced-system Cholesky (f64 MFMA trailing
+            # updates) [+ trust-region trial costing for small problems], one workgroup per launch; flops = algorithmic
+            # (DESIGN.md 4.2); launch_us = HIP events around that kernel alone on the BA stream
             "roofline": {"kernel": "kb_solve_try", "bound": "mfma", "achieved": round(ba_tflops, 6),
                          "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ba_tflops / F64_MFMA_PEAK_TFLOPS, 8),
                          "traffic": traffic.get("kb_solve_try"),
+                         "peak_measured": mfma_meas, "frac_of_measured": round(ba_tflops / mfma_meas, 8) if mfma_meas else None,
                          "algorithmic_flops_per_launch": round(bst.flops_solve_try / max(1, bst.n_timed), 1),
                          "launch_us": round(1e3 * bst.ms_solve_try / max(1, bst.n_timed), 3),
                          "launches": int(bst.n_timed), "trials": int(bst.n_trials)},
             "roofline_lk": {"kernel": "k_lk_track", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic.get("k_lk_track"),
+                            "peak_measured": hbm_meas, "frac_of_measured": round(achieved / hbm_meas, 6) if hbm_meas else None,
                             "algorithmic_bytes_per_launch": round(lk_bytes / n_launch, 1),
                             "launch_us": round(lk_ms * 1e3, 3)},
-        }
+            "traffic_source": traffic_note,
+        })
         if os.environ.get("XRSLAM_HIP_LIB"):      # instrumented build variant: report its in-kernel phase timers
             import ctypes
             buf = (ctypes.c_longlong * 32)()
             ctypes.CDLL(_lib.LIB_PATH).xrhip_debug_kprof(buf, 0)
             out["kprof_ms"] = [round(v / 1e5, 3) for v in buf]    # 100 MHz ticks -> ms (whole run incl. warmup)
-            out["kprof_ms"][19] = int(buf[19])                    # slot 19 counts trust-region trials
-        if args.cpu_frames > 40 and world == 1:
+            for slot in (19, 27, 31):                             # counters: trust-region trials, single-launch rounds, solves
+                out["kprof_ms"][slot] = int(buf[slot])
+        if host_frames > 0:
+            # the reference-shaped call: XRSLAMPushSensorData(XRSLAM_SENSOR_CAMERA) deep-copies a HOST image
+            # (XRSLAMManager.cpp:113-131); here that is the upload, inside the timed call, on the same stream
+            sess.device_frames = None
+            h0 = time.perf_counter()
+            for _ in range(host_frames):
+                sess.step()
+            torch.cuda.synchronize()
+            ht = time.perf_counter() - h0
+            out["host_image_path"] = {"value": round(host_frames / ht, 3), "unit": "frames/s", "frames": host_frames,
+                                      "note": "same stream continued through XRSLAM_SENSOR_CAMERA (host image, PCIe upload inside the call)"}
+        if args.cpu_frames > 40 and world == 1 and S == 1:
             import subprocess
             ref_lib = os.path.join(ROOT, "oracle", "_build", "libxrslam_oracle.so")
             if not os.path.exists(ref_lib):
@@ -183,7 +325,7 @@ def main():
             def cpu_leg(threads):
                 # XR_ORACLE_THREADS is read when the session creates its KLT context (oracle/xrhip_shim.cpp)
                 os.environ["XR_ORACLE_THREADS"] = str(threads)
-                cpu = runner.Session(ref_lib, seq, slam_yaml=SLAM_YAML, sensor_yaml=SENSOR_YAML)
+                cpu = runner.Session(ref_lib, seq, slam_yaml=slam_yaml, sensor_yaml=sensor_yaml)
                 for _ in range(40):
                     cpu.step()
                 c0 = time.perf_counter()
@@ -194,7 +336,7 @@ def main():
                 return round((nc - 40) / ct, 3)
 
             sample = ("frames 40..%d of the same stream through the same host pipeline linked against the CPU oracle "
-                      "(oracle/_build/libxrslam_oracle.so, gcc -O2)" % nc)
+                      "(oracle/_build/libxrslam_oracle.so, gcc -O2; our restatement, not the XRSLAM binary)" % nc)
             # the reference-faithful figure: solver num_threads = 1 (estimation/solver.cpp:185), image loops on one core
             out["cpu_baseline"] = {"value": cpu_leg(1), "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": sample + ", single thread"}
@@ -205,7 +347,8 @@ def main():
                 out["cpu_baseline_mt"] = {"value": cpu_leg(cores), "unit": "frames/s", "cores": cores, "kind": "port",
                                           "sample": sample + ", image and LK point loops on %d OpenMP threads" % cores}
         print(json.dumps(out))
-    sess.close()
+    for s in sessions:
+        s.close()
     group.close()
 
 

@@ -9,7 +9,8 @@
  *
  * Differences, all additive:
  *   - the XRSLAMAmd* entry points at the bottom (optional externally supplied initial
- *     states, device-resident images, stage timers, initialiser report);
+ *     states, device-resident images, stage timers, initialiser report), and their
+ *     XRSLAMAmdInstance* forms for several sequences per process;
  *   - XRSLAMFeatures is declared for C++ only, like the reference (it holds a std::vector).
  */
 #ifndef XRSLAM_AMD_XRSLAM_H
@@ -179,6 +180,31 @@ typedef struct XRSLAMAmdInitReport {
 void XRSLAMAmdGetInitReport(XRSLAMAmdInitReport *out);
 /* last error raised inside the library ("" if none); the reference aborts/throws instead */
 const char *XRSLAMAmdLastError(void);
+
+/* ---- instance-scoped entry points (additive) ----
+ * The six reference symbols above act on one process-global instance, like the reference's XRSLAMManager singleton
+ * (xrslam-interface/src/XRSLAMManager.cpp:6-9).  The reference cannot do otherwise -- solver configuration, CLAHE /
+ * GFTT objects, id counters and the RD-VIO bin confidences are function- or class-level statics there --
+ * here all of that state lives in the instance, so one process can run several independent sequences on one GPU
+ * (each instance owns its HIP streams; kernels of different instances overlap on the device).  Same semantics as the
+ * global entry points, with the instance as first argument.  One thread at a time per instance; different instances
+ * may be driven from different threads.  An instance belongs to the HIP device that was current when it was created. */
+typedef struct XRSLAMAmdInstance XRSLAMAmdInstance;
+int XRSLAMAmdInstanceCreate(const char *slam_config_path, const char *device_config_path, XRSLAMAmdInstance **out,
+                            void **config);
+void XRSLAMAmdInstanceDestroy(XRSLAMAmdInstance *inst);
+void XRSLAMAmdInstancePushSensorData(XRSLAMAmdInstance *inst, XRSLAMSensorType sensor_type, void *sensor_data);
+void XRSLAMAmdInstanceRunOneFrame(XRSLAMAmdInstance *inst);
+void XRSLAMAmdInstanceGetResult(XRSLAMAmdInstance *inst, XRSLAMResultType result_type, void *result_data);
+void XRSLAMAmdInstanceSetInitialState(XRSLAMAmdInstance *inst, double t, const double q[4], const double p[3],
+                                      const double v[3], const double bg[3], const double ba[3]);
+void XRSLAMAmdInstancePushImageDevice(XRSLAMAmdInstance *inst, const void *gray_dev, int stride, double timestamp);
+void XRSLAMAmdInstanceGetTimes(XRSLAMAmdInstance *inst, XRSLAMAmdTimes *out);
+void XRSLAMAmdInstanceSetProfiling(XRSLAMAmdInstance *inst, int enable);
+void XRSLAMAmdInstanceGetBaStats(XRSLAMAmdInstance *inst, void *xrhip_ba_stats_out, int reset);
+void XRSLAMAmdInstanceGetKltStats(XRSLAMAmdInstance *inst, void *xrhip_klt_stats_out, int reset);
+void XRSLAMAmdInstanceGetInitReport(XRSLAMAmdInstance *inst, XRSLAMAmdInitReport *out);
+const char *XRSLAMAmdInstanceLastError(XRSLAMAmdInstance *inst);
 
 #ifdef __cplusplus
 }

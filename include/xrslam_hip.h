@@ -39,10 +39,16 @@ extern "C" {
 #define XRHIP_ESTATE (-6)
 
 const char *xrhip_last_error(void);
+/* identifies the device code this library was built from (hash of the kernel sources) */
+const char *xrhip_kernel_revision(void);
 /* number of usable gfx950 devices (0 if none); never fails */
 int xrhip_device_count(void);
 /* binds the calling thread (and contexts created afterwards) to a device */
 int xrhip_set_device(int device);
+/* the calling thread's current device / make `device` current for the calling thread without re-validating it
+ * (the current device is a per-thread setting: a thread that drives a context created elsewhere binds first) */
+int xrhip_get_device(int *device);
+int xrhip_bind_device(int device);
 
 /* ------------------------------------------------------------------------
  * Plug point #1: KLT front-end.

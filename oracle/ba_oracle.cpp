@@ -693,7 +693,27 @@ struct Dogleg {
 
 extern "C" {
 
+// Optional per-iteration record of the last orc_ba_solve_trace call (regression pin of the minimiser's decisions,
+// tests/golden/ba_snapshots): rows of {iteration, x_cost, candidate cost, model cost change, relative decrease,
+// radius before the decision, |step|, mu, accepted}.
+static double *g_trace = nullptr;
+static int g_trace_cap = 0, g_trace_rows = 0;
+static int orc_ba_solve_impl(const xrhip_ba_problem *P, xrhip_ba_summary *summary);
 int orc_ba_solve(const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
+    g_trace = nullptr;
+    g_trace_cap = g_trace_rows = 0;
+    return orc_ba_solve_impl(P, summary);
+}
+int orc_ba_solve_trace(const xrhip_ba_problem *P, xrhip_ba_summary *summary, double *trace9, int max_rows, int *rows) {
+    g_trace = trace9;
+    g_trace_cap = max_rows;
+    g_trace_rows = 0;
+    const int rc = orc_ba_solve_impl(P, summary);
+    if (rows) *rows = g_trace_rows;
+    g_trace = nullptr;
+    return rc;
+}
+static int orc_ba_solve_impl(const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
     Problem pb;
     init_problem(pb, P);
     const int n = pb.n_local;
@@ -898,6 +918,11 @@ int orc_ba_solve(const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
         if (std::getenv("ORC_BA_TRACE"))
             std::fprintf(stderr, "it %2d cost %.9e cand %.9e model %.3e rho %.3f radius %.3e |step| %.3e mu %.1e\n",
                          iteration, x_cost, cand_cost, model_cost_change, relative_decrease, dl.radius, step_l2, dl.mu);
+        if (g_trace && g_trace_rows < g_trace_cap) {
+            double *row = g_trace + 9 * (g_trace_rows++);
+            row[0] = iteration; row[1] = x_cost; row[2] = cand_cost; row[3] = model_cost_change; row[4] = relative_decrease;
+            row[5] = dl.radius; row[6] = step_l2; row[7] = dl.mu; row[8] = relative_decrease > min_relative_decrease ? 1.0 : 0.0;
+        }
         if (relative_decrease > min_relative_decrease) {
             // HandleSuccessfulStep
             x = cand;

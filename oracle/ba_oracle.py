@@ -39,6 +39,18 @@ def solve(pd):
     return sm
 
 
+def solve_trace(pd, max_rows=256):
+    """Like solve(); also returns the per-iteration record [rows][9] = {iteration, x_cost, candidate cost, model cost
+    change, relative decrease, radius, |step|, mu, accepted} of the trials that reached the accept / reject decision."""
+    s = pd.struct()
+    sm = abi.BaSummary()
+    tr = np.zeros((max_rows, 9))
+    rows = C.c_int()
+    rc = lib().orc_ba_solve_trace(C.byref(s), C.byref(sm), _p(tr), max_rows, C.byref(rows))
+    assert rc == 0
+    return sm, tr[:rows.value].copy()
+
+
 def linearize(pd, want_H=True):
     s = pd.struct()
     nf, nl = len(pd.frame_state), len(pd.inv_depth)

@@ -53,6 +53,12 @@ extern "C" {
 const char *xrhip_last_error(void) { return g_err.c_str(); }
 int xrhip_device_count(void) { return 0; }
 int xrhip_set_device(int) { return 0; }
+int xrhip_get_device(int *device) {
+    if (device) *device = 0;
+    return 0;
+}
+int xrhip_bind_device(int) { return 0; }
+const char *xrhip_kernel_revision(void) { return "cpu-oracle"; }
 
 int xrhip_klt_create(int width, int height, int, xrhip_klt **out) {
     // XR_ORACLE_THREADS: threads of the image / point loops (OpenCV's parallel_for_ in the reference); the solver stays

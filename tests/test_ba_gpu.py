@@ -191,6 +191,33 @@ def test_config5_sized_window(ctx, bo):
     assert sm_h.final_cost < sm_h.initial_cost
 
 
+def test_pipeline_snapshots_match_golden(ctx):
+    """SURVEY.md 8d "S4": the frozen problems the pipeline assembled on the S1 / S2 / S3 streams (localize_newframe,
+    refine_subwindow, refine_window with prior; tests/golden/ba_snapshots, made by tests/golden/make_ba_snapshots.py)
+    against the oracle's committed result -- iteration count, accepted steps, termination, costs and final states.  Unlike
+    the oracle-vs-GPU tests above, the expected values here are files: an edit of the oracle that shifts an accept / reject
+    decision shows up in tests/test_oracle_ba.py, an edit of the kernels here."""
+    from tests import ba_snapshots
+    snaps = ba_snapshots.load_all()
+    assert len(snaps) >= 5
+    for name, pd, exp in snaps:
+        b = pd.copy()
+        sm = ctx.solve(b)
+        ok = (sm.iterations == int(exp["iterations"]) and sm.successful_steps == int(exp["successful_steps"]) and
+              np.allclose(b.frame_state, exp["frame_state"], rtol=1e-6, atol=1e-9))
+        if not ok:
+            _dump("ba_snapshot_mismatch_" + name, sh=b.frame_state, so=exp["frame_state"], dh=b.inv_depth, do=exp["inv_depth"],
+                  meta=np.array([sm.iterations, int(exp["iterations"]), sm.successful_steps, int(exp["successful_steps"]),
+                                 sm.termination, int(exp["termination"]), sm.final_cost, float(exp["final_cost"])]))
+        assert sm.iterations == int(exp["iterations"]), name
+        assert sm.successful_steps == int(exp["successful_steps"]), name
+        assert sm.termination == int(exp["termination"]), name
+        assert abs(sm.initial_cost - float(exp["initial_cost"])) <= 1e-9 * float(exp["initial_cost"]), name
+        assert abs(sm.final_cost - float(exp["final_cost"])) <= 1e-8 * float(exp["final_cost"]), name
+        np.testing.assert_allclose(b.frame_state, exp["frame_state"], rtol=1e-6, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(b.inv_depth, exp["inv_depth"], rtol=1e-6, atol=1e-9, err_msg=name)
+
+
 def _marg_problem(pd, victim=0):
     seen = set(pd.obs_lm[(pd.obs_ref == victim) | (pd.obs_tgt == victim)])
     sel = np.array([l in seen for l in pd.obs_lm])

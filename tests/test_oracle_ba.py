@@ -381,3 +381,29 @@ def test_se3_cost_function_pattern():
         assert np.abs(r).max() < 1e-12          # an exact fit exists (6 dof, 3 residuals)
         assert abs(np.linalg.norm(q) - 1.0) < 1e-15
         assert err < 2.0e-6
+
+
+def test_pipeline_snapshots_regression():
+    """Regression pin of the oracle's minimiser on the frozen problems of tests/golden/ba_snapshots (SURVEY.md 8d "S4";
+    tests/golden/make_ba_snapshots.py): iteration count, accepted steps, termination, the per-iteration record (costs,
+    model cost change, radius, accept / reject) and the final states must stay what they were when the fixtures were
+    made.  The reference holds no golden vectors for this boundary (parity unpinned); this pins the
+    oracle to ITSELF so that an edit which shifts a decision cannot pass unnoticed just because the GPU follows it."""
+    from tests import ba_snapshots
+    snaps = ba_snapshots.load_all()
+    assert len(snaps) >= 5
+    kinds = set()
+    for name, pd, exp in snaps:
+        kinds.add(name.split("_")[1])
+        a = pd.copy()
+        sm, trace = bo.solve_trace(a)
+        assert sm.iterations == int(exp["iterations"]) and sm.successful_steps == int(exp["successful_steps"]), name
+        assert sm.termination == int(exp["termination"]), name
+        np.testing.assert_allclose(sm.initial_cost, float(exp["initial_cost"]), rtol=1e-12, err_msg=name)
+        np.testing.assert_allclose(sm.final_cost, float(exp["final_cost"]), rtol=1e-10, err_msg=name)
+        assert trace.shape == exp["trace"].shape, name
+        np.testing.assert_array_equal(trace[:, [0, 8]], exp["trace"][:, [0, 8]], err_msg=name)        # iteration, accepted
+        np.testing.assert_allclose(trace[:, [1, 2, 5, 7]], exp["trace"][:, [1, 2, 5, 7]], rtol=1e-9, err_msg=name)   # costs, radius, mu
+        np.testing.assert_allclose(a.frame_state, exp["frame_state"], rtol=1e-9, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(a.inv_depth, exp["inv_depth"], rtol=1e-9, atol=1e-12, err_msg=name)
+    assert kinds == {"localize", "subwindow", "window"}

@@ -77,6 +77,7 @@ if os.path.isdir(pmc_dir):
         out[n] = {"launches": f[1], "fetch_kb": round(fk, 2), "write_kb": round(wk, 2)}
         head += "| `%s` | %d | %.1f | %.1f |\n" % (n, f[1], fk, wk)
     open(md, "w").write(head)
+    out["_kernel_rev"] = bj.get("kernel_rev")   # bench.py shows these numbers only beside timings of the same kernels
     json.dump(out, open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd), "w"), indent=1)
 print("\n".join(lines[5:22]))
 print(bj["roofline"])

@@ -49,6 +49,12 @@ def check(rc):
     return rc
 
 
+def kernel_revision():
+    f = lib().xrhip_kernel_revision
+    f.restype = C.c_char_p
+    return f().decode()
+
+
 def device_count():
     return lib().xrhip_device_count()
 

@@ -459,16 +459,18 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
         hipLaunchKernelGGL((kb_solve_try<512, false>), dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
                            wide_trials(d) ? 1 : 0);
     XR_HIP(hipGetLastError());
+    if (c->profiling) XR_HIP(hipEventRecord(e1, s));   // the events bracket kb_solve_try alone (what rocprofv3 reports for it)
     if (wide_first(d)) {   // the first trial batch rides right behind the solve: no host round trip in between
         const size_t wlds = sizeof(double) * (size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np);
         hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, s, d, p, cam, imu, sx, sy, seq, 1, mode);
         XR_HIP(hipGetLastError());
     }
     if (c->profiling) {
-        XR_HIP(hipEventRecord(e1, s));
         const double na = d.na;
+        // algorithmic flops of this kernel: the factorisation + substitutions, and -- unless the trials are costed by
+        // kb_trials_wide -- the factor evaluations of every trial it runs
         c->pending.push_back({e0, e1, na * na * na / 3.0 + 2.0 * na * na,
-                              450.0 * d.M + 3000.0 * d.NI + 2.0 * (double)d.np * d.np, -1});
+                              wide_first(d) ? 0.0 : 450.0 * d.M + 3000.0 * d.NI + 2.0 * (double)d.np * d.np, -1});
     }
     c->stats.n_solve_try++;
     return XRHIP_OK;

@@ -1,0 +1,61 @@
+// ba_dump.hpp -- development / test aid: writes the problem a BaBuilder hands to xrhip_ba_solve to a file, so that the
+// solves of a run can be frozen and replayed (SURVEY.md 8d "S4": frozen refine_window snapshots; tests/golden/ba_snapshots).
+// Enabled by the environment:  XRSLAM_AMD_DUMP_BA=<directory>  [XRSLAM_AMD_DUMP_MIN_OBS=<n>]  [XRSLAM_AMD_DUMP_EVERY=<k>]
+// File layout (little endian): "XRBA1\0\0\0", 8 int32 counts {F, L, M, MR, NI, NP, max_iterations, 0}, then the arrays
+// of xrhip_ba_problem in declaration order (include/xrslam_hip.h), doubles as f64, indices as i32, flags as u8.
+// tests/ba_snapshots.py reads it back.  No HIP dependency.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "../../../include/xrslam_hip.h"
+
+namespace xrh {
+
+struct BaDumper {
+    std::string dir;
+    int min_obs = 0, every = 1;
+    long seen = 0, written = 0;
+    BaDumper() {
+        if (const char *d = std::getenv("XRSLAM_AMD_DUMP_BA")) dir = d;
+        if (const char *m = std::getenv("XRSLAM_AMD_DUMP_MIN_OBS")) min_obs = std::atoi(m);
+        if (const char *e = std::getenv("XRSLAM_AMD_DUMP_EVERY")) every = std::max(1, std::atoi(e));
+    }
+    bool enabled() const { return !dir.empty(); }
+    void maybe_dump(const xrhip_ba_problem &pb, long frame_count) {
+        if (!enabled() || pb.n_obs < min_obs) return;
+        if (seen++ % every) return;
+        char name[512];
+        std::snprintf(name, sizeof name, "%s/ba_%05ld_f%05ld_F%d_L%d_M%d.xrba", dir.c_str(), written++, frame_count, pb.n_frames,
+                      pb.n_landmarks, pb.n_obs);
+        FILE *fp = std::fopen(name, "wb");
+        if (!fp) return;
+        const char magic[8] = {'X', 'R', 'B', 'A', '1', 0, 0, 0};
+        const int32_t hdr[8] = {pb.n_frames, pb.n_landmarks, pb.n_obs, pb.n_rot, pb.n_imu, pb.prior_n, pb.max_iterations, 0};
+        std::fwrite(magic, 1, 8, fp);
+        std::fwrite(hdr, sizeof(int32_t), 8, fp);
+        auto wd = [&](const double *p, size_t n) { if (n) std::fwrite(p, sizeof(double), n, fp); };
+        auto wi = [&](const int *p, size_t n) { if (n) std::fwrite(p, sizeof(int), n, fp); };
+        auto wb = [&](const uint8_t *p, size_t n) { if (n) std::fwrite(p, 1, n, fp); };
+        const size_t F = pb.n_frames, L = pb.n_landmarks, M = pb.n_obs, MR = pb.n_rot, NI = pb.n_imu, NP = pb.prior_n;
+        wd(pb.frame_state, 16 * F);
+        wb(pb.frame_fix, F);
+        wd(pb.cam_q_bc, 4); wd(pb.cam_p_bc, 3); wd(pb.imu_q_bi, 4); wd(pb.imu_p_bi, 3); wd(pb.sqrt_inv_cov, 2);
+        wd(pb.inv_depth, L);
+        wb(pb.landmark_fix, L);
+        wi(pb.obs_tgt, M); wi(pb.obs_ref, M); wi(pb.obs_lm, M);
+        wd(pb.obs_z_tgt, 3 * M); wd(pb.obs_z_ref, 3 * M);
+        wi(pb.rot_tgt, MR); wi(pb.rot_ref, MR);
+        wd(pb.rot_z_tgt, 3 * MR); wd(pb.rot_z_ref, 3 * MR);
+        wi(pb.imu_i, NI); wi(pb.imu_j, NI);
+        wd(pb.imu_data, (size_t)XRHIP_IMU_DIM * NI);
+        wi(pb.prior_frames, NP);
+        wd(pb.prior_sqrt_info, 225 * NP * NP); wd(pb.prior_infovec, 15 * NP); wd(pb.prior_lin, 16 * NP);
+        std::fclose(fp);
+    }
+};
+
+}   // namespace xrh

@@ -29,6 +29,7 @@
 
 #include "../host_select.hpp"
 #include "../hostprof.hpp"
+#include "ba_dump.hpp"
 #include "config.hpp"
 #include "map.hpp"
 #include "parsac.hpp"
@@ -73,6 +74,7 @@ struct Pipeline {
     double noise36[36];
     StageTimes times;
     unsigned long ba_generation = 0;   // BaBuilder instances stamp frames / tracks with it
+    BaDumper ba_dump;                  // XRSLAM_AMD_DUMP_BA=<dir>: freeze the problems handed to xrhip_ba_solve (ba_dump.hpp)
 
     explicit Pipeline(const Config &c) : config(c) {
         hip_check(xrhip_klt_create((int)c.cam_resolution[0], (int)c.cam_resolution[1],
@@ -537,6 +539,7 @@ class BaBuilder {
             pb.prior_lin = prior_->lin.data();
         }
         pb.max_iterations = (int)c.solver_iteration_limit;
+        if (P_.ba_dump.enabled()) P_.ba_dump.maybe_dump(pb, P_.times.frames);
         xrhip_ba_summary sm;
         WallTimer wt_w_solve(P_.times.w_solve);
         hip_check(xrhip_ba_solve(P_.ba, &pb, &sm), "xrhip_ba_solve");

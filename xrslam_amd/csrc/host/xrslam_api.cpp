@@ -1,6 +1,11 @@
 // xrslam_api.cpp -- the outer C ABI (include/XRSLAM.h) on top of the host pipeline.
 // Mirrors XRSLAMManager (reference xrslam-interface/src/XRSLAMManager.cpp:85-242) and
-// XRSLAMInternal.cpp:4-90: a process-global instance, deep-copied images, synchronous calls.
+// XRSLAMInternal.cpp:4-90: deep-copied images, synchronous calls.  The six reference symbols keep the reference's
+// process-global instance (XRSLAMManager.cpp:6-9); every entry point is a thin wrapper over the same functions on an
+// `Instance`, and the additive XRSLAMAmdInstance* symbols expose those directly, so that one process can run several
+// independent sequences on one GPU (the reference's globals force one instance per process; here all
+// state -- id counters, CLAHE / Harris scratch, solver configuration, RD-VIO bin confidences -- lives in the instance).
+// An instance may be driven by one thread at a time; different instances may be driven by different threads.
 #include "../../../include/XRSLAM.h"
 
 #include <cstring>
@@ -19,6 +24,7 @@ struct Manager {
     std::mutex input_mutex;
     std::string last_error;
     std::vector<uint8_t> gray;
+    int device = -1;   // HIP device the instance was created on (the current device is a per-thread setting)
 };
 
 Manager &mgr() {
@@ -26,11 +32,16 @@ Manager &mgr() {
     return m;
 }
 
-template <class F> void guarded(F &&f) {
+// The thread that drives an instance need not be the one that created it: make the instance's device current.
+void bind_device(const Manager &m) {
+    if (m.device >= 0) xrhip_bind_device(m.device);
+}
+
+template <class F> void guarded(Manager &m, F &&f) {
     try {
         f();
     } catch (const std::exception &e) {
-        mgr().last_error = e.what();
+        m.last_error = e.what();
         std::fprintf(stderr, "[xrslam_hip] %s\n", e.what());
     }
 }
@@ -48,16 +59,12 @@ void fill_pose(const xrh::PoseState &latest, const xrh::Quat &q_ext, const xrh::
     pose->translation[2] = p.z;
 }
 
-}   // namespace
 
-extern "C" {
-
-int XRSLAMCreate(const char *slam_config_path, const char *device_config_path, const char *, const char *,
-                 void **config) {
-    Manager &m = mgr();
+int impl_create(Manager &m, const char *slam_config_path, const char *device_config_path, void **config) {
     int ok = 0;
+    if (xrhip_get_device(&m.device) != 0) m.device = -1;
     m.last_error.clear();   // XRSLAMAmdLastError speaks about the instance being created, not about an earlier one
-    guarded([&] {
+    guarded(m, [&] {
         {   // a second Create without Destroy: drop the previous instance first, in XRSLAMDestroy's order -- the pending
             // image returns its device buffer to the Pipeline that owns it, which must still be alive at that point
             std::lock_guard<std::mutex> lk(m.input_mutex);
@@ -72,10 +79,10 @@ int XRSLAMCreate(const char *slam_config_path, const char *device_config_path, c
     return ok;
 }
 
-void XRSLAMPushSensorData(XRSLAMSensorType type, void *data) {
-    Manager &m = mgr();
+void impl_push(Manager &m, XRSLAMSensorType type, void *data) {
     if (!m.sys || !data) return;
-    guarded([&] {
+    bind_device(m);
+    guarded(m, [&] {
         switch (type) {
         case XRSLAM_SENSOR_CAMERA: {
             auto *im = static_cast<XRSLAMImage *>(data);
@@ -115,21 +122,18 @@ void XRSLAMPushSensorData(XRSLAMSensorType type, void *data) {
     });
 }
 
-void XRSLAMRunOneFrame() {
-    Manager &m = mgr();
+void impl_run(Manager &m) {
     if (!m.sys) return;
-    guarded([&] {
+    bind_device(m);
+    guarded(m, [&] {
         std::lock_guard<std::mutex> lk(m.input_mutex);
         if (m.cur_image) m.sys->track_camera(m.cur_image);
     });
 }
 
-void XRSLAMSetViewer(void *) {}
-
-void XRSLAMGetResult(XRSLAMResultType type, void *out) {
-    Manager &m = mgr();
+void impl_get_result(Manager &m, XRSLAMResultType type, void *out) {
     if (!m.sys || !out) return;
-    guarded([&] {
+    guarded(m, [&] {
         switch (type) {
         case XRSLAM_RESULT_BODY_POSE:
             fill_pose(m.sys->latest_pose, m.config.q_bi, m.config.p_bi, m.sys->latest_timestamp, static_cast<XRSLAMPose *>(out));
@@ -199,17 +203,16 @@ void XRSLAMGetResult(XRSLAMResultType type, void *out) {
     });
 }
 
-void XRSLAMDestroy() {
-    Manager &m = mgr();
-    guarded([&] {
+void impl_destroy(Manager &m) {
+    bind_device(m);
+    guarded(m, [&] {
         m.cur_image.reset();
         m.sys.reset();
     });
 }
 
-void XRSLAMAmdSetInitialState(double t, const double q[4], const double p[3], const double v[3], const double bg[3],
-                              const double ba[3]) {
-    Manager &m = mgr();
+void impl_set_initial_state(Manager &m, double t, const double q[4], const double p[3], const double v[3],
+                            const double bg[3], const double ba[3]) {
     if (!m.sys) return;
     xrh::InitialState s;
     s.t = t;
@@ -221,17 +224,16 @@ void XRSLAMAmdSetInitialState(double t, const double q[4], const double p[3], co
     m.sys->init.states.push_back(s);
 }
 
-void XRSLAMAmdPushImageDevice(const void *gray_dev, int stride, double timestamp) {
-    Manager &m = mgr();
+void impl_push_image_device(Manager &m, const void *gray_dev, int stride, double timestamp) {
     if (!m.sys) return;
-    guarded([&] {
+    bind_device(m);
+    guarded(m, [&] {
         std::lock_guard<std::mutex> lk(m.input_mutex);
         m.cur_image = m.sys->P.make_image(static_cast<const uint8_t *>(gray_dev), stride, timestamp, true);
     });
 }
 
-void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out) {
-    Manager &m = mgr();
+void impl_get_times(Manager &m, XRSLAMAmdTimes *out) {
     if (!out) return;
     std::memset(out, 0, sizeof(*out));
     if (!m.sys) return;
@@ -252,28 +254,27 @@ void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out) {
     for (int i = 0; i < 16; ++i) out->wall_scope[i] = t.scope[i];
 }
 
-void XRSLAMAmdSetProfiling(int enable) {
-    Manager &m = mgr();
+void impl_set_profiling(Manager &m, int enable) {
     if (m.sys) {
+        bind_device(m);
         xrhip_klt_set_profiling(m.sys->P.klt, enable);
         xrhip_ba_set_profiling(m.sys->P.ba, enable);
     }
 }
 
-void XRSLAMAmdGetBaStats(void *out, int reset) {
-    Manager &m = mgr();
+void impl_get_ba_stats(Manager &m, void *out, int reset) {
     if (!m.sys || !out) return;
-    guarded([&] { xrh::hip_check(xrhip_ba_get_stats(m.sys->P.ba, static_cast<xrhip_ba_stats *>(out), reset), "xrhip_ba_get_stats"); });
+    bind_device(m);
+    guarded(m, [&] { xrh::hip_check(xrhip_ba_get_stats(m.sys->P.ba, static_cast<xrhip_ba_stats *>(out), reset), "xrhip_ba_get_stats"); });
 }
 
-void XRSLAMAmdGetKltStats(void *out, int reset) {
-    Manager &m = mgr();
+void impl_get_klt_stats(Manager &m, void *out, int reset) {
     if (!m.sys || !out) return;
-    guarded([&] { xrh::hip_check(xrhip_klt_get_stats(m.sys->P.klt, static_cast<xrhip_klt_stats *>(out), reset), "xrhip_klt_get_stats"); });
+    bind_device(m);
+    guarded(m, [&] { xrh::hip_check(xrhip_klt_get_stats(m.sys->P.klt, static_cast<xrhip_klt_stats *>(out), reset), "xrhip_klt_get_stats"); });
 }
 
-void XRSLAMAmdGetInitReport(XRSLAMAmdInitReport *out) {
-    Manager &m = mgr();
+void impl_get_init_report(Manager &m, XRSLAMAmdInitReport *out) {
     if (!m.sys || !out) return;
     const xrh::Initializer &in = m.sys->init;
     out->attempts = in.attempts;
@@ -287,6 +288,92 @@ void XRSLAMAmdGetInitReport(XRSLAMAmdInitReport *out) {
     }
 }
 
+}   // namespace
+
+// An opaque handle for the instance-scoped entry points
+struct XRSLAMAmdInstance {
+    Manager m;
+};
+
+extern "C" {
+
+// ---- the reference's six symbols: one process-global instance (XRSLAMManager.cpp:6-9)
+int XRSLAMCreate(const char *slam_config_path, const char *device_config_path, const char *, const char *, void **config) {
+    return impl_create(mgr(), slam_config_path, device_config_path, config);
+}
+void XRSLAMPushSensorData(XRSLAMSensorType type, void *data) { impl_push(mgr(), type, data); }
+void XRSLAMRunOneFrame() { impl_run(mgr()); }
+void XRSLAMSetViewer(void *) {}
+void XRSLAMGetResult(XRSLAMResultType type, void *out) { impl_get_result(mgr(), type, out); }
+void XRSLAMDestroy() { impl_destroy(mgr()); }
+
+// ---- additive entry points on the process-global instance
+void XRSLAMAmdSetInitialState(double t, const double q[4], const double p[3], const double v[3], const double bg[3],
+                              const double ba[3]) {
+    impl_set_initial_state(mgr(), t, q, p, v, bg, ba);
+}
+void XRSLAMAmdPushImageDevice(const void *gray_dev, int stride, double timestamp) {
+    impl_push_image_device(mgr(), gray_dev, stride, timestamp);
+}
+void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out) { impl_get_times(mgr(), out); }
+void XRSLAMAmdSetProfiling(int enable) { impl_set_profiling(mgr(), enable); }
+void XRSLAMAmdGetBaStats(void *out, int reset) { impl_get_ba_stats(mgr(), out, reset); }
+void XRSLAMAmdGetKltStats(void *out, int reset) { impl_get_klt_stats(mgr(), out, reset); }
+void XRSLAMAmdGetInitReport(XRSLAMAmdInitReport *out) { impl_get_init_report(mgr(), out); }
 const char *XRSLAMAmdLastError(void) { return mgr().last_error.c_str(); }
+
+// ---- the same entry points on caller-owned instances (several sequences per process / per GPU)
+int XRSLAMAmdInstanceCreate(const char *slam_config_path, const char *device_config_path, XRSLAMAmdInstance **out,
+                            void **config) {
+    if (!out) return 0;
+    *out = nullptr;
+    XRSLAMAmdInstance *inst = new (std::nothrow) XRSLAMAmdInstance();
+    if (!inst) return 0;
+    if (impl_create(inst->m, slam_config_path, device_config_path, config) != 1) {
+        // the error text must outlive the failed instance: park it in the global one, where XRSLAMAmdLastError reads
+        mgr().last_error = inst->m.last_error;
+        delete inst;
+        return 0;
+    }
+    *out = inst;
+    return 1;
+}
+void XRSLAMAmdInstanceDestroy(XRSLAMAmdInstance *inst) {
+    if (!inst) return;
+    impl_destroy(inst->m);
+    delete inst;
+}
+void XRSLAMAmdInstancePushSensorData(XRSLAMAmdInstance *inst, XRSLAMSensorType type, void *data) {
+    if (inst) impl_push(inst->m, type, data);
+}
+void XRSLAMAmdInstanceRunOneFrame(XRSLAMAmdInstance *inst) {
+    if (inst) impl_run(inst->m);
+}
+void XRSLAMAmdInstanceGetResult(XRSLAMAmdInstance *inst, XRSLAMResultType type, void *out) {
+    if (inst) impl_get_result(inst->m, type, out);
+}
+void XRSLAMAmdInstanceSetInitialState(XRSLAMAmdInstance *inst, double t, const double q[4], const double p[3],
+                                      const double v[3], const double bg[3], const double ba[3]) {
+    if (inst) impl_set_initial_state(inst->m, t, q, p, v, bg, ba);
+}
+void XRSLAMAmdInstancePushImageDevice(XRSLAMAmdInstance *inst, const void *gray_dev, int stride, double timestamp) {
+    if (inst) impl_push_image_device(inst->m, gray_dev, stride, timestamp);
+}
+void XRSLAMAmdInstanceGetTimes(XRSLAMAmdInstance *inst, XRSLAMAmdTimes *out) {
+    if (inst) impl_get_times(inst->m, out);
+}
+void XRSLAMAmdInstanceSetProfiling(XRSLAMAmdInstance *inst, int enable) {
+    if (inst) impl_set_profiling(inst->m, enable);
+}
+void XRSLAMAmdInstanceGetBaStats(XRSLAMAmdInstance *inst, void *out, int reset) {
+    if (inst) impl_get_ba_stats(inst->m, out, reset);
+}
+void XRSLAMAmdInstanceGetKltStats(XRSLAMAmdInstance *inst, void *out, int reset) {
+    if (inst) impl_get_klt_stats(inst->m, out, reset);
+}
+void XRSLAMAmdInstanceGetInitReport(XRSLAMAmdInstance *inst, XRSLAMAmdInitReport *out) {
+    if (inst) impl_get_init_report(inst->m, out);
+}
+const char *XRSLAMAmdInstanceLastError(XRSLAMAmdInstance *inst) { return inst ? inst->m.last_error.c_str() : ""; }
 
 }   // extern "C"

@@ -70,26 +70,72 @@ def load(lib_path):
     lib.XRSLAMAmdSetProfiling.restype = None
     lib.XRSLAMAmdGetKltStats.argtypes = [C.c_void_p, C.c_int]
     lib.XRSLAMAmdGetKltStats.restype = None
+    lib.XRSLAMAmdGetBaStats.argtypes = [C.c_void_p, C.c_int]
+    lib.XRSLAMAmdGetBaStats.restype = None
+    if hasattr(lib, "XRSLAMAmdInstanceCreate"):   # instance-scoped forms: the instance handle is the first argument
+        H = C.c_void_p
+        lib.XRSLAMAmdInstanceCreate.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(H), C.POINTER(C.c_void_p)]
+        for name, args, res in (("Destroy", [], None), ("PushSensorData", [C.c_int, C.c_void_p], None),
+                                ("RunOneFrame", [], None), ("GetResult", [C.c_int, C.c_void_p], None),
+                                ("SetInitialState", [C.c_double] + [C.c_void_p] * 5, None),
+                                ("PushImageDevice", [C.c_void_p, C.c_int, C.c_double], None),
+                                ("GetTimes", [C.POINTER(XRSLAMAmdTimes)], None), ("SetProfiling", [C.c_int], None),
+                                ("GetBaStats", [C.c_void_p, C.c_int], None), ("GetKltStats", [C.c_void_p, C.c_int], None),
+                                ("GetInitReport", [C.POINTER(XRSLAMAmdInitReport)], None), ("LastError", [], C.c_char_p)):
+            fn = getattr(lib, "XRSLAMAmdInstance" + name)
+            fn.argtypes = [H] + args
+            fn.restype = res
     return lib
 
 
+class _Api:
+    """The entry points a Session drives: the process-global ones (the reference's six symbols + XRSLAMAmd*), or their
+    XRSLAMAmdInstance* forms bound to one instance handle."""
+
+    def __init__(self, lib, handle=None):
+        import functools
+        names = {"push": ("XRSLAMPushSensorData", "XRSLAMAmdInstancePushSensorData"),
+                 "run": ("XRSLAMRunOneFrame", "XRSLAMAmdInstanceRunOneFrame"),
+                 "get_result": ("XRSLAMGetResult", "XRSLAMAmdInstanceGetResult"),
+                 "destroy": ("XRSLAMDestroy", "XRSLAMAmdInstanceDestroy"),
+                 "set_initial_state": ("XRSLAMAmdSetInitialState", "XRSLAMAmdInstanceSetInitialState"),
+                 "push_image_device": ("XRSLAMAmdPushImageDevice", "XRSLAMAmdInstancePushImageDevice"),
+                 "get_times": ("XRSLAMAmdGetTimes", "XRSLAMAmdInstanceGetTimes"),
+                 "set_profiling": ("XRSLAMAmdSetProfiling", "XRSLAMAmdInstanceSetProfiling"),
+                 "get_ba_stats": ("XRSLAMAmdGetBaStats", "XRSLAMAmdInstanceGetBaStats"),
+                 "get_klt_stats": ("XRSLAMAmdGetKltStats", "XRSLAMAmdInstanceGetKltStats"),
+                 "get_init_report": ("XRSLAMAmdGetInitReport", "XRSLAMAmdInstanceGetInitReport"),
+                 "last_error": ("XRSLAMAmdLastError", "XRSLAMAmdInstanceLastError")}
+        for attr, (glob, inst) in names.items():
+            setattr(self, attr, getattr(lib, glob) if handle is None else functools.partial(getattr(lib, inst), handle))
+
+
 class Session:
-    """One XRSLAM instance (the reference is a process singleton, XRSLAMManager.cpp:6-9)."""
+    """One XRSLAM instance: the process singleton behind the reference's six symbols (XRSLAMManager.cpp:6-9), or --
+    instance=True -- an XRSLAMAmdInstance of its own, so that several sessions can live in one process."""
 
     def __init__(self, lib_path, seq, slam_yaml=SLAM_YAML, sensor_yaml=SENSOR_YAML, device_frames=None,
-                 init_frames=60):
+                 init_frames=60, instance=False):
         self.lib = load(lib_path)
         self.seq = seq
         cfg = C.c_void_p()
-        ok = self.lib.XRSLAMCreate(slam_yaml.encode(), sensor_yaml.encode(), b"", b"xrslam_amd", C.byref(cfg))
-        if ok != 1:
-            raise RuntimeError("XRSLAMCreate failed: %s" % self.lib.XRSLAMAmdLastError().decode())
+        if instance:
+            handle = C.c_void_p()
+            ok = self.lib.XRSLAMAmdInstanceCreate(slam_yaml.encode(), sensor_yaml.encode(), C.byref(handle), C.byref(cfg))
+            if ok != 1:
+                raise RuntimeError("XRSLAMAmdInstanceCreate failed: %s" % self.lib.XRSLAMAmdLastError().decode())
+            self.api = _Api(self.lib, handle)
+        else:
+            ok = self.lib.XRSLAMCreate(slam_yaml.encode(), sensor_yaml.encode(), b"", b"xrslam_amd", C.byref(cfg))
+            if ok != 1:
+                raise RuntimeError("XRSLAMCreate failed: %s" % self.lib.XRSLAMAmdLastError().decode())
+            self.api = _Api(self.lib)
         st = seq["states"]
         for i in range(min(init_frames, len(st))):
             s = np.ascontiguousarray(st[i])
             q, p, v, bg, ba = [np.ascontiguousarray(s[a:b]) for a, b in ((0, 4), (4, 7), (7, 10), (10, 13), (13, 16))]
-            self.lib.XRSLAMAmdSetInitialState(float(seq["cam_t"][i]), q.ctypes.data, p.ctypes.data, v.ctypes.data,
-                                              bg.ctypes.data, ba.ctypes.data)
+            self.api.set_initial_state(float(seq["cam_t"][i]), q.ctypes.data, p.ctypes.data, v.ctypes.data,
+                                       bg.ctypes.data, ba.ctypes.data)
         self.device_frames = device_frames   # (base pointer, bytes per frame, stride) when frames live in HBM
         self.imu_k = 0
         self.frame_k = 0
@@ -111,7 +157,7 @@ class Session:
     def _push_imu_until(self, t_limit):
         if not hasattr(self, "_gy"):
             self._imu_structs()
-        push, gy, ac, ts, n = self.lib.XRSLAMPushSensorData, self._gy, self._ac, self._imu_t, len(self._imu_t)
+        push, gy, ac, ts, n = self.api.push, self._gy, self._ac, self._imu_t, len(self._imu_t)
         k = self.imu_k
         lim = t_limit + 1e-9
         while k < n and ts[k] <= lim:
@@ -128,17 +174,17 @@ class Session:
         self._push_imu_until(t)
         if self.device_frames is not None:
             base, fbytes, stride = self.device_frames
-            self.lib.XRSLAMAmdPushImageDevice(C.c_void_p(base + self.frame_k * fbytes), stride, t)
+            self.api.push_image_device(C.c_void_p(base + self.frame_k * fbytes), stride, t)
         else:
             fr = self.seq["frames"][self.frame_k]
             img = XRSLAMImage(fr.ctypes.data, t, fr.strides[0], 0, 1, None)
-            self.lib.XRSLAMPushSensorData(XRSLAM_SENSOR_CAMERA, C.byref(img))
-        self.lib.XRSLAMRunOneFrame()
+            self.api.push(XRSLAM_SENSOR_CAMERA, C.byref(img))
+        self.api.run()
         state = C.c_int(-1)
-        self.lib.XRSLAMGetResult(XRSLAM_RESULT_STATE, C.byref(state))
+        self.api.get_result(XRSLAM_RESULT_STATE, C.byref(state))
         if state.value == 1:
             pose = XRSLAMPose()
-            self.lib.XRSLAMGetResult(XRSLAM_RESULT_BODY_POSE, C.byref(pose))
+            self.api.get_result(XRSLAM_RESULT_BODY_POSE, C.byref(pose))
             self.poses.append([pose.timestamp] + list(pose.translation) + list(pose.quaternion))
         self.frame_k += 1
         return True
@@ -150,33 +196,33 @@ class Session:
 
     def times(self):
         t = XRSLAMAmdTimes()
-        self.lib.XRSLAMAmdGetTimes(C.byref(t))
+        self.api.get_times(C.byref(t))
         return t
 
     def set_profiling(self, on):
-        self.lib.XRSLAMAmdSetProfiling(1 if on else 0)
+        self.api.set_profiling(1 if on else 0)
 
     def klt_stats(self, reset=False):
         from xrslam_amd.klt import KltStats
         st = KltStats()
-        self.lib.XRSLAMAmdGetKltStats(C.byref(st), 1 if reset else 0)
+        self.api.get_klt_stats(C.byref(st), 1 if reset else 0)
         return st
 
     def ba_stats(self, reset=False):
         st = BaStats()
-        self.lib.XRSLAMAmdGetBaStats(C.byref(st), 1 if reset else 0)
+        self.api.get_ba_stats(C.byref(st), 1 if reset else 0)
         return st
 
     def init_report(self):
         r = XRSLAMAmdInitReport()
-        self.lib.XRSLAMAmdGetInitReport(C.byref(r))
+        self.api.get_init_report(C.byref(r))
         return r
 
     def error(self):
-        return self.lib.XRSLAMAmdLastError().decode()
+        return self.api.last_error().decode()
 
     def close(self):
-        self.lib.XRSLAMDestroy()
+        self.api.destroy()
 
 
 def ate_rmse(poses, seq):
