@@ -15,6 +15,7 @@
  */
 #ifndef XRSLAM_AMD_XRSLAM_H
 #define XRSLAM_AMD_XRSLAM_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 #include <vector>
@@ -205,6 +206,16 @@ void XRSLAMAmdInstanceGetBaStats(XRSLAMAmdInstance *inst, void *xrhip_ba_stats_o
 void XRSLAMAmdInstanceGetKltStats(XRSLAMAmdInstance *inst, void *xrhip_klt_stats_out, int reset);
 void XRSLAMAmdInstanceGetInitReport(XRSLAMAmdInstance *inst, XRSLAMAmdInitReport *out);
 const char *XRSLAMAmdInstanceLastError(XRSLAMAmdInstance *inst);
+/* The player's loop (xrslam-pc/player/src/main.cpp:116-169) over a pre-staged sequence for the next `n_steps` camera frames:
+ * IMU samples up to each frame's time (gyroscope before accelerometer, IO/async_dataset_reader.cpp:41-48), the frame,
+ * XRSLAMRunOneFrame, state / body-pose query.  imu7: [n_imu][7] = t, gyroscope xyz, accelerometer xyz; cam_t: [n_frames];
+ * frames: n_frames 8-bit images of frame_bytes each, host memory or (on_device != 0) HBM; the cursors are advanced.
+ * poses_out8 (may be NULL): [n_steps][8] = t, translation xyz, quaternion xyzw of every frame answered in state
+ * TRACKING_SUCCESS.  Returns the number of poses written, -1 on bad arguments.  Lets a harness drive several instances from
+ * several threads without a host-language call per sensor sample. */
+int XRSLAMAmdInstanceReplay(XRSLAMAmdInstance *inst, const double *imu7, int n_imu, const double *cam_t, int n_frames,
+                            const void *frames, size_t frame_bytes, int stride, int on_device, int *imu_cursor,
+                            int *frame_cursor, int n_steps, double *poses_out8);
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,7 @@
 // linearisation or a re-solve of the linear system is needed.
 #include "../../include/xrslam_hip.h"
 #include "ba_kernels.hip.h"
+#include "ba_chain.hip.h"
 #include "marg_kernels.hip.h"
 #include "common.hip.h"
 
@@ -187,6 +188,11 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     d.nla = 0;
     for (int l = 0; l < L; ++l) d.nla += lact[l] ? 1 : 0;
     d.lm_rows = d.Lp;   // xrhip_ba_solve drops the landmark rows when no landmark is free
+    d.nfree = 0;
+    for (int f = 0; f < F; ++f) d.nfree += (P->frame_fix[f] & 3) != 3 ? 1 : 0;
+    d.nffp = 0;
+    for (int o = 0; o < M; ++o)
+        d.nffp += (!(P->frame_fix[P->obs_tgt[o]] & XRHIP_FIX_POSE) && !(P->frame_fix[P->obs_ref[o]] & XRHIP_FIX_POSE)) ? 1 : 0;
     std::vector<int> imuf(2 * F, -1), priorf(F, -1);
     for (int k = 0; k < NI; ++k) {
         if (imuf[2 * P->imu_j[k]] >= 0 || imuf[2 * P->imu_i[k] + 1] >= 0)
@@ -384,6 +390,18 @@ static bool tiny(const BaDims &d) {
     return !off && d.nla == 0 && d.na <= 16 && d.M + d.MR <= 640 && d.F <= 64;   // kb_tiny lists the free frames in s_free[64]
 }
 static bool small_mid(const BaDims &d) { return d.nla == 0 && d.na <= 16; }   // measured: beyond one free frame the wide launches win
+// no free landmark, no prior, a handful of free frames: the LDS-resident single-launch solve (ba_chain.hip.h)
+static bool chain(const BaDims &d, size_t lds_limit, size_t *lds_bytes) {
+    static const bool off = std::getenv("XRHIP_NO_CHAIN") != nullptr;   // development switch: the round-1 paths
+    if (off || d.nla != 0 || d.NP != 0 || d.nffp != 0) return false;
+    if (d.na < 1 || d.na > CHAIN_MAX_NA || d.NI > CHAIN_MAX_NI || d.F > CHAIN_MAX_F || d.M + d.MR > CHAIN_MAX_OBS ||
+        d.nfree > CHAIN_MAX_FREE)
+        return false;
+    const size_t bytes = sizeof(double) * (size_t)chain_layout(d.F, d.na, d.NI, d.nfree).total;
+    if (bytes > lds_limit) return false;
+    *lds_bytes = bytes;
+    return true;
+}
 
 // one linearisation: 3 launches + the cost (and, for the solver, gradient norm + per-solve preparation)
 static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
@@ -547,6 +565,7 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
     XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+    XR_HIP(hipFuncSetAttribute((const void *)kb_chain, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_chol, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     // pre-size for the advertised maxima
@@ -615,7 +634,17 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16)), dim3(256), 0, s, d.np, p.pS, p.pLam);
     bool done = false, relinearise = true;
     int mode = 1, iter_seen = 0;
-    if (tiny(d)) {   // the whole trust-region loop in one launch (kb_tiny)
+    size_t chain_lds = 0;
+    if (chain(d, (size_t)c->lds_limit, &chain_lds)) {   // the whole solve in one launch, LDS-resident (kb_chain)
+        const int seq = ++c->seq;
+        hipLaunchKernelGGL(kb_chain, dim3(1), dim3(256), chain_lds, s, c->tiny_args, seq, 4 * (P->max_iterations + 8));
+        XR_HIP(hipGetLastError());
+        rc = wait_mailbox(c, seq);
+        if (rc) return rc;
+        if (c->h_ctl->status != ST_DONE) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: trust-region loop did not terminate");
+        c->stats.n_tiny++;
+        done = true;
+    } else if (tiny(d)) {   // the whole trust-region loop in one launch (kb_tiny)
         const int seq = ++c->seq;
         size_t lds = 0;
         int use_lds = 1;

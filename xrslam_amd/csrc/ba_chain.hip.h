@@ -1,0 +1,569 @@
+// ba_chain.hip.h -- a whole solve in ONE launch, LDS-resident, for problems WITHOUT a free landmark and without a
+// marginalisation prior: localize_newframe (one free frame against constant landmarks, sliding_window_tracker.cpp:119-143),
+// refine_subwindow (a chain of free subframes tied by IMU factors, :370-465) and the initialiser's PnP (initializer.cpp:296-314).
+//
+// Why: these solves are tiny (15..90 unknowns, a few hundred observations, ~0.3 MFLOP per round) and there are one or
+// two of them per frame.  The generic path (ba_kernels.hip.h) runs them through bodies written for window-sized problems --
+// full 15F x 15F Hessian layout in global memory, one phase per global-memory round trip -- and measured 113-155 us
+// per localize_newframe solve of ONE trust-region round (profiles/r02_kprof_v19.md): almost all of it latency between
+// phases.  Here the unknowns are the `na` free frame dofs only; the Hessian (packed triangle), its scaled copy, all
+// vectors, the frame states and the whitened IMU Jacobians live in LDS; the only global traffic is the observation
+// list (read once per evaluation) and the per-observation Jacobian records between linearisation and block sums.
+//
+// The minimiser is the same code as everywhere else (TrialScalars, trial_begin, dogleg_point, trial_decide) and the
+// arithmetic follows the generic bodies expression by expression (same factor order in every sum of the assembly,
+// same thread -> element mapping in the block sums), so the iteration / accept / reject sequence and the states
+// agree with the generic path and with the oracle exactly as before (tests/test_ba_gpu.py, golden snapshots).
+// Trials whose dogleg point is the one just costed (Gauss-Newton step inside the radius, radius halved after a
+// rejection: still inside) reuse that cost instead of evaluating the identical candidate again.
+#pragma once
+#include "ba_kernels.hip.h"
+
+namespace xrhip {
+
+constexpr int CHAIN_MAX_NA = 90;    // six free frames
+constexpr int CHAIN_MAX_NI = 8;
+constexpr int CHAIN_MAX_F = 64;
+constexpr int CHAIN_MAX_OBS = 1024; // reprojection + rotation factors: four per thread
+constexpr int CHAIN_MAX_FREE = 6;
+
+#ifdef XRHIP_KPROF
+#define CPROF(slot)                                   \
+    do {                                              \
+        __syncthreads();                              \
+        if (threadIdx.x == 0) {                       \
+            const long long cp_n = wall_clock64();    \
+            s_ctl.prof[slot] += cp_n - cp_t;          \
+            cp_t = cp_n;                              \
+        }                                             \
+    } while (0)
+#else
+#define CPROF(slot) \
+    do {            \
+    } while (0)
+#endif
+
+struct ChainLayout {   // offsets in doubles into the dynamic LDS block
+    int sx, cs, Hp, gp, A, sp, D, gs, grad, gn, delta, gt, wJi, wJj, wr, bref, raw, Hv, total;
+};
+__host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int NI, int nfree) {
+    ChainLayout L;
+    int o = 0;
+    auto take = [&](int n) {
+        const int r = o;
+        o += (n + 1) & ~1;
+        return r;
+    };
+    L.sx = take(16 * F);
+    L.cs = take(16 * F);
+    L.Hp = take(na * (na + 1) / 2);
+    L.gp = take(na);
+    const int a_tri = (na + 1) * (na + 2) / 2, scr = NI * IMU_SCR;   // the raw IMU Jacobians are dead before A is formed
+    L.A = take(a_tri > scr ? a_tri : scr);
+    L.sp = take(na);
+    L.D = take(na);
+    L.gs = take(na);
+    L.grad = take(na);
+    L.gn = take(na);
+    L.delta = take(na);
+    L.gt = take(na);
+    L.wJi = take(225 * NI);
+    L.wJj = take(225 * NI);
+    L.wr = take(16 * NI);
+    L.bref = take(6 * NI);
+    L.raw = take(15 * NI);
+    L.Hv = take(28 * nfree);
+    L.total = o;
+    return L;
+}
+
+__global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ args, int seq, int max_rounds) {
+    const BaDims &d = args->d;
+    const BaPtrs &p = args->p;
+    const Ext &cam = args->cam, &imu = args->imu;
+    const double sx_ = args->sx, sy_ = args->sy;
+    extern __shared__ double lds[];
+    __shared__ double scratch[64];
+    __shared__ double Dblk[CH_NB][CH_NB + 1];
+    __shared__ double s_vis[4][27];
+    __shared__ int s_fail;
+    __shared__ int s_free[CHAIN_MAX_FREE], s_slot[CHAIN_MAX_F], s_nfree;
+    __shared__ BaCtl s_ctl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int nt = 256;
+    const int F = d.F, n = d.n, na = d.na, NI = d.NI, M = d.M, MR = d.MR;
+#ifdef XRHIP_KPROF
+    long long cp_t = wall_clock64();
+#endif
+
+    if (tid == 0) {
+        int nf = 0;
+        for (int f = 0; f < F; ++f) {
+            s_slot[f] = -1;
+            if (p.fix[f] != 3 && nf < CHAIN_MAX_FREE) {
+                s_slot[f] = nf;
+                s_free[nf++] = f;
+            }
+        }
+        s_nfree = nf;
+        const long long *src = reinterpret_cast<const long long *>(static_cast<BaCtl *>(p.ctl));
+        long long *dst = reinterpret_cast<long long *>(&s_ctl);
+        for (unsigned i = 0; i < sizeof(BaCtl) / sizeof(long long); ++i) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int nfree = s_nfree;
+    const ChainLayout Lo = chain_layout(F, na, NI, nfree);
+    double *const X = lds + Lo.sx, *const CS = lds + Lo.cs, *const Hp = lds + Lo.Hp, *const gp = lds + Lo.gp;
+    double *const A = lds + Lo.A, *const sp = lds + Lo.sp, *const Dg = lds + Lo.D, *const gs = lds + Lo.gs;
+    double *const grad = lds + Lo.grad, *const gn = lds + Lo.gn, *const delta = lds + Lo.delta, *const gt = lds + Lo.gt;
+    double *const wJi = lds + Lo.wJi, *const wJj = lds + Lo.wJj, *const wr = lds + Lo.wr, *const bref = lds + Lo.bref;
+    double *const raw = lds + Lo.raw, *const Hv = lds + Lo.Hv;
+    BaCtl *const c = &s_ctl;
+
+    // this thread's slots of the full 15F layout (element a = tid + 256 m, like the strided loops of the generic bodies):
+    // act[m] = index of that dof among the free ones, or -1
+    int act[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int a = tid + nt * m;
+        act[m] = a < n ? p.act_inv[a] : -1;
+    }
+    for (int e = tid; e < 16 * F; e += nt) X[e] = p.state[e];
+    for (int e = tid; e < 6 * NI; e += nt) bref[e] = p.bias_ref[e];
+    __syncthreads();
+    CPROF(0);   // set-up: control block, states, index slots
+
+    bool relin = true;
+    int mode = 1, st = ST_RUNNING;
+    for (int round = 0; round < max_rounds; ++round) {
+        if (relin) {
+            // ---------------- linearisation: IMU factors on the lanes of wavefront 0 (one factor each, the SO(3) chains
+            // advance in lockstep), the observations on everybody, thread t taking o = t, t + 256, ...
+            double *scr = A;   // [NI][IMU_SCR]
+            for (int e = tid; e < NI * IMU_SCR; e += nt) scr[e] = 0.0;
+            __syncthreads();
+            if (tid < NI) {
+                const int k = tid, fi = p.imu_i[k], fj = p.imu_j[k];
+                if (!(p.fix[fi] == 3 && p.fix[fj] == 3)) {
+                    double *rw = scr + k * IMU_SCR, *Ji = rw + 15, *Jj = rw + 240;
+                    const FState si = load_state(X + 16 * fi), sj = load_state(X + 16 * fj);
+                    const ImuRec pre = load_imu(p.imu_data + (size_t)k * XRHIP_IMU_DIM);
+                    const V3 bg0 = v3(bref[6 * k], bref[6 * k + 1], bref[6 * k + 2]);
+                    const V3 ba0 = v3(bref[6 * k + 3], bref[6 * k + 4], bref[6 * k + 5]);
+                    double r15[15];
+                    imu_raw_residual(si, sj, pre, bg0, ba0, imu, r15);
+                    for (int i = 0; i < 15; ++i) rw[i] = r15[i];
+                    imu_raw_jacobians(si, sj, pre, bg0, ba0, imu, v3(r15[0], r15[1], r15[2]), Ji, Jj, p.fix[fi] != 3, p.fix[fj] != 3);
+                }
+            }
+            double cost_part = 0.0;   // this thread's share of the total cost, in sum_cost_block's order
+            for (int o = tid; o < M; o += nt) {
+                double rec[OREC];
+                const double co = obs_eval(d, p, o, X, p.depth, cam, sx_, sy_, true, rec);
+                cost_part += co;
+#pragma unroll
+                for (int i = 0; i < OREC; ++i) p.orec[(size_t)o * OREC + i] = rec[i];
+            }
+            for (int o = tid; o < MR; o += nt) {
+                double rec[RREC];
+                const double co = rot_eval(d, p, o, X, cam, sx_, sy_, true, rec);
+                cost_part += co;
+#pragma unroll
+                for (int i = 0; i < RREC; ++i) p.rrec[(size_t)o * RREC + i] = rec[i];
+            }
+            __syncthreads();
+            CPROF(1);   // linearisation of the factors
+            // ---------------- whitening of the IMU factors: one wavefront per factor (lin_imu_item's second half)
+            for (int k = wave; k < NI; k += 4) {
+                const double *rw = scr + k * IMU_SCR, *Ji = rw + 15, *Jj = rw + 240;
+                const int fi = p.imu_i[k], fj = p.imu_j[k];
+                const bool active = !(p.fix[fi] == 3 && p.fix[fj] == 3);
+                const double *S = p.imu_data + (size_t)k * XRHIP_IMU_DIM + 56;
+                double cost = 0.0;
+                if (lane < 15) {
+                    double s = 0;
+                    if (active)
+                        for (int j = 0; j < 15; ++j) s += S[15 * lane + j] * rw[j];
+                    wr[16 * k + lane] = s;
+                    cost = 0.5 * s * s;
+                }
+                cost = wave_sum(cost);
+                if (lane == 0) wr[16 * k + 15] = cost;
+                for (int e = lane; e < 225; e += 64) {
+                    const int i = e / 15, cc = e - 15 * i;
+                    double a = 0, b = 0;
+                    if (active) {
+                        const bool col_i = cc < 6 ? pose_free(p.fix[fi]) : motion_free(p.fix[fi]);
+                        const bool col_j = cc < 6 ? pose_free(p.fix[fj]) : motion_free(p.fix[fj]);
+                        if (col_i)
+                            for (int j = 0; j < 15; ++j) a += S[15 * i + j] * Ji[15 * j + cc];
+                        if (col_j)
+                            for (int j = 0; j < 15; ++j) b += S[15 * i + j] * Jj[15 * j + cc];
+                    }
+                    wJi[225 * k + e] = a;
+                    wJj[225 * k + e] = b;
+                }
+            }
+            CPROF(2);   // IMU whitening
+            // ---------------- reprojection blocks of the free frames: the (f, f) pair list over all four wavefronts,
+            // upper triangle + gradient = 27 sums (kb_tiny's single-frame form, once per free frame)
+            for (int s = 0; s < nfree; ++s) {
+                const int f = s_free[s], pair = f * F + f;
+                const int s0 = p.pair_start[pair], s1 = p.pair_start[pair + 1];
+                double acc[27];
+#pragma unroll
+                for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+                for (int it = s0 + tid; it < s1; it += nt) {
+                    const int code = p.pair_items[it];
+                    const double *rec = p.orec + (size_t)(code >> 1) * OREC + ((code & 1) ? 12 : 0);
+                    double j[12];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) j[i] = rec[i];
+                    const double *rr = p.orec + (size_t)(code >> 1) * OREC + 26;
+                    const double r0 = rr[0], r1 = rr[1];
+                    int e = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                        for (int b = a; b < 6; ++b) acc[e++] += j[a] * j[b] + j[6 + a] * j[6 + b];
+                        acc[21 + a] += j[a] * r0 + j[6 + a] * r1;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
+                if (lane == 0)
+#pragma unroll
+                    for (int i = 0; i < 27; ++i) s_vis[wave][i] = acc[i];
+                __syncthreads();
+                if (tid < 27) Hv[28 * s + tid] = (s_vis[0][tid] + s_vis[1][tid]) + (s_vis[2][tid] + s_vis[3][tid]);
+                __syncthreads();
+            }
+            CPROF(3);   // reprojection blocks
+            // ---------------- assembly of the free x free entries (packed lower triangle) and of the gradient:
+            // reprojection block, rotation priors, the IMU factor ending at the frame, the one starting at it --
+            // assemble_item's order
+            for (int e = tid; e < na * (na + 1) / 2 + na; e += nt) {
+                int i, j;
+                const bool want_g = e >= na * (na + 1) / 2;
+                if (want_g) {
+                    i = e - na * (na + 1) / 2;
+                    j = 0;
+                } else {   // e = i (i + 1) / 2 + j
+                    i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+                    while (i * (i + 1) / 2 > e) --i;
+                    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+                    j = e - i * (i + 1) / 2;
+                }
+                const int a = p.act_idx[i], b = p.act_idx[j];
+                const int fa = a / 15, ka = a - 15 * fa, fb = b / 15, kb = b - 15 * fb;
+                double h = 0.0, g = 0.0;
+                if (ka < 6) {
+                    const double *hv = Hv + 28 * s_slot[fa];
+                    if (!want_g && kb < 6 && fb == fa) {
+                        const int lo = ka < kb ? ka : kb, hi = ka < kb ? kb : ka;
+                        h += hv[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+                    }
+                    if (want_g) g += hv[21 + ka];
+                    if (ka < 3) {
+                        const int s = p.rotf_start[fa], t = p.rotf_start[fa + 1];
+                        for (int it = s; it < t; ++it) {
+                            const double *rec = p.rrec + (size_t)p.rotf_items[it] * RREC;
+                            if (!want_g && fb == fa && kb < 3) h += rec[ka] * rec[kb] + rec[3 + ka] * rec[3 + kb];
+                            if (want_g) g += rec[ka] * rec[6] + rec[3 + ka] * rec[7];
+                        }
+                    }
+                }
+                for (int side = 0; side < 2; ++side) {
+                    const int k = p.imuf[2 * fa + side];
+                    if (k < 0) continue;
+                    const double *Ja = (side == 0 ? wJj : wJi) + 225 * k;
+                    const int fi = p.imu_i[k], fj = p.imu_j[k];
+                    if (want_g) {
+                        const double *r = wr + 16 * k;
+                        for (int q = 0; q < 15; ++q) g += Ja[15 * q + ka] * r[q];
+                    } else if (fb == fi || fb == fj) {
+                        const double *Jb = (fb == fj ? wJj : wJi) + 225 * k;
+                        for (int q = 0; q < 15; ++q) h += Ja[15 * q + ka] * Jb[15 * q + kb];
+                    }
+                }
+                if (want_g) gp[i] = g;
+                else Hp[e] = h;
+            }
+            CPROF(4);   // assembly
+            // ---------------- total cost (sum_cost_block: observations, rotation factors, IMU factors k = tid, ...)
+            for (int k = tid; k < NI; k += nt) cost_part += wr[16 * k + 15];
+            const double ctot = block_sum(cost_part, scratch);
+            if (tid == 0) {
+                c->x_cost = ctot + 0.0;   // + the prior's cost: there is none
+                if (c->first) {
+                    c->initial_cost = c->x_cost;
+                    c->minimum_cost = c->x_cost;
+                }
+            }
+            __syncthreads();
+            // ---------------- gradient max-norm |x - Plus(x, -g)|_inf over the free frames (gradmax_block)
+            {
+                double mx = 0;
+                if (tid < nfree) {
+                    const int f = s_free[tid];
+                    double neg[15], out[16];
+                    for (int k = 0; k < 15; ++k) {
+                        const int i = p.act_inv[15 * f + k];
+                        neg[k] = i >= 0 ? -gp[i] : -0.0;
+                    }
+                    const double *s = X + 16 * f;
+                    state_plus(s, neg, pose_free(p.fix[f]), motion_free(p.fix[f]), out);
+                    for (int k = 0; k < 16; ++k) mx = fmax(mx, fabs(s[k] - out[k]));
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+                if (tid == 0) c->gmax = mx;   // the free frames sit in wavefront 0 (nfree <= 6)
+            }
+            __syncthreads();
+            CPROF(5);   // cost, gradient max-norm
+        }
+        // -------------------- preparation (prepare_block): Jacobi scales at the first linearisation, dogleg diagonal
+        const double mu = c->mu;
+        for (int i = tid; i < na; i += nt) {
+            const double h = Hp[i * (i + 1) / 2 + i];
+            if (c->first) sp[i] = 1.0 / (1.0 + sqrt(h));
+            const double s = sp[i];
+            const double Dv = sqrt(fmin(fmax(s * s * h, 1e-6), 1e32));
+            Dg[i] = Dv;
+            const double gsv = s * gp[i];
+            gs[i] = gsv;
+            gt[i] = s * (gsv / (Dv * Dv));
+        }
+        __syncthreads();
+        // -------------------- reduced system S = sp H sp + mu D^2 (packed, the rhs as row na) and Q(g~, g~)
+        for (int e = tid; e < na * (na + 1) / 2; e += nt) {
+            int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            while (i * (i + 1) / 2 > e) --i;
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            const int j = e - i * (i + 1) / 2;
+            double v = Hp[e] * (sp[i] * sp[j]);
+            if (i == j) v += mu * Dg[i] * Dg[i];
+            A[e] = v;
+        }
+        double *y = A + na * (na + 1) / 2;
+        for (int i = tid; i < na; i += nt) y[i] = gp[i] * sp[i];
+        double qacc = 0;
+        for (int i = wave; i < na; i += 4) {
+            double t = 0;
+            for (int j = lane; j < na; j += 64) t += Hp[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i] * gt[j];
+            qacc += gt[i] * t;
+        }
+        const double qgg = block_sum(qacc, scratch);   // (block_sum ends with a barrier: A and y are complete)
+        CPROF(6);   // preparation, reduced system, Q(g~, g~)
+        // -------------------- Cholesky + substitution (solve_block)
+        bool lin_ok = chol_blocked(A, na, na + 1, Dblk, &s_fail);
+        CPROF(7);   // Cholesky
+        if (lin_ok) {
+            trsv_lower_t(A, na, y);
+            int bad = 0;
+            for (int i = tid; i < na; i += nt) {
+                const double ya = y[i];
+                gn[i] = -Dg[i] * ya;
+                grad[i] = gs[i] / Dg[i];
+                if (!isfinite(ya)) bad = 1;
+            }
+            if (bad) atomicExch(&s_fail, 1);
+            __syncthreads();
+            if (s_fail) lin_ok = false;
+        }
+        __syncthreads();
+        if (lin_ok) {
+            double r3[3] = {0, 0, 0};   // |grad|^2, n~ . gs, |gn|^2   (a = tid, tid + 256, ... of the full layout)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int i = act[m];
+                if (i >= 0) {
+                    const double g = grad[i], nn = gn[i];
+                    r3[0] += g * g;
+                    r3[1] += (nn / Dg[i]) * gs[i];
+                    r3[2] += nn * nn;
+                }
+            }
+            block_sum_n<3>(r3, scratch);
+            if (tid == 0) {
+                c->alpha = r3[0] / qgg;
+                c->q_gg = qgg;
+                c->q_gn = -r3[0] - mu * r3[1];
+                c->q_nn = -r3[1] - mu * r3[2];
+            }
+        }
+        if (tid == 0) c->linear_ok = lin_ok ? 1 : 0;
+        __syncthreads();
+        CPROF(8);   // substitution, Gauss-Newton step, dogleg scalars
+        // -------------------- trials (try_block)
+        if (mode == 1) {
+            // FinalizeIterationAndCheckIfMinimizerCanContinue of the iteration that produced this x: the IMU factors
+            // read their bias reference from the user state, refreshed by the StateUpdatingCallback
+            for (int k = tid; k < NI; k += nt) {
+                const double *sti = X + 16 * p.imu_i[k];
+                for (int i = 0; i < 6; ++i) bref[6 * k + i] = sti[10 + i];
+            }
+            double s2 = 0;
+            for (int f = tid; f < F; f += nt) {
+                const double *x = X + 16 * f;
+                if (pose_free(p.fix[f]))
+                    for (int k = 0; k < 7; ++k) s2 += x[k] * x[k];
+                if (motion_free(p.fix[f]))
+                    for (int k = 7; k < 16; ++k) s2 += x[k] * x[k];
+            }
+            s2 = block_sum(s2, scratch);
+            if (tid == 0) {
+                c->x_norm = sqrt(s2);
+                c->first = 0;
+            }
+            __syncthreads();
+        }
+        {
+            double r3[3] = {0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int i = act[m];
+                if (i >= 0 && lin_ok) {
+                    r3[0] += grad[i] * grad[i];
+                    r3[1] += gn[i] * gn[i];
+                    r3[2] += grad[i] * gn[i];
+                }
+            }
+            block_sum_n<3>(r3, scratch);
+            if (tid == 0) {
+                c->gnorm = sqrt(r3[0]);
+                c->gn_norm = sqrt(r3[1]);
+                c->gd = r3[2];
+            }
+            __syncthreads();
+        }
+        CPROF(9);   // start of the trial phase (user-state refresh, norms)
+        TrialScalars t;
+        trial_load(c, t);
+        bool check_gradient = (mode == 1), skip_finalize = (mode == 3);
+        bool have_prev = false;
+        double prev_ca = 0, prev_cb = 0, prev_mcc = 0, prev_cost = 0, prev_dn2 = 0, prev_sn = 0;
+        int accepted = 0;
+        while (t.status == ST_RUNNING) {
+            trial_begin(t, skip_finalize, check_gradient);
+            skip_finalize = false;
+            check_gradient = false;
+            if (t.status != ST_RUNNING) break;
+            double ca, cb, step_norm;
+            dogleg_point(t, t.radius, ca, cb, step_norm);
+            double mcc, cost, dn2;
+            if (have_prev && ca == prev_ca && cb == prev_cb && step_norm >= 0.0) {
+                // the same dogleg point as the trial just rejected (not the interpolated case, whose coefficients depend
+                // on the radius): same candidate, same sums
+                mcc = prev_mcc;
+                cost = prev_cost;
+                dn2 = prev_dn2;
+                step_norm = prev_sn;
+            } else {
+                double red2[2] = {0, 0};   // |step|^2 (D-scaled), step . gs
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int i = act[m];
+                    if (i >= 0) {
+                        const double v = ca * grad[i] + cb * gn[i];
+                        red2[0] += v * v;
+                        const double stv = v / Dg[i];
+                        red2[1] += stv * gs[i];
+                        delta[i] = stv * sp[i];
+                    }
+                }
+                block_sum_n<2>(red2, scratch);
+                if (step_norm < 0) step_norm = sqrt(red2[0]);
+                mcc = dogleg_model_change(t, ca, cb, red2[1]);
+                __syncthreads();
+                // candidate states (every frame, like the generic path: constant frames are copies)
+                for (int f = tid; f < F; f += nt) {
+                    double d15[15];
+                    for (int k = 0; k < 15; ++k) {
+                        const int i = p.act_inv[15 * f + k];
+                        d15[k] = i >= 0 ? delta[i] : 0.0;
+                    }
+                    state_plus(X + 16 * f, d15, pose_free(p.fix[f]), motion_free(p.fix[f]), CS + 16 * f);
+                }
+                __syncthreads();
+                double red[2] = {0, 0};   // cost, |x - candidate|^2
+                for (int o = tid; o < M; o += nt) red[0] += obs_eval(d, p, o, CS, p.depth, cam, sx_, sy_, false, nullptr);
+                for (int o = tid; o < MR; o += nt) red[0] += rot_eval(d, p, o, CS, cam, sx_, sy_, false, nullptr);
+                for (int k = tid; k < NI; k += nt) {
+                    const int fi = p.imu_i[k], fj = p.imu_j[k];
+                    double r15[15];
+                    if (p.fix[fi] == 3 && p.fix[fj] == 3) {
+                        for (int q = 0; q < 15; ++q) r15[q] = 0.0;
+                    } else {
+                        imu_raw_residual(load_state(CS + 16 * fi), load_state(CS + 16 * fj), load_imu(p.imu_data + (size_t)k * XRHIP_IMU_DIM),
+                                         v3(bref[6 * k], bref[6 * k + 1], bref[6 * k + 2]),
+                                         v3(bref[6 * k + 3], bref[6 * k + 4], bref[6 * k + 5]), imu, r15);
+                    }
+                    for (int q = 0; q < 15; ++q) raw[15 * k + q] = r15[q];
+                }
+                __syncthreads();
+                for (int it = tid; it < NI * 15; it += nt) {
+                    const int k = it / 15, i = it - 15 * k;
+                    const double *S = p.imu_data + (size_t)k * XRHIP_IMU_DIM + 56 + 15 * i;
+                    double acc = 0;
+#pragma unroll
+                    for (int j = 0; j < 15; ++j) acc += S[j] * raw[15 * k + j];
+                    red[0] += 0.5 * acc * acc;
+                }
+                for (int f = tid; f < F; f += nt) {
+                    const double *a = X + 16 * f, *b = CS + 16 * f;
+                    double acc = 0;
+                    if (pose_free(p.fix[f]))
+                        for (int q = 0; q < 7; ++q) acc += (a[q] - b[q]) * (a[q] - b[q]);
+                    if (motion_free(p.fix[f]))
+                        for (int q = 7; q < 16; ++q) acc += (a[q] - b[q]) * (a[q] - b[q]);
+                    red[1] += acc;
+                }
+                block_sum_n<2>(red, scratch);
+                cost = red[0];
+                dn2 = red[1];
+                have_prev = true;
+                prev_ca = ca;
+                prev_cb = cb;
+                prev_mcc = mcc;
+                prev_cost = cost;
+                prev_dn2 = dn2;
+                prev_sn = step_norm;
+            }
+            if (trial_decide(t, 0, mcc, cost, dn2, step_norm)) accepted = 1;
+        }
+        if (accepted) {
+            for (int e = tid; e < 16 * F; e += nt) X[e] = CS[e];
+        }
+        if (tid == 0) trial_store(c, t);
+        __syncthreads();
+        CPROF(10);  // trials
+#ifdef XRHIP_KPROF
+        if (tid == 0) s_ctl.prof[27] += 1;   // rounds
+#endif
+        st = t.status;
+        if (st == ST_DONE) break;
+        if (st == ST_ACCEPTED) {
+            relin = true;
+            mode = 1;
+        } else if (st == ST_RESOLVE || st == ST_RESOLVE_INNER) {
+            relin = false;
+            mode = (st == ST_RESOLVE) ? 2 : 3;
+        } else {
+            break;
+        }
+    }
+    // -------------------- publication: states back to the arena, control block + states + sequence number to the host
+    for (int e = tid; e < 16 * F; e += nt) p.state[e] = X[e];
+    __syncthreads();
+    if (tid == 0) {
+        c->status = (st == ST_DONE) ? ST_DONE : -1;   // -1: not terminated within the round budget, the host reports an error
+        const long long *src = reinterpret_cast<const long long *>(&s_ctl);
+        long long *dst = reinterpret_cast<long long *>(static_cast<BaCtl *>(p.ctl));
+        for (unsigned i = 0; i < sizeof(BaCtl) / sizeof(long long); ++i) dst[i] = src[i];
+    }
+    __syncthreads();
+    publish_block(d, p, st == ST_DONE ? ST_DONE : -1, seq, true);
+}
+
+}   // namespace xrhip

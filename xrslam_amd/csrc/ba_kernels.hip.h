@@ -78,6 +78,8 @@ struct BaDims {
     int na;             // number of free frame dofs (size of the reduced system actually factored)
     int nla;            // number of free landmarks (0: no Schur complement)
     int lm_rows;        // landmark rows kb_landmark_vision builds: Lp, or 0 when the solver has no free landmark
+    int nfree;          // frames with a free pose or motion block
+    int nffp;           // reprojection factors whose target AND reference pose are free (off-diagonal reprojection blocks)
 };
 
 // Pointers of the argument blocks.  Kernels that receive BaPtrs by value see global-address-space pointers (the

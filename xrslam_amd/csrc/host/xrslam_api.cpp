@@ -376,4 +376,57 @@ void XRSLAMAmdInstanceGetInitReport(XRSLAMAmdInstance *inst, XRSLAMAmdInitReport
 }
 const char *XRSLAMAmdInstanceLastError(XRSLAMAmdInstance *inst) { return inst ? inst->m.last_error.c_str() : ""; }
 
+// The player's loop (xrslam-pc/player/src/main.cpp:116-169) for n_steps camera frames of a pre-staged sequence, without a
+// host-language round trip per sensor sample: at equal timestamps gyroscope, then accelerometer, then camera
+// (IO/async_dataset_reader.cpp:41-48); RunOneFrame and the state / pose query after every image.
+int XRSLAMAmdInstanceReplay(XRSLAMAmdInstance *inst, const double *imu7, int n_imu, const double *cam_t, int n_frames,
+                            const void *frames, size_t frame_bytes, int stride, int on_device, int *imu_cursor,
+                            int *frame_cursor, int n_steps, double *poses_out8) {
+    if (!inst || !imu7 || !cam_t || !frames || !imu_cursor || !frame_cursor) return -1;
+    Manager &m = inst->m;
+    int n_poses = 0;
+    for (int s = 0; s < n_steps && *frame_cursor < n_frames; ++s) {
+        const int fk = *frame_cursor;
+        const double t = cam_t[fk], lim = t + 1e-9;
+        int k = *imu_cursor;
+        while (k < n_imu && imu7[7 * (size_t)k] <= lim) {
+            const double *r = imu7 + 7 * (size_t)k;
+            XRSLAMGyroscope g;
+            g.data[0] = r[1]; g.data[1] = r[2]; g.data[2] = r[3]; g.timestamp = r[0];
+            XRSLAMAcceleration a;
+            a.data[0] = r[4]; a.data[1] = r[5]; a.data[2] = r[6]; a.timestamp = r[0];
+            impl_push(m, XRSLAM_SENSOR_GYROSCOPE, &g);
+            impl_push(m, XRSLAM_SENSOR_ACCELERATION, &a);
+            ++k;
+        }
+        *imu_cursor = k;
+        const unsigned char *img = static_cast<const unsigned char *>(frames) + (size_t)fk * frame_bytes;
+        if (on_device) {
+            impl_push_image_device(m, img, stride, t);
+        } else {
+            XRSLAMImage im;
+            im.data = const_cast<unsigned char *>(img);
+            im.timeStamp = t;
+            im.stride = stride;
+            im.camera_id = 0;
+            im.channel = 1;
+            im.ext = nullptr;
+            impl_push(m, XRSLAM_SENSOR_CAMERA, &im);
+        }
+        impl_run(m);
+        XRSLAMState state = XRSLAM_STATE_INITIALIZING;
+        impl_get_result(m, XRSLAM_RESULT_STATE, &state);
+        if (state == XRSLAM_STATE_TRACKING_SUCCESS && poses_out8) {
+            XRSLAMPose pose;
+            impl_get_result(m, XRSLAM_RESULT_BODY_POSE, &pose);
+            double *o = poses_out8 + 8 * (size_t)n_poses++;
+            o[0] = pose.timestamp;
+            for (int i = 0; i < 3; ++i) o[1 + i] = pose.translation[i];
+            for (int i = 0; i < 4; ++i) o[4 + i] = pose.quaternion[i];
+        }
+        *frame_cursor = fk + 1;
+    }
+    return n_poses;
+}
+
 }   // extern "C"

@@ -85,6 +85,9 @@ def load(lib_path):
             fn = getattr(lib, "XRSLAMAmdInstance" + name)
             fn.argtypes = [H] + args
             fn.restype = res
+        lib.XRSLAMAmdInstanceReplay.argtypes = [H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p]
+        lib.XRSLAMAmdInstanceReplay.restype = C.c_int
     return lib
 
 
@@ -125,6 +128,7 @@ class Session:
             if ok != 1:
                 raise RuntimeError("XRSLAMAmdInstanceCreate failed: %s" % self.lib.XRSLAMAmdLastError().decode())
             self.api = _Api(self.lib, handle)
+            self._handle = handle
         else:
             ok = self.lib.XRSLAMCreate(slam_yaml.encode(), sensor_yaml.encode(), b"", b"xrslam_amd", C.byref(cfg))
             if ok != 1:
@@ -188,6 +192,31 @@ class Session:
             self.poses.append([pose.timestamp] + list(pose.translation) + list(pose.quaternion))
         self.frame_k += 1
         return True
+
+    def step_n(self, n):
+        """n camera frames through XRSLAMAmdInstanceReplay: the same call sequence as n x step(), issued natively (one
+        foreign call, the interpreter lock released throughout) -- instance sessions only."""
+        if not hasattr(self, "_rp"):
+            imu = np.ascontiguousarray(self.seq["imu"], np.float64)
+            cam_t = np.ascontiguousarray(self.seq["cam_t"], np.float64)
+            frames = np.ascontiguousarray(self.seq["frames"])
+            self._rp = (imu, cam_t, frames, C.c_int(self.imu_k), C.c_int(self.frame_k))
+        imu, cam_t, frames, ic, fc = self._rp
+        ic.value, fc.value = self.imu_k, self.frame_k
+        out = np.zeros((max(n, 1), 8))
+        if self.device_frames is not None:
+            base, fbytes, stride = self.device_frames
+            ptr, on_dev = C.c_void_p(base), 1
+        else:
+            ptr, fbytes, stride, on_dev = C.c_void_p(frames.ctypes.data), frames.strides[0], frames.strides[1], 0
+        k = self.lib.XRSLAMAmdInstanceReplay(self._handle, imu.ctypes.data, len(imu), cam_t.ctypes.data, len(cam_t), ptr, fbytes,
+                                             stride, on_dev, C.byref(ic), C.byref(fc), int(n), out.ctypes.data)
+        if k < 0:
+            raise RuntimeError("XRSLAMAmdInstanceReplay: bad arguments")
+        self.imu_k, self.frame_k = ic.value, fc.value
+        for r in out[:k]:
+            self.poses.append([r[0]] + list(r[1:4]) + list(r[4:8]))
+        return k
 
     def flush(self):
         """Pushes the IMU samples after the last frame so the last queued frame is processed
