@@ -540,7 +540,8 @@ __device__ __forceinline__ void landmark_item(const BaDims &d, const BaPtrs &p, 
 // Reprojection blocks: one wavefront per (row frame, column frame) pair.  The lanes stride over the pair's
 // observation list, each accumulating a private 6x6 block (+ 6-vector for the diagonal pair); a fixed
 // butterfly reduction combines them -- "batched small-block JtJ accumulation with wavefront-shuffle reductions".
-__device__ __forceinline__ void assemble_vision_item(const BaDims &d, const BaPtrs &p, int pair, int lane) {
+constexpr int VIS_RED = 42 * 65;   // doubles of LDS assemble_vision_item needs per wavefront
+__device__ __forceinline__ void assemble_vision_item(const BaDims &d, const BaPtrs &p, int pair, int lane, double *red) {
     const int fa = pair / d.F, fb = pair - fa * d.F;
     if (!pose_free(p.fix[fa]) || !pose_free(p.fix[fb])) return;   // the block is never read (kb_assemble)
     const int s0 = p.pair_start[fa * d.F + fb], s1 = p.pair_start[fa * d.F + fb + 1];
@@ -574,19 +575,24 @@ __device__ __forceinline__ void assemble_vision_item(const BaDims &d, const BaPt
             if (diag) g[a] += ja[a] * r0 + ja[6 + a] * r1;
         }
     }
+    // The lanes' private blocks are combined through LDS: every lane parks its 42 partial sums as a column, lane e then
+    // adds up row e over the lanes that had observations, in lane order.  (The first version ran 42 butterfly reductions
+    // of doubles per pair -- 12 ds_bpermute each -- which was most of kb_landmark_vision's 25 us on a 10-keyframe window.)
+    wave_sync();   // a previous pair's rows have been read
 #pragma unroll
-    for (int i = 0; i < 36; ++i) h[i] = wave_sum(h[i]);
+    for (int i = 0; i < 36; ++i) red[i * 65 + lane] = h[i];
     if (diag) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) g[i] = wave_sum(g[i]);
+        for (int i = 0; i < 6; ++i) red[(36 + i) * 65 + lane] = g[i];
     }
-    if (lane == 0) {
-        double *out = p.Hv + (size_t)pair * 36;
-#pragma unroll
-        for (int i = 0; i < 36; ++i) out[i] = h[i];
-        if (diag)
-#pragma unroll
-            for (int i = 0; i < 6; ++i) p.gv[6 * fa + i] = g[i];
+    wave_sync();
+    const int nl = min(64, s1 - s0);
+    if (lane < (diag ? 42 : 36)) {
+        const double *row = red + lane * 65;
+        double acc = 0.0;
+        for (int q = 0; q < nl; ++q) acc += row[q];
+        if (lane < 36) p.Hv[(size_t)pair * 36 + lane] = acc;
+        else p.gv[6 * fa + lane - 36] = acc;
     }
 }
 
@@ -915,8 +921,18 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
         __syncthreads();
         KPROF(0);
         // ---- S = sp (Hpp - T) sp + mu D^2 over the free dofs was written by kb_schur_aux as a packed triangle in Sred
-        if (use_lds)
-            for (int e = tid; e < na * (na + 1) / 2; e += nt) A[e] = p.Sred[e];
+        if (use_lds) {   // eight loads per thread in flight (one at a time, this copy took 7 us at 165 unknowns)
+            const int tri = na * (na + 1) / 2;
+            const double *src = p.Sred;
+            for (int e0 = tid; e0 < tri; e0 += 8 * nt) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = src[min(e0 + q * nt, tri - 1)];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (e0 + q * nt < tri) A[e0 + q * nt] = v[q];
+            }
+        }
         __syncthreads();
         KPROF(1);
 #ifdef XRHIP_KPROF
@@ -960,7 +976,6 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
             p.grad[n + l] = 0.0;
         }
     } else {
-        const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
         const int P6 = 6 * d.F;
         double *x6 = work;   // [P6] scaled frame step gathered to the pose columns (the triangle is dead by now)
         for (int cidx = tid; cidx < P6; cidx += nt) {
@@ -968,45 +983,26 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
             x6[cidx] = p.sp[15 * f + k] * p.delta[15 * f + k];
         }
         __syncthreads();
-        for (int l0 = QF_ROWS * wave; l0 < d.L; l0 += QF_ROWS * nw) {   // QF_ROWS landmark rows per wavefront in flight
-            double w8[QF_ROWS];
-#pragma unroll
-            for (int r = 0; r < QF_ROWS; ++r) w8[r] = 0.0;
-            for (int c0 = 0; c0 < P6; c0 += 128) {
-                double w[2][QF_ROWS];
-#pragma unroll
-                for (int cch = 0; cch < 2; ++cch) {
-                    const int cidx = c0 + 64 * cch + lane;
-#pragma unroll
-                    for (int r = 0; r < QF_ROWS; ++r)
-                        w[cch][r] = (cidx < P6 && l0 + r < d.L) ? p.Wt[(size_t)(l0 + r) * d.PF + cidx] : 0.0;
-                }
-#pragma unroll
-                for (int cch = 0; cch < 2; ++cch) {
-                    const int cidx = c0 + 64 * cch + lane;
-                    const double x = cidx < P6 ? x6[cidx] : 0.0;
-#pragma unroll
-                    for (int r = 0; r < QF_ROWS; ++r) w8[r] += w[cch][r] * x;
-                }
+        // One landmark per thread: its row of W against the frame step, a plain 6F-term dot product (x6 is a broadcast
+        // read from LDS, the row streams through the thread's own cache lines).  The first version gave a wavefront
+        // eight rows and reduced every row across the lanes -- eight butterfly reductions per pass, five passes for 278
+        // landmarks, 35 us of the 158 us this kernel took on a 10-keyframe window (profiles/r02_kprof_v19.md).
+        for (int l = tid; l < d.L; l += nt) {
+            double w = 0.0;
+            if (p.lact[l]) {
+                const double *row = p.Wt + (size_t)l * d.PF;
+#pragma unroll 8
+                for (int cidx = 0; cidx < P6; ++cidx) w += row[cidx] * x6[cidx];
             }
-#pragma unroll
-            for (int r = 0; r < QF_ROWS; ++r) w8[r] = wave_sum(w8[r]);
-#pragma unroll
-            for (int r = 0; r < QF_ROWS; ++r) {
-                const int l = l0 + r;
-                if (l >= d.L) continue;
-                double yl = 0.0;
-                const double D = p.diagD[n + l];
-                if (p.lact[l]) {
-                    const double sl = p.sl[l];
-                    yl = (sl * p.gl[l] - sl * w8[r]) / (sl * sl * p.hll[l] + mu * D * D);
-                    if (!isfinite(yl)) bad = 1;
-                }
-                if (lane == 0) {
-                    p.gn[n + l] = -D * yl;
-                    p.grad[n + l] = p.lact[l] ? p.gs[n + l] / D : 0.0;
-                }
+            double yl = 0.0;
+            const double D = p.diagD[n + l];
+            if (p.lact[l]) {
+                const double sl = p.sl[l];
+                yl = (sl * p.gl[l] - sl * w) / (sl * sl * p.hll[l] + mu * D * D);
+                if (!isfinite(yl)) bad = 1;
             }
+            p.gn[n + l] = -D * yl;
+            p.grad[n + l] = p.lact[l] ? p.gs[n + l] / D : 0.0;
         }
     }
     if (bad) atomicExch(&fail, 1);
@@ -1588,9 +1584,10 @@ __host__ __device__ __forceinline__ int lin_all_blocks(int M, int MR, int NI) { 
 // per-landmark rows and per-frame-pair reprojection blocks: [Lp landmarks | F*F pairs], one wavefront each
 // (no landmark rows are needed when every landmark is constant: nla == 0)
 __global__ __launch_bounds__(64) void kb_landmark_vision(BaDims d, BaPtrs p) {
+    __shared__ double red[VIS_RED];
     const int lp = d.lm_rows;
     if ((int)blockIdx.x < lp) landmark_item(d, p, blockIdx.x, threadIdx.x);
-    else assemble_vision_item(d, p, blockIdx.x - lp, threadIdx.x);
+    else assemble_vision_item(d, p, blockIdx.x - lp, threadIdx.x, red);
 }
 
 // total cost, gradient max-norm and the per-solve preparation, one workgroup
@@ -1653,9 +1650,26 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
         }
     }
     // otherwise the batch continues a run of rejections: trial 0 replays the finalize step of its rejected predecessor
+    // Slot -> trial.  While the Gauss-Newton step lies inside the radius the dogleg point IS that step, whatever the
+    // radius: the first `dup` trials of the batch (radius, radius / 2, ... all still >= |gn|) share one candidate and one
+    // cost -- slot 0 stands for all of them and the other slots continue behind them.  (The reference's live-bias quirk
+    // ends most refine_window solves in ~25 rejections, about half of them of this kind: the S1 snapshot of
+    // tests/golden/ba_snapshots repeats one candidate 12 times.)
+    int dup = 0;
+    {
+        double rk = t.radius;
+        while (dup < 60 && t.gn_norm <= rk) {
+            ++dup;
+            rk *= 0.5;
+        }
+        if (dup < 1) dup = 1;
+    }
     double ca[WIDE_B], cb[WIDE_B], step_norm[WIDE_B];
 #pragma unroll
-    for (int k = 0; k < WIDE_B; ++k) dogleg_point(t, t.radius * (1.0 / (double)(1 << k)), ca[k], cb[k], step_norm[k]);
+    for (int k = 0; k < WIDE_B; ++k) {
+        const int j = k == 0 ? 0 : dup + k - 1;   // trial index of slot k
+        dogleg_point(t, scalbn(t.radius, -j), ca[k], cb[k], step_norm[k]);
+    }
     // ---- candidate frame states (every block, LDS) and prior deltas
     for (int e = tid; e < WIDE_B * d.F; e += nt) {
         const int k = e / d.F, f = e - k * d.F;
@@ -1787,18 +1801,31 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
     double tot[4 * WIDE_B];
 #pragma unroll
     for (int q = 0; q < 4 * WIDE_B; ++q) tot[q] = scratch[q];
-    int accepted = -1;
+    double mcc[WIDE_B];
 #pragma unroll
     for (int k = 0; k < WIDE_B; ++k) {
-        if (t.status != ST_RUNNING) continue;
         if (step_norm[k] < 0) step_norm[k] = sqrt(tot[4 * k + 2]);
-        const double mcc = dogleg_model_change(t, ca[k], cb[k], tot[4 * k + 3]);
+        mcc[k] = dogleg_model_change(t, ca[k], cb[k], tot[4 * k + 3]);
+    }
+    int accepted = -1;
+    // the decisions, trial by trial: `dup` of them on slot 0's sums, then one per remaining slot
+    for (int j = 0; j < dup + WIDE_B - 1 && t.status == ST_RUNNING; ++j) {
+        const int ks = j < dup ? 0 : j - dup + 1;
+        double m_k = 0, c_k = 0, d_k = 0, s_k = 0;
+#pragma unroll
+        for (int k = 0; k < WIDE_B; ++k)
+            if (k == ks) {
+                m_k = mcc[k];
+                c_k = tot[4 * k];
+                d_k = tot[4 * k + 1];
+                s_k = step_norm[k];
+            }
         // as the continuation of a rejection run every trial of the batch, the first included, starts with the
-        // finalize step of its rejected predecessor (k + 1 > 0)
+        // finalize step of its rejected predecessor (j + 1 > 0)
 #ifdef XRHIP_KPROF
         if (tid == 0) p.ctl->prof[19] += 1;
 #endif
-        if (trial_decide(t, first ? k : k + 1, mcc, tot[4 * k], tot[4 * k + 1], step_norm[k])) accepted = k;
+        if (trial_decide(t, first ? j : j + 1, m_k, c_k, d_k, s_k)) accepted = ks;
     }
     if (accepted >= 0) {
         for (int e = tid; e < 16 * d.F; e += nt) p.state[e] = cand[(size_t)accepted * 16 * d.F + e];
@@ -1896,6 +1923,7 @@ __global__ __launch_bounds__(256) void kb_tiny(const TinyArgs *__restrict__ args
     __shared__ int s_next;
     __shared__ double s_vis[4][27];
     __shared__ int s_free[64], s_nfree;   // frames with a free pose: only their pairs carry a reprojection block
+    __shared__ double s_red[VIS_RED];
     if (tid == 0) {
         int nf = 0;
         for (int f = 0; f < d.F; ++f)
@@ -1965,9 +1993,9 @@ __global__ __launch_bounds__(256) void kb_tiny(const TinyArgs *__restrict__ args
                     const int a = tid - 36;
                     p.gv[6 * f + a] = (s_vis[0][21 + a] + s_vis[1][21 + a]) + (s_vis[2][21 + a] + s_vis[3][21 + a]);
                 }
-            } else {
-                for (int it = wave; it < s_nfree * s_nfree; it += 4)
-                    assemble_vision_item(d, p, s_free[it / s_nfree] * d.F + s_free[it % s_nfree], lane);
+            } else if (wave == 0) {   // (a path kb_chain has taken over for every problem it accepts: kept simple)
+                for (int it = 0; it < s_nfree * s_nfree; ++it)
+                    assemble_vision_item(d, p, s_free[it / s_nfree] * d.F + s_free[it % s_nfree], lane, s_red);
             }
             __syncthreads();
             KPROF(22);

@@ -55,12 +55,32 @@ typedef double chol_d4 __attribute__((ext_vector_type(4)));
 // If `rhs` is given (the LAST panel of a system with one right-hand-side row), the inverse is not needed: the
 // row segment rhs[j0 .. j0+nb) is forward-substituted in registers instead and Dinv is left untouched.
 // Returns false (uniformly over the wavefront) on a non-positive pivot.
-__device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double (*Dinv)[CH_NB + 1], int lane,
-                                               double *rhs = nullptr) {
+#ifdef XRHIP_KPROF
+#define DGPROF(slot)                                   \
+    do {                                               \
+        if (dprof && lane == 0) {                      \
+            const long long t_now = wall_clock64();    \
+            dprof[slot] += t_now - t_dg;               \
+            t_dg = t_now;                              \
+        }                                              \
+    } while (0)
+#else
+#define DGPROF(slot) \
+    do {             \
+    } while (0)
+#endif
+template <bool WITH_RHS>
+__device__ __forceinline__ bool chol_diag_wave_t(double *A, int j0, int nb, double (*Dinv)[CH_NB + 1], int lane, double *rhs,
+                                                 long long *dprof = nullptr) {
+#ifdef XRHIP_KPROF
+    long long t_dg = wall_clock64();
+#endif
     double x[CH_NB];   // row `lane` of the block; rows >= nb are identity rows
 #pragma unroll
     for (int k = 0; k < CH_NB; ++k) x[k] = (lane < nb && k <= lane) ? A[tri_idx(j0 + lane, j0 + k)] : ((k == lane) ? 1.0 : 0.0);
+    DGPROF(4);   // block load
     double dinv[CH_NB];
+    double xi[CH_NB];   // column `lane` of L^-1: xi[r] = Linv[r][lane]
     bool ok = true;
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) {
@@ -93,8 +113,18 @@ __device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double
             const double lkc = lane_bcast(x[c], k);   // L[k][c]
             x[k] -= x[c] * lkc;                        // meaningful for lane >= k (lower triangle)
         }
+        if (!WITH_RHS) {
+            // row c of L^-1 by forward substitution, in the same pass: it needs L[c][0..c], final by now, and nothing the
+            // later columns produce -- independent work for the issue slots the pivot chain (rsq + Newton) leaves empty.
+            // Same terms in the same order as a separate loop over r = 0..15 would add them.
+            double acc = (c == lane) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < c; ++k) acc -= lane_bcast(x[k], c) * xi[k];   // L[c][k] * Linv[k][lane]
+            xi[c] = (c < lane) ? 0.0 : acc * dinv[c];
+        }
     }
-    if (rhs) {
+    DGPROF(5);   // factorisation (+ inverse)
+    if (WITH_RHS) {
         double r = (lane < nb) ? rhs[j0 + lane] : 0.0;
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c) {
@@ -110,15 +140,6 @@ __device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double
         }
         return ok;
     }
-    // column `lane` of L^-1 by forward substitution: xi[r] = Linv[r][lane]
-    double xi[CH_NB];
-#pragma unroll
-    for (int r = 0; r < CH_NB; ++r) {
-        double acc = (r == lane) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) acc -= lane_bcast(x[k], r) * xi[k];   // L[r][k] * Linv[k][lane]
-        xi[r] = (r < lane) ? 0.0 : acc * dinv[r];
-    }
     if (lane < CH_NB) {
 #pragma unroll
         for (int r = 0; r < CH_NB; ++r) Dinv[r][lane] = xi[r];
@@ -126,7 +147,12 @@ __device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double
         for (int k = 0; k < CH_NB; ++k)
             if (lane < nb && k <= lane) A[tri_idx(j0 + lane, j0 + k)] = x[k];
     }
+    DGPROF(6);   // write-back
     return ok;
+}
+__device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double (*Dinv)[CH_NB + 1], int lane,
+                                               double *rhs = nullptr, long long *dprof = nullptr) {
+    return rhs ? chol_diag_wave_t<true>(A, j0, nb, Dinv, lane, rhs, dprof) : chol_diag_wave_t<false>(A, j0, nb, Dinv, lane, nullptr, dprof);
 }
 
 // In-place blocked Cholesky of the packed lower triangle A (n x n): on success A holds L.  Rows n .. nrows-1
@@ -220,7 +246,7 @@ __device__ __forceinline__ bool chol_blocked(double *A, int n, int nrows, double
             chol_trailing_tile(A, n, nrows, j0, nb, jb, 0, 0, r16, q);
             if (lwr1 && rhs_ti != 0) chol_trailing_tile(A, n, nrows, j0, nb, jb, rhs_ti, 0, r16, q);
             __threadfence_block();   // other lanes of this wavefront read those entries next (A may be in global memory)
-            if (!chol_diag_wave(A, jb, nb1, Dinv, lane, lwr1 ? rhs : nullptr) && lane == 0) *s_fail = 1;
+            if (!chol_diag_wave(A, jb, nb1, Dinv, lane, lwr1 ? rhs : nullptr, prof) && lane == 0) *s_fail = 1;
         } else {
             const int workers = look ? nw - 1 : nw, me = look ? wave - 1 : wave;
             int t = 0;

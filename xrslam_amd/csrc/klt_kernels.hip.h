@@ -477,6 +477,33 @@ __device__ __forceinline__ int lk_tap(int sample, int weight) {
     return r;
 }
 
+// acc + sample * weight for the same operand ranges (v_mad_i32_i24: 24-bit signed factors, full 32-bit addend): one
+// full-rate instruction per tap of the iteration loop, where mul + add3 took 1.5.
+__device__ __forceinline__ int lk_tap_acc(int sample, int weight, int acc) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(sample), "v"(weight), "v"(acc));
+    return r;
+}
+
+// Exact wavefront-wide sum of a 32-bit integer whose 64 terms may not fit 32 bits together (|v| < 2^31 per lane):
+// the low 16 bits (unsigned) and the high 16 bits (signed) are summed separately -- 64 terms of at most 16 bits stay
+// below 2^22 -- as 32-bit DPP scans (one v_add per stage instead of the add / add-with-carry pair and the two moves a
+// 64-bit scan needs), and recombined in double precision, where every integer below 2^53 is exact.  Returns the sum
+// as a double in every lane; (float) of it is the correctly rounded value, the same float (float)(int64 sum) is.
+__device__ __forceinline__ int dpp_scan_add_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ double wave_sum_i32_exact(int v) {
+    const int lo = dpp_scan_add_i32(v & 0xffff), hi = dpp_scan_add_i32(v >> 16);
+    return (double)hi * 65536.0 + (double)lo;
+}
+
 struct LkCounters {
     unsigned long long templates;
     unsigned long long iterations;
@@ -614,7 +641,9 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
             iw01 = __float2int_rn(a * (1.f - b) * (1 << LK_W_BITS));
             iw10 = __float2int_rn((1.f - a) * b * (1 << LK_W_BITS));
             iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
-            long long sb1 = 0, sb2 = 0;
+            // per-lane partial sums stay in 32 bits: |diff| <= 8160 (8-bit pixels with 5 fractional bits), |Ix|, |Iy| <= 4080
+            // (Scharr 3/10/3 of 8-bit pixels), seven slots: < 2.4e8
+            int sb1 = 0, sb2 = 0;
             const int rx = inx - tx0, ry = iny - ty0;
             if (staged && rx >= 0 && rx <= LK_TILE_W - 22 && ry >= 0 && ry <= LK_TILE_H - 22) {
                 // LDS-qualified pointer: keeps these reads ds_read (the compiler otherwise sinks the last slot of this
@@ -626,27 +655,31 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
                 for (int s = 0; s < LK_SLOTS; ++s) {
                     const lds_bytes j0 = t + wy[s] * LK_TILE_W + wx[s];
                     const lds_bytes j1 = j0 + LK_TILE_W;
-                    int diff = lk_descale(lk_tap(j0[0], iw00) + lk_tap(j0[1], iw01) + lk_tap(j1[0], iw10) + lk_tap(j1[1], iw11),
-                                          LK_W_BITS - 5) - Iv[s];
-                    sb1 += (long long)(diff * Ix[s]);
-                    sb2 += (long long)(diff * Iy[s]);
+                    int acc = lk_tap_acc(j0[0], iw00, 1 << (LK_W_BITS - 5 - 1));   // the rounding term of lk_descale rides along
+                    acc = lk_tap_acc(j0[1], iw01, acc);
+                    acc = lk_tap_acc(j1[0], iw10, acc);
+                    acc = lk_tap_acc(j1[1], iw11, acc);
+                    const int diff = (acc >> (LK_W_BITS - 5)) - Iv[s];
+                    sb1 = lk_tap_acc(diff, Ix[s], sb1);
+                    sb2 = lk_tap_acc(diff, Iy[s], sb2);
                 }
             } else {
 #pragma unroll
                 for (int s = 0; s < LK_SLOTS; ++s) {
                     const uint8_t *j0 = J.img + (ptrdiff_t)(iny + wy[s]) * J.istride + (inx + wx[s]);
                     const uint8_t *j1 = j0 + J.istride;
-                    int diff = lk_descale(lk_tap(j0[0], iw00) + lk_tap(j0[1], iw01) + lk_tap(j1[0], iw10) + lk_tap(j1[1], iw11),
-                                          LK_W_BITS - 5) - Iv[s];
-                    sb1 += (long long)(diff * Ix[s]);
-                    sb2 += (long long)(diff * Iy[s]);
+                    int acc = lk_tap_acc(j0[0], iw00, 1 << (LK_W_BITS - 5 - 1));
+                    acc = lk_tap_acc(j0[1], iw01, acc);
+                    acc = lk_tap_acc(j1[0], iw10, acc);
+                    acc = lk_tap_acc(j1[1], iw11, acc);
+                    const int diff = (acc >> (LK_W_BITS - 5)) - Iv[s];
+                    sb1 = lk_tap_acc(diff, Ix[s], sb1);
+                    sb2 = lk_tap_acc(diff, Iy[s], sb2);
                 }
             }
-            sb1 = wave_sum_i64(sb1);
-            sb2 = wave_sum_i64(sb2);
             n_iters++;
-            const float b1 = (float)sb1 * FLT_SCALE;
-            const float b2 = (float)sb2 * FLT_SCALE;
+            const float b1 = (float)wave_sum_i32_exact(sb1) * FLT_SCALE;
+            const float b2 = (float)wave_sum_i32_exact(sb2) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             nx += dx;
