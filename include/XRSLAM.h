@@ -150,6 +150,26 @@ void XRSLAMAmdSetInitialState(double t, const double q[4], const double p[3], co
                               const double bg[3], const double ba[3]);
 /* like XRSLAM_SENSOR_CAMERA but `gray_dev` is an 8-bit single-channel image already resident in HBM */
 void XRSLAMAmdPushImageDevice(const void *gray_dev, int stride, double timestamp);
+/* What the reference's dataset readers ask the YamlConfig* for (xrslam-pc/player/src/IO/euroc_dataset_reader.cpp:4-7,16,62-66;
+ * tum_dataset_reader.cpp:4-6,67-76): camera_time_offset(), camera_distortion_flag(), camera_distortion(),
+ * camera_intrinsic(), camera_resolution().  The `config` out-parameter of XRSLAMCreate is an opaque handle here (the
+ * reference hands out a C++ object whose virtuals the player calls -- not something a C ABI can promise), so a reader that
+ * is built against this library takes those five values from this call instead (INTEGRATION.md section 1 shows the patch). */
+typedef struct XRSLAMAmdCameraConfig {
+    double time_offset;       /* cam0.time_offset */
+    int distortion_flag;      /* cam0.camera_distortion_flag */
+    double distortion[4];     /* cam0.distortion: k1 k2 p1 p2 (radtan) or k1..k4 (equidistant) */
+    double intrinsics[4];     /* cam0.intrinsics: fx fy cx cy */
+    int resolution[2];        /* cam0.resolution: width height */
+} XRSLAMAmdCameraConfig;
+void XRSLAMAmdGetCameraConfig(XRSLAMAmdCameraConfig *out);
+/* Undistortion on the device.  The reference's readers rectify every frame on the host before pushing it
+ * (cv::undistort, xrslam-pc/player/src/IO/euroc_dataset_reader.cpp:62-69; xrslam::extra::ImageUndistorter,
+ * IO/tum_dataset_reader.cpp:67-76).  After this call the images handed to XRSLAM_SENSOR_CAMERA / XRSLAMAmdPushImageDevice
+ * are taken as the camera recorded them and rectified on the GPU with cam0.intrinsics / cam0.distortion of the device
+ * configuration -- bit-identical to the host path (the map is built once, on the host, in the reference's arithmetic).
+ * model: "cv_undistort" (EuRoC reader), "radtan" or "equidistant" (ImageUndistorter); NULL or "" switches it off. */
+void XRSLAMAmdSetDeviceUndistort(const char *model);
 typedef struct XRSLAMAmdTimes {
     long frames, solves, solve_iterations, marginalizations, keyframes;
     double ba_device_ms; /* sum of xrhip_ba_summary.ms_solve (staging + kernels + result read-back of every solve) */
@@ -200,6 +220,8 @@ void XRSLAMAmdInstanceGetResult(XRSLAMAmdInstance *inst, XRSLAMResultType result
 void XRSLAMAmdInstanceSetInitialState(XRSLAMAmdInstance *inst, double t, const double q[4], const double p[3],
                                       const double v[3], const double bg[3], const double ba[3]);
 void XRSLAMAmdInstancePushImageDevice(XRSLAMAmdInstance *inst, const void *gray_dev, int stride, double timestamp);
+void XRSLAMAmdInstanceGetCameraConfig(XRSLAMAmdInstance *inst, XRSLAMAmdCameraConfig *out);
+void XRSLAMAmdInstanceSetDeviceUndistort(XRSLAMAmdInstance *inst, const char *model);
 void XRSLAMAmdInstanceGetTimes(XRSLAMAmdInstance *inst, XRSLAMAmdTimes *out);
 void XRSLAMAmdInstanceSetProfiling(XRSLAMAmdInstance *inst, int enable);
 void XRSLAMAmdInstanceGetBaStats(XRSLAMAmdInstance *inst, void *xrhip_ba_stats_out, int reset);

@@ -73,6 +73,17 @@ int xrhip_image_upload(xrhip_image *img, const uint8_t *gray, int stride_bytes);
 /* same, but `gray_dev` already lives in HBM (device pointer; used by bench.py so
  * the timed region starts with inputs resident on the device). */
 int xrhip_image_upload_device(xrhip_image *img, const void *gray_dev, int stride_bytes);
+/* Undistortion on the device.  replaces: cv::undistort in the dataset reader
+ * (xrslam-pc/player/src/IO/euroc_dataset_reader.cpp:62-69) / xrslam::extra::ImageUndistorter::undistort_image
+ * (IO/tum_dataset_reader.cpp:67-76).  `map2` is the packed 1/32-pixel inverse map [height][width][2]
+ * (word 0 = int16 sx | int16 sy << 16, word 1 = ax | ay << 8) built once per camera on the host in the reference's own
+ * arithmetic (xrslam_amd/csrc/host/undistort_map.hpp); NULL switches the feature off.  With a map set,
+ * xrhip_image_upload_distorted takes the frame as the camera recorded it (host pointer, or an HBM pointer when on_device)
+ * and leaves the rectified frame where xrhip_image_preprocess reads it: one upload, no host pass over the pixels. */
+int xrhip_klt_set_undistort_map(xrhip_klt *ctx, const uint32_t *map2);
+int xrhip_image_upload_distorted(xrhip_image *img, const void *gray, int stride_bytes, int on_device);
+/* parity aid: the 8-bit frame xrhip_image_preprocess will read */
+int xrhip_debug_get_raw(xrhip_image *img, uint8_t *out);
 void xrhip_image_destroy(xrhip_image *img);
 
 /* replaces: Image::preprocess(clipLimit, width, height)  (xrslam.h:153,

@@ -779,3 +779,24 @@ void orc_poisson_select(const double *pts, int n, double radius, uint8_t *keep) 
     }
     pdf_free(&f);
 }
+
+/* cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) on a packed 1/32-pixel fixed-point map ([h][w][2]: word 0 = int16 sx |
+ * int16 sy << 16, word 1 = ax | ay << 8), the per-frame half of cv::undistort as the reference's readers use it
+ * (xrslam-pc/player/src/IO/euroc_dataset_reader.cpp:62-69); same arithmetic as oracle/undistort.py::_remap_fixed. */
+void orc_remap_packed(const uint32_t *map2, int w, int h, const uint8_t *src, int sstride, uint8_t *dst, int dstride) {
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            const uint32_t m0 = map2[2 * ((size_t)i * w + j)], m1 = map2[2 * ((size_t)i * w + j) + 1];
+            const int sx = (int16_t)(m0 & 0xffffu), sy = (int16_t)(m0 >> 16), ax = (int)(m1 & 31u), ay = (int)((m1 >> 8) & 31u);
+            long long acc = 0;
+            for (int dy = 0; dy < 2; ++dy)
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int y = sy + dy, x = sx + dx;
+                    const int px = (x >= 0 && x < w && y >= 0 && y < h) ? src[(size_t)y * sstride + x] : 0;
+                    const int wy = dy ? ay : 32 - ay, wx = dx ? ax : 32 - ax;
+                    acc += (long long)px * (wy * wx * 32);
+                }
+            long long v = (acc + (1 << 14)) >> 15;
+            dst[(size_t)i * dstride + j] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+}

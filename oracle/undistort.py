@@ -116,3 +116,32 @@ def undistort_model(gray, K4, D, model):
     iu = (np.clip(iu >> INTER_BITS, -32768, 32767) << INTER_BITS) | (iu & (INTER_TAB_SIZE - 1))
     iv = (np.clip(iv >> INTER_BITS, -32768, 32767) << INTER_BITS) | (iv & (INTER_TAB_SIZE - 1))
     return _remap_fixed(gray, iu, iv)
+
+
+def packed_map(w, h, K4, D, model="cv_undistort"):
+    """The inverse map in the packed form of include/xrslam_hip.h (xrhip_klt_set_undistort_map): [h][w][2] uint32, word 0 =
+    int16 sx | int16 sy << 16, word 1 = ax | ay << 8 -- built here from this module's own arithmetic, independently of
+    the product's builder (xrslam_amd/csrc/host/undistort_map.hpp), for the tests of the device remap."""
+    probe = np.zeros((h, w), np.uint8)
+    grabbed = {}
+
+    def grab(gray, iu, iv):
+        grabbed["iu"], grabbed["iv"] = iu, iv
+        return gray
+    global _remap_fixed
+    keep = _remap_fixed
+    _remap_fixed = grab
+    try:
+        if model == "cv_undistort":
+            undistort(probe, K4, D)
+        else:
+            undistort_model(probe, K4, D, model)
+    finally:
+        _remap_fixed = keep
+    iu, iv = grabbed["iu"] + np.zeros((h, w), np.int64), grabbed["iv"] + np.zeros((h, w), np.int64)
+    sx = np.clip(iu >> INTER_BITS, -32768, 32767).astype(np.int16).view(np.uint16).astype(np.uint32)
+    sy = np.clip(iv >> INTER_BITS, -32768, 32767).astype(np.int16).view(np.uint16).astype(np.uint32)
+    out = np.empty((h, w, 2), np.uint32)
+    out[..., 0] = sx | (sy << 16)
+    out[..., 1] = (iu & 31).astype(np.uint32) | ((iv & 31).astype(np.uint32) << 8)
+    return out

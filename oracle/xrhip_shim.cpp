@@ -32,6 +32,7 @@ int orc_preintegrate(const double *samples, int n, double t_end, const double *b
 
 struct xrhip_klt {
     int w, h;
+    std::vector<uint32_t> undist_map;   // packed 1/32-pixel map, empty = frames arrive rectified
 };
 struct xrhip_image {
     xrhip_klt *ctx;
@@ -87,6 +88,27 @@ int xrhip_image_upload(xrhip_image *im, const uint8_t *gray, int stride) {
     for (int y = 0; y < im->ctx->h; ++y) std::memcpy(&im->raw[(size_t)y * im->ctx->w], gray + (size_t)y * stride, im->ctx->w);
     im->have_raw = true;
     im->have_pyr = false;
+    return 0;
+}
+extern "C" void orc_remap_packed(const uint32_t *map2, int w, int h, const uint8_t *src, int sstride, uint8_t *dst, int dstride);
+int xrhip_klt_set_undistort_map(xrhip_klt *c, const uint32_t *map2) {
+    if (map2) c->undist_map.assign(map2, map2 + (size_t)2 * c->w * c->h);
+    else c->undist_map.clear();
+    return 0;
+}
+int xrhip_image_upload_distorted(xrhip_image *im, const void *gray, int stride, int) {
+    if (im->ctx->undist_map.empty()) {
+        g_err = "upload_distorted: no undistortion map";
+        return XRHIP_ESTATE;
+    }
+    orc_remap_packed(im->ctx->undist_map.data(), im->ctx->w, im->ctx->h, static_cast<const uint8_t *>(gray), stride, im->raw.data(),
+                     im->ctx->w);
+    im->have_raw = true;
+    im->have_pyr = false;
+    return 0;
+}
+int xrhip_debug_get_raw(xrhip_image *im, uint8_t *out) {
+    std::memcpy(out, im->raw.data(), im->raw.size());
     return 0;
 }
 int xrhip_image_upload_device(xrhip_image *im, const void *gray, int stride) {

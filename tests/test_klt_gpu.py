@@ -225,3 +225,36 @@ def test_full_size_properties(mods):
     ok = st > 0
     assert ok.mean() > 0.9
     assert np.median(np.abs(nx[ok] - kp[ok] - shift)) < 0.05
+
+
+def test_device_undistortion_bit_exact(mods):
+    """SURVEY.md 8f-f2: cv::undistort / ImageUndistorter on the device (k_undistort) against oracle/undistort.py -- the
+    EuRoC radial-tangential lens at 752x480 and the TUM-VI equidistant fisheye at 512x512, host and HBM-resident input;
+    the map comes from the oracle's own arithmetic, not from the product's builder."""
+    import torch
+    from oracle import undistort as ou
+    _, klt = mods
+    cases = [("cv_undistort", 752, 480, (458.654, 457.296, 367.215, 248.375), (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)),
+             ("equidistant", 512, 512, (190.97847715128717, 190.9733070521226, 254.93170605935475, 256.8974428996504),
+              (0.0034823894022493434, 0.0007150348452162257, -0.0020532361418706202, 0.00020293673591811182))]
+    for model, w, h, K, D in cases:
+        img = noise_image(w, h, seed=31 + w)
+        exp = ou.undistort(img, K, D) if model == "cv_undistort" else ou.undistort_model(img, K, D, model)
+        ctx = klt.KltContext(w, h, 150)
+        ctx.set_undistort_map(ou.packed_map(w, h, K, D, model))
+        im = ctx.image()
+        im.upload_distorted(img)
+        np.testing.assert_array_equal(im.raw(), exp)
+        dev = torch.from_numpy(img).cuda()
+        im2 = ctx.image()
+        im2.upload_distorted_device(dev.data_ptr(), w)
+        np.testing.assert_array_equal(im2.raw(), exp)
+        assert (exp != img).mean() > 0.5                     # the lens model does move the pixels
+        # and the rectified frame feeds the same preprocessing as a host-rectified one
+        im.preprocess()
+        ref = ctx.image(exp)
+        ref.preprocess()
+        np.testing.assert_array_equal(im.level(0)[0], ref.level(0)[0])
+        ctx.set_undistort_map(None)
+        with pytest.raises(Exception):
+            im.upload_distorted(img)

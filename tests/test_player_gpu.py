@@ -83,6 +83,11 @@ def test_player_undistorts_a_lens_distorted_stream(tmp_path):
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["error"] == "" and res["frames"] == 80 and res["tracked"] >= 35
     assert 0 <= res["ate_rmse_m"] < 0.03
+    # the run above rectified on the GPU (the player's default); the reference's arrangement -- the reader rectifies on the
+    # host -- must see the same pixels, hence report the same trajectory error to the last digit
+    p1 = subprocess.run(base + ["--host-undistort"], capture_output=True, text=True, timeout=300)
+    res1 = json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res1["error"] == "" and res1["tracked"] == res["tracked"] and res1["ate_rmse_m"] == res["ate_rmse_m"]
     # without the rectification the same stream must do clearly worse (the check above is not vacuous)
     p2 = subprocess.run(base + ["--no-undistort"], capture_output=True, text=True, timeout=300)
     res2 = json.loads([ln for ln in p2.stdout.splitlines() if ln.startswith("{")][-1])

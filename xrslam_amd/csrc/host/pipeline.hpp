@@ -34,6 +34,7 @@
 #include "map.hpp"
 #include "parsac.hpp"
 #include "two_view.hpp"
+#include "undistort_map.hpp"
 
 namespace xrh {
 
@@ -74,6 +75,20 @@ struct Pipeline {
     double noise36[36];
     StageTimes times;
     unsigned long ba_generation = 0;   // BaBuilder instances stamp frames / tracks with it
+    bool undistort_on_device = false;  // frames arrive as the camera recorded them; the KLT context holds the inverse map
+    // cv::undistort / ImageUndistorter on the device from now on (model: "cv_undistort", "radtan", "equidistant"), or off (nullptr)
+    void set_device_undistort(const char *model) {
+        if (!model || !*model) {
+            hip_check(xrhip_klt_set_undistort_map(klt, nullptr), "xrhip_klt_set_undistort_map");
+            undistort_on_device = false;
+            return;
+        }
+        const double K4[4] = {config.K.fx, config.K.fy, config.K.cx, config.K.cy};
+        const std::vector<uint32_t> map = build_undistort_map((int)config.cam_resolution[0], (int)config.cam_resolution[1], K4,
+                                                              config.cam_distortion, 4, model);
+        hip_check(xrhip_klt_set_undistort_map(klt, map.data()), "xrhip_klt_set_undistort_map");
+        undistort_on_device = true;
+    }
     BaDumper ba_dump;                  // XRSLAM_AMD_DUMP_BA=<dir>: freeze the problems handed to xrhip_ba_solve (ba_dump.hpp)
 
     explicit Pipeline(const Config &c) : config(c) {
@@ -118,7 +133,8 @@ struct Pipeline {
         img->t = t;
         img->w = (int)config.cam_resolution[0];
         img->hgt = (int)config.cam_resolution[1];
-        if (device_ptr) hip_check(xrhip_image_upload_device(img->h, gray, stride), "xrhip_image_upload_device");
+        if (undistort_on_device) hip_check(xrhip_image_upload_distorted(img->h, gray, stride, device_ptr ? 1 : 0), "xrhip_image_upload_distorted");
+        else if (device_ptr) hip_check(xrhip_image_upload_device(img->h, gray, stride), "xrhip_image_upload_device");
         else hip_check(xrhip_image_upload(img->h, gray, stride), "xrhip_image_upload");
         return img;
     }

@@ -233,6 +233,28 @@ void impl_push_image_device(Manager &m, const void *gray_dev, int stride, double
     });
 }
 
+void impl_get_camera_config(Manager &m, XRSLAMAmdCameraConfig *out) {
+    if (!out) return;
+    std::memset(out, 0, sizeof(*out));
+    if (!m.sys) return;
+    const xrh::Config &c = m.config;
+    out->time_offset = c.cam_time_offset;
+    out->distortion_flag = (int)c.cam_distortion_flag;
+    for (int i = 0; i < 4; ++i) out->distortion[i] = c.cam_distortion[i];
+    out->intrinsics[0] = c.K.fx;
+    out->intrinsics[1] = c.K.fy;
+    out->intrinsics[2] = c.K.cx;
+    out->intrinsics[3] = c.K.cy;
+    out->resolution[0] = (int)c.cam_resolution[0];
+    out->resolution[1] = (int)c.cam_resolution[1];
+}
+
+void impl_set_device_undistort(Manager &m, const char *model) {
+    if (!m.sys) return;
+    bind_device(m);
+    guarded(m, [&] { m.sys->P.set_device_undistort(model); });
+}
+
 void impl_get_times(Manager &m, XRSLAMAmdTimes *out) {
     if (!out) return;
     std::memset(out, 0, sizeof(*out));
@@ -315,6 +337,8 @@ void XRSLAMAmdSetInitialState(double t, const double q[4], const double p[3], co
 void XRSLAMAmdPushImageDevice(const void *gray_dev, int stride, double timestamp) {
     impl_push_image_device(mgr(), gray_dev, stride, timestamp);
 }
+void XRSLAMAmdGetCameraConfig(XRSLAMAmdCameraConfig *out) { impl_get_camera_config(mgr(), out); }
+void XRSLAMAmdSetDeviceUndistort(const char *model) { impl_set_device_undistort(mgr(), model); }
 void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out) { impl_get_times(mgr(), out); }
 void XRSLAMAmdSetProfiling(int enable) { impl_set_profiling(mgr(), enable); }
 void XRSLAMAmdGetBaStats(void *out, int reset) { impl_get_ba_stats(mgr(), out, reset); }
@@ -358,6 +382,12 @@ void XRSLAMAmdInstanceSetInitialState(XRSLAMAmdInstance *inst, double t, const d
 }
 void XRSLAMAmdInstancePushImageDevice(XRSLAMAmdInstance *inst, const void *gray_dev, int stride, double timestamp) {
     if (inst) impl_push_image_device(inst->m, gray_dev, stride, timestamp);
+}
+void XRSLAMAmdInstanceGetCameraConfig(XRSLAMAmdInstance *inst, XRSLAMAmdCameraConfig *out) {
+    if (inst) impl_get_camera_config(inst->m, out);
+}
+void XRSLAMAmdInstanceSetDeviceUndistort(XRSLAMAmdInstance *inst, const char *model) {
+    if (inst) impl_set_device_undistort(inst->m, model);
 }
 void XRSLAMAmdInstanceGetTimes(XRSLAMAmdInstance *inst, XRSLAMAmdTimes *out) {
     if (inst) impl_get_times(inst->m, out);

@@ -35,6 +35,10 @@ struct xrhip_klt {
     // scratch shared by the images of this sequence
     uint8_t *lut = nullptr;          // tiles*256
     int lut_tiles = 0;
+    // device undistortion (k_undistort): packed 1/32-pixel map [h][w][2] and the frame as the camera recorded it
+    uint32_t *undist_map = nullptr;
+    uint8_t *undist_src = nullptr;
+    bool have_undist = false;
     float *resp = nullptr;           // w*h Harris response
     int *max_key = nullptr;          // 1 int (+ candidate counter next to it)
     int *cand_count = nullptr;
@@ -201,6 +205,8 @@ void xrhip_klt_destroy(xrhip_klt *c) {
     hostprof_dump();
     hipStreamSynchronize(c->stream);
     hipFree(c->lut);
+    hipFree(c->undist_map);
+    hipFree(c->undist_src);
     hipFree(c->resp);
     hipFree(c->max_key);
     hipFree(c->cand);
@@ -277,6 +283,56 @@ int xrhip_image_upload(xrhip_image *im, const uint8_t *gray, int stride) {
     im->have_pyramid = false;
     im->want_detect = false;
     im->detect_seq = 0;
+    return XRHIP_OK;
+}
+
+int xrhip_klt_set_undistort_map(xrhip_klt *c, const uint32_t *map2) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_klt_set_undistort_map: null context");
+    if (!map2) {   // back to "frames arrive rectified"
+        c->have_undist = false;
+        return XRHIP_OK;
+    }
+    const size_t bytes = sizeof(uint32_t) * 2 * (size_t)c->w * c->h;
+    if (!c->undist_map) {
+        XR_HIP(hipMalloc(&c->undist_map, bytes));
+        XR_HIP(hipMalloc(&c->undist_src, (size_t)c->w * c->h));
+    }
+    XR_HIP(hipMemcpyAsync(c->undist_map, map2, bytes, hipMemcpyHostToDevice, c->stream));
+    XR_HIP(hipStreamSynchronize(c->stream));
+    c->have_undist = true;
+    return XRHIP_OK;
+}
+
+int xrhip_image_upload_distorted(xrhip_image *im, const void *gray, int stride, int on_device) {
+    if (!im || !gray || stride < im->ctx->w) return xr_fail(XRHIP_EINVAL, "xrhip_image_upload_distorted: bad arguments");
+    xrhip_klt *c = im->ctx;
+    if (!c->have_undist) return xr_fail(XRHIP_ESTATE, "xrhip_image_upload_distorted: no undistortion map (xrhip_klt_set_undistort_map)");
+    const uint8_t *src = static_cast<const uint8_t *>(gray);
+    int sstride = stride;
+    if (!on_device) {   // one upload of the frame as the camera recorded it; the remap below reads it in HBM
+        XR_HIP(hipMemcpy2DAsync(c->undist_src, c->w, gray, stride, c->w, c->h, hipMemcpyHostToDevice, c->stream));
+        src = c->undist_src;
+        sstride = c->w;
+    }
+    hipLaunchKernelGGL(k_undistort, dim3((c->w + 63) / 64, (c->h + 3) / 4), dim3(256), 0, c->stream, src, sstride,
+                       (const uint2 *)c->undist_map, im->raw, c->w, c->w, c->h);
+    XR_HIP(hipGetLastError());
+    // the host buffer may be reused by the caller as soon as we return (PushImage deep-copies)
+    if (!on_device) XR_HIP(hipStreamSynchronize(c->stream));
+    im->have_raw = true;
+    im->have_pyramid = false;
+    im->want_detect = false;
+    im->detect_seq = 0;
+    return XRHIP_OK;
+}
+
+/* parity aid: the 8-bit frame preprocess() will read (after an upload / the device undistortion) */
+int xrhip_debug_get_raw(xrhip_image *im, uint8_t *out) {
+    if (!im || !out) return xr_fail(XRHIP_EINVAL, "xrhip_debug_get_raw: null argument");
+    if (!im->have_raw) return xr_fail(XRHIP_ESTATE, "xrhip_debug_get_raw: no image uploaded");
+    xrhip_klt *c = im->ctx;
+    XR_HIP(hipMemcpyAsync(out, im->raw, (size_t)c->w * c->h, hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipStreamSynchronize(c->stream));
     return XRHIP_OK;
 }
 

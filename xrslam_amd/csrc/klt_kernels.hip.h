@@ -422,6 +422,28 @@ __global__ __launch_bounds__(1024) void k_harris_select(const HarrisCand *__rest
 }
 
 // ----------------------------------------------------------------------- LK
+// ------------------------------------------------------------------------------------------- undistortion
+// cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) with the 1/32-pixel fixed-point map of cv::undistort /
+// xrslam::extra::ImageUndistorter (host/undistort_map.hpp builds it once per camera): what the reference's dataset
+// reader does to every frame on the host (xrslam-pc/player/src/IO/euroc_dataset_reader.cpp:62-69,
+// tum_dataset_reader.cpp:67-76).  Integer arithmetic only -- 15-bit weights (32 - ay)(32 - ax) * 32 ..., rounding
+// (acc + 2^14) >> 15 -- hence bit-exact against oracle/undistort.py.  One pixel per thread, four per lane row-wise would
+// buy nothing: the launch is bound by its ~5 us of dispatch, the 13 bytes per pixel (8 map, ~4 source, 1 out) stream.
+__global__ __launch_bounds__(256) void k_undistort(const uint8_t *__restrict__ src, int sstride, const uint2 *__restrict__ map,
+                                                   uint8_t *__restrict__ dst, int dstride, int w, int h) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const uint2 m = map[(size_t)y * w + x];
+    const int sx = (int)(short)(m.x & 0xffff), sy = (int)(short)(m.x >> 16), ax = (int)(m.y & 31), ay = (int)((m.y >> 8) & 31);
+    const bool x0 = sx >= 0 && sx < w, x1 = sx + 1 >= 0 && sx + 1 < w, y0 = sy >= 0 && sy < h, y1 = sy + 1 >= 0 && sy + 1 < h;
+    const uint8_t *r0 = src + (ptrdiff_t)min(max(sy, 0), h - 1) * sstride, *r1 = src + (ptrdiff_t)min(max(sy + 1, 0), h - 1) * sstride;
+    const int cx0 = min(max(sx, 0), w - 1), cx1 = min(max(sx + 1, 0), w - 1);
+    const int p00 = (x0 && y0) ? r0[cx0] : 0, p01 = (x1 && y0) ? r0[cx1] : 0, p10 = (x0 && y1) ? r1[cx0] : 0, p11 = (x1 && y1) ? r1[cx1] : 0;
+    const int w00 = (32 - ay) * (32 - ax) * 32, w01 = (32 - ay) * ax * 32, w10 = ay * (32 - ax) * 32, w11 = ay * ax * 32;
+    const int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+    dst[(size_t)y * dstride + x] = (uint8_t)min(255, max(0, v));
+}
+
 constexpr int LK_SLOTS = 7;   // ceil(441 / 64)
 constexpr int LK_W_BITS = 14;
 // Search neighbourhood of the second image staged in LDS once per pyramid level: the 22x22 footprint of the window

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../host/hla.hpp"
+#include "../host/undistort_map.hpp"
 
 namespace xrplayer {
 
@@ -184,6 +185,7 @@ inline GrayImage decode_png(const std::vector<uint8_t> &file) {
         const uint8_t *data = &file[pos + 8];
         if (pos + 12 + len > file.size()) throw std::runtime_error("png: truncated chunk");
         if (!std::memcmp(type, "IHDR", 4)) {
+            if (len != 13) throw std::runtime_error("png: bad IHDR length");   // the fields below are read at fixed offsets
             w = (int)be32(data);
             h = (int)be32(data + 4);
             depth = data[8];
@@ -200,6 +202,7 @@ inline GrayImage decode_png(const std::vector<uint8_t> &file) {
     // them to 8 bits (png_set_strip_16) before any colour conversion
     if (w <= 0 || h <= 0 || (depth != 8 && depth != 16) || interlace != 0)
         throw std::runtime_error("png: only 8- or 16-bit non-interlaced images");
+    if (w > 16384 || h > 16384) throw std::runtime_error("png: implausible image size");   // bounds the allocation below
     int ch = 0;
     if (ctype == 0) ch = 1;
     else if (ctype == 2) ch = 3;
@@ -263,93 +266,21 @@ inline std::vector<uint8_t> read_file(const std::string &path) {
 }
 
 // -------------------------------------------------------------------------------------- undistortion
-// cv::undistort(src, dst, K, D) for the radial-tangential model (k1, k2, p1, p2): inverse map in double, rounded
-// through float32 to 1/32-pixel fixed point, bilinear remap with 15-bit weights, constant-0 border.  K and D pass through float32
-// because the reference builds CV_32F matrices.  The map only depends on (K, D, size) and is cached.
+// cv::undistort(src, dst, K, D) for the radial-tangential model (k1, k2, p1, p2) and the maps of
+// xrslam::extra::ImageUndistorter ("radtan", "equidistant"): the packed 1/32-pixel map of host/undistort_map.hpp (which
+// the library's device remap shares) applied on the host -- what the reference's reader thread does with OpenCV.
 class Undistorter {
   public:
-    Undistorter(int w, int h, const double K4[4], const double D4[4]) : w_(w), h_(h), map_((size_t)w * h) {
-        const double fx = (double)(float)K4[0], fy = (double)(float)K4[1], cx = (double)(float)K4[2], cy = (double)(float)K4[3];
-        const double k1 = (double)(float)D4[0], k2 = (double)(float)D4[1], p1 = (double)(float)D4[2], p2 = (double)(float)D4[3];
-        for (int i = 0; i < h; ++i)
-            for (int j = 0; j < w; ++j) {
-                const double x = (j - cx) / fx, y = (i - cy) / fy;
-                const double x2 = x * x, y2 = y * y, r2 = x2 + y2, xy2 = 2 * x * y;
-                const double kr = 1 + ((0.0 * r2 + k2) * r2 + k1) * r2;
-                const double xd = x * kr + p1 * xy2 + p2 * (r2 + 2 * x2);
-                const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * xy2;
-                // the source position passes through float32 before the 1/32-pixel rounding (cvRound(float * 32.f), like
-                // cv::convertMaps): this form -- not the rounding straight from the double -- reproduces the known answers
-                // of the reference's test_feature_track on its two EuRoC frames (oracle/undistort.py)
-                const long long iu = std::lrintf((float)(fx * xd + cx) * 32.0f), iv = std::lrintf((float)(fy * yd + cy) * 32.0f);
-                Entry &e = map_[(size_t)i * w + j];
-                e.sx = (int)(iu >> 5);
-                e.sy = (int)(iv >> 5);
-                e.ax = (int)(iu & 31);
-                e.ay = (int)(iv & 31);
-            }
-    }
-    // xrslam::extra::ImageUndistorter (xrslam-extra/include/xrslam/extra/image_undistorter.h:14-92), the map the
-    // reference's TUM-VI reader builds (tum_dataset_reader.cpp:67-76, model "equidistant"; "radtan" also defined
-    // there with D = k1 k2 p1 p2 [k3]): distort_pixel() in double, stored as float32 maps, cv::convertMaps to the
-    // 1/32-pixel fixed-point form (the product with INTER_TAB_SIZE is a float product), then the same remap.
+    Undistorter(int w, int h, const double K4[4], const double D4[4]) : w_(w), h_(h), map_(xrh::build_undistort_map(w, h, K4, D4, 4, "cv_undistort")) {}
     Undistorter(int w, int h, const double K4[4], const std::vector<double> &D, const std::string &model)
-        : w_(w), h_(h), map_((size_t)w * h) {
-        if (model != "radtan" && model != "equidistant") throw std::runtime_error("unknown model: " + model);
-        if (D.size() < 4) throw std::runtime_error("distortion model needs at least 4 coefficients");
-        const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
-        for (int i = 0; i < h; ++i)
-            for (int j = 0; j < w; ++j) {
-                const double x = (j - cx) / fx, y = (i - cy) / fy;
-                double u = j, v = i;
-                if (model == "radtan") {
-                    const double k3 = D.size() > 4 ? D[4] : 0.0;
-                    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-                    const double kr = 1.0 + D[0] * r2 + D[1] * r4 + k3 * r6;
-                    u = fx * (x * kr + 2.0 * D[2] * x * y + D[3] * (r2 + 2.0 * x * x)) + cx;
-                    v = fy * (y * kr + 2.0 * D[3] * x * y + D[2] * (r2 + 2.0 * y * y)) + cy;
-                } else {
-                    const double r = std::sqrt(x * x + y * y);
-                    if (r >= 1e-10) {   // the principal point maps to itself
-                        const double th = std::atan(r), th2 = th * th, th4 = th2 * th2, th6 = th2 * th4, th8 = th4 * th4;
-                        const double thd = th * (1 + D[0] * th2 + D[1] * th4 + D[2] * th6 + D[3] * th8);
-                        const double sc = (r > 1e-8) ? thd / r : 1.0;
-                        u = fx * (x * sc) + cx;
-                        v = fy * (y * sc) + cy;
-                    }
-                }
-                const long iu = std::lrintf((float)u * 32.0f), iv = std::lrintf((float)v * 32.0f);
-                Entry &e = map_[(size_t)i * w + j];
-                // convertMaps stores the integer part as int16 (saturating)
-                e.sx = (int)std::min(32767L, std::max(-32768L, iu >> 5));
-                e.sy = (int)std::min(32767L, std::max(-32768L, iv >> 5));
-                e.ax = (int)(iu & 31);
-                e.ay = (int)(iv & 31);
-            }
-    }
+        : w_(w), h_(h), map_(xrh::build_undistort_map(w, h, K4, D.data(), (int)D.size(), model)) {}
     void apply(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride) const {
-        for (int i = 0; i < h_; ++i)
-            for (int j = 0; j < w_; ++j) {
-                const Entry &e = map_[(size_t)i * w_ + j];
-                const int w00 = (32 - e.ay) * (32 - e.ax) * 32, w01 = (32 - e.ay) * e.ax * 32;
-                const int w10 = e.ay * (32 - e.ax) * 32, w11 = e.ay * e.ax * 32;
-                const long long acc = (long long)tap(src, src_stride, e.sy, e.sx) * w00 + (long long)tap(src, src_stride, e.sy, e.sx + 1) * w01 +
-                                      (long long)tap(src, src_stride, e.sy + 1, e.sx) * w10 +
-                                      (long long)tap(src, src_stride, e.sy + 1, e.sx + 1) * w11;
-                const long long v = (acc + (1 << 14)) >> 15;
-                dst[(size_t)i * dst_stride + j] = (uint8_t)std::min(255LL, std::max(0LL, v));
-            }
+        xrh::remap_packed(map_.data(), w_, h_, src, src_stride, dst, dst_stride);
     }
 
   private:
-    struct Entry {
-        int sx, sy, ax, ay;
-    };
-    int tap(const uint8_t *src, int stride, int y, int x) const {
-        return (x >= 0 && x < w_ && y >= 0 && y < h_) ? src[(size_t)y * stride + x] : 0;
-    }
     int w_, h_;
-    std::vector<Entry> map_;
+    std::vector<uint32_t> map_;
 };
 
 // ------------------------------------------------------------------------------------------------- TUM

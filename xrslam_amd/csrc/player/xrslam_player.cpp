@@ -6,7 +6,7 @@
 // is present, reports the ATE.  It links against libxrslam_hip.so only through XRSLAM.h.
 //
 //   xrslam-player --slam configs/euroc_slam.yaml --device configs/euroc_sensor.yaml --euroc <dir>/mav0
-//                 [--out traj.tum] [--bootstrap-frames N] [--max-frames N] [--no-undistort]
+//                 [--out traj.tum] [--bootstrap-frames N] [--max-frames N] [--no-undistort | --host-undistort]
 //
 // The reference player's own command line (main.cpp:57-79) is accepted as well, so its invocations carry over:
 //
@@ -48,7 +48,7 @@ static const TruthRow *nearest_truth(const std::vector<TruthRow> &gt, double t, 
 
 int main(int argc, char **argv) {
     std::map<std::string, std::string> opt;
-    bool undistort = true;
+    bool undistort = true, host_undistort = false;
     // the reference's option names (main.cpp:57-71) map onto ours
     const std::map<std::string, std::string> alias = {{"-sc", "slam"}, {"--slamconfig", "slam"}, {"-dc", "device"},
                                                       {"--deviceconfig", "device"}, {"-lc", "license"}, {"--license", "license"},
@@ -56,6 +56,7 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--no-undistort") undistort = false;
+        else if (a == "--host-undistort") host_undistort = true;   // the reference's arrangement: the reader rectifies on the host
         else if (a == "-p" || a == "--play") continue;
         else if (alias.count(a) && i + 1 < argc) opt[alias.at(a)] = argv[++i];
         else if (a.rfind("--", 0) == 0 && i + 1 < argc) opt[a.substr(2)] = argv[++i];
@@ -77,7 +78,7 @@ int main(int argc, char **argv) {
     }
     if (!opt.count("slam") || !opt.count("device") || !opt.count("euroc")) {
         std::fprintf(stderr, "usage: xrslam-player --slam cfg.yaml --device sensor.yaml --euroc <dir>/mav0 [--out traj.tum] "
-                             "[--csv traj.csv] [--bootstrap-frames N] [--max-frames N] [--no-undistort]\n"
+                             "[--csv traj.csv] [--bootstrap-frames N] [--max-frames N] [--no-undistort | --host-undistort]\n"
                              "   or: xrslam-player -sc cfg.yaml -dc sensor.yaml [--tum traj.tum] [--csv traj.csv] [-p] "
                              "euroc://<dir>/mav0 | tum://<dir>/mav0\n");
         return 2;
@@ -108,6 +109,11 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "XRSLAMCreate failed: %s\n", XRSLAMAmdLastError());
         return 1;
     }
+    // Frames are rectified on the GPU by default (one upload of the frame as recorded, no host pass over the pixels);
+    // --host-undistort keeps the reference's arrangement, where the reader thread runs cv::undistort.  Same pixels
+    // either way: the library builds the same 1/32-pixel map (host/undistort_map.hpp).
+    const bool device_undistort = undistort && cfg.cam_distortion_flag && !host_undistort;
+    if (device_undistort) XRSLAMAmdSetDeviceUndistort(model.c_str());
     size_t seeded = 0;
     for (size_t i = 0; i < cam.size() && i < bootstrap; ++i) {
         const double t = cam[i].t + cfg.cam_time_offset;
@@ -152,8 +158,15 @@ int main(int argc, char **argv) {
                 std::fprintf(stderr, "%s: %s\n", cam[ev.index].filename.c_str(), e.what());
                 break;
             }
+            // the library copies cam0.resolution rows x columns out of the buffer it is handed
+            // (XRSLAMManager.cpp:113-131 does the same with the configured size): a frame of any other size is an error
+            if (img.w != (int)cfg.cam_resolution[0] || img.h != (int)cfg.cam_resolution[1]) {
+                std::fprintf(stderr, "%s: image is %dx%d, the device configuration says %dx%d\n", cam[ev.index].filename.c_str(), img.w,
+                             img.h, (int)cfg.cam_resolution[0], (int)cfg.cam_resolution[1]);
+                break;
+            }
             const uint8_t *pixels = img.px.data();
-            if (undistort && cfg.cam_distortion_flag) {
+            if (undistort && cfg.cam_distortion_flag && !device_undistort) {
                 if (!und) {
                     if (model == "cv_undistort") und.reset(new Undistorter(img.w, img.h, K4, cfg.cam_distortion));
                     else und.reset(new Undistorter(img.w, img.h, K4, std::vector<double>(cfg.cam_distortion, cfg.cam_distortion + 4), model));

@@ -42,6 +42,9 @@ def _bind():
     L.xrhip_klt_set_profiling.argtypes = [vp, C.c_int]
     L.xrhip_klt_get_stats.argtypes = [vp, C.POINTER(KltStats), C.c_int]
     L.xrhip_klt_synchronize.argtypes = [vp]
+    L.xrhip_klt_set_undistort_map.argtypes = [vp, vp]
+    L.xrhip_image_upload_distorted.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.xrhip_debug_get_raw.argtypes = [vp, vp]
     return L
 
 
@@ -89,6 +92,16 @@ class KltContext:
     def synchronize(self):
         check(L().xrhip_klt_synchronize(self._h))
 
+    def set_undistort_map(self, map2):
+        """Packed 1/32-pixel inverse map [h][w][2] uint32 (include/xrslam_hip.h), or None to switch the device
+        undistortion off."""
+        if map2 is None:
+            check(L().xrhip_klt_set_undistort_map(self._h, None))
+            return
+        map2 = np.ascontiguousarray(map2, dtype=np.uint32)
+        assert map2.shape == (self.h, self.w, 2), map2.shape
+        check(L().xrhip_klt_set_undistort_map(self._h, _p(map2)))
+
 
 class HipImage:
     """xrslam::Image on the MI355X."""
@@ -126,6 +139,21 @@ class HipImage:
         gray = np.ascontiguousarray(gray, dtype=np.uint8)
         assert gray.shape == (self.ctx.h, self.ctx.w), gray.shape
         check(L().xrhip_image_upload(self._h, _p(gray), gray.strides[0]))
+
+    def upload_distorted(self, gray):
+        """The frame as the camera recorded it: rectified on the device (KltContext.set_undistort_map)."""
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        assert gray.shape == (self.ctx.h, self.ctx.w), gray.shape
+        check(L().xrhip_image_upload_distorted(self._h, _p(gray), gray.strides[0], 0))
+
+    def upload_distorted_device(self, dev_ptr, stride):
+        check(L().xrhip_image_upload_distorted(self._h, C.c_void_p(dev_ptr), int(stride), 1))
+
+    def raw(self):
+        """The 8-bit frame preprocess() will read (parity aid)."""
+        out = np.empty((self.ctx.h, self.ctx.w), np.uint8)
+        check(L().xrhip_debug_get_raw(self._h, _p(out)))
+        return out
 
     def upload_device(self, dev_ptr, stride):
         check(L().xrhip_image_upload_device(self._h, C.c_void_p(int(dev_ptr)), int(stride)))
