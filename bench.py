@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="s1", choices=["s1", "s2", "s3", "s4"])
+    ap.add_argument("--euroc", default=None, metavar="MAV0_DIR",
+                    help="a real ASL / EuRoC sequence (<...>/MH_01_easy/mav0) instead of the synthetic stream: frames as recorded, "
+                         "rectified on the GPU, self-initialising like the reference; reports ATE against its ground truth")
     ap.add_argument("--sequences-per-gpu", type=int, default=1,
                     help="independent sequences per GPU, one host thread each (instance-scoped entry points)")
     ap.add_argument("--cpu-frames", type=int, default=240,
@@ -167,8 +170,17 @@ def main():
         group.close()
         return
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
     slam_yaml, sensor_yaml = os.path.join(CFG, wl["slam"]), os.path.join(CFG, wl["sensor"])
+    real = None
+    if args.euroc:
+        from xrslam_amd.harness import euroc
+        if S != 1 or world != 1:
+            raise SystemExit("--euroc runs one sequence on one GPU")
+        real = euroc.read_euroc(args.euroc, max_frames=preroll + args.warmup + args.steps + args.host_frames + 1)
+        wl["text"] = ("real EuRoC sequence %s, %dx%d frames as recorded (rectified on the GPU), %d features, %d-keyframe window, "
+                      "self-initialising" % (os.path.basename(os.path.dirname(os.path.normpath(args.euroc))), real["frames"].shape[2],
+                                             real["frames"].shape[1], wl["features"], wl["window"]))
     host_frames = args.host_frames if (S == 1 and world == 1) else 0
     n_frames = preroll + args.warmup + args.steps + host_frames
     seq_kw = dict(w=wl["w"], h=wl["h"])
@@ -179,12 +191,14 @@ def main():
         kw = dict(seq_kw)
         if wl["traj"]:
             kw["traj"] = Trajectory(**wl["traj"])
-        seq = scene.make_sequence(n_frames=n_frames + 1, seed=1 + rank * S + i, **kw)
+        seq = real if real is not None else scene.make_sequence(n_frames=n_frames + 1, seed=1 + rank * S + i, **kw)
         dev = torch.from_numpy(seq["frames"]).cuda()     # inputs resident in HBM before the timed region
         keep.append(dev)
         h, w = seq["frames"].shape[1:]
         sessions.append(runner.Session(_lib.LIB_PATH, seq, slam_yaml=slam_yaml, sensor_yaml=sensor_yaml,
-                                       device_frames=(dev.data_ptr(), h * w, w), instance=(S > 1)))
+                                       device_frames=(dev.data_ptr(), h * w, w), instance=(S > 1),
+                                       init_frames=0 if real is not None else 60,
+                                       device_undistort="cv_undistort" if real is not None else None))
     torch.cuda.synchronize()
     sess, seq = sessions[0], sessions[0].seq
 
@@ -261,7 +275,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "dtype": "u8/i16 images, f32 LK with exact i64 reductions, f64 BA",
-            "data": "synthetic",
+            "data": "synthetic" if real is None else "real (EuRoC)",
             "config": {"workload": wl["text"], "features": wl["features"], "window_keyframes": wl["window"],
                        "sequences_per_gpu": S, "untimed_preroll_frames": preroll},
             "ms_per_ba_iteration": round(ba_ms / iters, 4),
@@ -315,7 +329,7 @@ def main():
             ht = time.perf_counter() - h0
             out["host_image_path"] = {"value": round(host_frames / ht, 3), "unit": "frames/s", "frames": host_frames,
                                       "note": "same stream continued through XRSLAM_SENSOR_CAMERA (host image, PCIe upload inside the call)"}
-        if args.cpu_frames > 40 and world == 1 and S == 1:
+        if args.cpu_frames > 40 and world == 1 and S == 1 and real is None:
             import subprocess
             ref_lib = os.path.join(ROOT, "oracle", "_build", "libxrslam_oracle.so")
             if not os.path.exists(ref_lib):

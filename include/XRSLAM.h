@@ -180,7 +180,8 @@ typedef struct XRSLAMAmdTimes {
      * of which 5-pt RANSAC, 2-pt RANSAC; Frame::detect_keypoints; mirror_frame; localize_newframe; manage_keyframe;
      * track_landmark; refine_window; slide_window; refine_subwindow; initialiser (SfM + alignment attempts);
      * [12], [13] are COUNTS of the RD-VIO filter (parsac.parsac_flag): frames on which judge_track_status separated a
-     * dynamic group, landmark observations it tagged as outliers; rest reserved */
+     * dynamic group, landmark observations it tagged as outliers; [14] COUNTS the constant copies the solver front end made for
+     * prior factors whose reference frame / landmark was also a free parameter of the same solve; [15] reserved */
     double wall_scope[16];
 } XRSLAMAmdTimes;
 void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out);

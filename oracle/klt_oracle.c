@@ -76,6 +76,15 @@ static inline int cv_floor_f(float v) { return (int)floorf(v); }
  * parallel_for_ would spread the same loops).  Results do not depend on it. */
 static int g_threads = 1;
 void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+/* Accumulation of the LK window sums (A11, A12, A22, b1, b2) -- a STUDY switch (tools/lk_accumulation_study.py), the
+ * default 0 is what every test and the HIP kernel use:
+ *   0  exact integers (deviation #1 of DESIGN.md section 5: order-independent, bit-reproducible)
+ *   1  float, one pixel after the other in raster order -- OpenCV's scalar path (lkpyramid.cpp: iA11 += (float)(ixval*ixval))
+ *   2  float in four lanes striding the row (pixels x, x+4, x+8, ... share a lane; the lanes are added at the end, the row
+ *      tail goes to a scalar sum) -- the shape of OpenCV's 128-bit SIMD path
+ * OpenCV's result depends on which of these its build took; the switch measures how far they can move a track. */
+static int g_lk_accum = 0;
+void orc_set_lk_accumulation(int mode) { g_lk_accum = mode; }
 int orc_get_threads(void) { return g_threads; }
 
 /* ------------------------------------------------------------------ CLAHE */
@@ -380,6 +389,8 @@ void orc_lk(const OrcPyramid *A, const OrcPyramid *B, const float *prev_pts, flo
             int iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
             int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             int64_t sA11 = 0, sA12 = 0, sA22 = 0;
+            float fA[3] = {0.f, 0.f, 0.f}, qA[3][4] = {{0.f}};   /* study modes 1 / 2 */
+            const int accum = g_lk_accum;
             for (int y = 0; y < win; ++y) {
                 const uint8_t *s0 = lv_img(I, ipx, ipy + y);
                 const uint8_t *s1 = lv_img(I, ipx, ipy + y + 1);
@@ -395,12 +406,27 @@ void orc_lk(const OrcPyramid *A, const OrcPyramid *B, const float *prev_pts, flo
                     sA11 += (int64_t)ixval * ixval;
                     sA12 += (int64_t)ixval * iyval;
                     sA22 += (int64_t)iyval * iyval;
+                    if (accum == 1 || (accum == 2 && x >= (win & ~3))) {
+                        fA[0] += (float)(ixval * ixval);
+                        fA[1] += (float)(ixval * iyval);
+                        fA[2] += (float)(iyval * iyval);
+                    } else if (accum == 2) {
+                        qA[0][x & 3] += (float)ixval * (float)ixval;
+                        qA[1][x & 3] += (float)ixval * (float)iyval;
+                        qA[2][x & 3] += (float)iyval * (float)iyval;
+                    }
                 }
             }
             n_templates++;
             float A11 = (float)sA11 * FLT_SCALE;
             float A12 = (float)sA12 * FLT_SCALE;
             float A22 = (float)sA22 * FLT_SCALE;
+            if (accum) {
+                for (int q = 0; q < 3; ++q) fA[q] += qA[q][0] + qA[q][1] + qA[q][2] + qA[q][3];
+                A11 = fA[0] * FLT_SCALE;
+                A12 = fA[1] * FLT_SCALE;
+                A22 = fA[2] * FLT_SCALE;
+            }
             float D = A11 * A22 - A12 * A12;
             float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
             if (minEig < min_eig_threshold || D < 1.1920929e-07f) {
@@ -424,6 +450,7 @@ void orc_lk(const OrcPyramid *A, const OrcPyramid *B, const float *prev_pts, flo
                 iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
                 iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
                 int64_t sb1 = 0, sb2 = 0;
+                float fb[2] = {0.f, 0.f}, qb[2][4] = {{0.f}};
                 for (int y = 0; y < win; ++y) {
                     const uint8_t *j0 = lv_img(J, inx, iny + y);
                     const uint8_t *j1 = lv_img(J, inx, iny + y + 1);
@@ -431,11 +458,23 @@ void orc_lk(const OrcPyramid *A, const OrcPyramid *B, const float *prev_pts, flo
                         int diff = descale(j0[x] * iw00 + j0[x + 1] * iw01 + j1[x] * iw10 + j1[x + 1] * iw11, W_BITS - 5) - Ibuf[y * win + x];
                         sb1 += (int64_t)diff * dIbuf[2 * (y * win + x)];
                         sb2 += (int64_t)diff * dIbuf[2 * (y * win + x) + 1];
+                        if (accum == 1 || (accum == 2 && x >= (win & ~3))) {
+                            fb[0] += (float)(diff * dIbuf[2 * (y * win + x)]);
+                            fb[1] += (float)(diff * dIbuf[2 * (y * win + x) + 1]);
+                        } else if (accum == 2) {
+                            qb[0][x & 3] += (float)(diff * dIbuf[2 * (y * win + x)]);
+                            qb[1][x & 3] += (float)(diff * dIbuf[2 * (y * win + x) + 1]);
+                        }
                     }
                 }
                 n_iters++;
                 float b1 = (float)sb1 * FLT_SCALE;
                 float b2 = (float)sb2 * FLT_SCALE;
+                if (accum) {
+                    for (int q = 0; q < 2; ++q) fb[q] += qb[q][0] + qb[q][1] + qb[q][2] + qb[q][3];
+                    b1 = fb[0] * FLT_SCALE;
+                    b2 = fb[1] * FLT_SCALE;
+                }
                 float dx = (A12 * b2 - A22 * b1) * D;
                 float dy = (A12 * b1 - A11 * b2) * D;
                 nx += dx;

@@ -14,7 +14,53 @@ from tests.util import noise_image, warp_affine  # noqa: E402
 from xrslam_amd.harness.dist import RunGroup  # noqa: E402
 
 
+def eleven():
+    """BASELINE config 4 in miniature: 11 independent sequences round-robined over the ranks, each rank driving its share
+    two at a time through instance-scoped entry points (some GPUs of the 8-GPU node carry two sequences), here with the
+    CPU reference build of the library; the only communication is the barrier pair and the metrics reduction."""
+    import threading
+
+    from xrslam_amd.harness import runner, scene
+    lib = os.path.join(ROOT, "oracle", "_build", "libxrslam_oracle.so")
+    g = RunGroup(backend="gloo")
+    mine = g.assign(list(range(11)))
+    n = 46
+    seqs = {k: scene.make_sequence(n_frames=n, seed=20 + k, w=320, h=240, K=(195.0, 194.5, 160.0, 120.0)) for k in mine}
+    sensor = os.path.join(ROOT, "tests", "golden", "small_sensor_320.yaml")
+    g.barrier()
+    t0 = time.perf_counter()
+    stats = {}
+
+    def work(k):
+        s = runner.Session(lib, seqs[k], slam_yaml=os.path.join(ROOT, "configs", "bench_slam_150.yaml"), sensor_yaml=sensor, instance=True)
+        while s.step():
+            pass
+        s.flush()
+        err = s.error()
+        P = np.array(s.poses)
+        s.close()
+        assert not err, err
+        P = P[np.abs(P[:, 4:8]).sum(1) > 0]        # results before the first tracked frame are the all-zero pose (detail.cpp:165-168)
+        idx = np.clip(np.searchsorted(seqs[k]["cam_t"], P[:, 0] - 1e-6), 0, n - 1)
+        stats[k] = (len(P), float(((P[:, 1:4] - seqs[k]["states"][idx, 4:7]) ** 2).sum()))
+    for i in range(0, len(mine), 2):               # two live instances per rank at a time
+        th = [threading.Thread(target=work, args=(k,)) for k in mine[i:i + 2]]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    g.barrier()
+    sec = time.perf_counter() - t0
+    assert sorted(stats) == sorted(mine)
+    out = g.reduce_metrics(n * len(mine), sec, sq_err_sum=sum(v[1] for v in stats.values()), n_poses=sum(v[0] for v in stats.values()))
+    if g.rank == 0:
+        print(json.dumps(dict(out, world=g.world, mine=mine, my_seconds=sec)))
+    g.close()
+
+
 def main():
+    if os.environ.get("DIST_MODE") == "eleven":
+        return eleven()
     g = RunGroup(backend="gloo")
     seqs = g.assign(list(range(5)))            # 5 "sequences" over 2 ranks -> 3 + 2
     g.barrier()

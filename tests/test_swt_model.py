@@ -1,0 +1,103 @@
+"""The C++ sliding-window tracker against an independent Python model of the reference's structural decisions.
+
+The host pipeline (xrslam_amd/csrc/host/pipeline.hpp) restates core/sliding_window_tracker.cpp function by function, and
+until now was only compared with itself (GPU build vs CPU build of the same source).  Here every frame's inputs to
+manage_keyframe -- new frame id, its FT_NO_TRANSLATION tag, the number of mapped landmarks in view -- are logged by the C++
+tracker (XRSLAM_AMD_DUMP_SWT) and replayed through tests/swt_model.py, a 60-line model written from the reference
+(:145-223, :360-393); the two must agree on keyframe / subframe at every frame and on the whole window afterwards (frame ids,
+tags, subframe lists, the merging of rotation-only subframe triples, the keyframe that slides out).  The stream stops
+translating for a while (pure rotation), so the lift / re-attach branches and the triple merge are exercised, not only the
+landmark-count rule.  CPU: the pipeline over the oracle; the GPU build runs the same host source."""
+import json
+import os
+
+import numpy as np
+
+from tests.swt_model import SwtModel
+from xrslam_amd.harness import runner, scene
+from xrslam_amd.harness.trajectory import Trajectory
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "libxrslam_oracle.so")
+SLAM = os.path.join(ROOT, "configs", "bench_slam_150.yaml")
+
+
+class PausingTrajectory(Trajectory):
+    """The S1 figure-eight whose translation freezes between t0 and t1 (smoothly) while the attitude keeps moving."""
+
+    def __init__(self, t0, t1, **kw):
+        super().__init__(**kw)
+        self.t0, self.t1 = t0, t1
+
+    def _warp(self, t):
+        # position runs on a warped clock g(t): g' = 1 outside [t0 - 0.5, t1 + 0.5], 0 inside [t0, t1], C1 in between
+        a, b = self.t0, self.t1
+
+        def ramp(x):   # integral of a smoothstep falling from 1 to 0 over a unit interval
+            x = np.clip(x, 0.0, 1.0)
+            return x - (x ** 3 - 0.5 * x ** 4)
+        g = t if t < a - 0.5 else (a - 0.5) + 0.5 * ramp((t - (a - 0.5)) / 0.5) if t < a else None
+        if g is None:
+            held = (a - 0.5) + 0.5 * ramp(1.0)
+            if t <= b:
+                g = held
+            elif t < b + 0.5:
+                x = (t - b) / 0.5
+                g = held + 0.5 * (np.clip(x, 0, 1) ** 3 - 0.5 * np.clip(x, 0, 1) ** 4)
+            else:
+                g = held + 0.5 * 0.5 + (t - (b + 0.5))
+        return g
+
+    def p(self, t):
+        return super().p(self._warp(t))
+
+
+def _config_values():
+    import yaml
+    with open(SLAM) as fh:
+        y = yaml.safe_load(fh.read().replace("%YAML:1.0", "", 1))   # the OpenCV FileStorage directive the reference's files carry
+    sw = y["sliding_window"]
+    return int(sw["size"]), int(sw["subframe_size"]), int(sw["force_keyframe_landmarks"])
+
+
+def test_tracker_decisions_match_the_reference_model(tmp_path):
+    if not os.path.exists(ORACLE_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    log = str(tmp_path / "swt.jsonl")
+    os.environ["XRSLAM_AMD_DUMP_SWT"] = log
+    try:
+        seq = scene.make_sequence(n_frames=170, seed=1, traj=PausingTrajectory(9.0, 10.6))
+        s = runner.Session(ORACLE_LIB, seq, slam_yaml=SLAM)
+        while s.step():
+            assert not s.error(), s.error()
+        s.flush()
+        n_pose = len(s.poses)
+        s.close()
+    finally:
+        del os.environ["XRSLAM_AMD_DUMP_SWT"]
+    rows = [json.loads(ln) for ln in open(log)]
+    assert len(rows) >= 120 and n_pose >= 120
+    size, subframe_size, force = _config_values()
+    # the model starts from the window the C++ tracker reported after its first frame and replays everything after it
+    model = SwtModel(rows[0]["window"], size, subframe_size, force)
+    seen = dict(keyframe=0, subframe=0, lift_to_keyframe=0, hang_below_lifted=0, merged=0, rotation_frames=0)
+    for k, r in enumerate(rows[1:], start=1):
+        before = json.dumps(model.window)
+        n_sub_before = sum(len(f[2]) for f in model.window)
+        is_kf = model.step(r["frame"], r["no_translation"], r["mapped"])
+        assert is_kf == bool(r["keyframe"]), "frame %d (log line %d): keyframe decision differs; window before: %s" % (r["frame"], k, before)
+        assert model.window == r["window"], "frame %d (log line %d): window differs\nmodel %s\nC++   %s" % (r["frame"], k, model.window, r["window"])
+        seen["keyframe" if is_kf else "subframe"] += 1
+        seen["rotation_frames"] += r["no_translation"]
+        if is_kf and model.window[-1][0] != r["frame"]:
+            if model.window[-1][2] and model.window[-1][2][-1][0] == r["frame"]:
+                seen["hang_below_lifted"] += 1
+        if is_kf and len(model.window) >= 2 and model.window[-1][0] == r["frame"] and model.window[-2][0] != json.loads(before)[-1][0]:
+            seen["lift_to_keyframe"] += 1
+        if not is_kf and sum(len(f[2]) for f in model.window) < n_sub_before + 1:
+            seen["merged"] += 1
+    # the stream must have exercised the branches this test is about
+    assert seen["keyframe"] >= 15 and seen["subframe"] >= 40, seen
+    assert seen["rotation_frames"] >= 10, seen
+    assert seen["hang_below_lifted"] >= 1 and seen["lift_to_keyframe"] >= 1, seen

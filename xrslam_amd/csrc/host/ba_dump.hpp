@@ -58,4 +58,22 @@ struct BaDumper {
     }
 };
 
+// Decision log of the sliding-window tracker (development / test aid): XRSLAM_AMD_DUMP_SWT=<file> makes
+// SlidingWindowTracker::track() append one JSON line per frame -- the inputs of manage_keyframe (new frame id, its
+// FT_NO_TRANSLATION tag, the number of mapped landmarks it observes) and the outcome (keyframe or subframe, the window of
+// keyframes with their subframe lists afterwards).  tests/test_swt_model.py replays the inputs through an independent
+// Python model of core/sliding_window_tracker.cpp:145-223,360-393 and requires the same outcome at every frame.
+struct SwtLogger {
+    FILE *fp = nullptr;
+    SwtLogger() {
+        if (const char *p = std::getenv("XRSLAM_AMD_DUMP_SWT")) fp = std::fopen(p, "w");
+    }
+    ~SwtLogger() {
+        if (fp) std::fclose(fp);
+    }
+    SwtLogger(const SwtLogger &) = delete;
+    SwtLogger &operator=(const SwtLogger &) = delete;
+    bool enabled() const { return fp != nullptr; }
+};
+
 }   // namespace xrh

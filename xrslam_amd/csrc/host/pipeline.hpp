@@ -56,7 +56,7 @@ struct StageTimes {   // seconds, accumulated (inspection slots feature_tracker_
     double scope[16] = {0};
 };
 enum { SC_FT_TRACK = 0, SC_RANSAC_E, SC_RANSAC_R, SC_FT_DETECT, SC_MIRROR, SC_LOCALIZE, SC_MANAGE_KF, SC_TRACK_LANDMARK,
-       SC_REFINE_WINDOW, SC_SLIDE_WINDOW, SC_REFINE_SUBWINDOW, SC_INITIALIZE, SC_RD_JUDGED, SC_RD_OUTLIERS, SC_COUNT };
+       SC_REFINE_WINDOW, SC_SLIDE_WINDOW, SC_REFINE_SUBWINDOW, SC_INITIALIZE, SC_RD_JUDGED, SC_RD_OUTLIERS, SC_CONST_COPIES, SC_COUNT };
 struct WallTimer {   // adds the scope's duration to a StageTimes slot
     double &slot;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -89,6 +89,7 @@ struct Pipeline {
         hip_check(xrhip_klt_set_undistort_map(klt, map.data()), "xrhip_klt_set_undistort_map");
         undistort_on_device = true;
     }
+    SwtLogger swt_log;                 // XRSLAM_AMD_DUMP_SWT=<file>: decisions of the sliding-window tracker (ba_dump.hpp)
     BaDumper ba_dump;                  // XRSLAM_AMD_DUMP_BA=<dir>: freeze the problems handed to xrhip_ba_solve (ba_dump.hpp)
 
     explicit Pipeline(const Config &c) : config(c) {
@@ -454,12 +455,14 @@ class BaBuilder {
         auto [ref, kr] = t->first_keypoint();
         // constants are represented by dedicated constant copies so that a frame/track that is also a
         // parameter elsewhere in the problem is still read as a constant here
+        const_obs_.push_back(obs_tgt_.size());
         push_obs(frame_index(frame, false), const_frame(ref), const_landmark(t), frame->get_keypoint(ki),
                  ref->get_keypoint(kr));
     }
     void add_rotation_prior(Frame *frame, size_t ki) {
         Track *t = frame->get_track(ki);
         auto [ref, kr] = t->first_keypoint();
+        const_rot_.push_back(rot_tgt_.size());
         rot_tgt_.push_back(frame_index(frame, false));
         rot_ref_.push_back(const_frame(ref));
         push3(rot_zt_, frame->get_keypoint(ki));
@@ -471,6 +474,7 @@ class BaBuilder {
         imu_pre_.push_back(&pre);
     }
     void add_preintegration_prior(Frame *fi, Frame *fj, const PreInt &pre) {
+        const_imu_.push_back(imu_i_.size());
         imu_i_.push_back(const_frame(fi));
         imu_j_.push_back(frame_index(fj, false));
         imu_pre_.push_back(&pre);
@@ -495,9 +499,47 @@ class BaBuilder {
             if (!motion_used[f]) fix_[f] |= XRHIP_FIX_MOTION;
         }
     }
+    // The *Prior factors read their reference frame / landmark as constants (reprojection_factor.h:92-123,
+    // rotation_factor.h:23-59, preintegration_factor.h:161-199: the reference object's current value, no Jacobian).  A
+    // constant use shares the object's ordinary entry as long as that entry is constant in this problem; when the same
+    // frame or track is ALSO a free parameter here (a rotation prior whose reference is a sibling subframe), the prior gets
+    // a constant copy of its own, taken at the states the solve starts from.
+    void split_aliased_constants() {
+        std::unordered_map<int, int> fcopy, lcopy;
+        auto frame_copy = [&](int idx) {
+            if (fix_[idx] == (XRHIP_FIX_POSE | XRHIP_FIX_MOTION)) return idx;
+            auto it = fcopy.find(idx);
+            if (it != fcopy.end()) return it->second;
+            const int ni = (int)frames_.size();
+            frames_.push_back(frames_[idx]);
+            fix_.push_back(XRHIP_FIX_POSE | XRHIP_FIX_MOTION);
+            fcopy[idx] = ni;
+            P_.times.scope[SC_CONST_COPIES] += 1.0;   // a COUNT (XRSLAMAmdTimes.wall_scope[14])
+            return ni;
+        };
+        auto landmark_copy = [&](int idx) {
+            if (lfix_[idx]) return idx;
+            auto it = lcopy.find(idx);
+            if (it != lcopy.end()) return it->second;
+            const int ni = (int)tracks_.size();
+            tracks_.push_back(tracks_[idx]);
+            lfix_.push_back(1);
+            lcopy[idx] = ni;
+            P_.times.scope[SC_CONST_COPIES] += 1.0;
+            return ni;
+        };
+        for (size_t o : const_obs_) {
+            obs_ref_[o] = frame_copy(obs_ref_[o]);
+            obs_lm_[o] = landmark_copy(obs_lm_[o]);
+        }
+        for (size_t o : const_rot_) rot_ref_[o] = frame_copy(rot_ref_[o]);
+        for (size_t o : const_imu_) imu_i_[o] = frame_copy(imu_i_[o]);
+    }
+
     bool solve(double *elapsed_device_ms = nullptr) {
         xrhip::HostProfScope hp_s(10, "BaBuilder::solve (all)");
         const Config &c = P_.config;
+        split_aliased_constants();
         drop_unreferenced_blocks();
         const int F = (int)frames_.size(), L = (int)tracks_.size();
         std::vector<double> state(16 * (size_t)F), depth(std::max(L, 1));
@@ -592,9 +634,8 @@ class BaBuilder {
     }
 
   private:
-    // A constant copy is only needed when the object is ALSO a parameter of this problem; the solves the
-    // reference assembles never mix the two roles for the same frame/track, so the plain entry is shared and
-    // simply never promoted to a parameter by this call.
+    // A constant use starts out on the object's ordinary entry (never promoted to a parameter by this call);
+    // split_aliased_constants() gives it a constant copy if that entry turns out to be free in this problem.
     int const_frame(Frame *f) { return frame_index(f, false); }
     int const_landmark(Track *t) { return landmark_index(t, false); }
     void push3(std::vector<double> &v, const V3 &a) {
@@ -617,6 +658,7 @@ class BaBuilder {
     std::vector<int> obs_tgt_, obs_ref_, obs_lm_, rot_tgt_, rot_ref_, imu_i_, imu_j_;
     std::vector<double> obs_zt_, obs_zr_, rot_zt_, rot_zr_, imu_data_;
     std::vector<const PreInt *> imu_pre_;
+    std::vector<size_t> const_obs_, const_rot_, const_imu_;   // factors whose reference side is a constant use
     MargPrior *prior_ = nullptr;
 };
 
@@ -845,13 +887,38 @@ class SlidingWindowTracker {
             if (judge_track_status()) update_track_status();
         }
         localize_newframe();
-        if (manage_keyframe()) {
+        size_t log_id = 0, log_mapped = 0;
+        bool log_nt = false;
+        if (P_.swt_log.enabled()) {   // the inputs manage_keyframe is about to look at
+            const Frame *nf = map->get_frame(map->frame_num() - 1);
+            log_id = nf->id;
+            log_nt = nf->tag(FT_NO_TRANSLATION);
+            for (size_t k = 0; k < nf->keypoint_num(); ++k)
+                if (Track *t = nf->get_track(k))
+                    if (t->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) log_mapped++;
+        }
+        const bool is_kf = manage_keyframe();
+        if (is_kf) {
             P_.times.keyframes++;
             track_landmark();
             refine_window();
             slide_window();
         } else {
             refine_subwindow();
+        }
+        if (P_.swt_log.enabled()) {
+            FILE *fp = P_.swt_log.fp;
+            std::fprintf(fp, "{\"frame\": %zu, \"no_translation\": %d, \"mapped\": %zu, \"keyframe\": %d, \"window\": [", log_id,
+                         log_nt ? 1 : 0, log_mapped, is_kf ? 1 : 0);
+            for (size_t i = 0; i < map->frame_num(); ++i) {
+                const Frame *f = map->get_frame(i);
+                std::fprintf(fp, "%s[%zu, %d, [", i ? ", " : "", f->id, f->tag(FT_NO_TRANSLATION) ? 1 : 0);
+                for (size_t j = 0; j < f->subframes.size(); ++j)
+                    std::fprintf(fp, "%s[%zu, %d]", j ? ", " : "", f->subframes[j]->id, f->subframes[j]->tag(FT_NO_TRANSLATION) ? 1 : 0);
+                std::fprintf(fp, "]]");
+            }
+            std::fprintf(fp, "]}\n");
+            std::fflush(fp);
         }
         speculate_subframes();
         return true;

@@ -37,3 +37,38 @@ def write_euroc(seq, root, n_frames=None):
             vals = (ns(seq["cam_t"][i]),) + tuple(p) + (q[3], q[0], q[1], q[2]) + tuple(v) + tuple(bg) + tuple(ba)
             f.write(("%d" + ",%.17g" * 16 + "\r\n") % vals)
     return root
+
+
+def read_euroc(root, max_frames=None):
+    """root = <dir>/mav0 of an ASL / EuRoC sequence -> the dict harness.scene.make_sequence returns (frames uint8 [n,h,w]
+    AS RECORDED -- rectify with XRSLAMAmdSetDeviceUndistort --, cam_t [s], imu [m,7] = t, gyroscope, accelerometer,
+    states [n,16] ground truth interpolated to the camera times where state_groundtruth_estimate0 exists, else zeros).
+    The layout the reference's reader parses (xrslam-pc/player/src/IO/euroc_dataset_reader.h:28-117)."""
+    from PIL import Image
+    rows = [ln.strip().split(",") for ln in open(os.path.join(root, "cam0", "data.csv")) if ln.strip() and not ln.startswith("#")]
+    if max_frames is not None:
+        rows = rows[:max_frames]
+    cam_t = np.array([int(r[0]) * 1e-9 for r in rows])
+    first = np.asarray(Image.open(os.path.join(root, "cam0", "data", rows[0][1].strip())))
+    frames = np.empty((len(rows),) + first.shape[:2], np.uint8)
+    for i, r in enumerate(rows):
+        im = np.asarray(Image.open(os.path.join(root, "cam0", "data", r[1].strip())))
+        if im.dtype == np.uint16:
+            im = (im >> 8).astype(np.uint8)                      # cv::imread(IMREAD_GRAYSCALE) strips 16-bit samples to their high byte
+        frames[i] = im if im.ndim == 2 else im[..., 0]
+    imu = np.array([[float(v) for v in ln.strip().split(",")[:7]] for ln in open(os.path.join(root, "imu0", "data.csv"))
+                    if ln.strip() and not ln.startswith("#")])
+    imu[:, 0] *= 1e-9
+    imu = imu[imu[:, 0] <= cam_t[-1] + 0.05]
+    states = np.zeros((len(rows), 16))
+    gt_path = os.path.join(root, "state_groundtruth_estimate0", "data.csv")
+    if os.path.exists(gt_path):
+        g = np.array([[float(v) for v in ln.strip().split(",")[:17]] for ln in open(gt_path) if ln.strip() and not ln.startswith("#")])
+        tg = g[:, 0] * 1e-9
+        idx = np.clip(np.searchsorted(tg, cam_t), 1, len(tg) - 1)
+        idx = np.where(np.abs(tg[idx - 1] - cam_t) < np.abs(tg[idx] - cam_t), idx - 1, idx)   # nearest sample (200 Hz)
+        r = g[idx]
+        states[:, 0:3], states[:, 3] = r[:, 5:8], r[:, 4]         # ASL stores the quaternion w first
+        states[:, 4:7], states[:, 7:10], states[:, 10:13], states[:, 13:16] = r[:, 1:4], r[:, 8:11], r[:, 11:14], r[:, 14:17]
+        states[np.abs(tg[idx] - cam_t) > 0.01] = 0.0              # no ground truth near this frame
+    return dict(frames=frames, cam_t=cam_t, imu=imu, states=states)

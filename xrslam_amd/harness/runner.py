@@ -72,6 +72,9 @@ def load(lib_path):
     lib.XRSLAMAmdGetKltStats.restype = None
     lib.XRSLAMAmdGetBaStats.argtypes = [C.c_void_p, C.c_int]
     lib.XRSLAMAmdGetBaStats.restype = None
+    if hasattr(lib, "XRSLAMAmdSetDeviceUndistort"):
+        lib.XRSLAMAmdSetDeviceUndistort.argtypes = [C.c_char_p]
+        lib.XRSLAMAmdSetDeviceUndistort.restype = None
     if hasattr(lib, "XRSLAMAmdInstanceCreate"):   # instance-scoped forms: the instance handle is the first argument
         H = C.c_void_p
         lib.XRSLAMAmdInstanceCreate.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(H), C.POINTER(C.c_void_p)]
@@ -81,7 +84,8 @@ def load(lib_path):
                                 ("PushImageDevice", [C.c_void_p, C.c_int, C.c_double], None),
                                 ("GetTimes", [C.POINTER(XRSLAMAmdTimes)], None), ("SetProfiling", [C.c_int], None),
                                 ("GetBaStats", [C.c_void_p, C.c_int], None), ("GetKltStats", [C.c_void_p, C.c_int], None),
-                                ("GetInitReport", [C.POINTER(XRSLAMAmdInitReport)], None), ("LastError", [], C.c_char_p)):
+                                ("GetInitReport", [C.POINTER(XRSLAMAmdInitReport)], None), ("LastError", [], C.c_char_p),
+                                ("SetDeviceUndistort", [C.c_char_p], None)):
             fn = getattr(lib, "XRSLAMAmdInstance" + name)
             fn.argtypes = [H] + args
             fn.restype = res
@@ -108,7 +112,8 @@ class _Api:
                  "get_ba_stats": ("XRSLAMAmdGetBaStats", "XRSLAMAmdInstanceGetBaStats"),
                  "get_klt_stats": ("XRSLAMAmdGetKltStats", "XRSLAMAmdInstanceGetKltStats"),
                  "get_init_report": ("XRSLAMAmdGetInitReport", "XRSLAMAmdInstanceGetInitReport"),
-                 "last_error": ("XRSLAMAmdLastError", "XRSLAMAmdInstanceLastError")}
+                 "last_error": ("XRSLAMAmdLastError", "XRSLAMAmdInstanceLastError"),
+                 "set_device_undistort": ("XRSLAMAmdSetDeviceUndistort", "XRSLAMAmdInstanceSetDeviceUndistort")}
         for attr, (glob, inst) in names.items():
             setattr(self, attr, getattr(lib, glob) if handle is None else functools.partial(getattr(lib, inst), handle))
 
@@ -118,7 +123,7 @@ class Session:
     instance=True -- an XRSLAMAmdInstance of its own, so that several sessions can live in one process."""
 
     def __init__(self, lib_path, seq, slam_yaml=SLAM_YAML, sensor_yaml=SENSOR_YAML, device_frames=None,
-                 init_frames=60, instance=False):
+                 init_frames=60, instance=False, device_undistort=None):
         self.lib = load(lib_path)
         self.seq = seq
         cfg = C.c_void_p()
@@ -134,6 +139,8 @@ class Session:
             if ok != 1:
                 raise RuntimeError("XRSLAMCreate failed: %s" % self.lib.XRSLAMAmdLastError().decode())
             self.api = _Api(self.lib)
+        if device_undistort:   # frames are pushed as the camera recorded them and rectified on the GPU
+            self.api.set_device_undistort(device_undistort.encode())
         st = seq["states"]
         for i in range(min(init_frames, len(st))):
             s = np.ascontiguousarray(st[i])
