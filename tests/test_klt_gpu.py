@@ -231,9 +231,13 @@ def test_device_undistortion_bit_exact(mods):
     """SURVEY.md 8f-f2: cv::undistort / ImageUndistorter on the device (k_undistort) against oracle/undistort.py -- the
     EuRoC radial-tangential lens at 752x480 and the TUM-VI equidistant fisheye at 512x512, host and HBM-resident input;
     the map comes from the oracle's own arithmetic, not from the product's builder."""
-    import torch
+    import ctypes as C
     from oracle import undistort as ou
     _, klt = mods
+    hip = C.CDLL("/opt/rocm/lib/libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
     cases = [("cv_undistort", 752, 480, (458.654, 457.296, 367.215, 248.375), (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)),
              ("equidistant", 512, 512, (190.97847715128717, 190.9733070521226, 254.93170605935475, 256.8974428996504),
               (0.0034823894022493434, 0.0007150348452162257, -0.0020532361418706202, 0.00020293673591811182))]
@@ -245,10 +249,16 @@ def test_device_undistortion_bit_exact(mods):
         im = ctx.image()
         im.upload_distorted(img)
         np.testing.assert_array_equal(im.raw(), exp)
-        dev = torch.from_numpy(img).cuda()
+        # the same frame already resident in HBM (allocated through the HIP runtime the library itself is linked to: a
+        # second runtime in the process -- torch brings its own copy -- cannot be initialised after the first)
+        dev = C.c_void_p()
+        assert hip.hipMalloc(C.byref(dev), C.c_size_t(img.size)) == 0
+        assert hip.hipMemcpy(dev, C.c_void_p(img.ctypes.data), C.c_size_t(img.size), 1) == 0   # hipMemcpyHostToDevice
         im2 = ctx.image()
-        im2.upload_distorted_device(dev.data_ptr(), w)
+        im2.upload_distorted_device(dev.value, w)
         np.testing.assert_array_equal(im2.raw(), exp)
+        ctx.synchronize()
+        assert hip.hipFree(dev) == 0
         assert (exp != img).mean() > 0.5                     # the lens model does move the pixels
         # and the rectified frame feeds the same preprocessing as a host-rectified one
         im.preprocess()
