@@ -66,6 +66,9 @@ struct xrhip_ba {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
     xrhip_ba_stats stats = {0, 0, 0.0, 0, 0.0, 0};
     const TinyArgs *tiny_args = nullptr;   // device address of the staged argument block (kb_tiny)
+    const uint4 *stage_src = nullptr;      // the staged problem: pinned host block (device-visible address) -> device arena
+    uint4 *stage_dst = nullptr;
+    size_t stage_n16 = 0;
     double *h_out = nullptr;  // pinned readback (states + depths)
     size_t h_out_cap = 0;
     int lds_limit = 150 * 1024;
@@ -122,8 +125,17 @@ static int validate(const xrhip_ba_problem *P) {
     return XRHIP_OK;
 }
 
+static int launch_stage_copy(xrhip_ba *c) {
+    const int blocks = (int)std::min<size_t>((c->stage_n16 + 255) / 256, 128);
+    hipLaunchKernelGGL(kb_stage, dim3(blocks), dim3(256), 0, c->stream, c->stage_src, c->stage_dst, c->stage_n16);
+    XR_HIP(hipGetLastError());
+    return XRHIP_OK;
+}
+
 // Packs the problem + gather indices into the input arena, carves the workspace and fills dims/ptrs.
-static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPtrs &p, Ext &cam, Ext &imu) {
+// defer_copy: do not queue the kb_stage launch; the caller hands the copy (c->stage_src / stage_dst / stage_n16) to a
+// kernel that pulls the problem itself before it starts (kb_chain), or calls launch_stage_copy().
+static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPtrs &p, Ext &cam, Ext &imu, bool defer_copy = false) {
     d.F = P->n_frames;
     d.n = 15 * d.F;
     d.PF = round_up(6 * d.F, 16);
@@ -372,10 +384,10 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     {
         char *host_dev = nullptr;   // device-visible address of the pinned staging block
         XR_HIP(hipHostGetDevicePointer((void **)&host_dev, A.host, 0));
-        const size_t n16 = (in_bytes + 15) / 16;
-        const int blocks = (int)std::min<size_t>((n16 + 255) / 256, 128);
-        hipLaunchKernelGGL(kb_stage, dim3(blocks), dim3(256), 0, c->stream, (const uint4 *)host_dev, (uint4 *)A.dev, n16);
-        XR_HIP(hipGetLastError());
+        c->stage_src = (const uint4 *)host_dev;
+        c->stage_dst = (uint4 *)A.dev;
+        c->stage_n16 = (in_bytes + 15) / 16;
+        if (!defer_copy) return launch_stage_copy(c);
     }
     return XRHIP_OK;
 }
@@ -624,8 +636,12 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     const auto t_begin = std::chrono::steady_clock::now();
     {
         HostProfScope hp(8, "ba_solve: stage_problem");
-        rc = stage_problem(c, P, d, p, cam, imu);
+        rc = stage_problem(c, P, d, p, cam, imu, true);
     }
+    if (rc) return rc;
+    size_t chain_lds = 0;
+    const bool use_chain = chain(d, (size_t)c->lds_limit, &chain_lds);
+    rc = launch_stage_copy(c);
     if (rc) return rc;
     HostProfScope hp_rounds(9, "ba_solve: rounds (launch+wait)");
     if (!d.nla) d.lm_rows = 0;
@@ -634,10 +650,9 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16)), dim3(256), 0, s, d.np, p.pS, p.pLam);
     bool done = false, relinearise = true;
     int mode = 1, iter_seen = 0;
-    size_t chain_lds = 0;
-    if (chain(d, (size_t)c->lds_limit, &chain_lds)) {   // the whole solve in one launch, LDS-resident (kb_chain)
+    if (use_chain) {   // the whole solve in one launch, LDS-resident (kb_chain)
         const int seq = ++c->seq;
-        hipLaunchKernelGGL(kb_chain, dim3(1), dim3(256), chain_lds, s, c->tiny_args, seq, 4 * (P->max_iterations + 8));
+        hipLaunchKernelGGL(kb_chain, dim3(1), dim3(CHAIN_THREADS), chain_lds, s, c->tiny_args, seq, 4 * (P->max_iterations + 8));
         XR_HIP(hipGetLastError());
         rc = wait_mailbox(c, seq);
         if (rc) return rc;

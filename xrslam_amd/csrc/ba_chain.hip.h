@@ -26,6 +26,12 @@ constexpr int CHAIN_MAX_NI = 8;
 constexpr int CHAIN_MAX_F = 64;
 constexpr int CHAIN_MAX_OBS = 1024; // reprojection + rotation factors: four per thread
 constexpr int CHAIN_MAX_FREE = 6;
+// Four worker wavefronts.  (A fifth "helper" wavefront that runs the serial SO(3) chains of the IMU factors BESIDE the
+// workers' reprojection factors is written below and selected by 320 here -- but two wavefronts then share a SIMD, the
+// register budget halves to 256 and this kernel, which holds 483, spills 1.1 KB per lane; measured slower.  Kept for a
+// leaner kernel.)
+constexpr int CHAIN_THREADS = 256;
+constexpr bool CHAIN_HELPER = CHAIN_THREADS > 256;
 
 #ifdef XRHIP_KPROF
 #define CPROF(slot)                                   \
@@ -77,7 +83,10 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
     return L;
 }
 
-__global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ args, int seq, int max_rounds) {
+// (Tried: this workgroup pulling the staged problem from the pinned host arena itself instead of a kb_stage launch in
+// front of it -- one compute unit reads the host link slower than kb_stage's 128 workgroups: localize_newframe
+// 0.132 -> 0.139 ms per frame, profiles/r02_ab_variants.md.)
+__global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__restrict__ args, int seq, int max_rounds) {
     const BaDims &d = args->d;
     const BaPtrs &p = args->p;
     const Ext &cam = args->cam, &imu = args->imu;
@@ -89,7 +98,15 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
     __shared__ int s_fail;
     __shared__ int s_free[CHAIN_MAX_FREE], s_slot[CHAIN_MAX_F], s_nfree;
     __shared__ BaCtl s_ctl;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Threads 0..255 are the workers: every strided loop, block sum and wavefront-indexed loop below runs on them exactly
+    // as it would in a 256-thread workgroup (same thread -> element mapping as the generic bodies).  With CHAIN_HELPER a
+    // fifth wavefront evaluates the IMU factors (lane k: factor k) while the workers evaluate the reprojection factors; it
+    // takes part in every barrier and collective and contributes zeros to the sums.  Without it, threads 0..NI-1 do.
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool worker = tid < 256;
+    const bool imu_lane = CHAIN_HELPER ? (!worker && lane < d.NI) : (tid < d.NI);
+    const int imu_k = CHAIN_HELPER ? lane : tid;
+    const int wtid = worker ? tid : (1 << 30), wave = worker ? (tid >> 6) : (1 << 28);
     constexpr int nt = 256;
     const int F = d.F, n = d.n, na = d.na, NI = d.NI, M = d.M, MR = d.MR;
 #ifdef XRHIP_KPROF
@@ -126,10 +143,10 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int a = tid + nt * m;
-        act[m] = a < n ? p.act_inv[a] : -1;
+        act[m] = (worker && a < n) ? p.act_inv[a] : -1;
     }
-    for (int e = tid; e < 16 * F; e += nt) X[e] = p.state[e];
-    for (int e = tid; e < 6 * NI; e += nt) bref[e] = p.bias_ref[e];
+    for (int e = wtid; e < 16 * F; e += nt) X[e] = p.state[e];
+    for (int e = wtid; e < 6 * NI; e += nt) bref[e] = p.bias_ref[e];
     __syncthreads();
     CPROF(0);   // set-up: control block, states, index slots
 
@@ -140,10 +157,10 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
             // ---------------- linearisation: IMU factors on the lanes of wavefront 0 (one factor each, the SO(3) chains
             // advance in lockstep), the observations on everybody, thread t taking o = t, t + 256, ...
             double *scr = A;   // [NI][IMU_SCR]
-            for (int e = tid; e < NI * IMU_SCR; e += nt) scr[e] = 0.0;
+            for (int e = wtid; e < NI * IMU_SCR; e += nt) scr[e] = 0.0;
             __syncthreads();
-            if (tid < NI) {
-                const int k = tid, fi = p.imu_i[k], fj = p.imu_j[k];
+            if (imu_lane) {
+                const int k = imu_k, fi = p.imu_i[k], fj = p.imu_j[k];
                 if (!(p.fix[fi] == 3 && p.fix[fj] == 3)) {
                     double *rw = scr + k * IMU_SCR, *Ji = rw + 15, *Jj = rw + 240;
                     const FState si = load_state(X + 16 * fi), sj = load_state(X + 16 * fj);
@@ -157,14 +174,14 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
                 }
             }
             double cost_part = 0.0;   // this thread's share of the total cost, in sum_cost_block's order
-            for (int o = tid; o < M; o += nt) {
+            for (int o = wtid; o < M; o += nt) {
                 double rec[OREC];
                 const double co = obs_eval(d, p, o, X, p.depth, cam, sx_, sy_, true, rec);
                 cost_part += co;
 #pragma unroll
                 for (int i = 0; i < OREC; ++i) p.orec[(size_t)o * OREC + i] = rec[i];
             }
-            for (int o = tid; o < MR; o += nt) {
+            for (int o = wtid; o < MR; o += nt) {
                 double rec[RREC];
                 const double co = rot_eval(d, p, o, X, cam, sx_, sy_, true, rec);
                 cost_part += co;
@@ -213,7 +230,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
                 double acc[27];
 #pragma unroll
                 for (int i = 0; i < 27; ++i) acc[i] = 0.0;
-                for (int it = s0 + tid; it < s1; it += nt) {
+                for (int it = s0 + wtid; it < s1; it += nt) {
                     const int code = p.pair_items[it];
                     const double *rec = p.orec + (size_t)(code >> 1) * OREC + ((code & 1) ? 12 : 0);
                     double j[12];
@@ -231,7 +248,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
                 }
 #pragma unroll
                 for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
-                if (lane == 0)
+                if (lane == 0 && worker)
 #pragma unroll
                     for (int i = 0; i < 27; ++i) s_vis[wave][i] = acc[i];
                 __syncthreads();
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
             // ---------------- assembly of the free x free entries (packed lower triangle) and of the gradient:
             // reprojection block, rotation priors, the IMU factor ending at the frame, the one starting at it --
             // assemble_item's order
-            for (int e = tid; e < na * (na + 1) / 2 + na; e += nt) {
+            for (int e = wtid; e < na * (na + 1) / 2 + na; e += nt) {
                 int i, j;
                 const bool want_g = e >= na * (na + 1) / 2;
                 if (want_g) {
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
             }
             CPROF(4);   // assembly
             // ---------------- total cost (sum_cost_block: observations, rotation factors, IMU factors k = tid, ...)
-            for (int k = tid; k < NI; k += nt) cost_part += wr[16 * k + 15];
+            for (int k = wtid; k < NI; k += nt) cost_part += wr[16 * k + 15];
             const double ctot = block_sum(cost_part, scratch);
             if (tid == 0) {
                 c->x_cost = ctot + 0.0;   // + the prior's cost: there is none
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
         }
         // -------------------- preparation (prepare_block): Jacobi scales at the first linearisation, dogleg diagonal
         const double mu = c->mu;
-        for (int i = tid; i < na; i += nt) {
+        for (int i = wtid; i < na; i += nt) {
             const double h = Hp[i * (i + 1) / 2 + i];
             if (c->first) sp[i] = 1.0 / (1.0 + sqrt(h));
             const double s = sp[i];
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
         }
         __syncthreads();
         // -------------------- reduced system S = sp H sp + mu D^2 (packed, the rhs as row na) and Q(g~, g~)
-        for (int e = tid; e < na * (na + 1) / 2; e += nt) {
+        for (int e = wtid; e < na * (na + 1) / 2; e += nt) {
             int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
             while (i * (i + 1) / 2 > e) --i;
             while ((i + 1) * (i + 2) / 2 <= e) ++i;
@@ -346,7 +363,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
             A[e] = v;
         }
         double *y = A + na * (na + 1) / 2;
-        for (int i = tid; i < na; i += nt) y[i] = gp[i] * sp[i];
+        for (int i = wtid; i < na; i += nt) y[i] = gp[i] * sp[i];
         double qacc = 0;
         for (int i = wave; i < na; i += 4) {
             double t = 0;
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
         if (lin_ok) {
             trsv_lower_t(A, na, y);
             int bad = 0;
-            for (int i = tid; i < na; i += nt) {
+            for (int i = wtid; i < na; i += nt) {
                 const double ya = y[i];
                 gn[i] = -Dg[i] * ya;
                 grad[i] = gs[i] / Dg[i];
@@ -399,12 +416,12 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
         if (mode == 1) {
             // FinalizeIterationAndCheckIfMinimizerCanContinue of the iteration that produced this x: the IMU factors
             // read their bias reference from the user state, refreshed by the StateUpdatingCallback
-            for (int k = tid; k < NI; k += nt) {
+            for (int k = wtid; k < NI; k += nt) {
                 const double *sti = X + 16 * p.imu_i[k];
                 for (int i = 0; i < 6; ++i) bref[6 * k + i] = sti[10 + i];
             }
             double s2 = 0;
-            for (int f = tid; f < F; f += nt) {
+            for (int f = wtid; f < F; f += nt) {
                 const double *x = X + 16 * f;
                 if (pose_free(p.fix[f]))
                     for (int k = 0; k < 7; ++k) s2 += x[k] * x[k];
@@ -477,7 +494,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
                 mcc = dogleg_model_change(t, ca, cb, red2[1]);
                 __syncthreads();
                 // candidate states (every frame, like the generic path: constant frames are copies)
-                for (int f = tid; f < F; f += nt) {
+                for (int f = wtid; f < F; f += nt) {
                     double d15[15];
                     for (int k = 0; k < 15; ++k) {
                         const int i = p.act_inv[15 * f + k];
@@ -487,9 +504,10 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
                 }
                 __syncthreads();
                 double red[2] = {0, 0};   // cost, |x - candidate|^2
-                for (int o = tid; o < M; o += nt) red[0] += obs_eval(d, p, o, CS, p.depth, cam, sx_, sy_, false, nullptr);
-                for (int o = tid; o < MR; o += nt) red[0] += rot_eval(d, p, o, CS, cam, sx_, sy_, false, nullptr);
-                for (int k = tid; k < NI; k += nt) {
+                for (int o = wtid; o < M; o += nt) red[0] += obs_eval(d, p, o, CS, p.depth, cam, sx_, sy_, false, nullptr);
+                for (int o = wtid; o < MR; o += nt) red[0] += rot_eval(d, p, o, CS, cam, sx_, sy_, false, nullptr);
+                if (imu_lane) {   // one IMU factor per lane
+                    const int k = imu_k;
                     const int fi = p.imu_i[k], fj = p.imu_j[k];
                     double r15[15];
                     if (p.fix[fi] == 3 && p.fix[fj] == 3) {
@@ -502,7 +520,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
                     for (int q = 0; q < 15; ++q) raw[15 * k + q] = r15[q];
                 }
                 __syncthreads();
-                for (int it = tid; it < NI * 15; it += nt) {
+                for (int it = wtid; it < NI * 15; it += nt) {
                     const int k = it / 15, i = it - 15 * k;
                     const double *S = p.imu_data + (size_t)k * XRHIP_IMU_DIM + 56 + 15 * i;
                     double acc = 0;
@@ -510,7 +528,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
                     for (int j = 0; j < 15; ++j) acc += S[j] * raw[15 * k + j];
                     red[0] += 0.5 * acc * acc;
                 }
-                for (int f = tid; f < F; f += nt) {
+                for (int f = wtid; f < F; f += nt) {
                     const double *a = X + 16 * f, *b = CS + 16 * f;
                     double acc = 0;
                     if (pose_free(p.fix[f]))
@@ -533,7 +551,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
             if (trial_decide(t, 0, mcc, cost, dn2, step_norm)) accepted = 1;
         }
         if (accepted) {
-            for (int e = tid; e < 16 * F; e += nt) X[e] = CS[e];
+            for (int e = wtid; e < 16 * F; e += nt) X[e] = CS[e];
         }
         if (tid == 0) trial_store(c, t);
         __syncthreads();
@@ -554,7 +572,7 @@ __global__ __launch_bounds__(256) void kb_chain(const TinyArgs *__restrict__ arg
         }
     }
     // -------------------- publication: states back to the arena, control block + states + sequence number to the host
-    for (int e = tid; e < 16 * F; e += nt) p.state[e] = X[e];
+    for (int e = wtid; e < 16 * F; e += nt) p.state[e] = X[e];
     __syncthreads();
     if (tid == 0) {
         c->status = (st == ST_DONE) ? ST_DONE : -1;   // -1: not terminated within the round budget, the host reports an error
