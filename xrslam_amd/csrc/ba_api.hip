@@ -491,7 +491,7 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
     XR_HIP(hipGetLastError());
     if (c->profiling) XR_HIP(hipEventRecord(e1, s));   // the events bracket kb_solve_try alone (what rocprofv3 reports for it)
     if (wide_first(d)) {   // the first trial batch rides right behind the solve: no host round trip in between
-        const size_t wlds = sizeof(double) * (size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np);
+        const size_t wlds = sizeof(double) * ((size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np) + (size_t)4 * WIDE_B * 257);
         hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, s, d, p, cam, imu, sx, sy, seq, 1, mode);
         XR_HIP(hipGetLastError());
     }
@@ -578,6 +578,7 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
     XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)kb_chain, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+    XR_HIP(hipFuncSetAttribute((const void *)kb_trials_wide, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_chol, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     // pre-size for the advertised maxima
@@ -691,7 +692,7 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
         int st = c->h_ctl->status;
         for (int wguard = 0; st == ST_NEED_TRIALS && wguard < 64; ++wguard) {   // run of rejected trials, 8 per launch
             const int wseq = ++c->seq;
-            const size_t wlds = sizeof(double) * (size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np);
+            const size_t wlds = sizeof(double) * ((size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np) + (size_t)4 * WIDE_B * 257);
             hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, s, d, p, cam, imu, sx, sy, wseq, 0, 0);
             XR_HIP(hipGetLastError());
             rc = wait_mailbox(c, wseq);

@@ -377,6 +377,61 @@ __device__ __forceinline__ void lin_imu_item(const BaDims &d, const BaPtrs &p, c
     wave_sync();   // scr may be reused by the caller for the next factor
 }
 
+// One WORKGROUP (four wavefronts) per IMU factor: lane 0 of every wavefront runs the raw residual (they all need its
+// rotation part), then one of the four independent parts of the raw Jacobians; the 15x15 whitening of the residual and of
+// both Jacobians is then one pass over the 256 threads.  Same expressions, entry by entry, as lin_imu_item -- which gave
+// a factor ONE wavefront, i.e. one lane for ~25 us of dependent SO(3) algebra, the long pole of kb_lin_all.
+// scr: IMU_SCR doubles of LDS owned by the workgroup.
+__device__ __forceinline__ void lin_imu_block(const BaDims &d, const BaPtrs &p, const Ext &imu, int k, double *scr) {
+    double *raw = scr, *Ji = scr + 15, *Jj = scr + 240;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = p.imu_i[k], fj = p.imu_j[k];
+    const double *data = p.imu_data + (size_t)k * XRHIP_IMU_DIM;
+    const bool active = !(p.fix[fi] == 3 && p.fix[fj] == 3);
+    for (int i = tid; i < 450; i += 256) Ji[i] = 0.0;   // Ji and Jj are contiguous
+    __syncthreads();
+    if (lane == 0 && active) {
+        const FState si = load_state(p.state + 16 * fi), sj = load_state(p.state + 16 * fj);
+        const ImuRec pre = load_imu(data);
+        const V3 bg0 = v3(p.bias_ref[6 * k], p.bias_ref[6 * k + 1], p.bias_ref[6 * k + 2]);
+        const V3 ba0 = v3(p.bias_ref[6 * k + 3], p.bias_ref[6 * k + 4], p.bias_ref[6 * k + 5]);
+        double r15[15];
+        imu_raw_residual(si, sj, pre, bg0, ba0, imu, r15);
+        if (wave == 0)
+            for (int i = 0; i < 15; ++i) raw[i] = r15[i];
+        imu_raw_jacobians_part(wave, si, sj, pre, bg0, ba0, imu, v3(r15[0], r15[1], r15[2]), Ji, Jj, p.fix[fi] != 3, p.fix[fj] != 3);
+    }
+    __syncthreads();
+    const double *S = data + 56;
+    if (wave == 0) {
+        double cost = 0.0;
+        if (lane < 15) {
+            double s = 0;
+            if (active)
+                for (int j = 0; j < 15; ++j) s += S[15 * lane + j] * raw[j];
+            p.imu_r[15 * k + lane] = s;
+            cost = 0.5 * s * s;
+        }
+        cost = wave_sum(cost);
+        if (lane == 0) p.imu_cost[k] = cost;
+    }
+    if (tid < 225) {
+        const int e = tid, i = e / 15, c = e - 15 * i;
+        double a = 0, b = 0;
+        if (active) {
+            // constant blocks contribute no columns
+            const bool col_i = c < 6 ? pose_free(p.fix[fi]) : motion_free(p.fix[fi]);
+            const bool col_j = c < 6 ? pose_free(p.fix[fj]) : motion_free(p.fix[fj]);
+            if (col_i)
+                for (int j = 0; j < 15; ++j) a += S[15 * i + j] * Ji[15 * j + c];
+            if (col_j)
+                for (int j = 0; j < 15; ++j) b += S[15 * i + j] * Jj[15 * j + c];
+        }
+        p.imu_Ji[(size_t)225 * k + e] = a;
+        p.imu_Jj[(size_t)225 * k + e] = b;
+    }
+}
+
 // ------------------------------------------------------------------------ prior
 // delta and Jr^-1 of prior frame i at `state`
 __device__ __forceinline__ void prior_delta(const BaPtrs &p, int i, const double *state, double *delta15, M3 *Jq) {
@@ -1553,12 +1608,12 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
 // trust-region round are small; independent phases therefore share a launch (block ranges select the role), and
 // consecutive single-workgroup phases run back to back in one kernel.
 
-// all four factor families at once: [obs | rot | imu (4 factors per block) | prior (1 block)]
+// all four factor families at once: [obs | rot | imu (one factor per block) | prior (1 block)]
 __global__ __launch_bounds__(256) void kb_lin_all(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy) {
     extern __shared__ double sh[];   // np doubles (prior role)
-    __shared__ double scr[4][IMU_SCR];
+    __shared__ double scr[IMU_SCR];
     __shared__ double scratch[8];
-    const int nbo = (d.M + 255) / 256, nbr = (d.MR + 255) / 256, nbi = (d.NI + 3) / 4;
+    const int nbo = (d.M + 255) / 256, nbr = (d.MR + 255) / 256, nbi = d.NI;
     int blk = blockIdx.x;
     if (blk < nbo) {
         const int o = blk * 256 + threadIdx.x;
@@ -1573,15 +1628,16 @@ __global__ __launch_bounds__(256) void kb_lin_all(BaDims d, BaPtrs p, Ext cam, E
     }
     blk -= nbr;
     if (blk < nbi) {
-        const int wave = threadIdx.x >> 6, k = 4 * blk + wave;
-        if (k < d.NI) lin_imu_item(d, p, imu, k, threadIdx.x & 63, scr[wave]);
+        lin_imu_block(d, p, imu, blk, scr);
         return;
     }
     lin_prior_block(d, p, sh, scratch);
 }
-__host__ __device__ __forceinline__ int lin_all_blocks(int M, int MR, int NI) { return (M + 255) / 256 + (MR + 255) / 256 + (NI + 3) / 4 + 1; }
+__host__ __device__ __forceinline__ int lin_all_blocks(int M, int MR, int NI) { return (M + 255) / 256 + (MR + 255) / 256 + NI + 1; }
 
 // per-landmark rows and per-frame-pair reprojection blocks: [Lp landmarks | F*F pairs], one wavefront each
+// (tried: 64 landmarks per block, one THREAD walking a landmark's observation list -- no butterflies, but ~8 dependent
+// round trips to L2 per landmark instead of one: 21.7 -> 24.1 us, profiles/r02_ab_variants.md)
 // (no landmark rows are needed when every landmark is constant: nla == 0)
 __global__ __launch_bounds__(64) void kb_landmark_vision(BaDims d, BaPtrs p) {
     __shared__ double red[VIS_RED];
@@ -1758,9 +1814,11 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
     }
     // IMU factors: raw residual + 15x15 whitening per (factor, candidate), taken by the blocks from the far end of the
     // grid so that they do not pile onto the threads that already hold a reprojection pair
-    for (int e = (G * nt - 1 - gtid); e < WIDE_B * d.NI; e += gnt) {
+    // (one WAVEFRONT per (factor, candidate) pair: lane 0 runs the SO(3) chain of the raw residual, fifteen lanes whiten
+    // it -- as a single thread the 225-term whitening doubled the chain, and these pairs are the last to finish)
+    for (int e = (G * nw - 1 - (blk * nw + wave)); e < WIDE_B * d.NI; e += G * nw) {
         const int k = e / d.NI, f = e - k * d.NI;
-        const double cst = imu_cost_eval(p, f, cand + (size_t)k * 16 * d.F, imu);
+        const double cst = imu_cost_wave(p, f, cand + (size_t)k * 16 * d.F, imu, lane);   // in lane 0, zero elsewhere
 #pragma unroll
         for (int kk = 0; kk < WIDE_B; ++kk)
             if (kk == k) acc[4 * kk] += cst;
@@ -1780,11 +1838,28 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
             if (lane == 0) acc[4 * k] += 0.5 * r * r;
         }
     }
-    // ---- block partial sums -> global; the last block to finish reduces and decides
-    block_sum_n<4 * WIDE_B>(acc, scratch);
-    if (tid == 0) {
+    // ---- block partial sums -> global; the last block to finish reduces and decides.  The 32 sums of a block go through
+    // an LDS tile [32][257] (every thread parks its terms as a column; 128 threads add up a quarter row each, 32 combine the
+    // quarters): 32 butterfly reductions of doubles -- 12 ds_bpermute each -- took a fifth of this kernel.
+    {
+        double *tile = wl + (size_t)WIDE_B * (16 * d.F + d.np);
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4 * WIDE_B; ++q) p.wide_part[(size_t)blk * 4 * WIDE_B + q] = acc[q];
+        for (int q = 0; q < 4 * WIDE_B; ++q) tile[q * 257 + tid] = acc[q];
+        __syncthreads();
+        if (tid < 4 * 4 * WIDE_B) {
+            const int q = tid >> 2, w4 = tid & 3;
+            const double *row = tile + q * 257 + 64 * w4;
+            double s2 = 0.0;
+            for (int i = 0; i < 64; ++i) s2 += row[i];
+            scratch[tid] = s2;
+        }
+        __syncthreads();
+        if (tid < 4 * WIDE_B)
+            p.wide_part[(size_t)blk * 4 * WIDE_B + tid] = ((scratch[4 * tid] + scratch[4 * tid + 1]) + scratch[4 * tid + 2]) + scratch[4 * tid + 3];
+    }
+    __syncthreads();
+    if (tid == 0) {
         __threadfence();
         const unsigned ticket = atomicAdd(&c->wide_ticket, 1u);
         s_last = (ticket == (unsigned)G - 1u) ? 1 : 0;

@@ -403,6 +403,59 @@ XD void imu_raw_jacobians(const FState &fi, const FState &fj, const ImuRec &pre,
     put33(Ji, 12, 12, -I3);
 }
 
+// The same Jacobians in four independent parts (part = 0..3), for four wavefronts working on ONE factor: every block
+// of imu_raw_jacobians is produced by exactly one part, with the same expression -- the union of the four calls writes
+// what the single call writes.  Part 0 and 1 carry the two long chains (right Jacobian + its inverse; expmap + a second
+// right Jacobian + three products), part 2 and 3 the rotation blocks.
+XD void imu_raw_jacobians_part(int part, const FState &fi, const FState &fj, const ImuRec &pre, V3 bg0, V3 ba0, const Ext &imu,
+                               V3 rq, double *Ji, double *Jj, bool need_i, bool need_j) {
+    const V3 gravity = v3(0.0, 0.0, -9.80665);
+    const double dt = pre.dt;
+    const M3 I3 = m3_identity();
+    if (part == 0) {
+        const M3 Jr_inv = inverse3(right_jacobian(rq));
+        if (need_j) put33(Jj, 0, 0, Jr_inv * q_mat(q_conj(imu.q)));
+        if (need_i) {
+            const Q4 q_j = q_mul(fj.q, imu.q);
+            put33(Ji, 0, 0, -(Jr_inv * q_mat(q_conj(q_j)) * q_mat(fi.q)));
+        }
+    } else if (part == 1) {
+        if (need_i) {
+            const V3 dbg = fi.bg - bg0;
+            const M3 Jr_inv = inverse3(right_jacobian(rq));
+            put33(Ji, 0, 9, -(Jr_inv * q_mat(q_conj(expmap(rq))) * right_jacobian(pre.dq_dbg * dbg) * pre.dq_dbg));
+        }
+    } else if (part == 2) {
+        if (need_i) {
+            const M3 Rimu_t = q_mat(q_conj(imu.q));
+            const V3 p_j = fj.p + q_rot(fj.q, imu.p);
+            put33(Ji, 3, 0, Rimu_t * hat(q_rot(q_conj(fi.q), p_j - fi.p - fi.v * dt - gravity * (0.5 * dt * dt))));
+            put33(Ji, 6, 0, Rimu_t * hat(q_rot(q_conj(fi.q), fj.v - fi.v - gravity * dt)));
+            put33(Ji, 3, 9, -pre.dp_dbg);
+            put33(Ji, 6, 9, -pre.dv_dbg);
+            put33(Ji, 9, 9, -I3);
+            put33(Ji, 3, 12, -pre.dp_dba);
+            put33(Ji, 6, 12, -pre.dv_dba);
+            put33(Ji, 12, 12, -I3);
+        }
+    } else {
+        const Q4 q_i = q_mul(fi.q, imu.q);
+        const M3 Rqi_t = q_mat(q_conj(q_i));
+        if (need_j) {
+            put33(Jj, 3, 0, -(Rqi_t * q_mat(fj.q) * hat(imu.p)));
+            put33(Jj, 3, 3, Rqi_t);
+            put33(Jj, 6, 6, Rqi_t);
+            put33(Jj, 9, 9, I3);
+            put33(Jj, 12, 12, I3);
+        }
+        if (need_i) {
+            put33(Ji, 3, 3, -Rqi_t);
+            put33(Ji, 3, 6, Rqi_t * (-dt));
+            put33(Ji, 6, 6, -Rqi_t);
+        }
+    }
+}
+
 // QuaternionParameterization::Plus + additive blocks; d15 = (dq3, dp, dv, dbg, dba); mask bit0: pose free, bit1: motion free
 XD void state_plus(const double *s, const double *d15, bool pose_free, bool motion_free, double *out) {
 #pragma unroll
