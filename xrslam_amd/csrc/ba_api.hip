@@ -403,15 +403,17 @@ static bool tiny(const BaDims &d) {
 }
 static bool small_mid(const BaDims &d) { return d.nla == 0 && d.na <= 16; }   // measured: beyond one free frame the wide launches win
 // no free landmark, no prior, a handful of free frames: the LDS-resident single-launch solve (ba_chain.hip.h)
-static bool chain(const BaDims &d, size_t lds_limit, size_t *lds_bytes) {
+static bool chain(const BaDims &d, size_t lds_limit, size_t *lds_bytes, int *vis_tile) {
     static const bool off = std::getenv("XRHIP_NO_CHAIN") != nullptr;   // development switch: the round-1 paths
     if (off || d.nla != 0 || d.NP != 0 || d.nffp != 0) return false;
     if (d.na < 1 || d.na > CHAIN_MAX_NA || d.NI > CHAIN_MAX_NI || d.F > CHAIN_MAX_F || d.M + d.MR > CHAIN_MAX_OBS ||
         d.nfree > CHAIN_MAX_FREE)
         return false;
-    const size_t bytes = sizeof(double) * (size_t)chain_layout(d.F, d.na, d.NI, d.nfree).total;
+    const size_t bytes = sizeof(double) * (size_t)chain_layout(d.F, d.na, d.NI, d.nfree, d.M + d.MR).total;
     if (bytes > lds_limit) return false;
-    *lds_bytes = bytes;
+    const size_t with_tile = bytes + sizeof(double) * (size_t)CHAIN_VIS_TILE;   // the reduction tile of the reprojection blocks, if it fits
+    *vis_tile = with_tile <= lds_limit ? 1 : 0;
+    *lds_bytes = *vis_tile ? with_tile : bytes;
     return true;
 }
 
@@ -641,7 +643,8 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     }
     if (rc) return rc;
     size_t chain_lds = 0;
-    const bool use_chain = chain(d, (size_t)c->lds_limit, &chain_lds);
+    int chain_tile = 0;
+    const bool use_chain = chain(d, (size_t)c->lds_limit, &chain_lds, &chain_tile);
     rc = launch_stage_copy(c);
     if (rc) return rc;
     HostProfScope hp_rounds(9, "ba_solve: rounds (launch+wait)");
@@ -653,7 +656,7 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     int mode = 1, iter_seen = 0;
     if (use_chain) {   // the whole solve in one launch, LDS-resident (kb_chain)
         const int seq = ++c->seq;
-        hipLaunchKernelGGL(kb_chain, dim3(1), dim3(CHAIN_THREADS), chain_lds, s, c->tiny_args, seq, 4 * (P->max_iterations + 8));
+        hipLaunchKernelGGL(kb_chain, dim3(1), dim3(CHAIN_THREADS), chain_lds, s, c->tiny_args, seq, 4 * (P->max_iterations + 8), chain_tile);
         XR_HIP(hipGetLastError());
         rc = wait_mailbox(c, seq);
         if (rc) return rc;

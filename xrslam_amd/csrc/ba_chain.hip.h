@@ -50,9 +50,9 @@ constexpr bool CHAIN_HELPER = CHAIN_THREADS > 256;
 #endif
 
 struct ChainLayout {   // offsets in doubles into the dynamic LDS block
-    int sx, cs, Hp, gp, A, sp, D, gs, grad, gn, delta, gt, wJi, wJj, wr, bref, raw, Hv, total;
+    int sx, cs, Hp, gp, A, sp, D, gs, grad, gn, delta, gt, wJi, wJj, wr, bref, raw, Hv, oc, total;
 };
-__host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int NI, int nfree) {
+__host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int NI, int nfree, int nobs) {
     ChainLayout L;
     int o = 0;
     auto take = [&](int n) {
@@ -79,6 +79,7 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
     L.bref = take(6 * NI);
     L.raw = take(15 * NI);
     L.Hv = take(28 * nfree);
+    L.oc = take(nobs);   // per-factor costs of the reprojection / rotation factors (evaluated by whoever is free, summed in fixed order)
     L.total = o;
     return L;
 }
@@ -86,7 +87,8 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
 // (Tried: this workgroup pulling the staged problem from the pinned host arena itself instead of a kb_stage launch in
 // front of it -- one compute unit reads the host link slower than kb_stage's 128 workgroups: localize_newframe
 // 0.132 -> 0.139 ms per frame, profiles/r02_ab_variants.md.)
-__global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__restrict__ args, int seq, int max_rounds) {
+constexpr int CHAIN_VIS_TILE = 27 * 257;   // doubles of LDS behind the layout when `vis_tile` is set
+__global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__restrict__ args, int seq, int max_rounds, int vis_tile) {
     const BaDims &d = args->d;
     const BaPtrs &p = args->p;
     const Ext &cam = args->cam, &imu = args->imu;
@@ -104,8 +106,17 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
     // takes part in every barrier and collective and contributes zeros to the sums.  Without it, threads 0..NI-1 do.
     const int tid = threadIdx.x, lane = tid & 63;
     const bool worker = tid < 256;
-    const bool imu_lane = CHAIN_HELPER ? (!worker && lane < d.NI) : (tid < d.NI);
-    const int imu_k = CHAIN_HELPER ? lane : tid;
+    // Who evaluates what.  An IMU factor is ONE lane's chain of a few thousand dependent double-precision operations
+    // (expmap, logmap, right Jacobian), about as long as two reprojection factors; lanes of one wavefront run in lockstep, so
+    // a wavefront that holds both kinds runs them one after the other.  With IMU factors present the last worker wavefront
+    // therefore takes the IMU factors only (lane k: factor k) and the reprojection / rotation factors are dealt to the other
+    // three (stride 192); their costs go through LDS and are added up in the fixed order o = t, t + 256, ... of the generic
+    // bodies, so the sums do not depend on who evaluated what.
+    const bool split = !CHAIN_HELPER && d.NI > 0;
+    const bool imu_lane = CHAIN_HELPER ? (!worker && lane < d.NI) : (split ? (tid >= 192 && tid - 192 < d.NI) : false);
+    const int imu_k = CHAIN_HELPER ? lane : tid - 192;
+    const int ostride = split ? 192 : 256;
+    const int otid = (worker && (!split || tid < 192)) ? tid : (1 << 30);
     const int wtid = worker ? tid : (1 << 30), wave = worker ? (tid >> 6) : (1 << 28);
     constexpr int nt = 256;
     const int F = d.F, n = d.n, na = d.na, NI = d.NI, M = d.M, MR = d.MR;
@@ -129,12 +140,12 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
     }
     __syncthreads();
     const int nfree = s_nfree;
-    const ChainLayout Lo = chain_layout(F, na, NI, nfree);
+    const ChainLayout Lo = chain_layout(F, na, NI, nfree, M + MR);
     double *const X = lds + Lo.sx, *const CS = lds + Lo.cs, *const Hp = lds + Lo.Hp, *const gp = lds + Lo.gp;
     double *const A = lds + Lo.A, *const sp = lds + Lo.sp, *const Dg = lds + Lo.D, *const gs = lds + Lo.gs;
     double *const grad = lds + Lo.grad, *const gn = lds + Lo.gn, *const delta = lds + Lo.delta, *const gt = lds + Lo.gt;
     double *const wJi = lds + Lo.wJi, *const wJj = lds + Lo.wJj, *const wr = lds + Lo.wr, *const bref = lds + Lo.bref;
-    double *const raw = lds + Lo.raw, *const Hv = lds + Lo.Hv;
+    double *const raw = lds + Lo.raw, *const Hv = lds + Lo.Hv, *const oc = lds + Lo.oc;
     BaCtl *const c = &s_ctl;
 
     // this thread's slots of the full 15F layout (element a = tid + 256 m, like the strided loops of the generic bodies):
@@ -173,18 +184,17 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                     imu_raw_jacobians(si, sj, pre, bg0, ba0, imu, v3(r15[0], r15[1], r15[2]), Ji, Jj, p.fix[fi] != 3, p.fix[fj] != 3);
                 }
             }
-            double cost_part = 0.0;   // this thread's share of the total cost, in sum_cost_block's order
-            for (int o = wtid; o < M; o += nt) {
+            for (int o = otid; o < M; o += ostride) {
                 double rec[OREC];
                 const double co = obs_eval(d, p, o, X, p.depth, cam, sx_, sy_, true, rec);
-                cost_part += co;
+                oc[o] = co;
 #pragma unroll
                 for (int i = 0; i < OREC; ++i) p.orec[(size_t)o * OREC + i] = rec[i];
             }
-            for (int o = wtid; o < MR; o += nt) {
+            for (int o = otid; o < MR; o += ostride) {
                 double rec[RREC];
                 const double co = rot_eval(d, p, o, X, cam, sx_, sy_, true, rec);
-                cost_part += co;
+                oc[M + o] = co;
 #pragma unroll
                 for (int i = 0; i < RREC; ++i) p.rrec[(size_t)o * RREC + i] = rec[i];
             }
@@ -246,11 +256,28 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                         acc[21 + a] += j[a] * r0 + j[6 + a] * r1;
                     }
                 }
+                if (vis_tile) {
+                    // every thread parks its 27 partial sums as a column of an LDS tile; 108 threads add up a quarter row
+                    // each (27 butterfly reductions of doubles per free frame were 5 us of every round)
+                    double *tile = lds + Lo.total;
+                    if (worker)
 #pragma unroll
-                for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
-                if (lane == 0 && worker)
+                        for (int i = 0; i < 27; ++i) tile[i * 257 + tid] = acc[i];
+                    __syncthreads();
+                    if (tid < 108) {
+                        const int q = tid >> 2, w4 = tid & 3;
+                        const double *row = tile + q * 257 + 64 * w4;
+                        double s2 = 0.0;
+                        for (int i = 0; i < 64; ++i) s2 += row[i];
+                        s_vis[w4][q] = s2;
+                    }
+                } else {
 #pragma unroll
-                    for (int i = 0; i < 27; ++i) s_vis[wave][i] = acc[i];
+                    for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
+                    if (lane == 0 && worker)
+#pragma unroll
+                        for (int i = 0; i < 27; ++i) s_vis[wave][i] = acc[i];
+                }
                 __syncthreads();
                 if (tid < 27) Hv[28 * s + tid] = (s_vis[0][tid] + s_vis[1][tid]) + (s_vis[2][tid] + s_vis[3][tid]);
                 __syncthreads();
@@ -308,6 +335,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
             }
             CPROF(4);   // assembly
             // ---------------- total cost (sum_cost_block: observations, rotation factors, IMU factors k = tid, ...)
+            double cost_part = 0.0;   // this thread's share of the total cost, in sum_cost_block's order
+            for (int o = wtid; o < M; o += nt) cost_part += oc[o];
+            for (int o = wtid; o < MR; o += nt) cost_part += oc[M + o];
             for (int k = wtid; k < NI; k += nt) cost_part += wr[16 * k + 15];
             const double ctot = block_sum(cost_part, scratch);
             if (tid == 0) {
@@ -504,8 +534,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                 }
                 __syncthreads();
                 double red[2] = {0, 0};   // cost, |x - candidate|^2
-                for (int o = wtid; o < M; o += nt) red[0] += obs_eval(d, p, o, CS, p.depth, cam, sx_, sy_, false, nullptr);
-                for (int o = wtid; o < MR; o += nt) red[0] += rot_eval(d, p, o, CS, cam, sx_, sy_, false, nullptr);
+                for (int o = otid; o < M; o += ostride) oc[o] = obs_eval(d, p, o, CS, p.depth, cam, sx_, sy_, false, nullptr);
+                for (int o = otid; o < MR; o += ostride) oc[M + o] = rot_eval(d, p, o, CS, cam, sx_, sy_, false, nullptr);
                 if (imu_lane) {   // one IMU factor per lane
                     const int k = imu_k;
                     const int fi = p.imu_i[k], fj = p.imu_j[k];
@@ -520,6 +550,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                     for (int q = 0; q < 15; ++q) raw[15 * k + q] = r15[q];
                 }
                 __syncthreads();
+                for (int o = wtid; o < M; o += nt) red[0] += oc[o];
+                for (int o = wtid; o < MR; o += nt) red[0] += oc[M + o];
                 for (int it = wtid; it < NI * 15; it += nt) {
                     const int k = it / 15, i = it - 15 * k;
                     const double *S = p.imu_data + (size_t)k * XRHIP_IMU_DIM + 56 + 15 * i;
