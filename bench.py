@@ -294,16 +294,27 @@ def main():
                  "track_landmark", "refine_window", "slide_window", "refine_subwindow"),
                 [round(1e3 * (t_e.wall_scope[i] - t_w.wall_scope[i]) / args.steps, 4) for i in range(11)])),
             "ate_rmse_m": (lambda a: round(a, 5) if a == a else None)(runner.ate_rmse(poses, seq)),   # None with < 3 poses
-            # dominant single kernel by total time (profiles/): kb_solve_try = reduced-system Cholesky (f64 MFMA trailing
-            # updates) [+ trust-region trial costing for small problems], one workgroup per launch; flops = algorithmic
-            # (DESIGN.md 4.2); launch_us = HIP events around that kernel alone on the BA stream
-            "roofline": {"kernel": "kb_solve_try", "bound": "mfma", "achieved": round(ba_tflops, 6),
-                         "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ba_tflops / F64_MFMA_PEAK_TFLOPS, 8),
-                         "traffic": traffic.get("kb_solve_try"),
-                         "peak_measured": mfma_meas, "frac_of_measured": round(ba_tflops / mfma_meas, 8) if mfma_meas else None,
-                         "algorithmic_flops_per_launch": round(bst.flops_solve_try / max(1, bst.n_timed), 1),
-                         "launch_us": round(1e3 * bst.ms_solve_try / max(1, bst.n_timed), 3),
-                         "launches": int(bst.n_timed), "trials": int(bst.n_trials)},
+            # dominant kernel by total time (profiles/r02_full_*_kernel_stats.md): kb_chain, the LDS-resident single-launch
+            # solve of localize_newframe / refine_subwindow (one workgroup; factor linearisation + trial costing stream the
+            # observation records: HBM-bound per SURVEY.md 8d).  achieved = algorithmic bytes per launch / HIP-event
+            # duration of that kernel on the BA stream.
+            "roofline": {"kernel": "kb_chain", "bound": "hbm",
+                         "achieved": round(bst.bytes_chain / max(1e-9, bst.ms_chain * 1e-3) / 1e9, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(bst.bytes_chain / max(1e-9, bst.ms_chain * 1e-3) / 1e9 / HBM_PEAK_GBS, 8),
+                         "traffic": traffic.get("kb_chain"),
+                         "peak_measured": hbm_meas,
+                         "frac_of_measured": round(bst.bytes_chain / max(1e-9, bst.ms_chain * 1e-3) / 1e9 / hbm_meas, 8) if hbm_meas else None,
+                         "algorithmic_bytes_per_launch": round(bst.bytes_chain / max(1, bst.n_chain_timed), 1),
+                         "launch_us": round(1e3 * bst.ms_chain / max(1, bst.n_chain_timed), 3), "launches": int(bst.n_chain_timed)},
+            # the window solve's factorisation kernel: reduced-system Cholesky on the f64 matrix cores (+ substitutions); flops =
+            # algorithmic; launch_us = HIP events around that kernel alone
+            "roofline_solve": {"kernel": "kb_solve_try", "bound": "mfma", "achieved": round(ba_tflops, 6),
+                               "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ba_tflops / F64_MFMA_PEAK_TFLOPS, 8),
+                               "traffic": traffic.get("kb_solve_try"),
+                               "peak_measured": mfma_meas, "frac_of_measured": round(ba_tflops / mfma_meas, 8) if mfma_meas else None,
+                               "algorithmic_flops_per_launch": round(bst.flops_solve_try / max(1, bst.n_timed), 1),
+                               "launch_us": round(1e3 * bst.ms_solve_try / max(1, bst.n_timed), 3),
+                               "launches": int(bst.n_timed), "trials": int(bst.n_trials)},
             "roofline_lk": {"kernel": "k_lk_track", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic.get("k_lk_track"),
                             "peak_measured": hbm_meas, "frac_of_measured": round(achieved / hbm_meas, 6) if hbm_meas else None,

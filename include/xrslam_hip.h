@@ -244,7 +244,13 @@ typedef struct xrhip_ba_stats {
     double ms_solve_try;     /* sum of HIP-event durations (only launches made while profiling was on) */
     long n_timed;            /* launches that contributed to ms_solve_try */
     double flops_solve_try;  /* algorithmic flops of the timed launches */
-    long n_tiny;             /* solves that ran as ONE launch (kb_tiny: no free landmark, a few free frames); not in the above */
+    long n_tiny;             /* solves that ran as ONE launch (kb_chain / kb_tiny: no free landmark, a few free frames); not in the above */
+    /* the single-launch solves (kb_chain): HIP-event durations of the launches made while profiling was on, and their
+     * ALGORITHMIC bytes (384 B per reprojection factor and linearisation, 280 B per factor and candidate
+     * costed, the packed reduced system once per round) -- what bench.py divides by the HBM peak */
+    long n_chain_timed;
+    double ms_chain;
+    double bytes_chain;
 } xrhip_ba_stats;
 int xrhip_ba_set_profiling(xrhip_ba *ctx, int enable);
 int xrhip_ba_get_stats(xrhip_ba *ctx, xrhip_ba_stats *out, int reset);

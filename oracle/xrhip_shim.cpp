@@ -171,7 +171,7 @@ int xrhip_ba_preintegrate(xrhip_ba *, const double *samples, int n, double t_end
 }
 int xrhip_ba_set_profiling(xrhip_ba *, int) { return 0; }
 int xrhip_ba_get_stats(xrhip_ba *, xrhip_ba_stats *out, int) {
-    if (out) *out = xrhip_ba_stats{0, 0, 0.0, 0, 0.0, 0};
+    if (out) *out = xrhip_ba_stats{0, 0, 0.0, 0, 0.0, 0, 0, 0.0, 0.0};
     return 0;
 }
 int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *begin, const int *count,

@@ -34,7 +34,7 @@ for n, s, e in rows:
 total = sum(t for t, _ in tot.values())
 b = open(os.path.join(go, "bench_%s.json" % tag)).read().strip().splitlines()[-1]
 bj = json.loads(b)
-frames = 140
+frames = max(1, tot["xrhip::k_clahe_lut"][1])   # one CLAHE pass per camera frame: counts the frames the traced command processed
 lines = ["# round %d, full pipeline %s (%s)" % (int(rnd[1:]), ver, desc), "",
          "`rocprofv3 --kernel-trace --memory-copy-trace --stats -- python bench.py --steps 100 --warmup 40 --cpu-frames 0 --no-profile` on one MI355X",
          "(gfx950, ROCm 7.2); kernel-trace statistics from the results database.", "",

@@ -63,8 +63,13 @@ struct xrhip_ba {
         int iter_before;
     };
     std::vector<Timed> pending;
+    struct TimedChain {
+        hipEvent_t e0, e1;
+        double bytes;
+    };
+    std::vector<TimedChain> pending_chain;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
-    xrhip_ba_stats stats = {0, 0, 0.0, 0, 0.0, 0};
+    xrhip_ba_stats stats = {0, 0, 0.0, 0, 0.0, 0, 0, 0.0, 0.0};
     const TinyArgs *tiny_args = nullptr;   // device address of the staged argument block (kb_tiny)
     const uint4 *stage_src = nullptr;      // the staged problem: pinned host block (device-visible address) -> device arena
     uint4 *stage_dst = nullptr;
@@ -541,6 +546,16 @@ static void ba_resolve_pending(xrhip_ba *c) {
         c->free_events.push_back({t.e0, t.e1});
     }
     c->pending.clear();
+    for (auto &t : c->pending_chain) {
+        float ms = 0.f;
+        if (hipEventSynchronize(t.e1) == hipSuccess && hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
+            c->stats.ms_chain += ms;
+            c->stats.n_chain_timed += 1;
+            c->stats.bytes_chain += t.bytes;
+        }
+        c->free_events.push_back({t.e0, t.e1});
+    }
+    c->pending_chain.clear();
 }
 
 int xrhip_ba_set_profiling(xrhip_ba *c, int enable) {
@@ -554,7 +569,7 @@ int xrhip_ba_get_stats(xrhip_ba *c, xrhip_ba_stats *out, int reset) {
     if (!c || !out) return xr_fail(XRHIP_EINVAL, "xrhip_ba_get_stats: null argument");
     ba_resolve_pending(c);
     *out = c->stats;
-    if (reset) c->stats = {0, 0, 0.0, 0, 0.0, 0};
+    if (reset) c->stats = {0, 0, 0.0, 0, 0.0, 0, 0, 0.0, 0.0};
     return XRHIP_OK;
 }
 
@@ -656,11 +671,29 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     int mode = 1, iter_seen = 0;
     if (use_chain) {   // the whole solve in one launch, LDS-resident (kb_chain)
         const int seq = ++c->seq;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->profiling) {
+            if (!c->free_events.empty()) {
+                e0 = c->free_events.back().first;
+                e1 = c->free_events.back().second;
+                c->free_events.pop_back();
+            } else {
+                XR_HIP(hipEventCreate(&e0));
+                XR_HIP(hipEventCreate(&e1));
+            }
+            XR_HIP(hipEventRecord(e0, s));
+        }
         hipLaunchKernelGGL(kb_chain, dim3(1), dim3(CHAIN_THREADS), chain_lds, s, c->tiny_args, seq, 4 * (P->max_iterations + 8), chain_tile);
         XR_HIP(hipGetLastError());
+        if (c->profiling) XR_HIP(hipEventRecord(e1, s));
         rc = wait_mailbox(c, seq);
         if (rc) return rc;
         if (c->h_ctl->status != ST_DONE) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: trust-region loop did not terminate");
+        if (c->profiling) {   // algorithmic bytes of this launch: rounds = accepted steps + 1 linearisations, `iteration` candidates
+            const double nf = (double)d.M + d.MR, rounds = c->h_ctl->successful_steps + 1.0, trials = c->h_ctl->iteration;
+            const double bytes = rounds * (384.0 * nf + 8.0 * (double)d.na * d.na + 2248.0 * d.NI) + trials * (280.0 * nf + 2248.0 * d.NI);
+            c->pending_chain.push_back({e0, e1, bytes});
+        }
         c->stats.n_tiny++;
         done = true;
     } else if (tiny(d)) {   // the whole trust-region loop in one launch (kb_tiny)

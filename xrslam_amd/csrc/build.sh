@@ -10,7 +10,7 @@ mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -I$HERE/../../include"
 # kernel revision = hash of the device sources; bench.py prints PMC traffic only from profiles taken at the same revision
-REV="$(cat "$HERE"/*.hip "$HERE"/*.hip.h | sha1sum | cut -c1-10)"
+REV="$(cat "$HERE"/*.hip.h | sha1sum | cut -c1-10)"   # the kernels live in the *.hip.h headers; the *.hip files hold the C ABI around them
 if [ "$(cat "$HERE/kernel_rev.gen.h" 2>/dev/null)" != "#define XRHIP_KERNEL_REV \"$REV\"" ]; then
   echo "#define XRHIP_KERNEL_REV \"$REV\"" > "$HERE/kernel_rev.gen.h"
 fi

@@ -26,7 +26,8 @@ class XRSLAMPose(C.Structure):
 
 class BaStats(C.Structure):   # xrhip_ba_stats (include/xrslam_hip.h)
     _fields_ = [("n_solve_try", C.c_long), ("n_trials", C.c_long), ("ms_solve_try", C.c_double), ("n_timed", C.c_long),
-                ("flops_solve_try", C.c_double), ("n_tiny", C.c_long)]
+                ("flops_solve_try", C.c_double), ("n_tiny", C.c_long), ("n_chain_timed", C.c_long), ("ms_chain", C.c_double),
+                ("bytes_chain", C.c_double)]
 
 
 class XRSLAMAmdTimes(C.Structure):
