@@ -71,6 +71,13 @@ struct xrhip_ba {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
     xrhip_ba_stats stats = {0, 0, 0.0, 0, 0.0, 0, 0, 0.0, 0.0};
     const TinyArgs *tiny_args = nullptr;   // device address of the staged argument block (kb_tiny)
+    // speculative linearisation of window solves (spec_state_block): second stream, second set of linearisation buffers
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_mid = nullptr, ev_spec = nullptr;
+    char *work_spec = nullptr;
+    size_t work_spec_cap = 0;
+    bool spec_outstanding = false;         // stream2 may still be writing work_spec / reading the input arena
+    long spec_launched = 0, spec_taken = 0;   // development counters (XRHIP_HOSTPROF prints them)
     const uint4 *stage_src = nullptr;      // the staged problem: pinned host block (device-visible address) -> device arena
     uint4 *stage_dst = nullptr;
     size_t stage_n16 = 0;
@@ -244,6 +251,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     ctl.linear_ok = 1;
     ctl.max_iterations = P->max_iterations;
     ctl.termination = XRHIP_BA_NO_CONVERGENCE;
+    ctl.accepted_slot = -1;
     const size_t o_state = put(P->frame_state, sizeof(double) * 16 * F);
     const size_t o_fix = put(P->frame_fix, F);
     const size_t o_depth = put(P->inv_depth, sizeof(double) * L);
@@ -424,8 +432,8 @@ static bool chain(const BaDims &d, size_t lds_limit, size_t *lds_bytes, int *vis
 
 // one linearisation: 3 launches + the cost (and, for the solver, gradient norm + per-solve preparation)
 static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
-                             double sy, bool for_solver) {
-    hipStream_t s = c->stream;
+                             double sy, bool for_solver, hipStream_t s_override = nullptr) {
+    hipStream_t s = s_override ? s_override : c->stream;
     hipLaunchKernelGGL(kb_lin_all, dim3(lin_all_blocks(d.M, d.MR, d.NI)), dim3(256), sizeof(double) * std::max(d.np, 1), s, d, p,
                        cam, imu, sx, sy);
     hipLaunchKernelGGL(kb_landmark_vision, dim3(d.lm_rows + d.F * d.F), dim3(64), 0, s, d, p);
@@ -458,18 +466,34 @@ static bool wide_trials(const BaDims &d) { return d.M >= 256 && d.F <= 32; }
 static bool wide_first(const BaDims &d) { return wide_trials(d) && d.M >= 600 && d.na >= 90; }
 
 // reduced-system solve + trust-region trials: 2 launches (3 when mu changed without a new linearisation)
-static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
-                            double sy, bool prepare, int mode, int seq) {
-    hipStream_t s = c->stream;
-    const bool mid = small_mid(d);
-    if (mid) hipLaunchKernelGGL(kb_small_mid, dim3(1), dim3(256), 0, s, d, p, prepare ? 0 : 1);
-    if (!mid && prepare) hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);
+static void launch_schur_aux(const BaDims &d, const BaPtrs &p, hipStream_t s) {
     const int tiles = d.PF / 16;
     const int nrest = (d.na * d.na + 255) / 256;   // blocks that write the Schur-free entries of the reduced system
-    if (!mid)
-        hipLaunchKernelGGL(kb_schur_aux, dim3(nrest + (d.nla ? tiles * tiles + aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64
-                                                            : aux_quad_blocks_n(d.n, d.L))),
-                           dim3(256), 0, s, d, p);
+    hipLaunchKernelGGL(kb_schur_aux, dim3(nrest + (d.nla ? tiles * tiles + aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64
+                                                        : aux_quad_blocks_n(d.n, d.L))),
+                       dim3(256), 0, s, d, p);
+}
+
+// skip_front: the reduced system is already there (a committed speculation built it on the second stream)
+static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
+                            double sy, bool prepare, int mode, int seq, bool skip_front = false, const BaPtrs *spec_set = nullptr) {
+    // spec_set: speculative linearisation is on.  The factorisation kernel leaves the first candidate in the second buffer
+    // set; the trials are costed on the SECOND stream (they pay the cross-stream hand-over, ~14 us, off the critical path),
+    // because the caller queues the linearisation chain at the candidate on THIS stream right behind the factorisation --
+    // and, when the candidate is accepted, the next factorisation right behind that chain, without any event in between.
+    // skip_front (with spec_set): that accepted case -- the kernel first takes cost / gradient norm over from the chain.
+    const bool mark_mid = spec_set != nullptr;
+    const int commit = (spec_set && skip_front) ? 1 : 0;
+    double *state2 = spec_set ? static_cast<double *>(spec_set->state) : nullptr;
+    double *depth2 = spec_set ? static_cast<double *>(spec_set->depth) : nullptr;
+    BaCtl *ctl2 = spec_set ? static_cast<BaCtl *>(spec_set->ctl) : nullptr;
+    hipStream_t s = c->stream;
+    const bool mid = small_mid(d);
+    if (!skip_front) {
+        if (mid) hipLaunchKernelGGL(kb_small_mid, dim3(1), dim3(256), 0, s, d, p, prepare ? 0 : 1);
+        if (!mid && prepare) hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);
+        if (!mid) launch_schur_aux(d, p, s);
+    }
     size_t lds = 0;
     int use_lds = 1;
     int rcl = solve_lds(d, (size_t)c->lds_limit, &lds, &use_lds);
@@ -488,18 +512,24 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
         XR_HIP(hipEventRecord(e0, s));
     }
     if (wide_first(d))
-        hipLaunchKernelGGL((kb_solve_try<512, true>), dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq, 2);
+        hipLaunchKernelGGL((kb_solve_try<512, true>), dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq, 2, state2, depth2, ctl2, commit);
     else if (d.M + d.MR <= 640 && d.na <= 64)
         hipLaunchKernelGGL((kb_solve_try<256, false>), dim3(1), dim3(256), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
-                           wide_trials(d) ? 1 : 0);
+                           wide_trials(d) ? 1 : 0, (double *)nullptr, (double *)nullptr, (BaCtl *)nullptr, 0);
     else
         hipLaunchKernelGGL((kb_solve_try<512, false>), dim3(1), dim3(512), lds, s, d, p, cam, imu, sx, sy, use_lds, mode, seq,
-                           wide_trials(d) ? 1 : 0);
+                           wide_trials(d) ? 1 : 0, (double *)nullptr, (double *)nullptr, (BaCtl *)nullptr, 0);
     XR_HIP(hipGetLastError());
     if (c->profiling) XR_HIP(hipEventRecord(e1, s));   // the events bracket kb_solve_try alone (what rocprofv3 reports for it)
     if (wide_first(d)) {   // the first trial batch rides right behind the solve: no host round trip in between
+        hipStream_t st = s;
+        if (mark_mid) {
+            XR_HIP(hipEventRecord(c->ev_mid, s));
+            XR_HIP(hipStreamWaitEvent(c->stream2, c->ev_mid, 0));
+            st = c->stream2;
+        }
         const size_t wlds = sizeof(double) * ((size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np) + (size_t)4 * WIDE_B * 257);
-        hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, s, d, p, cam, imu, sx, sy, seq, 1, mode);
+        hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, st, d, p, cam, imu, sx, sy, seq, 1, mode);
         XR_HIP(hipGetLastError());
     }
     if (c->profiling) {
@@ -516,12 +546,12 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
 // Spin on the sequence number kb_solve_try stores (system-scope release) after its results: completion is seen a
 // few microseconds after the kernel's last store, where a blocking hipStreamSynchronize costs 20-30 us.
 // hipStreamQuery is polled now and then so that a faulted kernel turns into an error instead of a hang.
-static int wait_mailbox(xrhip_ba *c, int seq) {
+static int wait_mailbox(xrhip_ba *c, int seq, hipStream_t publisher = nullptr) {
     volatile int *flag = c->h_seq;
     for (unsigned long spin = 1;; ++spin) {
         if (*flag == seq) return XRHIP_OK;
         if ((spin & 0x3FFF) == 0) {
-            const hipError_t q = hipStreamQuery(c->stream);
+            const hipError_t q = hipStreamQuery(publisher ? publisher : c->stream);
             if (q == hipSuccess) {
                 if (*flag == seq) return XRHIP_OK;
                 return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: trial kernel retired without publishing its result");
@@ -588,6 +618,9 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
     if (rc) return rc;
     xrhip_ba *c = new xrhip_ba();
     XR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    XR_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    XR_HIP(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
+    XR_HIP(hipEventCreateWithFlags(&c->ev_spec, hipEventDisableTiming));
     XR_HIP(hipHostMalloc(&c->h_ctl, sizeof(BaCtl), hipHostMallocDefault));
     XR_HIP(hipHostMalloc(&c->h_seq, 64, hipHostMallocDefault));
     *c->h_seq = 0;
@@ -609,6 +642,13 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
 void xrhip_ba_destroy(xrhip_ba *c) {
     if (!c) return;
     hipStreamSynchronize(c->stream);
+    if (c->stream2) hipStreamSynchronize(c->stream2);
+    if (std::getenv("XRHIP_HOSTPROF") && c->spec_launched)
+        std::fprintf(stderr, "[hostprof] speculative linearisations: %ld launched, %ld taken\n", c->spec_launched, c->spec_taken);
+    hipFree(c->work_spec);
+    if (c->ev_mid) hipEventDestroy(c->ev_mid);
+    if (c->ev_spec) hipEventDestroy(c->ev_spec);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     hipFree(c->in.dev);
     hipHostFree(c->in.host);
     hipFree(c->work);
@@ -711,13 +751,64 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
         c->stats.n_tiny++;
         done = true;
     }
+    // ---- speculative linearisation (window solves, see spec_state_block in ba_kernels.hip.h): the second buffer set mirrors the workspace
+    static const bool spec_off = std::getenv("XRHIP_NO_SPEC") != nullptr;   // development switch
+    const bool spec = !spec_off && !use_chain && wide_first(d);
+    BaPtrs p2 = p;
+    if (spec) {
+        const size_t extra = sizeof(double) * (16 * (size_t)d.F + (size_t)std::max(d.L, 1)) + sizeof(BaCtl) + 1024;
+        if (c->work_spec_cap < c->work_cap + extra) {
+            if (c->work_spec) hipFree(c->work_spec);
+            c->work_spec = nullptr;
+            XR_HIP(hipMalloc(&c->work_spec, c->work_cap + extra));
+            c->work_spec_cap = c->work_cap + extra;
+        }
+        auto shift = [&](auto &member) {
+            using T = std::remove_reference_t<decltype(*(static_cast<decltype(&*member)>(nullptr)))>;
+            member = reinterpret_cast<T *>(c->work_spec + (reinterpret_cast<const char *>(static_cast<T *>(member)) - c->work));
+        };
+        shift(p2.orec); shift(p2.ocost); shift(p2.rrec); shift(p2.rcost);
+        shift(p2.imu_r); shift(p2.imu_Ji); shift(p2.imu_Jj); shift(p2.imu_cost);
+        shift(p2.pr); shift(p2.pt); shift(p2.pJq); shift(p2.pcost);
+        shift(p2.hll); shift(p2.gl); shift(p2.Wt); shift(p2.Hv); shift(p2.gv);
+        shift(p2.Hpp); shift(p2.gp); shift(p2.diagD); shift(p2.gs); shift(p2.omega);
+        shift(p2.T); shift(p2.Sred); shift(p2.partial); shift(p2.wog);
+        char *x = c->work_spec + ((c->work_cap + 255) & ~size_t(255));
+        p2.state = reinterpret_cast<double *>(x);
+        p2.depth = reinterpret_cast<double *>(x + sizeof(double) * 16 * (size_t)d.F);
+        p2.ctl = reinterpret_cast<BaCtl *>(x + ((sizeof(double) * (16 * (size_t)d.F + (size_t)std::max(d.L, 1)) + 255) & ~size_t(255)));
+    }
+    auto swap_sets = [&]() {   // the products of the linearisation chain change places; state / depth / ctl stay the minimiser's
+        std::swap(p.orec, p2.orec); std::swap(p.ocost, p2.ocost); std::swap(p.rrec, p2.rrec); std::swap(p.rcost, p2.rcost);
+        std::swap(p.imu_r, p2.imu_r); std::swap(p.imu_Ji, p2.imu_Ji); std::swap(p.imu_Jj, p2.imu_Jj); std::swap(p.imu_cost, p2.imu_cost);
+        std::swap(p.pr, p2.pr); std::swap(p.pt, p2.pt); std::swap(p.pJq, p2.pJq); std::swap(p.pcost, p2.pcost);
+        std::swap(p.hll, p2.hll); std::swap(p.gl, p2.gl); std::swap(p.Wt, p2.Wt); std::swap(p.Hv, p2.Hv); std::swap(p.gv, p2.gv);
+        std::swap(p.Hpp, p2.Hpp); std::swap(p.gp, p2.gp); std::swap(p.diagD, p2.diagD); std::swap(p.gs, p2.gs); std::swap(p.omega, p2.omega);
+        std::swap(p.T, p2.T); std::swap(p.Sred, p2.Sred); std::swap(p.partial, p2.partial); std::swap(p.wog, p2.wog);
+    };
+    bool spec_ready = false;   // the linearisation at the state just accepted is already queued on the second stream
     for (int guard = 0; guard < 4 * (P->max_iterations + 8) && !done; ++guard) {
         const int seq = ++c->seq;
-        if (relinearise) launch_linearize(c, d, p, cam, imu, sx, sy, true);
-        rc = launch_solve_try(c, d, p, cam, imu, sx, sy, !relinearise, mode, seq);
+        if (spec_ready) {   // (the chain that built this linearisation is ahead of us on this very stream)
+            rc = launch_solve_try(c, d, p, cam, imu, sx, sy, false, mode, seq, true, &p2);
+        } else {
+            if (relinearise) launch_linearize(c, d, p, cam, imu, sx, sy, true);
+            rc = launch_solve_try(c, d, p, cam, imu, sx, sy, !relinearise, mode, seq, false, spec ? &p2 : nullptr);
+        }
         if (rc) return rc;
-        rc = wait_mailbox(c, seq);   // no copy, no driver wait: the kernel's last store is the sequence number
+        spec_ready = false;
+        bool spec_launched = false;
+        if (spec) {   // behind the factorisation, beside kb_trials_wide (second stream): the problem linearised at the first candidate
+            BaPtrs q = p2;             // the chain reads the candidate as "the state"
+            launch_linearize(c, d, q, cam, imu, sx, sy, true);
+            launch_schur_aux(d, q, s);
+            XR_HIP(hipGetLastError());
+            spec_launched = true;
+            c->spec_launched++;
+        }
+        rc = wait_mailbox(c, seq, spec ? c->stream2 : nullptr);   // no copy, no driver wait: the kernel's last store is the sequence number
         if (rc) return rc;
+        const bool first_batch_accept = spec_launched && c->h_ctl->status == ST_ACCEPTED && c->h_ctl->accepted_slot == 0;
         {   // trials this launch costed = trust-region iterations it advanced
             const int it_now = c->h_ctl->iteration;
             const int trials = std::max(0, it_now - iter_seen);
@@ -729,9 +820,9 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
         for (int wguard = 0; st == ST_NEED_TRIALS && wguard < 64; ++wguard) {   // run of rejected trials, 8 per launch
             const int wseq = ++c->seq;
             const size_t wlds = sizeof(double) * ((size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np) + (size_t)4 * WIDE_B * 257);
-            hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, s, d, p, cam, imu, sx, sy, wseq, 0, 0);
+            hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, spec ? c->stream2 : s, d, p, cam, imu, sx, sy, wseq, 0, 0);
             XR_HIP(hipGetLastError());
-            rc = wait_mailbox(c, wseq);
+            rc = wait_mailbox(c, wseq, spec ? c->stream2 : nullptr);
             if (rc) return rc;
             const int it_now = c->h_ctl->iteration;
             c->stats.n_trials += std::max(0, it_now - iter_seen);
@@ -743,6 +834,11 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
         } else if (st == ST_ACCEPTED) {
             relinearise = true;
             mode = 1;
+            if (first_batch_accept) {   // the speculation linearised exactly this state: take its buffers
+                swap_sets();
+                spec_ready = true;
+                c->spec_taken++;
+            }
         } else if (st == ST_RESOLVE || st == ST_RESOLVE_INNER) {
             relinearise = false;
             mode = (st == ST_RESOLVE) ? 2 : 3;

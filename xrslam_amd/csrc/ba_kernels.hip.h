@@ -45,6 +45,8 @@ struct BaCtl {   // device-resident solver state (one per context)
     int first;          // first linearisation of this solve (Jacobi scales are frozen afterwards)
     int max_iterations;
     unsigned wide_ticket;   // blocks of the running kb_trials_wide launch that have delivered their partial sums
+    int accepted_slot;      // kb_trials_wide: candidate slot of the accepted step (-1: none); slot 0 of a first batch is the
+                            // candidate spec_state_block linearised ahead of the decision
     long long prof[32];   // accumulated 100 MHz ticks per kernel phase (only written by -DXRHIP_KPROF builds)
 };
 #ifdef XRHIP_KPROF
@@ -1655,6 +1657,43 @@ __global__ __launch_bounds__(256) void kb_cost_prepare(BaDims d, BaPtrs p) {
     prepare_block(d, p);
 }
 
+// Speculative linearisation (window solves).  While kb_trials_wide costs the first candidate of a round on its 32
+// workgroups, the rest of the chip linearises the problem AT that candidate -- spec_state_block forms it (the same
+// trial_begin / dogleg_point / Plus expressions kb_trials_wide uses, hence the same bits) into a second set of buffers,
+// and kb_lin_all .. kb_schur_aux run on it in a second stream.  The first candidate of a round is accepted in three
+// rounds out of four (tests/golden/ba_snapshots): the host then swaps the buffer sets and goes straight to the
+// factorisation, ~90 us of dependent launches earlier.  Otherwise the second set is simply never looked at.
+// The candidate is formed by the factorisation kernel itself, right after it has produced the step (spec_state_block at the
+// end of kb_solve_try): it depends on the minimiser's scalars and on the state, both of which kb_trials_wide rewrites
+// when it finishes -- nothing that runs BESIDE kb_trials_wide may read them.  The linearisation chain on the second stream
+// only reads the candidate (state2 / depth2 / ctl2) and the problem's constant inputs.
+__device__ __forceinline__ void spec_state_block(const BaDims &d, const BaPtrs &p, double *state2, double *depth2, BaCtl *ctl2, int mode) {
+    const int tid = threadIdx.x, nt = blockDim.x, n = d.n;
+    TrialScalars t;
+    trial_load(p.ctl, t);
+    trial_begin(t, mode == 3, mode == 1);
+    const bool ok = t.status == ST_RUNNING;
+    double ca = 0.0, cb = 0.0, sn = 0.0;
+    if (ok) dogleg_point(t, t.radius, ca, cb, sn);
+    for (int f = tid; f < d.F; f += nt) {
+        double dl[15];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) {
+            const int a = 15 * f + q;
+            dl[q] = ((ca * p.grad[a] + cb * p.gn[a]) / p.diagD[a]) * p.sp[a];
+        }
+        state_plus(p.state + 16 * f, dl, pose_free(p.fix[f]), motion_free(p.fix[f]), state2 + 16 * f);
+    }
+    for (int l = tid; l < d.L; l += nt) {
+        const double dep = p.depth[l];
+        depth2[l] = p.lact[l] ? dep + ((ca * p.grad[n + l] + cb * p.gn[n + l]) / p.diagD[n + l]) * p.sl[l] : dep;
+    }
+    if (tid == 0) {   // the two fields the linearisation chain reads from its control block
+        ctl2->mu = fmax(1e-8, 2.0 * t.mu / 10.0);   // what trial_decide leaves behind when it accepts a step
+        ctl2->first = 0;
+        ctl2->status = ok ? 1 : 0;
+    }
+}
 // reduced-system solve followed by the trust-region trials, one workgroup
 // wide_trials: 1 = a rejected first trial hands over to kb_trials_wide instead of looping in here; 2 = every trial,
 // the first included, is costed by kb_trials_wide (queued behind this kernel by the host)
@@ -1663,14 +1702,30 @@ __global__ __launch_bounds__(256) void kb_cost_prepare(BaDims d, BaPtrs p) {
 // nothing -- small problems (one observation per thread either way) run the 256-thread instance.
 // PREP = true is the wide_trials == 2 instance: the trial code is not even compiled in, so the factorisation of a
 // window-sized system runs in a 512-thread kernel without the ~190 spilled registers the trial loop costs there.
+// state2 / depth2 / ctl2 (PREP only, may be null): where the first candidate goes for the speculative linearisation
 template <int NT, bool PREP>
 __global__ __launch_bounds__(NT) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int use_lds,
-                                                   int after_linearisation, int seq, int wide_trials) {
+                                                   int after_linearisation, int seq, int wide_trials, double *state2, double *depth2,
+                                                   BaCtl *ctl2, int commit) {
     extern __shared__ double lds[];   // max(solve_block's region, try_block's staging)
+    if (PREP && commit) {   // the speculation was right: the cost and gradient norm of its linearisation become the minimiser's
+        if (threadIdx.x == 0) {
+            p.ctl->x_cost = ctl2->x_cost;
+            p.ctl->gmax = ctl2->gmax;
+        }
+        __syncthreads();
+    }
     solve_block(d, p, use_lds, lds);
     __syncthreads();
-    if (PREP) try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, true, lds, true);
-    else try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, wide_trials != 0, lds, false);
+    if (PREP) {
+        try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, true, lds, true);
+        if (state2) {
+            __syncthreads();   // thread 0's control-block stores of the phase above
+            spec_state_block(d, p, state2, depth2, ctl2, after_linearisation);
+        }
+    } else {
+        try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, wide_trials != 0, lds, false);
+    }
 }
 
 // The rejected-trial tail of a large solve on the whole chip.  After a rejection the next radii are radius/2,
@@ -1918,6 +1973,7 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
     if (tid == 0) {
         trial_store(c, t);
         c->wide_ticket = 0;
+        c->accepted_slot = accepted;
     }
     __syncthreads();
     publish_block(d, p, t.status, seq, true);
