@@ -581,7 +581,7 @@ int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const dou
     ProfScope prof(c, CAT_TRACK);
     const int seq = ++c->trk_seq;
     c->done_base += (unsigned)n;
-    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, c->stream, A, B, dv_curr, dv_next, has_guess ? 1 : 0, dv_status, n,
+    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(LK_THREADS), 0, c->stream, A, B, dv_curr, dv_next, has_guess ? 1 : 0, dv_status, n,
                        c->profiling ? c->d_counters : (LkCounters *)nullptr, c->d_done, c->done_base, d_seq, seq);
     XR_HIP(hipGetLastError());
     prof.finish();
@@ -624,7 +624,7 @@ int xrhip_image_lk(const xrhip_image *prev, const xrhip_image *next, const float
     XR_HIP(hipMemcpyAsync(c->d_fprev, prev_xy, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
     XR_HIP(hipMemcpyAsync(c->d_fnext, next_xy_inout, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
     PyrView A = make_view(prev), B = make_view(next);
-    hipLaunchKernelGGL(k_lk_plain, dim3(n), dim3(64), 0, c->stream, A, B, c->d_fprev, c->d_fnext, c->d_status, n);
+    hipLaunchKernelGGL(k_lk_plain, dim3(n), dim3(LK_THREADS), 0, c->stream, A, B, c->d_fprev, c->d_fnext, c->d_status, n);
     XR_HIP(hipGetLastError());
     XR_HIP(hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
     XR_HIP(hipMemcpyAsync(next_xy_inout, c->d_fnext, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));

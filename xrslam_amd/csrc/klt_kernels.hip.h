@@ -444,7 +444,17 @@ __global__ __launch_bounds__(256) void k_undistort(const uint8_t *__restrict__ s
     dst[(size_t)y * dstride + x] = (uint8_t)min(255, max(0, v));
 }
 
-constexpr int LK_SLOTS = 7;   // ceil(441 / 64)
+// LK_WAVES wavefronts share one keypoint: the 441 pixels of the window are dealt to LK_THREADS lanes (pixel p = tid +
+// LK_THREADS * slot) and every window sum is reduced inside the wavefront (DPP scans) and then across the wavefronts through
+// a few bytes of LDS and ONE barrier.  The sums are exact integers, so the result does not depend on how the pixels are
+// dealt: the same bits as one wavefront per point -- which is what the kernel was until the in-kernel cycle counters
+// showed it bound by that one wavefront's instruction stream (40 % iterations, 25 % templates; profiles/r02_ab_variants.md).
+#ifndef XRHIP_LK_WAVES
+#define XRHIP_LK_WAVES 4
+#endif
+constexpr int LK_WAVES = XRHIP_LK_WAVES;
+constexpr int LK_THREADS = 64 * LK_WAVES;
+constexpr int LK_SLOTS = (21 * 21 + LK_THREADS - 1) / LK_THREADS;
 constexpr int LK_W_BITS = 14;
 // Search neighbourhood of the second image staged in LDS once per pyramid level: the 22x22 footprint of the window
 // (21 + 1 for the bilinear taps) plus LK_TILE_R pixels on every side of the level's starting position, the left edge
@@ -456,9 +466,10 @@ constexpr int LK_TILE_W = 36;               // 22 + 2 * LK_TILE_R + up to 3 pixe
 constexpr int LK_TILE_W4 = LK_TILE_W / 4;
 constexpr int LK_TILE_H = 22 + 2 * LK_TILE_R;
 constexpr int LK_TILE_DWORDS = LK_TILE_H * LK_TILE_W4;
-constexpr int LK_TILE_LOADS = (LK_TILE_DWORDS + 63) / 64;   // dwords per lane
+constexpr int LK_TILE_LOADS = (LK_TILE_DWORDS + LK_THREADS - 1) / LK_THREADS;   // dwords per lane
 
 __device__ __forceinline__ int lk_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+constexpr int lk_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Exact wavefront-wide sum of a 64-bit integer, result in every lane.  DPP data movement (row_shr 1/2/4/8 scan
 // inside each row of 16 lanes, row_bcast:15 / row_bcast:31 across the rows, v_readlane of lane 63) instead of six
@@ -538,7 +549,12 @@ struct LkCounters {
 __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, float px0, float py0, float &nx_io,
                                           float &ny_io, const int (&wx)[LK_SLOTS], const int (&wy)[LK_SLOTS],
                                           const bool (&wvalid)[LK_SLOTS], unsigned &n_templates,
-                                          unsigned &n_iters, uint32_t *tile) {
+                                          unsigned &n_iters, uint32_t *tile, double (*xch)[LK_WAVES][4], int &xpar) {
+    // xch: [2][LK_WAVES][4] doubles of LDS through which the wavefronts of this point exchange their partial window sums
+    // (every value an exact integer below 2^53, so their sum is exact in any order); xpar alternates between the two
+    // halves, which is what lets one barrier per exchange suffice (a wavefront can only be writing half h for exchange
+    // n + 1 after every wavefront passed the barrier of exchange n, i.e. after all reads of half h for exchange n - 1)
+    const int wave_id = (int)threadIdx.x >> 6;
     const float FLT_SCALE = 1.f / (1 << 20);
     const float half = (KLT_WIN - 1) * 0.5f;
     const double epsilon = 0.01 * 0.01;
@@ -572,7 +588,7 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
                 tx0 -= (int)(reinterpret_cast<uintptr_t>(J.img + tx0) & 3);   // row strides are multiples of 64 bytes
 #pragma unroll
                 for (int k = 0; k < LK_TILE_LOADS; ++k) {
-                    const int idx = min((int)threadIdx.x + 64 * k, LK_TILE_DWORDS - 1);
+                    const int idx = min((int)threadIdx.x + LK_THREADS * k, LK_TILE_DWORDS - 1);
                     const int r = idx / LK_TILE_W4, c4 = idx - r * LK_TILE_W4;
                     // rows / dwords outside the padded plane are never part of a valid footprint: clamp the address
                     const int y = min(max(ty0 + r, -KLT_PAD), J.h + KLT_PAD - 1);
@@ -626,10 +642,28 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
         sA11 = wave_sum_i64(sA11);
         sA12 = wave_sum_i64(sA12);
         sA22 = wave_sum_i64(sA22);
+        double dA11 = (double)sA11, dA12 = (double)sA12, dA22 = (double)sA22;   // < 2^37: exact
+        if (LK_WAVES > 1) {
+            if ((threadIdx.x & 63) == 0) {
+                xch[xpar][wave_id][0] = dA11;
+                xch[xpar][wave_id][1] = dA12;
+                xch[xpar][wave_id][2] = dA22;
+            }
+            __syncthreads();
+            dA11 = dA12 = dA22 = 0.0;
+#pragma unroll
+            for (int w = 0; w < LK_WAVES; ++w) {
+                dA11 += xch[xpar][w][0];
+                dA12 += xch[xpar][w][1];
+                dA22 += xch[xpar][w][2];
+            }
+            xpar ^= 1;
+        }
         n_templates++;
-        const float A11 = (float)sA11 * FLT_SCALE;
-        const float A12 = (float)sA12 * FLT_SCALE;
-        const float A22 = (float)sA22 * FLT_SCALE;
+        // (float) of the exact sum held as a double is the correctly rounded value, the same float (float)(int64 sum) is
+        const float A11 = (float)dA11 * FLT_SCALE;
+        const float A12 = (float)dA12 * FLT_SCALE;
+        const float A22 = (float)dA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig =
             (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * KLT_WIN * KLT_WIN);
@@ -645,7 +679,7 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
             __syncthreads();   // readers of the previous level's tile are done
 #pragma unroll
             for (int k = 0; k < LK_TILE_LOADS; ++k) {
-                const int idx = (int)threadIdx.x + 64 * k;
+                const int idx = (int)threadIdx.x + LK_THREADS * k;
                 if (idx < LK_TILE_DWORDS) tile[idx] = tile_regs[k];
             }
             __syncthreads();
@@ -700,8 +734,23 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
                 }
             }
             n_iters++;
-            const float b1 = (float)wave_sum_i32_exact(sb1) * FLT_SCALE;
-            const float b2 = (float)wave_sum_i32_exact(sb2) * FLT_SCALE;
+            double db1 = wave_sum_i32_exact(sb1), db2 = wave_sum_i32_exact(sb2);
+            if (LK_WAVES > 1) {
+                if ((threadIdx.x & 63) == 0) {
+                    xch[xpar][wave_id][0] = db1;
+                    xch[xpar][wave_id][1] = db2;
+                }
+                __syncthreads();
+                db1 = db2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < LK_WAVES; ++w) {
+                    db1 += xch[xpar][w][0];
+                    db2 += xch[xpar][w][1];
+                }
+                xpar ^= 1;
+            }
+            const float b1 = (float)db1 * FLT_SCALE;
+            const float b2 = (float)db2 * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             nx += dx;
@@ -727,7 +776,7 @@ __device__ __forceinline__ void lk_lane_layout(int lane, int (&wx)[LK_SLOTS], in
                                                bool (&wvalid)[LK_SLOTS]) {
 #pragma unroll
     for (int s = 0; s < LK_SLOTS; ++s) {
-        int p = lane + 64 * s;
+        int p = lane + LK_THREADS * s;
         wvalid[s] = p < KLT_WIN * KLT_WIN;
         if (!wvalid[s]) p = 0;
         wy[s] = p / KLT_WIN;
@@ -741,7 +790,7 @@ __device__ __forceinline__ void lk_lane_layout(int lane, int (&wx)[LK_SLOTS], in
 // the kernel reads and writes them over the host link itself.  done / done_target / host_seq implement the
 // completion mailbox: every wavefront publishes its result (system-scope fence), bumps `done`, and the one that
 // reaches done_target stores `seq` where the host is spinning.
-__global__ __launch_bounds__(64) void k_lk_track(PyrView A, PyrView B, const double2 *__restrict__ curr,
+__global__ __launch_bounds__(LK_THREADS) void k_lk_track(PyrView A, PyrView B, const double2 *__restrict__ curr,
                                                  double2 *__restrict__ next_io, int has_guess,
                                                  uint8_t *__restrict__ status_out, int n,
                                                  LkCounters *__restrict__ counters, unsigned *done, unsigned done_target,
@@ -762,7 +811,9 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrView A, PyrView B, const dou
     }
     unsigned n_templates = 0, n_iters = 0;
     __shared__ uint32_t tile[LK_TILE_DWORDS];
-    int status = lk_one_way(A, B, cx, cy, nx, ny, wx, wy, wvalid, n_templates, n_iters, tile);
+    __shared__ double xch[2][LK_WAVES][4];
+    int xpar = 0;
+    int status = lk_one_way(A, B, cx, cy, nx, ny, wx, wy, wvalid, n_templates, n_iters, tile, xch, xpar);
     const int cols = A.lv[0].w, rows = A.lv[0].h;
     if (nx < 20 || nx >= cols - 20 || ny < 20 || ny >= rows - 20) status = 0;
     if (status) {
@@ -772,7 +823,7 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrView A, PyrView B, const dou
     }
     if (status) {
         float rx = cx, ry = cy;
-        int st2 = lk_one_way(B, A, nx, ny, rx, ry, wx, wy, wvalid, n_templates, n_iters, tile);
+        int st2 = lk_one_way(B, A, nx, ny, rx, ry, wx, wy, wvalid, n_templates, n_iters, tile, xch, xpar);
         const float dx = cx - rx, dy = cy - ry;
         const double nrm = sqrt((double)dx * (double)dx + (double)dy * (double)dy);
         if (!st2 || nrm > 0.5) status = 0;
@@ -795,7 +846,7 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrView A, PyrView B, const dou
 }
 
 // plain calcOpticalFlowPyrLK (float in/out, every point) -- parity aid
-__global__ __launch_bounds__(64) void k_lk_plain(PyrView A, PyrView B, const float2 *__restrict__ prev,
+__global__ __launch_bounds__(LK_THREADS) void k_lk_plain(PyrView A, PyrView B, const float2 *__restrict__ prev,
                                                  float2 *__restrict__ next_io, uint8_t *__restrict__ status_out,
                                                  int n) {
     const int pt = blockIdx.x;
@@ -808,7 +859,9 @@ __global__ __launch_bounds__(64) void k_lk_plain(PyrView A, PyrView B, const flo
     float2 q = next_io[pt];
     unsigned a = 0, b = 0;
     __shared__ uint32_t tile[LK_TILE_DWORDS];
-    int status = lk_one_way(A, B, p.x, p.y, q.x, q.y, wx, wy, wvalid, a, b, tile);
+    __shared__ double xch[2][LK_WAVES][4];
+    int xpar = 0;
+    int status = lk_one_way(A, B, p.x, p.y, q.x, q.y, wx, wy, wvalid, a, b, tile, xch, xpar);
     if (lane == 0) {
         status_out[pt] = (uint8_t)status;
         next_io[pt] = q;
