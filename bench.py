@@ -135,6 +135,12 @@ def main():
                     help="frames of the bounded CPU-reference sample (0 = skip); the first 36 only seed the window")
     ap.add_argument("--host-frames", type=int, default=60,
                     help="frames of the extra leg through the reference-shaped host-image call (0 = skip)")
+    ap.add_argument("--threading", default="pipelined", choices=["inline", "pipelined"],
+                    help="inline: feature tracker and sliding-window tracker one after the other in the caller (the reference's PC "
+                         "build); pipelined (default): its XRSLAM_ENABLE_THREADING build with deterministic hand-offs -- the "
+                         "backend of frame t on a library thread beside the feature tracker of frame t+1 (XRSLAMAmdSetThreading)")
+    ap.add_argument("--inline-frames", type=int, default=100,
+                    help="frames of the same stream continued with threading switched off after the timed region (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the KLT kernels")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl == RCCL); 'gloo' lets two "
                     "ranks share one GPU when the multi-process path is exercised on a single-GPU box")
@@ -182,7 +188,9 @@ def main():
                       "self-initialising" % (os.path.basename(os.path.dirname(os.path.normpath(args.euroc))), real["frames"].shape[2],
                                              real["frames"].shape[1], wl["features"], wl["window"]))
     host_frames = args.host_frames if (S == 1 and world == 1) else 0
-    n_frames = preroll + args.warmup + args.steps + host_frames
+    pipelined = args.threading == "pipelined"
+    inline_frames = args.inline_frames if (S == 1 and world == 1 and pipelined) else 0
+    n_frames = preroll + args.warmup + args.steps + host_frames + inline_frames
     seq_kw = dict(w=wl["w"], h=wl["h"])
     if wl["K"]:
         seq_kw["K"] = wl["K"]
@@ -197,7 +205,7 @@ def main():
         h, w = seq["frames"].shape[1:]
         sessions.append(runner.Session(_lib.LIB_PATH, seq, slam_yaml=slam_yaml, sensor_yaml=sensor_yaml,
                                        device_frames=(dev.data_ptr(), h * w, w), instance=(S > 1),
-                                       init_frames=0 if real is not None else 60,
+                                       init_frames=0 if real is not None else 60, threading=1 if pipelined else 0,
                                        device_undistort="cv_undistort" if real is not None else None))
     torch.cuda.synchronize()
     sess, seq = sessions[0], sessions[0].seq
@@ -212,12 +220,14 @@ def main():
         if S == 1:
             for _ in range(n):
                 sess.step()
+            sess.sync()   # pipelined mode: the backend job of the last frame is part of the n frames
             return
         errs = []
 
         def work(s):
             try:
                 s.step_n(n)   # XRSLAMAmdInstanceReplay: the player's loop issued natively, one foreign call per thread
+                s.sync()
             except Exception as e:   # noqa: BLE001
                 errs.append(repr(e))
         th = [threading.Thread(target=work, args=(s,)) for s in sessions]
@@ -277,7 +287,11 @@ def main():
             "dtype": "u8/i16 images, f32 LK with exact i64 reductions, f64 BA",
             "data": "synthetic" if real is None else "real (EuRoC)",
             "config": {"workload": wl["text"], "features": wl["features"], "window_keyframes": wl["window"],
-                       "sequences_per_gpu": S, "untimed_preroll_frames": preroll},
+                       "sequences_per_gpu": S, "untimed_preroll_frames": preroll,
+                       "threading": ("pipelined: sliding-window tracker of frame t on a library thread beside the feature tracker of "
+                                     "frame t+1 (the reference's XRSLAM_ENABLE_THREADING build, deterministic hand-offs; timed region "
+                                     "starts and ends with the pipeline drained)") if pipelined else
+                                    "inline: feature tracker then sliding-window tracker in the caller (the reference's PC build)"},
             "ms_per_ba_iteration": round(ba_ms / iters, 4),
             "ba": {"solves_per_frame": round(solves / args.steps, 3), "iterations_per_solve": round(iters / solves, 2),
                    "device_ms_per_solve": round(ba_ms / solves, 4),
@@ -293,6 +307,8 @@ def main():
                 ("ft_track", "ransac_essential", "ransac_rotation", "ft_detect", "mirror_frame", "localize", "manage_keyframe",
                  "track_landmark", "refine_window", "slide_window", "refine_subwindow"),
                 [round(1e3 * (t_e.wall_scope[i] - t_w.wall_scope[i]) / args.steps, 4) for i in range(11)])),
+            # pipelined mode: what the feature tracker's thread spent waiting for the previous frame's backend at the hand-off
+            "backend_wait_ms_per_frame": round(1e3 * (t_e.wall_scope[15] - t_w.wall_scope[15]) / args.steps, 4),
             "ate_rmse_m": (lambda a: round(a, 5) if a == a else None)(runner.ate_rmse(poses, seq)),   # None with < 3 poses
             # dominant kernel by total time (profiles/r02_full_*_kernel_stats.md): kb_chain, the LDS-resident single-launch
             # solve of localize_newframe / refine_subwindow (one workgroup; factor linearisation + trial costing stream the
@@ -336,10 +352,23 @@ def main():
             h0 = time.perf_counter()
             for _ in range(host_frames):
                 sess.step()
+            sess.sync()
             torch.cuda.synchronize()
             ht = time.perf_counter() - h0
             out["host_image_path"] = {"value": round(host_frames / ht, 3), "unit": "frames/s", "frames": host_frames,
                                       "note": "same stream continued through XRSLAM_SENSOR_CAMERA (host image, PCIe upload inside the call)"}
+        if inline_frames > 0:
+            # the reference's PC build (threading off): the same stream continued with the backend inline in the caller
+            sess.api.set_threading(0)
+            sess.device_frames = (keep[0].data_ptr(), seq["frames"].shape[1] * seq["frames"].shape[2], seq["frames"].shape[2])
+            i0 = time.perf_counter()
+            for _ in range(inline_frames):
+                sess.step()
+            torch.cuda.synchronize()
+            it = time.perf_counter() - i0
+            out["inline_threading"] = {"value": round(inline_frames / it, 3), "unit": "frames/s", "frames": inline_frames,
+                                       "note": "same stream continued with XRSLAMAmdSetThreading(0): feature tracker and sliding-window "
+                                               "tracker one after the other in the caller (frames resident in HBM)"}
         if args.cpu_frames > 40 and world == 1 and S == 1 and real is None:
             import subprocess
             ref_lib = os.path.join(ROOT, "oracle", "_build", "libxrslam_oracle.so")
@@ -347,15 +376,16 @@ def main():
                 subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
             nc = min(args.cpu_frames, n_frames)
 
-            def cpu_leg(threads):
+            def cpu_leg(threads, threading=0):
                 # XR_ORACLE_THREADS is read when the session creates its KLT context (oracle/xrhip_shim.cpp)
                 os.environ["XR_ORACLE_THREADS"] = str(threads)
-                cpu = runner.Session(ref_lib, seq, slam_yaml=slam_yaml, sensor_yaml=sensor_yaml)
+                cpu = runner.Session(ref_lib, seq, slam_yaml=slam_yaml, sensor_yaml=sensor_yaml, threading=threading)
                 for _ in range(40):
                     cpu.step()
                 c0 = time.perf_counter()
                 for _ in range(nc - 40):
                     cpu.step()
+                cpu.sync()
                 ct = time.perf_counter() - c0
                 cpu.close()
                 return round((nc - 40) / ct, 3)
@@ -369,8 +399,11 @@ def main():
             # cores (capped at 16), solver and marginalisation still single-threaded like the reference
             cores = min(16, len(os.sched_getaffinity(0)))
             if cores > 1:
-                out["cpu_baseline_mt"] = {"value": cpu_leg(cores), "unit": "frames/s", "cores": cores, "kind": "port",
-                                          "sample": sample + ", image and LK point loops on %d OpenMP threads" % cores}
+                out["cpu_baseline_mt"] = {"value": cpu_leg(cores, 1 if pipelined else 0), "unit": "frames/s", "cores": cores,
+                                          "kind": "port",
+                                          "sample": sample + ", image and LK point loops on %d OpenMP threads%s"
+                                                    % (cores, ", backend thread beside the feature tracker (the same pipelined "
+                                                               "mode as the GPU line)" if pipelined else "")}
         print(json.dumps(out))
     for s in sessions:
         s.close()

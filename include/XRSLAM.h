@@ -181,7 +181,8 @@ typedef struct XRSLAMAmdTimes {
      * track_landmark; refine_window; slide_window; refine_subwindow; initialiser (SfM + alignment attempts);
      * [12], [13] are COUNTS of the RD-VIO filter (parsac.parsac_flag): frames on which judge_track_status separated a
      * dynamic group, landmark observations it tagged as outliers; [14] COUNTS the constant copies the solver front end made for
-     * prior factors whose reference frame / landmark was also a free parameter of the same solve; [15] reserved */
+     * prior factors whose reference frame / landmark was also a free parameter of the same solve; [15] pipelined mode
+     * (XRSLAMAmdSetThreading): seconds the feature tracker waited for the previous frame's backend at the hand-off */
     double wall_scope[16];
 } XRSLAMAmdTimes;
 void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out);
@@ -202,6 +203,18 @@ typedef struct XRSLAMAmdInitReport {
 void XRSLAMAmdGetInitReport(XRSLAMAmdInitReport *out);
 /* last error raised inside the library ("" if none); the reference aborts/throws instead */
 const char *XRSLAMAmdLastError(void);
+/* Threading.  0 (default) = the reference's PC build: XRSLAMRunOneFrame / the IMU push that completes a frame run feature
+ * tracker and sliding-window tracker inline, one after the other (utility/worker.h:37-45 without XRSLAM_ENABLE_THREADING).
+ * 1 = its XRSLAM_ENABLE_THREADING build (utility/worker.h:16-60; feature tracker and frontend on threads of their own) with
+ * deterministic hand-offs: the sliding-window tracker of frame t runs on a thread of the library beside the feature tracker of
+ * frame t+1, which sees the state published for frame t-1 and propagates it by pre-integration exactly as
+ * FeatureTracker::work does when the frontend lags (core/feature_tracker.cpp:44-66).  Same arithmetic, same kernels; poses
+ * and landmark sets are those of a run whose backend is one frame late, reproducible bit for bit, and NOT those of mode 0.
+ * With parsac.parsac_flag the frames stay inline (update_track_status reads the tracking map from inside the backend).
+ * May be switched between frames.  XRSLAMAmdFlush waits for the frame in flight (also done by Destroy, by the LANDMARKS / BIAS
+ * results and by the statistics getters). */
+void XRSLAMAmdSetThreading(int mode);
+void XRSLAMAmdFlush(void);
 
 /* ---- instance-scoped entry points (additive) ----
  * The six reference symbols above act on one process-global instance, like the reference's XRSLAMManager singleton
@@ -229,6 +242,8 @@ void XRSLAMAmdInstanceGetBaStats(XRSLAMAmdInstance *inst, void *xrhip_ba_stats_o
 void XRSLAMAmdInstanceGetKltStats(XRSLAMAmdInstance *inst, void *xrhip_klt_stats_out, int reset);
 void XRSLAMAmdInstanceGetInitReport(XRSLAMAmdInstance *inst, XRSLAMAmdInitReport *out);
 const char *XRSLAMAmdInstanceLastError(XRSLAMAmdInstance *inst);
+void XRSLAMAmdInstanceSetThreading(XRSLAMAmdInstance *inst, int mode);
+void XRSLAMAmdInstanceFlush(XRSLAMAmdInstance *inst);
 /* The player's loop (xrslam-pc/player/src/main.cpp:116-169) over a pre-staged sequence for the next `n_steps` camera frames:
  * IMU samples up to each frame's time (gyroscope before accelerometer, IO/async_dataset_reader.cpp:41-48), the frame,
  * XRSLAMRunOneFrame, state / body-pose query.  imu7: [n_imu][7] = t, gyroscope xyz, accelerometer xyz; cam_t: [n_frames];

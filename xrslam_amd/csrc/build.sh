@@ -8,7 +8,7 @@ VAR="${XR_VARIANT:+_$XR_VARIANT}"
 OBJ="$HERE/_obj$VAR"
 mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -I$HERE/../../include"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -I$HERE/../../include"
 # kernel revision = hash of the device sources; bench.py prints PMC traffic only from profiles taken at the same revision
 REV="$(cat "$HERE"/*.hip.h | sha1sum | cut -c1-10)"   # the kernels live in the *.hip.h headers; the *.hip files hold the C ABI around them
 if [ "$(cat "$HERE/kernel_rev.gen.h" 2>/dev/null)" != "#define XRHIP_KERNEL_REV \"$REV\"" ]; then
@@ -26,7 +26,7 @@ for s in $SRCS; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libxrslam_hip$VAR.so" $OBJS
+$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o "$OUT/libxrslam_hip$VAR.so" $OBJS
 echo "built $OUT/libxrslam_hip$VAR.so"
 # headless EuRoC player (host only: XRSLAM.h + zlib), links the library just built
 if [ -z "$VAR" ]; then

@@ -9,7 +9,9 @@
 //     refine_window, slide_window, refine_subwindow)      core/sliding_window_tracker.cpp:19-474
 //   Map::marginalize_frame                                map/map.cpp:51-63
 //   Solver facade (problem assembly)                      estimation/solver.cpp:84-173
-// PC semantics: threading off, every worker runs inline in the caller.
+// PC semantics (the default): threading off, every worker runs inline in the caller.
+// System::set_threading(1) is the reference's XRSLAM_ENABLE_THREADING (utility/worker.h:16-60) with the hand-offs made
+// deterministic: the sliding-window tracker of frame t runs on a thread of its own beside the feature tracker of frame t+1.
 // All arithmetic of the hot path is delegated to xrhip_* (KLT, pre-integration, BA, marginalisation).
 //   Initializer (SfM + visual-inertial alignment)         core/initializer.cpp:22-571   (geometry: two_view.hpp)
 //   RD-VIO outlier filters (judge / update_track_status)  core/sliding_window_tracker.cpp:523-790   (parsac.hpp, epnp.hpp)
@@ -20,9 +22,15 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <deque>
+#include <exception>
+#include <functional>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <unordered_set>
@@ -52,6 +60,8 @@ struct StageTimes {   // seconds, accumulated (inspection slots feature_tracker_
     // host wall-clock seconds spent inside the C-ABI calls, and in the whole per-frame work
     double w_upload = 0, w_preprocess = 0, w_track = 0, w_detect = 0, w_preintegrate = 0, w_solve = 0, w_marginalize = 0,
            w_frame = 0;
+    double w_preintegrate_ft = 0;   // pre-integrations of the feature tracker's own context (pipelined mode: another thread)
+    double w_join = 0;              // pipelined mode: the feature tracker waiting for the previous frame's backend
     // host wall-clock seconds of whole pipeline stages (device waits included), see SC_* below
     double scope[16] = {0};
 };
@@ -70,6 +80,8 @@ struct Pipeline {
     xrhip_ba *ba = nullptr;
     xrhip_ba *ba_marg = nullptr;   // marginalisation has a context (buffers, stream) of its own: it runs beside the next frame
     xrhip_ba *ba_aux = nullptr;    // speculative pre-integration batches (started a frame ahead), same reason
+    xrhip_ba *ba_ft = nullptr;     // pipelined mode: the feature tracker's pre-integrations (its thread must not touch `ba`)
+    std::mutex pool_mutex;         // image buffers return from whichever thread drops the last reference
     IdSource ids;
     std::vector<xrhip_image *> image_pool;
     double noise36[36];
@@ -111,19 +123,27 @@ struct Pipeline {
         if (ba) xrhip_ba_destroy(ba);
         if (ba_marg) xrhip_ba_destroy(ba_marg);
         if (ba_aux) xrhip_ba_destroy(ba_aux);
+        if (ba_ft) xrhip_ba_destroy(ba_ft);
         if (klt) xrhip_klt_destroy(klt);
     }
+    void ensure_ft_context() {
+        if (!ba_ft) hip_check(xrhip_ba_create(32, 2048, 16384, &ba_ft), "xrhip_ba_create");
+    }
     xrhip_image *acquire_image() {
-        if (!image_pool.empty()) {
-            xrhip_image *im = image_pool.back();
-            image_pool.pop_back();
-            return im;
+        {
+            std::lock_guard<std::mutex> lk(pool_mutex);
+            if (!image_pool.empty()) {
+                xrhip_image *im = image_pool.back();
+                image_pool.pop_back();
+                return im;
+            }
         }
         xrhip_image *im = nullptr;
         hip_check(xrhip_image_create(klt, &im), "xrhip_image_create");
         return im;
     }
     void recycle_image(xrhip_image *im) {
+        std::lock_guard<std::mutex> lk(pool_mutex);
         xrhip_image_release(im);
         image_pool.push_back(im);
     }
@@ -140,7 +160,9 @@ struct Pipeline {
         return img;
     }
     // PreIntegrator::integrate (preintegrator.cpp:78-95) on the device
-    bool integrate(PreInt &pre, double t, const V3 &bg, const V3 &ba_, bool jac, bool cov) {
+    // (`ctx`: the context whose stream runs it; the feature tracker passes its own in pipelined mode)
+    double &preintegrate_slot(xrhip_ba *ctx) { return ctx && ctx == ba_ft ? times.w_preintegrate_ft : times.w_preintegrate; }
+    bool integrate(PreInt &pre, double t, const V3 &bg, const V3 &ba_, bool jac, bool cov, xrhip_ba *ctx = nullptr) {
         if (pre.data.empty()) return false;
         std::vector<double> smp(pre.data.size() * 7);
         for (size_t i = 0; i < pre.data.size(); ++i) {
@@ -151,14 +173,15 @@ struct Pipeline {
             s[4] = d.a.x; s[5] = d.a.y; s[6] = d.a.z;
         }
         const double b1[3] = {bg.x, bg.y, bg.z}, b2[3] = {ba_.x, ba_.y, ba_.z};
-        WallTimer wt_w_preintegrate(times.w_preintegrate);
-        hip_check(xrhip_ba_preintegrate(ba, smp.data(), (int)pre.data.size(), t, b1, b2, noise36, jac, cov, pre.rec),
+        WallTimer wt_w_preintegrate(preintegrate_slot(ctx));
+        hip_check(xrhip_ba_preintegrate(ctx ? ctx : ba, smp.data(), (int)pre.data.size(), t, b1, b2, noise36, jac, cov, pre.rec),
                   "xrhip_ba_preintegrate");
         pre.valid = true;
         return true;
     }
     // asynchronous form for one interval: integrate_begin queues the kernel, integrate_end waits and stores the record
-    bool integrate_begin(const std::vector<ImuData> &data, double t, const V3 &bg, const V3 &ba_, bool jac, bool cov) {
+    bool integrate_begin(const std::vector<ImuData> &data, double t, const V3 &bg, const V3 &ba_, bool jac, bool cov,
+                         xrhip_ba *ctx = nullptr) {
         if (data.empty()) return false;
         std::vector<double> smp(data.size() * 7);
         for (size_t i = 0; i < data.size(); ++i) {
@@ -170,14 +193,14 @@ struct Pipeline {
         }
         const double b1[3] = {bg.x, bg.y, bg.z}, b2[3] = {ba_.x, ba_.y, ba_.z};
         const int begin = 0, count = (int)data.size();
-        WallTimer wt_w_preintegrate(times.w_preintegrate);
-        hip_check(xrhip_ba_preintegrate_begin(ba, smp.data(), &begin, &count, &t, b1, b2, 1, noise36, jac, cov),
+        WallTimer wt_w_preintegrate(preintegrate_slot(ctx));
+        hip_check(xrhip_ba_preintegrate_begin(ctx ? ctx : ba, smp.data(), &begin, &count, &t, b1, b2, 1, noise36, jac, cov),
                   "xrhip_ba_preintegrate_begin");
         return true;
     }
-    void integrate_end(PreInt &pre) {
-        WallTimer wt_w_preintegrate(times.w_preintegrate);
-        hip_check(xrhip_ba_preintegrate_end(ba, pre.rec), "xrhip_ba_preintegrate_end");
+    void integrate_end(PreInt &pre, xrhip_ba *ctx = nullptr) {
+        WallTimer wt_w_preintegrate(preintegrate_slot(ctx));
+        hip_check(xrhip_ba_preintegrate_end(ctx ? ctx : ba, pre.rec), "xrhip_ba_preintegrate_end");
         pre.valid = true;
     }
     // several integrations in one launch (refine_window re-integrates every keyframe interval, refine_subwindow
@@ -823,9 +846,50 @@ class SlidingWindowTracker {
         if (std::getenv("XRHIP_HOSTPROF"))
             std::fprintf(stderr, "[hostprof] subframe re-integrations: %ld speculated, %ld taken from mirror_frame, %ld computed in place\n",
                          spec_hits_, memo_hits_, spec_misses_);
+        if (std::getenv("XRHIP_HOSTPROF"))
+            std::fprintf(stderr, "[hostprof] mirror_frame: %ld of %ld interval integrations were queued ahead\n", mirror_prepared_,
+                         mirror_total_);
     }
     size_t prepared_id_ = nil(), prepared_from_ = nil(), prepared_samples_ = 0;
     bool prepared_ = false;
+    long mirror_prepared_ = 0, mirror_total_ = 0;
+
+    // Pipelined mode (System::set_threading): the window map belongs to the backend thread while the feature tracker works on
+    // the next frame, so mirror_prepare cannot be called from there.  The feature tracker posts what it knows -- the samples of
+    // the interval that will be mirrored next -- and the backend, at the end of track(), when the biases that integration
+    // starts from are final, queues it; mirror_frame then finds it prepared exactly as after mirror_prepare.  A hint that
+    // comes too late is dropped (mirror_frame integrates in place): the values are the same either way.
+    struct MirrorHint {
+        size_t id, from;
+        double t;
+        std::vector<ImuData> samples;
+    };
+    void post_mirror_hint(MirrorHint h) {
+        std::lock_guard<std::mutex> lk(hint_mutex_);
+        hint_ = std::move(h);
+    }
+    void drop_mirror_hint() {
+        std::lock_guard<std::mutex> lk(hint_mutex_);
+        hint_.reset();
+    }
+    void take_mirror_hint() {   // backend thread
+        std::optional<MirrorHint> h;
+        {
+            std::lock_guard<std::mutex> lk(hint_mutex_);
+            h.swap(hint_);
+        }
+        if (!h) return;
+        cancel_prepared();
+        Frame *keyframe = map->get_frame(map->frame_num() - 1);
+        Frame *new_i = keyframe->subframes.empty() ? keyframe : keyframe->subframes.back().get();
+        if (new_i->id != h->from) return;
+        prepared_ = P_.integrate_begin(h->samples, h->t, new_i->motion.bg, new_i->motion.ba, true, true);
+        prepared_id_ = h->id;
+        prepared_from_ = h->from;
+        prepared_samples_ = h->samples.size();
+    }
+    std::mutex hint_mutex_;
+    std::optional<MirrorHint> hint_;
 
     void mirror_frame(Map *ft_map, size_t frame_id) {   // sliding_window_tracker.cpp:31-80
         xrhip::HostProfScope hp_m(7, "mirror_frame");
@@ -850,9 +914,11 @@ class SlidingWindowTracker {
         // mirror_prepare queued it when the frame entered the tracker (it has been running beside the LK kernel);
         // otherwise it is queued now and runs while the track links are copied below
         bool integrating;
+        mirror_total_++;
         if (prepared_id_ == frame_id && prepared_from_ == new_i->id && prepared_samples_ == nd.size()) {
             integrating = prepared_;
             prepared_id_ = nil();
+            mirror_prepared_++;
         } else {
             cancel_prepared();
             integrating = P_.integrate_begin(nd, curr->image->t, new_i->motion.bg, new_i->motion.ba, true, true);
@@ -921,6 +987,7 @@ class SlidingWindowTracker {
             std::fflush(fp);
         }
         speculate_subframes();
+        take_mirror_hint();
         return true;
     }
 
@@ -1812,12 +1879,145 @@ class Initializer {
     std::unique_ptr<Map> map;
 };
 
+// ------------------------------------------------------------------------------------ the backend thread
+// One job at a time on a thread of its own (utility/worker.h:7-60 with XRSLAM_ENABLE_THREADING).  A frame is a fraction of
+// a millisecond: both sides spin on an atomic before they fall back to the condition variable.
+class JobThread {
+  public:
+    explicit JobThread(int device) : device_(device), th_([this] { loop(); }) {}
+    ~JobThread() {
+        state_.store(QUIT, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    JobThread(const JobThread &) = delete;
+    JobThread &operator=(const JobThread &) = delete;
+    void post(std::function<void()> job) {   // the previous job must have been waited for
+        job_ = std::move(job);
+        error_ = nullptr;
+        state_.store(POSTED, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+        }
+        cv_.notify_all();
+    }
+    void wait() {   // returns when the posted job has finished; rethrows what it threw
+        await([this] { return state_.load(std::memory_order_acquire) == DONE; });
+        state_.store(IDLE, std::memory_order_relaxed);
+        if (error_) {
+            std::exception_ptr e = error_;
+            error_ = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+
+  private:
+    enum { IDLE = 0, POSTED, DONE, QUIT };
+    static void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
+    template <class Pred> void await(Pred pred) {
+        for (int spin = 0; spin < 40000; ++spin) {
+            if (pred()) return;
+            relax();
+        }
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, pred);
+    }
+    void loop() {
+        if (device_ >= 0) xrhip_bind_device(device_);
+        for (;;) {
+            await([this] {
+                const int s = state_.load(std::memory_order_acquire);
+                return s == POSTED || s == QUIT;
+            });
+            if (state_.load(std::memory_order_acquire) == QUIT) return;
+            try {
+                job_();
+            } catch (...) {
+                error_ = std::current_exception();
+            }
+            state_.store(DONE, std::memory_order_release);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+            }
+            cv_.notify_all();
+        }
+    }
+    int device_;
+    std::function<void()> job_;
+    std::exception_ptr error_;
+    std::atomic<int> state_{IDLE};
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread th_;   // last: the members above exist before the thread starts
+};
+
 // ------------------------------------------------------------------------------------ the system
 enum SysState { SYS_INITIALIZING = 0, SYS_TRACKING, SYS_CRASH, SYS_UNKNOWN };
 
-class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no threads)
+enum Threading { THREADING_OFF = 0, THREADING_PIPELINED = 1 };
+
+class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or the backend on a thread (set_threading)
   public:
-    explicit System(const Config &c) : P(c), ft_map(std::make_unique<Map>(&P.ids)), init(P) {}
+    explicit System(const Config &c) : P(c), ft_map(std::make_unique<Map>(&P.ids)), init(P) {
+        if (const char *e = std::getenv("XRSLAM_AMD_THREADING"))
+            if (!std::strcmp(e, "1") || !std::strcmp(e, "pipelined")) set_threading(THREADING_PIPELINED);
+    }
+    ~System() {
+        try {
+            sync();
+        } catch (...) {
+        }
+        worker.reset();
+    }
+
+    // -------- threading.  THREADING_OFF is the PC build of the reference: the feature tracker calls the backend inline.
+    // THREADING_PIPELINED is its XRSLAM_ENABLE_THREADING build with fixed hand-off points, so that a run is reproducible:
+    // the backend (SlidingWindowTracker::track) of frame t runs on `worker` while this thread tracks the features of
+    // frame t+1; the feature tracker of frame t+1 therefore sees the state the backend published for frame t-1 (one frame
+    // older than inline) and propagates it over the frames in between exactly as FeatureTracker::work does whenever the
+    // backend lags (feature_tracker.cpp:44-66).  Hand-offs, all on the feature tracker's thread: wait for the job of
+    // frame t-1 and publish its state (FrontendWorker's latest_state), mirror frame t into the window map (the only step
+    // that touches both maps; SlidingWindowTracker::mirror_frame takes the tracking map's lock for it), post the job
+    // of frame t.  Between hand-offs the two threads share nothing: the feature tracker owns `ft_map`, the KLT context
+    // and `P.ba_ft`; the backend owns the window map and the other BA contexts.  Poses lag one frame more than inline.
+    // RD-VIO's update_track_status reads the tracking map from inside the backend (:741-788): with parsac_flag the
+    // frames stay inline.
+    void set_threading(int mode) {
+        sync();
+        threading = mode == THREADING_PIPELINED ? THREADING_PIPELINED : THREADING_OFF;
+        if (threading == THREADING_PIPELINED) {
+            P.ensure_ft_context();
+            if (!worker) {
+                int dev = -1;
+                if (xrhip_get_device(&dev) != 0) dev = -1;
+                worker = std::make_unique<JobThread>(dev);
+            }
+        }
+    }
+    bool pipelined() const { return threading == THREADING_PIPELINED && !P.config.parsac_flag; }
+    // the backend job in flight (if any) has finished and its state is published when this returns
+    void sync() {
+        if (inflight_id_ == nil()) return;
+        const size_t id = inflight_id_;
+        inflight_id_ = nil();
+        {
+            WallTimer wt(P.times.w_join);
+            worker->wait();
+        }
+        if (inflight_ok_) {
+            auto [t, pose, motion] = swt->get_latest_state();
+            frontend_latest_state = {t, id, pose, motion};
+        }
+    }
 
     // -------- Detail (core/detail.cpp:46-177)
     PoseState track_gyroscope(double t, double x, double y, double z) {
@@ -1931,6 +2131,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
         };
         auto [opt_t, opt_id, opt_pose, opt_motion] = frontend_latest_state;
         (void)opt_t;
+        xrhip_ba *ft_ctx = pipelined() ? P.ba_ft : nullptr;
         bool is_initialized = opt_id != nil();
         bool swt_tag = !is_initialized || frame->id % c.sliding_window_tracker_frequent == 0;
         Map *map = ft_map.get();
@@ -1943,7 +2144,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
                     of->motion = opt_motion;
                     for (size_t j = oi + 1; j < map->frame_num(); ++j) {
                         Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
-                        P.integrate(fj->preintegration, fj->image->t, fi->motion.bg, fi->motion.ba, false, false);
+                        P.integrate(fj->preintegration, fj->image->t, fi->motion.bg, fi->motion.ba, false, false, ft_ctx);
                         predict(fj->preintegration, fi, fj);
                     }
                 } else {
@@ -1959,15 +2160,28 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
                     frame->preintegration.data.insert(frame->preintegration.data.begin(), imu);
                 }
             }
-            if (P.integrate_begin(frame->preintegration.data, frame->image->t, last->motion.bg, last->motion.ba, false, false)) {
+            // pipelined mode: the backend queues that integration itself once its biases are final (take_mirror_hint)
+            if (swt && swt_tag && is_initialized && pipelined()) {
+                if (const size_t from = map->frame_index_by_id(last_mirrored_id_); from != nil()) {
+                    SlidingWindowTracker::MirrorHint h{frame->id, last_mirrored_id_, frame->image->t, frame->preintegration.data};
+                    for (size_t index = map->frame_num() - 1; index > from; --index) {
+                        const std::vector<ImuData> &od = map->get_frame(index)->preintegration.data;
+                        h.samples.insert(h.samples.begin(), od.begin(), od.end());
+                    }
+                    swt->post_mirror_hint(std::move(h));
+                }
+            }
+            if (P.integrate_begin(frame->preintegration.data, frame->image->t, last->motion.bg, last->motion.ba, false, false,
+                                  ft_ctx)) {
                 preprocess();
-                P.integrate_end(frame->preintegration);
+                P.integrate_end(frame->preintegration, ft_ctx);
             }
             preprocess();
             if (swt_tag) hip_check(xrhip_image_prefetch_detect(frame->image->h), "xrhip_image_prefetch_detect");
             // the backend will pre-integrate the same interval with Jacobians and covariance when it mirrors this frame:
             // queued now, it runs beside the LK kernel and the RANSAC gates instead of in front of localize_newframe
-            if (swt && swt_tag && is_initialized) swt->mirror_prepare(map, frame.get());
+            // (inline mode only: in pipelined mode the window map belongs to the backend thread until the hand-off)
+            if (swt && swt_tag && is_initialized && !pipelined()) swt->mirror_prepare(map, frame.get());
             frame_track_keypoints(P, last, frame.get());
             if (is_initialized) {
                 predict(frame->preintegration, last, frame.get());
@@ -1992,6 +2206,14 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
                 auto [t, pose, motion] = swt->get_latest_state();
                 frontend_latest_state = {t, pending_frame_id, pose, motion};
             }
+        } else if (pipelined()) {
+            sync();
+            swt->drop_mirror_hint();   // a hint the backend did not get to is stale from here on
+            swt->mirror_frame(ft_map.get(), pending_frame_id);
+            last_mirrored_id_ = pending_frame_id;
+            inflight_ok_ = false;
+            inflight_id_ = pending_frame_id;
+            worker->post([this] { inflight_ok_ = swt->track(); });
         } else {
             swt->mirror_frame(ft_map.get(), pending_frame_id);
             if (swt->track()) {
@@ -2021,6 +2243,11 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker, inline (no
     std::tuple<double, size_t, PoseState, MotionState> frontend_latest_state{0.0, nil(), PoseState{}, MotionState{}};
     PoseState latest_pose;
     double latest_timestamp = 0;
+    int threading = THREADING_OFF;
+    size_t inflight_id_ = nil();   // frame whose backend job is running on `worker`
+    size_t last_mirrored_id_ = nil();
+    bool inflight_ok_ = false;
+    std::unique_ptr<JobThread> worker;
 };
 
 }   // namespace xrh

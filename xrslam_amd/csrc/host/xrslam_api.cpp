@@ -149,6 +149,7 @@ void impl_get_result(Manager &m, XRSLAMResultType type, void *out) {
             break;
         }
         case XRSLAM_RESULT_LANDMARKS: {
+            m.sys->sync();   // pipelined mode: the window map belongs to the backend thread while a frame is in flight
             auto *lm = static_cast<XRSLAMLandmarks *>(out);
             lm->num_landmarks = 0;
             lm->landmarks = nullptr;
@@ -170,6 +171,7 @@ void impl_get_result(Manager &m, XRSLAMResultType type, void *out) {
         }
         case XRSLAM_RESULT_BIAS: {
             auto *b = static_cast<XRSLAMIMUBias *>(out);
+            m.sys->sync();
             if (m.sys->swt) {
                 auto [t, pose, motion] = m.sys->swt->get_latest_state();
                 (void)t;
@@ -255,10 +257,23 @@ void impl_set_device_undistort(Manager &m, const char *model) {
     guarded(m, [&] { m.sys->P.set_device_undistort(model); });
 }
 
+void impl_flush(Manager &m) {
+    if (!m.sys) return;
+    bind_device(m);
+    guarded(m, [&] { m.sys->sync(); });
+}
+
+void impl_set_threading(Manager &m, int mode) {
+    if (!m.sys) return;
+    bind_device(m);
+    guarded(m, [&] { m.sys->set_threading(mode); });
+}
+
 void impl_get_times(Manager &m, XRSLAMAmdTimes *out) {
     if (!out) return;
     std::memset(out, 0, sizeof(*out));
     if (!m.sys) return;
+    impl_flush(m);
     const xrh::StageTimes &t = m.sys->P.times;
     out->frames = t.frames;
     out->solves = t.solves;
@@ -269,11 +284,12 @@ void impl_get_times(Manager &m, XRSLAMAmdTimes *out) {
     out->wall_preprocess = t.w_preprocess;
     out->wall_track = t.w_track;
     out->wall_detect = t.w_detect;
-    out->wall_preintegrate = t.w_preintegrate;
+    out->wall_preintegrate = t.w_preintegrate + t.w_preintegrate_ft;
     out->wall_solve = t.w_solve;
     out->wall_marginalize = t.w_marginalize;
     out->wall_frame = t.w_frame;
-    for (int i = 0; i < 16; ++i) out->wall_scope[i] = t.scope[i];
+    for (int i = 0; i < 15; ++i) out->wall_scope[i] = t.scope[i];
+    out->wall_scope[15] = t.w_join;
 }
 
 void impl_set_profiling(Manager &m, int enable) {
@@ -286,6 +302,7 @@ void impl_set_profiling(Manager &m, int enable) {
 
 void impl_get_ba_stats(Manager &m, void *out, int reset) {
     if (!m.sys || !out) return;
+    impl_flush(m);
     bind_device(m);
     guarded(m, [&] { xrh::hip_check(xrhip_ba_get_stats(m.sys->P.ba, static_cast<xrhip_ba_stats *>(out), reset), "xrhip_ba_get_stats"); });
 }
@@ -345,6 +362,8 @@ void XRSLAMAmdGetBaStats(void *out, int reset) { impl_get_ba_stats(mgr(), out, r
 void XRSLAMAmdGetKltStats(void *out, int reset) { impl_get_klt_stats(mgr(), out, reset); }
 void XRSLAMAmdGetInitReport(XRSLAMAmdInitReport *out) { impl_get_init_report(mgr(), out); }
 const char *XRSLAMAmdLastError(void) { return mgr().last_error.c_str(); }
+void XRSLAMAmdSetThreading(int mode) { impl_set_threading(mgr(), mode); }
+void XRSLAMAmdFlush(void) { impl_flush(mgr()); }
 
 // ---- the same entry points on caller-owned instances (several sequences per process / per GPU)
 int XRSLAMAmdInstanceCreate(const char *slam_config_path, const char *device_config_path, XRSLAMAmdInstance **out,
@@ -405,6 +424,12 @@ void XRSLAMAmdInstanceGetInitReport(XRSLAMAmdInstance *inst, XRSLAMAmdInitReport
     if (inst) impl_get_init_report(inst->m, out);
 }
 const char *XRSLAMAmdInstanceLastError(XRSLAMAmdInstance *inst) { return inst ? inst->m.last_error.c_str() : ""; }
+void XRSLAMAmdInstanceSetThreading(XRSLAMAmdInstance *inst, int mode) {
+    if (inst) impl_set_threading(inst->m, mode);
+}
+void XRSLAMAmdInstanceFlush(XRSLAMAmdInstance *inst) {
+    if (inst) impl_flush(inst->m);
+}
 
 // The player's loop (xrslam-pc/player/src/main.cpp:116-169) for n_steps camera frames of a pre-staged sequence, without a
 // host-language round trip per sensor sample: at equal timestamps gyroscope, then accelerometer, then camera

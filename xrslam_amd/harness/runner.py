@@ -76,6 +76,9 @@ def load(lib_path):
     if hasattr(lib, "XRSLAMAmdSetDeviceUndistort"):
         lib.XRSLAMAmdSetDeviceUndistort.argtypes = [C.c_char_p]
         lib.XRSLAMAmdSetDeviceUndistort.restype = None
+    lib.XRSLAMAmdSetThreading.argtypes = [C.c_int]
+    lib.XRSLAMAmdSetThreading.restype = None
+    lib.XRSLAMAmdFlush.restype = None
     if hasattr(lib, "XRSLAMAmdInstanceCreate"):   # instance-scoped forms: the instance handle is the first argument
         H = C.c_void_p
         lib.XRSLAMAmdInstanceCreate.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(H), C.POINTER(C.c_void_p)]
@@ -86,7 +89,8 @@ def load(lib_path):
                                 ("GetTimes", [C.POINTER(XRSLAMAmdTimes)], None), ("SetProfiling", [C.c_int], None),
                                 ("GetBaStats", [C.c_void_p, C.c_int], None), ("GetKltStats", [C.c_void_p, C.c_int], None),
                                 ("GetInitReport", [C.POINTER(XRSLAMAmdInitReport)], None), ("LastError", [], C.c_char_p),
-                                ("SetDeviceUndistort", [C.c_char_p], None)):
+                                ("SetDeviceUndistort", [C.c_char_p], None), ("SetThreading", [C.c_int], None),
+                                ("Flush", [], None)):
             fn = getattr(lib, "XRSLAMAmdInstance" + name)
             fn.argtypes = [H] + args
             fn.restype = res
@@ -114,7 +118,9 @@ class _Api:
                  "get_klt_stats": ("XRSLAMAmdGetKltStats", "XRSLAMAmdInstanceGetKltStats"),
                  "get_init_report": ("XRSLAMAmdGetInitReport", "XRSLAMAmdInstanceGetInitReport"),
                  "last_error": ("XRSLAMAmdLastError", "XRSLAMAmdInstanceLastError"),
-                 "set_device_undistort": ("XRSLAMAmdSetDeviceUndistort", "XRSLAMAmdInstanceSetDeviceUndistort")}
+                 "set_device_undistort": ("XRSLAMAmdSetDeviceUndistort", "XRSLAMAmdInstanceSetDeviceUndistort"),
+                 "set_threading": ("XRSLAMAmdSetThreading", "XRSLAMAmdInstanceSetThreading"),
+                 "sync": ("XRSLAMAmdFlush", "XRSLAMAmdInstanceFlush")}
         for attr, (glob, inst) in names.items():
             setattr(self, attr, getattr(lib, glob) if handle is None else functools.partial(getattr(lib, inst), handle))
 
@@ -124,7 +130,7 @@ class Session:
     instance=True -- an XRSLAMAmdInstance of its own, so that several sessions can live in one process."""
 
     def __init__(self, lib_path, seq, slam_yaml=SLAM_YAML, sensor_yaml=SENSOR_YAML, device_frames=None,
-                 init_frames=60, instance=False, device_undistort=None):
+                 init_frames=60, instance=False, device_undistort=None, threading=0):
         self.lib = load(lib_path)
         self.seq = seq
         cfg = C.c_void_p()
@@ -140,6 +146,8 @@ class Session:
             if ok != 1:
                 raise RuntimeError("XRSLAMCreate failed: %s" % self.lib.XRSLAMAmdLastError().decode())
             self.api = _Api(self.lib)
+        if threading:   # 1 = backend of frame t beside the feature tracker of frame t+1 (XRSLAMAmdSetThreading)
+            self.api.set_threading(int(threading))
         if device_undistort:   # frames are pushed as the camera recorded them and rectified on the GPU
             self.api.set_device_undistort(device_undistort.encode())
         st = seq["states"]
@@ -230,6 +238,10 @@ class Session:
         """Pushes the IMU samples after the last frame so the last queued frame is processed
         (processing is triggered by the first IMU sample later than the frame, detail.cpp:130-142)."""
         self._push_imu_until(1e300)
+
+    def sync(self):
+        """Pipelined mode: waits for the backend job in flight (no-op otherwise)."""
+        self.api.sync()
 
     def times(self):
         t = XRSLAMAmdTimes()
