@@ -283,6 +283,15 @@ int xrhip_ba_preintegrate_begin(xrhip_ba *ctx, const double *samples, const int 
                                 const double *t_end, const double *bg, const double *ba, int n_jobs,
                                 const double *noise_cov36, int compute_jacobian, int compute_covariance);
 int xrhip_ba_preintegrate_end(xrhip_ba *ctx, double *out);
+/* A batch whose integrations start from biases the NEXT xrhip_ba_solve on this context is about to produce: job k uses
+ * bg / ba of frame bias_frame[k] of that problem as the solve leaves them (PreIntegrator::integrate(t, bg, ba, ...) of the
+ * reference called right after Solver::solve with frame->motion.bg / .ba, e.g. sliding_window_tracker.cpp:54-56 after :441).
+ * The call only stages the batch; the solve launches it behind its last kernel (the single-launch solves: on the device,
+ * reading the biases where that kernel leaves them, so the integration needs no host round trip in between), and
+ * xrhip_ba_preintegrate_end collects it as usual.  Same values as _begin with the biases read back by the host. */
+int xrhip_ba_preintegrate_after_solve(xrhip_ba *ctx, const double *samples, const int *sample_begin, const int *sample_count,
+                                      const double *t_end, const int *bias_frame, int n_jobs, const double *noise_cov36,
+                                      int compute_jacobian, int compute_covariance);
 
 /* parity/testing aids (not part of the reference interface): the unreduced normal equations of one
  * linearisation, and the MFMA Schur product kernel on arbitrary inputs. */

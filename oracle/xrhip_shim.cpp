@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -45,6 +46,14 @@ struct xrhip_ba {
     // results of the asynchronous forms, per context like the product (computed at _begin, handed over at _end)
     std::vector<double> preint_out, marg_si, marg_iv, marg_lin;
     int preint_rc = 0, marg_rc = 0;
+    // xrhip_ba_preintegrate_after_solve: the batch waits here for the next solve's biases
+    struct Deferred {
+        std::vector<double> samples, t_end, noise;
+        std::vector<int> begin, count, frame;
+        int jac = 0, cov = 0;
+    };
+    bool have_deferred = false;
+    Deferred deferred;
 };
 
 static thread_local std::string g_err;
@@ -157,7 +166,30 @@ int xrhip_ba_create(int, int, int, xrhip_ba **out) {
     return 0;
 }
 void xrhip_ba_destroy(xrhip_ba *c) { delete c; }
-int xrhip_ba_solve(xrhip_ba *, const xrhip_ba_problem *P, xrhip_ba_summary *s) { return orc_ba_solve(P, s); }
+int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *begin, const int *count, const double *t_end,
+                                const double *bg, const double *ba, int n_jobs, const double *noise36, int jac, int cov);
+int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *s) {
+    int rc = orc_ba_solve(P, s);
+    if (rc == 0 && c && c->have_deferred) {   // the deferred batch starts from the biases this solve produced
+        c->have_deferred = false;
+        const xrhip_ba::Deferred &d = c->deferred;
+        const int n = (int)d.frame.size();
+        std::vector<double> bg(3 * (size_t)n), ba(3 * (size_t)n);
+        for (int k = 0; k < n; ++k) {
+            if (d.frame[k] < 0 || d.frame[k] >= P->n_frames) {
+                g_err = "xrhip_ba_preintegrate_after_solve: bias frame is not a frame of the solve";
+                return XRHIP_EINVAL;
+            }
+            for (int i = 0; i < 3; ++i) {
+                bg[3 * k + i] = P->frame_state[16 * d.frame[k] + 10 + i];
+                ba[3 * k + i] = P->frame_state[16 * d.frame[k] + 13 + i];
+            }
+        }
+        xrhip_ba_preintegrate_begin(c, d.samples.data(), d.begin.data(), d.count.data(), d.t_end.data(), bg.data(), ba.data(), n,
+                                    d.noise.data(), d.jac, d.cov);
+    }
+    return rc;
+}
 int xrhip_ba_marginalize(xrhip_ba *, const xrhip_marg_problem *M, double *a, double *b, double *c) {
     int rc = orc_ba_marginalize(M, a, b, c);
     if (rc) g_err = "marginalize failed";
@@ -191,7 +223,32 @@ int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *b
     c->preint_rc = xrhip_ba_preintegrate_batch(c, samples, begin, count, t_end, bg, ba, n_jobs, noise36, jac, cov, c->preint_out.data());
     return 0;
 }
+int xrhip_ba_preintegrate_after_solve(xrhip_ba *c, const double *samples, const int *begin, const int *count, const double *t_end,
+                                      const int *bias_frame, int n_jobs, const double *noise36, int jac, int cov) {
+    if (!c || !samples || !begin || !count || !t_end || !bias_frame || !noise36 || n_jobs <= 0) {
+        g_err = "xrhip_ba_preintegrate_after_solve: bad arguments";
+        return XRHIP_EINVAL;
+    }
+    int total = 0;
+    for (int k = 0; k < n_jobs; ++k) total = std::max(total, begin[k] + count[k]);
+    xrhip_ba::Deferred &d = c->deferred;
+    d.samples.assign(samples, samples + 7 * (size_t)total);
+    d.begin.assign(begin, begin + n_jobs);
+    d.count.assign(count, count + n_jobs);
+    d.t_end.assign(t_end, t_end + n_jobs);
+    d.frame.assign(bias_frame, bias_frame + n_jobs);
+    d.noise.assign(noise36, noise36 + 36);
+    d.jac = jac;
+    d.cov = cov;
+    c->have_deferred = true;
+    return 0;
+}
 int xrhip_ba_preintegrate_end(xrhip_ba *c, double *out) {
+    if (c->have_deferred) {
+        c->have_deferred = false;
+        g_err = "xrhip_ba_preintegrate_end: the batch waits for a solve that never ran";
+        return XRHIP_ESTATE;
+    }
     if (c->preint_rc) return c->preint_rc;
     std::memcpy(out, c->preint_out.data(), sizeof(double) * c->preint_out.size());
     return 0;

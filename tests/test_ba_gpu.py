@@ -218,6 +218,31 @@ def test_pipeline_snapshots_match_golden(ctx):
         np.testing.assert_allclose(b.inv_depth, exp["inv_depth"], rtol=1e-6, atol=1e-9, err_msg=name)
 
 
+def test_preintegration_queued_behind_a_solve(ctx):
+    """xrhip_ba_preintegrate_after_solve: the integration starts from the biases the solve leaves on the device.  Same
+    kernel, same inputs as the host-mediated form (solve, read the biases back, xrhip_ba_preintegrate) -> the same bits, for
+    the single-launch solves (the batch runs behind kb_chain, reading the device state) and for the window solves (launched
+    when the solve returns).  A batch that no solve follows is refused by _end, and the context stays usable."""
+    from tests import ba_snapshots
+    _, truth = bs.make_window(K=5, L=20, seed=31)
+    smp, t_end = truth["samples"][1], truth["times"][2]
+    for name, pd, _exp in ba_snapshots.load_all():
+        free = [f for f in range(len(pd.frame_state)) if (pd.frame_fix[f] & 2) == 0]      # frames whose motion is optimised
+        f = free[-1] if free else 0
+        b = pd.copy()
+        ctx.preintegrate_after_solve(smp, t_end, f, bs.NOISE36)
+        ctx.solve(b)
+        chained = ctx.preintegrate_end()
+        direct = ctx.preintegrate(smp, t_end, b.frame_state[f, 10:13], b.frame_state[f, 13:16], bs.NOISE36)
+        np.testing.assert_array_equal(chained, direct, err_msg=name)
+        assert not np.array_equal(b.frame_state[f, 10:16], pd.frame_state[f, 10:16]) or not free, name   # the solve did move them
+    ctx.preintegrate_after_solve(smp, t_end, 0, bs.NOISE36)
+    with pytest.raises(Exception):
+        ctx.preintegrate_end()
+    np.testing.assert_array_equal(ctx.preintegrate(smp, t_end, np.zeros(3), np.zeros(3), bs.NOISE36),
+                                  ctx.preintegrate(smp, t_end, np.zeros(3), np.zeros(3), bs.NOISE36))
+
+
 def _marg_problem(pd, victim=0):
     seen = set(pd.obs_lm[(pd.obs_ref == victim) | (pd.obs_tgt == victim)])
     sel = np.array([l in seen for l in pd.obs_lm])

@@ -4,6 +4,8 @@ of every production factor (the method of the reference's own CostFunctionValida
 estimation/ceres/cost_function_validator.h: central differences here, tolerance 2e-6 relative),
 an independent numpy restatement of pre-integration, an independent numpy Schur complement
 for marginalisation, and an independent minimiser (scipy) for the solver's fixed point."""
+import os
+
 import numpy as np
 import pytest
 
@@ -407,3 +409,32 @@ def test_pipeline_snapshots_regression():
         np.testing.assert_allclose(a.frame_state, exp["frame_state"], rtol=1e-9, atol=1e-12, err_msg=name)
         np.testing.assert_allclose(a.inv_depth, exp["inv_depth"], rtol=1e-9, atol=1e-12, err_msg=name)
     assert kinds == {"localize", "subwindow", "window"}
+
+
+def test_preintegration_queued_behind_a_solve_cpu_shim():
+    """xrhip_ba_preintegrate_after_solve through the CPU shim (oracle/xrhip_shim.cpp exports the plug point's symbols over the
+    oracle): the record equals the one integrated from the biases the solve returned -- what tests/test_ba_gpu.py asserts of
+    the device path, where the batch runs behind the solve's last kernel."""
+    import ctypes
+    from tests import ba_snapshots, ba_synth as bs
+    from xrslam_amd import ba
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libxrslam_oracle.so")
+    if not os.path.exists(shim):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(os.path.dirname(shim))])
+    ctx = ba.BaContext(lib=ba.configure(ctypes.CDLL(shim)))
+    _, truth = bs.make_window(K=5, L=20, seed=31)
+    smp, t_end = truth["samples"][1], truth["times"][2]
+    for name, pd, _exp in ba_snapshots.load_all()[:3]:
+        free = [f for f in range(len(pd.frame_state)) if (pd.frame_fix[f] & 2) == 0]
+        f = free[-1] if free else 0
+        b = pd.copy()
+        ctx.preintegrate_after_solve(smp, t_end, f, bs.NOISE36)
+        ctx.solve(b)
+        chained = ctx.preintegrate_end()
+        direct = ctx.preintegrate(smp, t_end, b.frame_state[f, 10:13], b.frame_state[f, 13:16], bs.NOISE36)
+        np.testing.assert_array_equal(chained, direct, err_msg=name)
+    ctx.preintegrate_after_solve(smp, t_end, 0, bs.NOISE36)
+    with pytest.raises(Exception):
+        ctx.preintegrate_end()
+    ctx.close()

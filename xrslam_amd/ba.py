@@ -9,25 +9,35 @@ from ._lib import check
 _L = None
 
 
+def configure(lib):
+    """Declares the argument types of the plug point's entry points on `lib` (the product library, or -- in tests -- the CPU
+    oracle's shim, which exports the same symbols)."""
+    vp = C.c_void_p
+    lib.xrhip_ba_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.xrhip_ba_destroy.argtypes = [vp]
+    lib.xrhip_ba_destroy.restype = None
+    lib.xrhip_ba_solve.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary)]
+    if hasattr(lib, "xrhip_ba_marginalize"):
+        lib.xrhip_ba_marginalize.argtypes = [vp, C.POINTER(abi.MargProblem), vp, vp, vp]
+    if hasattr(lib, "xrhip_ba_marginalize_begin"):
+        lib.xrhip_ba_marginalize_begin.argtypes = [vp, C.POINTER(abi.MargProblem)]
+        lib.xrhip_ba_marginalize_end.argtypes = [vp, vp, vp, vp]
+    if hasattr(lib, "xrhip_ba_preintegrate"):
+        lib.xrhip_ba_preintegrate.argtypes = [vp, vp, C.c_int, C.c_double, vp, vp, vp, C.c_int, C.c_int, vp]
+    if hasattr(lib, "xrhip_ba_preintegrate_after_solve"):
+        lib.xrhip_ba_preintegrate_after_solve.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int]
+        lib.xrhip_ba_preintegrate_end.argtypes = [vp, vp]
+    if hasattr(lib, "xrhip_ba_debug_linearize"):
+        lib.xrhip_ba_debug_linearize.argtypes = [vp, C.POINTER(abi.BaProblem), vp, vp, vp, vp, vp, vp]
+    if hasattr(lib, "xrhip_ba_debug_schur"):
+        lib.xrhip_ba_debug_schur.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    return lib
+
+
 def L():
     global _L
     if _L is None:
-        lib = _lib.lib()
-        vp = C.c_void_p
-        lib.xrhip_ba_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
-        lib.xrhip_ba_destroy.argtypes = [vp]
-        lib.xrhip_ba_destroy.restype = None
-        lib.xrhip_ba_solve.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary)]
-        if hasattr(lib, "xrhip_ba_marginalize"):
-            lib.xrhip_ba_marginalize.argtypes = [vp, C.POINTER(abi.MargProblem), vp, vp, vp]
-        if hasattr(lib, "xrhip_ba_marginalize_begin"):
-            lib.xrhip_ba_marginalize_begin.argtypes = [vp, C.POINTER(abi.MargProblem)]
-            lib.xrhip_ba_marginalize_end.argtypes = [vp, vp, vp, vp]
-        if hasattr(lib, "xrhip_ba_preintegrate"):
-            lib.xrhip_ba_preintegrate.argtypes = [vp, vp, C.c_int, C.c_double, vp, vp, vp, C.c_int, C.c_int, vp]
-        lib.xrhip_ba_debug_linearize.argtypes = [vp, C.POINTER(abi.BaProblem), vp, vp, vp, vp, vp, vp]
-        lib.xrhip_ba_debug_schur.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
-        _L = lib
+        _L = configure(_lib.lib())
     return _L
 
 
@@ -38,14 +48,15 @@ def _p(a):
 class BaContext:
     """One per sequence: owns the BA stream and device arenas."""
 
-    def __init__(self, max_frames=24, max_landmarks=1024, max_obs=8192):
+    def __init__(self, max_frames=24, max_landmarks=1024, max_obs=8192, lib=None):
+        self._lib = lib if lib is not None else L()
         h = C.c_void_p()
-        check(L().xrhip_ba_create(int(max_frames), int(max_landmarks), int(max_obs), C.byref(h)))
+        check(self._lib.xrhip_ba_create(int(max_frames), int(max_landmarks), int(max_obs), C.byref(h)))
         self._h = h
 
     def close(self):
         if getattr(self, "_h", None):
-            L().xrhip_ba_destroy(self._h)
+            self._lib.xrhip_ba_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -58,7 +69,7 @@ class BaContext:
         """Solver::solve(): optimises pd.frame_state / pd.inv_depth in place; returns abi.BaSummary."""
         s = pd.struct()
         sm = abi.BaSummary()
-        check(L().xrhip_ba_solve(self._h, C.byref(s), C.byref(sm)))
+        check(self._lib.xrhip_ba_solve(self._h, C.byref(s), C.byref(sm)))
         return sm
 
     def marginalize(self, md):
@@ -68,13 +79,13 @@ class BaContext:
         si = np.zeros((n, n))
         iv = np.zeros(n)
         lin = np.zeros((k, 16))
-        check(L().xrhip_ba_marginalize(self._h, C.byref(s), _p(si), _p(iv), _p(lin)))
+        check(self._lib.xrhip_ba_marginalize(self._h, C.byref(s), _p(si), _p(iv), _p(lin)))
         return si, iv, lin
 
     def marginalize_begin(self, md):
         """Queues the marginalisation (xrhip_ba_marginalize_begin); marginalize_end() returns its result."""
         self._marg_k = len(md.frame_state) - 1
-        check(L().xrhip_ba_marginalize_begin(self._h, C.byref(md.struct())))
+        check(self._lib.xrhip_ba_marginalize_begin(self._h, C.byref(md.struct())))
 
     def marginalize_end(self):
         k = self._marg_k
@@ -82,16 +93,31 @@ class BaContext:
         si = np.zeros((n, n))
         iv = np.zeros(n)
         lin = np.zeros((k, 16))
-        check(L().xrhip_ba_marginalize_end(self._h, _p(si), _p(iv), _p(lin)))
+        check(self._lib.xrhip_ba_marginalize_end(self._h, _p(si), _p(iv), _p(lin)))
         return si, iv, lin
 
     def preintegrate(self, samples, t_end, bg, ba, noise36, jac=True, cov=True):
         samples = np.ascontiguousarray(samples, np.float64).reshape(-1, 7)
         bg, ba, noise36 = [np.ascontiguousarray(v, np.float64) for v in (bg, ba, noise36)]
         out = np.zeros(abi.IMU_DIM)
-        check(L().xrhip_ba_preintegrate(self._h, _p(samples), len(samples), float(t_end), _p(bg), _p(ba), _p(noise36),
+        check(self._lib.xrhip_ba_preintegrate(self._h, _p(samples), len(samples), float(t_end), _p(bg), _p(ba), _p(noise36),
                                         int(jac), int(cov), _p(out)))
         return out
+
+    def preintegrate_after_solve(self, samples, t_end, bias_frame, noise36, jac=True, cov=True):
+        """Stages one interval whose integration starts from the biases the NEXT solve() gives frame `bias_frame` of its
+        problem (xrhip_ba_preintegrate_after_solve); preintegrate_end() returns the record once that solve has run."""
+        samples = np.ascontiguousarray(samples, np.float64).reshape(-1, 7)
+        noise36 = np.ascontiguousarray(noise36, np.float64)
+        begin, count, frame = (np.array([v], np.int32) for v in (0, len(samples), bias_frame))
+        t = np.array([t_end], np.float64)
+        check(self._lib.xrhip_ba_preintegrate_after_solve(self._h, _p(samples), _p(begin), _p(count), _p(t), _p(frame), 1, _p(noise36),
+                                                    int(jac), int(cov)))
+
+    def preintegrate_end(self, n_jobs=1):
+        out = np.zeros((n_jobs, abi.IMU_DIM))
+        check(self._lib.xrhip_ba_preintegrate_end(self._h, _p(out)))
+        return out[0] if n_jobs == 1 else out
 
     def debug_linearize(self, pd):
         s = pd.struct()
@@ -102,7 +128,7 @@ class BaContext:
         gl = np.zeros(max(Ln, 1))
         W = np.zeros((max(Ln, 1), 6 * F))
         cost = C.c_double()
-        check(L().xrhip_ba_debug_linearize(self._h, C.byref(s), _p(H), _p(g), _p(hll), _p(gl), _p(W), C.byref(cost)))
+        check(self._lib.xrhip_ba_debug_linearize(self._h, C.byref(s), _p(H), _p(g), _p(hll), _p(gl), _p(W), C.byref(cost)))
         return dict(H=H, g=g, hll=hll[:Ln], gl=gl[:Ln], W=W[:Ln], cost=cost.value)
 
     def debug_schur(self, W, w):
@@ -110,5 +136,5 @@ class BaContext:
         w = np.ascontiguousarray(w, np.float64)
         Ln, P = W.shape
         out = np.zeros((P, P))
-        check(L().xrhip_ba_debug_schur(self._h, _p(W), _p(w), Ln, P, _p(out)))
+        check(self._lib.xrhip_ba_debug_schur(self._h, _p(W), _p(w), Ln, P, _p(out)))
         return out

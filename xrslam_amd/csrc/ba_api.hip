@@ -55,6 +55,9 @@ struct xrhip_ba {
     } marg;
     int preint_pending = 0;            // jobs of the pre-integration batch in flight (begin/end), 0 = none
     size_t preint_o_out = 0, preint_o_st = 0;
+    // a batch staged by xrhip_ba_preintegrate_after_solve: launched by the next xrhip_ba_solve behind its last kernel
+    int preint_deferred = 0, preint_def_jac = 0, preint_def_cov = 0;
+    size_t preint_o_jobs = 0, preint_o_smp = 0, preint_o_noise = 0;
     // optional HIP-event profiling of kb_solve_try
     bool profiling = false;
     struct Timed {
@@ -666,6 +669,8 @@ void xrhip_ba_destroy(xrhip_ba *c) {
     delete c;
 }
 
+static int preint_launch_deferred(xrhip_ba *c, const xrhip_ba_problem *P, const double *state_dev);   // defined with the pre-integration entry points
+
 int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
     if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: null context");
     int rc = validate(P);
@@ -686,7 +691,7 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
         sm.termination = XRHIP_BA_CONVERGENCE;
         sm.usable = 1;
         if (summary) *summary = sm;
-        return XRHIP_OK;
+        return preint_launch_deferred(c, P, nullptr);
     }
     BaDims d;
     BaPtrs p;
@@ -726,6 +731,9 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
         hipLaunchKernelGGL(kb_chain, dim3(1), dim3(CHAIN_THREADS), chain_lds, s, c->tiny_args, seq, 4 * (P->max_iterations + 8), chain_tile);
         XR_HIP(hipGetLastError());
         if (c->profiling) XR_HIP(hipEventRecord(e1, s));
+        // a pre-integration that starts from this solve's biases runs right behind it, reading them where the kernel leaves them
+        rc = preint_launch_deferred(c, P, p.state);
+        if (rc) return rc;
         rc = wait_mailbox(c, seq);
         if (rc) return rc;
         if (c->h_ctl->status != ST_DONE) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: trust-region loop did not terminate");
@@ -850,6 +858,8 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     // the optimised states (in place, like the reference)
     std::memcpy(P->frame_state, c->h_out, sizeof(double) * 16 * d.F);
     if (d.L) std::memcpy(P->inv_depth, c->h_out + 16 * d.F, sizeof(double) * d.L);
+    rc = preint_launch_deferred(c, P, nullptr);   // (the single-launch path has launched it already)
+    if (rc) return rc;
     const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     const BaCtl &ctl = *c->h_ctl;
     {   // development aid: XRHIP_KPROF_MIN_NA restricts the accumulated phase timers to solves of at least that size
@@ -1141,17 +1151,18 @@ int xrhip_ba_marginalize_end(xrhip_ba *c, double *out_sqrt_info, double *out_inf
     return marg_collect(c, out_sqrt_info, out_infovec, out_lin);
 }
 
-int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *sample_begin, const int *sample_count,
-                                const double *t_end, const double *bg, const double *ba, int n_jobs,
-                                const double *noise_cov36, int compute_jacobian, int compute_covariance) {
-    if (!c || !samples || !sample_begin || !sample_count || !t_end || !bg || !ba || !noise_cov36 || n_jobs <= 0)
-        return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: bad arguments");
+// Stages a batch in the pinned block (jobs, samples, noise; results and status words behind them).  bias_frame: per job, the
+// frame of the next solve whose biases the integration starts from (the values in bg / ba are then ignored), or nullptr.
+static int preint_stage(xrhip_ba *c, const double *samples, const int *sample_begin, const int *sample_count,
+                        const double *t_end, const double *bg, const double *ba, const int *bias_frame, int n_jobs,
+                        const double *noise_cov36) {
     if (c->preint_pending) {
         // a batch nobody collected (its owner unwound on an error between begin and end): the staging block it writes
         // to is about to be reused, so wait for its kernel and forget it instead of refusing every later frame
         XR_HIP(hipStreamSynchronize(c->stream));
         c->preint_pending = 0;
     }
+    c->preint_deferred = 0;
     int total = 0;
     for (int k = 0; k < n_jobs; ++k) {
         if (sample_count[k] <= 0 || sample_begin[k] < 0) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: empty IMU segment");
@@ -1169,34 +1180,96 @@ int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *s
     int rc = ensure_work2(c, 0, bytes);
     if (rc) return rc;
     char *H = c->h_stage;
-    char *Dv = nullptr;
-    XR_HIP(hipHostGetDevicePointer((void **)&Dv, H, 0));
     PreintJob *jobs = (PreintJob *)(H + o_jobs);
     for (int k = 0; k < n_jobs; ++k) {
         jobs[k].sample_begin = sample_begin[k];
         jobs[k].sample_count = sample_count[k];
         jobs[k].t_end = t_end[k];
         for (int i = 0; i < 3; ++i) {
-            jobs[k].bg[i] = bg[3 * k + i];
-            jobs[k].ba[i] = ba[3 * k + i];
+            jobs[k].bg[i] = bg ? bg[3 * k + i] : 0.0;
+            jobs[k].ba[i] = ba ? ba[3 * k + i] : 0.0;
         }
+        jobs[k].bias_frame = bias_frame ? bias_frame[k] : -1;
+        jobs[k].pad_ = 0;
     }
     std::memcpy(H + o_smp, samples, b_smp);
     std::memcpy(H + o_noise, noise_cov36, b_noise);
     std::memset(H + o_st, 0, sizeof(int) * n_jobs);
-    hipStream_t s = c->stream;
-    hipLaunchKernelGGL(kp_preintegrate, dim3(n_jobs), dim3(64), 0, s, (const PreintJob *)(Dv + o_jobs),
-                       (const double *)(Dv + o_smp), (const double *)(Dv + o_noise), compute_jacobian ? 1 : 0,
-                       compute_covariance ? 1 : 0, (double *)(Dv + o_out), (int *)(Dv + o_st));
-    XR_HIP(hipGetLastError());
-    c->preint_pending = n_jobs;
+    c->preint_o_jobs = o_jobs;
+    c->preint_o_smp = o_smp;
+    c->preint_o_noise = o_noise;
     c->preint_o_out = o_out;
     c->preint_o_st = o_st;
     return XRHIP_OK;
 }
 
+static int preint_launch(xrhip_ba *c, int n_jobs, int jac, int cov, const double *state_dev) {
+    char *Dv = nullptr;
+    XR_HIP(hipHostGetDevicePointer((void **)&Dv, c->h_stage, 0));
+    hipLaunchKernelGGL(kp_preintegrate, dim3(n_jobs), dim3(64), 0, c->stream, (const PreintJob *)(Dv + c->preint_o_jobs),
+                       (const double *)(Dv + c->preint_o_smp), (const double *)(Dv + c->preint_o_noise), jac ? 1 : 0, cov ? 1 : 0,
+                       (double *)(Dv + c->preint_o_out), (int *)(Dv + c->preint_o_st), state_dev);
+    XR_HIP(hipGetLastError());
+    c->preint_pending = n_jobs;
+    c->preint_deferred = 0;
+    return XRHIP_OK;
+}
+
+// The deferred batch of xrhip_ba_preintegrate_after_solve, launched by xrhip_ba_solve.  state_dev: the solve's frame states on
+// the device, final once everything queued on the stream so far has run (the single-launch path), or nullptr: the solve has
+// returned its states to the host already (P->frame_state), the biases go into the jobs by value.
+static int preint_launch_deferred(xrhip_ba *c, const xrhip_ba_problem *P, const double *state_dev) {
+    if (!c->preint_deferred) return XRHIP_OK;
+    const int n_jobs = c->preint_deferred;
+    PreintJob *jobs = (PreintJob *)(c->h_stage + c->preint_o_jobs);
+    for (int k = 0; k < n_jobs; ++k) {
+        const int f = jobs[k].bias_frame;
+        if (f < 0 || f >= P->n_frames) {
+            c->preint_deferred = 0;
+            return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_after_solve: bias frame is not a frame of the solve");
+        }
+        if (!state_dev) {
+            for (int i = 0; i < 3; ++i) {
+                jobs[k].bg[i] = P->frame_state[16 * f + 10 + i];
+                jobs[k].ba[i] = P->frame_state[16 * f + 13 + i];
+            }
+            jobs[k].bias_frame = -1;
+        }
+    }
+    return preint_launch(c, n_jobs, c->preint_def_jac, c->preint_def_cov, state_dev);
+}
+
+int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *sample_begin, const int *sample_count,
+                                const double *t_end, const double *bg, const double *ba, int n_jobs,
+                                const double *noise_cov36, int compute_jacobian, int compute_covariance) {
+    if (!c || !samples || !sample_begin || !sample_count || !t_end || !bg || !ba || !noise_cov36 || n_jobs <= 0)
+        return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: bad arguments");
+    int rc = preint_stage(c, samples, sample_begin, sample_count, t_end, bg, ba, nullptr, n_jobs, noise_cov36);
+    if (rc) return rc;
+    return preint_launch(c, n_jobs, compute_jacobian, compute_covariance, nullptr);
+}
+
+int xrhip_ba_preintegrate_after_solve(xrhip_ba *c, const double *samples, const int *sample_begin, const int *sample_count,
+                                      const double *t_end, const int *bias_frame, int n_jobs, const double *noise_cov36,
+                                      int compute_jacobian, int compute_covariance) {
+    if (!c || !samples || !sample_begin || !sample_count || !t_end || !bias_frame || !noise_cov36 || n_jobs <= 0)
+        return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_after_solve: bad arguments");
+    for (int k = 0; k < n_jobs; ++k)
+        if (bias_frame[k] < 0) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_after_solve: negative bias frame");
+    int rc = preint_stage(c, samples, sample_begin, sample_count, t_end, nullptr, nullptr, bias_frame, n_jobs, noise_cov36);
+    if (rc) return rc;
+    c->preint_deferred = n_jobs;
+    c->preint_def_jac = compute_jacobian ? 1 : 0;
+    c->preint_def_cov = compute_covariance ? 1 : 0;
+    return XRHIP_OK;
+}
+
 int xrhip_ba_preintegrate_end(xrhip_ba *c, double *out) {
     if (!c || !out) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_end: bad arguments");
+    if (c->preint_deferred) {
+        c->preint_deferred = 0;
+        return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate_end: the batch waits for a solve that never ran");
+    }
     if (!c->preint_pending) return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate_end: nothing in flight");
     const int n_jobs = c->preint_pending;
     c->preint_pending = 0;

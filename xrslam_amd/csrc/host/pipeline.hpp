@@ -198,6 +198,23 @@ struct Pipeline {
                   "xrhip_ba_preintegrate_begin");
         return true;
     }
+    // one interval whose integration starts from the biases the NEXT solve on `ba` gives frame `frame_index` of its problem:
+    // staged now, launched by that solve behind its last kernel (xrhip_ba_preintegrate_after_solve), collected by integrate_end
+    bool integrate_after_solve_begin(const std::vector<ImuData> &data, double t, int frame_index, bool jac, bool cov) {
+        if (data.empty() || frame_index < 0) return false;
+        std::vector<double> smp(data.size() * 7);
+        for (size_t i = 0; i < data.size(); ++i) {
+            const ImuData &d = data[i];
+            double *s = &smp[7 * i];
+            s[0] = d.t;
+            s[1] = d.w.x; s[2] = d.w.y; s[3] = d.w.z;
+            s[4] = d.a.x; s[5] = d.a.y; s[6] = d.a.z;
+        }
+        const int begin = 0, count = (int)data.size();
+        hip_check(xrhip_ba_preintegrate_after_solve(ba, smp.data(), &begin, &count, &t, &frame_index, 1, noise36, jac, cov),
+                  "xrhip_ba_preintegrate_after_solve");
+        return true;
+    }
     void integrate_end(PreInt &pre, xrhip_ba *ctx = nullptr) {
         WallTimer wt_w_preintegrate(preintegrate_slot(ctx));
         hip_check(xrhip_ba_preintegrate_end(ctx ? ctx : ba, pre.rec), "xrhip_ba_preintegrate_end");
@@ -261,7 +278,7 @@ struct Pipeline {
             bas.insert(bas.end(), b2, b2 + 3);
         }
         if (pending.empty()) return ok;
-        WallTimer wt_w_preintegrate(times.w_preintegrate);
+        WallTimer wt_w_preintegrate(preintegrate_slot(ctx));
         hip_check(xrhip_ba_preintegrate_begin(ctx, smp.data(), begin.data(), count.data(), t_end.data(), bgs.data(), bas.data(),
                                               (int)pending.size(), noise36, jac, cov),
                   "xrhip_ba_preintegrate_begin");
@@ -269,7 +286,7 @@ struct Pipeline {
     }
     std::vector<double> batch_collect(xrhip_ba *ctx, size_t n_jobs) {
         std::vector<double> out((size_t)XRHIP_IMU_DIM * n_jobs);
-        WallTimer wt_w_preintegrate(times.w_preintegrate);
+        WallTimer wt_w_preintegrate(preintegrate_slot(ctx));
         hip_check(xrhip_ba_preintegrate_end(ctx, out.data()), "xrhip_ba_preintegrate_end");
         return out;
     }
@@ -503,6 +520,14 @@ class BaBuilder {
         imu_pre_.push_back(&pre);
     }
     void add_marginalization(MargPrior *m) { prior_ = m; }
+    // An IMU interval to integrate from the biases this solve is about to give `f` (a frame of the problem): queued behind
+    // the solve on the device.  chained() tells afterwards whether it was (Pipeline::integrate_end collects it).
+    void chain_integration(Frame *f, std::vector<ImuData> samples, double t) {
+        chain_f_ = f;
+        chain_samples_ = std::move(samples);
+        chain_t_ = t;
+    }
+    bool chained() const { return chain_queued_; }
 
     size_t factor_num() const { return obs_tgt_.size() + rot_tgt_.size() + imu_i_.size() + (prior_ ? 1 : 0); }
     // Parameter blocks that no factor touches are not part of the program Ceres minimises (it drops them while
@@ -623,6 +648,8 @@ class BaBuilder {
         if (P_.ba_dump.enabled()) P_.ba_dump.maybe_dump(pb, P_.times.frames);
         xrhip_ba_summary sm;
         WallTimer wt_w_solve(P_.times.w_solve);
+        if (chain_f_ && chain_f_->ba_gen == gen_)
+            chain_queued_ = P_.integrate_after_solve_begin(chain_samples_, chain_t_, chain_f_->ba_index, true, true);
         hip_check(xrhip_ba_solve(P_.ba, &pb, &sm), "xrhip_ba_solve");
         for (int f = 0; f < F; ++f)
             if (fix_[f] != (XRHIP_FIX_POSE | XRHIP_FIX_MOTION)) unpack_state(&state[16 * (size_t)f], frames_[f], fix_[f]);
@@ -683,6 +710,10 @@ class BaBuilder {
     std::vector<const PreInt *> imu_pre_;
     std::vector<size_t> const_obs_, const_rot_, const_imu_;   // factors whose reference side is a constant use
     MargPrior *prior_ = nullptr;
+    Frame *chain_f_ = nullptr;
+    std::vector<ImuData> chain_samples_;
+    double chain_t_ = 0;
+    bool chain_queued_ = false;
 };
 
 // MarginalizationFactor ctor (estimation/marginalization_factor.h:18-33): gauge prior on the first pose
@@ -847,12 +878,12 @@ class SlidingWindowTracker {
             std::fprintf(stderr, "[hostprof] subframe re-integrations: %ld speculated, %ld taken from mirror_frame, %ld computed in place\n",
                          spec_hits_, memo_hits_, spec_misses_);
         if (std::getenv("XRHIP_HOSTPROF"))
-            std::fprintf(stderr, "[hostprof] mirror_frame: %ld of %ld interval integrations were queued ahead\n", mirror_prepared_,
-                         mirror_total_);
+            std::fprintf(stderr, "[hostprof] mirror_frame: %ld of %ld interval integrations were queued ahead (%ld behind a solve, on the device)\n",
+                         mirror_prepared_, mirror_total_, mirror_chained_);
     }
     size_t prepared_id_ = nil(), prepared_from_ = nil(), prepared_samples_ = 0;
     bool prepared_ = false;
-    long mirror_prepared_ = 0, mirror_total_ = 0;
+    long mirror_prepared_ = 0, mirror_total_ = 0, mirror_chained_ = 0;
 
     // Pipelined mode (System::set_threading): the window map belongs to the backend thread while the feature tracker works on
     // the next frame, so mirror_prepare cannot be called from there.  The feature tracker posts what it knows -- the samples of
@@ -888,6 +919,32 @@ class SlidingWindowTracker {
         prepared_from_ = h->from;
         prepared_samples_ = h->samples.size();
     }
+    // The same, earlier: refine_subwindow is the last solve of a non-keyframe frame and `newest` the frame the next interval
+    // starts from -- if the hint is there already, the integration is queued BEHIND that solve on the device and reads the
+    // biases where the solve leaves them (BaBuilder::chain_integration), instead of after the host has read them back.
+    void chain_mirror_hint(BaBuilder &b, Frame *newest) {
+        std::optional<MirrorHint> h;
+        {
+            std::lock_guard<std::mutex> lk(hint_mutex_);
+            if (hint_ && hint_->from == newest->id) h.swap(hint_);
+        }
+        if (!h) return;
+        cancel_prepared();
+        chained_id_ = h->id;
+        chained_from_ = h->from;
+        chained_samples_ = h->samples.size();
+        b.chain_integration(newest, std::move(h->samples), h->t);
+    }
+    void chained_solve_done(const BaBuilder &b) {
+        if (chained_id_ == nil()) return;
+        prepared_ = b.chained();
+        if (prepared_) mirror_chained_++;
+        prepared_id_ = chained_id_;
+        prepared_from_ = chained_from_;
+        prepared_samples_ = chained_samples_;
+        chained_id_ = nil();
+    }
+    size_t chained_id_ = nil(), chained_from_ = nil(), chained_samples_ = 0;
     std::mutex hint_mutex_;
     std::optional<MirrorHint> hint_;
 
@@ -968,9 +1025,11 @@ class SlidingWindowTracker {
             P_.times.keyframes++;
             track_landmark();
             refine_window();
+            take_mirror_hint();   // the newest frame's biases are final: the next interval integrates beside slide_window
             slide_window();
         } else {
             refine_subwindow();
+            take_mirror_hint();
         }
         if (P_.swt_log.enabled()) {
             FILE *fp = P_.swt_log.fp;
@@ -1430,7 +1489,9 @@ class SlidingWindowTracker {
                 }
             }
             P_.integrate_batch_end();
+            chain_mirror_hint(b, frame->subframes.back().get());
             b.solve();
+            chained_solve_done(b);
             frame->tag(FT_FIX_POSE) = false;
             frame->tag(FT_FIX_MOTION) = false;
         } else {
@@ -1456,7 +1517,9 @@ class SlidingWindowTracker {
                 }
             }
             P_.integrate_batch_end();
+            chain_mirror_hint(b, frame->subframes.back().get());
             b.solve();
+            chained_solve_done(b);
             frame->tag(FT_FIX_POSE) = false;
             frame->tag(FT_FIX_MOTION) = false;
         }
@@ -1905,7 +1968,7 @@ class JobThread {
         cv_.notify_all();
     }
     void wait() {   // returns when the posted job has finished; rethrows what it threw
-        await([this] { return state_.load(std::memory_order_acquire) == DONE; });
+        await([this] { return state_.load(std::memory_order_acquire) == DONE; }, 20000);   // a backend job is a few ms at most
         state_.store(IDLE, std::memory_order_relaxed);
         if (error_) {
             std::exception_ptr e = error_;
@@ -1923,10 +1986,15 @@ class JobThread {
         std::this_thread::yield();
 #endif
     }
-    template <class Pred> void await(Pred pred) {
-        for (int spin = 0; spin < 40000; ++spin) {
-            if (pred()) return;
-            relax();
+    // spin for at most `spin_us` (a sleeping thread costs tens of microseconds to wake), then sleep on the condition variable
+    template <class Pred> void await(Pred pred, long spin_us) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int spin = 0; spin < 256; ++spin) {
+                if (pred()) return;
+                relax();
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
         }
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, pred);
@@ -1937,7 +2005,7 @@ class JobThread {
             await([this] {
                 const int s = state_.load(std::memory_order_acquire);
                 return s == POSTED || s == QUIT;
-            });
+            }, 2000);   // back-to-back frames keep the thread awake; a live 20 Hz stream lets it sleep between frames
             if (state_.load(std::memory_order_acquire) == QUIT) return;
             try {
                 job_();
@@ -1984,11 +2052,12 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
     // the backend (SlidingWindowTracker::track) of frame t runs on `worker` while this thread tracks the features of
     // frame t+1; the feature tracker of frame t+1 therefore sees the state the backend published for frame t-1 (one frame
     // older than inline) and propagates it over the frames in between exactly as FeatureTracker::work does whenever the
-    // backend lags (feature_tracker.cpp:44-66).  Hand-offs, all on the feature tracker's thread: wait for the job of
-    // frame t-1 and publish its state (FrontendWorker's latest_state), mirror frame t into the window map (the only step
-    // that touches both maps; SlidingWindowTracker::mirror_frame takes the tracking map's lock for it), post the job
-    // of frame t.  Between hand-offs the two threads share nothing: the feature tracker owns `ft_map`, the KLT context
-    // and `P.ba_ft`; the backend owns the window map and the other BA contexts.  Poses lag one frame more than inline.
+    // backend lags (feature_tracker.cpp:44-66).  Hand-offs: at the end of its frame t the feature tracker waits for the job
+    // of frame t-1, publishes its state (FrontendWorker's latest_state) and posts the job of frame t = mirror_frame + track.
+    // mirror_frame is the only step that touches both maps (the reference holds the tracking map's lock for it): the
+    // feature tracker of frame t+1 does not look at the tracking map before the backend has flagged that copy as done.
+    // Otherwise the two threads share nothing: the feature tracker owns `ft_map`, the KLT context and `P.ba_ft`; the
+    // backend owns the window map and the other BA contexts.  Poses lag one frame more than inline.
     // RD-VIO's update_track_status reads the tracking map from inside the backend (:741-788): with parsac_flag the
     // frames stay inline.
     void set_threading(int mode) {
@@ -2132,25 +2201,16 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         auto [opt_t, opt_id, opt_pose, opt_motion] = frontend_latest_state;
         (void)opt_t;
         xrhip_ba *ft_ctx = pipelined() ? P.ba_ft : nullptr;
+        if (pipelined() && !mirror_done_.load(std::memory_order_acquire)) {
+            // the backend is still copying the previous frame out of the tracking map: the image needs nothing from the
+            // maps, its kernels go first
+            preprocess();
+            wait_mirror();
+        }
         bool is_initialized = opt_id != nil();
         bool swt_tag = !is_initialized || frame->id % c.sliding_window_tracker_frequent == 0;
         Map *map = ft_map.get();
         if (map->frame_num() > 0) {
-            if (is_initialized) {
-                size_t oi = map->frame_index_by_id(opt_id);
-                if (oi != nil()) {
-                    Frame *of = map->get_frame(oi);
-                    of->pose = opt_pose;
-                    of->motion = opt_motion;
-                    for (size_t j = oi + 1; j < map->frame_num(); ++j) {
-                        Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
-                        P.integrate(fj->preintegration, fj->image->t, fi->motion.bg, fi->motion.ba, false, false, ft_ctx);
-                        predict(fj->preintegration, fi, fj);
-                    }
-                } else {
-                    ft_latest_state.reset();   // "SWT cannot catch up."
-                }
-            }
             Frame *last = map->get_frame(map->frame_num() - 1);
             if (!last->preintegration.data.empty()) {
                 if (frame->preintegration.data.empty() ||
@@ -2160,7 +2220,8 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
                     frame->preintegration.data.insert(frame->preintegration.data.begin(), imu);
                 }
             }
-            // pipelined mode: the backend queues that integration itself once its biases are final (take_mirror_hint)
+            // pipelined mode: the backend queues the integration of the interval it will mirror next itself, once the
+            // biases it starts from are final (SlidingWindowTracker::take_mirror_hint)
             if (swt && swt_tag && is_initialized && pipelined()) {
                 if (const size_t from = map->frame_index_by_id(last_mirrored_id_); from != nil()) {
                     SlidingWindowTracker::MirrorHint h{frame->id, last_mirrored_id_, frame->image->t, frame->preintegration.data};
@@ -2171,7 +2232,49 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
                     swt->post_mirror_hint(std::move(h));
                 }
             }
-            if (P.integrate_begin(frame->preintegration.data, frame->image->t, last->motion.bg, last->motion.ba, false, false,
+            bool integrated = false;
+            if (is_initialized) {
+                size_t oi = map->frame_index_by_id(opt_id);
+                if (oi != nil()) {
+                    Frame *of = map->get_frame(oi);
+                    of->pose = opt_pose;
+                    of->motion = opt_motion;
+                    if (ft_ctx && oi + 1 < map->frame_num()) {
+                        // pipelined mode: the published state is (at least) one frame old.  predict() hands the biases on
+                        // unchanged, so every interval behind it -- and the new frame's -- integrates from the published
+                        // biases: one launch for all of them instead of one launch and one wait per interval
+                        std::vector<Pipeline::IntegrateJob> jobs;
+                        for (size_t j = oi + 1; j < map->frame_num(); ++j) {
+                            Frame *fj = map->get_frame(j);
+                            jobs.push_back({&fj->preintegration, fj->image->t, opt_motion.bg, opt_motion.ba});
+                        }
+                        jobs.push_back({&frame->preintegration, frame->image->t, opt_motion.bg, opt_motion.ba});
+                        std::vector<PreInt *> pending;
+                        P.batch_begin(ft_ctx, pending, jobs, false, false);
+                        preprocess();
+                        if (!pending.empty()) {
+                            const std::vector<double> rec = P.batch_collect(ft_ctx, pending.size());
+                            for (size_t k = 0; k < pending.size(); ++k) {
+                                std::memcpy(pending[k]->rec, &rec[(size_t)XRHIP_IMU_DIM * k], sizeof(double) * XRHIP_IMU_DIM);
+                                pending[k]->valid = true;
+                            }
+                        }
+                        for (size_t j = oi + 1; j < map->frame_num(); ++j)
+                            predict(map->get_frame(j)->preintegration, map->get_frame(j - 1), map->get_frame(j));
+                        integrated = true;
+                    } else {
+                        for (size_t j = oi + 1; j < map->frame_num(); ++j) {
+                            Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
+                            P.integrate(fj->preintegration, fj->image->t, fi->motion.bg, fi->motion.ba, false, false, ft_ctx);
+                            predict(fj->preintegration, fi, fj);
+                        }
+                    }
+                } else {
+                    ft_latest_state.reset();   // "SWT cannot catch up."
+                }
+            }
+            if (!integrated &&
+                P.integrate_begin(frame->preintegration.data, frame->image->t, last->motion.bg, last->motion.ba, false, false,
                                   ft_ctx)) {
                 preprocess();
                 P.integrate_end(frame->preintegration, ft_ctx);
@@ -2209,11 +2312,22 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         } else if (pipelined()) {
             sync();
             swt->drop_mirror_hint();   // a hint the backend did not get to is stale from here on
-            swt->mirror_frame(ft_map.get(), pending_frame_id);
             last_mirrored_id_ = pending_frame_id;
             inflight_ok_ = false;
             inflight_id_ = pending_frame_id;
-            worker->post([this] { inflight_ok_ = swt->track(); });
+            // mirror_frame runs on the backend thread too (as in the reference, under the tracking map's lock): the window
+            // map's frames and tracks stay in that core's caches.  The tracking map is the backend's until mirror_done_.
+            mirror_done_.store(false, std::memory_order_relaxed);
+            worker->post([this, pending_frame_id] {
+                {
+                    struct Release {
+                        std::atomic<bool> &flag;
+                        ~Release() { flag.store(true, std::memory_order_release); }
+                    } release{mirror_done_};
+                    swt->mirror_frame(ft_map.get(), pending_frame_id);
+                }
+                inflight_ok_ = swt->track();
+            });
         } else {
             swt->mirror_frame(ft_map.get(), pending_frame_id);
             if (swt->track()) {
@@ -2246,6 +2360,18 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
     int threading = THREADING_OFF;
     size_t inflight_id_ = nil();   // frame whose backend job is running on `worker`
     size_t last_mirrored_id_ = nil();
+    std::atomic<bool> mirror_done_{true};   // false while the backend thread copies the new frame out of the tracking map
+    void wait_mirror() {
+        if (mirror_done_.load(std::memory_order_acquire)) return;
+        WallTimer wt(P.times.w_join);
+        while (!mirror_done_.load(std::memory_order_acquire)) {
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
+        }
+    }
     bool inflight_ok_ = false;
     std::unique_ptr<JobThread> worker;
 };

@@ -436,6 +436,7 @@ struct PreintJob {
     int sample_begin, sample_count;   // into samples [.][7] = t, w, a
     double t_end;
     double bg[3], ba[3];
+    int bias_frame, pad_;             // >= 0: the biases are those of this frame in `state_dev` ([.][16], bg at 10, ba at 13) instead
 };
 
 constexpr int PI_CHUNK = 32;
@@ -451,7 +452,8 @@ __device__ __forceinline__ void preint_publish(int *status, int code) {
 __global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restrict__ jobs,
                                                       const double *__restrict__ samples,
                                                       const double *__restrict__ noise_host, int want_jac, int want_cov,
-                                                      double *__restrict__ out, int *__restrict__ status) {
+                                                      double *__restrict__ out, int *__restrict__ status,
+                                                      const double *__restrict__ state_dev) {
     __shared__ double cov[15][15], Tm[9][9], inv[15][15];
     __shared__ double Jac[5][9], Jnew[5][9];   // dq_dbg, dp_dbg, dp_dba, dv_dbg, dv_dba
     __shared__ double sA[PI_CHUNK][81], sG[PI_CHUNK][81];
@@ -472,7 +474,10 @@ __global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restric
         for (int i = 0; i < 3; ++i) sp3[i] = sv3[i] = 0.0;
         sdt = 0.0;
     }
-    const V3 bg = v3(job.bg[0], job.bg[1], job.bg[2]), ba = v3(job.ba[0], job.ba[1], job.ba[2]);
+    // a batch queued behind a solve (xrhip_ba_preintegrate_after_solve) starts from the biases that solve left on the device
+    const double *bsrc = (job.bias_frame >= 0 && state_dev) ? state_dev + 16 * (size_t)job.bias_frame + 10 : nullptr;
+    const V3 bg = bsrc ? v3(bsrc[0], bsrc[1], bsrc[2]) : v3(job.bg[0], job.bg[1], job.bg[2]);
+    const V3 ba = bsrc ? v3(bsrc[3], bsrc[4], bsrc[5]) : v3(job.ba[0], job.ba[1], job.ba[2]);
     double walk = 0.0;   // lanes 46..63: one entry of the two 3x3 bias random-walk blocks
     __syncthreads();
     for (int n0 = 0; n0 < job.sample_count; n0 += PI_CHUNK) {
