@@ -135,10 +135,14 @@ def main():
                     help="frames of the bounded CPU-reference sample (0 = skip); the first 36 only seed the window")
     ap.add_argument("--host-frames", type=int, default=60,
                     help="frames of the extra leg through the reference-shaped host-image call (0 = skip)")
-    ap.add_argument("--threading", default="pipelined", choices=["inline", "pipelined"],
+    ap.add_argument("--python-loop", action="store_true",
+                    help="drive the six reference symbols from the interpreter, one foreign call per sensor sample, instead of the "
+                         "native replay loop (XRSLAMAmdInstanceReplay: the player's main loop, same call sequence)")
+    ap.add_argument("--threading", default=None, choices=["inline", "pipelined"],
                     help="inline: feature tracker and sliding-window tracker one after the other in the caller (the reference's PC "
                          "build); pipelined (default): its XRSLAM_ENABLE_THREADING build with deterministic hand-offs -- the "
-                         "backend of frame t on a library thread beside the feature tracker of frame t+1 (XRSLAMAmdSetThreading)")
+                         "backend of frame t on a library thread beside the feature tracker of frame t+1 (XRSLAMAmdSetThreading); "
+                         "default: pipelined for one sequence per GPU, inline for several (their host threads already overlap)")
     ap.add_argument("--inline-frames", type=int, default=100,
                     help="frames of the same stream continued with threading switched off after the timed region (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the KLT kernels")
@@ -188,7 +192,10 @@ def main():
                       "self-initialising" % (os.path.basename(os.path.dirname(os.path.normpath(args.euroc))), real["frames"].shape[2],
                                              real["frames"].shape[1], wl["features"], wl["window"]))
     host_frames = args.host_frames if (S == 1 and world == 1) else 0
+    if args.threading is None:
+        args.threading = "pipelined" if S == 1 else "inline"
     pipelined = args.threading == "pipelined"
+    native = not args.python_loop or S > 1
     inline_frames = args.inline_frames if (S == 1 and world == 1 and pipelined) else 0
     n_frames = preroll + args.warmup + args.steps + host_frames + inline_frames
     seq_kw = dict(w=wl["w"], h=wl["h"])
@@ -204,7 +211,7 @@ def main():
         keep.append(dev)
         h, w = seq["frames"].shape[1:]
         sessions.append(runner.Session(_lib.LIB_PATH, seq, slam_yaml=slam_yaml, sensor_yaml=sensor_yaml,
-                                       device_frames=(dev.data_ptr(), h * w, w), instance=(S > 1),
+                                       device_frames=(dev.data_ptr(), h * w, w), instance=native,
                                        init_frames=0 if real is not None else 60, threading=1 if pipelined else 0,
                                        device_undistort="cv_undistort" if real is not None else None))
     torch.cuda.synchronize()
@@ -218,8 +225,11 @@ def main():
         """n frames on every session: inline for one, one host thread per sequence otherwise (the foreign calls release
         the interpreter lock, so the sequences' host work and device waits overlap)."""
         if S == 1:
-            for _ in range(n):
-                sess.step()
+            if native:
+                sess.step_n(n)
+            else:
+                for _ in range(n):
+                    sess.step()
             sess.sync()   # pipelined mode: the backend job of the last frame is part of the n frames
             return
         errs = []
@@ -288,6 +298,9 @@ def main():
             "data": "synthetic" if real is None else "real (EuRoC)",
             "config": {"workload": wl["text"], "features": wl["features"], "window_keyframes": wl["window"],
                        "sequences_per_gpu": S, "untimed_preroll_frames": preroll,
+                       "driver": ("native replay loop (XRSLAMAmdInstanceReplay: the reference player's main loop, "
+                                  "xrslam-pc/player/src/main.cpp:116-169, over the instance-scoped entry points)") if native else
+                                 "the six reference symbols called from the interpreter, one foreign call per sensor sample",
                        "threading": ("pipelined: sliding-window tracker of frame t on a library thread beside the feature tracker of "
                                      "frame t+1 (the reference's XRSLAM_ENABLE_THREADING build, deterministic hand-offs; timed region "
                                      "starts and ends with the pipeline drained)") if pipelined else
@@ -350,8 +363,11 @@ def main():
             # (XRSLAMManager.cpp:113-131); here that is the upload, inside the timed call, on the same stream
             sess.device_frames = None
             h0 = time.perf_counter()
-            for _ in range(host_frames):
-                sess.step()
+            if native:
+                sess.step_n(host_frames)
+            else:
+                for _ in range(host_frames):
+                    sess.step()
             sess.sync()
             torch.cuda.synchronize()
             ht = time.perf_counter() - h0
@@ -362,8 +378,11 @@ def main():
             sess.api.set_threading(0)
             sess.device_frames = (keep[0].data_ptr(), seq["frames"].shape[1] * seq["frames"].shape[2], seq["frames"].shape[2])
             i0 = time.perf_counter()
-            for _ in range(inline_frames):
-                sess.step()
+            if native:
+                sess.step_n(inline_frames)
+            else:
+                for _ in range(inline_frames):
+                    sess.step()
             torch.cuda.synchronize()
             it = time.perf_counter() - i0
             out["inline_threading"] = {"value": round(inline_frames / it, 3), "unit": "frames/s", "frames": inline_frames,

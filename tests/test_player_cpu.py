@@ -55,6 +55,31 @@ def test_cpu_reference_player_on_a_synthetic_euroc_directory(player, tmp_path):
     assert np.abs(ref[-n:, 1:4] - rows[-n:, 1:4]).max() < 5e-3
 
 
+def test_cpu_reference_player_pipelined(player, tmp_path):
+    """--pipelined (XRSLAMAmdSetThreading(1)): the same trajectory as the ctypes session in that mode; a run is reproducible."""
+    from xrslam_amd.harness import euroc, runner, scene
+    seq = scene.make_sequence(n_frames=70, seed=5)
+    root = euroc.write_euroc(seq, str(tmp_path / "mav0"))
+    rows = []
+    for k in range(2):
+        tum = str(tmp_path / ("traj%d.tum" % k))
+        res = _run([player, "-sc", SLAM, "-dc", SENSOR, "--tum", tum, "--no-undistort", "--pipelined", "--bootstrap-frames", "60",
+                    "euroc://" + root])
+        assert res["error"] == "" and res["frames"] == 70 and res["tracked"] >= 25
+        assert 0 <= res["ate_rmse_m"] < 0.03
+        rows.append(np.loadtxt(tum))
+    np.testing.assert_array_equal(rows[0], rows[1])
+    sess = runner.Session(REF_LIB, seq, slam_yaml=SLAM, sensor_yaml=SENSOR, threading=1)
+    for _ in range(70):
+        sess.step()
+    sess.sync()
+    ref = np.array([ps for ps in sess.poses if abs(ps[4]) + abs(ps[5]) + abs(ps[6]) + abs(ps[7]) > 0])
+    sess.close()
+    n = min(len(ref), len(rows[0]))
+    assert n >= 25
+    assert np.abs(ref[-n:, 1:4] - rows[0][-n:, 1:4]).max() < 5e-3
+
+
 def test_cpu_reference_player_rectifies_and_stops_at_max_frames(player, tmp_path):
     from xrslam_amd.harness import euroc, scene
     dist = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)

@@ -988,7 +988,10 @@ class SlidingWindowTracker {
                 if (kj != nil()) {
                     Track *nt = new_i->get_track(ki, map.get());
                     nt->add_keypoint(new_j, kj);
-                    track->tag(TT_TRASH) = nt->tag(TT_TRASH) && !nt->tag(TT_STATIC);
+                    // (written only when it changes: in pipelined mode the tracking map's tracks live in the other thread's
+                    // caches, and a store would take every one of those lines away from it)
+                    const bool trash = nt->tag(TT_TRASH) && !nt->tag(TT_STATIC);
+                    if (track->tag(TT_TRASH) != trash) track->tag(TT_TRASH) = trash;
                 }
             }
         }

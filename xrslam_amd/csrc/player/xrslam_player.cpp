@@ -6,8 +6,9 @@
 // is present, reports the ATE.  It links against libxrslam_hip.so only through XRSLAM.h.
 //
 //   xrslam-player --slam configs/euroc_slam.yaml --device configs/euroc_sensor.yaml --euroc <dir>/mav0
-//                 [--out traj.tum] [--bootstrap-frames N] [--max-frames N] [--no-undistort | --host-undistort]
+//                 [--out traj.tum] [--bootstrap-frames N] [--max-frames N] [--no-undistort | --host-undistort] [--pipelined]
 //
+// (--pipelined: XRSLAMAmdSetThreading(1), the reference's XRSLAM_ENABLE_THREADING build with deterministic hand-offs.)
 // The reference player's own command line (main.cpp:57-79) is accepted as well, so its invocations carry over:
 //
 //   xrslam-player -sc configs/euroc_slam.yaml -dc configs/euroc_sensor.yaml [-lc license] [--tum traj.tum]
@@ -48,7 +49,7 @@ static const TruthRow *nearest_truth(const std::vector<TruthRow> &gt, double t, 
 
 int main(int argc, char **argv) {
     std::map<std::string, std::string> opt;
-    bool undistort = true, host_undistort = false;
+    bool undistort = true, host_undistort = false, pipelined = false;
     // the reference's option names (main.cpp:57-71) map onto ours
     const std::map<std::string, std::string> alias = {{"-sc", "slam"}, {"--slamconfig", "slam"}, {"-dc", "device"},
                                                       {"--deviceconfig", "device"}, {"-lc", "license"}, {"--license", "license"},
@@ -57,6 +58,7 @@ int main(int argc, char **argv) {
         const std::string a = argv[i];
         if (a == "--no-undistort") undistort = false;
         else if (a == "--host-undistort") host_undistort = true;   // the reference's arrangement: the reader rectifies on the host
+        else if (a == "--pipelined") pipelined = true;
         else if (a == "-p" || a == "--play") continue;
         else if (alias.count(a) && i + 1 < argc) opt[alias.at(a)] = argv[++i];
         else if (a.rfind("--", 0) == 0 && i + 1 < argc) opt[a.substr(2)] = argv[++i];
@@ -78,7 +80,7 @@ int main(int argc, char **argv) {
     }
     if (!opt.count("slam") || !opt.count("device") || !opt.count("euroc")) {
         std::fprintf(stderr, "usage: xrslam-player --slam cfg.yaml --device sensor.yaml --euroc <dir>/mav0 [--out traj.tum] "
-                             "[--csv traj.csv] [--bootstrap-frames N] [--max-frames N] [--no-undistort | --host-undistort]\n"
+                             "[--csv traj.csv] [--bootstrap-frames N] [--max-frames N] [--no-undistort | --host-undistort] [--pipelined]\n"
                              "   or: xrslam-player -sc cfg.yaml -dc sensor.yaml [--tum traj.tum] [--csv traj.csv] [-p] "
                              "euroc://<dir>/mav0 | tum://<dir>/mav0\n");
         return 2;
@@ -114,6 +116,7 @@ int main(int argc, char **argv) {
     // either way: the library builds the same 1/32-pixel map (host/undistort_map.hpp).
     const bool device_undistort = undistort && cfg.cam_distortion_flag && !host_undistort;
     if (device_undistort) XRSLAMAmdSetDeviceUndistort(model.c_str());
+    if (pipelined) XRSLAMAmdSetThreading(1);
     size_t seeded = 0;
     for (size_t i = 0; i < cam.size() && i < bootstrap; ++i) {
         const double t = cam[i].t + cfg.cam_time_offset;
@@ -208,6 +211,7 @@ int main(int argc, char **argv) {
             ++frames;
         }
     }
+    XRSLAMAmdFlush();   // pipelined mode: the backend of the last frame belongs to the run
     const double busy = std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_begin).count() - io_seconds;
     if (out) std::fclose(out);
     if (csv) std::fclose(csv);
