@@ -948,25 +948,65 @@ class SlidingWindowTracker {
     std::mutex hint_mutex_;
     std::optional<MirrorHint> hint_;
 
-    void mirror_frame(Map *ft_map, size_t frame_id) {   // sliding_window_tracker.cpp:31-80
-        xrhip::HostProfScope hp_m(7, "mirror_frame");
-        feature_tracking_map_ = ft_map;
-        WallTimer sc_t(P_.times.scope[SC_MIRROR]);
-        Frame *keyframe = map->get_frame(map->frame_num() - 1);
-        Frame *new_i = keyframe;
-        if (!keyframe->subframes.empty()) new_i = keyframe->subframes.back().get();
-        size_t idx_i = ft_map->frame_index_by_id(new_i->id), idx_j = ft_map->frame_index_by_id(frame_id);
-        if (idx_i == nil() || idx_j == nil()) {
-            cancel_prepared();
-            return;
-        }
+    // mirror_frame (sliding_window_tracker.cpp:31-80) in two halves.  What it reads from the TRACKING map -- the new frame,
+    // the IMU samples of the frames it skips, and which keypoint of the last window frame continues as which keypoint of the
+    // new one -- is gathered into a packet (by the thread that owns the tracking map: in pipelined mode the feature
+    // tracker's, where those frames and tracks are in cache); the window map's half then works from the packet alone.
+    struct MirrorPacket {
+        struct Link {
+            uint32_t ki, kj;      // keypoint of the last window frame -> keypoint of the new frame
+            Track *ft_track;      // the tracking map's track (only written to when its trash tag changes)
+            bool trash;           // that tag as it stands
+        };
+        size_t from_id = nil(), frame_id = nil();
+        bool valid = false;
+        std::unique_ptr<Frame> frame;   // clone of the new frame, its interval extended over the skipped frames
+        std::vector<Link> links;
+    };
+    size_t newest_frame_id() const {
+        const Frame *keyframe = map->get_frame(map->frame_num() - 1);
+        return keyframe->subframes.empty() ? keyframe->id : keyframe->subframes.back()->id;
+    }
+    static MirrorPacket make_mirror_packet(Map *ft_map, size_t frame_id, size_t from_id) {
+        MirrorPacket pk;
+        pk.from_id = from_id;
+        pk.frame_id = frame_id;
+        const size_t idx_i = ft_map->frame_index_by_id(from_id), idx_j = ft_map->frame_index_by_id(frame_id);
+        if (idx_i == nil() || idx_j == nil()) return pk;
         Frame *old_i = ft_map->get_frame(idx_i), *old_j = ft_map->get_frame(idx_j);
-        std::unique_ptr<Frame> curr = old_j->clone();
-        std::vector<ImuData> &nd = curr->preintegration.data;
+        pk.frame = old_j->clone();
+        std::vector<ImuData> &nd = pk.frame->preintegration.data;
         for (size_t index = idx_j - 1; index > idx_i; --index) {
             const std::vector<ImuData> &od = ft_map->get_frame(index)->preintegration.data;
             nd.insert(nd.begin(), od.begin(), od.end());
         }
+        pk.links.reserve(old_i->keypoint_num());
+        for (size_t ki = 0; ki < old_i->keypoint_num(); ++ki) {
+            if (Track *track = old_i->get_track(ki)) {
+                const size_t kj = track->get_keypoint_index(old_j);
+                if (kj != nil()) pk.links.push_back({(uint32_t)ki, (uint32_t)kj, track, track->tag(TT_TRASH)});
+            }
+        }
+        pk.valid = true;
+        return pk;
+    }
+    void mirror_frame(Map *ft_map, size_t frame_id) {
+        feature_tracking_map_ = ft_map;
+        mirror_frame(make_mirror_packet(ft_map, frame_id, newest_frame_id()));
+    }
+    void mirror_frame(MirrorPacket pk) {
+        xrhip::HostProfScope hp_m(7, "mirror_frame");
+        WallTimer sc_t(P_.times.scope[SC_MIRROR]);
+        Frame *keyframe = map->get_frame(map->frame_num() - 1);
+        Frame *new_i = keyframe;
+        if (!keyframe->subframes.empty()) new_i = keyframe->subframes.back().get();
+        if (!pk.valid || pk.from_id != new_i->id) {
+            cancel_prepared();
+            return;
+        }
+        const size_t frame_id = pk.frame_id;
+        std::unique_ptr<Frame> curr = std::move(pk.frame);
+        std::vector<ImuData> &nd = curr->preintegration.data;
         // the pre-integration of the new interval only needs its IMU samples and the biases of the last window frame:
         // mirror_prepare queued it when the frame entered the tracker (it has been running beside the LK kernel);
         // otherwise it is queued now and runs while the track links are copied below
@@ -980,20 +1020,15 @@ class SlidingWindowTracker {
             cancel_prepared();
             integrating = P_.integrate_begin(nd, curr->image->t, new_i->motion.bg, new_i->motion.ba, true, true);
         }
-        map->attach_frame(curr->clone());
+        map->attach_frame(std::move(curr));
         Frame *new_j = map->get_frame(map->frame_num() - 1);
-        for (size_t ki = 0; ki < old_i->keypoint_num(); ++ki) {
-            if (Track *track = old_i->get_track(ki)) {
-                size_t kj = track->get_keypoint_index(old_j);
-                if (kj != nil()) {
-                    Track *nt = new_i->get_track(ki, map.get());
-                    nt->add_keypoint(new_j, kj);
-                    // (written only when it changes: in pipelined mode the tracking map's tracks live in the other thread's
-                    // caches, and a store would take every one of those lines away from it)
-                    const bool trash = nt->tag(TT_TRASH) && !nt->tag(TT_STATIC);
-                    if (track->tag(TT_TRASH) != trash) track->tag(TT_TRASH) = trash;
-                }
-            }
+        for (const MirrorPacket::Link &ln : pk.links) {
+            Track *nt = new_i->get_track(ln.ki, map.get());
+            nt->add_keypoint(new_j, ln.kj);
+            // (written only when it changes: in pipelined mode the tracking map's tracks live in the other thread's
+            // caches, and a store would take every one of those lines away from it)
+            const bool trash = nt->tag(TT_TRASH) && !nt->tag(TT_STATIC);
+            if (ln.trash != trash) ln.ft_track->tag(TT_TRASH) = trash;
         }
         map->prune_tracks([](const Track *t) { return t->tag(TT_TRASH) && !t->tag(TT_STATIC); });
         if (integrating) {
@@ -2056,9 +2091,10 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
     // frame t+1; the feature tracker of frame t+1 therefore sees the state the backend published for frame t-1 (one frame
     // older than inline) and propagates it over the frames in between exactly as FeatureTracker::work does whenever the
     // backend lags (feature_tracker.cpp:44-66).  Hand-offs: at the end of its frame t the feature tracker waits for the job
-    // of frame t-1, publishes its state (FrontendWorker's latest_state) and posts the job of frame t = mirror_frame + track.
-    // mirror_frame is the only step that touches both maps (the reference holds the tracking map's lock for it): the
-    // feature tracker of frame t+1 does not look at the tracking map before the backend has flagged that copy as done.
+    // of frame t-1, publishes its state (FrontendWorker's latest_state), gathers what mirror_frame reads from the tracking map
+    // into a packet and posts the job of frame t = mirror_frame (from the packet) + track.  mirror_frame is the only step that
+    // touches both maps (the reference holds the tracking map's lock for it): what it may still write there -- a track's
+    // trash tag when it changes -- the feature tracker of frame t+1 does not look at before the backend has flagged it done.
     // Otherwise the two threads share nothing: the feature tracker owns `ft_map`, the KLT context and `P.ba_ft`; the
     // backend owns the window map and the other BA contexts.  Poses lag one frame more than inline.
     // RD-VIO's update_track_status reads the tracking map from inside the backend (:741-788): with parsac_flag the
@@ -2204,12 +2240,6 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         auto [opt_t, opt_id, opt_pose, opt_motion] = frontend_latest_state;
         (void)opt_t;
         xrhip_ba *ft_ctx = pipelined() ? P.ba_ft : nullptr;
-        if (pipelined() && !mirror_done_.load(std::memory_order_acquire)) {
-            // the backend is still copying the previous frame out of the tracking map: the image needs nothing from the
-            // maps, its kernels go first
-            preprocess();
-            wait_mirror();
-        }
         bool is_initialized = opt_id != nil();
         bool swt_tag = !is_initialized || frame->id % c.sliding_window_tracker_frequent == 0;
         Map *map = ft_map.get();
@@ -2288,6 +2318,9 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
             // queued now, it runs beside the LK kernel and the RANSAC gates instead of in front of localize_newframe
             // (inline mode only: in pipelined mode the window map belongs to the backend thread until the hand-off)
             if (swt && swt_tag && is_initialized && !pipelined()) swt->mirror_prepare(map, frame.get());
+            // pipelined mode: the backend may still be writing changed trash tags into this map's tracks (its half of
+            // mirror_frame); nothing above looks at tracks, everything from here on does
+            if (pipelined()) wait_mirror();
             frame_track_keypoints(P, last, frame.get());
             if (is_initialized) {
                 predict(frame->preintegration, last, frame.get());
@@ -2315,19 +2348,23 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         } else if (pipelined()) {
             sync();
             swt->drop_mirror_hint();   // a hint the backend did not get to is stale from here on
-            last_mirrored_id_ = pending_frame_id;
             inflight_ok_ = false;
             inflight_id_ = pending_frame_id;
-            // mirror_frame runs on the backend thread too (as in the reference, under the tracking map's lock): the window
-            // map's frames and tracks stay in that core's caches.  The tracking map is the backend's until mirror_done_.
+            // The tracking map's half of mirror_frame here (its frames and tracks are in this core's caches), the window map's
+            // half on the backend thread.  Only a trash tag that CHANGES is written back into the tracking map (rare):
+            // the feature tracker of the next frame does not read those tags before mirror_done_.
+            swt->feature_tracking_map_ = ft_map.get();
+            auto packet = std::make_shared<SlidingWindowTracker::MirrorPacket>(
+                SlidingWindowTracker::make_mirror_packet(ft_map.get(), pending_frame_id, swt->newest_frame_id()));
+            if (packet->valid) last_mirrored_id_ = pending_frame_id;
             mirror_done_.store(false, std::memory_order_relaxed);
-            worker->post([this, pending_frame_id] {
+            worker->post([this, packet] {
                 {
                     struct Release {
                         std::atomic<bool> &flag;
                         ~Release() { flag.store(true, std::memory_order_release); }
                     } release{mirror_done_};
-                    swt->mirror_frame(ft_map.get(), pending_frame_id);
+                    swt->mirror_frame(std::move(*packet));
                 }
                 inflight_ok_ = swt->track();
             });
