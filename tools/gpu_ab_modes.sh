@@ -27,10 +27,10 @@ PY
 }
 for rep in 1 2; do
   one "pipelined_native_$rep" --threading pipelined
-  one "pipelined_python_$rep" --threading pipelined --python-loop
+
   one "inline_native_$rep" --threading inline
-  one "inline_python_$rep" --threading inline --python-loop
-  if [ -f xrslam_amd/lib/libxrslam_hip_prio.so ]; then one "pipelined_prio_$rep" XRSLAM_HIP_LIB="$PWD/xrslam_amd/lib/libxrslam_hip_prio.so" --threading pipelined; fi
+
+
 done
 grep "mirror_frame:" "gpurun_out/bench_${TAG}_pipelined_native_1.err" | tail -1
 timeout 120 python bench.py > "gpurun_out/bench_$TAG.json" 2> "gpurun_out/bench_$TAG.err"; cut -c1-300 "gpurun_out/bench_$TAG.json"; tail -3 "gpurun_out/bench_$TAG.err"

@@ -89,9 +89,6 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
 // 0.132 -> 0.139 ms per frame, profiles/r02_ab_variants.md.)
 constexpr int CHAIN_VIS_TILE = 27 * 257;   // doubles of LDS behind the layout when `vis_tile` is set
 __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__restrict__ args, int seq, int max_rounds, int vis_tile) {
-#ifdef XRHIP_SETPRIO   // A/B switch: issue priority over wavefronts of other streams' kernels that share the compute unit
-    __builtin_amdgcn_s_setprio(3);
-#endif
     const BaDims &d = args->d;
     const BaPtrs &p = args->p;
     const Ext &cam = args->cam, &imu = args->imu;

@@ -1707,9 +1707,6 @@ template <int NT, bool PREP>
 __global__ __launch_bounds__(NT) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int use_lds,
                                                    int after_linearisation, int seq, int wide_trials, double *state2, double *depth2,
                                                    BaCtl *ctl2, int commit) {
-#ifdef XRHIP_SETPRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
     extern __shared__ double lds[];   // max(solve_block's region, try_block's staging)
     if (PREP && commit) {   // the speculation was right: the cost and gradient norm of its linearisation become the minimiser's
         if (threadIdx.x == 0) {
