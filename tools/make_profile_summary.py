@@ -69,6 +69,8 @@ if os.path.isdir(pmc_dir):
     import glob
     md = os.path.join(ROOT, "profiles", "%s_pmc_traffic.md" % rnd)
     head = open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.md")))[-1]).read().split("| kernel |")[0]
+    head = "# round %d (%s, kernel revision %s): HBM-side traffic per launch from rocprofv3 PMC counters\n" % (
+        int(rnd[1:]), ver, bj.get("kernel_rev")) + head.split("\n", 1)[1]
     head += "| kernel | launches | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch |\n|---|---|---|---|\n"
     for n in names:
         f = res["FETCH_SIZE"][n]
