@@ -86,6 +86,52 @@ def roofline_extras(kernel_rev):
     return peaks, traffic, note
 
 
+def precision_study():
+    """BASELINE config 5's "fp32 vs bf16 BA solve" on the device: the Schur contraction of the frozen S3 window problem
+    (tests/golden/ba_snapshots/s3_window: 21 frames, 1268 landmarks) with f64 / f32 / bf16 matrix-core operands
+    (csrc/study_api.hip), the error each implies for the Gauss-Newton step of the reduced system, and the matrix-core rates."""
+    from xrslam_amd import ba
+    from tests import ba_snapshots
+    snap = [x for x in ba_snapshots.load_all() if x[0] == "s3_window"]
+    if not snap:
+        return None
+    _, pd, _ = snap[0]
+    ctx = ba.BaContext(max_frames=32, max_landmarks=2048, max_obs=16384)
+    lin = ctx.debug_linearize(pd)
+    ctx.close()
+    F = len(pd.frame_state)
+    H, g, hll, gl, W = lin["H"], lin["g"], lin["hll"], lin["gl"], lin["W"]
+    free = hll > 0
+    W, w, gl = W[free], 1.0 / hll[free], gl[free]
+    T, ms = ba.study_schur_precision(W, w, reps=50)
+    pose = np.array([15 * f + k for f in range(F) for k in range(6)])
+    act = np.where(np.diag(H) > 0)[0]                 # fixed frames contribute empty rows
+    rhs = g.copy()
+    rhs[pose] -= W.T @ (w * gl)
+
+    def step(Tm):
+        S = H.copy()
+        S[np.ix_(pose, pose)] -= Tm
+        S = S[np.ix_(act, act)]
+        d = 1.0 / np.sqrt(np.diag(S).clip(1e-300))   # Jacobi scaling, like the solver
+        Ss = S * np.outer(d, d) + 1e-9 * np.eye(len(act))
+        return -d * np.linalg.solve(Ss, d * rhs[act])
+
+    d64 = step(T["f64"])
+    Ln, PF = len(w), (W.shape[1] + 15) // 16 * 16
+    flops = 2.0 * ((Ln + 63) // 64 * 64) * PF * PF
+    peak = {"f64": F64_MFMA_PEAK_TFLOPS, "f32": 157.3, "bf16": 2500.0}   # dense matrix-core peaks (MI355X_MICROARCH.md)
+    out = {"problem": "s3_window: %d frames, %d free landmarks, contraction [%d x %d]^T diag [%d x %d]" % (F, Ln, Ln, W.shape[1], Ln, W.shape[1]),
+           "tolerance": "north_star: 1e-4 relative on the states"}
+    for m in ("f64", "f32", "bf16"):
+        dm = step(T[m])
+        out[m] = {"kernel_us": round(1e3 * ms[m], 3), "tflops": round(flops / (ms[m] * 1e-3) / 1e12, 4),
+                  "mfma_frac_of_peak": round(flops / (ms[m] * 1e-3) / 1e12 / peak[m], 6),
+                  "product_rel_error": float("%.3e" % (np.abs(T[m] - T["f64"]).max() / np.abs(T["f64"]).max())),
+                  "gauss_newton_step_rel_error": float("%.3e" % (np.linalg.norm(dm - d64) / np.linalg.norm(d64)))}
+    return out
+
+
 def bench_s4(args, out_common):
     """S4: frozen refine_window problems replayed through the C ABI of plug point #2."""
     from xrslam_amd import ba
@@ -351,6 +397,11 @@ def main():
                             "launch_us": round(lk_ms * 1e3, 3)},
             "traffic_source": traffic_note,
         })
+        if args.workload == "s3":
+            try:
+                out["precision_study"] = precision_study()
+            except Exception as e:   # noqa: BLE001  (a study, not the measurement)
+                out["precision_study"] = {"error": repr(e)}
         if os.environ.get("XRSLAM_HIP_LIB"):      # instrumented build variant: report its in-kernel phase timers
             import ctypes
             buf = (ctypes.c_longlong * 32)()

@@ -298,6 +298,12 @@ int xrhip_ba_preintegrate_after_solve(xrhip_ba *ctx, const double *samples, cons
 int xrhip_ba_debug_linearize(xrhip_ba *ctx, const xrhip_ba_problem *problem, double *H, double *g, double *hll,
                              double *gl, double *W, double *cost);
 int xrhip_ba_debug_schur(xrhip_ba *ctx, const double *W, const double *w, int L, int P, double *out);
+/* BASELINE config 5's precision study on the device (csrc/study_api.hip; not part of the reference interface, never called by
+ * the product path): T = W^T diag(w) W for W [L][P] row-major, w [L] >= 0, computed by the same tiling with f64, f32 and
+ * bf16 (f32 accumulation) matrix-core operands; out64 / out32 / out16: [P][P]; ms_per_launch[3]: average of `reps` launches of
+ * each kernel (HIP events on the stream they run on). */
+int xrhip_study_schur_precision(const double *W, const double *w, int L, int P, int reps, double *out64, double *out32,
+                                double *out16, float ms_per_launch[3]);
 /* development aid: accumulated in-kernel phase timers (100 MHz ticks) of the BA kernels; all zero unless the
  * library was built with -DXRHIP_KPROF (csrc/build.sh, XR_VARIANT=kprof) */
 void xrhip_debug_kprof(long long *out32, int reset);

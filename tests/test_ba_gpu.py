@@ -218,6 +218,29 @@ def test_pipeline_snapshots_match_golden(ctx):
         np.testing.assert_allclose(b.inv_depth, exp["inv_depth"], rtol=1e-6, atol=1e-9, err_msg=name)
 
 
+def test_precision_study_kernels(ctx):
+    """csrc/study_api.hip (BASELINE config 5's fp32 / bf16 study): the f64 kernel equals the product's Schur kernel, the f32
+    and bf16 kernels equal a numpy contraction of the equally rounded operands up to accumulation order."""
+    from xrslam_amd import ba
+    rng = np.random.RandomState(5)
+    for Ln, P in ((600, 126), (150, 66), (70, 6)):
+        W = rng.randn(Ln, P) * (1 + np.arange(P))[None, :]
+        w = rng.rand(Ln) + 0.5
+        T, ms = ba.study_schur_precision(W, w, reps=3)
+        A = np.sqrt(w)[:, None] * W
+        ref = A.T @ A
+        scale = np.abs(ref).max()
+        assert np.abs(T["f64"] - ref).max() <= 1e-12 * scale
+        assert np.abs(T["f64"] - ctx.debug_schur(W, w)).max() <= 1e-12 * scale
+        A32 = A.astype(np.float32)
+        assert np.abs(T["f32"] - (A32.astype(np.float64).T @ A32.astype(np.float64))).max() <= 2e-5 * scale
+        u = A32.view(np.uint32).astype(np.uint64)
+        A16 = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32).astype(np.float64)
+        assert np.abs(T["bf16"] - A16.T @ A16).max() <= 2e-5 * scale          # same operands: only the f32 accumulation differs
+        assert np.abs(T["bf16"] - ref).max() <= 2e-2 * scale                    # and bf16 itself is that coarse
+        assert all(v > 0 for v in ms.values())
+
+
 def test_preintegration_queued_behind_a_solve(ctx):
     """xrhip_ba_preintegrate_after_solve: the integration starts from the biases the solve leaves on the device.  Same
     kernel, same inputs as the host-mediated form (solve, read the biases back, xrhip_ba_preintegrate) -> the same bits, for

@@ -45,6 +45,22 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def study_schur_precision(W, w, reps=20):
+    """BASELINE config 5's study (xrhip_study_schur_precision): T = W^T diag(w) W with f64 / f32 / bf16 matrix-core operands.
+    Returns ({"f64": T, "f32": T, "bf16": T}, {"f64": ms, ...}) -- products [P][P] and the average kernel time per launch."""
+    lib = L()
+    W = np.ascontiguousarray(W, np.float64)
+    w = np.ascontiguousarray(w, np.float64)
+    Ln, P = W.shape
+    outs = [np.zeros((P, P)) for _ in range(3)]
+    ms = (C.c_float * 3)()
+    lib.xrhip_study_schur_precision.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.POINTER(C.c_float)]
+    check(lib.xrhip_study_schur_precision(_p(W), _p(w), Ln, P, int(reps), _p(outs[0]), _p(outs[1]), _p(outs[2]), ms))
+    names = ("f64", "f32", "bf16")
+    return dict(zip(names, outs)), dict(zip(names, [float(v) for v in ms]))
+
+
 class BaContext:
     """One per sequence: owns the BA stream and device arenas."""
 
