@@ -81,6 +81,10 @@ __device__ __forceinline__ bool chol_diag_wave_t(double *A, int j0, int nb, doub
     DGPROF(4);   // block load
     double dinv[CH_NB];
     double xi[CH_NB];   // column `lane` of L^-1: xi[r] = Linv[r][lane]
+    // acc[r] = delta(r, lane) - sum_{k < r} L[r][k] Linv[k][lane], built up column by column (see below)
+    double acc[CH_NB];
+#pragma unroll
+    for (int r = 0; r < CH_NB; ++r) acc[r] = (r == lane) ? 1.0 : 0.0;
     bool ok = true;
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) {
@@ -108,19 +112,18 @@ __device__ __forceinline__ bool chol_diag_wave_t(double *A, int j0, int nb, doub
         }
         dinv[c] = hh + hh;
         x[c] = (lane == c) ? dd : x[c] * dinv[c];
+        // Row c of L^-1 is complete once the columns before c have been through (forward substitution, terms added in the
+        // order k = 0, 1, ...).  The inverse is built RIGHT-looking, beside the factorisation: the broadcast L[k][c] that
+        // updates column k of the block also carries row c of the inverse into acc[k].  (Left-looking -- row c summed up
+        // when column c is reached -- reads the same broadcasts a second time, up to fifteen columns later: the compiler
+        // keeps all 120 of them alive in scalar registers and spills them through v_writelane.)  Same products, same order of
+        // additions: the same bits.
+        if (!WITH_RHS) xi[c] = (c < lane) ? 0.0 : acc[c] * dinv[c];
 #pragma unroll
         for (int k = c + 1; k < CH_NB; ++k) {
             const double lkc = lane_bcast(x[c], k);   // L[k][c]
             x[k] -= x[c] * lkc;                        // meaningful for lane >= k (lower triangle)
-        }
-        if (!WITH_RHS) {
-            // row c of L^-1 by forward substitution, in the same pass: it needs L[c][0..c], final by now, and nothing the
-            // later columns produce -- independent work for the issue slots the pivot chain (rsq + Newton) leaves empty.
-            // Same terms in the same order as a separate loop over r = 0..15 would add them.
-            double acc = (c == lane) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < c; ++k) acc -= lane_bcast(x[k], c) * xi[k];   // L[c][k] * Linv[k][lane]
-            xi[c] = (c < lane) ? 0.0 : acc * dinv[c];
+            if (!WITH_RHS) acc[k] -= lkc * xi[c];      // L[k][c] * Linv[c][lane]
         }
     }
     DGPROF(5);   // factorisation (+ inverse)
@@ -140,9 +143,15 @@ __device__ __forceinline__ bool chol_diag_wave_t(double *A, int j0, int nb, doub
         }
         return ok;
     }
-    if (lane < CH_NB) {
+    // Every lane stores its column of the inverse -- lanes 16..63 into the padding column of Dinv.  Under `if (lane < 16)` the
+    // compiler sinks the whole inverse into that branch: it then runs AFTER the factorisation instead of beside it, from
+    // broadcasts it has kept in VGPR lanes (v_writelane / v_readlane, a third of this routine's instruction stream).
+    {
+        const int col = lane < CH_NB ? lane : CH_NB;
 #pragma unroll
-        for (int r = 0; r < CH_NB; ++r) Dinv[r][lane] = xi[r];
+        for (int r = 0; r < CH_NB; ++r) Dinv[r][col] = xi[r];
+    }
+    if (lane < CH_NB) {
 #pragma unroll
         for (int k = 0; k < CH_NB; ++k)
             if (lane < nb && k <= lane) A[tri_idx(j0 + lane, j0 + k)] = x[k];
