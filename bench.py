@@ -191,6 +191,8 @@ def main():
                          "default: pipelined for one sequence per GPU, inline for several (their host threads already overlap)")
     ap.add_argument("--inline-frames", type=int, default=100,
                     help="frames of the same stream continued with threading switched off after the timed region (0 = skip)")
+    ap.add_argument("--step-times", action="store_true",
+                    help="development aid (with --python-loop): wall time of every timed step -> median and the five longest")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the KLT kernels")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl == RCCL); 'gloo' lets two "
                     "ranks share one GPU when the multi-process path is exercised on a single-GPU box")
@@ -267,6 +269,8 @@ def main():
         group.barrier()
         torch.cuda.synchronize()
 
+    step_ms = []
+
     def run_all(n):
         """n frames on every session: inline for one, one host thread per sequence otherwise (the foreign calls release
         the interpreter lock, so the sequences' host work and device waits overlap)."""
@@ -275,7 +279,9 @@ def main():
                 sess.step_n(n)
             else:
                 for _ in range(n):
+                    t1 = time.perf_counter()
                     sess.step()
+                    step_ms.append(1e3 * (time.perf_counter() - t1))
             sess.sync()   # pipelined mode: the backend job of the last frame is part of the n frames
             return
         errs = []
@@ -305,6 +311,7 @@ def main():
         if not args.no_profile:
             s.set_profiling(True)
     barrier()
+    del step_ms[:]
     t0 = time.perf_counter()
     run_all(args.steps)
     barrier()
@@ -397,6 +404,10 @@ def main():
                             "launch_us": round(lk_ms * 1e3, 3)},
             "traffic_source": traffic_note,
         })
+        if args.step_times and step_ms:
+            ts = sorted(step_ms[:args.steps])
+            out["step_ms"] = {"median": round(ts[len(ts) // 2], 4), "longest": [round(v, 3) for v in ts[-5:]],
+                              "at": [int(i) for i in sorted(range(len(step_ms[:args.steps])), key=lambda i: step_ms[i])[-5:]]}
         if args.workload == "s3":
             try:
                 out["precision_study"] = precision_study()

@@ -983,6 +983,16 @@ extern "C" {
 // Marginalisation in two halves.  marg_launch stages the problem and queues EVERY kernel and copy of the Cholesky
 // path (the common one) without waiting; marg_collect waits, re-does the tail through the eigen-solver if the device
 // reported that the Cholesky path does not apply, and hands the prior out.
+// status words of a marginalisation (device, 8 ints): [0] singular victim block, [1] support size, [2] Cholesky failed (later: the
+// sweeps of the eigen path), [3] eigenvalue guard failed, [4] the eigen path was taken, [5] the support size km_jacobi sees
+__global__ void kx_marg_gate(int *st) {
+    if (threadIdx.x == 0) {
+        const int need = (st[2] != 0 || st[3] != 0) ? 1 : 0;
+        st[4] = need;
+        st[5] = need ? st[1] : 0;
+    }
+}
+
 static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     if (c->marg.pending) return xr_fail(XRHIP_ESTATE, "xrhip_ba_marginalize: a marginalisation is already in flight");
     if (M->n_frames < 2 || M->victim < 0 || M->victim >= M->n_frames)
@@ -1042,9 +1052,9 @@ static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     const size_t o_Hm = carve(D8 * (size_t)N * N), o_bm = carve(D8 * N), o_T2 = carve(D8 * (size_t)R * 15);
     const size_t o_A = carve(D8 * (size_t)R * R), o_bp = carve(D8 * R), o_B = carve(D8 * (size_t)R * R);
     const size_t o_V = carve(D8 * (size_t)R * R), o_si = carve(D8 * (size_t)R * R), o_iv = carve(D8 * R);
-    const size_t o_st = carve(sizeof(int) * 4), o_lam = carve(D8 * 2), o_sup = carve(sizeof(int) * (size_t)R);
+    const size_t o_st = carve(sizeof(int) * 8), o_lam = carve(D8 * 2), o_sup = carve(sizeof(int) * (size_t)R);
     const size_t o_As = carve(D8 * (size_t)R * R), o_bs = carve(D8 * R), o_Ss = carve(D8 * (size_t)R * R), o_ivs = carve(D8 * R);
-    rc = ensure_work2(c, w + 256, D8 * ((size_t)R * R + R) + 64 + sizeof(int) * 4);
+    rc = ensure_work2(c, w + 256, D8 * ((size_t)R * R + R) + 64 + sizeof(int) * 8);
     if (rc) return rc;
     char *W2 = c->work2;
     double *Hm = (double *)(W2 + o_Hm), *bm = (double *)(W2 + o_bm), *T2 = (double *)(W2 + o_T2);
@@ -1052,7 +1062,7 @@ static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     double *dsi = (double *)(W2 + o_si), *div = (double *)(W2 + o_iv);
     int *dst = (int *)(W2 + o_st);
     hipStream_t s = c->stream;
-    XR_HIP(hipMemsetAsync(dst, 0, sizeof(int) * 4, s));
+    XR_HIP(hipMemsetAsync(dst, 0, sizeof(int) * 8, s));
     if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16)), dim3(256), 0, s, d.np, p.pS, p.pLam);
     launch_linearize(c, d, p, cam, imu, M->sqrt_inv_cov[0], M->sqrt_inv_cov[1], false);
     hipLaunchKernelGGL(km_omega, dim3((std::max(d.L, 1) + 255) / 256), dim3(256), 0, s, d, p);
@@ -1071,12 +1081,19 @@ static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     hipLaunchKernelGGL(km_chol, dim3(1), dim3(512), (size_t)c->lds_limit, s, dsn, lds_doubles, As, bs, Ss, ivs,
                        (double *)(W2 + o_lam), dst);
     XR_HIP(hipGetLastError());
-    // optimistic tail: expand the Cholesky factor and copy everything out; status words last
+    // The eigen path (the reference's SelfAdjointEigenSolver route, km_jacobi: milliseconds) is needed when the Cholesky
+    // factor failed or an eigenvalue sits near the 1e-8 floor -- typically the first marginalisation of a sequence.  It used to
+    // be started by the HOST when it collected the result, i.e. on the critical path of the next refine_window.  Now the
+    // device decides: kx_marg_gate hands km_jacobi the support size if the fast path's status words ask for the fallback, and 0
+    // otherwise (km_jacobi returns at once on an empty support), so the fallback runs behind the fast path on this context's
+    // own stream like the rest of the marginalisation.  Then one expansion of whichever factor is in place, and the copies.
+    hipLaunchKernelGGL(kx_marg_gate, dim3(1), dim3(64), 0, s, dst);
+    hipLaunchKernelGGL(km_jacobi, dim3(1), dim3(1024), (size_t)c->lds_limit, s, dst + 5, lds_doubles, As, bs, B, V, Ss, ivs, 60, dst + 2);
     hipLaunchKernelGGL(km_expand, dim3((R * R + 255) / 256), dim3(256), 0, s, R, dsup, dsn, Ss, ivs, dsi, div);
     XR_HIP(hipGetLastError());
     XR_HIP(hipMemcpyAsync(hs, dsi, D8 * (size_t)R * R, hipMemcpyDeviceToHost, s));
     XR_HIP(hipMemcpyAsync(hs + (size_t)R * R, div, D8 * R, hipMemcpyDeviceToHost, s));
-    XR_HIP(hipMemcpyAsync(hs + (size_t)R * R + R, dst, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    XR_HIP(hipMemcpyAsync(hs + (size_t)R * R + R, dst, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
     xrhip_ba::MargPending &mp = c->marg;
     mp.pending = true;
     mp.K = K;
@@ -1105,10 +1122,13 @@ static int marg_collect(xrhip_ba *c, double *out_sqrt_info, double *out_infovec,
     const int R = mp.R, K = mp.K;
     double *hs = (double *)c->h_stage;
     XR_HIP(hipStreamSynchronize(s));
-    int hst[4];
+    int hst[8];
     std::memcpy(hst, hs + (size_t)R * R + R, sizeof(hst));
     if (hst[0]) return xr_fail(XRHIP_ESTATE, "xrhip_ba_marginalize: singular victim block");
-    if (hst[2] != 0 || hst[3] != 0) {
+    if (hst[4] && std::getenv("XRHIP_HOSTPROF"))
+        std::fprintf(stderr, "[hostprof] marginalisation took the eigen path on the device: guard %s, support %d of %d, %d sweeps\n",
+                     hst[3] ? "failed" : "ok", hst[1], R, hst[2]);
+    if ((hst[2] != 0 || hst[3] != 0) && !hst[4]) {   // (not reached: the gate kernel has made this decision on the device)
         if (std::getenv("XRHIP_HOSTPROF"))
             std::fprintf(stderr, "[hostprof] marginalisation falls back to the eigen path: cholesky %s, guard %s, support %d of %d\n",
                          hst[2] ? "failed" : "ok", hst[3] ? "failed" : "ok", hst[1], R);
