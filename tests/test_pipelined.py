@@ -139,3 +139,40 @@ def test_gpu_pipelined_matches_cpu_pipelined_stress_config():
     assert poses_h.shape == poses_o.shape
     np.testing.assert_allclose(poses_h[:, 1:], poses_o[:, 1:], rtol=1e-4, atol=1e-6)
     assert runner.ate_rmse(list(poses_h), seq) < 0.03
+
+
+def test_flush_destroy_and_results_with_a_frame_in_flight(seq):
+    """XRSLAMAmdFlush on an idle pipeline is a no-op; LANDMARKS / BIAS results and the statistics getters wait for the backend
+    job in flight by themselves; Destroy with a job in flight joins it (no crash, no leak of the worker thread)."""
+    import ctypes as C
+    s = runner.Session(ORACLE_LIB, seq, threading=1)
+    s.sync()                                     # nothing in flight yet
+    for _ in range(50):
+        assert s.step()
+    bias = (C.c_double * 6)()
+    s.api.get_result(5, C.byref(bias))           # XRSLAM_RESULT_BIAS: joins the job of the frame just posted
+    t = s.times()                                # ... and so do the statistics
+    assert t.frames >= 49 and t.solves > 0
+    assert s.step() and s.step()
+    s.close()                                    # Destroy while the backend is (most likely) still working on the last frame
+    s2 = runner.Session(ORACLE_LIB, seq, threading=1)     # the process-global instance is reusable afterwards
+    for _ in range(45):
+        assert s2.step()
+    s2.sync()
+    assert not s2.error(), s2.error()
+    s2.close()
+
+
+def test_pipelined_request_with_rdvio_filter_stays_inline(tmp_path):
+    """With parsac.parsac_flag the backend reads the tracking map (update_track_status): threading mode 1 is accepted but the
+    frames run inline -- the trajectory is the inline one, bit for bit."""
+    text = open(os.path.join(ROOT, "configs", "euroc_slam.yaml")).read()
+    assert "parsac_flag" in text
+    import re
+    yaml_on = tmp_path / "parsac_slam.yaml"
+    yaml_on.write_text(re.sub(r"parsac_flag:\s*\S+", "parsac_flag: true", text))
+    sq = scene.make_sequence(n_frames=56, seed=2)
+    inline, c_inline = _run(ORACLE_LIB, sq, 0, str(yaml_on))
+    asked, c_asked = _run(ORACLE_LIB, sq, 1, str(yaml_on))
+    assert c_asked == c_inline
+    np.testing.assert_array_equal(asked, inline)
