@@ -76,4 +76,21 @@ struct SwtLogger {
     bool enabled() const { return fp != nullptr; }
 };
 
+// Log of the sensor synchronisation (development / test aid): XRSLAM_AMD_DUMP_SYNC=<file> makes System::feature_tracker_work
+// append one JSON line per frame -- the frame's id and time and the IMU samples Detail::track_imu attached to it (time, angular
+// rate, acceleration, %.17g) -- and System::track_camera one line per answered pose.  tests/test_sync_model.py replays the same
+// sensor events through an independent Python model of core/detail.cpp:46-177 and requires identical samples and poses.
+struct SyncLogger {
+    FILE *fp = nullptr;
+    SyncLogger() {
+        if (const char *p = std::getenv("XRSLAM_AMD_DUMP_SYNC")) fp = std::fopen(p, "w");
+    }
+    ~SyncLogger() {
+        if (fp) std::fclose(fp);
+    }
+    SyncLogger(const SyncLogger &) = delete;
+    SyncLogger &operator=(const SyncLogger &) = delete;
+    bool enabled() const { return fp != nullptr; }
+};
+
 }   // namespace xrh

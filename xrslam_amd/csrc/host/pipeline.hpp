@@ -102,6 +102,7 @@ struct Pipeline {
         undistort_on_device = true;
     }
     SwtLogger swt_log;                 // XRSLAM_AMD_DUMP_SWT=<file>: decisions of the sliding-window tracker (ba_dump.hpp)
+    SyncLogger sync_log;               // XRSLAM_AMD_DUMP_SYNC=<file>: IMU samples attached to every frame, poses answered (ba_dump.hpp)
     BaDumper ba_dump;                  // XRSLAM_AMD_DUMP_BA=<dir>: freeze the problems handed to xrhip_ba_solve (ba_dump.hpp)
 
     explicit Pipeline(const Config &c) : config(c) {
@@ -2176,6 +2177,20 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         f->imu = {c.q_bi, c.p_bi};
         frames.emplace_back(std::move(f));
         PoseState out = predict_pose(image->t);
+        if (P.sync_log.enabled()) {
+            std::fprintf(P.sync_log.fp, "{\"pose_t\": %.17g, \"q\": [%.17g, %.17g, %.17g, %.17g], \"p\": [%.17g, %.17g, %.17g]", image->t, out.q.x,
+                         out.q.y, out.q.z, out.q.w, out.p.x, out.p.y, out.p.z);
+            if (ft_latest_state) {
+                const auto &[st, sp, sm] = ft_latest_state.value();
+                std::fprintf(P.sync_log.fp,
+                             ", \"state_t\": %.17g, \"sq\": [%.17g, %.17g, %.17g, %.17g], \"sp\": [%.17g, %.17g, %.17g], \"sv\": [%.17g, %.17g, %.17g], "
+                             "\"sbg\": [%.17g, %.17g, %.17g], \"sba\": [%.17g, %.17g, %.17g]",
+                             st, sp.q.x, sp.q.y, sp.q.z, sp.q.w, sp.p.x, sp.p.y, sp.p.z, sm.v.x, sm.v.y, sm.v.z, sm.bg.x, sm.bg.y, sm.bg.z,
+                             sm.ba.x, sm.ba.y, sm.ba.z);
+            }
+            std::fprintf(P.sync_log.fp, "}\n");
+            std::fflush(P.sync_log.fp);
+        }
         if (image->t > latest_timestamp) {
             latest_pose = out;
             latest_timestamp = image->t;
@@ -2226,6 +2241,17 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         xrhip::HostProfScope hp_f(11, "feature_tracker_work (all)");
         WallTimer wt_frame(P.times.w_frame);
         const Config &c = P.config;
+        if (P.sync_log.enabled()) {   // what Detail::track_imu attached to this frame (before the tracker adds its boundary sample)
+            FILE *fp = P.sync_log.fp;
+            std::fprintf(fp, "{\"frame\": %zu, \"t\": %.17g, \"imu\": [", frame->id, frame->image->t);
+            for (size_t i = 0; i < frame->preintegration.data.size(); ++i) {
+                const ImuData &d = frame->preintegration.data[i];
+                std::fprintf(fp, "%s[%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g]", i ? ", " : "", d.t, d.w.x, d.w.y, d.w.z, d.a.x,
+                             d.a.y, d.a.z);
+            }
+            std::fprintf(fp, "]}\n");
+            std::fflush(fp);
+        }
         // CLAHE / pyramid / gradients of the new image depend on nothing else: their launches are issued while the
         // pre-integration of the new interval runs on the BA stream (below), or right away when there is none to wait for
         bool preprocessed = false;
