@@ -76,7 +76,7 @@ def test_tracker_decisions_match_the_reference_model(tmp_path):
         s.close()
     finally:
         del os.environ["XRSLAM_AMD_DUMP_SWT"]
-    rows = [json.loads(ln) for ln in open(log)]
+    rows = [r for r in (json.loads(ln) for ln in open(log)) if "window" in r]      # (the log also carries mirror_frame's records)
     assert len(rows) >= 120 and n_pose >= 120
     size, subframe_size, force = _config_values()
     # the model starts from the window the C++ tracker reported after its first frame and replays everything after it
@@ -101,3 +101,67 @@ def test_tracker_decisions_match_the_reference_model(tmp_path):
     assert seen["keyframe"] >= 15 and seen["subframe"] >= 40, seen
     assert seen["rotation_frames"] >= 10, seen
     assert seen["hang_below_lifted"] >= 1 and seen["lift_to_keyframe"] >= 1, seen
+
+
+def test_mirror_frame_links_match_an_independent_model(tmp_path):
+    """mirror_frame (core/sliding_window_tracker.cpp:31-80), so far only compared with itself.  The C++ pipeline logs the
+    tracking map's side -- for the last two frames, which track every keypoint is on -- and, per mirrored frame, the links it
+    made: (keypoint of the last window frame, keypoint of the new frame, window-map track, created or continued) plus what the
+    new frame carries after the prune.  The model below derives the links from the tracking map's structure alone and keeps the
+    newest window frame's keypoint -> track table itself: same links in the same order, a track is continued exactly when the
+    model knows one on that keypoint (and then it is that track), created otherwise, and the table after the prune only ever
+    loses entries."""
+    if not os.path.exists(ORACLE_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    log = str(tmp_path / "swt.jsonl")
+    os.environ["XRSLAM_AMD_DUMP_SWT"] = log
+    try:
+        seq = scene.make_sequence(n_frames=110, seed=4)
+        s = runner.Session(ORACLE_LIB, seq, slam_yaml=SLAM)
+        while s.step():
+            assert not s.error(), s.error()
+        s.flush()
+        s.close()
+    finally:
+        del os.environ["XRSLAM_AMD_DUMP_SWT"]
+    ft = {}                      # tracking map: frame id -> track id per keypoint (-1: none), latest record wins
+    newest = None                # (frame id, {keypoint: window-map track}) of the newest window frame, as the model knows it
+    n_mirror = n_links = n_created = n_continued = n_pruned = 0
+    seen_ids = set()
+    for ln in open(log):
+        r = json.loads(ln)
+        if "ft" in r:
+            for f in r["ft"]:
+                ft[f["id"]] = f["tracks"]
+        elif "mirror" in r:
+            i, j = r["from"], r["mirror"]
+            assert i in ft and j in ft
+            pos_j = {t: k for k, t in enumerate(ft[j]) if t != -1}
+            expect = [(ki, pos_j[t]) for ki, t in enumerate(ft[i]) if t != -1 and t in pos_j]
+            got = [(a, b) for a, b, _, _ in r["links"]]
+            assert got == expect, "frame %d: links differ" % j
+            table = newest[1] if newest is not None and newest[0] == i else None
+            after = {}
+            for ki, kj, tid, created in r["links"]:
+                if table is not None:
+                    if ki in table:
+                        assert not created and tid == table[ki], "frame %d keypoint %d: a known track was not continued" % (j, ki)
+                    else:
+                        assert created, "frame %d keypoint %d: continued a track the model does not know" % (j, ki)
+                if created:
+                    assert tid not in seen_ids                       # a fresh id
+                    n_created += 1
+                else:
+                    n_continued += 1
+                seen_ids.add(tid)
+                assert kj not in after                                # one track per keypoint
+                after[kj] = tid
+            logged_after = {k: t for k, t in r["after"]}
+            assert set(logged_after.items()) <= set(after.items())   # the prune only removes
+            n_pruned += len(after) - len(logged_after)
+            newest = (j, logged_after)
+            n_mirror += 1
+            n_links += len(got)
+    assert n_mirror >= 60 and n_links >= 60 * 80, (n_mirror, n_links)
+    assert n_created >= 150 and n_continued >= 40 * 80, (n_created, n_continued)

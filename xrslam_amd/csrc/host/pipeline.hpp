@@ -1023,15 +1023,34 @@ class SlidingWindowTracker {
         }
         map->attach_frame(std::move(curr));
         Frame *new_j = map->get_frame(map->frame_num() - 1);
+        const bool log_links = P_.swt_log.enabled();
+        if (log_links) std::fprintf(P_.swt_log.fp, "{\"mirror\": %zu, \"from\": %zu, \"links\": [", frame_id, new_i->id);
+        bool first_link = true;
         for (const MirrorPacket::Link &ln : pk.links) {
+            const bool existed = new_i->get_track(ln.ki) != nullptr;
             Track *nt = new_i->get_track(ln.ki, map.get());
             nt->add_keypoint(new_j, ln.kj);
+            if (log_links) {
+                std::fprintf(P_.swt_log.fp, "%s[%u, %u, %zu, %d]", first_link ? "" : ", ", ln.ki, ln.kj, nt->id, existed ? 0 : 1);
+                first_link = false;
+            }
             // (written only when it changes: in pipelined mode the tracking map's tracks live in the other thread's
             // caches, and a store would take every one of those lines away from it)
             const bool trash = nt->tag(TT_TRASH) && !nt->tag(TT_STATIC);
             if (ln.trash != trash) ln.ft_track->tag(TT_TRASH) = trash;
         }
         map->prune_tracks([](const Track *t) { return t->tag(TT_TRASH) && !t->tag(TT_STATIC); });
+        if (log_links) {   // what the new frame carries after the prune: keypoint -> window-map track
+            std::fprintf(P_.swt_log.fp, "], \"after\": [");
+            bool first = true;
+            for (size_t kj = 0; kj < new_j->keypoint_num(); ++kj)
+                if (Track *t = new_j->get_track(kj)) {
+                    std::fprintf(P_.swt_log.fp, "%s[%zu, %zu]", first ? "" : ", ", kj, t->id);
+                    first = false;
+                }
+            std::fprintf(P_.swt_log.fp, "]}\n");
+            std::fflush(P_.swt_log.fp);
+        }
         if (integrating) {
             P_.integrate_end(new_j->preintegration);
             memo_id_ = new_j->id;
@@ -2357,6 +2376,20 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         preprocess();
         if (swt_tag) frame_detect_keypoints(P, frame.get());
         map->attach_frame(std::move(frame));
+        if (P.swt_log.enabled()) {   // the tracking map's side of mirror_frame: which track every keypoint of the last two frames is on
+            FILE *fp = P.swt_log.fp;
+            std::fprintf(fp, "{\"ft\": [");
+            const size_t nf = map->frame_num();
+            for (size_t j = nf >= 2 ? nf - 2 : 0; j < nf; ++j) {
+                const Frame *f = map->get_frame(j);
+                std::fprintf(fp, "%s{\"id\": %zu, \"tracks\": [", j + 1 < nf ? "" : (nf >= 2 ? ", " : ""), f->id);
+                for (size_t k = 0; k < f->keypoint_num(); ++k)
+                    std::fprintf(fp, "%s%ld", k ? ", " : "", f->get_track(k) ? (long)f->get_track(k)->id : -1L);
+                std::fprintf(fp, "]}");
+            }
+            std::fprintf(fp, "]}\n");
+            std::fflush(fp);
+        }
         size_t max_frames = is_initialized ? c.feature_tracker_max_frames : c.feature_tracker_max_init_frames;
         while (map->frame_num() > max_frames && map->get_frame(0)->id < opt_id) map->erase_frame(0);
         P.times.frames++;
