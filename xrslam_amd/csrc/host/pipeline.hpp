@@ -74,6 +74,93 @@ struct WallTimer {   // adds the scope's duration to a StageTimes slot
     ~WallTimer() { slot += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// ------------------------------------------------------------------------------------ worker threads
+// One job at a time on a thread of its own (utility/worker.h:7-60 with XRSLAM_ENABLE_THREADING): the backend thread of the
+// pipelined mode (System), and the thread that issues a marginalisation's launches (Pipeline::marg_launcher).  A frame is a fraction of
+// a millisecond: both sides spin on an atomic before they fall back to the condition variable.
+class JobThread {
+  public:
+    explicit JobThread(int device) : device_(device), th_([this] { loop(); }) {}
+    ~JobThread() {
+        state_.store(QUIT, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    JobThread(const JobThread &) = delete;
+    JobThread &operator=(const JobThread &) = delete;
+    void post(std::function<void()> job) {   // the previous job must have been waited for
+        job_ = std::move(job);
+        error_ = nullptr;
+        state_.store(POSTED, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+        }
+        cv_.notify_all();
+    }
+    void wait() {   // returns when the posted job has finished; rethrows what it threw
+        await([this] { return state_.load(std::memory_order_acquire) == DONE; }, 20000);   // a backend job is a few ms at most
+        state_.store(IDLE, std::memory_order_relaxed);
+        if (error_) {
+            std::exception_ptr e = error_;
+            error_ = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+
+  private:
+    enum { IDLE = 0, POSTED, DONE, QUIT };
+    static void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
+    // spin for at most `spin_us` (a sleeping thread costs tens of microseconds to wake), then sleep on the condition variable
+    template <class Pred> void await(Pred pred, long spin_us) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int spin = 0; spin < 256; ++spin) {
+                if (pred()) return;
+                relax();
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+        }
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, pred);
+    }
+    void loop() {
+        if (device_ >= 0) xrhip_bind_device(device_);
+        for (;;) {
+            await([this] {
+                const int s = state_.load(std::memory_order_acquire);
+                return s == POSTED || s == QUIT;
+            }, 2000);   // back-to-back frames keep the thread awake; a live 20 Hz stream lets it sleep between frames
+            if (state_.load(std::memory_order_acquire) == QUIT) return;
+            try {
+                job_();
+            } catch (...) {
+                error_ = std::current_exception();
+            }
+            state_.store(DONE, std::memory_order_release);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+            }
+            cv_.notify_all();
+        }
+    }
+    int device_;
+    std::function<void()> job_;
+    std::exception_ptr error_;
+    std::atomic<int> state_{IDLE};
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread th_;   // last: the members above exist before the thread starts
+};
+
 struct Pipeline {
     Config config;
     xrhip_klt *klt = nullptr;
@@ -82,6 +169,16 @@ struct Pipeline {
     xrhip_ba *ba_aux = nullptr;    // speculative pre-integration batches (started a frame ahead), same reason
     xrhip_ba *ba_ft = nullptr;     // pipelined mode: the feature tracker's pre-integrations (its thread must not touch `ba`)
     std::mutex pool_mutex;         // image buffers return from whichever thread drops the last reference
+    // xrhip_ba_marginalize_begin is ~20 API calls (staging, a memset, sixteen launches, three copies: 0.14 ms) whose result nobody
+    // reads for several frames: they are issued by a thread of their own, on the marginalisation's context, while the caller goes
+    // on; resolve_marginalization waits for that thread before it waits for the device.  XRSLAM_AMD_SYNC_MARG_LAUNCH=1: inline.
+    std::unique_ptr<JobThread> marg_launcher;
+    bool marg_launch_pending = false;
+    void marg_launch_wait() {
+        if (!marg_launch_pending) return;
+        marg_launch_pending = false;
+        marg_launcher->wait();   // rethrows what the launch threw
+    }
     IdSource ids;
     std::vector<xrhip_image *> image_pool;
     double noise36[36];
@@ -120,6 +217,11 @@ struct Pipeline {
         }
     }
     ~Pipeline() {
+        try {
+            marg_launch_wait();
+        } catch (...) {
+        }
+        marg_launcher.reset();
         for (xrhip_image *im : image_pool) xrhip_image_destroy(im);
         if (ba) xrhip_ba_destroy(ba);
         if (ba_marg) xrhip_ba_destroy(ba_marg);
@@ -428,6 +530,7 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
 // marginalisation, at shutdown.
 inline void resolve_marginalization(Pipeline &P, MargPrior *prior) {
     if (!prior || !prior->pending) return;
+    P.marg_launch_wait();
     const size_t n = prior->frames.size(), R = 15 * n;
     std::vector<double> si(R * R), iv(R), lin(16 * n);
     {
@@ -734,18 +837,27 @@ inline std::unique_ptr<MargPrior> create_marginalization_factor(Map *map) {
 }
 
 // CeresMarginalizationFactor::marginalize (ceres/marginalization_factor.h:74-475) via xrhip_ba_marginalize
+// The arrays an xrhip_marg_problem points into: kept alive until the call that stages them has been made
+struct MargJob {
+    xrhip_marg_problem mp;
+    std::vector<double> state, imu_data, zt, zr, depth;
+    std::vector<int> pframes, imu_i, imu_j, ot, orf, ol;
+};
+
 inline void marginalize_frame(Pipeline &P, Map *map, size_t index) {   // Map::marginalize_frame (map.cpp:51-63)
     MargPrior *prior = map->marginalization_factor.get();
     if (!prior) throw std::logic_error("marginalization_factor is not initialized yet");
     resolve_marginalization(P, prior);   // the previous result is this one's input
     const int K = (int)map->frame_num();
     std::unordered_map<Frame *, int> fidx;
-    std::vector<double> state(16 * (size_t)K);
+    auto job = std::make_shared<MargJob>();
+    std::vector<double> &state = job->state;
+    state.resize(16 * (size_t)K);
     for (int i = 0; i < K; ++i) {
         fidx[map->get_frame(i)] = i;
         BaBuilder::pack_state(map->get_frame(i), &state[16 * (size_t)i]);
     }
-    xrhip_marg_problem mp;
+    xrhip_marg_problem &mp = job->mp;
     std::memset(&mp, 0, sizeof(mp));
     mp.n_frames = K;
     mp.victim = (int)index;
@@ -761,15 +873,16 @@ inline void marginalize_frame(Pipeline &P, Map *map, size_t index) {   // Map::m
     }
     mp.sqrt_inv_cov[0] = any->sqrt_inv_cov[0];
     mp.sqrt_inv_cov[1] = any->sqrt_inv_cov[1];
-    std::vector<int> pframes;
+    std::vector<int> &pframes = job->pframes;
     for (Frame *f : prior->frames) pframes.push_back(fidx.at(f));
     mp.prior_n = (int)pframes.size();
     mp.prior_frames = pframes.data();
+    // (the prior's arrays are read in place: nothing writes them before resolve_marginalization, which waits for the launch)
     mp.prior_sqrt_info = prior->sqrt_info.data();
     mp.prior_infovec = prior->infovec.data();
     mp.prior_lin = prior->lin.data();
-    std::vector<int> imu_i, imu_j;
-    std::vector<double> imu_data;
+    std::vector<int> &imu_i = job->imu_i, &imu_j = job->imu_j;
+    std::vector<double> &imu_data = job->imu_data;
     for (size_t j = index; j <= index + 1; ++j) {
         if (j == 0 || j >= (size_t)K) continue;
         Frame *fj = map->get_frame(j);
@@ -781,8 +894,8 @@ inline void marginalize_frame(Pipeline &P, Map *map, size_t index) {   // Map::m
     mp.imu_i = imu_i.data();
     mp.imu_j = imu_j.data();
     mp.imu_data = imu_data.data();
-    std::vector<int> ot, orf, ol;
-    std::vector<double> zt, zr, depth;
+    std::vector<int> &ot = job->ot, &orf = job->orf, &ol = job->ol;
+    std::vector<double> &zt = job->zt, &zr = job->zr, &depth = job->depth;
     Frame *victim = map->get_frame(index);
     for (size_t j = 0; j < victim->keypoint_num(); ++j) {
         Track *track = victim->get_track(j);
@@ -818,7 +931,19 @@ inline void marginalize_frame(Pipeline &P, Map *map, size_t index) {   // Map::m
     mp.obs_z_ref = zr.data();
     {   // queued on the marginalisation's own context; the new sqrt_info / infovec / lin are fetched on first use
         WallTimer wt_w_marginalize(P.times.w_marginalize);
-        hip_check(xrhip_ba_marginalize_begin(P.ba_marg, &mp), "xrhip_ba_marginalize_begin");
+        static const bool sync_launch = std::getenv("XRSLAM_AMD_SYNC_MARG_LAUNCH") != nullptr;   // development switch
+        if (sync_launch) {
+            hip_check(xrhip_ba_marginalize_begin(P.ba_marg, &mp), "xrhip_ba_marginalize_begin");
+        } else {
+            if (!P.marg_launcher) {
+                int dev = -1;
+                if (xrhip_get_device(&dev) != 0) dev = -1;
+                P.marg_launcher = std::make_unique<JobThread>(dev);
+            }
+            xrhip_ba *ctx = P.ba_marg;
+            P.marg_launcher->post([ctx, job] { hip_check(xrhip_ba_marginalize_begin(ctx, &job->mp), "xrhip_ba_marginalize_begin"); });
+            P.marg_launch_pending = true;
+        }
     }
     prior->pending = true;
     prior->frames.clear();
@@ -1998,92 +2123,6 @@ class Initializer {
   public:
     Pipeline &P_;
     std::unique_ptr<Map> map;
-};
-
-// ------------------------------------------------------------------------------------ the backend thread
-// One job at a time on a thread of its own (utility/worker.h:7-60 with XRSLAM_ENABLE_THREADING).  A frame is a fraction of
-// a millisecond: both sides spin on an atomic before they fall back to the condition variable.
-class JobThread {
-  public:
-    explicit JobThread(int device) : device_(device), th_([this] { loop(); }) {}
-    ~JobThread() {
-        state_.store(QUIT, std::memory_order_release);
-        {
-            std::lock_guard<std::mutex> lk(m_);
-        }
-        cv_.notify_all();
-        th_.join();
-    }
-    JobThread(const JobThread &) = delete;
-    JobThread &operator=(const JobThread &) = delete;
-    void post(std::function<void()> job) {   // the previous job must have been waited for
-        job_ = std::move(job);
-        error_ = nullptr;
-        state_.store(POSTED, std::memory_order_release);
-        {
-            std::lock_guard<std::mutex> lk(m_);
-        }
-        cv_.notify_all();
-    }
-    void wait() {   // returns when the posted job has finished; rethrows what it threw
-        await([this] { return state_.load(std::memory_order_acquire) == DONE; }, 20000);   // a backend job is a few ms at most
-        state_.store(IDLE, std::memory_order_relaxed);
-        if (error_) {
-            std::exception_ptr e = error_;
-            error_ = nullptr;
-            std::rethrow_exception(e);
-        }
-    }
-
-  private:
-    enum { IDLE = 0, POSTED, DONE, QUIT };
-    static void relax() {
-#if defined(__x86_64__) || defined(__i386__)
-        __builtin_ia32_pause();
-#else
-        std::this_thread::yield();
-#endif
-    }
-    // spin for at most `spin_us` (a sleeping thread costs tens of microseconds to wake), then sleep on the condition variable
-    template <class Pred> void await(Pred pred, long spin_us) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            for (int spin = 0; spin < 256; ++spin) {
-                if (pred()) return;
-                relax();
-            }
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
-        }
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, pred);
-    }
-    void loop() {
-        if (device_ >= 0) xrhip_bind_device(device_);
-        for (;;) {
-            await([this] {
-                const int s = state_.load(std::memory_order_acquire);
-                return s == POSTED || s == QUIT;
-            }, 2000);   // back-to-back frames keep the thread awake; a live 20 Hz stream lets it sleep between frames
-            if (state_.load(std::memory_order_acquire) == QUIT) return;
-            try {
-                job_();
-            } catch (...) {
-                error_ = std::current_exception();
-            }
-            state_.store(DONE, std::memory_order_release);
-            {
-                std::lock_guard<std::mutex> lk(m_);
-            }
-            cv_.notify_all();
-        }
-    }
-    int device_;
-    std::function<void()> job_;
-    std::exception_ptr error_;
-    std::atomic<int> state_{IDLE};
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::thread th_;   // last: the members above exist before the thread starts
 };
 
 // ------------------------------------------------------------------------------------ the system
