@@ -19,9 +19,13 @@ Workloads (config.workload):
   s3  1280x720 stream, 600 features, 20-keyframe window (BASELINE config 5)
   s4  BA micro-bench: the frozen refine_window problems of tests/golden/ba_snapshots/ replayed through xrhip_ba_solve
       (a "step" is one whole solve; value = solves/s, ms_per_ba_iteration is the figure of interest)
-The first 36 frames of a stream only seed the window (initial states supplied from the ground truth, so that every run
-measures the same steady-state path): they are never timed -- with --warmup W < 40 the missing 40 - W frames
-run as an untimed pre-roll in front of the W warmup steps (config.untimed_preroll_frames).
+The timed region is the steady state the metric is quoted on -- the window at its configured size, one marginalisation per
+keyframe.  The first 36 frames of a stream only seed the window (initial states supplied from the ground truth, so that every
+run measures the same path) and the window then grows by one keyframe every ~4 frames: it is full, and the first keyframe has
+been marginalised (once per sequence through the eigen path: a rank-deficient prior), by frame
+4 * window_keyframes + 8.  Frames before 4 * window_keyframes + 16 are therefore never timed: with --warmup W shorter than that
+the missing frames run as an untimed pre-roll in front of the W warmup steps (config.untimed_preroll_frames) -- the frames it
+skips are cheaper on average (smaller windows), so this never flatters `value` except for that one-off.
 `value` is measured with frames resident in HBM; `host_image_path` repeats a bounded number of frames through the
 reference-shaped XRSLAM_SENSOR_CAMERA call (host image, uploaded inside the timed call) on the same stream.
 One independent sequence per GPU: no data-path collective, only a barrier and a MAX
@@ -202,9 +206,6 @@ def main():
     S = args.sequences_per_gpu
     if S > 1:   # every instance owns four HIP streams; the runtime multiplexes streams over this many hardware queues
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(4 * S, 24)))
-    # the first 36 frames of a stream only seed the sliding window (no pose, no solve): they never fall into the timed
-    # region -- a warmup shorter than 40 steps is preceded by the missing frames as an untimed pre-roll
-    preroll = max(0, 40 - args.warmup)
 
     import torch
     if not torch.cuda.is_available():
@@ -229,6 +230,9 @@ def main():
         return
 
     wl = dict(WORKLOADS[args.workload])
+    # steady state (window full, first marginalisation done) from frame 4 * window + 16 on: a shorter warmup is preceded by the
+    # missing frames as an untimed pre-roll (module docstring)
+    preroll = max(0, 4 * wl["window"] + 16 - args.warmup)
     slam_yaml, sensor_yaml = os.path.join(CFG, wl["slam"]), os.path.join(CFG, wl["sensor"])
     real = None
     if args.euroc:
