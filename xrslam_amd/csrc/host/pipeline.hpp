@@ -2403,7 +2403,9 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
             // (inline mode only: in pipelined mode the window map belongs to the backend thread until the hand-off)
             if (swt && swt_tag && is_initialized && !pipelined()) swt->mirror_prepare(map, frame.get());
             // pipelined mode: the backend may still be writing changed trash tags into this map's tracks (its half of
-            // mirror_frame); nothing above looks at tracks, everything from here on does
+            // mirror_frame); nothing above looks at tracks, everything from here on does.  The wait also orders the track-id
+            // counter the two maps share (P.ids): mirror_frame's new window-map tracks take their ids before this frame's new
+            // tracking-map tracks do, as inline -- ids are reproducible and the counter is never touched by both threads at once.
             if (pipelined()) wait_mirror();
             frame_track_keypoints(P, last, frame.get());
             if (is_initialized) {
