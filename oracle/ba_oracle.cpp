@@ -696,8 +696,8 @@ extern "C" {
 // Optional per-iteration record of the last orc_ba_solve_trace call (regression pin of the minimiser's decisions,
 // tests/golden/ba_snapshots): rows of {iteration, x_cost, candidate cost, model cost change, relative decrease,
 // radius before the decision, |step|, mu, accepted}.
-static double *g_trace = nullptr;
-static int g_trace_cap = 0, g_trace_rows = 0;
+static thread_local double *g_trace = nullptr;   // per thread: several pipelines may solve at once (instances, backend threads)
+static thread_local int g_trace_cap = 0, g_trace_rows = 0;
 static int orc_ba_solve_impl(const xrhip_ba_problem *P, xrhip_ba_summary *summary);
 int orc_ba_solve(const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
     g_trace = nullptr;

@@ -2142,6 +2142,10 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         } catch (...) {
         }
         worker.reset();
+        try {   // the launches of the last marginalisation read the prior's arrays, which die with `swt` (before `P`)
+            P.marg_launch_wait();
+        } catch (...) {
+        }
     }
 
     // -------- threading.  THREADING_OFF is the PC build of the reference: the feature tracker calls the backend inline.

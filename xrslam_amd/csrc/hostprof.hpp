@@ -15,11 +15,25 @@ struct HostProf {
     const char *name[N] = {nullptr};
 };
 inline HostProf g_hostprof;
+// Process-wide accumulators: written only when XRHIP_HOSTPROF is set (several instances / the backend thread of the pipelined
+// mode then add to them without synchronisation -- a development aid, figures are approximate in that case; without the
+// variable nothing is written, so instances share no mutable state through this header).
+inline bool hostprof_enabled() {
+    static const bool on = std::getenv("XRHIP_HOSTPROF") != nullptr;
+    return on;
+}
 struct HostProfScope {
     int slot;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    HostProfScope(int s, const char *name) : slot(s) { g_hostprof.name[s] = name; }
+    bool on = hostprof_enabled();
+    std::chrono::steady_clock::time_point t0;
+    HostProfScope(int s, const char *name) : slot(s) {
+        if (on) {
+            g_hostprof.name[s] = name;
+            t0 = std::chrono::steady_clock::now();
+        }
+    }
     ~HostProfScope() {
+        if (!on) return;
         g_hostprof.sec[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         g_hostprof.calls[slot] += 1;
     }
