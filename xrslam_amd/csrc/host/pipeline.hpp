@@ -1944,6 +1944,11 @@ class Initializer {
         }
         sfm_candidate = (int)best;
         sfm_triangulated = counts[best];
+        if (std::getenv("XRSLAM_AMD_DEBUG_INIT")) {   // development aid: the vote over the eight (R, T) hypotheses
+            std::fprintf(stderr, "[init] %d matches, parallax %.1f px; (count, sum of errors) per hypothesis:", common, parallax);
+            for (size_t h = 0; h < Rs.size(); ++h) std::fprintf(stderr, " %zu:(%zu, %.3g)", h, counts[h], scores[h]);
+            std::fprintf(stderr, " -> %zu\n", best);
+        }
         if (counts[best] < c.initializer_min_triangulation) return false;
 
         PoseState pose;
