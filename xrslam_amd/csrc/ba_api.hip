@@ -675,6 +675,14 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: null context");
     int rc = validate(P);
     if (rc) return rc;
+    if (c->preint_deferred) {   // a batch staged by xrhip_ba_preintegrate_after_solve: refuse a bad frame index before anything is queued
+        const PreintJob *jobs = (const PreintJob *)(c->h_stage + c->preint_o_jobs);
+        for (int k = 0; k < c->preint_deferred; ++k)
+            if (jobs[k].bias_frame < 0 || jobs[k].bias_frame >= P->n_frames) {
+                c->preint_deferred = 0;
+                return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_after_solve: bias frame is not a frame of the solve");
+            }
+    }
     xrhip_ba_summary sm;
     std::memset(&sm, 0, sizeof(sm));
     // trivial problem: nothing to optimise
