@@ -169,6 +169,13 @@ void xrhip_ba_destroy(xrhip_ba *c) { delete c; }
 int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *begin, const int *count, const double *t_end,
                                 const double *bg, const double *ba, int n_jobs, const double *noise36, int jac, int cov);
 int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *s) {
+    if (c && c->have_deferred && P)   // like the product: a bad frame index is refused before the solve touches anything
+        for (int f : c->deferred.frame)
+            if (f < 0 || f >= P->n_frames) {
+                c->have_deferred = false;
+                g_err = "xrhip_ba_preintegrate_after_solve: bias frame is not a frame of the solve";
+                return XRHIP_EINVAL;
+            }
     int rc = orc_ba_solve(P, s);
     if (rc == 0 && c && c->have_deferred) {   // the deferred batch starts from the biases this solve produced
         c->have_deferred = false;

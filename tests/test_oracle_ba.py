@@ -437,4 +437,11 @@ def test_preintegration_queued_behind_a_solve_cpu_shim():
     ctx.preintegrate_after_solve(smp, t_end, 0, bs.NOISE36)
     with pytest.raises(Exception):
         ctx.preintegrate_end()
+    name, pd, _exp = ba_snapshots.load_all()[0]
+    ctx.preintegrate_after_solve(smp, t_end, len(pd.frame_state), bs.NOISE36)     # one past the last frame of the problem
+    b = pd.copy()
+    with pytest.raises(Exception):
+        ctx.solve(b)                                                                # refused before the solve touches anything
+    np.testing.assert_array_equal(b.frame_state, pd.frame_state)
+    ctx.solve(b)                                                                    # and the context is usable again
     ctx.close()
