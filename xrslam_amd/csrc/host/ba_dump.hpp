@@ -5,6 +5,7 @@
 // of xrhip_ba_problem in declaration order (include/xrslam_hip.h), doubles as f64, indices as i32, flags as u8.
 // tests/ba_snapshots.py reads it back.  No HIP dependency.
 #pragma once
+#include <mutex>
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -65,6 +66,7 @@ struct BaDumper {
 // Python model of core/sliding_window_tracker.cpp:145-223,360-393 and requires the same outcome at every frame.
 struct SwtLogger {
     FILE *fp = nullptr;
+    std::mutex mu;   // a record is several fprintf calls; in pipelined mode two threads write records
     SwtLogger() {
         if (const char *p = std::getenv("XRSLAM_AMD_DUMP_SWT")) fp = std::fopen(p, "w");
     }

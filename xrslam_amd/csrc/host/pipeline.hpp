@@ -1149,6 +1149,8 @@ class SlidingWindowTracker {
         map->attach_frame(std::move(curr));
         Frame *new_j = map->get_frame(map->frame_num() - 1);
         const bool log_links = P_.swt_log.enabled();
+        std::unique_lock<std::mutex> log_lock(P_.swt_log.mu, std::defer_lock);
+        if (log_links) log_lock.lock();
         if (log_links) std::fprintf(P_.swt_log.fp, "{\"mirror\": %zu, \"from\": %zu, \"links\": [", frame_id, new_i->id);
         bool first_link = true;
         for (const MirrorPacket::Link &ln : pk.links) {
@@ -1175,6 +1177,7 @@ class SlidingWindowTracker {
                 }
             std::fprintf(P_.swt_log.fp, "]}\n");
             std::fflush(P_.swt_log.fp);
+            log_lock.unlock();
         }
         if (integrating) {
             P_.integrate_end(new_j->preintegration);
@@ -1215,6 +1218,7 @@ class SlidingWindowTracker {
             take_mirror_hint();
         }
         if (P_.swt_log.enabled()) {
+            std::lock_guard<std::mutex> log_lock(P_.swt_log.mu);
             FILE *fp = P_.swt_log.fp;
             std::fprintf(fp, "{\"frame\": %zu, \"no_translation\": %d, \"mapped\": %zu, \"keyframe\": %d, \"window\": [", log_id,
                          log_nt ? 1 : 0, log_mapped, is_kf ? 1 : 0);
@@ -2427,6 +2431,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         if (swt_tag) frame_detect_keypoints(P, frame.get());
         map->attach_frame(std::move(frame));
         if (P.swt_log.enabled()) {   // the tracking map's side of mirror_frame: which track every keypoint of the last two frames is on
+            std::lock_guard<std::mutex> log_lock(P.swt_log.mu);
             FILE *fp = P.swt_log.fp;
             std::fprintf(fp, "{\"ft\": [");
             const size_t nf = map->frame_num();
