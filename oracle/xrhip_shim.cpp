@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../include/xrslam_hip.h"
+#include "../xrslam_amd/csrc/hostprof.hpp"
 
 extern "C" {
 // oracle/klt_oracle.c
@@ -77,7 +78,10 @@ int xrhip_klt_create(int width, int height, int, xrhip_klt **out) {
     *out = new xrhip_klt{width, height};
     return 0;
 }
-void xrhip_klt_destroy(xrhip_klt *c) { delete c; }
+void xrhip_klt_destroy(xrhip_klt *c) {
+    delete c;
+    xrhip::hostprof_dump();   // XRHIP_HOSTPROF=1: the host pipeline's named wall-clock accumulators, like the product library
+}
 int xrhip_image_create(xrhip_klt *c, xrhip_image **out) {
     xrhip_image *im = new xrhip_image();
     im->ctx = c;

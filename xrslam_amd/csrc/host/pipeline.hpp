@@ -1387,6 +1387,7 @@ class SlidingWindowTracker {
 
     void localize_newframe() {   // :119-143
         WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
+        xrhip::HostProfScope *hp_a = new xrhip::HostProfScope(12, "localize: problem assembly");
         BaBuilder b(P_);
         Frame *fi = map->get_frame(map->frame_num() - 2);
         if (!fi->subframes.empty()) fi = fi->subframes.back().get();
@@ -1396,6 +1397,7 @@ class SlidingWindowTracker {
         for (size_t k = 0; k < fj->keypoint_num(); ++k)
             if (Track *t = fj->get_track(k))
                 if (t->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) b.add_reprojection_prior(fj, k);
+        delete hp_a;
         b.solve();
     }
 
