@@ -283,6 +283,9 @@ int xrhip_ba_preintegrate_begin(xrhip_ba *ctx, const double *samples, const int 
                                 const double *t_end, const double *bg, const double *ba, int n_jobs,
                                 const double *noise_cov36, int compute_jacobian, int compute_covariance);
 int xrhip_ba_preintegrate_end(xrhip_ba *ctx, double *out);
+/* the unwind path of an owner that cannot reach _end (an error between the two calls): waits for the batch's kernel and
+ * forgets it, staged-behind-a-solve batches included.  A second _begin without _end or _cancel fails with XRHIP_ESTATE. */
+int xrhip_ba_preintegrate_cancel(xrhip_ba *ctx);
 /* A batch whose integrations start from biases the NEXT xrhip_ba_solve on this context is about to produce: job k uses
  * bg / ba of frame bias_frame[k] of that problem as the solve leaves them (PreIntegrator::integrate(t, bg, ba, ...) of the
  * reference called right after Solver::solve with frame->motion.bg / .ba, e.g. sliding_window_tracker.cpp:54-56 after :441).

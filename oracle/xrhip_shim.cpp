@@ -254,6 +254,12 @@ int xrhip_ba_preintegrate_after_solve(xrhip_ba *c, const double *samples, const 
     c->have_deferred = true;
     return 0;
 }
+int xrhip_ba_preintegrate_cancel(xrhip_ba *c) {
+    if (!c) return XRHIP_EINVAL;
+    c->have_deferred = false;
+    c->preint_rc = 0;
+    return 0;
+}
 int xrhip_ba_preintegrate_end(xrhip_ba *c, double *out) {
     if (c->have_deferred) {
         c->have_deferred = false;

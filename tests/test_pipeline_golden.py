@@ -23,3 +23,34 @@ def test_cpu_pipeline_reproduces_the_committed_trajectory(mode, name):
     assert poses.shape == g[name + "_poses"].shape
     np.testing.assert_array_equal(poses[:, 0], g[name + "_poses"][:, 0])
     np.testing.assert_allclose(poses[:, 1:], g[name + "_poses"][:, 1:], rtol=1e-9, atol=1e-12)
+
+
+def test_getters_between_frames_do_not_move_the_pipelined_trajectory():
+    """XRSLAMAmdFlush / XRSLAMGetResult(XRSLAM_RESULT_BIAS) wait for the backend job in flight; they must not PUBLISH its state
+    (that happens at the next frame's hand-off, host/pipeline.hpp System::publish_backend_state), or the feature tracker of the
+    next frame would start from the state of frame t instead of t-1 and the trajectory would depend on which getters a caller
+    uses.  A run that calls both after every frame answers the committed pipelined trajectory."""
+    import ctypes as C
+    from xrslam_amd.harness import runner, scene
+    if not os.path.exists(gen.ORACLE_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(gen.ROOT, "oracle")])
+    g = np.load(GOLDEN)
+    seq = scene.make_sequence(n_frames=gen.N_FRAMES, seed=1)
+    s = runner.Session(gen.ORACLE_LIB, seq, threading=1)
+    bias = (C.c_double * 6)()           # XRSLAMIMUBias: two XRSLAMBias of three doubles
+    k = 0
+    while s.step():
+        assert not s.error(), s.error()
+        s.sync()
+        if k % 2:
+            s.api.get_result(5, C.byref(bias))      # XRSLAM_RESULT_BIAS
+        k += 1
+    s.flush()
+    s.sync()
+    t = s.times()
+    counts = np.array([t.frames, t.solves, t.solve_iterations, t.marginalizations, t.keyframes], np.int64)
+    poses = np.array(s.poses)
+    s.close()
+    np.testing.assert_array_equal(counts, g["pipelined_counts"])
+    np.testing.assert_allclose(poses[:, 1:], g["pipelined_poses"][:, 1:], rtol=1e-9, atol=1e-12)

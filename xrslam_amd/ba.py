@@ -24,9 +24,14 @@ def configure(lib):
         lib.xrhip_ba_marginalize_end.argtypes = [vp, vp, vp, vp]
     if hasattr(lib, "xrhip_ba_preintegrate"):
         lib.xrhip_ba_preintegrate.argtypes = [vp, vp, C.c_int, C.c_double, vp, vp, vp, C.c_int, C.c_int, vp]
+    if hasattr(lib, "xrhip_ba_preintegrate_begin"):
+        lib.xrhip_ba_preintegrate_begin.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int]
+    if hasattr(lib, "xrhip_ba_preintegrate_end"):
+        lib.xrhip_ba_preintegrate_end.argtypes = [vp, vp]
+    if hasattr(lib, "xrhip_ba_preintegrate_cancel"):
+        lib.xrhip_ba_preintegrate_cancel.argtypes = [vp]
     if hasattr(lib, "xrhip_ba_preintegrate_after_solve"):
         lib.xrhip_ba_preintegrate_after_solve.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int]
-        lib.xrhip_ba_preintegrate_end.argtypes = [vp, vp]
     if hasattr(lib, "xrhip_ba_debug_linearize"):
         lib.xrhip_ba_debug_linearize.argtypes = [vp, C.POINTER(abi.BaProblem), vp, vp, vp, vp, vp, vp]
     if hasattr(lib, "xrhip_ba_debug_schur"):

@@ -671,8 +671,14 @@ void xrhip_ba_destroy(xrhip_ba *c) {
 
 static int preint_launch_deferred(xrhip_ba *c, const xrhip_ba_problem *P, const double *state_dev);   // defined with the pre-integration entry points
 
+static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary);
 int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
     if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: null context");
+    const int rc = ba_solve_impl(c, P, summary);
+    if (rc) c->preint_deferred = 0;   // a batch staged behind a solve that failed must not ride on the next, unrelated one
+    return rc;
+}
+static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
     int rc = validate(P);
     if (rc) return rc;
     if (c->preint_deferred) {   // a batch staged by xrhip_ba_preintegrate_after_solve: refuse a bad frame index before anything is queued
@@ -1184,13 +1190,11 @@ int xrhip_ba_marginalize_end(xrhip_ba *c, double *out_sqrt_info, double *out_inf
 static int preint_stage(xrhip_ba *c, const double *samples, const int *sample_begin, const int *sample_count,
                         const double *t_end, const double *bg, const double *ba, const int *bias_frame, int n_jobs,
                         const double *noise_cov36) {
-    if (c->preint_pending) {
-        // a batch nobody collected (its owner unwound on an error between begin and end): the staging block it writes
-        // to is about to be reused, so wait for its kernel and forget it instead of refusing every later frame
-        XR_HIP(hipStreamSynchronize(c->stream));
-        c->preint_pending = 0;
-    }
-    c->preint_deferred = 0;
+    // one batch in flight per context: a second begin would overwrite the staging block the first one's kernel reads and
+    // writes, and the first owner's _end would collect the wrong record.  An owner that unwinds on an error between begin
+    // and end releases the context with xrhip_ba_preintegrate_cancel.
+    if (c->preint_pending || c->preint_deferred)
+        return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate_begin: a batch is already in flight on this context");
     int total = 0;
     for (int k = 0; k < n_jobs; ++k) {
         if (sample_count[k] <= 0 || sample_begin[k] < 0) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate: empty IMU segment");
@@ -1289,6 +1293,16 @@ int xrhip_ba_preintegrate_after_solve(xrhip_ba *c, const double *samples, const 
     c->preint_deferred = n_jobs;
     c->preint_def_jac = compute_jacobian ? 1 : 0;
     c->preint_def_cov = compute_covariance ? 1 : 0;
+    return XRHIP_OK;
+}
+
+int xrhip_ba_preintegrate_cancel(xrhip_ba *c) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_cancel: null context");
+    if (c->preint_pending) {   // its kernel writes the staging block: wait before anybody reuses it
+        XR_HIP(hipStreamSynchronize(c->stream));
+        c->preint_pending = 0;
+    }
+    c->preint_deferred = 0;
     return XRHIP_OK;
 }
 

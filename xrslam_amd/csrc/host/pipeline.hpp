@@ -82,6 +82,12 @@ class JobThread {
   public:
     explicit JobThread(int device) : device_(device), th_([this] { loop(); }) {}
     ~JobThread() {
+        // a job that is still running would overwrite QUIT with DONE when it finishes (and the loop would never leave): let it
+        // finish first.  Callers wait for their jobs by convention; this makes the destructor safe without it.
+        {
+            const int s = state_.load(std::memory_order_acquire);
+            if (s == POSTED) await([this] { return state_.load(std::memory_order_acquire) == DONE; }, 20000);
+        }
         state_.store(QUIT, std::memory_order_release);
         {
             std::lock_guard<std::mutex> lk(m_);
@@ -317,6 +323,10 @@ struct Pipeline {
         hip_check(xrhip_ba_preintegrate_after_solve(ba, smp.data(), &begin, &count, &t, &frame_index, 1, noise36, jac, cov),
                   "xrhip_ba_preintegrate_after_solve");
         return true;
+    }
+    void cancel_integrations() noexcept {   // error unwind: no batch stays between begin and end on any context
+        for (xrhip_ba *c : {ba, ba_aux, ba_ft})
+            if (c) xrhip_ba_preintegrate_cancel(c);
     }
     void integrate_end(PreInt &pre, xrhip_ba *ctx = nullptr) {
         WallTimer wt_w_preintegrate(preintegrate_slot(ctx));
@@ -2174,7 +2184,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
     // RD-VIO's update_track_status reads the tracking map from inside the backend (:741-788): with parsac_flag the
     // frames stay inline.
     void set_threading(int mode) {
-        sync();
+        publish_backend_state();   // a mode switch is a deterministic point of the caller's sequence: nothing is lost across it
         threading = mode == THREADING_PIPELINED ? THREADING_PIPELINED : THREADING_OFF;
         if (threading == THREADING_PIPELINED) {
             P.ensure_ft_context();
@@ -2186,15 +2196,28 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         }
     }
     bool pipelined() const { return threading == THREADING_PIPELINED && !P.config.parsac_flag; }
-    // the backend job in flight (if any) has finished and its state is published when this returns
+    // The backend job in flight (if any) has finished when this returns.  It only WAITS: the job's state stays pending and is
+    // published (FrontendWorker's latest_state) at the deterministic hand-off of the next frame (frontend_work) or at a mode
+    // switch -- never by a getter / Flush between two frames, so the trajectory does not depend on which statistics a caller
+    // reads in between (the feature tracker of frame t+1 always starts from the state of frame t-1).
     void sync() {
+        if (inflight_id_ == nil() || inflight_joined_) return;
+        inflight_joined_ = true;   // set first: if the job threw, wait() rethrows and the job must not be waited for twice
+        WallTimer wt(P.times.w_join);
+        worker->wait();
+    }
+    // join + publish: the hand-off proper
+    void publish_backend_state() {
         if (inflight_id_ == nil()) return;
         const size_t id = inflight_id_;
-        inflight_id_ = nil();
-        {
-            WallTimer wt(P.times.w_join);
-            worker->wait();
-        }
+        struct Clear {
+            System &s;
+            ~Clear() {
+                s.inflight_id_ = nil();
+                s.inflight_joined_ = false;
+            }
+        } clear{*this};
+        sync();
         if (inflight_ok_) {
             auto [t, pose, motion] = swt->get_latest_state();
             frontend_latest_state = {t, id, pose, motion};
@@ -2462,19 +2485,18 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
                 frontend_latest_state = {t, pending_frame_id, pose, motion};
             }
         } else if (pipelined()) {
-            sync();
+            publish_backend_state();
             swt->drop_mirror_hint();   // a hint the backend did not get to is stale from here on
             inflight_ok_ = false;
-            inflight_id_ = pending_frame_id;
             // The tracking map's half of mirror_frame here (its frames and tracks are in this core's caches), the window map's
             // half on the backend thread.  Only a trash tag that CHANGES is written back into the tracking map (rare):
             // the feature tracker of the next frame does not read those tags before mirror_done_.
             swt->feature_tracking_map_ = ft_map.get();
+            // everything that can throw (the packet, its control block, the job's closure) comes BEFORE the in-flight markers:
+            // a failed hand-off must not leave a job "in flight" that was never posted (sync() / wait_mirror() would wait forever)
             auto packet = std::make_shared<SlidingWindowTracker::MirrorPacket>(
                 SlidingWindowTracker::make_mirror_packet(ft_map.get(), pending_frame_id, swt->newest_frame_id()));
-            if (packet->valid) last_mirrored_id_ = pending_frame_id;
-            mirror_done_.store(false, std::memory_order_relaxed);
-            worker->post([this, packet] {
+            std::function<void()> job = [this, packet] {
                 {
                     struct Release {
                         std::atomic<bool> &flag;
@@ -2483,7 +2505,17 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
                     swt->mirror_frame(std::move(*packet));
                 }
                 inflight_ok_ = swt->track();
-            });
+            };
+            if (packet->valid) last_mirrored_id_ = pending_frame_id;
+            mirror_done_.store(false, std::memory_order_relaxed);
+            try {
+                worker->post(std::move(job));
+            } catch (...) {
+                mirror_done_.store(true, std::memory_order_release);
+                throw;
+            }
+            inflight_id_ = pending_frame_id;
+            inflight_joined_ = false;
         } else {
             swt->mirror_frame(ft_map.get(), pending_frame_id);
             if (swt->track()) {
@@ -2514,7 +2546,8 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
     PoseState latest_pose;
     double latest_timestamp = 0;
     int threading = THREADING_OFF;
-    size_t inflight_id_ = nil();   // frame whose backend job is running on `worker`
+    size_t inflight_id_ = nil();   // frame whose backend job is running on `worker` (or finished, its state not yet published)
+    bool inflight_joined_ = false; // that job has been waited for (sync()); publication happens at the next hand-off
     size_t last_mirrored_id_ = nil();
     std::atomic<bool> mirror_done_{true};   // false while the backend thread copies the new frame out of the tracking map
     void wait_mirror() {

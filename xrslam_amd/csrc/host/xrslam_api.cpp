@@ -43,6 +43,9 @@ template <class F> void guarded(Manager &m, F &&f) {
     } catch (const std::exception &e) {
         m.last_error = e.what();
         std::fprintf(stderr, "[xrslam_hip] %s\n", e.what());
+        // whoever threw may have left a pre-integration batch between begin and end: release the contexts so that the frames
+        // that follow are not refused (an error raised on the backend thread surfaces here, in sync(), with that thread idle)
+        if (m.sys) m.sys->P.cancel_integrations();
     }
 }
 
@@ -294,6 +297,7 @@ void impl_get_times(Manager &m, XRSLAMAmdTimes *out) {
 
 void impl_set_profiling(Manager &m, int enable) {
     if (m.sys) {
+        impl_flush(m);   // pipelined mode: the backend thread may be inside xrhip_ba_solve, which reads the profiling switch
         bind_device(m);
         xrhip_klt_set_profiling(m.sys->P.klt, enable);
         xrhip_ba_set_profiling(m.sys->P.ba, enable);
