@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec + ms/BA-iteration of the XRSLAM per-frame hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (one JSON line on rank 0)
+  python bench.py --gpus N --steps K --warmup W        (one JSON line on rank 0; N > 1 without a launcher: re-executes
+                                                        itself as N ranks under torch.distributed.run, one per GPU)
   python bench.py --workload {s1,s2,s3,s4}             (default s1 == BASELINE config 2; the others are extra lines)
   python bench.py --sequences-per-gpu S                (S independent sequences on each GPU, one host thread each)
 
-A "step" is one camera frame of one sequence pushed through the whole hot path behind the
-reference's C API (include/XRSLAM.h, the player's call sequence of xrslam-pc/player/src/main.cpp:116-169):
-~10 gyro + ~10 accel samples, XRSLAMAmdPushImageDevice (frame already resident in HBM), XRSLAMRunOneFrame,
-XRSLAMGetResult.  Inside: CLAHE + LK pyramid + Scharr, IMU pre-integration, forward/backward pyramidal LK,
-5-pt/2-pt RANSAC gates, Harris re-detection, localize_newframe solve, keyframe policy, landmark
+A "step" is one camera frame of one sequence pushed through the whole hot path behind the reference's C API
+(include/XRSLAM.h, the player's call sequence of xrslam-pc/player/src/main.cpp:116-169): ~10 gyro + ~10 accel samples,
+XRSLAMPushSensorData(XRSLAM_SENSOR_CAMERA) with a HOST image (XRSLAMManager.cpp:104-136: the library copies it -- here: uploads
+it -- inside the call), XRSLAMRunOneFrame, XRSLAMGetResult.  Inside: CLAHE + LK pyramid + Scharr, IMU pre-integration,
+forward/backward pyramidal LK, 5-pt/2-pt RANSAC gates, Harris re-detection, localize_newframe solve, keyframe policy, landmark
 triangulation, refine_window / refine_subwindow dogleg solves, marginalisation.
+
+`value` is the reference-shaped call: host image, threading OFF (the reference's PC build, CMakeLists.txt:13 -- feature tracker
+and sliding-window tracker one after the other in the caller, utility/worker.h:35-42).  The same stream is then continued
+through the library's faster modes, reported beside it as `variants`: `resident` (frame already in HBM,
+XRSLAMAmdPushImageDevice), `pipelined` (XRSLAMAmdSetThreading(1): the reference's XRSLAM_ENABLE_THREADING build with
+deterministic hand-offs) and `pipelined_resident`.
 
 Workloads (config.workload):
   s1  synthetic "EuRoC MH_01-like" stream: 752x480 (the real EuRoC cam0 size; BASELINE.json's 640x480 is a known
@@ -25,9 +32,8 @@ run measures the same path) and the window then grows by one keyframe every ~4 f
 been marginalised (once per sequence through the eigen path: a rank-deficient prior), by frame
 4 * window_keyframes + 8.  Frames before 4 * window_keyframes + 16 are therefore never timed: with --warmup W shorter than that
 the missing frames run as an untimed pre-roll in front of the W warmup steps (config.untimed_preroll_frames) -- the frames it
-skips are cheaper on average (smaller windows), so this never flatters `value` except for that one-off.
-`value` is measured with frames resident in HBM; `host_image_path` repeats a bounded number of frames through the
-reference-shaped XRSLAM_SENSOR_CAMERA call (host image, uploaded inside the timed call) on the same stream.
+skips are cheaper on average (smaller windows), so this never flatters `value` except for that one-off, whose cost the line
+states as `one_off_ms` (the longest pre-roll frame against the pre-roll's median frame).
 One independent sequence per GPU: no data-path collective, only a barrier and a MAX
 reduction of the wall time over RCCL.  --sequences-per-gpu S puts S sequences on every GPU (instance-scoped entry points,
 XRSLAMAmdInstance*): `value` is then the aggregate over all sequences of all GPUs.
@@ -170,6 +176,36 @@ def bench_s4(args, out_common):
     print(json.dumps(out))
 
 
+def relaunch_as_ranks(args):
+    """--gpus N > 1 without a launcher's environment: this process becomes the launcher -- the command line the driver itself
+    uses (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) around the same bench.py arguments."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: the only mode the host driver supports (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def rendezvous_only(args):
+    """The multi-process plumbing alone (no device, no measurement): process group, barrier, the SUM / MAX reduction of the
+    metrics vector -- what tests/test_dist_cpu.py drives with --backend gloo on a box without a GPU."""
+    from xrslam_amd.harness.dist import RunGroup
+    group = RunGroup(backend=args.backend or "gloo")
+    group.barrier()
+    red = group.reduce_metrics(args.steps, 1.0 + 0.25 * group.rank)
+    if group.rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": group.world, "frames": red["frames"], "seconds_max": red["seconds"],
+                          "note": "no measurement: the launcher / process-group path of bench.py --gpus N exercised without a device"}))
+    group.barrier()
+    group.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,38 +218,82 @@ def main():
     ap.add_argument("--sequences-per-gpu", type=int, default=1,
                     help="independent sequences per GPU, one host thread each (instance-scoped entry points)")
     ap.add_argument("--cpu-frames", type=int, default=240,
-                    help="frames of the bounded CPU-reference sample (0 = skip); the first 36 only seed the window")
-    ap.add_argument("--host-frames", type=int, default=60,
-                    help="frames of the extra leg through the reference-shaped host-image call (0 = skip)")
+                    help="most frames of the bounded CPU-reference sample (0 = skip); the first 40 are its warm-up")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0,
+                    help="time budget of each CPU-reference leg: the sample stops at --cpu-frames or here, whichever comes first")
+    ap.add_argument("--variant-frames", type=int, default=100,
+                    help="frames of each extra leg on the same stream after the timed region -- resident / pipelined / "
+                         "pipelined_resident (0 = skip; one sequence on one GPU only)")
+    ap.add_argument("--image", default="host", choices=["host", "resident"],
+                    help="host (default): the reference-shaped camera call, a host image uploaded inside XRSLAMPushSensorData; "
+                         "resident: frames already in HBM (XRSLAMAmdPushImageDevice)")
     ap.add_argument("--python-loop", action="store_true",
                     help="drive the six reference symbols from the interpreter, one foreign call per sensor sample, instead of the "
                          "native replay loop (XRSLAMAmdInstanceReplay: the player's main loop, same call sequence)")
     ap.add_argument("--threading", default=None, choices=["inline", "pipelined"],
-                    help="inline: feature tracker and sliding-window tracker one after the other in the caller (the reference's PC "
-                         "build); pipelined (default): its XRSLAM_ENABLE_THREADING build with deterministic hand-offs -- the "
-                         "backend of frame t on a library thread beside the feature tracker of frame t+1 (XRSLAMAmdSetThreading); "
-                         "default: pipelined for one sequence per GPU, inline for several (their host threads already overlap)")
-    ap.add_argument("--inline-frames", type=int, default=100,
-                    help="frames of the same stream continued with threading switched off after the timed region (0 = skip)")
+                    help="inline (default): feature tracker and sliding-window tracker one after the other in the caller -- the "
+                         "reference's PC build; pipelined: its XRSLAM_ENABLE_THREADING build with deterministic hand-offs -- the "
+                         "backend of frame t on a library thread beside the feature tracker of frame t+1 (XRSLAMAmdSetThreading)")
     ap.add_argument("--step-times", action="store_true",
                     help="development aid (with --python-loop): wall time of every timed step -> median and the five longest")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the KLT kernels")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl == RCCL); 'gloo' lets two "
                     "ranks share one GPU when the multi-process path is exercised on a single-GPU box")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="exercise only the launcher / process-group path (no device needed, prints no measurement)")
     args = ap.parse_args()
-    if args.steps < 1 or args.warmup < 0 or args.sequences_per_gpu < 1:
-        raise SystemExit("--steps must be >= 1, --warmup >= 0, --sequences-per-gpu >= 1")
+    if args.steps < 1 or args.warmup < 0 or args.sequences_per_gpu < 1 or args.gpus < 1:
+        raise SystemExit("--gpus and --steps must be >= 1, --warmup >= 0, --sequences-per-gpu >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        relaunch_as_ranks(args)          # does not return
+    if env_world is not None and args.gpus > 1 and int(env_world) != args.gpus:
+        raise SystemExit("--gpus %d contradicts the launcher's WORLD_SIZE=%s" % (args.gpus, env_world))
+    if args.rendezvous_only:
+        rendezvous_only(args)
+        return
     S = args.sequences_per_gpu
     if S > 1:   # every instance owns four HIP streams; the runtime multiplexes streams over this many hardware queues
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(4 * S, 24)))
+    rank, world = int(os.environ.get("RANK", "0")), int(env_world or "1")
+
+    from xrslam_amd.harness import scene
+    from xrslam_amd.harness.trajectory import Trajectory
+    wl = dict(WORKLOADS[args.workload]) if args.workload != "s4" else None
+    seqs, real, preroll, n_frames, variant_frames, slam_yaml, sensor_yaml = [], None, 0, 0, 0, None, None
+    if wl is not None:
+        # steady state (window full, first marginalisation done) from frame 4 * window + 16 on: a shorter warmup is preceded by
+        # the missing frames as an untimed pre-roll (module docstring)
+        preroll = max(0, 4 * wl["window"] + 16 - args.warmup)
+        slam_yaml, sensor_yaml = os.path.join(CFG, wl["slam"]), os.path.join(CFG, wl["sensor"])
+        variant_frames = args.variant_frames if (S == 1 and world == 1) else 0
+        n_frames = preroll + args.warmup + args.steps + 3 * variant_frames
+        if args.euroc:
+            from xrslam_amd.harness import euroc
+            if S != 1 or world != 1:
+                raise SystemExit("--euroc runs one sequence on one GPU")
+            real = euroc.read_euroc(args.euroc, max_frames=n_frames + 1)
+            wl["text"] = ("real EuRoC sequence %s, %dx%d frames as recorded (rectified on the GPU), %d features, %d-keyframe window, "
+                          "self-initialising" % (os.path.basename(os.path.dirname(os.path.normpath(args.euroc))),
+                                                 real["frames"].shape[2], real["frames"].shape[1], wl["features"], wl["window"]))
+            seqs = [real]
+        else:
+            # rendered before anything in this process touches the GPU runtime (the renderer forks its workers)
+            seq_kw = dict(w=wl["w"], h=wl["h"], workers=max(1, min(16, len(os.sched_getaffinity(0)) // max(1, min(world, 8)))))
+            if wl["K"]:
+                seq_kw["K"] = wl["K"]
+            for i in range(S):
+                kw = dict(seq_kw)
+                if wl["traj"]:
+                    kw["traj"] = Trajectory(**wl["traj"])
+                seqs.append(scene.make_sequence(n_frames=n_frames + 1, seed=1 + rank * S + i, **kw))
 
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product has no CPU fallback)")
     from xrslam_amd import _lib
-    from xrslam_amd.harness import runner, scene
+    from xrslam_amd.harness import runner
     from xrslam_amd.harness.dist import RunGroup
-    from xrslam_amd.harness.trajectory import Trajectory
     device_index = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()   # == LOCAL_RANK on a full node
     torch.cuda.set_device(device_index)
     group = RunGroup(backend=args.backend)  # one process per GPU; "nccl" == RCCL over xGMI
@@ -226,48 +306,27 @@ def main():
     if args.workload == "s4":
         if rank == 0:
             bench_s4(args, common)
+        group.barrier()
         group.close()
         return
 
-    wl = dict(WORKLOADS[args.workload])
-    # steady state (window full, first marginalisation done) from frame 4 * window + 16 on: a shorter warmup is preceded by the
-    # missing frames as an untimed pre-roll (module docstring)
-    preroll = max(0, 4 * wl["window"] + 16 - args.warmup)
-    slam_yaml, sensor_yaml = os.path.join(CFG, wl["slam"]), os.path.join(CFG, wl["sensor"])
-    real = None
-    if args.euroc:
-        from xrslam_amd.harness import euroc
-        if S != 1 or world != 1:
-            raise SystemExit("--euroc runs one sequence on one GPU")
-        real = euroc.read_euroc(args.euroc, max_frames=preroll + args.warmup + args.steps + args.host_frames + 1)
-        wl["text"] = ("real EuRoC sequence %s, %dx%d frames as recorded (rectified on the GPU), %d features, %d-keyframe window, "
-                      "self-initialising" % (os.path.basename(os.path.dirname(os.path.normpath(args.euroc))), real["frames"].shape[2],
-                                             real["frames"].shape[1], wl["features"], wl["window"]))
-    host_frames = args.host_frames if (S == 1 and world == 1) else 0
     if args.threading is None:
-        args.threading = "pipelined" if S == 1 else "inline"
+        args.threading = "inline"
     pipelined = args.threading == "pipelined"
+    resident = args.image == "resident"
     native = not args.python_loop or S > 1
-    inline_frames = args.inline_frames if (S == 1 and world == 1 and pipelined) else 0
-    n_frames = preroll + args.warmup + args.steps + host_frames + inline_frames
-    seq_kw = dict(w=wl["w"], h=wl["h"])
-    if wl["K"]:
-        seq_kw["K"] = wl["K"]
     sessions, keep = [], []
-    for i in range(S):
-        kw = dict(seq_kw)
-        if wl["traj"]:
-            kw["traj"] = Trajectory(**wl["traj"])
-        seq = real if real is not None else scene.make_sequence(n_frames=n_frames + 1, seed=1 + rank * S + i, **kw)
-        dev = torch.from_numpy(seq["frames"]).cuda()     # inputs resident in HBM before the timed region
+    for seq in seqs:
+        dev = torch.from_numpy(seq["frames"]).cuda()     # the `resident` legs read their frames from here
         keep.append(dev)
         h, w = seq["frames"].shape[1:]
         sessions.append(runner.Session(_lib.LIB_PATH, seq, slam_yaml=slam_yaml, sensor_yaml=sensor_yaml,
-                                       device_frames=(dev.data_ptr(), h * w, w), instance=native,
+                                       device_frames=(dev.data_ptr(), h * w, w) if resident else None, instance=native,
                                        init_frames=0 if real is not None else 60, threading=1 if pipelined else 0,
                                        device_undistort="cv_undistort" if real is not None else None))
     torch.cuda.synchronize()
     sess, seq = sessions[0], sessions[0].seq
+    dev_frames0 = (keep[0].data_ptr(), seq["frames"].shape[1] * seq["frames"].shape[2], seq["frames"].shape[2])
 
     def barrier():
         group.barrier()
@@ -275,17 +334,20 @@ def main():
 
     step_ms = []
 
-    def run_all(n):
+    def run_all(n, per_step=None):
         """n frames on every session: inline for one, one host thread per sequence otherwise (the foreign calls release
         the interpreter lock, so the sequences' host work and device waits overlap)."""
         if S == 1:
-            if native:
+            if native and per_step is None:
                 sess.step_n(n)
             else:
                 for _ in range(n):
                     t1 = time.perf_counter()
-                    sess.step()
-                    step_ms.append(1e3 * (time.perf_counter() - t1))
+                    if native:
+                        sess.step_n(1)
+                    else:
+                        sess.step()
+                    (step_ms if per_step is None else per_step).append(1e3 * (time.perf_counter() - t1))
             sess.sync()   # pipelined mode: the backend job of the last frame is part of the n frames
             return
         errs = []
@@ -304,7 +366,11 @@ def main():
         if errs:
             raise SystemExit("sequence thread failed: " + errs[0])
 
-    run_all(preroll + args.warmup)
+    # untimed pre-roll, frame by frame on rank 0's first sequence so that the one-off it hides can be stated
+    pre_ms = []
+    if preroll > 0:
+        run_all(preroll, per_step=pre_ms if S == 1 else None)
+    run_all(args.warmup)
     for s in sessions:
         if s.error():
             raise SystemExit("warmup failed: " + s.error())
@@ -355,6 +421,9 @@ def main():
             "data": "synthetic" if real is None else "real (EuRoC)",
             "config": {"workload": wl["text"], "features": wl["features"], "window_keyframes": wl["window"],
                        "sequences_per_gpu": S, "untimed_preroll_frames": preroll,
+                       "image": ("resident: frames already in HBM (XRSLAMAmdPushImageDevice)" if resident else
+                                 "host: XRSLAMPushSensorData(XRSLAM_SENSOR_CAMERA) with a host image, uploaded inside the timed call "
+                                 "(the reference's call, XRSLAMManager.cpp:104-136)"),
                        "driver": ("native replay loop (XRSLAMAmdInstanceReplay: the reference player's main loop, "
                                   "xrslam-pc/player/src/main.cpp:116-169, over the instance-scoped entry points)") if native else
                                  "the six reference symbols called from the interpreter, one foreign call per sensor sample",
@@ -380,7 +449,7 @@ def main():
             # pipelined mode: what the feature tracker's thread spent waiting for the previous frame's backend at the hand-off
             "backend_wait_ms_per_frame": round(1e3 * (t_e.wall_scope[15] - t_w.wall_scope[15]) / args.steps, 4),
             "ate_rmse_m": (lambda a: round(a, 5) if a == a else None)(runner.ate_rmse(poses, seq)),   # None with < 3 poses
-            # dominant kernel by total time (profiles/r02_full_*_kernel_stats.md): kb_chain, the LDS-resident single-launch
+            # dominant kernel by total time (profiles/r0x_full_*_kernel_stats.md): kb_chain, the LDS-resident single-launch
             # solve of localize_newframe / refine_subwindow (one workgroup; factor linearisation + trial costing stream the
             # observation records: HBM-bound per SURVEY.md 8d).  achieved = algorithmic bytes per launch / HIP-event
             # duration of that kernel on the BA stream.
@@ -408,6 +477,15 @@ def main():
                             "launch_us": round(lk_ms * 1e3, 3)},
             "traffic_source": traffic_note,
         })
+        if pre_ms:
+            # what the untimed pre-roll hides: the first marginalisation of a sequence goes through the eigen path (km_jacobi,
+            # DESIGN.md section 6) -- once per sequence; stated as the longest pre-roll frame against the pre-roll's median frame
+            srt = sorted(pre_ms)
+            worst = max(range(len(pre_ms)), key=lambda i: pre_ms[i])
+            out["one_off_ms"] = {"frame": worst, "ms": round(pre_ms[worst], 3), "preroll_median_ms": round(srt[len(srt) // 2], 3),
+                                 "extra_ms": round(pre_ms[worst] - srt[len(srt) // 2], 3),
+                                 "note": "longest untimed pre-roll frame (the first marginalisation's eigen path, once per sequence); "
+                                         "frames counted from the stream's start, the first 36 seed the window"}
         if args.step_times and step_ms:
             ts = sorted(step_ms[:args.steps])
             out["step_ms"] = {"median": round(ts[len(ts) // 2], 4), "longest": [round(v, 3) for v in ts[-5:]],
@@ -424,36 +502,33 @@ def main():
             out["kprof_ms"] = [round(v / 1e5, 3) for v in buf]    # 100 MHz ticks -> ms (whole run incl. warmup)
             for slot in (19, 27, 31):                             # counters: trust-region trials, single-launch rounds, solves
                 out["kprof_ms"][slot] = int(buf[slot])
-        if host_frames > 0:
-            # the reference-shaped call: XRSLAMPushSensorData(XRSLAM_SENSOR_CAMERA) deep-copies a HOST image
-            # (XRSLAMManager.cpp:113-131); here that is the upload, inside the timed call, on the same stream
-            sess.device_frames = None
-            h0 = time.perf_counter()
-            if native:
-                sess.step_n(host_frames)
-            else:
-                for _ in range(host_frames):
-                    sess.step()
-            sess.sync()
-            torch.cuda.synchronize()
-            ht = time.perf_counter() - h0
-            out["host_image_path"] = {"value": round(host_frames / ht, 3), "unit": "frames/s", "frames": host_frames,
-                                      "note": "same stream continued through XRSLAM_SENSOR_CAMERA (host image, PCIe upload inside the call)"}
-        if inline_frames > 0:
-            # the reference's PC build (threading off): the same stream continued with the backend inline in the caller
-            sess.api.set_threading(0)
-            sess.device_frames = (keep[0].data_ptr(), seq["frames"].shape[1] * seq["frames"].shape[2], seq["frames"].shape[2])
-            i0 = time.perf_counter()
-            if native:
-                sess.step_n(inline_frames)
-            else:
-                for _ in range(inline_frames):
-                    sess.step()
-            torch.cuda.synchronize()
-            it = time.perf_counter() - i0
-            out["inline_threading"] = {"value": round(inline_frames / it, 3), "unit": "frames/s", "frames": inline_frames,
-                                       "note": "same stream continued with XRSLAMAmdSetThreading(0): feature tracker and sliding-window "
-                                               "tracker one after the other in the caller (frames resident in HBM)"}
+        if variant_frames > 0:
+            # the same stream continued through the other three combinations of {host, resident} x {inline, pipelined}
+            def leg(thr, res):
+                sess.api.set_threading(1 if thr else 0)
+                sess.device_frames = dev_frames0 if res else None
+                sess.sync()
+                torch.cuda.synchronize()
+                v0 = time.perf_counter()
+                if native:
+                    sess.step_n(variant_frames)
+                else:
+                    for _ in range(variant_frames):
+                        sess.step()
+                sess.sync()
+                torch.cuda.synchronize()
+                return round(variant_frames / (time.perf_counter() - v0), 3)
+
+            var = {}
+            for name, thr, res in (("resident", False, True), ("pipelined", True, False), ("pipelined_resident", True, True)):
+                if (thr, res) == (pipelined, resident):
+                    thr, res, name = False, False, "inline_host"   # the timed region was that combination: this leg is the default one
+                var[name] = {"value": leg(thr, res), "unit": "frames/s", "frames": variant_frames}
+            var["note"] = ("same stream continued after the timed region; resident = frame already in HBM (XRSLAMAmdPushImageDevice), "
+                           "pipelined = XRSLAMAmdSetThreading(1), the reference's XRSLAM_ENABLE_THREADING build with deterministic "
+                           "hand-offs (a different, reproducible trajectory: the backend is one frame late)")
+            out["variants"] = var
+            sess.api.set_threading(1 if pipelined else 0)
         if args.cpu_frames > 40 and world == 1 and S == 1 and real is None:
             import subprocess
             ref_lib = os.path.join(ROOT, "oracle", "_build", "libxrslam_oracle.so")
@@ -467,29 +542,33 @@ def main():
                 cpu = runner.Session(ref_lib, seq, slam_yaml=slam_yaml, sensor_yaml=sensor_yaml, threading=threading)
                 for _ in range(40):
                     cpu.step()
-                c0 = time.perf_counter()
-                for _ in range(nc - 40):
+                cpu.sync()
+                c0, done = time.perf_counter(), 0
+                while done < nc - 40 and time.perf_counter() - c0 < args.cpu_seconds:
                     cpu.step()
+                    done += 1
                 cpu.sync()
                 ct = time.perf_counter() - c0
                 cpu.close()
-                return round((nc - 40) / ct, 3)
+                return round(done / ct, 3), done
 
-            sample = ("frames 40..%d of the same stream through the same host pipeline linked against the CPU oracle "
-                      "(oracle/_build/libxrslam_oracle.so, gcc -O2; our restatement, not the XRSLAM binary)" % nc)
+            sample = ("frames 40..%d of the same stream (host images, the six reference symbols) through the same host pipeline linked "
+                      "against the CPU oracle (oracle/_build/libxrslam_oracle.so, gcc -O2; our restatement, not the XRSLAM binary)")
             # the reference-faithful figure: solver num_threads = 1 (estimation/solver.cpp:185), image loops on one core
-            out["cpu_baseline"] = {"value": cpu_leg(1), "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": sample + ", single thread"}
+            v1, d1 = cpu_leg(1)
+            out["cpu_baseline"] = {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": sample % (40 + d1) + ", single thread, inline"}
             # OpenCV spreads the image / LK point loops with parallel_for_: same sample with those loops on the host's
-            # cores (capped at 16), solver and marginalisation still single-threaded like the reference
+            # cores (capped at 16), solver and marginalisation still single-threaded like the reference, and the backend on a
+            # thread of its own (the strongest CPU configuration this port has)
             cores = min(16, len(os.sched_getaffinity(0)))
             if cores > 1:
-                out["cpu_baseline_mt"] = {"value": cpu_leg(cores, 1 if pipelined else 0), "unit": "frames/s", "cores": cores,
-                                          "kind": "port",
-                                          "sample": sample + ", image and LK point loops on %d OpenMP threads%s"
-                                                    % (cores, ", backend thread beside the feature tracker (the same pipelined "
-                                                               "mode as the GPU line)" if pipelined else "")}
+                vm, dm = cpu_leg(cores, 1)
+                out["cpu_baseline_mt"] = {"value": vm, "unit": "frames/s", "cores": cores, "kind": "port",
+                                          "sample": sample % (40 + dm) + ", image and LK point loops on %d OpenMP threads, backend "
+                                                    "thread beside the feature tracker (pipelined mode)" % cores}
         print(json.dumps(out))
+    group.barrier()
     for s in sessions:
         s.close()
     group.close()

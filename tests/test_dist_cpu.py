@@ -39,3 +39,27 @@ def test_eleven_sequences_over_two_ranks():
     rmse = (out["sq_err_sum"] / out["n_poses"]) ** 0.5    # unaligned position error over all sequences
     assert rmse < 0.06
     assert out["seconds"] >= out["my_seconds"] - 1e-9
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must BECOME two ranks (it re-executes itself under
+    torch.distributed.run, the driver's own command line) -- the flag used to be parsed and never read, so a node-level run
+    would have printed n_gpus: 1.  --rendezvous-only stops after the process group / barrier / metric reduction, which is all a
+    box without a GPU can run; the measuring path behind it is the same code with world > 1."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rendezvous-only", "--steps", "7"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                 # rank 0 alone prints
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["frames"] == 14      # SUM over both ranks
+    assert out["seconds_max"] == 1.25                      # MAX over ranks (rank 1 reports 1.25)
+
+
+def test_bench_refuses_a_gpus_flag_that_contradicts_the_launcher():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0 and "contradicts" in p.stderr

@@ -8,7 +8,7 @@ TAG="${1:?tag}"; VAR="${2:?variant}"
 lib="$PWD/xrslam_amd/lib/libxrslam_hip_$VAR.so"
 mkdir -p gpurun_out
 timeout 400 python -m pytest tests -m gpu -x -q > "gpurun_out/gpu_tests_$TAG.log" 2>&1; tail -3 "gpurun_out/gpu_tests_$TAG.log"
-s1() { env "$@" timeout 120 python bench.py --steps 300 --warmup 50 --cpu-frames 0 --host-frames 0 --inline-frames 0 2>/dev/null | python -c "
+s1() { env "$@" timeout 120 python bench.py --steps 300 --warmup 50 --cpu-frames 0 --variant-frames 0 2>/dev/null | python -c "
 import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); sc=d['host_scope_ms_per_frame']
 print('%.1f f/s  ba-it %.4f  chain %.1f us  solve_try %.1f us  localize %.3f window %.3f sub %.3f' % (d['value'], d['ms_per_ba_iteration'], d['roofline']['launch_us'], d['roofline_solve']['launch_us'], sc['localize'], sc['refine_window'], sc['refine_subwindow']))"; }
 s4() { env "$@" timeout 120 python bench.py --workload s4 --steps 100 2>/dev/null | python -c "

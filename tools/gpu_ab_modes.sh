@@ -11,7 +11,7 @@ one() {   # label, env assignments / bench flags
   local label="$1"; shift
   local envs=() flags=()
   for a in "$@"; do if [[ "$a" == *=* && "$a" != --* ]]; then envs+=("$a"); else flags+=("$a"); fi; done
-  env "${envs[@]}" XRHIP_HOSTPROF=1 timeout 120 python bench.py --steps 300 --warmup 50 --cpu-frames 0 --host-frames 0 --inline-frames 0 "${flags[@]}" \
+  env "${envs[@]}" XRHIP_HOSTPROF=1 timeout 120 python bench.py --steps 300 --warmup 50 --cpu-frames 0 --variant-frames 0 "${flags[@]}" \
       > "gpurun_out/bench_${TAG}_$label.json" 2> "gpurun_out/bench_${TAG}_$label.err"
   python - "$label" "gpurun_out/bench_${TAG}_$label.json" <<'PY'
 import json, sys

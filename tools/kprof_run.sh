@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 TAG="${1:?tag}"
 lib="$PWD/xrslam_amd/lib/libxrslam_hip_kprof.so"
 [ -f "$lib" ] || XR_VARIANT=kprof bash xrslam_amd/csrc/build.sh -DXRHIP_KPROF
-run() { env XRSLAM_HIP_LIB="$lib" "$@" python bench.py --steps 300 --warmup 50 --cpu-frames 0 --host-frames 0 --inline-frames 0 --threading inline 2>/dev/null | grep '^{' ; }
+run() { env XRSLAM_HIP_LIB="$lib" "$@" python bench.py --steps 300 --warmup 50 --cpu-frames 0 --variant-frames 0 --threading inline 2>/dev/null | grep '^{' ; }
 run XRHIP_KPROF_MAX_NA=16 > gpurun_out/kprof_${TAG}_tiny.json
 run XRHIP_KPROF_MIN_NA=17 XRHIP_KPROF_MAX_NA=99 > gpurun_out/kprof_${TAG}_mid.json
 run XRHIP_KPROF_MIN_NA=100 > gpurun_out/kprof_${TAG}_window.json

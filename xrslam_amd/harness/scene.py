@@ -122,8 +122,27 @@ class BoxRoom:
         return np.where(hit_box, vo, val)
 
 
-def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True, traj=None, K=K_EUROC, dist=None, moving_object=None):
-    """Returns dict(frames uint8 [n,h,w], cam_t [n], imu [m,7] (t, w, a), states [n,16] ground truth body states)."""
+_RENDER_JOB = None   # (room, traj, cam_t, w, h, K, dist, moving_object): inherited by the forked render workers
+
+
+def _render_range(lo_hi):
+    room, traj, cam_t, w, h, K, dist, moving_object = _RENDER_JOB
+    lo, hi = lo_hi
+    out = np.zeros((hi - lo, h, w), np.uint8)
+    for i in range(lo, hi):
+        t = cam_t[i]
+        q, p = traj.q(t), traj.p(t)
+        obj = moving_object(t) if moving_object is not None else None
+        out[i - lo] = room.render(qmul(q, Q_BC), p + qrot(q, P_BC), w, h, K, dist, obj)
+    return lo, out
+
+
+def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True, traj=None, K=K_EUROC, dist=None, moving_object=None,
+                  workers=1):
+    """Returns dict(frames uint8 [n,h,w], cam_t [n], imu [m,7] (t, w, a), states [n,16] ground truth body states).
+    A sequence of n frames is a prefix of every longer one with the same arguments (the random draws are sequential in
+    time and the frames are rendered independently).  workers > 1: the frames are rendered by that many forked processes
+    (same pixels; call it before anything in the process has touched the GPU runtime)."""
     rng = np.random.RandomState(seed)
     traj = traj or Trajectory()
     room = BoxRoom(seed=seed)
@@ -141,10 +160,20 @@ def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0,
     cam_t = t0 + np.arange(n_frames) / cam_hz
     states = np.zeros((n_frames, 16))
     for i, t in enumerate(cam_t):
-        q, p = traj.q(t), traj.p(t)
-        states[i] = np.concatenate([q, p, traj.v(t), bg, ba])
-        obj = None
-        if moving_object is not None:   # callable t -> (centre, half extents), or None when absent
-            obj = moving_object(t)
-        frames[i] = room.render(qmul(q, Q_BC), p + qrot(q, P_BC), w, h, K, dist, obj)
+        states[i] = np.concatenate([traj.q(t), traj.p(t), traj.v(t), bg, ba])
+    global _RENDER_JOB
+    _RENDER_JOB = (room, traj, cam_t, w, h, K, dist, moving_object)   # moving_object: callable t -> (centre, half extents) or None
+    try:
+        workers = max(1, min(int(workers), n_frames // 8))
+        if workers > 1:
+            import multiprocessing as mp
+            chunk = max(1, (n_frames + 4 * workers - 1) // (4 * workers))
+            jobs = [(lo, min(n_frames, lo + chunk)) for lo in range(0, n_frames, chunk)]
+            with mp.get_context("fork").Pool(workers) as pool:
+                for lo, part in pool.imap_unordered(_render_range, jobs):
+                    frames[lo:lo + len(part)] = part
+        else:
+            frames[:] = _render_range((0, n_frames))[1]
+    finally:
+        _RENDER_JOB = None
     return dict(frames=frames, cam_t=cam_t, imu=imu, states=states, bg=bg, ba=ba)
