@@ -36,7 +36,7 @@ b = open(os.path.join(go, "bench_%s.json" % tag)).read().strip().splitlines()[-1
 bj = json.loads(b)
 frames = max(1, tot["xrhip::k_clahe_lut"][1])   # one CLAHE pass per camera frame: counts the frames the traced command processed
 lines = ["# round %d, full pipeline %s (%s)" % (int(rnd[1:]), ver, desc), "",
-         "`rocprofv3 --kernel-trace --memory-copy-trace --stats -- python bench.py --steps 100 --warmup 40 --cpu-frames 0 --no-profile` on one MI355X",
+         "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 40 --cpu-frames 0 --variant-frames 0 --no-profile` (the reference-shaped call: inline, host image) on one MI355X",
          "(gfx950, ROCm 7.2); kernel-trace statistics from the results database.", "",
          ("Total kernel time %.2f ms over %d frames (%.3f ms / frame); default `python bench.py` on the same box: %.1f frames/s, "
           "%.4f ms/frame, %.4f ms/BA-iteration, CPU reference %.1f frames/s on 1 core (`" + rnd + "_full_%s_bench.json`).") %
