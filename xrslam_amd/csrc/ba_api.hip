@@ -871,7 +871,7 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     if (!done) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: trust-region loop did not terminate");
     // the optimised states (in place, like the reference)
     std::memcpy(P->frame_state, c->h_out, sizeof(double) * 16 * d.F);
-    if (d.L) std::memcpy(P->inv_depth, c->h_out + 16 * d.F, sizeof(double) * d.L);
+    if (d.L && d.nla) std::memcpy(P->inv_depth, c->h_out + 16 * d.F, sizeof(double) * d.L);   // no free landmark: nothing moved
     rc = preint_launch_deferred(c, P, nullptr);   // (the single-launch path has launched it already)
     if (rc) return rc;
     const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

@@ -50,7 +50,7 @@ constexpr bool CHAIN_HELPER = CHAIN_THREADS > 256;
 #endif
 
 struct ChainLayout {   // offsets in doubles into the dynamic LDS block
-    int sx, cs, Hp, gp, A, sp, D, gs, grad, gn, delta, gt, wJi, wJj, wr, bref, raw, Hv, oc, total;
+    int sx, cs, Hp, gp, A, sp, D, gs, grad, gn, delta, gt, wJi, wJj, wr, bref, raw, Hv, oc, S, total;
 };
 __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int NI, int nfree, int nobs) {
     ChainLayout L;
@@ -80,6 +80,7 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
     L.raw = take(15 * NI);
     L.Hv = take(28 * nfree);
     L.oc = take(nobs);   // per-factor costs of the reprojection / rotation factors (evaluated by whoever is free, summed in fixed order)
+    L.S = take(225 * NI);   // sqrt_inv_cov of every IMU factor (constant over the solve; read 15 x 15 x 3 times per linearisation)
     L.total = o;
     return L;
 }
@@ -122,21 +123,23 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
     const int F = d.F, n = d.n, na = d.na, NI = d.NI, M = d.M, MR = d.MR;
 #ifdef XRHIP_KPROF
     long long cp_t = wall_clock64();
+    const long long cp_t0 = cp_t;
 #endif
 
-    if (tid == 0) {
-        int nf = 0;
-        for (int f = 0; f < F; ++f) {
-            s_slot[f] = -1;
-            if (p.fix[f] != 3 && nf < CHAIN_MAX_FREE) {
-                s_slot[f] = nf;
-                s_free[nf++] = f;
-            }
-        }
-        s_nfree = nf;
+    // free frames in index order (F <= 64: one lane per frame, the slot is the number of free frames before it) and the
+    // control block, one word per thread -- a single thread walking both lists was 4 us of every solve
+    if (tid < 64) {
+        const bool fr = tid < F && p.fix[tid < F ? tid : 0] != 3;
+        const unsigned long long m = __ballot(fr);
+        const int slot = __popcll(m & ((1ull << tid) - 1ull));
+        if (tid < F) s_slot[tid] = (fr && slot < CHAIN_MAX_FREE) ? slot : -1;
+        if (fr && slot < CHAIN_MAX_FREE) s_free[slot] = tid;
+        if (tid == 0) s_nfree = min(__popcll(m), CHAIN_MAX_FREE);
+    } else {
+        constexpr unsigned ctl_words = sizeof(BaCtl) / sizeof(long long);
         const long long *src = reinterpret_cast<const long long *>(static_cast<BaCtl *>(p.ctl));
         long long *dst = reinterpret_cast<long long *>(&s_ctl);
-        for (unsigned i = 0; i < sizeof(BaCtl) / sizeof(long long); ++i) dst[i] = src[i];
+        for (unsigned i = tid - 64; i < ctl_words; i += nt - 64) dst[i] = src[i];
     }
     __syncthreads();
     const int nfree = s_nfree;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
     double *const A = lds + Lo.A, *const sp = lds + Lo.sp, *const Dg = lds + Lo.D, *const gs = lds + Lo.gs;
     double *const grad = lds + Lo.grad, *const gn = lds + Lo.gn, *const delta = lds + Lo.delta, *const gt = lds + Lo.gt;
     double *const wJi = lds + Lo.wJi, *const wJj = lds + Lo.wJj, *const wr = lds + Lo.wr, *const bref = lds + Lo.bref;
-    double *const raw = lds + Lo.raw, *const Hv = lds + Lo.Hv, *const oc = lds + Lo.oc;
+    double *const raw = lds + Lo.raw, *const Hv = lds + Lo.Hv, *const oc = lds + Lo.oc, *const Ssh = lds + Lo.S;
     BaCtl *const c = &s_ctl;
 
     // this thread's slots of the full 15F layout (element a = tid + 256 m, like the strided loops of the generic bodies):
@@ -158,6 +161,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
     }
     for (int e = wtid; e < 16 * F; e += nt) X[e] = p.state[e];
     for (int e = wtid; e < 6 * NI; e += nt) bref[e] = p.bias_ref[e];
+    for (int e = wtid; e < 225 * NI; e += nt) {
+        const int k = e / 225;
+        Ssh[e] = p.imu_data[(size_t)k * XRHIP_IMU_DIM + 56 + (e - 225 * k)];
+    }
     __syncthreads();
     CPROF(0);   // set-up: control block, states, index slots
 
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
             if (imu_lane) {
                 const int k = imu_k, fi = p.imu_i[k], fj = p.imu_j[k];
                 if (!(p.fix[fi] == 3 && p.fix[fj] == 3)) {
-                    double *rw = scr + k * IMU_SCR, *Ji = rw + 15, *Jj = rw + 240;
+                    double *rw = scr + k * IMU_SCR;
                     const FState si = load_state(X + 16 * fi), sj = load_state(X + 16 * fj);
                     const ImuRec pre = load_imu(p.imu_data + (size_t)k * XRHIP_IMU_DIM);
                     const V3 bg0 = v3(bref[6 * k], bref[6 * k + 1], bref[6 * k + 2]);
@@ -181,7 +188,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                     double r15[15];
                     imu_raw_residual(si, sj, pre, bg0, ba0, imu, r15);
                     for (int i = 0; i < 15; ++i) rw[i] = r15[i];
-                    imu_raw_jacobians(si, sj, pre, bg0, ba0, imu, v3(r15[0], r15[1], r15[2]), Ji, Jj, p.fix[fi] != 3, p.fix[fj] != 3);
+                    if (CHAIN_HELPER)
+                        imu_raw_jacobians(si, sj, pre, bg0, ba0, imu, v3(r15[0], r15[1], r15[2]), rw + 15, rw + 240, p.fix[fi] != 3,
+                                          p.fix[fj] != 3);
                 }
             }
             for (int o = otid; o < M; o += ostride) {
@@ -199,25 +208,45 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                 for (int i = 0; i < RREC; ++i) p.rrec[(size_t)o * RREC + i] = rec[i];
             }
             __syncthreads();
+            // The raw Jacobians of an IMU factor are ~1300 double-precision instructions on one lane, and a wavefront issues them
+            // one at a time whatever the number of active lanes: the four independent parts (imu_raw_jacobians_part -- the split
+            // kb_lin_all uses) go to the four wavefronts, lane k of every wavefront taking its part of factor k.  They need the
+            // rotation part of the residual, which wavefront 3 has just left in LDS.
+            if (!CHAIN_HELPER && lane < NI && worker) {
+                const int k = lane, fi = p.imu_i[k], fj = p.imu_j[k];
+                if (!(p.fix[fi] == 3 && p.fix[fj] == 3)) {
+                    double *rw = scr + k * IMU_SCR;
+                    const FState si = load_state(X + 16 * fi), sj = load_state(X + 16 * fj);
+                    const ImuRec pre = load_imu(p.imu_data + (size_t)k * XRHIP_IMU_DIM);
+                    const V3 bg0 = v3(bref[6 * k], bref[6 * k + 1], bref[6 * k + 2]);
+                    const V3 ba0 = v3(bref[6 * k + 3], bref[6 * k + 4], bref[6 * k + 5]);
+                    imu_raw_jacobians_part(wave, si, sj, pre, bg0, ba0, imu, v3(rw[0], rw[1], rw[2]), rw + 15, rw + 240, p.fix[fi] != 3,
+                                           p.fix[fj] != 3);
+                }
+            }
+            if (!CHAIN_HELPER) __syncthreads();
             CPROF(1);   // linearisation of the factors
-            // ---------------- whitening of the IMU factors: one wavefront per factor (lin_imu_item's second half)
-            for (int k = wave; k < NI; k += 4) {
+            // ---------------- whitening of the IMU factors (lin_imu_block's second half): the 225 entries of a factor's two
+            // Jacobians over the whole workgroup, the residual on the first lanes of wavefront 0; sqrt_inv_cov from LDS
+            for (int k = 0; k < NI; ++k) {
                 const double *rw = scr + k * IMU_SCR, *Ji = rw + 15, *Jj = rw + 240;
                 const int fi = p.imu_i[k], fj = p.imu_j[k];
                 const bool active = !(p.fix[fi] == 3 && p.fix[fj] == 3);
-                const double *S = p.imu_data + (size_t)k * XRHIP_IMU_DIM + 56;
-                double cost = 0.0;
-                if (lane < 15) {
-                    double s = 0;
-                    if (active)
-                        for (int j = 0; j < 15; ++j) s += S[15 * lane + j] * rw[j];
-                    wr[16 * k + lane] = s;
-                    cost = 0.5 * s * s;
+                const double *S = Ssh + 225 * k;
+                if (wave == (k & 3)) {
+                    double cost = 0.0;
+                    if (lane < 15) {
+                        double s = 0;
+                        if (active)
+                            for (int j = 0; j < 15; ++j) s += S[15 * lane + j] * rw[j];
+                        wr[16 * k + lane] = s;
+                        cost = 0.5 * s * s;
+                    }
+                    cost = wave_sum(cost);
+                    if (lane == 0) wr[16 * k + 15] = cost;
                 }
-                cost = wave_sum(cost);
-                if (lane == 0) wr[16 * k + 15] = cost;
-                for (int e = lane; e < 225; e += 64) {
-                    const int i = e / 15, cc = e - 15 * i;
+                if (wtid < 225) {
+                    const int e = wtid, i = e / 15, cc = e - 15 * i;
                     double a = 0, b = 0;
                     if (active) {
                         const bool col_i = cc < 6 ? pose_free(p.fix[fi]) : motion_free(p.fix[fi]);
@@ -348,27 +377,30 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                 }
             }
             __syncthreads();
-            // ---------------- gradient max-norm |x - Plus(x, -g)|_inf over the free frames (gradmax_block)
-            {
-                double mx = 0;
-                if (tid < nfree) {
-                    const int f = s_free[tid];
-                    double neg[15], out[16];
-                    for (int k = 0; k < 15; ++k) {
-                        const int i = p.act_inv[15 * f + k];
-                        neg[k] = i >= 0 ? -gp[i] : -0.0;
-                    }
-                    const double *s = X + 16 * f;
-                    state_plus(s, neg, pose_free(p.fix[f]), motion_free(p.fix[f]), out);
-                    for (int k = 0; k < 16; ++k) mx = fmax(mx, fabs(s[k] - out[k]));
-                }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
-                if (tid == 0) c->gmax = mx;   // the free frames sit in wavefront 0 (nfree <= 6)
-            }
-            __syncthreads();
-            CPROF(5);   // cost, gradient max-norm
+            CPROF(5);   // cost
         }
+        // ---------------- gradient max-norm |x - Plus(x, -g)|_inf over the free frames (gradmax_block): an exponential map on
+        // a handful of lanes, ~3 us of which nothing below needs before the trial logic -- wavefront 1 computes it while
+        // wavefront 0 factors the first diagonal block of the reduced system (chol_blocked's `side`)
+        const bool want_gmax = relin;
+        auto gradmax_side = [&]() __attribute__((always_inline)) {
+            if (!want_gmax) return;
+            double mx = 0;
+            if (lane < nfree) {
+                const int f = s_free[lane];
+                double neg[15], out[16];
+                for (int k = 0; k < 15; ++k) {
+                    const int i = p.act_inv[15 * f + k];
+                    neg[k] = i >= 0 ? -gp[i] : -0.0;
+                }
+                const double *s = X + 16 * f;
+                state_plus(s, neg, pose_free(p.fix[f]), motion_free(p.fix[f]), out);
+                for (int k = 0; k < 16; ++k) mx = fmax(mx, fabs(s[k] - out[k]));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+            if (lane == 0) c->gmax = mx;   // nfree <= 6 lanes of this wavefront
+        };
         // -------------------- preparation (prepare_block): Jacobi scales at the first linearisation, dogleg diagonal
         const double mu = c->mu;
         for (int i = wtid; i < na; i += nt) {
@@ -403,7 +435,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
         const double qgg = block_sum(qacc, scratch);   // (block_sum ends with a barrier: A and y are complete)
         CPROF(6);   // preparation, reduced system, Q(g~, g~)
         // -------------------- Cholesky + substitution (solve_block)
-        bool lin_ok = chol_blocked(A, na, na + 1, Dblk, &s_fail);
+        bool lin_ok = chol_blocked(A, na, na + 1, Dblk, &s_fail, nullptr, gradmax_side);
         CPROF(7);   // Cholesky
         if (lin_ok) {
             trsv_lower_t(A, na, y);
@@ -523,6 +555,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                 if (step_norm < 0) step_norm = sqrt(red2[0]);
                 mcc = dogleg_model_change(t, ca, cb, red2[1]);
                 __syncthreads();
+                CPROF(13);  // trial: dogleg point, step sums
                 // candidate states (every frame, like the generic path: constant frames are copies)
                 for (int f = wtid; f < F; f += nt) {
                     double d15[15];
@@ -533,6 +566,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                     state_plus(X + 16 * f, d15, pose_free(p.fix[f]), motion_free(p.fix[f]), CS + 16 * f);
                 }
                 __syncthreads();
+                CPROF(14);  // trial: candidate states
                 double red[2] = {0, 0};   // cost, |x - candidate|^2
                 for (int o = otid; o < M; o += ostride) oc[o] = obs_eval(d, p, o, CS, p.depth, cam, sx_, sy_, false, nullptr);
                 for (int o = otid; o < MR; o += ostride) oc[M + o] = rot_eval(d, p, o, CS, cam, sx_, sy_, false, nullptr);
@@ -550,6 +584,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                     for (int q = 0; q < 15; ++q) raw[15 * k + q] = r15[q];
                 }
                 __syncthreads();
+                CPROF(15);  // trial: factor evaluations at the candidate
                 for (int o = wtid; o < M; o += nt) red[0] += oc[o];
                 for (int o = wtid; o < MR; o += nt) red[0] += oc[M + o];
                 for (int it = wtid; it < NI * 15; it += nt) {
@@ -570,6 +605,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                     red[1] += acc;
                 }
                 block_sum_n<2>(red, scratch);
+                CPROF(16);  // trial: cost sums
                 cost = red[0];
                 dn2 = red[1];
                 have_prev = true;
@@ -606,14 +642,30 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
     // -------------------- publication: states back to the arena, control block + states + sequence number to the host
     for (int e = wtid; e < 16 * F; e += nt) p.state[e] = X[e];
     __syncthreads();
-    if (tid == 0) {
-        c->status = (st == ST_DONE) ? ST_DONE : -1;   // -1: not terminated within the round budget, the host reports an error
+#ifdef XRHIP_KPROF
+    if (tid == 0) s_ctl.prof[12] += wall_clock64() - cp_t0;   // kernel entry -> publication
+#endif
+    // One pass: the optimised states and the control block go to the host mailbox straight from LDS, one word per thread
+    // (the landmarks are constant in these problems: the host keeps its inverse depths), then the sequence number.  The
+    // control block also returns to the arena (the next solve of this context reads radius / counters from there).
+    const int fin = (st == ST_DONE) ? ST_DONE : -1;   // -1: not terminated within the round budget, the host reports an error
+    if (tid == 0) c->status = fin;
+    __syncthreads();
+    for (int e = wtid; e < 16 * F; e += nt) p.host_out[e] = X[e];
+    {
+        constexpr unsigned ctl_words = sizeof(BaCtl) / sizeof(long long);
         const long long *src = reinterpret_cast<const long long *>(&s_ctl);
         long long *dst = reinterpret_cast<long long *>(static_cast<BaCtl *>(p.ctl));
-        for (unsigned i = 0; i < sizeof(BaCtl) / sizeof(long long); ++i) dst[i] = src[i];
+        long long *hst = reinterpret_cast<long long *>(static_cast<BaCtl *>(p.host_ctl));
+        for (unsigned i = tid; i < ctl_words; i += nt) {
+            const long long v = src[i];
+            dst[i] = v;
+            hst[i] = v;
+        }
     }
+    __threadfence_system();
     __syncthreads();
-    publish_block(d, p, st == ST_DONE ? ST_DONE : -1, seq, true);
+    if (tid == 0) *reinterpret_cast<volatile int *>(static_cast<int *>(p.host_seq)) = seq;
 }
 
 }   // namespace xrhip

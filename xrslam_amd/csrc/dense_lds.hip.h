@@ -195,8 +195,14 @@ __device__ __forceinline__ void chol_trailing_tile(double *A, int n, int nrows, 
     }
 }
 
+struct CholNoSide {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `side`: work wavefront 1 does while wavefront 0 factors the FIRST diagonal block (a serial chain during which every other
+// wavefront would only wait at the barrier) -- anything that does not touch A, Dinv or s_fail.
+template <class Side = CholNoSide>
 __device__ __forceinline__ bool chol_blocked(double *A, int n, int nrows, double (*Dinv)[CH_NB + 1], int *s_fail,
-                                             long long *prof = nullptr) {
+                                             long long *prof = nullptr, Side side = Side()) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     const int r16 = lane & 15, q = lane >> 4;
 #ifdef XRHIP_KPROF
@@ -211,6 +217,8 @@ __device__ __forceinline__ bool chol_blocked(double *A, int n, int nrows, double
         const int nb0 = min(CH_NB, n);
         const bool lwr0 = (nb0 >= n) && (nrows == n + 1);
         if (!chol_diag_wave(A, 0, nb0, Dinv, lane, lwr0 ? rhs : nullptr) && lane == 0) *s_fail = 1;
+    } else if (wave == 1) {
+        side();
     }
     __syncthreads();
     CHPROF(0);
