@@ -69,6 +69,46 @@ def test_factor_math_matches_oracle(hc):
             assert np.abs(Jj.reshape(15, 15) - Jjo).max() < 1e-10 * scale
 
 
+def test_imu_factor_in_pieces_is_the_single_lane_factor_bit_for_bit(hc):
+    """kb_chain cuts an IMU factor's residual and Jacobians along their data dependencies and deals the pieces to its four
+    wavefronts (ba_chain.hip.h).  Every piece uses the single-lane form's expression for its values, operand for operand: the
+    pieces put together are the single-lane result, bit for bit (host compile of the same header; free and constant sides)."""
+    pd, _ = bs.make_window(K=5, L=40, seed=21)
+    st = pd.frame_state
+    ext = np.array([0.01, -0.02, 0.03, 0.9993, 0.02, -0.01, 0.03])
+    ext[:4] /= np.linalg.norm(ext[:4])
+    for k in range(len(pd.imu_i)):
+        i, j = pd.imu_i[k], pd.imu_j[k]
+        ref = st[i, 10:16] + np.array([1e-4, -2e-4, 1e-4, 3e-3, -2e-3, 1e-3])
+        for need_i, need_j in ((1, 1), (0, 1), (1, 0)):
+            raw = np.zeros(30); Ji = np.zeros(450); Jj = np.zeros(450)
+            hc.hc_imu_pieces(_p(st[i].copy()), _p(st[j].copy()), _p(pd.imu_data[k].copy()), _p(ref), _p(ext), need_i, need_j,
+                             _p(raw), _p(Ji), _p(Jj))
+            np.testing.assert_array_equal(raw[:15], raw[15:])
+            np.testing.assert_array_equal(Ji[:225], Ji[225:])
+            np.testing.assert_array_equal(Jj[:225], Jj[225:])
+            assert np.abs(raw[:3]).max() > 0 and (not need_i or np.abs(Ji[:225]).max() > 0)
+
+
+def test_constant_landmark_reprojection_is_the_general_factor_bit_for_bit(hc):
+    """kb_chain evaluates reprojection factors against constant landmarks from per-solve constants (tangent basis, landmark in
+    the reference rig / in the world): same expressions as eval_reprojection, hence the same bits for r, Jt and Jr."""
+    pd, _ = bs.make_window(K=5, L=60, seed=14)
+    st = pd.frame_state
+    cam, sic = np.ascontiguousarray(bs.CAM_EXT), np.ascontiguousarray(bs.SQRT_INV_COV)
+    for o in range(0, len(pd.obs_tgt), 3):
+        ft, fr, l = pd.obs_tgt[o], pd.obs_ref[o], pd.obs_lm[o]
+        zt, zr = np.ascontiguousarray(pd.obs_z_tgt[o]), np.ascontiguousarray(pd.obs_z_ref[o])
+        for ref_free in (0, 1):
+            r = np.zeros(4); Jt = np.zeros(24); Jr = np.zeros(24)
+            hc.hc_reprojection_cached(_p(st[ft].copy()), _p(st[fr].copy()), C.c_double(pd.inv_depth[l]), _p(zt), _p(zr), _p(cam),
+                                      _p(sic), ref_free, _p(r), _p(Jt), _p(Jr))
+            np.testing.assert_array_equal(r[:2], r[2:])
+            np.testing.assert_array_equal(Jt[:12], Jt[12:])
+            np.testing.assert_array_equal(Jr[:12], Jr[12:])
+            assert np.abs(Jt[:12]).max() > 0 and (not ref_free or np.abs(Jr[:12]).max() > 0)
+
+
 def test_plus_and_log(hc):
     rng = np.random.RandomState(1)
     for _ in range(20):

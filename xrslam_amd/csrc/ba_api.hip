@@ -426,10 +426,24 @@ static bool chain(const BaDims &d, size_t lds_limit, size_t *lds_bytes, int *vis
         d.nfree > CHAIN_MAX_FREE)
         return false;
     const size_t bytes = sizeof(double) * (size_t)chain_layout(d.F, d.na, d.NI, d.nfree, d.M + d.MR).total;
-    if (bytes > lds_limit) return false;
-    const size_t with_tile = bytes + sizeof(double) * (size_t)CHAIN_VIS_TILE;   // the reduction tile of the reprojection blocks, if it fits
-    *vis_tile = with_tile <= lds_limit ? 1 : 0;
-    *lds_bytes = *vis_tile ? with_tile : bytes;
+    if (bytes > lds_limit || d.F > 255) return false;
+    // optional regions behind the layout, while they fit: the reduction tile of the reprojection blocks, then the table of
+    // per-solve constants of the reprojection factors (the bigger win: taken first when only one fits)
+    const size_t tile = sizeof(double) * (size_t)CHAIN_VIS_TILE;
+    const size_t cache = sizeof(double) * (size_t)CHAIN_OBS_CACHE * (size_t)chain_cache_stride(d.M);
+    static const bool no_cache = std::getenv("XRHIP_NO_OBS_CACHE") != nullptr;   // development switch (A/B, parity)
+    int o = 0;
+    size_t total = bytes;
+    if (!no_cache && d.M > 0 && total + cache <= lds_limit) {
+        o |= CHAIN_OPT_CACHE;
+        total += cache;
+    }
+    if (total + tile <= lds_limit) {
+        o |= CHAIN_OPT_TILE;
+        total += tile;
+    }
+    *vis_tile = o;
+    *lds_bytes = total;
     return true;
 }
 

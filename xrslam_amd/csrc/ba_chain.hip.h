@@ -26,12 +26,9 @@ constexpr int CHAIN_MAX_NI = 8;
 constexpr int CHAIN_MAX_F = 64;
 constexpr int CHAIN_MAX_OBS = 1024; // reprojection + rotation factors: four per thread
 constexpr int CHAIN_MAX_FREE = 6;
-// Four worker wavefronts.  (A fifth "helper" wavefront that runs the serial SO(3) chains of the IMU factors BESIDE the
-// workers' reprojection factors is written below and selected by 320 here -- but two wavefronts then share a SIMD, the
-// register budget halves to 256 and this kernel, which holds 483, spills 1.1 KB per lane; measured slower.  Kept for a
-// leaner kernel.)
+// Four wavefronts, one per SIMD: the kernel holds ~480 registers per lane, so a fifth wavefront (two on one SIMD) would halve the
+// budget and spill (measured in round 2: slower).
 constexpr int CHAIN_THREADS = 256;
-constexpr bool CHAIN_HELPER = CHAIN_THREADS > 256;
 
 #ifdef XRHIP_KPROF
 #define CPROF(slot)                                   \
@@ -50,7 +47,7 @@ constexpr bool CHAIN_HELPER = CHAIN_THREADS > 256;
 #endif
 
 struct ChainLayout {   // offsets in doubles into the dynamic LDS block
-    int sx, cs, Hp, gp, A, sp, D, gs, grad, gn, delta, gt, wJi, wJj, wr, bref, raw, Hv, oc, S, total;
+    int sx, cs, Hp, gp, A, scr, sp, D, gs, grad, gn, delta, gt, wJi, wJj, wr, bref, raw, Hv, oc, rec, xch, total;
 };
 __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int NI, int nfree, int nobs) {
     ChainLayout L;
@@ -64,8 +61,8 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
     L.cs = take(16 * F);
     L.Hp = take(na * (na + 1) / 2);
     L.gp = take(na);
-    const int a_tri = (na + 1) * (na + 2) / 2, scr = NI * IMU_SCR;   // the raw IMU Jacobians are dead before A is formed
-    L.A = take(a_tri > scr ? a_tri : scr);
+    L.A = take((na + 1) * (na + 2) / 2);
+    L.scr = take(NI * IMU_SCR);   // raw IMU residuals / Jacobians: a region of its own, so that its zero pattern survives the rounds
     L.sp = take(na);
     L.D = take(na);
     L.gs = take(na);
@@ -80,7 +77,8 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
     L.raw = take(15 * NI);
     L.Hv = take(28 * nfree);
     L.oc = take(nobs);   // per-factor costs of the reprojection / rotation factors (evaluated by whoever is free, summed in fixed order)
-    L.S = take(225 * NI);   // sqrt_inv_cov of every IMU factor (constant over the solve; read 15 x 15 x 3 times per linearisation)
+    L.rec = take(XRHIP_IMU_DIM * NI);   // the IMU records (pre-integrated measurement + sqrt_inv_cov): constant over the solve
+    L.xch = take(IMU_XCH * NI);         // matrices handed from one wavefront to another inside a linearisation
     L.total = o;
     return L;
 }
@@ -88,8 +86,54 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
 // (Tried: this workgroup pulling the staged problem from the pinned host arena itself instead of a kb_stage launch in
 // front of it -- one compute unit reads the host link slower than kb_stage's 128 workgroups: localize_newframe
 // 0.132 -> 0.139 ms per frame, profiles/r02_ab_variants.md.)
-constexpr int CHAIN_VIS_TILE = 27 * 257;   // doubles of LDS behind the layout when `vis_tile` is set
-__global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__restrict__ args, int seq, int max_rounds, int vis_tile) {
+constexpr int CHAIN_VIS_TILE = 27 * 257;   // doubles of LDS behind the layout when `opts & CHAIN_OPT_TILE`
+constexpr int CHAIN_OBS_CACHE = 16;        // doubles per reprojection factor behind that when `opts & CHAIN_OPT_CACHE`
+enum { CHAIN_OPT_TILE = 1, CHAIN_OPT_CACHE = 2 };
+__host__ __device__ __forceinline__ int chain_cache_stride(int M) { return (M + 1) & ~1; }
+
+// A reprojection factor of these problems sees a constant landmark and -- mostly -- a constant reference frame: its tangent basis,
+// the landmark in the reference rig and in the world do not change during the solve.  They are evaluated once (set-up) into an
+// LDS table, SoA over the factors: rows 0-2 b1, 3-5 b2, 6-8 y_ref_center, 9-11 x, 12-14 z_tgt, 15 = tgt | ref << 8 | tgt free << 16
+// | ref free << 17 (as a double).  An evaluation is then ~450 instead of ~1000 double-precision instructions per lane -- and the
+// linearisation of the reprojection factors, not the IMU factor, was the longest stream of a round (profiles/r03_ab_variants.md).
+__device__ __forceinline__ double obs_eval_cached(const BaDims &d, const double *oca, int Mp, int o, const double *state, const Ext &cam,
+                                                  double sx, double sy, bool want_j, double *rec) {
+    const int inf = (int)oca[15 * Mp + o];
+    const int ft = inf & 255, fr = (inf >> 8) & 255;
+    const bool at = (inf >> 16) & 1, ar = (inf >> 17) & 1;
+    if (!at && !ar) {
+        if (want_j)
+            for (int i = 0; i < OREC; ++i) rec[i] = 0.0;
+        return 0.0;
+    }
+    ObsConst c;
+    c.b1 = v3(oca[o], oca[Mp + o], oca[2 * Mp + o]);
+    c.b2 = v3(oca[3 * Mp + o], oca[4 * Mp + o], oca[5 * Mp + o]);
+    c.y_ref_center = v3(oca[6 * Mp + o], oca[7 * Mp + o], oca[8 * Mp + o]);
+    c.x = v3(oca[9 * Mp + o], oca[10 * Mp + o], oca[11 * Mp + o]);
+    const V3 zt = v3(oca[12 * Mp + o], oca[13 * Mp + o], oca[14 * Mp + o]);
+    const FState st = load_state(state + 16 * ft), sr = load_state(state + 16 * fr);
+    double r[2], Jt[12], Jr[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Jr[i] = 0.0;
+    eval_reprojection_cached(st, sr, ar, c, zt, cam, sx, sy, r, want_j, Jt, Jr);
+    const double s = r[0] * r[0] + r[1] * r[1];
+    if (want_j) {
+        const double sc = d.robust ? sqrt(fmax(2.2250738585072014e-308, 1.0 / (1.0 + s))) : 1.0;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            rec[i] = at ? Jt[i] * sc : 0.0;
+            rec[12 + i] = ar ? Jr[i] * sc : 0.0;
+        }
+        rec[24] = 0.0;
+        rec[25] = 0.0;
+        rec[26] = r[0] * sc;
+        rec[27] = r[1] * sc;
+    }
+    return d.robust ? 0.5 * log(1.0 + s) : 0.5 * s;
+}
+
+__global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__restrict__ args, int seq, int max_rounds, int opts) {
     const BaDims &d = args->d;
     const BaPtrs &p = args->p;
     const Ext &cam = args->cam, &imu = args->imu;
@@ -101,24 +145,24 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
     __shared__ int s_fail;
     __shared__ int s_free[CHAIN_MAX_FREE], s_slot[CHAIN_MAX_F], s_nfree;
     __shared__ BaCtl s_ctl;
-    // Threads 0..255 are the workers: every strided loop, block sum and wavefront-indexed loop below runs on them exactly
-    // as it would in a 256-thread workgroup (same thread -> element mapping as the generic bodies).  With CHAIN_HELPER a
-    // fifth wavefront evaluates the IMU factors (lane k: factor k) while the workers evaluate the reprojection factors; it
-    // takes part in every barrier and collective and contributes zeros to the sums.  Without it, threads 0..NI-1 do.
     const int tid = threadIdx.x, lane = tid & 63;
-    const bool worker = tid < 256;
-    // Who evaluates what.  An IMU factor is ONE lane's chain of a few thousand dependent double-precision operations
-    // (expmap, logmap, right Jacobian), about as long as two reprojection factors; lanes of one wavefront run in lockstep, so
-    // a wavefront that holds both kinds runs them one after the other.  With IMU factors present the last worker wavefront
-    // therefore takes the IMU factors only (lane k: factor k) and the reprojection / rotation factors are dealt to the other
-    // three (stride 192); their costs go through LDS and are added up in the fixed order o = t, t + 256, ... of the generic
-    // bodies, so the sums do not depend on who evaluated what.
-    const bool split = !CHAIN_HELPER && d.NI > 0;
-    const bool imu_lane = CHAIN_HELPER ? (!worker && lane < d.NI) : (split ? (tid >= 192 && tid - 192 < d.NI) : false);
-    const int imu_k = CHAIN_HELPER ? lane : tid - 192;
+    // Who evaluates what.  A double-precision instruction costs its wavefront ~8 cycles of issue whatever the number of active
+    // lanes (tools/latency.hip), so an IMU factor -- ~900 instructions for the residual, ~1300 more for the Jacobians, on ONE lane --
+    // is the longest instruction stream of a round by far, and lanes of one wavefront run in lockstep: a wavefront that holds two
+    // kinds of work runs them one after the other.  The streams of an IMU factor are therefore cut along their data dependencies
+    // and dealt to the four wavefronts (lane k of every wavefront: its piece of factor k; ba_math.hip.h, imu_residual_rq ...):
+    //   phase A   wavefront 3: the rotation residual (expmap, three quaternion products, logmap), then Jr^-1(rq), R(expmap(rq))^T and
+    //             the rest of the residual
+    //             wavefronts 0-2: the reprojection / rotation factors (stride 192), then the rq-free pieces of the IMU factor
+    //   phase B   wavefronts 0, 1: the two triple products
+    // The factors' costs go through LDS and are added up in the fixed order o = t, t + 256, ... of the generic bodies, so the sums
+    // do not depend on who evaluated what.
+    const bool split = d.NI > 0;
+    const bool imu_lane = lane < d.NI;          // in every wavefront
     const int ostride = split ? 192 : 256;
-    const int otid = (worker && (!split || tid < 192)) ? tid : (1 << 30);
-    const int wtid = worker ? tid : (1 << 30), wave = worker ? (tid >> 6) : (1 << 28);
+    const int otid = (!split || tid < 192) ? tid : (1 << 30);
+    const int wtid = tid, wave = tid >> 6;
+    constexpr bool worker = true;
     constexpr int nt = 256;
     const int F = d.F, n = d.n, na = d.na, NI = d.NI, M = d.M, MR = d.MR;
 #ifdef XRHIP_KPROF
@@ -148,7 +192,11 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
     double *const A = lds + Lo.A, *const sp = lds + Lo.sp, *const Dg = lds + Lo.D, *const gs = lds + Lo.gs;
     double *const grad = lds + Lo.grad, *const gn = lds + Lo.gn, *const delta = lds + Lo.delta, *const gt = lds + Lo.gt;
     double *const wJi = lds + Lo.wJi, *const wJj = lds + Lo.wJj, *const wr = lds + Lo.wr, *const bref = lds + Lo.bref;
-    double *const raw = lds + Lo.raw, *const Hv = lds + Lo.Hv, *const oc = lds + Lo.oc, *const Ssh = lds + Lo.S;
+    double *const raw = lds + Lo.raw, *const Hv = lds + Lo.Hv, *const oc = lds + Lo.oc, *const recs = lds + Lo.rec, *const xch = lds + Lo.xch;
+    double *const scr = lds + Lo.scr;   // [NI][IMU_SCR]
+    const bool vis_tile = (opts & CHAIN_OPT_TILE) != 0, use_cache = (opts & CHAIN_OPT_CACHE) != 0;
+    const int Mp = chain_cache_stride(M);
+    double *const oca = lds + Lo.total + (vis_tile ? CHAIN_VIS_TILE : 0);   // [16][Mp]
     BaCtl *const c = &s_ctl;
 
     // this thread's slots of the full 15F layout (element a = tid + 256 m, like the strided loops of the generic bodies):
@@ -161,41 +209,42 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
     }
     for (int e = wtid; e < 16 * F; e += nt) X[e] = p.state[e];
     for (int e = wtid; e < 6 * NI; e += nt) bref[e] = p.bias_ref[e];
-    for (int e = wtid; e < 225 * NI; e += nt) {
-        const int k = e / 225;
-        Ssh[e] = p.imu_data[(size_t)k * XRHIP_IMU_DIM + 56 + (e - 225 * k)];
-    }
+    for (int e = wtid; e < XRHIP_IMU_DIM * NI; e += nt) recs[e] = p.imu_data[e];
+    for (int e = wtid; e < NI * IMU_SCR; e += nt) scr[e] = 0.0;   // the blocks a linearisation writes are the same every round
     __syncthreads();
+    if (use_cache) {
+        for (int o = wtid; o < M; o += nt) {
+            const int ft = p.obs_tgt[o], fr = p.obs_ref[o];
+            const bool at = pose_free(p.fix[ft]), ar = pose_free(p.fix[fr]);
+            const V3 zt = v3(p.obs_zt[3 * o], p.obs_zt[3 * o + 1], p.obs_zt[3 * o + 2]);
+            if (at || ar) {
+                const V3 zr = v3(p.obs_zr[3 * o], p.obs_zr[3 * o + 1], p.obs_zr[3 * o + 2]);
+                const ObsConst c = reprojection_constants(load_state(X + 16 * fr), p.depth[p.obs_lm[o]], zt, zr, cam);
+                oca[o] = c.b1.x; oca[Mp + o] = c.b1.y; oca[2 * Mp + o] = c.b1.z;
+                oca[3 * Mp + o] = c.b2.x; oca[4 * Mp + o] = c.b2.y; oca[5 * Mp + o] = c.b2.z;
+                oca[6 * Mp + o] = c.y_ref_center.x; oca[7 * Mp + o] = c.y_ref_center.y; oca[8 * Mp + o] = c.y_ref_center.z;
+                oca[9 * Mp + o] = c.x.x; oca[10 * Mp + o] = c.x.y; oca[11 * Mp + o] = c.x.z;
+                oca[12 * Mp + o] = zt.x; oca[13 * Mp + o] = zt.y; oca[14 * Mp + o] = zt.z;
+            }
+            oca[15 * Mp + o] = (double)(ft | (fr << 8) | ((int)at << 16) | ((int)ar << 17));
+        }
+        __syncthreads();
+    }
     CPROF(0);   // set-up: control block, states, index slots
 
     bool relin = true;
     int mode = 1, st = ST_RUNNING;
     for (int round = 0; round < max_rounds; ++round) {
         if (relin) {
-            // ---------------- linearisation: IMU factors on the lanes of wavefront 0 (one factor each, the SO(3) chains
-            // advance in lockstep), the observations on everybody, thread t taking o = t, t + 256, ...
-            double *scr = A;   // [NI][IMU_SCR]
-            for (int e = wtid; e < NI * IMU_SCR; e += nt) scr[e] = 0.0;
-            __syncthreads();
-            if (imu_lane) {
-                const int k = imu_k, fi = p.imu_i[k], fj = p.imu_j[k];
-                if (!(p.fix[fi] == 3 && p.fix[fj] == 3)) {
-                    double *rw = scr + k * IMU_SCR;
-                    const FState si = load_state(X + 16 * fi), sj = load_state(X + 16 * fj);
-                    const ImuRec pre = load_imu(p.imu_data + (size_t)k * XRHIP_IMU_DIM);
-                    const V3 bg0 = v3(bref[6 * k], bref[6 * k + 1], bref[6 * k + 2]);
-                    const V3 ba0 = v3(bref[6 * k + 3], bref[6 * k + 4], bref[6 * k + 5]);
-                    double r15[15];
-                    imu_raw_residual(si, sj, pre, bg0, ba0, imu, r15);
-                    for (int i = 0; i < 15; ++i) rw[i] = r15[i];
-                    if (CHAIN_HELPER)
-                        imu_raw_jacobians(si, sj, pre, bg0, ba0, imu, v3(r15[0], r15[1], r15[2]), rw + 15, rw + 240, p.fix[fi] != 3,
-                                          p.fix[fj] != 3);
-                }
-            }
+            // ---------------- linearisation (the schedule at the top of the kernel)
+            // phase A
+#ifdef XRHIP_KPROF
+            const long long pa_t0 = wall_clock64();
+#endif
             for (int o = otid; o < M; o += ostride) {
                 double rec[OREC];
-                const double co = obs_eval(d, p, o, X, p.depth, cam, sx_, sy_, true, rec);
+                const double co = use_cache ? obs_eval_cached(d, oca, Mp, o, X, cam, sx_, sy_, true, rec)
+                                            : obs_eval(d, p, o, X, p.depth, cam, sx_, sy_, true, rec);
                 oc[o] = co;
 #pragma unroll
                 for (int i = 0; i < OREC; ++i) p.orec[(size_t)o * OREC + i] = rec[i];
@@ -207,24 +256,59 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
 #pragma unroll
                 for (int i = 0; i < RREC; ++i) p.rrec[(size_t)o * RREC + i] = rec[i];
             }
-            __syncthreads();
-            // The raw Jacobians of an IMU factor are ~1300 double-precision instructions on one lane, and a wavefront issues them
-            // one at a time whatever the number of active lanes: the four independent parts (imu_raw_jacobians_part -- the split
-            // kb_lin_all uses) go to the four wavefronts, lane k of every wavefront taking its part of factor k.  They need the
-            // rotation part of the residual, which wavefront 3 has just left in LDS.
-            if (!CHAIN_HELPER && lane < NI && worker) {
+#ifdef XRHIP_KPROF
+            const long long pa_t1 = wall_clock64();
+            if (tid == 0) s_ctl.prof[21] += pa_t1 - pa_t0;   // wavefront 0: its reprojection / rotation factors
+#endif
+            bool imu_on = false;
+            int nfi = 0, nfj = 0;
+            if (imu_lane) {
                 const int k = lane, fi = p.imu_i[k], fj = p.imu_j[k];
-                if (!(p.fix[fi] == 3 && p.fix[fj] == 3)) {
+                nfi = p.fix[fi] != 3;
+                nfj = p.fix[fj] != 3;
+                imu_on = nfi || nfj;
+                if (imu_on) {
                     double *rw = scr + k * IMU_SCR;
                     const FState si = load_state(X + 16 * fi), sj = load_state(X + 16 * fj);
-                    const ImuRec pre = load_imu(p.imu_data + (size_t)k * XRHIP_IMU_DIM);
+                    const ImuRec pre = load_imu(recs + k * XRHIP_IMU_DIM);
                     const V3 bg0 = v3(bref[6 * k], bref[6 * k + 1], bref[6 * k + 2]);
                     const V3 ba0 = v3(bref[6 * k + 3], bref[6 * k + 4], bref[6 * k + 5]);
-                    imu_raw_jacobians_part(wave, si, sj, pre, bg0, ba0, imu, v3(rw[0], rw[1], rw[2]), rw + 15, rw + 240, p.fix[fi] != 3,
-                                           p.fix[fj] != 3);
+                    if (wave == 3) {
+                        // the long pole: the rotation residual, then -- without waiting for anybody -- what only needs it
+                        const V3 rq = imu_residual_rq(si, sj, pre, bg0, imu);
+                        rw[0] = rq.x;
+                        rw[1] = rq.y;
+                        rw[2] = rq.z;
+                        double *xk = xch + k * IMU_XCH;
+                        store33(xk + 45, imu_jac_jrinv(rq));
+                        if (nfi) store33(xk + 36, imu_jac_B(rq));
+                        imu_residual_rest(si, sj, pre, bg0, ba0, imu, rw);   // this wavefront has no reprojection factors
+                    } else if (wave == 0) {
+                        imu_raw_jacobians_part(2, si, sj, pre, bg0, ba0, imu, v3(0, 0, 0), rw + 15, rw + 240, nfi, nfj);
+                    } else if (wave == 1) {
+                        imu_jac_pre(si, sj, pre, bg0, imu, xch + k * IMU_XCH, nfi, nfj);
+                    } else {
+                        imu_raw_jacobians_part(3, si, sj, pre, bg0, ba0, imu, v3(0, 0, 0), rw + 15, rw + 240, nfi, nfj);
+                    }
                 }
             }
-            if (!CHAIN_HELPER) __syncthreads();
+#ifdef XRHIP_KPROF
+            if (tid == 192) atomicAdd((unsigned long long *)&s_ctl.prof[22], (unsigned long long)(wall_clock64() - pa_t1));   // wavefront 3: rq chain + Jr^-1, B
+            if (tid == 0) atomicAdd((unsigned long long *)&s_ctl.prof[23], (unsigned long long)(wall_clock64() - pa_t1));     // wavefront 0: its rq-free piece
+#endif
+            __syncthreads();
+            CPROF(18);  // lin: phase A (reprojection factors; rotation residual, Jr^-1, B; rq-free pieces)
+            if (split) {
+                // phase B: the products
+                if (imu_on) {
+                    double *rw = scr + lane * IMU_SCR;
+                    const double *xk = xch + lane * IMU_XCH;
+                    if (wave == 0) imu_jac_finish0(load33(xk + 45), xk, rw + 15, rw + 240, nfi, nfj);
+                    else if (wave == 1)
+                        imu_jac_finish1(load33(xk + 45), load33(xk + 36), xk, load33(recs + lane * XRHIP_IMU_DIM + 11), rw + 15, nfi);
+                }
+                __syncthreads();
+            }
             CPROF(1);   // linearisation of the factors
             // ---------------- whitening of the IMU factors (lin_imu_block's second half): the 225 entries of a factor's two
             // Jacobians over the whole workgroup, the residual on the first lanes of wavefront 0; sqrt_inv_cov from LDS
@@ -232,7 +316,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                 const double *rw = scr + k * IMU_SCR, *Ji = rw + 15, *Jj = rw + 240;
                 const int fi = p.imu_i[k], fj = p.imu_j[k];
                 const bool active = !(p.fix[fi] == 3 && p.fix[fj] == 3);
-                const double *S = Ssh + 225 * k;
+                const double *S = recs + k * XRHIP_IMU_DIM + 56;
                 if (wave == (k & 3)) {
                     double cost = 0.0;
                     if (lane < 15) {
@@ -568,20 +652,35 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                 __syncthreads();
                 CPROF(14);  // trial: candidate states
                 double red[2] = {0, 0};   // cost, |x - candidate|^2
-                for (int o = otid; o < M; o += ostride) oc[o] = obs_eval(d, p, o, CS, p.depth, cam, sx_, sy_, false, nullptr);
+                for (int o = otid; o < M; o += ostride)
+                    oc[o] = use_cache ? obs_eval_cached(d, oca, Mp, o, CS, cam, sx_, sy_, false, nullptr)
+                                      : obs_eval(d, p, o, CS, p.depth, cam, sx_, sy_, false, nullptr);
                 for (int o = otid; o < MR; o += ostride) oc[M + o] = rot_eval(d, p, o, CS, cam, sx_, sy_, false, nullptr);
-                if (imu_lane) {   // one IMU factor per lane
-                    const int k = imu_k;
+                if (imu_lane && wave >= 2) {   // lane k of wavefront 3: the rotation residual of factor k; of wavefront 2: the rest
+                    const int k = lane;
                     const int fi = p.imu_i[k], fj = p.imu_j[k];
                     double r15[15];
-                    if (p.fix[fi] == 3 && p.fix[fj] == 3) {
-                        for (int q = 0; q < 15; ++q) r15[q] = 0.0;
-                    } else {
-                        imu_raw_residual(load_state(CS + 16 * fi), load_state(CS + 16 * fj), load_imu(p.imu_data + (size_t)k * XRHIP_IMU_DIM),
-                                         v3(bref[6 * k], bref[6 * k + 1], bref[6 * k + 2]),
-                                         v3(bref[6 * k + 3], bref[6 * k + 4], bref[6 * k + 5]), imu, r15);
+#pragma unroll
+                    for (int q = 0; q < 15; ++q) r15[q] = 0.0;
+                    if (!(p.fix[fi] == 3 && p.fix[fj] == 3)) {
+                        const FState ci = load_state(CS + 16 * fi), cj = load_state(CS + 16 * fj);
+                        const ImuRec cpre = load_imu(recs + k * XRHIP_IMU_DIM);
+                        const V3 cbg = v3(bref[6 * k], bref[6 * k + 1], bref[6 * k + 2]);
+                        const V3 cba = v3(bref[6 * k + 3], bref[6 * k + 4], bref[6 * k + 5]);
+                        if (wave == 3) {
+                            const V3 rq = imu_residual_rq(ci, cj, cpre, cbg, imu);
+                            r15[0] = rq.x;
+                            r15[1] = rq.y;
+                            r15[2] = rq.z;
+                        } else {
+                            imu_residual_rest(ci, cj, cpre, cbg, cba, imu, r15);
+                        }
                     }
-                    for (int q = 0; q < 15; ++q) raw[15 * k + q] = r15[q];
+                    if (wave == 3) {
+                        for (int q = 0; q < 3; ++q) raw[15 * k + q] = r15[q];
+                    } else {
+                        for (int q = 3; q < 15; ++q) raw[15 * k + q] = r15[q];
+                    }
                 }
                 __syncthreads();
                 CPROF(15);  // trial: factor evaluations at the candidate
@@ -589,7 +688,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
                 for (int o = wtid; o < MR; o += nt) red[0] += oc[M + o];
                 for (int it = wtid; it < NI * 15; it += nt) {
                     const int k = it / 15, i = it - 15 * k;
-                    const double *S = p.imu_data + (size_t)k * XRHIP_IMU_DIM + 56 + 15 * i;
+                    const double *S = recs + k * XRHIP_IMU_DIM + 56 + 15 * i;
                     double acc = 0;
 #pragma unroll
                     for (int j = 0; j < 15; ++j) acc += S[j] * raw[15 * k + j];

@@ -301,6 +301,67 @@ XD void eval_reprojection(const FState &tgt, const FState &ref, double inv_depth
     Jl[1] = -(D[3] * t.x + D[4] * t.y + D[5] * t.z) / inv_depth;
 }
 
+// The same factor for a landmark that is held CONSTANT (every landmark of localize_newframe / refine_subwindow / PnP), cut in two:
+// what depends only on the measurement, the landmark and -- when it is constant too -- the reference frame is evaluated once per
+// solve (reprojection_constants), the rest once per evaluation (eval_reprojection_cached).  Expression for expression the body of
+// eval_reprojection (same operands, same order): r, Jt, Jr are bit-identical; Jl is not produced (the landmark has no column).
+struct ObsConst {
+    V3 b1, b2;            // tangent basis at z_tgt
+    V3 y_ref_center;      // landmark in the reference camera rig's body frame
+    V3 x;                 // landmark in the world (valid when the reference frame is constant)
+};
+XD ObsConst reprojection_constants(const FState &ref, double inv_depth, V3 z_tgt, V3 z_ref, const Ext &cam) {
+    ObsConst c;
+    s2_tangential_basis(z_tgt, c.b1, c.b2);
+    V3 y_ref = z_ref / inv_depth;
+    c.y_ref_center = q_rot(cam.q, y_ref) + cam.p;
+    c.x = q_rot(ref.q, c.y_ref_center) + ref.p;
+    return c;
+}
+// ref_free: the reference frame moves (x is recomputed, Jr is produced); otherwise Jr is left untouched.
+XD void eval_reprojection_cached(const FState &tgt, const FState &ref, bool ref_free, const ObsConst &c, V3 z_tgt, const Ext &cam,
+                                 double sx, double sy, double *r, bool want_j, double *Jt, double *Jr) {
+    const V3 b1 = c.b1, b2 = c.b2, y_ref_center = c.y_ref_center;
+    V3 x = ref_free ? q_rot(ref.q, y_ref_center) + ref.p : c.x;
+    V3 y_tgt_center = q_rot(q_conj(tgt.q), x - tgt.p);
+    V3 y_tgt = q_rot(q_conj(cam.q), y_tgt_center - cam.p);
+    double u0 = dot(b1, y_tgt), u1 = dot(b2, y_tgt), u2 = dot(z_tgt, y_tgt);
+    r[0] = sx * (u0 / u2);
+    r[1] = sy * (u1 / u2);
+    if (!want_j) return;
+    double d00 = 1.0 / u2, d02 = -u0 / (u2 * u2), d11 = 1.0 / u2, d12 = -u1 / (u2 * u2);
+    double A[6];
+    A[0] = sx * (d00 * b1.x + d02 * z_tgt.x);
+    A[1] = sx * (d00 * b1.y + d02 * z_tgt.y);
+    A[2] = sx * (d00 * b1.z + d02 * z_tgt.z);
+    A[3] = sy * (d11 * b2.x + d12 * z_tgt.x);
+    A[4] = sy * (d11 * b2.y + d12 * z_tgt.y);
+    A[5] = sy * (d11 * b2.z + d12 * z_tgt.z);
+    double B[6], C[6], E[6];
+    mul23(A, q_mat(q_conj(cam.q)), B);    // dr_dy_tgt_center
+    mul23(B, q_mat(q_conj(tgt.q)), C);    // dr_dx
+    mul23(B, hat(y_tgt_center), E);       // dr_dq_tgt
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Jt[6 * i + j] = E[3 * i + j];
+            Jt[6 * i + 3 + j] = -C[3 * i + j];
+        }
+    if (!ref_free) return;
+    double D[6];
+    mul23(C, q_mat(ref.q), D);            // dr_dy_ref_center
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Jr[6 * i + 3 + j] = C[3 * i + j];
+    mul23(D, hat(y_ref_center), E);       // -dr_dq_ref
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Jr[6 * i + j] = -E[3 * i + j];
+}
+
 // CeresRotationPriorFactor::Evaluate.  Jq: 2x3 row-major.
 XD void eval_rotation(const FState &tgt, const FState &ref, V3 z_tgt, V3 z_ref, const Ext &cam, double sx, double sy,
                       double *r, bool want_j, double *Jq) {
@@ -467,6 +528,70 @@ XD void imu_raw_jacobians_part(int part, const FState &fi, const FState &fj, con
             put33(Ji, 6, 6, -Rqi_t);
         }
     }
+}
+
+// ---- the same residual and Jacobians cut along their data dependencies, for SEVERAL wavefronts working on one factor
+// (ba_chain.hip.h).  A double-precision instruction costs its wavefront ~8 cycles of issue whatever the number of active lanes,
+// so one lane's stream of ~2200 instructions is 8 us; the only way down is more streams.  Every value below is produced by the
+// expression imu_raw_residual / imu_raw_jacobians use for it, operand for operand and in the same order (left-associated
+// products included): the pieces put together are bit-identical to the single-lane forms.
+//   rq chain (long: expmap, three quaternion products, logmap)          imu_residual_rq
+//   everything else of the residual (no transcendental)                imu_residual_rest -> r15[3..15)
+//   matrices that do not depend on rq                                   imu_jac_pre
+//   Jr^-1(rq) | R(expmap(rq))^T                                         imu_jac_jrinv | imu_jac_B   (need rq)
+//   the products                                                        imu_jac_finish0 | imu_jac_finish1
+XD V3 imu_residual_rq(const FState &fi, const FState &fj, const ImuRec &pre, V3 bg0, const Ext &imu) {
+    const Q4 q_i = q_mul(fi.q, imu.q);
+    const Q4 q_j = q_mul(fj.q, imu.q);
+    const V3 dbg = fi.bg - bg0;
+    return logmap(q_mul(q_mul(q_conj(q_mul(pre.dq, expmap(pre.dq_dbg * dbg))), q_conj(q_i)), q_j));
+}
+XD void imu_residual_rest(const FState &fi, const FState &fj, const ImuRec &pre, V3 bg0, V3 ba0, const Ext &imu, double *r15) {
+    const V3 gravity = v3(0.0, 0.0, -9.80665);
+    const Q4 q_i = q_mul(fi.q, imu.q);
+    const V3 p_i = fi.p + q_rot(fi.q, imu.p);
+    const V3 p_j = fj.p + q_rot(fj.q, imu.p);
+    const double dt = pre.dt;
+    const V3 dbg = fi.bg - bg0, dba = fi.ba - ba0;
+    V3 rp = q_rot(q_conj(q_i), p_j - p_i - fi.v * dt - gravity * (0.5 * dt * dt)) -
+            (pre.dp + pre.dp_dbg * dbg + pre.dp_dba * dba);
+    V3 rv = q_rot(q_conj(q_i), fj.v - fi.v - gravity * dt) - (pre.dv + pre.dv_dbg * dbg + pre.dv_dba * dba);
+    V3 rbg = fj.bg - fi.bg, rba = fj.ba - fi.ba;
+    r15[3] = rp.x; r15[4] = rp.y; r15[5] = rp.z;
+    r15[6] = rv.x; r15[7] = rv.y; r15[8] = rv.z;
+    r15[9] = rbg.x; r15[10] = rbg.y; r15[11] = rbg.z;
+    r15[12] = rba.x; r15[13] = rba.y; r15[14] = rba.z;
+}
+XD void store33(double *d, const M3 &a) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = a.m[i];
+}
+XD M3 load33(const double *d) {
+    M3 a;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.m[i] = d[i];
+    return a;
+}
+constexpr int IMU_XCH = 54;   // doubles exchanged per factor: RJth, Q1, Q2, Rimu_t (imu_jac_pre) | B | Jr_inv
+XD void imu_jac_pre(const FState &fi, const FState &fj, const ImuRec &pre, V3 bg0, const Ext &imu, double *x36, bool need_i = true,
+                    bool need_j = true) {
+    if (need_i) {   // only the Jacobian with respect to frame i uses these
+        const V3 dbg = fi.bg - bg0;
+        const Q4 q_j = q_mul(fj.q, imu.q);
+        store33(x36, right_jacobian(pre.dq_dbg * dbg));
+        store33(x36 + 9, q_mat(q_conj(q_j)));
+        store33(x36 + 18, q_mat(fi.q));
+    }
+    if (need_j) store33(x36 + 27, q_mat(q_conj(imu.q)));
+}
+XD M3 imu_jac_jrinv(V3 rq) { return inverse3(right_jacobian(rq)); }
+XD M3 imu_jac_B(V3 rq) { return q_mat(q_conj(expmap(rq))); }
+XD void imu_jac_finish0(const M3 &Jr_inv, const double *x36, double *Ji, double *Jj, bool need_i, bool need_j) {
+    if (need_j) put33(Jj, 0, 0, Jr_inv * load33(x36 + 27));
+    if (need_i) put33(Ji, 0, 0, -(Jr_inv * load33(x36 + 9) * load33(x36 + 18)));
+}
+XD void imu_jac_finish1(const M3 &Jr_inv, const M3 &B, const double *x36, const M3 &dq_dbg, double *Ji, bool need_i) {
+    if (need_i) put33(Ji, 0, 9, -(Jr_inv * B * load33(x36) * dq_dbg));
 }
 
 // QuaternionParameterization::Plus + additive blocks; d15 = (dq3, dp, dv, dbg, dba); mask bit0: pose free, bit1: motion free

@@ -354,4 +354,237 @@ __device__ __forceinline__ void trsv_lower_t(const double *A, int n, double *y) 
     }
 }
 
+
+// =====================================================================================================================
+// Tiled variant (round 3) -- for systems that live in LDS.
+//
+// Why a second layout.  In the packed triangle the 16x16 blocks the matrix cores consume have a different row stride in every
+// row (bank conflicts on every operand load), the diagonal block's load and write-back are sixteen predicated accesses each, and
+// the back-substitution has to re-solve every diagonal block as a 16-step dependent chain because the inverse of a block is
+// gone once the next panel has used it.  In-kernel timers of round 2 (profiles/r02_kprof_v39.md): of a panel step's 5.8 us the
+// serial diagonal block was 3.9 (0.5 load + 2.0 factor/invert + 1.4 write-back), the substitution another 1.6 us per block.
+//
+// Layout: the lower triangle in 16x16 tiles, tile (ti, tj), tj <= ti, at (ti (ti + 1) / 2 + tj) * TL_TILE doubles; inside a tile
+// element (r, c) at c * TL_LD + r with TL_LD = 17: "row = lane" reads (the matrix-core operands, the diagonal block) and "column =
+// lane" reads (the transposed accesses of the back-substitution) are both free of bank conflicts.  Rows >= nrows are zero, the
+// padding diagonal is 1: nothing in the loops is predicated.  A right-hand side rides along as row n (nrows = n + 1): the
+// factorisation leaves L^-1 rhs there.  The strictly upper triangle of a DIAGONAL tile -- unused by L -- keeps the transposed
+// strictly lower triangle of that block's inverse, its diagonal goes to dinv[tile][16]: the back-substitution is then one
+// 16x16 matrix-vector product per block instead of a 16-step chain.
+//
+// Diagonal block (tl_diag_wave): lanes 0-15 hold the rows of the block, lanes 16-31 the columns of the inverse under
+// construction, in the SAME registers: the rank-1 update of column c is one FMA per later column for both (the inverse was a second
+// FMA on the same lanes before).  Same products and sums as chol_diag_wave_t, in the same order: the same bits.
+constexpr int TL_LD = 17, TL_TILE = 16 * TL_LD;
+__host__ __device__ __forceinline__ int tl_tile_rows(int nrows) { return (nrows + 15) >> 4; }
+__host__ __device__ __forceinline__ int tl_doubles(int nrows) {
+    const int T = tl_tile_rows(nrows);
+    return T * (T + 1) / 2 * TL_TILE;
+}
+__host__ __device__ __forceinline__ int tl_tile(int ti, int tj) { return (ti * (ti + 1) / 2 + tj) * TL_TILE; }
+__host__ __device__ __forceinline__ int tl_idx(int i, int j) { return tl_tile(i >> 4, j >> 4) + (j & 15) * TL_LD + (i & 15); }   // j <= i
+
+// zero fill with an identity padding diagonal (rows / columns >= n of the diagonal tiles); all threads
+__device__ __forceinline__ void tl_clear(double *A, int n, int nrows) {
+    const int T = tl_tile_rows(nrows), total = T * (T + 1) / 2 * TL_TILE;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) A[e] = 0.0;
+    __syncthreads();
+    for (int i = n + threadIdx.x; i < 16 * T; i += blockDim.x) A[tl_idx(i, i)] = 1.0;
+}
+
+// Wavefront 0.  Factors the diagonal tile `tile` (in place: L in the lower triangle), leaves the block's inverse in Dinv (for the
+// panel product) and, transposed, in the tile's upper triangle + dinv16 (for the back-substitution).  nb: rows of the block that are
+// matrix rows; rows nb.. (a right-hand-side row, padding) take part in the column operations but are never pivots.
+__device__ __forceinline__ bool tl_diag_wave(double *tile, int nb, double (*Dinv)[CH_NB + 1], double *dinv16, int lane,
+                                             long long *dprof = nullptr) {
+#ifdef XRHIP_KPROF
+    long long t_dg = wall_clock64();
+#endif
+    const int l16 = lane & 15;
+    const bool is_row = lane < 16, is_inv = lane >= 16 && lane < 32;
+    // lanes 0-15: X[k] = row l16 of the block (lower triangle); lanes 16-31: X[k] = delta(k, l16), the running forward substitution
+    // of unit vector l16 (column l16 of the inverse once divided through)
+    double X[CH_NB];
+#pragma unroll
+    for (int k = 0; k < CH_NB; ++k) {
+        const double v = tile[k * TL_LD + l16];
+        X[k] = is_row ? (k <= l16 ? v : 0.0) : ((k == l16) ? 1.0 : 0.0);
+    }
+    DGPROF(4);   // block load
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) {
+        double dcc = lane_bcast(X[c], c);
+        if (c >= nb) dcc = 1.0;   // not a pivot: the row only rides along
+        if (!(dcc > 0.0) || !isfinite(dcc)) {
+            ok = false;
+            dcc = 1.0;
+        }
+        double dd, hh;
+        {   // sqrt(d) and 1/sqrt(d): v_rsq_f64 + two coupled Newton steps (see chol_diag_wave_t)
+            const double r0 = __builtin_amdgcn_rsq(dcc);
+            dd = dcc * r0;
+            hh = 0.5 * r0;
+            double e = fma(-hh, dd, 0.5);
+            dd = fma(dd, e, dd);
+            hh = fma(hh, e, hh);
+            e = fma(-hh, dd, 0.5);
+            dd = fma(dd, e, dd);
+            hh = fma(hh, e, hh);
+            const double res = fma(-dd, dd, dcc);
+            dd = fma(res, hh, dd);
+        }
+        const double dinv = hh + hh;
+        // row lanes: L[l][c] = x / d (the pivot row itself: d); inverse lanes: Linv[c][m] = acc / d
+        X[c] = (lane == c) ? dd : X[c] * dinv;
+#pragma unroll
+        for (int k = c + 1; k < CH_NB; ++k) {
+            const double lkc = lane_bcast(X[c], k);   // L[k][c] (held by row lane k)
+            X[k] -= X[c] * lkc;                        // rows: A[l][k] -= L[l][c] L[k][c];  inverse: acc[k] -= Linv[c][m] L[k][c]
+        }
+    }
+    DGPROF(5);   // factorisation + inverse
+    // write-back.  Row lane l: L[l][k], k <= l, to (l, k).  Inverse lane m (column m of the inverse, X[r] = Linv[r][m], r >= m): Dinv[r][m]
+    // for the panel product; transposed into the strictly upper triangle, (m, r) for r > m; the diagonal to dinv16.
+    double *dummy = &Dinv[0][CH_NB];   // padding column: a harmless target for lanes that have nothing to store
+#pragma unroll
+    for (int k = 0; k < CH_NB; ++k) {
+        double *dst = dummy;
+        if (is_row && k <= l16) dst = tile + k * TL_LD + l16;
+        else if (is_inv) dst = &Dinv[k][l16];
+        *dst = X[k];
+    }
+#pragma unroll
+    for (int r = 1; r < CH_NB; ++r) {
+        double *dst = dummy;
+        if (is_inv && r > l16) dst = tile + r * TL_LD + l16;
+        *dst = X[r];
+    }
+    {
+        // the diagonal of the inverse: lane 16 + m holds it in X[m] (register index = lane index): select without dynamic indexing
+        double dgl = 0.0;
+#pragma unroll
+        for (int k = 0; k < CH_NB; ++k) dgl = (k == l16) ? X[k] : dgl;
+        if (is_inv) dinv16[l16] = dgl;
+    }
+    DGPROF(6);   // write-back
+    return ok;
+}
+
+// tile (ti, tj) -= P_ti P_tj^T with the panel tiles of tile column tc; computed as the TRANSPOSED product (operands swapped) so that
+// the accumulator's lane layout, D[(lane >> 4) + 4 r][lane & 15], is a column-major store
+__device__ __forceinline__ void tl_trailing_tile(double *A, int tc, int ti, int tj, int r16, int q) {
+    const double *pi = A + tl_tile(ti, tc) + r16, *pj = A + tl_tile(tj, tc) + r16;
+    double *out = A + tl_tile(ti, tj) + r16;
+    chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int kc = (4 * s4 + q) * TL_LD;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[kc], pi[kc], acc, 0, 0, 0);   // D'[j][i] = sum_k P_tj[j][k] P_ti[i][k]
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(q + 4 * r) * TL_LD] -= acc[r];   // element (row r16, column q + 4 r)
+}
+
+// In-place blocked Cholesky in the tiled layout; rows n .. nrows-1 ride along as right-hand sides.  dinv: [tile rows][16].
+// All threads must call; returns false (uniformly) on a non-positive pivot.  `side`: see chol_blocked.
+template <class Side = CholNoSide>
+__device__ __forceinline__ bool tl_chol(double *A, int n, int nrows, double (*Dinv)[CH_NB + 1], double *dinv, int *s_fail,
+                                        long long *prof = nullptr, Side side = Side()) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int T = tl_tile_rows(nrows), Tm = tl_tile_rows(n);
+#ifdef XRHIP_KPROF
+    long long t_prev = wall_clock64();
+#endif
+    if (tid == 0) *s_fail = 0;
+    __syncthreads();
+    if (n > 0 && wave == 0) {
+        if (!tl_diag_wave(A + tl_tile(0, 0), min(CH_NB, n), Dinv, dinv, lane) && lane == 0) *s_fail = 1;
+    } else if (wave == 1) {
+        side();
+    }
+    __syncthreads();
+    CHPROF(0);
+    if (*s_fail) return false;
+    for (int j = 0; j < Tm; ++j) {
+        if (j + 1 >= T) break;   // nothing below this block
+        // ---- panel: X = P Linv^T for the tile rows below, as X^T = Linv P^T (column-major store of the accumulator)
+        for (int t = j + 1 + wave; t < T; t += nw) {
+            double *pt = A + tl_tile(t, j) + r16;
+            chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int kcol = 4 * s4 + q;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dinv[r16][kcol], pt[kcol * TL_LD], acc, 0, 0, 0);   // D'[c][i] = sum_k Linv[c][k] P[i][k]
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // every lane has read the tile before anybody overwrites it
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pt[(q + 4 * r) * TL_LD] = acc[r];   // element (row r16, column q + 4 r)
+        }
+        __syncthreads();
+        CHPROF(1);
+        // ---- trailing update over the tiles (ti, tj), j < tj <= ti < T, tj < Tm; wavefront 0 takes the next diagonal tile first and
+        // factors it while the others finish (one panel of look-ahead)
+        const bool has_next = j + 1 < Tm;
+        const bool look = has_next && nw > 1;
+        if (look && wave == 0) {
+            tl_trailing_tile(A, j, j + 1, j + 1, r16, q);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!tl_diag_wave(A + tl_tile(j + 1, j + 1), min(CH_NB, n - 16 * (j + 1)), Dinv, dinv + 16 * (j + 1), lane, prof) && lane == 0)
+                *s_fail = 1;
+        } else {
+            const int workers = look ? nw - 1 : nw, me = look ? wave - 1 : wave;
+            int t = 0;
+            for (int ti = j + 1; ti < T; ++ti)
+                for (int tj = j + 1; tj <= ti && tj < Tm; ++tj) {
+                    if (look && ti == j + 1) continue;   // (j + 1, j + 1): wavefront 0's
+                    if (t++ % workers != me) continue;
+                    tl_trailing_tile(A, j, ti, tj, r16, q);
+                }
+        }
+        __syncthreads();
+        if (has_next && !look) {
+            if (!tl_diag_wave(A + tl_tile(j + 1, j + 1), min(CH_NB, n - 16 * (j + 1)), Dinv, dinv + 16 * (j + 1), lane) && lane == 0) *s_fail = 1;
+            __syncthreads();
+        }
+        CHPROF(2);
+        if (*s_fail) return false;
+    }
+    return true;
+}
+
+// y <- L^-T y with the factor and the block inverses tl_chol left behind.  y: a vector of 16 * tile_rows(n) doubles in LDS whose
+// entries >= n are ZERO.  All threads must call.
+__device__ __forceinline__ void tl_trsv_t(const double *A, int n, const double *dinv, double *y) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int Tm = tl_tile_rows(n);
+    for (int j = Tm - 1; j >= 0; --j) {
+        // x_r = sum_{c >= r} Linv[c][r] y_c : the diagonal from dinv, the rest from the upper triangle of the tile, (r, c) = Linv[c][r]
+        double xr = 0.0;
+        if (tid < 16) {
+            const double *tile = A + tl_tile(j, j) + tid;
+            const double *yj = y + 16 * j;
+            xr = dinv[16 * j + tid] * yj[tid];
+#pragma unroll
+            for (int c = 1; c < 16; ++c) xr += (c > tid ? tile[c * TL_LD] : 0.0) * yj[c];
+        }
+        __syncthreads();
+        if (tid < 16) y[16 * j + tid] = xr;
+        __syncthreads();
+        // y_i -= sum_c L[16 j + c][i] x_c for the rows above: thread i reads element (c, i & 15) of tile (j, i >> 4), c = 0 .. 15
+        for (int i = tid; i < 16 * j; i += nt) {
+            const double *col = A + tl_tile(j, i >> 4) + (i & 15) * TL_LD;
+            const double *xj = y + 16 * j;
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) s += col[c] * xj[c];
+            y[i] -= s;
+        }
+        __syncthreads();
+    }
+}
+
 }   // namespace xrhip
