@@ -464,12 +464,18 @@ static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, cons
 // frame step of the back-substitution); systems whose triangle does not fit `limit` are factored in the global
 // buffer Sred instead
 static int solve_lds(const BaDims &d, size_t limit, size_t *bytes, int *use_lds) {
+    static const bool no_tiled = std::getenv("XRHIP_NO_TILED") != nullptr;   // development switch (A/B, parity)
     const size_t tri = (size_t)(d.na + 1) * (d.na + 2) / 2;
+    const size_t tiled = (size_t)tl_doubles(d.na + 1) + 32 * (size_t)tl_tile_rows(d.na + 1);   // tiles + L^-1 rhs + inverse diagonals
     const size_t aux = (size_t)d.PF;
-    size_t lds = sizeof(double) * std::max(tri, aux);
-    *use_lds = 1;
+    size_t lds = sizeof(double) * std::max(tiled, aux);
+    *use_lds = 2;   // tiled layout (dense_lds.hip.h, round 3)
+    if (no_tiled || lds > limit) {
+        lds = sizeof(double) * std::max(tri, aux);
+        *use_lds = 1;   // packed triangle in LDS
+    }
     if (lds > limit) {
-        *use_lds = 0;
+        *use_lds = 0;   // packed triangle in the global buffer Sred
         lds = sizeof(double) * aux;
     }
     *bytes = lds;

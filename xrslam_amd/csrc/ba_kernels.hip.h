@@ -1022,7 +1022,88 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
         __syncthreads();
         return true;
     };
-    if (use_lds) {
+    // use_lds == 2: the tiled layout of dense_lds.hip.h (bank-conflict-free 16x16 tiles, block inverses kept for the
+    // back-substitution).  The reduced system arrives as a packed triangle in Sred; it is dealt to the tiles by wavefront -- lane
+    // (column c = lane & 15, row rr + 4 pass): sixteen lanes read 128 contiguous bytes of one row.
+    auto factor_stage_tiled = [&](double *A) __attribute__((always_inline)) -> bool {
+        const int nrows = na + 1, T = tl_tile_rows(nrows);
+        double *yv = A + tl_doubles(nrows), *dinv = yv + 16 * T;
+        const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6, cc = lane & 15, rr = lane >> 4;
+        const int n_tiles = T * (T + 1) / 2;
+        const double *src = p.Sred;
+        KPROF(0);
+        // the right-hand side row sp (gp - W^T (omega gl)): its two-level gathers are issued first and parked in a register
+        double rhs_v = 0.0;
+        if (tid < na) {
+            const int a = p.act_idx[tid];
+            const int fa = a / 15, ka = a - 15 * fa;
+            const double sacc = (d.nla && ka < 6) ? p.wog[6 * fa + ka] : 0.0;
+            rhs_v = (p.gp[a] - sacc) * p.sp[a];
+        }
+        constexpr int TU = 3;   // tiles (4 loads each) in flight per wavefront; loads are unconditional (clamped), selected afterwards
+        for (int t0 = wave; t0 < n_tiles; t0 += TU * nw) {
+            double v[TU][4];
+            int base[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int t = min(t0 + u * nw, n_tiles - 1);
+                int ti = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+                while (ti * (ti + 1) / 2 > t) --ti;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                const int tj = t - ti * (ti + 1) / 2;
+                base[u] = tl_tile(ti, tj) + cc * TL_LD + rr;
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int i = 16 * ti + rr + 4 * ps, j = 16 * tj + cc;
+                    const bool in = i < na && j <= i;
+                    const double x = src[in ? tri_idx(i, j) : 0];
+                    v[u][ps] = in ? x : ((i == j && i >= na) ? 1.0 : 0.0);   // identity padding; zero elsewhere outside the triangle
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TU; ++u)
+                if (t0 + u * nw < n_tiles)
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) A[base[u] + 4 * ps] = v[u][ps];
+        }
+        __syncthreads();
+        if (tid < na) A[tl_idx(na, tid)] = rhs_v;
+        __syncthreads();
+        KPROF(1);
+#ifdef XRHIP_KPROF
+        const bool ok = tl_chol(A, na, nrows, Dblk, dinv, &fail, p.ctl->prof + 24);
+#else
+        const bool ok = tl_chol(A, na, nrows, Dblk, dinv, &fail);
+#endif
+        KPROF(2);
+        if (!ok) {
+            if (tid == 0) c->linear_ok = 0;
+            return false;
+        }
+        for (int i = tid; i < 16 * T; i += nt) yv[i] = i < na ? A[tl_idx(na, i)] : 0.0;   // L^-1 rhs; zero beyond n (tl_trsv_t)
+        __syncthreads();
+        KPROF(3);
+        tl_trsv_t(A, na, dinv, yv);
+        KPROF(4);
+        for (int a = tid; a < n; a += nt) {
+            p.gn[a] = 0.0;
+            p.grad[a] = dof_active(p.fix, a) ? p.gs[a] / p.diagD[a] : 0.0;
+            p.delta[a] = 0.0;
+        }
+        __syncthreads();
+        for (int i = tid; i < na; i += nt) {
+            const int a = p.act_idx[i];
+            const double ya = yv[i];
+            p.gn[a] = -p.diagD[a] * ya;
+            p.delta[a] = ya;
+            if (!isfinite(ya)) bad = 1;
+        }
+        __syncthreads();
+        return true;
+    };
+    if (use_lds == 2) {
+        if (!factor_stage_tiled(work)) return;
+    } else if (use_lds) {
         if (!factor_stage(work)) return;
     } else {
         if (!factor_stage(static_cast<double *>(p.Sred))) return;
