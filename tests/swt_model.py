@@ -61,3 +61,67 @@ class SwtModel:
             for i in range(len(subs) // 3, 0, -1):
                 for j in range(i * 3 - 1, (i - 1) * 3, -1):
                     del subs[j - 1]
+
+
+# ------------------------------------------------------------------------------------------------ landmark decisions
+# track_landmark (core/sliding_window_tracker.cpp:225-245 -> map/track.cpp:46-76, 97-101, geometry/stereo.h:84-94) and the
+# landmark sweep after the window solve (:325-357), restated with numpy from the reference; fed with the observations the C++
+# tracker logged (XRSLAM_AMD_DUMP_SWT: camera pose q xyzw, p; bearing; keyframe flag; fx fy cx cy -- in the track's order).
+import numpy as np  # noqa: E402
+
+
+def _rot(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def triangulate(obs):
+    """Track::triangulate: DLT over every observation, then the cheirality test q_z * h_w > 0 in every view.
+    Returns the point or None."""
+    A, Ps = [], []
+    for o in obs:
+        R = _rot(o[:4]).T                                 # camera-from-world
+        P = np.hstack([R, (-R @ np.array(o[4:7])).reshape(3, 1)])
+        z = o[7:10]
+        A.append(z[0] * P[2] - z[2] * P[0])
+        A.append(z[1] * P[2] - z[2] * P[1])
+        Ps.append(P)
+    h = np.linalg.svd(np.array(A))[2][-1]                 # right singular vector of the smallest singular value
+    for P in Ps:
+        if not (P[2] @ h) * h[3] > 0:
+            return None
+    return h[:3] / h[3]
+
+
+def anchor_inv_depth(obs, p):
+    """Track::set_landmark_point: the inverse distance from the track's first observation."""
+    o = obs[0]
+    return 1.0 / np.linalg.norm(_rot(o[:4]).T @ (p - np.array(o[4:7])))
+
+
+def landmark_point(obs, inv_depth):
+    """Track::get_landmark_point."""
+    o = obs[0]
+    return _rot(o[:4]) @ np.array(o[7:10]) / inv_depth + np.array(o[4:7])
+
+
+def landmark_is_valid(obs, inv_depth):
+    """The sweep of refine_window over a triangulated track: depth in (1e-3, 50] in every KEYFRAME that sees it, and a mean
+    reprojection error below 3 pixels over those keyframes."""
+    x = landmark_point(obs, inv_depth)
+    rpe, cnt = 0.0, 0.0
+    for o in obs:
+        if not o[10]:
+            continue
+        y = _rot(o[:4]).T @ (x - np.array(o[4:7]))
+        if y[2] <= 1.0e-3 or y[2] > 50:
+            return False
+        fx, fy, cx, cy = o[11:15]
+        z = o[7:10]
+        a = np.array([y[0] / y[2] * fx + cx, y[1] / y[2] * fy + cy])
+        b = np.array([z[0] / z[2] * fx + cx, z[1] / z[2] * fy + cy])
+        rpe += np.linalg.norm(a - b)
+        cnt += 1.0
+    return rpe / max(cnt, 1.0) < 3.0

@@ -165,3 +165,52 @@ def test_mirror_frame_links_match_an_independent_model(tmp_path):
             n_links += len(got)
     assert n_mirror >= 60 and n_links >= 60 * 80, (n_mirror, n_links)
     assert n_created >= 150 and n_continued >= 40 * 80, (n_created, n_continued)
+
+
+def test_landmark_decisions_match_an_independent_model(tmp_path):
+    """track_landmark and the landmark sweep of refine_window (core/sliding_window_tracker.cpp:225-245, 323-357; map/track.cpp:46-101),
+    so far read but not tested.  The C++ pipeline logs, for every track it triangulates or sweeps, the
+    observations the decision looks at and what it decided; tests/swt_model.py restates both decisions from the reference with
+    numpy.  Same accept / reject for every triangulation, the same anchored inverse depth, the same validity verdict for every
+    landmark after every window solve (the stream's own tracking errors and short baselines produce the rejections)."""
+    if not os.path.exists(ORACLE_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    from tests import swt_model as sm
+    log = str(tmp_path / "swt.jsonl")
+    os.environ["XRSLAM_AMD_DUMP_SWT"] = log
+    try:
+        seq = scene.make_sequence(n_frames=90, seed=2)
+        s = runner.Session(ORACLE_LIB, seq, slam_yaml=SLAM)
+        while s.step():
+            assert not s.error(), s.error()
+        s.flush()
+        s.close()
+    finally:
+        del os.environ["XRSLAM_AMD_DUMP_SWT"]
+    n_tri = n_tri_rejected = n_cull = n_invalid = n_untri = 0
+    for ln in open(log):
+        r = json.loads(ln)
+        if "triangulate" in r:
+            obs = r["obs"]
+            p = sm.triangulate(obs)
+            assert (p is not None) == bool(r["ok"]), "track %d at frame %d: triangulation verdict differs" % (r["track"], r["triangulate"])
+            if p is None:
+                assert r["inv_depth"] == -1.0
+                n_tri_rejected += 1
+            else:
+                np.testing.assert_allclose(sm.anchor_inv_depth(obs, p), r["inv_depth"], rtol=1e-7)
+            n_tri += 1
+        elif "cull" in r:
+            if r["triangulated"]:
+                valid = sm.landmark_is_valid(r["obs"], r["inv_depth"])
+                assert valid == bool(r["valid"]), "track %d after the solve of frame %d: validity differs" % (r["track"], r["cull"])
+                assert r["inv_depth_after"] == r["inv_depth"]
+                n_invalid += not valid
+                n_cull += 1
+            else:
+                assert r["inv_depth_after"] == -1.0      # not triangulated: the inverse depth is reset (:351-353)
+                n_untri += 1
+    print("triangulations %d (%d rejected), swept landmarks %d (%d invalid), untriangulated %d" % (n_tri, n_tri_rejected, n_cull, n_invalid, n_untri))
+    assert n_tri >= 200 and n_cull >= 2000, (n_tri, n_cull)
+    assert n_tri_rejected + n_invalid >= 1, (n_tri_rejected, n_invalid)   # the stream exercised a rejection somewhere

@@ -1453,12 +1453,34 @@ class SlidingWindowTracker {
         return false;
     }
 
+    // XRSLAM_AMD_DUMP_SWT: what a landmark decision looked at -- every observation of the track as (camera pose q xyzw, p; bearing;
+    // keyframe flag; fx fy cx cy), in the track's own order (the first one anchors the inverse depth); tests/swt_model.py
+    static void log_track_observations(FILE *fp, const Track *t) {
+        std::fprintf(fp, "\"obs\": [");
+        bool first = true;
+        for (const auto &[f, ki] : t->keypoint_refs) {
+            const PoseState pose = f->get_pose(f->camera);
+            const V3 z = f->get_keypoint(ki);
+            std::fprintf(fp, "%s[%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %d, %.17g, %.17g, %.17g, %.17g]",
+                         first ? "" : ", ", pose.q.x, pose.q.y, pose.q.z, pose.q.w, pose.p.x, pose.p.y, pose.p.z, z.x, z.y, z.z,
+                         f->tag(FT_KEYFRAME) ? 1 : 0, f->K.fx, f->K.fy, f->K.cx, f->K.cy);
+            first = false;
+        }
+        std::fprintf(fp, "]");
+    }
     void track_landmark() {   // :225-245
         WallTimer sc_t(P_.times.scope[SC_TRACK_LANDMARK]);
         Frame *nf = map->get_frame(map->frame_num() - 1);
+        const bool log = P_.swt_log.enabled();
         for (size_t k = 0; k < nf->keypoint_num(); ++k) {
             if (Track *t = nf->get_track(k)) {
                 if (!t->tag(TT_TRIANGULATED)) {
+                    std::unique_lock<std::mutex> log_lock(P_.swt_log.mu, std::defer_lock);
+                    if (log) {   // the inputs first: set_landmark_point does not move them, but keep the record self-contained
+                        log_lock.lock();
+                        std::fprintf(P_.swt_log.fp, "{\"triangulate\": %zu, \"track\": %zu, ", nf->id, t->id);
+                        log_track_observations(P_.swt_log.fp, t);
+                    }
                     if (auto p = t->triangulate()) {
                         t->set_landmark_point(p.value());
                         t->tag(TT_TRIANGULATED) = true;
@@ -1468,6 +1490,10 @@ class SlidingWindowTracker {
                         t->landmark.inv_depth = -1.0;
                         t->tag(TT_TRIANGULATED) = false;
                         t->tag(TT_VALID) = false;
+                    }
+                    if (log) {
+                        std::fprintf(P_.swt_log.fp, ", \"ok\": %d, \"inv_depth\": %.17g}\n", t->tag(TT_TRIANGULATED) ? 1 : 0, t->landmark.inv_depth);
+                        std::fflush(P_.swt_log.fp);
                     }
                 }
             }
@@ -1525,8 +1551,25 @@ class SlidingWindowTracker {
         }
         P_.integrate_batch_end();
         b.solve();
+        const bool log_cull = P_.swt_log.enabled();
         for (size_t k = 0; k < map->track_num(); ++k) {
             Track *t = map->get_track(k);
+            std::unique_lock<std::mutex> log_lock(P_.swt_log.mu, std::defer_lock);
+            if (log_cull) {   // the landmark sweep after the window solve (:325-357): inputs, then the verdict below
+                log_lock.lock();
+                std::fprintf(P_.swt_log.fp, "{\"cull\": %zu, \"track\": %zu, \"triangulated\": %d, \"inv_depth\": %.17g, ",
+                             map->get_frame(map->frame_num() - 1)->id, t->id, t->tag(TT_TRIANGULATED) ? 1 : 0, t->landmark.inv_depth);
+                log_track_observations(P_.swt_log.fp, t);
+            }
+            struct Verdict {   // written when the track's branch below is done
+                FILE *fp;
+                Track *t;
+                ~Verdict() {
+                    if (!fp) return;
+                    std::fprintf(fp, ", \"valid\": %d, \"inv_depth_after\": %.17g}\n", t->tag(TT_VALID) ? 1 : 0, t->landmark.inv_depth);
+                    std::fflush(fp);
+                }
+            } verdict{log_cull ? P_.swt_log.fp : nullptr, t};
             if (t->tag(TT_TRIANGULATED)) {
                 bool valid = true;
                 V3 x = t->get_landmark_point();
