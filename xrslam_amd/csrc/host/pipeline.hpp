@@ -1557,8 +1557,10 @@ class SlidingWindowTracker {
             std::unique_lock<std::mutex> log_lock(P_.swt_log.mu, std::defer_lock);
             if (log_cull) {   // the landmark sweep after the window solve (:325-357): inputs, then the verdict below
                 log_lock.lock();
+                // (a track that never triangulated can carry a NaN inverse depth: JSON has no NaN, the log says -1 like the reset below)
                 std::fprintf(P_.swt_log.fp, "{\"cull\": %zu, \"track\": %zu, \"triangulated\": %d, \"inv_depth\": %.17g, ",
-                             map->get_frame(map->frame_num() - 1)->id, t->id, t->tag(TT_TRIANGULATED) ? 1 : 0, t->landmark.inv_depth);
+                             map->get_frame(map->frame_num() - 1)->id, t->id, t->tag(TT_TRIANGULATED) ? 1 : 0,
+                             std::isfinite(t->landmark.inv_depth) ? t->landmark.inv_depth : -1.0);
                 log_track_observations(P_.swt_log.fp, t);
             }
             struct Verdict {   // written when the track's branch below is done
