@@ -139,7 +139,45 @@ def precision_study():
                   "mfma_frac_of_peak": round(flops / (ms[m] * 1e-3) / 1e12 / peak[m], 6),
                   "product_rel_error": float("%.3e" % (np.abs(T[m] - T["f64"]).max() / np.abs(T["f64"]).max())),
                   "gauss_newton_step_rel_error": float("%.3e" % (np.linalg.norm(dm - d64) / np.linalg.norm(d64)))}
+    out["full_solve"] = precision_study_full_solve(pd)
     return out
+
+
+def precision_study_full_solve(pd):
+    """Config 5 as written -- "fp32 vs bf16 BA *solve*": the WHOLE frozen S3 window solve (21 keyframes, 1268 landmarks, 10 466
+    observations, 30-iteration cap) with the Schur contraction of every linearisation in f64 (the product), f32 and bf16 matrix-core
+    operands (xrhip_ba_debug_set_schur_precision): final states against the f64 solve, iterations / accepted steps / termination, cost."""
+    from xrslam_amd import ba
+    ctx = ba.BaContext(max_frames=32, max_landmarks=2048, max_obs=16384)
+    res, ref = {}, None
+    try:
+        for mode, name in ((0, "f64"), (1, "f32"), (2, "bf16")):
+            ctx.set_schur_precision(mode)
+            b = pd.copy()
+            sm = ctx.solve(b)
+            ms = []
+            for _ in range(5):
+                bb = pd.copy()
+                ms.append(ctx.solve(bb).ms_solve)
+            pos, dep = b.frame_state[:, 4:7].copy(), b.inv_depth.copy()
+            q = b.frame_state[:, 0:4].copy()
+            if ref is None:
+                ref = (pos, dep, q, b.frame_state.copy())
+            row = {"iterations": int(sm.iterations), "accepted_steps": int(sm.successful_steps), "termination": int(sm.termination),
+                   "final_cost": float("%.10g" % sm.final_cost), "ms_per_solve": round(float(np.median(ms)), 4)}
+            if mode:
+                row["position_rel_error"] = float("%.3e" % (np.linalg.norm(pos - ref[0]) / np.linalg.norm(ref[0])))
+                row["position_max_abs_error_m"] = float("%.3e" % np.abs(pos - ref[0]).max())
+                row["rotation_max_error_rad"] = float("%.3e" % (2.0 * np.arcsin(np.clip(np.linalg.norm(
+                    q[:, :3] * ref[2][:, 3:4] - ref[2][:, :3] * q[:, 3:4] + np.cross(q[:, :3], ref[2][:, :3]), axis=1), 0, 1)).max()))
+                row["inv_depth_rel_error"] = float("%.3e" % (np.linalg.norm(dep - ref[1]) / np.linalg.norm(ref[1])))
+                row["state_rel_error"] = float("%.3e" % (np.linalg.norm(b.frame_state - ref[3]) / np.linalg.norm(ref[3])))
+            res[name] = row
+    finally:
+        ctx.set_schur_precision(0)
+        ctx.close()
+    res["tolerance"] = "north_star: 1e-4 relative on the states"
+    return res
 
 
 def bench_s4(args, out_common):

@@ -301,6 +301,9 @@ int xrhip_ba_preintegrate_after_solve(xrhip_ba *ctx, const double *samples, cons
 int xrhip_ba_debug_linearize(xrhip_ba *ctx, const xrhip_ba_problem *problem, double *H, double *g, double *hll,
                              double *gl, double *W, double *cost);
 int xrhip_ba_debug_schur(xrhip_ba *ctx, const double *W, const double *w, int L, int P, double *out);
+/* study aid (BASELINE.json config 5, "fp32 vs bf16 BA solve"): mode 1 / 2 run the Schur contraction of the following solves on this
+ * context with f32 / bf16 matrix-core operands; mode 0 (the default, and what the product always uses) is f64. */
+int xrhip_ba_debug_set_schur_precision(xrhip_ba *ctx, int mode);
 /* BASELINE config 5's precision study on the device (csrc/study_api.hip; not part of the reference interface, never called by
  * the product path): T = W^T diag(w) W for W [L][P] row-major, w [L] >= 0, computed by the same tiling with f64, f32 and
  * bf16 (f32 accumulation) matrix-core operands; out64 / out32 / out16: [P][P]; ms_per_launch[3]: average of `reps` launches of

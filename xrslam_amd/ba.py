@@ -36,6 +36,8 @@ def configure(lib):
         lib.xrhip_ba_debug_linearize.argtypes = [vp, C.POINTER(abi.BaProblem), vp, vp, vp, vp, vp, vp]
     if hasattr(lib, "xrhip_ba_debug_schur"):
         lib.xrhip_ba_debug_schur.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    if hasattr(lib, "xrhip_ba_debug_set_schur_precision"):
+        lib.xrhip_ba_debug_set_schur_precision.argtypes = [vp, C.c_int]
     return lib
 
 
@@ -151,6 +153,10 @@ class BaContext:
         cost = C.c_double()
         check(self._lib.xrhip_ba_debug_linearize(self._h, C.byref(s), _p(H), _p(g), _p(hll), _p(gl), _p(W), C.byref(cost)))
         return dict(H=H, g=g, hll=hll[:Ln], gl=gl[:Ln], W=W[:Ln], cost=cost.value)
+
+    def set_schur_precision(self, mode):
+        """Study aid (BASELINE config 5): 0 = f64 (product), 1 = f32, 2 = bf16 operands in the Schur contraction of the solves that follow."""
+        check(self._lib.xrhip_ba_debug_set_schur_precision(self._h, int(mode)))
 
     def debug_schur(self, W, w):
         W = np.ascontiguousarray(W, np.float64)

@@ -87,6 +87,7 @@ struct xrhip_ba {
     double *h_out = nullptr;  // pinned readback (states + depths)
     size_t h_out_cap = 0;
     int lds_limit = 150 * 1024;
+    int schur_mode = 0;                // study only (xrhip_ba_debug_set_schur_precision): 1 = f32, 2 = bf16 Schur contraction
     // last linearisation (debug/parity access)
     BaDims dims{};
     BaPtrs ptrs{};
@@ -163,6 +164,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     d.np = 15 * d.NP;
     d.NV = d.n + d.L;
     d.robust = 1;
+    d.schur_mode = c->schur_mode;
     const int F = d.F, L = d.L, M = d.M, MR = d.MR, NI = d.NI, NP = d.NP, np = d.np, n = d.n;
 
     // ---- host-side index structures
@@ -918,6 +920,14 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     return XRHIP_OK;
 }
 
+/* study aid (BASELINE config 5, "fp32 vs bf16 BA solve"): the Schur contraction of every following solve on this context runs with f32
+ * (mode 1) or bf16 (mode 2) matrix-core operands instead of f64 (mode 0, what the product always uses). */
+int xrhip_ba_debug_set_schur_precision(xrhip_ba *c, int mode) {
+    if (!c || mode < 0 || mode > 2) return xr_fail(XRHIP_EINVAL, "xrhip_ba_debug_set_schur_precision: bad arguments");
+    c->schur_mode = mode;
+    return XRHIP_OK;
+}
+
 /* parity/testing aid: linearise the problem at its current states (no solve) and return the unreduced
  * normal equations in "frame-major" layout: H [15F x 15F], g [15F], hll [L], gl [L], W [L x 6F] (row l =
  * cross terms of landmark l with the pose dofs of every frame), cost.  Constant blocks have zero rows. */
@@ -1074,6 +1084,7 @@ static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     rc = stage_problem(c, &P, d, p, cam, imu);
     if (rc) return rc;
     d.robust = 0;
+    d.schur_mode = 0;
     const int N = d.n, R = N - 15;
     if (R > 512) return xr_fail(XRHIP_EINVAL, "xrhip_ba_marginalize: window too large");   // before anything is queued
     const size_t D8 = sizeof(double);

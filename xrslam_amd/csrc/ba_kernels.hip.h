@@ -82,6 +82,8 @@ struct BaDims {
     int lm_rows;        // landmark rows kb_landmark_vision builds: Lp, or 0 when the solver has no free landmark
     int nfree;          // frames with a free pose or motion block
     int nffp;           // reprojection factors whose target AND reference pose are free (off-diagonal reprojection blocks)
+    int schur_mode;     // 0 (always, in the product): f64 Schur contraction; 1 / 2: f32 / bf16 matrix-core operands -- BASELINE config 5's
+                        // precision study only (xrhip_ba_debug_set_schur_precision)
 };
 
 // Pointers of the argument blocks.  Kernels that receive BaPtrs by value see global-address-space pointers (the
@@ -770,16 +772,55 @@ __device__ __forceinline__ void schur_tile_block(const BaDims &d, const BaPtrs &
     const int kq = d.Lp / 4;   // landmarks per wavefront (multiple of 4)
     const int k0 = wave * kq;
     const int i = lane & 15, kk = lane >> 4;
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k = k0; k < k0 + kq; k += 4) {
-        const int l = k + kk;
-        const double w = (l < d.L) ? p.omega[l] : 0.0;
-        const double a = p.Wt[(size_t)l * d.PF + 16 * ti + i];
-        const double b = p.Wt[(size_t)l * d.PF + 16 * tj + i] * w;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
+    if (d.schur_mode == 0) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k = k0; k < k0 + kq; k += 4) {
+            const int l = k + kk;
+            const double w = (l < d.L) ? p.omega[l] : 0.0;
+            const double a = p.Wt[(size_t)l * d.PF + 16 * ti + i];
+            const double b = p.Wt[(size_t)l * d.PF + 16 * tj + i] * w;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][(kk + 4 * r) * 16 + i] = acc[r];
+        for (int r = 0; r < 4; ++r) red[wave][(kk + 4 * r) * 16 + i] = acc[r];
+    } else {
+        // BASELINE config 5's study ("fp32 vs bf16 BA solve"): the same contraction with f32 operands and accumulation
+        // (v_mfma_f32_16x16x4_f32) or bf16 operands with f32 accumulation (v_mfma_f32_16x16x16_bf16) inside a real solve.  Accumulator
+        // layout of both: register r of lane (i, kk) is element (row 4 kk + r, column i).
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        typedef short s4_t __attribute__((ext_vector_type(4)));
+        f4_t acc = {0.f, 0.f, 0.f, 0.f};
+        auto bf16 = [](float f) -> short {   // round to nearest even
+            unsigned u = __float_as_uint(f);
+            u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+            return (short)u;
+        };
+        if (d.schur_mode == 1) {
+            for (int k = k0; k < k0 + kq; k += 4) {
+                const int l = k + kk;
+                const double w = (l < d.L) ? p.omega[l] : 0.0;
+                const float a = (float)p.Wt[(size_t)l * d.PF + 16 * ti + i];
+                const float b = (float)(p.Wt[(size_t)l * d.PF + 16 * tj + i] * w);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            }
+        } else {
+            for (int k = k0; k < k0 + kq; k += 16) {   // K = 16: lane (i, kk) carries landmarks k + 4 kk .. + 3
+                s4_t a, b;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int l = k + 4 * kk + q;
+                    const bool in = l < k0 + kq;
+                    const double w = (in && l < d.L) ? p.omega[l] : 0.0;
+                    const size_t row = (size_t)(in ? l : k0) * d.PF;
+                    a[q] = in ? bf16((float)p.Wt[row + 16 * ti + i]) : (short)0;
+                    b[q] = in ? bf16((float)(p.Wt[row + 16 * tj + i] * w)) : (short)0;
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(4 * kk + r) * 16 + i] = (double)acc[r];
+    }
     __syncthreads();
     const int e = threadIdx.x;   // 256 elements of the tile
     const double s = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
