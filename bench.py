@@ -291,8 +291,11 @@ def main():
         rendezvous_only(args)
         return
     S = args.sequences_per_gpu
-    if S > 1:   # every instance owns four HIP streams; the runtime multiplexes streams over this many hardware queues
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(4 * S, 24)))
+    if S > 1:
+        # Every instance owns several HIP streams; the runtime multiplexes them over this many hardware queues.  MORE is not better:
+        # measured at 8 sequences (profiles/r03_multi_sequence.md) 8 queues 3590 frames/s, 16: 3528, 24: 2557, 32: 2040, 48: 1438 --
+        # beyond a handful the scheduler time-slices the queues and every kernel stretches (k_pyrdown 4.7 -> 22 us at 24 queues).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank, world = int(os.environ.get("RANK", "0")), int(env_world or "1")
 
     from xrslam_amd.harness import scene

@@ -293,12 +293,12 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     };
     const size_t D8 = sizeof(double);
     const size_t w_cand = carve(D8 * 16 * F * TRY_B), w_dcand = carve(D8 * L * TRY_B);
-    const size_t w_pLam = carve(D8 * (size_t)np * np);
+    const size_t w_pLam = carve(D8 * (size_t)np * np), w_pc0 = carve(D8 * np);
     const size_t w_orec = carve(D8 * OREC * M), w_ocost = carve(D8 * M);
     const size_t w_rrec = carve(D8 * RREC * MR), w_rcost = carve(D8 * MR);
     const size_t w_ir = carve(D8 * 15 * NI), w_iJi = carve(D8 * 225 * NI), w_iJj = carve(D8 * 225 * NI);
     const size_t w_ic = carve(D8 * NI);
-    const size_t w_pr = carve(D8 * np), w_pt = carve(D8 * np), w_pJq = carve(D8 * 9 * NP), w_pc = carve(D8);
+    const size_t w_pr = carve(D8 * np), w_pt = carve(D8 * np), w_pJq = carve(D8 * 9 * NP), w_pc = carve(D8 * (1 + (np + 15) / 16));
     const size_t w_H = carve(D8 * (size_t)n * n), w_g = carve(D8 * n);
     const size_t w_hll = carve(D8 * d.Lp), w_gl = carve(D8 * d.Lp), w_Wt = carve(D8 * (size_t)d.Lp * d.PF);
     const size_t w_sp = carve(D8 * n), w_sl = carve(D8 * d.Lp), w_om = carve(D8 * d.Lp);
@@ -338,6 +338,7 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     p.pinfo = (const double *)(I + o_pi);
     p.plin = (const double *)(I + o_pl);
     p.pLam = (double *)(W + w_pLam);
+    p.pc0 = (double *)(W + w_pc0);
     p.lm_start = (const int *)(I + o_lms);
     p.lm_obs = (const int *)(I + o_lmo);
     p.pair_start = (const int *)(I + o_ps);
@@ -453,7 +454,7 @@ static bool chain(const BaDims &d, size_t lds_limit, size_t *lds_bytes, int *vis
 static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx,
                              double sy, bool for_solver, hipStream_t s_override = nullptr) {
     hipStream_t s = s_override ? s_override : c->stream;
-    hipLaunchKernelGGL(kb_lin_all, dim3(lin_all_blocks(d.M, d.MR, d.NI)), dim3(256), sizeof(double) * std::max(d.np, 1), s, d, p,
+    hipLaunchKernelGGL(kb_lin_all, dim3(lin_all_blocks(d.M, d.MR, d.NI, d.np)), dim3(256), sizeof(double) * std::max(d.np, 1), s, d, p,
                        cam, imu, sx, sy);
     hipLaunchKernelGGL(kb_landmark_vision, dim3(d.lm_rows + d.F * d.F), dim3(64), 0, s, d, p);
     if (for_solver && small_mid(d)) return;   // kb_small_mid (launch_solve_try) assembles what the solve reads
@@ -747,7 +748,7 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     if (!d.nla) d.lm_rows = 0;
     const double sx = P->sqrt_inv_cov[0], sy = P->sqrt_inv_cov[1];
     hipStream_t s = c->stream;
-    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16)), dim3(256), 0, s, d.np, p.pS, p.pLam);
+    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16 + 1)), dim3(256), 0, s, d.np, p.pS, p.pLam, p.pinfo, p.pc0);
     bool done = false, relinearise = true;
     int mode = 1, iter_seen = 0;
     if (use_chain) {   // the whole solve in one launch, LDS-resident (kb_chain)
@@ -942,7 +943,7 @@ int xrhip_ba_debug_linearize(xrhip_ba *c, const xrhip_ba_problem *P, double *H, 
     rc = stage_problem(c, P, d, p, cam, imu);
     if (rc) return rc;
     hipStream_t s = c->stream;
-    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16)), dim3(256), 0, s, d.np, p.pS, p.pLam);
+    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16 + 1)), dim3(256), 0, s, d.np, p.pS, p.pLam, p.pinfo, p.pc0);
     launch_linearize(c, d, p, cam, imu, P->sqrt_inv_cov[0], P->sqrt_inv_cov[1], false);
     XR_HIP(hipGetLastError());
     XR_HIP(hipMemcpyAsync(c->h_ctl, p.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, s));
@@ -1108,7 +1109,7 @@ static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     int *dst = (int *)(W2 + o_st);
     hipStream_t s = c->stream;
     XR_HIP(hipMemsetAsync(dst, 0, sizeof(int) * 8, s));
-    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16)), dim3(256), 0, s, d.np, p.pS, p.pLam);
+    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16 + 1)), dim3(256), 0, s, d.np, p.pS, p.pLam, p.pinfo, p.pc0);
     launch_linearize(c, d, p, cam, imu, M->sqrt_inv_cov[0], M->sqrt_inv_cov[1], false);
     hipLaunchKernelGGL(km_omega, dim3((std::max(d.L, 1) + 255) / 256), dim3(256), 0, s, d, p);
     const int tiles = d.PF / 16;

@@ -121,6 +121,7 @@ struct BaPtrs {
     gptr<const int> prior_frames;
     gptr<const double> pS, pinfo, plin;
     gptr<double> pLam;                    // S^T S
+    gptr<double> pc0;                     // S^T infovec   (both once per solve: kb_prior_lambda)
     // index structures (built on the host)
     gptr<const int> lm_start, lm_obs;    // CSR landmark -> observations
     gptr<const int> pair_start, pair_items;   // CSR (row frame, col frame) -> (obs << 1 | role)
@@ -134,7 +135,7 @@ struct BaPtrs {
     gptr<double> orec, ocost;            // [M][28], [M]
     gptr<double> rrec, rcost;
     gptr<double> imu_r, imu_Ji, imu_Jj, imu_cost;   // [NI][15], [NI][225] x2, [NI]
-    gptr<double> pr, pt, pJq, pcost;   // prior residual [np], S^T r [np], Jr^-1 [NP][9], cost [1]
+    gptr<double> pr, pt, pJq, pcost;   // prior residual [np], S^T r [np], Jr^-1 [NP][9], cost [1 + ceil(np / 16)]: total | per row block
     gptr<double> Hpp, gp;                // [n][n], [n]   unscaled frame Hessian / gradient
     gptr<double> hll, gl, Wt;           // [L], [L], [Lp][PF]
     gptr<double> sp, sl, omega;         // Jacobi scales [n], [L]; Schur weights [L]
@@ -483,6 +484,56 @@ __device__ __forceinline__ double prior_cost_block(const BaDims &d, const BaPtrs
     return 0.5 * block_sum(c, scratch);
 }
 
+// The same linearisation spread over ceil(np / 16) workgroups of 256 (kb_lin_all): the single workgroup above walks the 150 x 150
+// matrix twice with four rows per wavefront in flight and a butterfly per row -- 25 us, the longest block of kb_lin_all by far.
+// Block b owns rows 16 b .. 16 b + 15 of r = S delta + infovec AND of t = S^T r, the latter from the per-solve products
+// Lam = S^T S and c0 = S^T infovec (kb_prior_lambda):  t = Lam delta + c0.  Eight threads per row and matrix (32 dot products of
+// length np per block), three butterfly stages.  Every block recomputes delta (a logmap per prior frame); block 0 also stores the
+// Jr^-1 blocks.  The cost is left as per-block partial sums pcost[1 + b] (sum_cost_block adds them in block order).
+__host__ __device__ __forceinline__ int prior_row_blocks(int np) { return (np + 15) / 16; }
+__device__ __forceinline__ void lin_prior_rows_block(const BaDims &d, const BaPtrs &p, int b, double *sh, double *scratch) {
+    const int tid = threadIdx.x, np = d.np;
+    for (int i = tid; i < d.NP; i += blockDim.x) {
+        double dl[15];
+        M3 Jq;
+        prior_delta(p, i, p.state, dl, &Jq);
+        for (int k = 0; k < 15; ++k) sh[15 * i + k] = dl[k];
+        if (b == 0)
+            for (int k = 0; k < 9; ++k) p.pJq[9 * i + k] = Jq.m[k];
+    }
+    __syncthreads();
+    const int dot = tid >> 3, part = tid & 7;          // 32 dot products: 0-15 rows of S, 16-31 rows of Lam
+    const int row = 16 * b + (dot & 15);
+    const double *M = (dot < 16 ? static_cast<const double *>(p.pS) : static_cast<const double *>(p.pLam)) + (size_t)min(row, np - 1) * np;
+    double s = 0.0;
+    for (int j0 = part; j0 < np; j0 += 64) {            // eight loads in flight
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = M[min(j0 + 8 * u, np - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + 8 * u < np) s += v[u] * sh[j0 + 8 * u];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    double c = 0.0;
+    if (part == 0 && row < np) {
+        if (dot < 16) {
+            const double r = s + p.pinfo[row];
+            p.pr[row] = r;
+            c = r * r;
+        } else {
+            p.pt[row] = s + p.pc0[row];
+        }
+    }
+    c = block_sum(c, scratch);
+    if (tid == 0) {
+        p.pcost[1 + b] = 0.5 * c;
+        if (b == 0) p.pcost[0] = 0.0;
+    }
+}
+
 // block-wide, any workgroup size; sh: np doubles of LDS, scratch: blockDim/64 doubles
 __device__ __forceinline__ void lin_prior_block(const BaDims &d, const BaPtrs &p, double *sh, double *scratch) {
     if (d.NP == 0) {
@@ -497,6 +548,7 @@ __device__ __forceinline__ void lin_prior_block(const BaDims &d, const BaPtrs &p
     }
     const double c = prior_cost_block(d, p, p.state, sh, scratch, p.pr);
     if (threadIdx.x == 0) p.pcost[0] = c;
+    for (int b = threadIdx.x; b < prior_row_blocks(d.np); b += blockDim.x) p.pcost[1 + b] = 0.0;   // (the row-block form's partial sums)
     __syncthreads();
     // t = S^T r  (thread per column: consecutive threads read consecutive addresses; eight rows per round trip)
     for (int j = threadIdx.x; j < d.np; j += blockDim.x) {
@@ -518,9 +570,23 @@ __device__ __forceinline__ void lin_prior_block(const BaDims &d, const BaPtrs &p
 
 // Lam = S^T S (once per solve with a prior) on the f64 matrix cores: one workgroup per 16x16 tile of Lam, the four
 // wavefronts split the contraction (rows of S) and combine in LDS in a fixed order.
-__global__ __launch_bounds__(256) void kb_prior_lambda(int np, const double *__restrict__ S, double *__restrict__ Lam) {
+__global__ __launch_bounds__(256) void kb_prior_lambda(int np, const double *__restrict__ S, double *__restrict__ Lam,
+                                                       const double *__restrict__ info, double *__restrict__ c0) {
     __shared__ double red[4][256];
     const int tiles = (np + 15) / 16;
+    if ((int)blockIdx.x >= tiles * tiles) {   // `tiles` extra blocks: c0 = S^T infovec, sixteen columns each -- thread (column jl, row part):
+        const int jl = threadIdx.x & 15, part = threadIdx.x >> 4, j = 16 * ((int)blockIdx.x - tiles * tiles) + jl;   // rows part, part + 16, ...
+        double s = 0;
+        for (int i = part; i < np; i += 16) s += S[(size_t)i * np + min(j, np - 1)] * info[i];
+        red[0][threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < 16 && j < np) {
+            double t = 0;
+            for (int q = 0; q < 16; ++q) t += red[0][16 * q + jl];
+            c0[j] = t;
+        }
+        return;
+    }
     const int ti = blockIdx.x / tiles, tj = blockIdx.x - ti * tiles;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 15, kk = lane >> 4;
@@ -1248,6 +1314,8 @@ __device__ __forceinline__ void sum_cost_block(const BaDims &d, const BaPtrs &p,
     c = block_sum(c, scratch);
     if (threadIdx.x == 0) {
         c += p.pcost[0];
+        if (d.np)
+            for (int b = 0; b < prior_row_blocks(d.np); ++b) c += p.pcost[1 + b];   // row-block form of the prior (zeros otherwise)
         BaCtl *ctl = p.ctl;
         ctl->x_cost = c;
         if (ctl->first) {
@@ -1755,9 +1823,17 @@ __global__ __launch_bounds__(256) void kb_lin_all(BaDims d, BaPtrs p, Ext cam, E
         lin_imu_block(d, p, imu, blk, scr);
         return;
     }
-    lin_prior_block(d, p, sh, scratch);
+    blk -= nbi;
+    if (d.NP == 0) {
+        if (threadIdx.x == 0) p.pcost[0] = 0.0;
+        return;
+    }
+    lin_prior_rows_block(d, p, blk, sh, scratch);
 }
-__host__ __device__ __forceinline__ int lin_all_blocks(int M, int MR, int NI) { return (M + 255) / 256 + (MR + 255) / 256 + NI + 1; }
+// blocks: [obs | rot | imu (one factor each) | prior: 16 rows each (one block when there is no prior: it clears the cost)]
+__host__ __device__ __forceinline__ int lin_all_blocks(int M, int MR, int NI, int np) {
+    return (M + 255) / 256 + (MR + 255) / 256 + NI + (np ? (np + 15) / 16 : 1);
+}
 
 // per-landmark rows and per-frame-pair reprojection blocks: [Lp landmarks | F*F pairs], one wavefront each
 // (tried: 64 landmarks per block, one THREAD walking a landmark's observation list -- no butterflies, but ~8 dependent
