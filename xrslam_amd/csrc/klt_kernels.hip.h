@@ -58,21 +58,30 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 __global__ __launch_bounds__(256) void k_clahe_lut(const uint8_t *__restrict__ src, int sstride, int w, int h,
                                                    int tw, int th, int tiles_x, int clip, float lut_scale,
                                                    uint8_t *__restrict__ lut) {
-    __shared__ int hist[256];
+    __shared__ int hist[4][256];   // one histogram per wavefront: neighbouring pixels share grey levels, a single one serialises its atomics
     __shared__ int scan[2][256];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wv = tid >> 6;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    hist[tid] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hist[q][tid] = 0;
     __syncthreads();
     const int area = tw * th;
-    for (int i = tid; i < area; i += 256) {
-        int y = i / tw;
-        int x = i - y * tw;
-        int gx = reflect101(tx * tw + x, w), gy = reflect101(ty * th + y, h);
-        atomicAdd(&hist[src[(size_t)gy * sstride + gx]], 1);
+    for (int i0 = tid; i0 < area; i0 += 8 * 256) {   // eight pixel loads in flight per thread, then their (exact, integer) counts
+        int px[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u * 256, area - 1);
+            const int y = i / tw;
+            const int x = i - y * tw;
+            const int gx = reflect101(tx * tw + x, w), gy = reflect101(ty * th + y, h);
+            px[u] = src[(size_t)gy * sstride + gx];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 256 < area) atomicAdd(&hist[wv][px[u]], 1);
     }
     __syncthreads();
-    int hv = hist[tid];
+    int hv = (hist[0][tid] + hist[1][tid]) + (hist[2][tid] + hist[3][tid]);
     if (clip > 0) {
         int excess = hv > clip ? hv - clip : 0;
         if (hv > clip) hv = clip;
@@ -331,21 +340,44 @@ __global__ __launch_bounds__(1024) void k_harris_select(const HarrisCand *__rest
                                                         int capacity, const int *__restrict__ max_key, double quality,
                                                         HarrisCand *top_out, int top_cap, SelectHeader *hdr, int seq) {
     __shared__ unsigned hist[SEL_BINS];
+    __shared__ HarrisCand sorted_buf[SEL_SORT];
     __shared__ unsigned part[64];
     __shared__ int s_bin, s_n;
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef XRHIP_KPROF
+    long long kp[8];
+    int kpn = 0;
+#define SELPROF() do { __syncthreads(); if (tid == 0) kp[kpn] = wall_clock64(); ++kpn; } while (0)
+#else
+#define SELPROF() do { } while (0)
+#endif
+    SELPROF();
     const int nc = min(*count, capacity);
     const float maxv = float_from_key(*max_key);
     const float thr = (float)((double)maxv * quality);
-    const float scale = (maxv > thr) ? (float)SEL_BINS / (maxv - thr) : 0.f;
+    // Bins are spaced LOGARITHMICALLY above the threshold (the bit pattern of a positive float is monotone in its value): the
+    // responses fall off like a power law, so linear bins put most of the ~10^4 candidates into the first few -- thousands of LDS
+    // atomics on the same words, which serialise (that histogram pass was ~25 of this kernel's 34 us).  64 bins per binade.
+    const unsigned thr_bits = __float_as_uint(fmaxf(thr, 1e-30f));
+    auto bin_of = [&](float v) __attribute__((always_inline)) -> int {
+        const unsigned b = __float_as_uint(fmaxf(v, 1e-30f));
+        return b > thr_bits ? (int)min((unsigned)(SEL_BINS - 1), (b - thr_bits) >> 17) : 0;
+    };
     for (int i = tid; i < SEL_BINS; i += 1024) hist[i] = 0;
     if (tid == 0) s_n = 0;
     __syncthreads();
-    for (int i = tid; i < nc; i += 1024) {
-        const int q = min(SEL_BINS - 1, max(0, (int)((cand[i].v - thr) * scale)));
-        atomicAdd(&hist[q], 1u);
+    // (eight candidate loads in flight per thread: with one, each of the ~13 trips of this loop waited out a full L2 round trip --
+    // that, not the atomics, was most of this kernel)
+    for (int i0 = tid; i0 < nc; i0 += 8 * 1024) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = cand[min(i0 + u * 1024, nc - 1)].v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < nc) atomicAdd(&hist[bin_of(v8[u])], 1u);
     }
     __syncthreads();
+    SELPROF();   // 1: histogram
     // boundary = largest bin b with count(bins >= b) >= SEL_K (0 when there are fewer candidates)
     if (tid < 64) {
         unsigned sum = 0;
@@ -353,63 +385,131 @@ __global__ __launch_bounds__(1024) void k_harris_select(const HarrisCand *__rest
         part[tid] = sum;
     }
     __syncthreads();
-    if (tid == 0) {
-        unsigned above = 0;
-        int g = 63;
-        while (g > 0 && above + part[g] < (unsigned)SEL_K) above += part[g--];
-        int b = g * (SEL_BINS / 64) + (SEL_BINS / 64) - 1;
-        while (b > g * (SEL_BINS / 64) && above + hist[b] < (unsigned)SEL_K) above += hist[b--];
-        if (above + hist[b] < (unsigned)SEL_K) b = 0;   // fewer than SEL_K candidates in total: keep all
-        s_bin = b;
+    if (tid < 64) {
+        // two suffix scans over 64 lanes instead of one thread walking up to 128 LDS words: group g = the largest group whose
+        // suffix count reaches SEL_K, then the same inside the group (SEL_BINS / 64 = 64 bins per group)
+        static_assert(SEL_BINS / 64 == 64, "one bin per lane in the second level");
+        auto suffix = [&](unsigned v) __attribute__((always_inline)) -> unsigned {   // sum over lanes >= this one
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_down(v, off);
+                if (lane + off < 64) v += o;
+            }
+            return v;
+        };
+        const unsigned sg = suffix(part[lane]);
+        const unsigned long long mg = __ballot(sg >= (unsigned)SEL_K);
+        int b = 0;                                             // fewer than SEL_K candidates in total: keep all
+        if (mg) {
+            const int g = 63 - __builtin_clzll(mg);
+            const unsigned above = __shfl(sg, g) - __shfl(part[lane], g);   // candidates in the groups above g
+            const unsigned sb = above + suffix(hist[g * 64 + lane]);
+            const unsigned long long mb = __ballot(sb >= (unsigned)SEL_K);
+            b = g * 64 + (mb ? 63 - __builtin_clzll(mb) : 0);
+        }
+        if (lane == 0) s_bin = b;
     }
     __syncthreads();
     const int bin = s_bin;
+    SELPROF();   // 2: boundary
     // the histogram is dead: its LDS now collects the selected candidates (SEL_SORT of them fit)
     HarrisCand *sel = reinterpret_cast<HarrisCand *>(hist);
-    for (int i = tid; i < nc; i += 1024) {
-        const HarrisCand cd = cand[i];
-        const int q = min(SEL_BINS - 1, max(0, (int)((cd.v - thr) * scale)));
-        if (q >= bin) {
-            const int pos = atomicAdd(&s_n, 1);
+    for (int i00 = 0; i00 < nc; i00 += 8 * 1024) {   // uniform trip counts: the ballot below wants whole wavefronts
+        HarrisCand c8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c8[u] = cand[min(i00 + u * 1024 + tid, nc - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+        const int i = i00 + u * 1024 + tid;
+        if (i00 + u * 1024 >= nc) break;
+        HarrisCand cd = c8[u];
+        const bool take = i < nc && bin_of(cd.v) >= bin;
+        // one LDS atomic per wavefront instead of one per selected candidate (a thousand increments of ONE word serialise); the
+        // order inside the selection is irrelevant: it is sorted below, or (unsorted case) the host orders it
+        const unsigned long long m = __ballot(take);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_n, (int)__popcll(m));
+        base = __shfl(base, 0);
+        if (take) {
+            const int pos = base + (int)__popcll(m & ((1ull << lane) - 1ull));
             if (pos < SEL_SORT) sel[pos] = cd;
             else if (pos < top_cap) top_out[pos] = cd;
         }
+      }
     }
     __syncthreads();
+    SELPROF();   // 3: selection
     const int n_top = s_n;
     int sorted = 0;
     if (n_top <= SEL_SORT && n_top <= top_cap) {
-        // bitonic sort into the visiting order of the greedy spacing pass: response descending, then index descending
-        // (the kernel runs while the host digests the tracks, so the sort is free)
-        const int ns = n_top <= 1024 ? 1024 : SEL_SORT;   // sort size: next power of two
-        for (int i = n_top + tid; i < ns; i += 1024) {
-            sel[i].v = -1.0f;   // responses above the threshold are positive: padding sorts last
-            sel[i].idx = -1;
-        }
-        __syncthreads();
-        for (int k = 2; k <= ns; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < ns; i += 1024) {
-                    const int l = i ^ j;
-                    if (l > i) {
-                        const HarrisCand a = sel[i], b = sel[l];
-                        const bool a_first = (a.v > b.v) || (a.v == b.v && a.idx > b.idx);
-                        const bool up = (i & k) == 0;
-                        if (up ? !a_first : a_first) {
-                            sel[i] = b;
-                            sel[l] = a;
+        // Bitonic sort into the visiting order of the greedy spacing pass: response descending, then index descending (a strict total
+        // order: indices are unique).  Up to 1024 candidates (the usual case: SEL_K = 896): ONE element per thread, in registers --
+        // compare-exchange distances below 64 stay inside the wavefront (shuffles), only the 10 stages at distance >= 64 go through
+        // LDS and a workgroup barrier.  The 55-stage network over LDS this replaces was 16 of the kernel's 34 us (in-kernel timers);
+        // counting ranks instead (n_top broadcast reads per thread) measured 90 us.
+        if (n_top <= 1024) {
+            HarrisCand me;
+            me.v = -1.0f;   // responses above the threshold are positive: padding sorts last
+            me.idx = -1;
+            if (tid < n_top) me = sel[tid];
+            __syncthreads();
+            for (int k = 2; k <= 1024; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    HarrisCand other;
+                    if (j < 64) {
+                        other.v = __shfl_xor(me.v, j);
+                        other.idx = __shfl_xor(me.idx, j);
+                    } else {
+                        sorted_buf[tid] = me;
+                        __syncthreads();
+                        other = sorted_buf[tid ^ j];
+                        __syncthreads();
+                    }
+                    const bool me_first = (me.v > other.v) || (me.v == other.v && me.idx > other.idx);
+                    const bool want_first = ((tid & j) == 0) == ((tid & k) == 0);   // the lower slot of an ascending pair keeps the first
+                    if (me_first != want_first) me = other;
+                }
+            sorted_buf[tid] = me;
+        } else {
+            const int ns = SEL_SORT;
+            for (int i = n_top + tid; i < ns; i += 1024) {
+                sel[i].v = -1.0f;
+                sel[i].idx = -1;
+            }
+            __syncthreads();
+            for (int k = 2; k <= ns; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < ns; i += 1024) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const HarrisCand ca = sel[i], cb = sel[l];
+                            const bool a_first = (ca.v > cb.v) || (ca.v == cb.v && ca.idx > cb.idx);
+                            const bool up = (i & k) == 0;
+                            if (up ? !a_first : a_first) {
+                                sel[i] = cb;
+                                sel[l] = ca;
+                            }
                         }
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
-            }
-        for (int i = tid; i < n_top; i += 1024) top_out[i] = sel[i];
+            for (int i = tid; i < n_top; i += 1024) sorted_buf[i] = sel[i];
+        }
+        __syncthreads();
+        for (int i = tid; i < n_top; i += 1024) top_out[i] = sorted_buf[i];
         sorted = 1;
     } else {
         for (int i = tid; i < min(n_top, min(SEL_SORT, top_cap)); i += 1024) top_out[i] = sel[i];
     }
+    SELPROF();   // 4: sort + copy out
     __threadfence_system();
     __syncthreads();
+    SELPROF();   // 5: fence
+#ifdef XRHIP_KPROF
+    if (tid == 0 && (seq & 63) == 0)
+        printf("k_harris_select nc %d n_top %d: hist %lld boundary %lld select %lld sort+out %lld fence %lld (x10 ns)\n", nc, n_top,
+               kp[1] - kp[0], kp[2] - kp[1], kp[3] - kp[2], kp[4] - kp[3], kp[5] - kp[4]);
+#endif
     if (tid == 0) {
         hdr->n_candidates = *count;
         hdr->n_top = n_top;
