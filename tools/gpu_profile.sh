@@ -8,8 +8,8 @@ R="$(cd "$(dirname "$0")/.." && pwd)"
 TAG="${1:?tag}"
 mkdir -p "$R/gpurun_out"
 cd "$R"
-timeout 400 python -m pytest tests -m gpu -x -q > "gpurun_out/gpu_tests_$TAG.log" 2>&1; tail -2 "gpurun_out/gpu_tests_$TAG.log"
-timeout 150 python bench.py > "gpurun_out/bench_$TAG.json" 2> "gpurun_out/bench_$TAG.err"; cut -c1-300 "gpurun_out/bench_$TAG.json"
+timeout 900 python -m pytest tests -m gpu -x -q > "gpurun_out/gpu_tests_$TAG.log" 2>&1; tail -2 "gpurun_out/gpu_tests_$TAG.log"
+timeout 300 python bench.py > "gpurun_out/bench_$TAG.json" 2> "gpurun_out/bench_$TAG.err"; cut -c1-300 "gpurun_out/bench_$TAG.json"
 cd /tmp && export TMPDIR=/tmp
 timeout 120 rocprofv3 --kernel-trace --memory-copy-trace --stats -d "$R/gpurun_out/prof_$TAG" -o full -- python "$R/bench.py" --steps 100 --warmup 40 --cpu-frames 0 --variant-frames 0 --no-profile > "$R/gpurun_out/prof_$TAG.log" 2>&1
 "$R/xrslam_amd/bin/xr-peaks" > "$R/gpurun_out/peaks_$TAG.json" 2> "$R/gpurun_out/peaks_$TAG.err"; cat "$R/gpurun_out/peaks_$TAG.json"
