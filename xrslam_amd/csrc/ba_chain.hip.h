@@ -485,120 +485,237 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__rest
             for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
             if (lane == 0) c->gmax = mx;   // nfree <= 6 lanes of this wavefront
         };
-        // -------------------- preparation (prepare_block): Jacobi scales at the first linearisation, dogleg diagonal
         const double mu = c->mu;
-        for (int i = wtid; i < na; i += nt) {
-            const double h = Hp[i * (i + 1) / 2 + i];
-            if (c->first) sp[i] = 1.0 / (1.0 + sqrt(h));
-            const double s = sp[i];
-            const double Dv = sqrt(fmin(fmax(s * s * h, 1e-6), 1e32));
-            Dg[i] = Dv;
-            const double gsv = s * gp[i];
-            gs[i] = gsv;
-            gt[i] = s * (gsv / (Dv * Dv));
-        }
-        __syncthreads();
-        // -------------------- reduced system S = sp H sp + mu D^2 (packed, the rhs as row na) and Q(g~, g~)
-        for (int e = wtid; e < na * (na + 1) / 2; e += nt) {
-            int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while (i * (i + 1) / 2 > e) --i;
-            while ((i + 1) * (i + 2) / 2 <= e) ++i;
-            const int j = e - i * (i + 1) / 2;
-            double v = Hp[e] * (sp[i] * sp[j]);
-            if (i == j) v += mu * Dg[i] * Dg[i];
-            A[e] = v;
-        }
-        double *y = A + na * (na + 1) / 2;
-        for (int i = wtid; i < na; i += nt) y[i] = gp[i] * sp[i];
-        double qacc = 0;
-        for (int i = wave; i < na; i += 4) {
-            double t = 0;
-            for (int j = lane; j < na; j += 64) t += Hp[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i] * gt[j];
-            qacc += gt[i] * t;
-        }
-        const double qgg = block_sum(qacc, scratch);   // (block_sum ends with a barrier: A and y are complete)
-        CPROF(6);   // preparation, reduced system, Q(g~, g~)
-        // -------------------- Cholesky + substitution (solve_block)
-        bool lin_ok = chol_blocked(A, na, na + 1, Dblk, &s_fail, nullptr, gradmax_side);
-        CPROF(7);   // Cholesky
-        if (lin_ok) {
-            trsv_lower_t(A, na, y);
-            int bad = 0;
+        const int first_lin = c->first;   // read before anybody clears it below
+        bool lin_ok = false;
+        if (na <= CH_NB) {
+            // ---------------- at most 16 unknowns (localize_newframe, PnP): the whole dense algebra of the round on ONE wavefront,
+            // lane = unknown, no workgroup barrier inside -- preparation, reduced system, Q(g~, g~), Cholesky with the right-hand side
+            // riding along, back-substitution, Gauss-Newton step and the six dogleg sums.  As four wavefronts with a block-wide
+            // reduction and a barrier per step these five phases were 12.6 us of a 36 us round (in-kernel timers), almost all of it
+            // waiting.  Beside it: wavefront 1 the gradient max-norm, wavefront 2 the bias-reference refresh and |x|.
+            __syncthreads();   // Hp, gp, the cost of the linearisation (or, on a re-solve, the previous trial phase) are complete
+            if (wave == 0) {
+                const int i = lane;
+                const bool on = i < na;
+                const double h = on ? Hp[tri_idx(i, i)] : 1.0;
+                double spi = on ? sp[i] : 0.0;
+                if (first_lin) spi = on ? 1.0 / (1.0 + sqrt(h)) : 0.0;
+                const double Dv = sqrt(fmin(fmax(spi * spi * h, 1e-6), 1e32));
+                const double gsv = on ? spi * gp[i] : 0.0;
+                const double gtv = on ? spi * (gsv / (Dv * Dv)) : 0.0;
+                // row i of S = sp H sp + mu D^2 and the right-hand side, into the packed triangle the factorisation reads
+                double *y = A + tri_idx(na, 0);
+                double t_i = 0.0;   // (H g~)_i
+#pragma unroll
+                for (int k = 0; k < CH_NB; ++k) {
+                    const double spk = lane_bcast(spi, k), gtk = lane_bcast(gtv, k);
+                    if (on && k < na) {
+                        const double hik = Hp[k <= i ? tri_idx(i, k) : tri_idx(k, i)];
+                        t_i += hik * gtk;
+                        if (k <= i) {
+                            double v = hik * (spi * spk);
+                            if (k == i) v += mu * Dv * Dv;
+                            A[tri_idx(i, k)] = v;
+                        }
+                    }
+                }
+                if (on) {
+                    y[i] = gp[i] * spi;
+                    if (first_lin) sp[i] = spi;
+                    Dg[i] = Dv;
+                    gs[i] = gsv;
+                }
+                double qgg = gtv * t_i;
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) qgg += __shfl_xor(qgg, off);
+                qgg = lane_bcast(qgg, 0);
+                wave_sync();
+                bool ok = chol_diag_wave(A, 0, na, Dblk, lane, y);   // L in place, y <- L^-1 y
+                wave_sync();
+                // y <- L^-T y (trsv_lower_t's single block): lane k owns column k of L
+                double ya = 0.0;
+                {
+                    double col[CH_NB], dl = 1.0;
+#pragma unroll
+                    for (int cc = 0; cc < CH_NB; ++cc) {
+                        col[cc] = (cc < na && lane <= cc) ? A[tri_idx(cc, min(lane, cc))] : ((cc == lane) ? 1.0 : 0.0);
+                        if (cc == lane) dl = col[cc];
+                    }
+                    const double dinv = 1.0 / dl;
+                    double r = on ? y[i] : 0.0;
+#pragma unroll
+                    for (int cc = CH_NB - 1; cc >= 0; --cc) {
+                        const double xc = lane_bcast(r, cc) * lane_bcast(dinv, cc);
+                        if (lane == cc) r = xc;
+                        else if (lane < cc) r -= col[cc] * xc;
+                    }
+                    ya = r;
+                }
+                if (__ballot(on && !isfinite(ya)) != 0ull) ok = false;
+                const double gnv = on ? -Dv * ya : 0.0, grv = on ? gsv / Dv : 0.0;
+                if (on) {
+                    gn[i] = gnv;
+                    grad[i] = grv;
+                }
+                // the six sums of the dogleg scalars over the unknowns (16 lanes: four shuffle stages each, interleaved)
+                double r6[6] = {grv * grv, on ? (gnv / Dv) * gsv : 0.0, gnv * gnv, grv * grv, gnv * gnv, grv * gnv};
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) r6[q] += __shfl_xor(r6[q], off);
+                if (lane == 0) {
+                    if (ok) {
+                        c->alpha = r6[0] / qgg;
+                        c->q_gg = qgg;
+                        c->q_gn = -r6[0] - mu * r6[1];
+                        c->q_nn = -r6[1] - mu * r6[2];
+                    }
+                    c->gnorm = ok ? sqrt(r6[3]) : 0.0;
+                    c->gn_norm = ok ? sqrt(r6[4]) : 0.0;
+                    c->gd = ok ? r6[5] : 0.0;
+                    c->linear_ok = ok ? 1 : 0;
+                }
+            } else if (wave == 1) {
+                gradmax_side();
+            } else if (wave == 2 && mode == 1) {
+                // FinalizeIterationAndCheckIfMinimizerCanContinue of the iteration that produced this x: the IMU factors read their
+                // bias reference from the user state, refreshed by the StateUpdatingCallback; |x| over the free blocks
+                if (lane < NI) {
+                    const double *sti = X + 16 * p.imu_i[lane];
+                    for (int q = 0; q < 6; ++q) bref[6 * lane + q] = sti[10 + q];
+                }
+                double s2 = 0;
+                for (int f = lane; f < F; f += 64) {
+                    const double *x = X + 16 * f;
+                    if (pose_free(p.fix[f]))
+                        for (int k = 0; k < 7; ++k) s2 += x[k] * x[k];
+                    if (motion_free(p.fix[f]))
+                        for (int k = 7; k < 16; ++k) s2 += x[k] * x[k];
+                }
+                s2 = wave_sum(s2);
+                if (lane == 0) {
+                    c->x_norm = sqrt(s2);
+                    c->first = 0;
+                }
+            }
+            __syncthreads();
+            lin_ok = c->linear_ok != 0;
+        } else {
+            // -------------------- preparation (prepare_block): Jacobi scales at the first linearisation, dogleg diagonal
             for (int i = wtid; i < na; i += nt) {
-                const double ya = y[i];
-                gn[i] = -Dg[i] * ya;
-                grad[i] = gs[i] / Dg[i];
-                if (!isfinite(ya)) bad = 1;
+                const double h = Hp[i * (i + 1) / 2 + i];
+                if (c->first) sp[i] = 1.0 / (1.0 + sqrt(h));
+                const double s = sp[i];
+                const double Dv = sqrt(fmin(fmax(s * s * h, 1e-6), 1e32));
+                Dg[i] = Dv;
+                const double gsv = s * gp[i];
+                gs[i] = gsv;
+                gt[i] = s * (gsv / (Dv * Dv));
             }
-            if (bad) atomicExch(&s_fail, 1);
             __syncthreads();
-            if (s_fail) lin_ok = false;
-        }
-        __syncthreads();
-        if (lin_ok) {
-            double r3[3] = {0, 0, 0};   // |grad|^2, n~ . gs, |gn|^2   (a = tid, tid + 256, ... of the full layout)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int i = act[m];
-                if (i >= 0) {
-                    const double g = grad[i], nn = gn[i];
-                    r3[0] += g * g;
-                    r3[1] += (nn / Dg[i]) * gs[i];
-                    r3[2] += nn * nn;
+            // -------------------- reduced system S = sp H sp + mu D^2 (packed, the rhs as row na) and Q(g~, g~)
+            for (int e = wtid; e < na * (na + 1) / 2; e += nt) {
+                int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+                while (i * (i + 1) / 2 > e) --i;
+                while ((i + 1) * (i + 2) / 2 <= e) ++i;
+                const int j = e - i * (i + 1) / 2;
+                double v = Hp[e] * (sp[i] * sp[j]);
+                if (i == j) v += mu * Dg[i] * Dg[i];
+                A[e] = v;
+            }
+            double *y = A + na * (na + 1) / 2;
+            for (int i = wtid; i < na; i += nt) y[i] = gp[i] * sp[i];
+            double qacc = 0;
+            for (int i = wave; i < na; i += 4) {
+                double t = 0;
+                for (int j = lane; j < na; j += 64) t += Hp[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i] * gt[j];
+                qacc += gt[i] * t;
+            }
+            const double qgg = block_sum(qacc, scratch);   // (block_sum ends with a barrier: A and y are complete)
+            CPROF(6);   // preparation, reduced system, Q(g~, g~)
+            // -------------------- Cholesky + substitution (solve_block)
+            lin_ok = chol_blocked(A, na, na + 1, Dblk, &s_fail, nullptr, gradmax_side);
+            CPROF(7);   // Cholesky
+            if (lin_ok) {
+                trsv_lower_t(A, na, y);
+                int bad = 0;
+                for (int i = wtid; i < na; i += nt) {
+                    const double ya = y[i];
+                    gn[i] = -Dg[i] * ya;
+                    grad[i] = gs[i] / Dg[i];
+                    if (!isfinite(ya)) bad = 1;
+                }
+                if (bad) atomicExch(&s_fail, 1);
+                __syncthreads();
+                if (s_fail) lin_ok = false;
+            }
+            __syncthreads();
+            if (lin_ok) {
+                double r3[3] = {0, 0, 0};   // |grad|^2, n~ . gs, |gn|^2   (a = tid, tid + 256, ... of the full layout)
+    #pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int i = act[m];
+                    if (i >= 0) {
+                        const double g = grad[i], nn = gn[i];
+                        r3[0] += g * g;
+                        r3[1] += (nn / Dg[i]) * gs[i];
+                        r3[2] += nn * nn;
+                    }
+                }
+                block_sum_n<3>(r3, scratch);
+                if (tid == 0) {
+                    c->alpha = r3[0] / qgg;
+                    c->q_gg = qgg;
+                    c->q_gn = -r3[0] - mu * r3[1];
+                    c->q_nn = -r3[1] - mu * r3[2];
                 }
             }
-            block_sum_n<3>(r3, scratch);
-            if (tid == 0) {
-                c->alpha = r3[0] / qgg;
-                c->q_gg = qgg;
-                c->q_gn = -r3[0] - mu * r3[1];
-                c->q_nn = -r3[1] - mu * r3[2];
-            }
-        }
-        if (tid == 0) c->linear_ok = lin_ok ? 1 : 0;
-        __syncthreads();
-        CPROF(8);   // substitution, Gauss-Newton step, dogleg scalars
-        // -------------------- trials (try_block)
-        if (mode == 1) {
-            // FinalizeIterationAndCheckIfMinimizerCanContinue of the iteration that produced this x: the IMU factors
-            // read their bias reference from the user state, refreshed by the StateUpdatingCallback
-            for (int k = wtid; k < NI; k += nt) {
-                const double *sti = X + 16 * p.imu_i[k];
-                for (int i = 0; i < 6; ++i) bref[6 * k + i] = sti[10 + i];
-            }
-            double s2 = 0;
-            for (int f = wtid; f < F; f += nt) {
-                const double *x = X + 16 * f;
-                if (pose_free(p.fix[f]))
-                    for (int k = 0; k < 7; ++k) s2 += x[k] * x[k];
-                if (motion_free(p.fix[f]))
-                    for (int k = 7; k < 16; ++k) s2 += x[k] * x[k];
-            }
-            s2 = block_sum(s2, scratch);
-            if (tid == 0) {
-                c->x_norm = sqrt(s2);
-                c->first = 0;
-            }
+            if (tid == 0) c->linear_ok = lin_ok ? 1 : 0;
             __syncthreads();
-        }
-        {
-            double r3[3] = {0, 0, 0};
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int i = act[m];
-                if (i >= 0 && lin_ok) {
-                    r3[0] += grad[i] * grad[i];
-                    r3[1] += gn[i] * gn[i];
-                    r3[2] += grad[i] * gn[i];
+            CPROF(8);   // substitution, Gauss-Newton step, dogleg scalars
+            // -------------------- trials (try_block)
+            if (mode == 1) {
+                // FinalizeIterationAndCheckIfMinimizerCanContinue of the iteration that produced this x: the IMU factors
+                // read their bias reference from the user state, refreshed by the StateUpdatingCallback
+                for (int k = wtid; k < NI; k += nt) {
+                    const double *sti = X + 16 * p.imu_i[k];
+                    for (int i = 0; i < 6; ++i) bref[6 * k + i] = sti[10 + i];
                 }
+                double s2 = 0;
+                for (int f = wtid; f < F; f += nt) {
+                    const double *x = X + 16 * f;
+                    if (pose_free(p.fix[f]))
+                        for (int k = 0; k < 7; ++k) s2 += x[k] * x[k];
+                    if (motion_free(p.fix[f]))
+                        for (int k = 7; k < 16; ++k) s2 += x[k] * x[k];
+                }
+                s2 = block_sum(s2, scratch);
+                if (tid == 0) {
+                    c->x_norm = sqrt(s2);
+                    c->first = 0;
+                }
+                __syncthreads();
             }
-            block_sum_n<3>(r3, scratch);
-            if (tid == 0) {
-                c->gnorm = sqrt(r3[0]);
-                c->gn_norm = sqrt(r3[1]);
-                c->gd = r3[2];
+            {
+                double r3[3] = {0, 0, 0};
+    #pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int i = act[m];
+                    if (i >= 0 && lin_ok) {
+                        r3[0] += grad[i] * grad[i];
+                        r3[1] += gn[i] * gn[i];
+                        r3[2] += grad[i] * gn[i];
+                    }
+                }
+                block_sum_n<3>(r3, scratch);
+                if (tid == 0) {
+                    c->gnorm = sqrt(r3[0]);
+                    c->gn_norm = sqrt(r3[1]);
+                    c->gd = r3[2];
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         CPROF(9);   // start of the trial phase (user-state refresh, norms)
         TrialScalars t;
