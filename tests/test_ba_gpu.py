@@ -117,7 +117,9 @@ def _solve_both(ctx, bo, pd, tag, rtol=1e-7):
     return sm_o, sm_h
 
 
-@pytest.mark.parametrize("K,Ln,seed", [(10, 150, 1), (11, 150, 2), (6, 60, 3)])
+# K = 11: 165 unknowns, the tiled LDS Cholesky (dense_lds.hip.h tl_*); K = 12: 180 unknowns no longer fit the tile layout and take the
+# packed triangle in LDS (the window holds 12 frames when manage_keyframe promoted a subframe and the new frame in one step)
+@pytest.mark.parametrize("K,Ln,seed", [(10, 150, 1), (11, 150, 2), (6, 60, 3), (12, 150, 4)])
 def test_refine_window_solve_parity(ctx, bo, K, Ln, seed):
     pd, _ = bs.make_window(K=K, L=Ln, seed=seed)
     sm_o, sm_h = _solve_both(ctx, bo, pd, "window%d" % seed)
@@ -363,3 +365,58 @@ def test_preintegration_parity(ctx, bo):
     long = np.concatenate(truth["samples"][:3])
     np.testing.assert_allclose(ctx.preintegrate(long, truth["times"][3], bg, ba, bs.NOISE36)[:56],
                                bo.preintegrate(long, truth["times"][3], bg, ba, bs.NOISE36)[:56], rtol=1e-9, atol=1e-13)
+
+
+def test_schur_precision_knob_is_a_study_aid_that_resets(ctx, bo):
+    """xrhip_ba_debug_set_schur_precision (BASELINE config 5's study): f32 operands move the result of a window solve by ~1e-7, and
+    mode 0 afterwards is the product's f64 path again -- bit for bit."""
+    pd, _ = bs.make_window(K=8, L=100, seed=41)
+    a, b, c2 = pd.copy(), pd.copy(), pd.copy()
+    ctx.solve(a)
+    ctx.set_schur_precision(1)
+    try:
+        ctx.solve(b)
+    finally:
+        ctx.set_schur_precision(0)
+    ctx.solve(c2)
+    np.testing.assert_array_equal(a.frame_state, c2.frame_state)
+    np.testing.assert_array_equal(a.inv_depth, c2.inv_depth)
+    assert not np.array_equal(a.frame_state, b.frame_state)
+    np.testing.assert_allclose(b.frame_state, a.frame_state, rtol=1e-5, atol=1e-7)
+    with pytest.raises(Exception):
+        ctx.set_schur_precision(7)
+
+
+def test_one_preintegration_batch_in_flight_per_context(ctx):
+    """A second xrhip_ba_preintegrate_begin without _end is refused (it would overwrite the staging block the first batch's kernel
+    writes its record into); xrhip_ba_preintegrate_cancel releases the context; a fresh begin / end then gives the blocking call's
+    record."""
+    import ctypes as C
+    from xrslam_amd import ba as _ba
+    rng = np.random.RandomState(5)
+    n = 10
+    smp = np.zeros((n, 7))
+    smp[:, 0] = 1.0 + 0.005 * np.arange(n)
+    smp[:, 1:4] = 0.1 * rng.randn(n, 3)
+    smp[:, 4:7] = np.array([0.0, 0.0, 9.8]) + 0.2 * rng.randn(n, 3)
+    t_end = float(smp[-1, 0] + 0.005)
+    ref = ctx.preintegrate(smp, t_end, np.zeros(3), np.zeros(3), bs.NOISE36)
+    lib = _ba.L()
+    vp = C.c_void_p
+    begin = np.zeros(1, np.int32)
+    count = np.array([n], np.int32)
+    te = np.array([t_end])
+    z3 = np.zeros(3)
+    s = np.ascontiguousarray(smp)
+    noise = np.ascontiguousarray(bs.NOISE36, np.float64)
+
+    def p(a):
+        return a.ctypes.data_as(vp)
+    args = (ctx._h, p(s), p(begin), p(count), p(te), p(z3), p(z3), 1, p(noise), 1, 1)
+    assert lib.xrhip_ba_preintegrate_begin(*args) == 0
+    assert lib.xrhip_ba_preintegrate_begin(*args) != 0          # XRHIP_ESTATE: one batch in flight
+    assert lib.xrhip_ba_preintegrate_cancel(ctx._h) == 0
+    assert lib.xrhip_ba_preintegrate_begin(*args) == 0
+    out = np.zeros(ref.size)
+    assert lib.xrhip_ba_preintegrate_end(ctx._h, p(out)) == 0
+    np.testing.assert_array_equal(out.reshape(ref.shape), ref)
