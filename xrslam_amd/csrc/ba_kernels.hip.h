@@ -840,12 +840,21 @@ __device__ __forceinline__ void schur_tile_block(const BaDims &d, const BaPtrs &
     const int i = lane & 15, kk = lane >> 4;
     if (d.schur_mode == 0) {
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
-        for (int k = k0; k < k0 + kq; k += 4) {
-            const int l = k + kk;
-            const double w = (l < d.L) ? p.omega[l] : 0.0;
-            const double a = p.Wt[(size_t)l * d.PF + 16 * ti + i];
-            const double b = p.Wt[(size_t)l * d.PF + 16 * tj + i] * w;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        // six operand pairs (18 loads) in flight per trip: with one, each of the ~18 trips waited out an L2 round trip before its
+        // matrix-core instruction (the products are issued in the same order: the same bits)
+        constexpr int SU = 6;
+        for (int k = k0; k < k0 + kq; k += 4 * SU) {
+            double av[SU], bv[SU], wv[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int l = min(k + 4 * u + kk, d.Lp - 1);
+                wv[u] = (l < d.L) ? p.omega[l] : 0.0;
+                av[u] = p.Wt[(size_t)l * d.PF + 16 * ti + i];
+                bv[u] = p.Wt[(size_t)l * d.PF + 16 * tj + i];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u)
+                if (k + 4 * u < k0 + kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u] * wv[u], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][(kk + 4 * r) * 16 + i] = acc[r];
