@@ -305,9 +305,9 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     const size_t w_T = carve(D8 * (size_t)d.PF * d.PF), w_S = carve(D8 * (size_t)n * n);
     const size_t w_dD = carve(D8 * d.NV), w_gr = carve(D8 * d.NV), w_gn = carve(D8 * d.NV), w_gs = carve(D8 * d.NV);
     const size_t w_st = carve(D8 * d.NV), w_de = carve(D8 * d.NV * TRY_B), w_part = carve(D8 * (size_t)(aux_quad_blocks_n(d.n, std::max(d.L, 1)) + 8));
-    const size_t w_wog = carve(D8 * d.PF);
+    const size_t w_wog = carve(D8 * d.PF * WOG_CH);
     const size_t w_wide = carve(D8 * WIDE_G * 4 * WIDE_B);
-    const size_t w_Hv = carve(D8 * 36 * (size_t)F * F), w_gv = carve(D8 * 6 * F);
+    const size_t w_Hv = carve(D8 * 36 * (size_t)F * F * VIS_CH), w_gv = carve(D8 * 6 * F * VIS_CH);
     int rc = ensure_arena(c, in_bytes, w + 256, (size_t)16 * F + L + 8);
     if (rc) return rc;
     for (const Item &it : items)
@@ -456,7 +456,7 @@ static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, cons
     hipStream_t s = s_override ? s_override : c->stream;
     hipLaunchKernelGGL(kb_lin_all, dim3(lin_all_blocks(d.M, d.MR, d.NI, d.np)), dim3(256), sizeof(double) * std::max(d.np, 1), s, d, p,
                        cam, imu, sx, sy);
-    hipLaunchKernelGGL(kb_landmark_vision, dim3(d.lm_rows + d.F * d.F), dim3(64), 0, s, d, p);
+    hipLaunchKernelGGL(kb_landmark_vision, dim3(d.lm_rows + d.F * d.F * VIS_CH), dim3(64), 0, s, d, p);
     if (for_solver && small_mid(d)) return;   // kb_small_mid (launch_solve_try) assembles what the solve reads
     hipLaunchKernelGGL(kb_assemble, dim3((d.n * d.n + 255) / 256), dim3(256), 0, s, d, p);
     if (for_solver) hipLaunchKernelGGL(kb_cost_prepare, dim3(1), dim3(256), 0, s, d, p);
@@ -495,7 +495,7 @@ static bool wide_first(const BaDims &d) { return wide_trials(d) && d.M >= 600 &&
 static void launch_schur_aux(const BaDims &d, const BaPtrs &p, hipStream_t s) {
     const int tiles = d.PF / 16;
     const int nrest = (d.na * d.na + 255) / 256;   // blocks that write the Schur-free entries of the reduced system
-    hipLaunchKernelGGL(kb_schur_aux, dim3(nrest + (d.nla ? tiles * tiles + aux_quad_blocks_n(d.n, d.L) + (6 * d.F + 63) / 64
+    hipLaunchKernelGGL(kb_schur_aux, dim3(nrest + (d.nla ? tiles * tiles + aux_quad_blocks_n(d.n, d.L) + aux_wog_blocks(d.F)
                                                         : aux_quad_blocks_n(d.n, d.L))),
                        dim3(256), 0, s, d, p);
 }
@@ -1114,7 +1114,7 @@ static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     hipLaunchKernelGGL(km_omega, dim3((std::max(d.L, 1) + 255) / 256), dim3(256), 0, s, d, p);
     const int tiles = d.PF / 16;
     hipLaunchKernelGGL(kb_schur_mfma, dim3(tiles * tiles), dim3(256), 0, s, d, p);
-    hipLaunchKernelGGL(km_wog, dim3((6 * d.F + 63) / 64), dim3(256), 0, s, d, p);
+    hipLaunchKernelGGL(km_wog, dim3(aux_wog_blocks(d.F)), dim3(256), 0, s, d, p);
     hipLaunchKernelGGL(km_permute, dim3((N * N + 255) / 256), dim3(256), 0, s, d, p, M->victim, Hm, bm);
     hipLaunchKernelGGL(km_victim, dim3(1), dim3(256), 0, s, N, Hm, T2, dst);
     hipLaunchKernelGGL(km_complement, dim3((R * R + 255) / 256), dim3(256), 0, s, N, Hm, bm, T2, A, bp);

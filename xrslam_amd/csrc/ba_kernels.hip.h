@@ -143,7 +143,7 @@ struct BaPtrs {
     gptr<double> Sred;                    // [n][n] scratch (global fallback of the Cholesky)
     gptr<double> diagD, grad, gn, gs, step, delta;   // [NV] each
     gptr<double> partial;                 // [aux_quad_blocks] partial sums of Q(g~,g~)
-    gptr<double> wog;                     // [PF] W^T (omega gl)
+    gptr<double> wog;                     // [WOG_CH][PF] W^T (omega gl), per landmark-row chunk (wog_at)
     gptr<double> wide_part;               // [WIDE_G][4 WIDE_B] per-block partial sums of kb_trials_wide
     // zero-copy mailbox in pinned host memory (device-visible addresses): the trial kernel publishes the
     // control block, on termination the optimised states, and last a sequence number the host spins on
@@ -666,13 +666,42 @@ __device__ __forceinline__ void landmark_item(const BaDims &d, const BaPtrs &p, 
 // observation list, each accumulating a private 6x6 block (+ 6-vector for the diagonal pair); a fixed
 // butterfly reduction combines them -- "batched small-block JtJ accumulation with wavefront-shuffle reductions".
 constexpr int VIS_RED = 42 * 65;   // doubles of LDS assemble_vision_item needs per wavefront
-__device__ __forceinline__ void assemble_vision_item(const BaDims &d, const BaPtrs &p, int pair, int lane, double *red) {
+// A pair's observation list is cut into VIS_CH chunks of >= 64 entries, one wavefront (workgroup of kb_landmark_vision) each; the
+// chunks' partial blocks are added by the reader in chunk order (vis_h / vis_g).  As ONE wavefront per pair the diagonal pair of the
+// oldest keyframe -- the reference frame of most landmarks, > 1000 entries -- ran 17-21 us while every other workgroup of the launch
+// was done within 7 (in-kernel block timers, round 3): it alone set kb_landmark_vision's 22.7 us.
+constexpr int VIS_CH = 8;
+__device__ __forceinline__ double vis_h(const BaDims &d, const BaPtrs &p, int pair, int e) {
+    double s = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < VIS_CH; ++ch) s += p.Hv[((size_t)ch * d.F * d.F + pair) * 36 + e];
+    return s;
+}
+__device__ __forceinline__ double vis_g(const BaDims &d, const BaPtrs &p, int a) {
+    double s = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < VIS_CH; ++ch) s += p.gv[(size_t)ch * 6 * d.F + a];
+    return s;
+}
+// ch / nch: this wavefront's chunk of the pair's list (nch == 1: the whole list into chunk 0, the other chunks cleared)
+__device__ __forceinline__ void assemble_vision_item(const BaDims &d, const BaPtrs &p, int pair, int lane, double *red, int ch = 0, int nch = 1) {
     const int fa = pair / d.F, fb = pair - fa * d.F;
     if (!pose_free(p.fix[fa]) || !pose_free(p.fix[fb])) return;   // the block is never read (kb_assemble)
-    const int s0 = p.pair_start[fa * d.F + fb], s1 = p.pair_start[fa * d.F + fb + 1];
+    const size_t FF = (size_t)d.F * d.F;
+    int s0 = p.pair_start[fa * d.F + fb], s1 = p.pair_start[fa * d.F + fb + 1];
+    if (nch > 1) {
+        const int per = max(64, (s1 - s0 + nch - 1) / nch);
+        s0 = min(s1, s0 + ch * per);
+        s1 = min(s1, s0 + per);
+    } else {
+        for (int c = 1; c < VIS_CH; ++c) {
+            if (lane < 36) p.Hv[(c * FF + pair) * 36 + lane] = 0.0;
+            if (fa == fb && lane < 6) p.gv[(size_t)c * 6 * d.F + 6 * fa + lane] = 0.0;
+        }
+    }
     if (s0 == s1) {   // no shared observation (always the case off the diagonal when the landmarks' reference frames are constant)
-        if (lane < 36) p.Hv[(size_t)pair * 36 + lane] = 0.0;
-        if (fa == fb && lane < 6) p.gv[6 * fa + lane] = 0.0;
+        if (lane < 36) p.Hv[(ch * FF + pair) * 36 + lane] = 0.0;
+        if (fa == fb && lane < 6) p.gv[(size_t)ch * 6 * d.F + 6 * fa + lane] = 0.0;
         return;
     }
     double h[36], g[6];
@@ -716,8 +745,8 @@ __device__ __forceinline__ void assemble_vision_item(const BaDims &d, const BaPt
         const double *row = red + lane * 65;
         double acc = 0.0;
         for (int q = 0; q < nl; ++q) acc += row[q];
-        if (lane < 36) p.Hv[(size_t)pair * 36 + lane] = acc;
-        else p.gv[6 * fa + lane - 36] = acc;
+        if (lane < 36) p.Hv[(ch * FF + pair) * 36 + lane] = acc;
+        else p.gv[(size_t)ch * 6 * d.F + 6 * fa + lane - 36] = acc;
     }
 }
 
@@ -732,8 +761,8 @@ __device__ __forceinline__ void assemble_item(const BaDims &d, const BaPtrs &p, 
     if (dof_active(p.fix, a) && (dof_active(p.fix, b) || want_g)) {
         const bool bact = dof_active(p.fix, b);
         if (ka < 6) {
-            if (kb < 6 && bact) h += p.Hv[(size_t)(fa * d.F + fb) * 36 + 6 * ka + kb];
-            if (want_g) g += p.gv[6 * fa + ka];
+            if (kb < 6 && bact) h += vis_h(d, p, fa * d.F + fb, 6 * ka + kb);
+            if (want_g) g += vis_g(d, p, 6 * fa + ka);
             if (ka < 3) {
                 const int s = p.rotf_start[fa], t = p.rotf_start[fa + 1];
                 for (int it = s; it < t; ++it) {
@@ -941,7 +970,15 @@ __global__ __launch_bounds__(256) void kb_schur_mfma(BaDims d, BaPtrs p) { schur
 //   role 0 (blocks [0, nbq)):       partial sums of Q(g~,g~): 16 frame rows or 32 landmark rows per block
 //   role 1 (blocks [nbq, nbq+nbr)): wog = W^T (omega gl), 64 pose columns per block
 __host__ __device__ __forceinline__ int aux_quad_blocks_n(int n, int L) { return (n + 15) / 16 + (L + 31) / 32; }
+constexpr int WOG_CH = 8;   // landmark-row chunks of the W^T (omega gl) product (one workgroup each per 64 pose columns)
+__host__ __device__ __forceinline__ int aux_wog_blocks(int F) { return WOG_CH * ((6 * F + 63) / 64); }
 
+__device__ __forceinline__ double wog_at(const BaDims &d, const BaPtrs &p, int c) {   // the chunks' partial sums, in chunk order
+    double s = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < WOG_CH; ++ch) s += p.wog[(size_t)ch * d.PF + c];
+    return s;
+}
 __device__ __forceinline__ void solve_aux_block(const BaDims &d, const BaPtrs &p, int blk) {
     __shared__ double scratch[8];
     __shared__ double part[4][64];
@@ -1025,31 +1062,52 @@ __device__ __forceinline__ void solve_aux_block(const BaDims &d, const BaPtrs &p
         return;
     }
     blk -= nbq;
-    {   // wog[c] = sum_l Wt[l][c] omega_l gl_l: 64 columns per block, the four wavefronts split the landmark rows
-        const int cc = 64 * blk + lane;
-        const int per = (d.L + 3) / 4, l0 = wave * per, l1 = min(d.L, l0 + per);
+    {   // wog[c] = sum_l Wt[l][c] omega_l gl_l.  WOG_CH row chunks x 64 pose columns per block, the four wavefronts split the chunk's
+        // landmark rows; the chunks' partial sums are added by the reader in chunk order (wog_at).  As ONE block per 64 columns --
+        // 278 rows of a freshly written 180 KB operand behind one workgroup -- this role took 15-21 us, three times the tiles and the
+        // quadratic-form blocks of the same launch (in-kernel block timers, round 3).
+        const int ncol = (P6 + 63) / 64, ch = blk / ncol, cb = blk - ch * ncol;
+        const int cc = 64 * cb + lane;
+        const int perc = (d.L + WOG_CH - 1) / WOG_CH, c0 = min(d.L, ch * perc), c1 = min(d.L, c0 + perc);
+        const int per = (c1 - c0 + 3) / 4, l0 = min(c1, c0 + wave * per), l1 = min(c1, l0 + per);
         double sacc = 0;
+        constexpr int WB = 12;
         if (cc < P6)
-            for (int lb = l0; lb < l1; lb += 8) {
-                double wv[8], og[8];
+            for (int lb = l0; lb < l1; lb += WB) {
+                double wv[WB], og[WB];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int l = min(lb + r, l1 - 1);
+                for (int r = 0; r < WB; ++r) {
+                    const int l = min(lb + r, max(l1 - 1, 0));
                     wv[r] = p.Wt[(size_t)l * d.PF + cc];
                     og[r] = (lb + r < l1) ? p.omega[l] * p.gl[l] : 0.0;
                 }
 #pragma unroll
-                for (int r = 0; r < 8; ++r) sacc += wv[r] * og[r];
+                for (int r = 0; r < WB; ++r) sacc += wv[r] * og[r];
             }
         part[wave][lane] = sacc;
         __syncthreads();
-        if (wave == 0 && cc < P6) p.wog[cc] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        if (wave == 0 && cc < P6) p.wog[(size_t)ch * d.PF + cc] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
     }
 }
 // Schur tiles and the solve's auxiliary passes in one launch: [tiles^2 | aux blocks]
 // (without free landmarks there is no Schur complement and no W^T (omega gl): only the quadratic-form blocks run)
 // layout of the grid: [Schur tiles | rest of S | aux blocks]
 __global__ __launch_bounds__(256) void kb_schur_aux(BaDims d, BaPtrs p) {
+#ifdef XRHIP_KPROF
+    const long long t0 = wall_clock64();
+    struct Tail {
+        long long t0;
+        const BaDims &d;
+        const BaPtrs &p;
+        __device__ ~Tail() {
+            const int nrest = (d.na * d.na + 255) / 256, tiles = d.PF / 16, b = blockIdx.x;
+            const int nbq = aux_quad_blocks_n(d.n, d.L);
+            if (threadIdx.x == 0 && d.M > 1500 &&
+                (b == 1 || b == nrest + 3 || b == nrest + tiles * tiles + 1 || b == nrest + tiles * tiles + nbq - 2 || b == nrest + tiles * tiles + nbq))
+                printf("kb_schur_aux block %d (rest %d tiles %d quad %d): %lld x10ns\n", b, nrest, tiles * tiles, nbq, wall_clock64() - t0);
+        }
+    } tail{t0, d, p};
+#endif
     const int t2 = d.nla ? (d.PF / 16) * (d.PF / 16) : 0;
     const int nrest = (d.na * d.na + 255) / 256;
     int blk = blockIdx.x;
@@ -1088,7 +1146,7 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
         for (int i = tid; i < na; i += nt) {   // rhs = sp (gp - W^T (omega gl)); the product comes from kb_solve_aux
             const int a = p.act_idx[i];
             const int fa = a / 15, ka = a - 15 * fa;
-            const double sacc = (d.nla && ka < 6) ? p.wog[6 * fa + ka] : 0.0;
+            const double sacc = (d.nla && ka < 6) ? wog_at(d, p, 6 * fa + ka) : 0.0;
             y[i] = (p.gp[a] - sacc) * p.sp[a];
         }
         __syncthreads();
@@ -1153,7 +1211,7 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
         if (tid < na) {
             const int a = p.act_idx[tid];
             const int fa = a / 15, ka = a - 15 * fa;
-            const double sacc = (d.nla && ka < 6) ? p.wog[6 * fa + ka] : 0.0;
+            const double sacc = (d.nla && ka < 6) ? wog_at(d, p, 6 * fa + ka) : 0.0;
             rhs_v = (p.gp[a] - sacc) * p.sp[a];
         }
         constexpr int TU = 3;   // tiles (4 loads each) in flight per wavefront; loads are unconditional (clamped), selected afterwards
@@ -1844,15 +1902,22 @@ __host__ __device__ __forceinline__ int lin_all_blocks(int M, int MR, int NI, in
     return (M + 255) / 256 + (MR + 255) / 256 + NI + (np ? (np + 15) / 16 : 1);
 }
 
-// per-landmark rows and per-frame-pair reprojection blocks: [Lp landmarks | F*F pairs], one wavefront each
+// per-landmark rows and per-frame-pair reprojection blocks: [Lp landmarks | F*F pairs x VIS_CH list chunks], one wavefront each
 // (tried: 64 landmarks per block, one THREAD walking a landmark's observation list -- no butterflies, but ~8 dependent
 // round trips to L2 per landmark instead of one: 21.7 -> 24.1 us, profiles/r02_ab_variants.md)
 // (no landmark rows are needed when every landmark is constant: nla == 0)
 __global__ __launch_bounds__(64) void kb_landmark_vision(BaDims d, BaPtrs p) {
     __shared__ double red[VIS_RED];
     const int lp = d.lm_rows;
+#ifdef XRHIP_KPROF
+    const long long t0 = wall_clock64();
+#endif
     if ((int)blockIdx.x < lp) landmark_item(d, p, blockIdx.x, threadIdx.x);
-    else assemble_vision_item(d, p, blockIdx.x - lp, threadIdx.x, red);
+    else assemble_vision_item(d, p, ((int)blockIdx.x - lp) / VIS_CH, threadIdx.x, red, ((int)blockIdx.x - lp) % VIS_CH, VIS_CH);
+#ifdef XRHIP_KPROF
+    if (threadIdx.x == 0 && d.M > 1500 && wall_clock64() - t0 > 800)
+        printf("kb_landmark_vision block %d of %d+%d*%d (%s): %lld x10ns\n", (int)blockIdx.x, lp, d.F, d.F, (int)blockIdx.x < lp ? "landmark" : "pair", wall_clock64() - t0);
+#endif
 }
 
 // total cost, gradient max-norm and the per-solve preparation, one workgroup
@@ -2327,9 +2392,11 @@ __global__ __launch_bounds__(256) void kb_tiny(const TinyArgs *__restrict__ args
                     const int a = tid / 6, b = tid - 6 * a, lo = a < b ? a : b, hi = a < b ? b : a;
                     const int e = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);   // index in the row-major upper triangle
                     p.Hv[(size_t)pair * 36 + tid] = (s_vis[0][e] + s_vis[1][e]) + (s_vis[2][e] + s_vis[3][e]);
+                    for (int c = 1; c < VIS_CH; ++c) p.Hv[((size_t)c * d.F * d.F + pair) * 36 + tid] = 0.0;   // (vis_h adds the chunks)
                 } else if (tid < 42) {
                     const int a = tid - 36;
                     p.gv[6 * f + a] = (s_vis[0][21 + a] + s_vis[1][21 + a]) + (s_vis[2][21 + a] + s_vis[3][21 + a]);
+                    for (int c = 1; c < VIS_CH; ++c) p.gv[(size_t)c * 6 * d.F + 6 * f + a] = 0.0;
                 }
             } else if (wave == 0) {   // (a path kb_chain has taken over for every problem it accepts: kept simple)
                 for (int it = 0; it < s_nfree * s_nfree; ++it)

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void km_permute(BaDims d, BaPtrs p, int victim
     if (ka < 6 && kb < 6) v -= p.T[(size_t)(6 * fa + ka) * d.PF + 6 * fb + kb];
     const int pa = 15 * pfa + ka, pb = 15 * pfb + kb;
     Hm[(size_t)pa * n + pb] = v;
-    if (b == 0) bm[pa] = p.gp[a] - (ka < 6 ? p.wog[6 * fa + ka] : 0.0);   // wog = W^T (omega gl), from km_wog
+    if (b == 0) bm[pa] = p.gp[a] - (ka < 6 ? wog_at(d, p, 6 * fa + ka) : 0.0);   // wog = W^T (omega gl), from km_wog
 }
 
 // In-LDS inverse of a 15x15 matrix by Gauss-Jordan with partial pivoting; any workgroup size >= 64, all threads
