@@ -27,7 +27,7 @@ constexpr int OREC = 28;   // per-observation record: Jt(12) Jr(12) jl(2) r(2), 
 constexpr int RREC = 8;
 constexpr int TRY_B = 4;   // trust-region trials costed per sweep after a rejection (inside kb_solve_try)
 constexpr int WIDE_B = 8;  // ... per kb_trials_wide launch
-constexpr int WIDE_G = 32; // workgroups of kb_trials_wide
+constexpr int WIDE_G = 64; // workgroups of kb_trials_wide
 constexpr int QF_ROWS = 8; // landmark rows a wavefront keeps in flight in the back-substitution
 
 struct BaCtl {   // device-resident solver state (one per context)
@@ -1523,8 +1523,22 @@ __device__ __forceinline__ double dogleg_model_change(const TrialScalars &t, dou
 
 // Decision for trial k of a batch whose predecessors were all rejected (k > 0 first replays their finalize step).
 // Returns true when the candidate is accepted; t.status != ST_RUNNING ends the batch.
-__device__ __forceinline__ bool trial_decide(TrialScalars &t, int k, double model_cost_change, double cost, double dn2,
-                                             double step_norm) {
+// The arithmetic of a decision that does not depend on the radius / counters the rejections before it changed -- the
+// parameter-tolerance norm and the relative decrease: a square root and a division -- is split off (trial_terms), so that a
+// batch of candidates computes it side by side, once per candidate, before walking through the decisions (kb_trials_wide:
+// 15-25 decisions per launch on the reference's rejection runs, each of which used to repeat them).
+struct TrialTerms {
+    double cost, dn, relative_decrease;
+};
+__device__ __forceinline__ TrialTerms trial_terms(const TrialScalars &t, double model_cost_change, double cost, double dn2) {
+    TrialTerms w;
+    if (!isfinite(cost)) cost = 1.7976931348623157e308;
+    w.cost = cost;
+    w.dn = sqrt(dn2);
+    w.relative_decrease = (t.x_cost - cost) / model_cost_change;
+    return w;
+}
+__device__ __forceinline__ bool trial_decide(TrialScalars &t, int k, double model_cost_change, const TrialTerms &w, double step_norm) {
     if (k > 0) {
         if (t.iteration >= t.max_iterations) {
             t.termination = XRHIP_BA_NO_CONVERGENCE;
@@ -1548,24 +1562,21 @@ __device__ __forceinline__ bool trial_decide(TrialScalars &t, int k, double mode
         }
         return false;
     }
-    if (!isfinite(cost)) cost = 1.7976931348623157e308;
-    const double dn = sqrt(dn2);
-    if (dn <= TR_PARAMETER_TOLERANCE * (t.x_norm + TR_PARAMETER_TOLERANCE) ||
-        fabs(t.x_cost - cost) <= TR_FUNCTION_TOLERANCE * t.x_cost) {
+    if (w.dn <= TR_PARAMETER_TOLERANCE * (t.x_norm + TR_PARAMETER_TOLERANCE) ||
+        fabs(t.x_cost - w.cost) <= TR_FUNCTION_TOLERANCE * t.x_cost) {
         t.termination = XRHIP_BA_CONVERGENCE;
         t.status = ST_DONE;
         return false;
     }
-    const double relative_decrease = (t.x_cost - cost) / model_cost_change;
-    if (relative_decrease > TR_MIN_RELATIVE_DECREASE) {
+    if (w.relative_decrease > TR_MIN_RELATIVE_DECREASE) {
         t.invalid_steps = 0;
         t.successful_steps += 1;
-        if (relative_decrease < 0.25) t.radius *= 0.5;
-        if (relative_decrease > 0.75) t.radius = fmax(t.radius, 3.0 * step_norm);
+        if (w.relative_decrease < 0.25) t.radius *= 0.5;
+        if (w.relative_decrease > 0.75) t.radius = fmax(t.radius, 3.0 * step_norm);
         t.radius = fmin(t.radius, TR_MAX_RADIUS);
         t.mu = fmax(1e-8, 2.0 * t.mu / 10.0);
         t.reuse = 0;
-        t.cand_cost = cost;
+        t.cand_cost = w.cost;
         t.last_step_norm = step_norm;
         t.status = ST_ACCEPTED;
         return true;
@@ -1574,6 +1585,10 @@ __device__ __forceinline__ bool trial_decide(TrialScalars &t, int k, double mode
     t.radius *= 0.5;   // StepRejected
     t.reuse = 1;
     return false;
+}
+__device__ __forceinline__ bool trial_decide(TrialScalars &t, int k, double model_cost_change, double cost, double dn2,
+                                             double step_norm) {
+    return trial_decide(t, k, model_cost_change, trial_terms(t, model_cost_change, cost, dn2), step_norm);
 }
 
 // Publish the result of a trial launch into the host mailbox: control block, on termination the optimised
@@ -1585,16 +1600,19 @@ __device__ __forceinline__ void publish_block(const BaDims &d, const BaPtrs &p, 
         for (int l = tid; l < d.L; l += nt) p.host_out[16 * d.F + l] = p.depth[l];
         __threadfence_system();
     }
+    if (tid == 0) p.ctl->status = status;
     __syncthreads();
-    if (tid == 0) {
-        p.ctl->status = status;
-        if (always || status == ST_DONE) {
-            const long long *src = reinterpret_cast<const long long *>(static_cast<BaCtl *>(p.ctl));
-            long long *dst = reinterpret_cast<long long *>(static_cast<BaCtl *>(p.host_ctl));
-            for (unsigned i = 0; i < sizeof(BaCtl) / sizeof(long long); ++i) dst[i] = src[i];
-            __threadfence_system();
-            *reinterpret_cast<volatile int *>(static_cast<int *>(p.host_seq)) = seq;
-        }
+    if (always || status == ST_DONE) {
+        // one word per thread, read past this CU's vector cache (the block's own thread 0 has just written some of them; lines of the
+        // control block are in the cache since trial_load).  As a loop of thread 0 -- 55 dependent load / host-store pairs -- the copy
+        // took 7 us of every kb_trials_wide / kb_solve_try launch.
+        constexpr unsigned ctl_words = sizeof(BaCtl) / sizeof(long long);
+        long long *src = reinterpret_cast<long long *>(static_cast<BaCtl *>(p.ctl));
+        long long *dst = reinterpret_cast<long long *>(static_cast<BaCtl *>(p.host_ctl));
+        for (unsigned i = tid; i < ctl_words; i += nt) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) *reinterpret_cast<volatile int *>(static_cast<int *>(p.host_seq)) = seq;
     }
     __syncthreads();
 }
@@ -2016,6 +2034,14 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     const int blk = blockIdx.x, G = gridDim.x;
     const int n = d.n;
+#ifdef XRHIP_KPROF
+    long long tw[16];
+    int twn = 0;
+#define WT() (tw[twn++] = wall_clock64())
+#else
+#define WT() ((void)0)
+#endif
+    WT();
     double *cand = wl;                           // [WIDE_B][F][16]
     double *pd = wl + (size_t)WIDE_B * 16 * d.F;   // [WIDE_B][np]
     BaCtl *c = p.ctl;
@@ -2053,6 +2079,7 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
         const int j = k == 0 ? 0 : dup + k - 1;   // trial index of slot k
         dogleg_point(t, scalbn(t.radius, -j), ca[k], cb[k], step_norm[k]);
     }
+    WT();
     // ---- candidate frame states (every block, LDS) and prior deltas
     for (int e = tid; e < WIDE_B * d.F; e += nt) {
         const int k = e / d.F, f = e - k * d.F;
@@ -2072,6 +2099,7 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
         state_plus(p.state + 16 * f, dl, pose_free(p.fix[f]), motion_free(p.fix[f]), cand + (size_t)(k * d.F + f) * 16);
     }
     __syncthreads();
+    WT();
     for (int e = tid; e < WIDE_B * d.NP; e += nt) {
         const int k = e / d.NP, i = e - k * d.NP;
         double dl[15];
@@ -2079,11 +2107,19 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
         for (int q = 0; q < 15; ++q) pd[k * d.np + 15 * i + q] = dl[q];
     }
     __syncthreads();
+    WT();
     // ---- this block's slice of the sums: per candidate cost, |x - cand|^2, |step|^2, step . gs
     double acc[4 * WIDE_B];
 #pragma unroll
     for (int q = 0; q < 4 * WIDE_B; ++q) acc[q] = 0.0;
-    const int gtid = blk * nt + tid, gnt = G * nt;
+    // With enough wavefronts in the grid the (IMU factor, candidate) pairs -- one wavefront each, a serial SO(3) chain of 5-9 us -- get
+    // wavefronts of their own (the far end of the grid) and the other wavefronts share the strided sums: the chain then runs beside the
+    // reprojection factors and the prior rows instead of behind them on the same wavefront (in-kernel timers, round 3).
+    const int W = G * nw, T = WIDE_B * d.NI, gw = blk * nw + wave;
+    const bool split = 2 * T <= W;
+    const bool strided = !(split && gw >= W - T);
+    const int gtid = blk * nt + tid, gnt = split ? (W - T) * 64 : G * nt, wstride = split ? W - T : W;
+    if (strided)
     for (int a = gtid; a < d.NV; a += gnt) {   // step norms / gradient products, landmark part of |x - cand|^2
         const double g = p.grad[a], gnv = p.gn[a], D = p.diagD[a], gsa = p.gs[a];
         const bool lm = a >= n;
@@ -2115,6 +2151,8 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
             for (int kk = 0; kk < WIDE_B; ++kk)
                 if (kk == k) acc[4 * kk + 1] += s2;
         }
+    WT();
+    if (strided)
     for (int e = gtid; e < WIDE_B * d.M; e += gnt) {   // reprojection factors: one (factor, candidate) pair per thread
         const int k = e / d.M, o = e - k * d.M;
         const int l = p.obs_lm[o];
@@ -2132,6 +2170,7 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
         for (int kk = 0; kk < WIDE_B; ++kk)
             if (kk == k) acc[4 * kk] += cst;
     }
+    if (strided)
     for (int e = gtid; e < WIDE_B * d.MR; e += gnt) {
         const int k = e / d.MR, o = e - k * d.MR;
         const double cst = rot_eval(d, p, o, cand + (size_t)k * 16 * d.F, cam, sx, sy, false, nullptr);
@@ -2140,17 +2179,20 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
             if (kk == k) acc[4 * kk] += cst;
     }
     // IMU factors: raw residual + 15x15 whitening per (factor, candidate), taken by the blocks from the far end of the
+    WT();
     // grid so that they do not pile onto the threads that already hold a reprojection pair
     // (one WAVEFRONT per (factor, candidate) pair: lane 0 runs the SO(3) chain of the raw residual, fifteen lanes whiten
     // it -- as a single thread the 225-term whitening doubled the chain, and these pairs are the last to finish)
-    for (int e = (G * nw - 1 - (blk * nw + wave)); e < WIDE_B * d.NI; e += G * nw) {
+    for (int e = W - 1 - gw; e < T; e += W) {
         const int k = e / d.NI, f = e - k * d.NI;
         const double cst = imu_cost_wave(p, f, cand + (size_t)k * 16 * d.F, imu, lane);   // in lane 0, zero elsewhere
 #pragma unroll
         for (int kk = 0; kk < WIDE_B; ++kk)
             if (kk == k) acc[4 * kk] += cst;
     }
-    for (int i = blk * nw + wave; i < d.np; i += G * nw) {   // prior rows: one wavefront per row, every candidate
+    WT();
+    if (strided)
+    for (int i = gw; i < d.np; i += wstride) {   // prior rows: one wavefront per row, every candidate
         double sr[WIDE_B];
 #pragma unroll
         for (int k = 0; k < WIDE_B; ++k) sr[k] = 0.0;
@@ -2165,6 +2207,7 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
             if (lane == 0) acc[4 * k] += 0.5 * r * r;
         }
     }
+    WT();
     // ---- block partial sums -> global; the last block to finish reduces and decides.  The 32 sums of a block go through
     // an LDS tile [32][257] (every thread parks its terms as a column; 128 threads add up a quarter row each, 32 combine the
     // quarters): 32 butterfly reductions of doubles -- 12 ds_bpermute each -- took a fifth of this kernel.
@@ -2186,49 +2229,76 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
             p.wide_part[(size_t)blk * 4 * WIDE_B + tid] = ((scratch[4 * tid] + scratch[4 * tid + 1]) + scratch[4 * tid + 2]) + scratch[4 * tid + 3];
     }
     __syncthreads();
+    WT();
     if (tid == 0) {
         __threadfence();
         const unsigned ticket = atomicAdd(&c->wide_ticket, 1u);
         s_last = (ticket == (unsigned)G - 1u) ? 1 : 0;
     }
     __syncthreads();
+#ifdef XRHIP_KPROF
+    if (!s_last && tid == 0 && d.M > 1500 && (blk == 0 || blk == G - 1 || blk == G / 2))
+        printf("kb_trials_wide block %d: load+dogleg %lld cand %lld prior_delta %lld nv %lld obs+rot %lld imu %lld prior %lld reduce %lld (x10ns)\n", blk, tw[1] - tw[0],
+               tw[2] - tw[1], tw[3] - tw[2], tw[4] - tw[3], tw[5] - tw[4], tw[6] - tw[5], tw[7] - tw[6], tw[8] - tw[7]);
+#endif
     if (!s_last) return;
-    __threadfence();
+    WT();
+    // The other blocks' partial sums are read past the caches (device-scope loads) instead of behind a device-scope acquire fence:
+    // that fence invalidates this XCD's L2 and, with the loads behind it, took 7-10 us of the last block (in-kernel timers, round 3).
+    // The ticket orders them: every block's sums are written back (its __threadfence) before its ticket, and these loads are issued
+    // after this block has seen the last ticket.
     if (tid < 4 * WIDE_B) {
+        const double *part = static_cast<const double *>(p.wide_part) + tid;
+        double v[WIDE_G];
+#pragma unroll
+        for (int b = 0; b < WIDE_G; ++b) v[b] = b < G ? __hip_atomic_load(part + (size_t)b * 4 * WIDE_B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         double s2 = 0;
-        for (int b = 0; b < G; ++b) s2 += p.wide_part[(size_t)b * 4 * WIDE_B + tid];   // fixed order
+#pragma unroll
+        for (int b = 0; b < WIDE_G; ++b)
+            if (b < G) s2 += v[b];   // fixed order
         scratch[tid] = s2;
     }
     __syncthreads();
+    WT();
     double tot[4 * WIDE_B];
 #pragma unroll
     for (int q = 0; q < 4 * WIDE_B; ++q) tot[q] = scratch[q];
     double mcc[WIDE_B];
+    TrialTerms terms[WIDE_B];
 #pragma unroll
     for (int k = 0; k < WIDE_B; ++k) {
         if (step_norm[k] < 0) step_norm[k] = sqrt(tot[4 * k + 2]);
         mcc[k] = dogleg_model_change(t, ca[k], cb[k], tot[4 * k + 3]);
+        terms[k] = trial_terms(t, mcc[k], tot[4 * k], tot[4 * k + 1]);
     }
     int accepted = -1;
-    // the decisions, trial by trial: `dup` of them on slot 0's sums, then one per remaining slot
-    for (int j = 0; j < dup + WIDE_B - 1 && t.status == ST_RUNNING; ++j) {
-        const int ks = j < dup ? 0 : j - dup + 1;
-        double m_k = 0, c_k = 0, d_k = 0, s_k = 0;
-#pragma unroll
-        for (int k = 0; k < WIDE_B; ++k)
-            if (k == ks) {
-                m_k = mcc[k];
-                c_k = tot[4 * k];
-                d_k = tot[4 * k + 1];
-                s_k = step_norm[k];
-            }
-        // as the continuation of a rejection run every trial of the batch, the first included, starts with the
-        // finalize step of its rejected predecessor (j + 1 > 0)
 #ifdef XRHIP_KPROF
-        if (tid == 0) p.ctl->prof[19] += 1;
+    int decisions = 0;
 #endif
-        if (trial_decide(t, first ? j : j + 1, m_k, c_k, d_k, s_k)) accepted = ks;
+    // the decisions, trial by trial: `dup` of them on slot 0's sums, then one per remaining slot.  As the continuation of a
+    // rejection run every trial of the batch, the first included, starts with the finalize step of its rejected predecessor
+    // (trial index j + 1 > 0).  (Written as one loop over j with the slot's terms picked by a select chain, the 15-25 decisions
+    // of a launch cost 7 us of issue slots: ~100 instructions each at one wavefront's ~8 cycles per instruction.)
+    int j = 0;
+    for (; j < dup && t.status == ST_RUNNING; ++j) {
+        if (trial_decide(t, first ? j : j + 1, mcc[0], terms[0], step_norm[0])) accepted = 0;
+#ifdef XRHIP_KPROF
+        ++decisions;
+#endif
     }
+#pragma unroll
+    for (int k = 1; k < WIDE_B; ++k) {
+        if (t.status != ST_RUNNING) continue;
+        const int jj = dup + k - 1;
+        if (trial_decide(t, first ? jj : jj + 1, mcc[k], terms[k], step_norm[k])) accepted = k;
+#ifdef XRHIP_KPROF
+        ++decisions;
+#endif
+    }
+#ifdef XRHIP_KPROF
+    if (tid == 0) p.ctl->prof[19] += decisions;
+#endif
+    WT();
     if (accepted >= 0) {
         for (int e = tid; e < 16 * d.F; e += nt) p.state[e] = cand[(size_t)accepted * 16 * d.F + e];
         double cak = 0, cbk = 0;
@@ -2248,7 +2318,15 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
         c->accepted_slot = accepted;
     }
     __syncthreads();
+    WT();
     publish_block(d, p, t.status, seq, true);
+#ifdef XRHIP_KPROF
+    if (tid == 0 && d.M > 1500)
+        printf("kb_trials_wide LAST block %d: load+dogleg %lld cand %lld prior_delta %lld nv %lld obs+rot %lld imu %lld prior %lld reduce %lld ticket %lld fence+sum %lld decide %lld apply %lld publish %lld (x10ns)\n", blk,
+               tw[1] - tw[0], tw[2] - tw[1], tw[3] - tw[2], tw[4] - tw[3], tw[5] - tw[4], tw[6] - tw[5], tw[7] - tw[6], tw[8] - tw[7], tw[9] - tw[8],
+               tw[10] - tw[9], tw[11] - tw[10], tw[12] - tw[11], wall_clock64() - tw[12]);
+#endif
+#undef WT
 }
 
 // Small problems without a free landmark (localize_newframe, refine_subwindow: a handful of free dofs): the three
