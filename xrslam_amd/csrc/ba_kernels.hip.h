@@ -27,7 +27,7 @@ constexpr int OREC = 28;   // per-observation record: Jt(12) Jr(12) jl(2) r(2), 
 constexpr int RREC = 8;
 constexpr int TRY_B = 4;   // trust-region trials costed per sweep after a rejection (inside kb_solve_try)
 constexpr int WIDE_B = 8;  // ... per kb_trials_wide launch
-constexpr int WIDE_G = 64; // workgroups of kb_trials_wide
+constexpr int WIDE_G = 64; // workgroups of kb_trials_wide (128: the last block's 128 loads per sum and the ticket cost what the thinner slices save)
 constexpr int QF_ROWS = 8; // landmark rows a wavefront keeps in flight in the back-substitution
 
 struct BaCtl {   // device-resident solver state (one per context)
@@ -2119,8 +2119,9 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
     const bool split = 2 * T <= W;
     const bool strided = !(split && gw >= W - T);
     const int gtid = blk * nt + tid, gnt = split ? (W - T) * 64 : G * nt, wstride = split ? W - T : W;
+    // (these few items go to the far end of the strided range: its near end is where a second reprojection pair per thread lands)
     if (strided)
-    for (int a = gtid; a < d.NV; a += gnt) {   // step norms / gradient products, landmark part of |x - cand|^2
+    for (int a = gnt - 1 - gtid; a < d.NV; a += gnt) {   // step norms / gradient products, landmark part of |x - cand|^2
         const double g = p.grad[a], gnv = p.gn[a], D = p.diagD[a], gsa = p.gs[a];
         const bool lm = a >= n;
         const double sl = lm ? p.sl[a - n] : 0.0;
@@ -2138,8 +2139,8 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
             }
         }
     }
-    if (blk == 0)
-        for (int e = tid; e < WIDE_B * d.F; e += nt) {
+    if (strided)
+        for (int e = gnt - 1 - gtid - d.NV; e >= 0 && e < WIDE_B * d.F; e += gnt) {
             const int k = e / d.F, f = e - k * d.F;
             const double *a = p.state + 16 * f, *b = cand + (size_t)(k * d.F + f) * 16;
             double s2 = 0;
@@ -2247,17 +2248,25 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
     // that fence invalidates this XCD's L2 and, with the loads behind it, took 7-10 us of the last block (in-kernel timers, round 3).
     // The ticket orders them: every block's sums are written back (its __threadfence) before its ticket, and these loads are issued
     // after this block has seen the last ticket.
-    if (tid < 4 * WIDE_B) {
-        const double *part = static_cast<const double *>(p.wide_part) + tid;
-        double v[WIDE_G];
+    static_assert(WIDE_G % 4 == 0, "the last block adds the partial sums up in four runs of WIDE_G / 4 blocks");
+    __shared__ double quarter[4 * 4 * WIDE_B];
+    if (tid < 4 * 4 * WIDE_B) {   // four threads per sum, a quarter of the blocks each (block order), combined in quarter order below
+        const int q = tid >> 2, w4 = tid & 3;
+        const double *part = static_cast<const double *>(p.wide_part) + q;
+        double v[WIDE_G / 4];
 #pragma unroll
-        for (int b = 0; b < WIDE_G; ++b) v[b] = b < G ? __hip_atomic_load(part + (size_t)b * 4 * WIDE_B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        for (int i = 0; i < WIDE_G / 4; ++i) {
+            const int b = w4 * (WIDE_G / 4) + i;
+            v[i] = b < G ? __hip_atomic_load(part + (size_t)b * 4 * WIDE_B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
         double s2 = 0;
 #pragma unroll
-        for (int b = 0; b < WIDE_G; ++b)
-            if (b < G) s2 += v[b];   // fixed order
-        scratch[tid] = s2;
+        for (int i = 0; i < WIDE_G / 4; ++i)
+            if (w4 * (WIDE_G / 4) + i < G) s2 += v[i];
+        quarter[tid] = s2;
     }
+    __syncthreads();
+    if (tid < 4 * WIDE_B) scratch[tid] = ((quarter[4 * tid] + quarter[4 * tid + 1]) + quarter[4 * tid + 2]) + quarter[4 * tid + 3];
     __syncthreads();
     WT();
     double tot[4 * WIDE_B];
