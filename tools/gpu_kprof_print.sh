@@ -1,10 +1,10 @@
 #!/bin/bash
 # Development iteration (GPU box):  gpurun --timeout 900 -- bash tools/gpu_kprof_print.sh TAG [tests|notests] [PATTERN]
-#   1. the kprof variant's in-kernel printf timers on the default S1 stream -> gpurun_out/blocks_TAG.txt (lines matching PATTERN shown)
+#   1. the kprint variant (XR_VARIANT=kprint build.sh -DXRHIP_KPROF -DXRHIP_KPROF_PRINT): in-kernel printf timers on the default S1 stream -> gpurun_out/blocks_TAG.txt (lines matching PATTERN shown)
 #   2. the default library: BA / pipeline parity tests (unless "notests"), the bench line, a kernel trace (average durations)
 cd "$(dirname "$0")/.."; R=$PWD; TAG="${1:-blk}"; mkdir -p gpurun_out
-XRSLAM_HIP_LIB=$R/xrslam_amd/lib/libxrslam_hip_kprof.so timeout 120 python bench.py --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --threading inline 2>/dev/null | grep -v '^{' > gpurun_out/blocks_$TAG.txt
-grep "${3:-kb_trials_wide}" gpurun_out/blocks_$TAG.txt | grep -v '{' | tail -10
+[ "${3:-}" = NOPRINT ] || XRSLAM_HIP_LIB=$R/xrslam_amd/lib/libxrslam_hip_kprint.so timeout 120 python bench.py --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --threading inline 2>/dev/null | grep -v '^{' > gpurun_out/blocks_$TAG.txt
+[ "${3:-}" = NOPRINT ] || grep "${3:-kb_trials_wide}" gpurun_out/blocks_$TAG.txt | grep -v '{' | tail -10
 if [ "${2:-}" != notests ]; then
   timeout 500 python -m pytest tests/test_ba_gpu.py tests/test_zz_golden_pinned_gpu.py tests/test_pipeline.py tests/test_bench_stream_parity.py -m gpu -x -q > gpurun_out/tests_$TAG.log 2>&1
   tail -3 gpurun_out/tests_$TAG.log

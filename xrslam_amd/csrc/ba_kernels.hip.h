@@ -49,6 +49,9 @@ struct BaCtl {   // device-resident solver state (one per context)
                             // candidate spec_state_block linearised ahead of the decision
     long long prof[32];   // accumulated 100 MHz ticks per kernel phase (only written by -DXRHIP_KPROF builds)
 };
+// -DXRHIP_KPROF: phase sums in BaCtl::prof (tools/kprof_run.sh); -DXRHIP_KPROF_PRINT: per-workgroup timers of the multi-workgroup
+// kernels, printed from the device (tools/gpu_kprof_print.sh) -- how the load imbalances of kb_landmark_vision / kb_schur_aux /
+// kb_trials_wide were found in round 3
 #ifdef XRHIP_KPROF
 #define KPROF_BEGIN() long long kp_t = wall_clock64()
 #define KPROF(slot)                                                   \
@@ -1093,7 +1096,7 @@ __device__ __forceinline__ void solve_aux_block(const BaDims &d, const BaPtrs &p
 // (without free landmarks there is no Schur complement and no W^T (omega gl): only the quadratic-form blocks run)
 // layout of the grid: [Schur tiles | rest of S | aux blocks]
 __global__ __launch_bounds__(256) void kb_schur_aux(BaDims d, BaPtrs p) {
-#ifdef XRHIP_KPROF
+#ifdef XRHIP_KPROF_PRINT
     const long long t0 = wall_clock64();
     struct Tail {
         long long t0;
@@ -1927,12 +1930,12 @@ __host__ __device__ __forceinline__ int lin_all_blocks(int M, int MR, int NI, in
 __global__ __launch_bounds__(64) void kb_landmark_vision(BaDims d, BaPtrs p) {
     __shared__ double red[VIS_RED];
     const int lp = d.lm_rows;
-#ifdef XRHIP_KPROF
+#ifdef XRHIP_KPROF_PRINT
     const long long t0 = wall_clock64();
 #endif
     if ((int)blockIdx.x < lp) landmark_item(d, p, blockIdx.x, threadIdx.x);
     else assemble_vision_item(d, p, ((int)blockIdx.x - lp) / VIS_CH, threadIdx.x, red, ((int)blockIdx.x - lp) % VIS_CH, VIS_CH);
-#ifdef XRHIP_KPROF
+#ifdef XRHIP_KPROF_PRINT
     if (threadIdx.x == 0 && d.M > 1500 && wall_clock64() - t0 > 800)
         printf("kb_landmark_vision block %d of %d+%d*%d (%s): %lld x10ns\n", (int)blockIdx.x, lp, d.F, d.F, (int)blockIdx.x < lp ? "landmark" : "pair", wall_clock64() - t0);
 #endif
@@ -2034,7 +2037,7 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     const int blk = blockIdx.x, G = gridDim.x;
     const int n = d.n;
-#ifdef XRHIP_KPROF
+#ifdef XRHIP_KPROF_PRINT
     long long tw[16];
     int twn = 0;
 #define WT() (tw[twn++] = wall_clock64())
@@ -2237,7 +2240,7 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
         s_last = (ticket == (unsigned)G - 1u) ? 1 : 0;
     }
     __syncthreads();
-#ifdef XRHIP_KPROF
+#ifdef XRHIP_KPROF_PRINT
     if (!s_last && tid == 0 && d.M > 1500 && (blk == 0 || blk == G - 1 || blk == G / 2))
         printf("kb_trials_wide block %d: load+dogleg %lld cand %lld prior_delta %lld nv %lld obs+rot %lld imu %lld prior %lld reduce %lld (x10ns)\n", blk, tw[1] - tw[0],
                tw[2] - tw[1], tw[3] - tw[2], tw[4] - tw[3], tw[5] - tw[4], tw[6] - tw[5], tw[7] - tw[6], tw[8] - tw[7]);
@@ -2329,7 +2332,7 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
     __syncthreads();
     WT();
     publish_block(d, p, t.status, seq, true);
-#ifdef XRHIP_KPROF
+#ifdef XRHIP_KPROF_PRINT
     if (tid == 0 && d.M > 1500)
         printf("kb_trials_wide LAST block %d: load+dogleg %lld cand %lld prior_delta %lld nv %lld obs+rot %lld imu %lld prior %lld reduce %lld ticket %lld fence+sum %lld decide %lld apply %lld publish %lld (x10ns)\n", blk,
                tw[1] - tw[0], tw[2] - tw[1], tw[3] - tw[2], tw[4] - tw[3], tw[5] - tw[4], tw[6] - tw[5], tw[7] - tw[6], tw[8] - tw[7], tw[9] - tw[8],

@@ -500,6 +500,7 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
         R = find_rotation_matrix(cur->bearings, next_bearings, mask, (M_PI / 180.0) * c.rotation_ransac_threshold);
     }
     xrhip::HostProfScope hp_b(6, "ft_track: angles+poisson+append");
+    xrhip::HostProfScope *hp_c = new xrhip::HostProfScope(13, "ft_track: angles");
     std::vector<double> angles;
     for (size_t i = 0; i < mask.size(); ++i)
         if (mask[i]) angles.push_back(std::acos(dot(R * cur->bearings[i], next_bearings[i])) * 180 / M_PI);
@@ -507,6 +508,8 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
     double misalignment = angles.size() > 0 ? angles[angles.size() * 7 / 10] : 0;
     if (misalignment < c.rotation_misalignment_threshold) next->tag(FT_NO_TRANSLATION) = true;
 
+    delete hp_c;
+    hp_c = new xrhip::HostProfScope(14, "ft_track: by_length+poisson");
     std::vector<std::pair<size_t, size_t>> by_length;
     by_length.reserve(n);
     for (size_t i = 0; i < n; ++i) {
@@ -526,6 +529,8 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
             status[ki] = 0;
         }
     }
+    delete hp_c;
+    xrhip::HostProfScope hp_d(15, "ft_track: append");
     for (size_t i = 0; i < n; ++i) {
         if (status[i]) {
             size_t nk = next->keypoint_num();
@@ -1502,6 +1507,7 @@ class SlidingWindowTracker {
 
     void refine_window() {   // :247-358
         WallTimer sc_t(P_.times.scope[SC_REFINE_WINDOW]);
+        xrhip::HostProfScope *hp_a = new xrhip::HostProfScope(17, "refine_window: assembly");
         BaBuilder b(P_);
         if (!map->marginalization_factor) map->marginalization_factor = create_marginalization_factor(map.get());
         // the keyframe intervals are re-integrated at the current biases: queued now, the device works on them while the
@@ -1549,8 +1555,13 @@ class SlidingWindowTracker {
                     b.add_preintegration_error(map->get_frame(j - 1), fj, fj->keyframe_preintegration);
                 }
         }
-        P_.integrate_batch_end();
+        delete hp_a;
+        {
+            xrhip::HostProfScope hp_w(18, "refine_window: batch_end wait");
+            P_.integrate_batch_end();
+        }
         b.solve();
+        xrhip::HostProfScope hp_c(19, "refine_window: landmark sweep");
         const bool log_cull = P_.swt_log.enabled();
         for (size_t k = 0; k < map->track_num(); ++k) {
             Track *t = map->get_track(k);
@@ -1709,6 +1720,7 @@ class SlidingWindowTracker {
                     tgt->preintegration.data.insert(tgt->preintegration.data.begin(), imu.begin(), imu.end());
                 }
             }
+            xrhip::HostProfScope hp_sa(20, "refine_subwindow: assembly..solve");
             BaBuilder b(P_);
             frame->tag(FT_FIX_POSE) = true;
             frame->tag(FT_FIX_MOTION) = true;
@@ -1739,6 +1751,7 @@ class SlidingWindowTracker {
             frame->tag(FT_FIX_POSE) = false;
             frame->tag(FT_FIX_MOTION) = false;
         } else {
+            xrhip::HostProfScope hp_sa(20, "refine_subwindow: assembly..solve");
             BaBuilder b(P_);
             frame->tag(FT_FIX_POSE) = true;
             frame->tag(FT_FIX_MOTION) = true;
