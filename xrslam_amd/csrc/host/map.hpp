@@ -180,6 +180,7 @@ class Track {
     size_t id = 0;
     unsigned long ba_gen = 0;   // see Frame::ba_gen
     int ba_index = -1;
+    unsigned long visit_gen = 0;   // "seen in this sweep" stamp (refine_window walks every track once through its frames' keypoint lists)
     bool tags[TT_COUNT] = {false, false, false, false, true, false, false};   // TT_STATIC set (track.cpp:8)
     size_t map_index = 0;
     Map *map = nullptr;

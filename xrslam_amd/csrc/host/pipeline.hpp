@@ -480,6 +480,9 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
     std::vector<char> status(st8.begin(), st8.begin() + n), mask;
     std::vector<V2> cur_h, next_h;
     std::vector<V3> next_bearings;
+    cur_h.reserve(n);
+    next_h.reserve(n);
+    next_bearings.reserve(n);
     for (size_t i = 0; i < n; ++i) {
         const V3 &b = cur->bearings[i];
         cur_h.push_back({b.x / b.z, b.y / b.z});
@@ -502,6 +505,7 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
     xrhip::HostProfScope hp_b(6, "ft_track: angles+poisson+append");
     xrhip::HostProfScope *hp_c = new xrhip::HostProfScope(13, "ft_track: angles");
     std::vector<double> angles;
+    angles.reserve(mask.size());
     for (size_t i = 0; i < mask.size(); ++i)
         if (mask[i]) angles.push_back(std::acos(dot(R * cur->bearings[i], next_bearings[i])) * 180 / M_PI);
     std::sort(angles.begin(), angles.end());
@@ -1525,13 +1529,13 @@ class SlidingWindowTracker {
         }
         const std::vector<char> ok = P_.integrate_batch_begin(kf_jobs, true, true);
         for (size_t i = 0; i < map->frame_num(); ++i) b.add_frame_states(map->get_frame(i));
-        std::unordered_set<Track *> visited;
+        const unsigned long visit = ++P_.ba_generation;   // (a stamp on the track instead of a hash set: ~400 tracks per window)
         for (size_t i = 0; i < map->frame_num(); ++i) {
             Frame *f = map->get_frame(i);
             for (size_t j = 0; j < f->keypoint_num(); ++j) {
                 Track *t = f->get_track(j);
-                if (!t || visited.count(t)) continue;
-                visited.insert(t);
+                if (!t || t->visit_gen == visit) continue;
+                t->visit_gen = visit;
                 if (!t->tag(TT_VALID) || !t->tag(TT_STATIC)) continue;
                 if (!t->first_frame()->tag(FT_KEYFRAME)) continue;
                 b.add_track_states(t);
@@ -1563,6 +1567,8 @@ class SlidingWindowTracker {
         b.solve();
         xrhip::HostProfScope hp_c(19, "refine_window: landmark sweep");
         const bool log_cull = P_.swt_log.enabled();
+        std::vector<std::pair<const Frame *, PoseState>> cam_cache;
+        cam_cache.reserve(16);
         for (size_t k = 0; k < map->track_num(); ++k) {
             Track *t = map->get_track(k);
             std::unique_lock<std::mutex> log_lock(P_.swt_log.mu, std::defer_lock);
@@ -1589,7 +1595,15 @@ class SlidingWindowTracker {
                 double rpe = 0.0, cnt = 0.0;
                 for (const auto &[f, ki] : t->keypoint_refs) {
                     if (!f->tag(FT_KEYFRAME)) continue;
-                    PoseState pose = f->get_pose(f->camera);
+                    // the camera pose of a keyframe is the same for every track seen in it: formed once per sweep
+                    // (~2000 observations over ~10 keyframes)
+                    PoseState pose;
+                    {
+                        size_t ci = 0;
+                        while (ci < cam_cache.size() && cam_cache[ci].first != f) ++ci;
+                        if (ci == cam_cache.size()) cam_cache.emplace_back(f, f->get_pose(f->camera));
+                        pose = cam_cache[ci].second;
+                    }
                     V3 y = pose.q.conjugate() * (x - pose.p);
                     if (y.z <= 1.0e-3 || y.z > 50) {
                         valid = false;

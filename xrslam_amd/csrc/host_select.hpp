@@ -41,6 +41,24 @@ class PoissonDisk2 {
     bool permit(double x, double y) const {
         const int cx = ix(x), cy = ix(y);
         const int bx = cx - span_, by = cy - span_, ex = cx + span_, ey = cy + span_;
+        // The scan below visits (bx+1 .. ex, by), then (bx .. ex, y) for y = by+1 .. ey, then (bx, ey+1) -- the reference's one-cell-late
+        // box.  When all of it lies inside the dense array (every point the tracker produces), the same cells are read row by row
+        // without the per-cell bounds test and hash fallback; the verdict does not depend on the order the cells are consulted in
+        // (any stored point closer than the radius forbids).
+        if (inside(bx, by) && inside(ex, ey + 1)) {
+            for (int yy = by; yy <= ey + 1; ++yy) {
+                const int x0 = yy == by ? bx + 1 : bx, x1 = yy == ey + 1 ? bx : ex;
+                const int *row = dense_.data() + (size_t)(yy + kMargin) * gw_ + kMargin;
+                for (int xx = x0; xx <= x1; ++xx) {
+                    const int at = row[xx];
+                    if (at >= 0) {
+                        const double dx = x - pts_[2 * at], dy = y - pts_[2 * at + 1];
+                        if (dx * dx + dy * dy < r2_) return false;
+                    }
+                }
+            }
+            return true;
+        }
         int x_it = bx, y_it = by;
         while (y_it <= ey) {
             ++x_it;
