@@ -84,6 +84,11 @@ int xrhip_klt_set_undistort_map(xrhip_klt *ctx, const uint32_t *map2);
 int xrhip_image_upload_distorted(xrhip_image *img, const void *gray, int stride_bytes, int on_device);
 /* parity aid: the 8-bit frame xrhip_image_preprocess will read */
 int xrhip_debug_get_raw(xrhip_image *img, uint8_t *out);
+/* Development / parity aids of the pyramid build (xrhip_image_preprocess): on = 1 (default) builds the CLAHE plane, the three
+   pyrDown levels and all Scharr planes in one launch, 0 in the five launches it replaces (same bits: tests/test_klt_gpu.py);
+   get_level_padded returns a level's image plane including its 21-pixel reflect-101 border (out may be NULL: sizes only). */
+int xrhip_debug_set_fused_pyramid(xrhip_klt *ctx, int on);
+int xrhip_debug_get_level_padded(const xrhip_image *img, int level, uint8_t *out, int *rows, int *cols);
 void xrhip_image_destroy(xrhip_image *img);
 
 /* replaces: Image::preprocess(clipLimit, width, height)  (xrslam.h:153,

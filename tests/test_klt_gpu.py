@@ -62,6 +62,47 @@ def test_preprocess_bit_exact(mods, shape, tiles):
     _assert_pyramid_equal(HA, OA, "noise%dx%d" % shape)
 
 
+@pytest.mark.parametrize("shape,tiles", [((480, 752), 8), ((479, 641), 8), ((720, 1280), 8), ((480, 752), 4), ((352, 353), 8)])
+def test_fused_pyramid_matches_the_five_launch_path_border_included(mods, shape, tiles):
+    """xrhip_image_preprocess builds the pyramid in one launch (k_pyramid); the five launches it replaces stay behind a switch.
+    Same image planes INCLUDING the 21-pixel reflect-101 borders (what the LK windows near the image edge read; the oracle
+    comparison above covers the interiors), same derivative planes, at sizes whose levels are odd / not multiples of the tile."""
+    ko, klt = mods
+    g = noise_image(shape[1], shape[0], seed=77)
+    ctx = klt.KltContext(shape[1], shape[0], 300)
+    planes = {}
+    for fused in (1, 0):
+        ctx.set_fused_pyramid(fused)
+        im = ctx.image(g)
+        im.preprocess(6.0, tiles, tiles)
+        planes[fused] = [(im.level_padded(l),) + im.level(l) for l in range(4)]
+    ctx.set_fused_pyramid(1)
+    for l in range(4):
+        for a, b, what in zip(planes[1][l], planes[0][l], ("padded plane", "image", "derivatives")):
+            if not np.array_equal(a, b):
+                _dump("fused_pyramid_mismatch_%dx%d_l%d" % (shape[1], shape[0], l), fused=a, unfused=b)
+            np.testing.assert_array_equal(a, b, err_msg="level %d %s" % (l, what))
+    OA = ko.OracleImage(g)
+    OA.preprocess(6.0, tiles, tiles)
+    for l in range(4):
+        oi, od = OA.level(l)
+        np.testing.assert_array_equal(planes[1][l][1], oi)
+        np.testing.assert_array_equal(planes[1][l][2], od)
+
+
+def test_small_images_take_the_five_launch_path(mods):
+    """A level narrower than 2 * 21 + 2 pixels needs more than one reflection for its border: those sizes keep the per-level
+    kernels (their reflect101 loops); the result is still the oracle's."""
+    ko, klt = mods
+    g = noise_image(320, 240, seed=5)      # level 3 is 40 x 30
+    ctx = klt.KltContext(320, 240, 100)
+    im = ctx.image(g)
+    im.preprocess(6.0, 8, 8)
+    OA = ko.OracleImage(g)
+    OA.preprocess(6.0, 8, 8)
+    _assert_pyramid_equal(im, OA, "small320x240")
+
+
 def golden_pair_parity(ko, klt, pair, expected, tag):
     """Planes, Harris response, corners, LK positions and status of the HIP path against the committed oracle results
     on one of the golden image pairs; returns (corners detected, points tracked)."""

@@ -48,6 +48,7 @@ struct xrhip_klt {
     hipEvent_t up_done[UP_SLOTS] = {nullptr, nullptr, nullptr};
     bool up_busy[UP_SLOTS] = {false, false, false};
     int up_next = 0;
+    bool fused_pyramid = true;       // xrhip_debug_set_fused_pyramid / XRHIP_NO_FUSED_PYRAMID: the five-launch path (A/B, parity)
     float *resp = nullptr;           // w*h Harris response
     int *max_key = nullptr;          // 1 int (+ candidate counter next to it)
     int *cand_count = nullptr;
@@ -184,6 +185,7 @@ int xrhip_klt_create(int width, int height, int max_points, xrhip_klt **out) {
     c->w = width;
     c->h = height;
     c->max_points = max_points;
+    c->fused_pyramid = std::getenv("XRHIP_NO_FUSED_PYRAMID") == nullptr;
     XR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->lut_tiles = 0;
     XR_HIP(hipMalloc(&c->resp, sizeof(float) * (size_t)width * height));
@@ -360,6 +362,27 @@ int xrhip_image_upload_distorted(xrhip_image *im, const void *gray, int stride, 
     return XRHIP_OK;
 }
 
+/* parity aids: the one-launch pyramid build on / off for this context; a level's plane WITH its border (rows = h + 2 pad, the
+   first `cols` = w + 2 pad columns of each padded row, pad = 21) */
+int xrhip_debug_set_fused_pyramid(xrhip_klt *c, int on) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_debug_set_fused_pyramid: null context");
+    c->fused_pyramid = on != 0;
+    return XRHIP_OK;
+}
+int xrhip_debug_get_level_padded(const xrhip_image *im, int level, uint8_t *out, int *rows, int *cols) {
+    if (!im || level < 0 || level >= KLT_LEVELS || !rows || !cols) return xr_fail(XRHIP_EINVAL, "xrhip_debug_get_level_padded: bad arguments");
+    if (!im->have_pyramid) return xr_fail(XRHIP_ESTATE, "xrhip_debug_get_level_padded: preprocess() has not run");
+    const LevelBuf &L = im->lv[level];
+    *rows = L.h + 2 * KLT_PAD;
+    *cols = L.w + 2 * KLT_PAD;
+    if (!out) return XRHIP_OK;
+    xrhip_klt *c = im->ctx;
+    XR_HIP(hipMemcpy2DAsync(out, (size_t)*cols, L.img - (ptrdiff_t)KLT_PAD * L.istride - KLT_PAD, L.istride, (size_t)*cols, (size_t)*rows,
+                            hipMemcpyDeviceToHost, c->stream));
+    XR_HIP(hipStreamSynchronize(c->stream));
+    return XRHIP_OK;
+}
+
 /* parity aid: the 8-bit frame preprocess() will read (after an upload / the device undistortion) */
 int xrhip_debug_get_raw(xrhip_image *im, uint8_t *out) {
     if (!im || !out) return xr_fail(XRHIP_EINVAL, "xrhip_debug_get_raw: null argument");
@@ -404,8 +427,43 @@ int xrhip_image_preprocess(xrhip_image *im, double clip_limit, int tiles_x, int 
         if (clip < 1) clip = 1;
     }
     ProfScope prof(c, CAT_PRE);
-    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles), dim3(256), 0, c->stream, im->raw, w, w, h, tw, th, tiles_x, clip,
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles), dim3(CL_THREADS), 0, c->stream, im->raw, w, w, h, tw, th, tiles_x, clip,
                        lut_scale, c->lut);
+    // the pyramid and its derivatives: two launches (k_pyr_a, k_pyr_b) when every level is large enough for its border to be one
+    // reflection away, else (or with the development switch) the five launches they replace
+    bool fused = c->fused_pyramid;
+    for (int l = 0; l < KLT_LEVELS; ++l) fused = fused && im->lv[l].w >= 2 * KLT_PAD + 2 && im->lv[l].h >= 2 * KLT_PAD + 2;
+    if (fused) {
+        PyrAArgs pa;
+        pa.raw = im->raw;
+        pa.rstride = w;
+        pa.tw = tw;
+        pa.th = th;
+        pa.tiles_x = tiles_x;
+        pa.tiles_y = tiles_y;
+        pa.lut = c->lut;
+        pa.img0 = im->lv[0].img;
+        pa.img1 = im->lv[1].img;
+        pa.der0 = im->lv[0].der;
+        pa.w0 = im->lv[0].w; pa.h0 = im->lv[0].h; pa.s0 = im->lv[0].istride;
+        pa.w1 = im->lv[1].w; pa.h1 = im->lv[1].h; pa.s1 = im->lv[1].istride;
+        pa.tiles_across = (w + PA_T - 1) / PA_T;
+        hipLaunchKernelGGL(k_pyr_a, dim3(pa.tiles_across * ((h + PA_T - 1) / PA_T)), dim3(PF_THREADS), 0, c->stream, pa);
+        PyrBArgs pb;
+        for (int l = 0; l < KLT_LEVELS; ++l) {
+            pb.img[l] = im->lv[l].img;
+            pb.der[l] = im->lv[l].der;
+            pb.w[l] = im->lv[l].w;
+            pb.h[l] = im->lv[l].h;
+            pb.istride[l] = im->lv[l].istride;
+        }
+        pb.tiles_across = (pb.w[1] + PB_T - 1) / PB_T;
+        hipLaunchKernelGGL(k_pyr_b, dim3(pb.tiles_across * ((pb.h[1] + PB_T - 1) / PB_T)), dim3(PF_THREADS), 0, c->stream, pb);
+        XR_HIP(hipGetLastError());
+        prof.finish();
+        im->have_pyramid = true;
+        return XRHIP_OK;
+    }
     {
         LevelBuf &L = im->lv[0];
         dim3 blk(64, 4);

@@ -55,22 +55,22 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // ---------------------------------------------------------------- CLAHE LUT
 // One workgroup per tile: LDS histogram, clip + redistribute, inclusive scan,
 // LUT.  (cv::CLAHE_CalcLut_Body restated; integer exact.)
-__global__ __launch_bounds__(256) void k_clahe_lut(const uint8_t *__restrict__ src, int sstride, int w, int h,
-                                                   int tw, int th, int tiles_x, int clip, float lut_scale,
-                                                   uint8_t *__restrict__ lut) {
-    __shared__ int hist[4][256];   // one histogram per wavefront: neighbouring pixels share grey levels, a single one serialises its atomics
+constexpr int CL_THREADS = 1024;   // sixteen wavefronts count a tile's pixels (one batch of loads each), four of them finish the LUT
+__global__ __launch_bounds__(CL_THREADS) void k_clahe_lut(const uint8_t *__restrict__ src, int sstride, int w, int h,
+                                                          int tw, int th, int tiles_x, int clip, float lut_scale,
+                                                          uint8_t *__restrict__ lut) {
+    __shared__ int hist[CL_THREADS / 64][256];   // one histogram per wavefront: neighbouring pixels share grey levels, a single one serialises its atomics
     __shared__ int scan[2][256];
     const int tid = threadIdx.x, wv = tid >> 6;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) hist[q][tid] = 0;
+    for (int i = tid; i < (CL_THREADS / 64) * 256; i += CL_THREADS) (&hist[0][0])[i] = 0;
     __syncthreads();
     const int area = tw * th;
-    for (int i0 = tid; i0 < area; i0 += 8 * 256) {   // eight pixel loads in flight per thread, then their (exact, integer) counts
+    for (int i0 = tid; i0 < area; i0 += 8 * CL_THREADS) {   // eight pixel loads in flight per thread, then their (exact, integer) counts
         int px[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = min(i0 + u * 256, area - 1);
+            const int i = min(i0 + u * CL_THREADS, area - 1);
             const int y = i / tw;
             const int x = i - y * tw;
             const int gx = reflect101(tx * tw + x, w), gy = reflect101(ty * th + y, h);
@@ -78,17 +78,23 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint8_t *__restrict__ s
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (i0 + u * 256 < area) atomicAdd(&hist[wv][px[u]], 1);
+            if (i0 + u * CL_THREADS < area) atomicAdd(&hist[wv][px[u]], 1);
     }
     __syncthreads();
-    int hv = (hist[0][tid] + hist[1][tid]) + (hist[2][tid] + hist[3][tid]);
+    const bool fin = tid < 256;   // the clip / redistribute / scan steps are 256 wide: the other wavefronts only keep the barriers
+    const int t = tid & 255;
+    int hv = 0;
+    if (fin) {
+#pragma unroll
+        for (int q = 0; q < CL_THREADS / 64; ++q) hv += hist[q][t];
+    }
     if (clip > 0) {
         int excess = hv > clip ? hv - clip : 0;
         if (hv > clip) hv = clip;
-        scan[0][tid] = excess;
+        if (fin) scan[0][t] = excess;
         __syncthreads();
         for (int s = 128; s > 0; s >>= 1) {
-            if (tid < s) scan[0][tid] += scan[0][tid + s];
+            if (fin && t < s) scan[0][t] += scan[0][t + s];
             __syncthreads();
         }
         int clipped = scan[0][0];
@@ -99,24 +105,27 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint8_t *__restrict__ s
         if (residual != 0) {
             int step = 256 / residual;
             if (step < 1) step = 1;
-            if (tid % step == 0 && tid / step < residual) hv++;
+            if (t % step == 0 && t / step < residual) hv++;
         }
     }
     // inclusive scan (Hillis-Steele, double buffered)
     int cur = 0;
-    scan[0][tid] = hv;
+    if (fin) scan[0][t] = hv;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
-        int v = scan[cur][tid];
-        if (tid >= off) v += scan[cur][tid - off];
-        scan[cur ^ 1][tid] = v;
+        if (fin) {
+            int v = scan[cur][t];
+            if (t >= off) v += scan[cur][t - off];
+            scan[cur ^ 1][t] = v;
+        }
         cur ^= 1;
         __syncthreads();
     }
-    int sum = scan[cur][tid];
+    if (!fin) return;
+    int sum = scan[cur][t];
     int v = __float2int_rn((float)sum * lut_scale);
     v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    lut[(size_t)blockIdx.x * 256 + tid] = (uint8_t)v;
+    lut[(size_t)blockIdx.x * 256 + t] = (uint8_t)v;
 }
 
 // -------------------------------------------------------------- CLAHE apply
@@ -209,6 +218,220 @@ __global__ __launch_bounds__(256) void k_scharr(ScharrArgs a) {
     d.x = (short)(t0p - t0m);
     d.y = (short)((t1p + t1m) * 3 + t1c * 10);
     a.out[l][(ptrdiff_t)y * L.pstride + x] = d;
+}
+
+// ------------------------------------------------------- fused pyramid build
+// The CLAHE plane, the three pyrDown levels and the Scharr derivatives of all four levels in TWO launches instead of five
+// (k_clahe_apply + 3 x k_pyrdown + k_scharr):
+//   k_pyr_a  level 0 (CLAHE interpolation) + level 1 + the level-0 derivatives; one workgroup per 32x32 tile of level 0
+//   k_pyr_b  levels 2, 3 + the derivatives of levels 1, 2, 3 from the level-1 plane; one workgroup per 32x32 tile of level 1
+// A workgroup builds its tile of every level it owns in LDS, together with the halo the level above and its own Scharr stencil
+// read, so it depends on nothing another workgroup of the same launch writes:
+//   k_pyr_a: level 1 16x16 <- level 0 35x35 (2 * 16 + 3; 1.2x the tile)
+//   k_pyr_b: level 3 8 + 2 = 10 <- level 2 2 * 10 + 3 = 23 <- level 1 2 * 23 + 3 = 49 (read from the padded level-1 plane)
+// A value at a coordinate outside the image is what the padded planes hold there: the level's own value at the reflect-101
+// coordinate (k_clahe_apply / k_pyrdown write their borders that way), i.e. the SAME integer expressions evaluated at the
+// reflected output coordinate -- bit-identical planes.  The 21-pixel border of each plane is written by the workgroup that owns
+// the mirrored interior pixel.  Halo entries further than two pixels outside the image are never read by a valid output (a
+// pyrDown tap reaches at most 2 * (w' - 1) + 2 <= w + 1); their reflected sources may fall outside the tile and are clamped.
+// (First version: all four levels in one launch, 64x64 tiles with a 101x101 level-0 halo -- 2.5x redundant CLAHE work on 96 of
+// the 256 CUs: 17.4 us against 23.5 us for the five kernels it replaced, profiles/r03_ab_variants.md.)
+// Used when every level is at least 2 * KLT_PAD + 2 wide and high (one reflection covers the border); otherwise the five-launch
+// path runs.
+constexpr int PF_THREADS = 256;
+__device__ __forceinline__ int pf_reflect(int i, int n) {   // one reflection, then clamped (far halo entries: see above)
+    if (i < 0) i = -i;
+    else if (i >= n) i = 2 * (n - 1) - i;
+    return min(max(i, 0), n - 1);
+}
+// store a plane value at (x, y) and at its mirror images inside the KLT_PAD border
+__device__ __forceinline__ void pf_store(uint8_t *img, int stride, int w, int h, int x, int y, uint8_t v) {
+    img[(ptrdiff_t)y * stride + x] = v;
+    const bool xl = x >= 1 && x <= KLT_PAD, xr = x <= w - 2 && x >= w - 1 - KLT_PAD;
+    const bool yt = y >= 1 && y <= KLT_PAD, yb = y <= h - 2 && y >= h - 1 - KLT_PAD;
+    if (!(xl || xr || yt || yb)) return;   // (nearly every pixel; whole wavefronts in the interior tiles)
+    int xs[3], ys[3], nx = 1, ny = 1;
+    xs[0] = x;
+    ys[0] = y;
+    if (xl) xs[nx++] = -x;
+    if (xr) xs[nx++] = 2 * (w - 1) - x;
+    if (yt) ys[ny++] = -y;
+    if (yb) ys[ny++] = 2 * (h - 1) - y;
+    for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i)
+            if (i + j) img[(ptrdiff_t)ys[j] * stride + xs[i]] = v;
+}
+// Scharr derivative of one level from its LDS tile (calcSharrDeriv, as k_scharr) for the tile's valid output pixels:
+// P = LDS row pitch, LO = halo below the tile origin, S = tile size, (X, Y) = tile origin
+template <int P, int LO, int S>
+__device__ __forceinline__ void pf_scharr(const uint8_t *T, int X, int Y, int w, int h, short2 *der, int stride, int tid) {
+    for (int i = tid; i < S * S; i += PF_THREADS) {
+        const int ly = i / S, lx = i - ly * S, x = X + lx, y = Y + ly;
+        if (x >= w || y >= h) continue;
+        const uint8_t *r1 = T + (ly + LO) * P + lx + LO, *r0 = r1 - P, *r2 = r1 + P;
+        const int t0m = (r0[-1] + r2[-1]) * 3 + r1[-1] * 10;
+        const int t0p = (r0[1] + r2[1]) * 3 + r1[1] * 10;
+        const int t1m = r2[-1] - r0[-1], t1c = r2[0] - r0[0], t1p = r2[1] - r0[1];
+        short2 d;
+        d.x = (short)(t0p - t0m);
+        d.y = (short)((t1p + t1m) * 3 + t1c * 10);
+        der[(ptrdiff_t)y * stride + x] = d;
+    }
+}
+// one pyrDown step LDS -> LDS (+ the plane): destination tile RD x RD (halo LOD, SD x SD outputs) at level origin (XD, YD) of a
+// wd x hd level, from the source tile (extent RS, pitch PS) whose entry (0, 0) is source coordinate (2 XD - LOS, 2 YD - LOS)
+template <int RD, int PD, int LOD, int SD, int RS, int PS, int LOS>
+__device__ __forceinline__ void pf_down(const uint8_t *Ts, uint8_t *Td, int XD, int YD, int wd, int hd, uint8_t *img, int stride,
+                                        int tid) {
+    const int XS = 2 * XD, YS = 2 * YD;
+    for (int i = tid; i < RD * RD; i += PF_THREADS) {
+        const int ry = i / RD, rx = i - ry * RD;
+        const int x = XD - LOD + rx, y = YD - LOD + ry;
+        const int ox = pf_reflect(x, wd), oy = pf_reflect(y, hd);
+        const int cx = min(max(2 * ox - 2 - (XS - LOS), 0), RS - 5), cy = min(max(2 * oy - 2 - (YS - LOS), 0), RS - 5);
+        const uint8_t *s0 = Ts + cy * PS + cx;
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int wj = (j == 0 || j == 4) ? 1 : ((j == 2) ? 6 : 4);
+            const uint8_t *r = s0 + j * PS;
+            const int row = r[0] + r[4] + 4 * (r[1] + r[3]) + 6 * r[2];
+            acc += wj * row;
+        }
+        const uint8_t v = (uint8_t)((acc + 128) >> 8);
+        Td[ry * PD + rx] = v;
+        if (rx >= LOD && rx < LOD + SD && ry >= LOD && ry < LOD + SD && x < wd && y < hd) pf_store(img, stride, wd, hd, x, y, v);
+    }
+}
+
+constexpr int PA_T = 32;                      // k_pyr_a: level-0 tile
+constexpr int PA_R0 = 35, PA_LO0 = 2, PA_P0 = 36;   // level-0 LDS tile: [X0 - 2, X0 + 33)
+constexpr int PA_R1 = 16, PA_P1 = 16;        // level-1 tile (no halo: nothing above it in this launch)
+struct PyrAArgs {
+    const uint8_t *raw;
+    int rstride;
+    int tw, th, tiles_x, tiles_y;   // CLAHE tile grid
+    const uint8_t *lut;
+    uint8_t *img0, *img1;           // pixel (0,0) of the padded planes
+    short2 *der0;
+    int w0, h0, s0, w1, h1, s1;
+    int tiles_across;
+};
+__global__ __launch_bounds__(PF_THREADS) void k_pyr_a(PyrAArgs a) {
+    __shared__ uint8_t T0[PA_R0 * PA_P0], T1[PA_R1 * PA_P1];
+    __shared__ int cs[PA_R0], ci1[PA_R0], ci2[PA_R0], rs[PA_R0], rp1[PA_R0], rp2[PA_R0];
+    __shared__ float cxa[PA_R0], cxa1[PA_R0], rya[PA_R0], rya1[PA_R0];
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x % a.tiles_across, by = blockIdx.x / a.tiles_across;
+    const int X0 = PA_T * bx, Y0 = PA_T * by;
+    // ---- level 0: CLAHE interpolation (cv::CLAHE_Interpolation_Body, the float expressions of k_clahe_apply).  What depends on the
+    // column alone (source column, the two LUT columns, the horizontal weights) and on the row alone is formed once per tile column /
+    // row; a pixel is then four LUT bytes and seven float operations.
+    const int w = a.w0, h = a.h0;
+    if (tid < PA_R0) {
+        const float inv_tw = 1.0f / a.tw;
+        const int sx = pf_reflect(X0 - PA_LO0 + tid, w);
+        float txf = sx * inv_tw - 0.5f;
+        int tx1 = (int)floorf(txf);
+        int tx2 = tx1 + 1;
+        const float xa = txf - tx1, xa1 = 1.0f - xa;
+        if (tx1 < 0) tx1 = 0;
+        if (tx2 > a.tiles_x - 1) tx2 = a.tiles_x - 1;
+        cs[tid] = sx;
+        ci1[tid] = tx1 * 256;
+        ci2[tid] = tx2 * 256;
+        cxa[tid] = xa;
+        cxa1[tid] = xa1;
+    } else if (tid >= 64 && tid < 64 + PA_R0) {
+        const int r = tid - 64;
+        const float inv_th = 1.0f / a.th;
+        const int sy = pf_reflect(Y0 - PA_LO0 + r, h);
+        float tyf = sy * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf);
+        int ty2 = ty1 + 1;
+        const float ya = tyf - ty1, ya1 = 1.0f - ya;
+        if (ty1 < 0) ty1 = 0;
+        if (ty2 > a.tiles_y - 1) ty2 = a.tiles_y - 1;
+        rs[r] = sy;
+        rp1[r] = ty1 * a.tiles_x * 256;
+        rp2[r] = ty2 * a.tiles_x * 256;
+        rya[r] = ya;
+        rya1[r] = ya1;
+    }
+    __syncthreads();
+    {   // (the frame's pixels first, all of a thread's loads in flight together, then the interpolation)
+        constexpr int N0 = (PA_R0 * PA_R0 + PF_THREADS - 1) / PF_THREADS;
+        int pix[N0];
+#pragma unroll
+        for (int u = 0; u < N0; ++u) {
+            const int i = min(tid + u * PF_THREADS, PA_R0 * PA_R0 - 1);
+            const int ry = i / PA_R0, rx = i - ry * PA_R0;
+            pix[u] = a.raw[(size_t)rs[ry] * a.rstride + cs[rx]];
+        }
+#pragma unroll
+        for (int u = 0; u < N0; ++u) {
+            const int i = tid + u * PF_THREADS;
+            if (i >= PA_R0 * PA_R0) break;
+            const int ry = i / PA_R0, rx = i - ry * PA_R0;
+            const int v = pix[u];
+            const uint8_t *p1 = a.lut + rp1[ry], *p2 = a.lut + rp2[ry];
+            const int i1 = ci1[rx] + v, i2 = ci2[rx] + v;
+            const float xa = cxa[rx], xa1 = cxa1[rx], ya = rya[ry], ya1 = rya1[ry];
+            const float res = (p1[i1] * xa1 + p1[i2] * xa) * ya1 + (p2[i1] * xa1 + p2[i2] * xa) * ya;
+            int r = __float2int_rn(res);
+            r = r < 0 ? 0 : (r > 255 ? 255 : r);
+            T0[ry * PA_P0 + rx] = (uint8_t)r;
+            const int x = X0 - PA_LO0 + rx, y = Y0 - PA_LO0 + ry;
+            if (rx >= PA_LO0 && rx < PA_LO0 + PA_T && ry >= PA_LO0 && ry < PA_LO0 + PA_T && x < w && y < h)
+                pf_store(a.img0, a.s0, w, h, x, y, (uint8_t)r);
+        }
+    }
+    __syncthreads();
+    pf_down<PA_R1, PA_P1, 0, PA_T / 2, PA_R0, PA_P0, PA_LO0>(T0, T1, X0 >> 1, Y0 >> 1, a.w1, a.h1, a.img1, a.s1, tid);
+    pf_scharr<PA_P0, PA_LO0, PA_T>(T0, X0, Y0, w, h, a.der0, a.s0, tid);
+}
+
+constexpr int PB_T = 32;                                  // k_pyr_b: level-1 tile = 16x16 of level 2 = 8x8 of level 3
+constexpr int PB_R1 = 49, PB_R2 = 23, PB_R3 = 10;        // LDS tile extents
+constexpr int PB_LO1 = 10, PB_LO2 = 4, PB_LO3 = 1;       // halo below the tile origin
+constexpr int PB_P1 = 52, PB_P2 = 24, PB_P3 = 12;        // LDS row pitches
+struct PyrBArgs {
+    uint8_t *img[KLT_LEVELS];       // pixel (0,0) of each padded plane (level 1: read, with its border; 2, 3: written)
+    short2 *der[KLT_LEVELS];
+    int w[KLT_LEVELS], h[KLT_LEVELS], istride[KLT_LEVELS];
+    int tiles_across;
+};
+__global__ __launch_bounds__(PF_THREADS) void k_pyr_b(PyrBArgs a) {
+    __shared__ uint8_t T1[PB_R1 * PB_P1], T2[PB_R2 * PB_P2], T3[PB_R3 * PB_P3];
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x % a.tiles_across, by = blockIdx.x / a.tiles_across;
+    const int X1 = PB_T * bx, Y1 = PB_T * by;
+    {   // the level-1 tile with its halo, straight from the padded plane (halo <= 10 + 6 < KLT_PAD); coordinates beyond the
+        // plane's border (tiles past the image's last row / column: never read by a valid output) are clamped into it
+        const int w = a.w[1], h = a.h[1];
+        constexpr int N1 = (PB_R1 * PB_R1 + PF_THREADS - 1) / PF_THREADS;
+        uint8_t px[N1];
+#pragma unroll
+        for (int u = 0; u < N1; ++u) {   // all of a thread's loads in flight together
+            const int i = min(tid + u * PF_THREADS, PB_R1 * PB_R1 - 1);
+            const int ry = i / PB_R1, rx = i - ry * PB_R1;
+            const int x = min(X1 - PB_LO1 + rx, w + KLT_PAD - 1), y = min(Y1 - PB_LO1 + ry, h + KLT_PAD - 1);
+            px[u] = a.img[1][(ptrdiff_t)y * a.istride[1] + x];
+        }
+#pragma unroll
+        for (int u = 0; u < N1; ++u) {
+            const int i = tid + u * PF_THREADS;
+            if (i < PB_R1 * PB_R1) T1[(i / PB_R1) * PB_P1 + (i % PB_R1)] = px[u];
+        }
+    }
+    __syncthreads();
+    pf_down<PB_R2, PB_P2, PB_LO2, PB_T / 2, PB_R1, PB_P1, PB_LO1>(T1, T2, X1 >> 1, Y1 >> 1, a.w[2], a.h[2], a.img[2], a.istride[2], tid);
+    pf_scharr<PB_P1, PB_LO1, PB_T>(T1, X1, Y1, a.w[1], a.h[1], a.der[1], a.istride[1], tid);
+    __syncthreads();
+    pf_down<PB_R3, PB_P3, PB_LO3, PB_T / 4, PB_R2, PB_P2, PB_LO2>(T2, T3, X1 >> 2, Y1 >> 2, a.w[3], a.h[3], a.img[3], a.istride[3], tid);
+    pf_scharr<PB_P2, PB_LO2, PB_T / 2>(T2, X1 >> 1, Y1 >> 1, a.w[2], a.h[2], a.der[2], a.istride[2], tid);
+    __syncthreads();
+    pf_scharr<PB_P3, PB_LO3, PB_T / 4>(T3, X1 >> 2, Y1 >> 2, a.w[3], a.h[3], a.der[3], a.istride[3], tid);
 }
 
 // ------------------------------------------------------------------- Harris

@@ -45,6 +45,8 @@ def _bind():
     L.xrhip_klt_set_undistort_map.argtypes = [vp, vp]
     L.xrhip_image_upload_distorted.argtypes = [vp, vp, C.c_int, C.c_int]
     L.xrhip_debug_get_raw.argtypes = [vp, vp]
+    L.xrhip_debug_set_fused_pyramid.argtypes = [vp, C.c_int]
+    L.xrhip_debug_get_level_padded.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return L
 
 
@@ -91,6 +93,10 @@ class KltContext:
 
     def synchronize(self):
         check(L().xrhip_klt_synchronize(self._h))
+
+    def set_fused_pyramid(self, on):
+        """Development / parity switch: preprocess() builds the pyramid in one launch (default) or in the five it replaces."""
+        check(L().xrhip_debug_set_fused_pyramid(self._h, 1 if on else 0))
 
     def set_undistort_map(self, map2):
         """Packed 1/32-pixel inverse map [h][w][2] uint32 (include/xrslam_hip.h), or None to switch the device
@@ -204,6 +210,14 @@ class HipImage:
         der = np.empty((h.value, w.value, 2), np.int16)
         check(L().xrhip_image_download_level(self._h, l, _p(img), _p(der)))
         return img, der
+
+    def level_padded(self, l):
+        """Level l's image plane with its 21-pixel reflect-101 border (what the LK windows read near the edges)."""
+        rows, cols = C.c_int(), C.c_int()
+        check(L().xrhip_debug_get_level_padded(self._h, l, None, C.byref(rows), C.byref(cols)))
+        out = np.empty((rows.value, cols.value), np.uint8)
+        check(L().xrhip_debug_get_level_padded(self._h, l, _p(out), C.byref(rows), C.byref(cols)))
+        return out
 
     def harris(self):
         out = np.empty((self.ctx.h, self.ctx.w), np.float32)
