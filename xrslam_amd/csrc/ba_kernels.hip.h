@@ -389,7 +389,7 @@ __device__ __forceinline__ void lin_imu_item(const BaDims &d, const BaPtrs &p, c
 // rotation part), then one of the four independent parts of the raw Jacobians; the 15x15 whitening of the residual and of
 // both Jacobians is then one pass over the 256 threads.  Same expressions, entry by entry, as lin_imu_item -- which gave
 // a factor ONE wavefront, i.e. one lane for ~25 us of dependent SO(3) algebra, the long pole of kb_lin_all.
-// scr: IMU_SCR doubles of LDS owned by the workgroup.
+// scr: IMU_SCR + IMU_XCH doubles of LDS owned by the workgroup.
 __device__ __forceinline__ void lin_imu_block(const BaDims &d, const BaPtrs &p, const Ext &imu, int k, double *scr) {
     double *raw = scr, *Ji = scr + 15, *Jj = scr + 240;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -398,16 +398,37 @@ __device__ __forceinline__ void lin_imu_block(const BaDims &d, const BaPtrs &p, 
     const bool active = !(p.fix[fi] == 3 && p.fix[fj] == 3);
     for (int i = tid; i < 450; i += 256) Ji[i] = 0.0;   // Ji and Jj are contiguous
     __syncthreads();
+    // kb_chain's schedule (ba_chain.hip.h; the pieces are bit-identical to the single-lane forms, tests/test_ba_math_host.py): the
+    // rotation residual -- the long chain -- runs ONCE, on wavefront 3, followed by what needs only it (Jr^-1, B) and the rest of the
+    // residual; the other wavefronts meanwhile form the parts of the Jacobians that do not depend on it; two short products finish.
+    // (Before: every wavefront's lane 0 ran the whole residual, then one of four Jacobian parts: ~8 of kb_lin_all's 11 us.)
+    double *xch = scr + IMU_SCR;
+    const bool nfi = p.fix[fi] != 3, nfj = p.fix[fj] != 3;
     if (lane == 0 && active) {
         const FState si = load_state(p.state + 16 * fi), sj = load_state(p.state + 16 * fj);
         const ImuRec pre = load_imu(data);
         const V3 bg0 = v3(p.bias_ref[6 * k], p.bias_ref[6 * k + 1], p.bias_ref[6 * k + 2]);
         const V3 ba0 = v3(p.bias_ref[6 * k + 3], p.bias_ref[6 * k + 4], p.bias_ref[6 * k + 5]);
-        double r15[15];
-        imu_raw_residual(si, sj, pre, bg0, ba0, imu, r15);
-        if (wave == 0)
-            for (int i = 0; i < 15; ++i) raw[i] = r15[i];
-        imu_raw_jacobians_part(wave, si, sj, pre, bg0, ba0, imu, v3(r15[0], r15[1], r15[2]), Ji, Jj, p.fix[fi] != 3, p.fix[fj] != 3);
+        if (wave == 3) {
+            const V3 rq = imu_residual_rq(si, sj, pre, bg0, imu);
+            raw[0] = rq.x;
+            raw[1] = rq.y;
+            raw[2] = rq.z;
+            store33(xch + 45, imu_jac_jrinv(rq));
+            if (nfi) store33(xch + 36, imu_jac_B(rq));
+            imu_residual_rest(si, sj, pre, bg0, ba0, imu, raw);
+        } else if (wave == 0) {
+            imu_raw_jacobians_part(2, si, sj, pre, bg0, ba0, imu, v3(0, 0, 0), Ji, Jj, nfi, nfj);
+        } else if (wave == 1) {
+            imu_jac_pre(si, sj, pre, bg0, imu, xch, nfi, nfj);
+        } else {
+            imu_raw_jacobians_part(3, si, sj, pre, bg0, ba0, imu, v3(0, 0, 0), Ji, Jj, nfi, nfj);
+        }
+    }
+    __syncthreads();
+    if (lane == 0 && active) {
+        if (wave == 0) imu_jac_finish0(load33(xch + 45), xch, Ji, Jj, nfi, nfj);
+        else if (wave == 1) imu_jac_finish1(load33(xch + 45), load33(xch + 36), xch, load33(data + 11), Ji, nfi);
     }
     __syncthreads();
     const double *S = data + 56;
@@ -1891,7 +1912,7 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
 // all four factor families at once: [obs | rot | imu (one factor per block) | prior (1 block)]
 __global__ __launch_bounds__(256) void kb_lin_all(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy) {
     extern __shared__ double sh[];   // np doubles (prior role)
-    __shared__ double scr[IMU_SCR];
+    __shared__ double scr[IMU_SCR + IMU_XCH];   // lin_imu_block: raw residual + the two raw Jacobians | the pieces' exchange area
     __shared__ double scratch[8];
     const int nbo = (d.M + 255) / 256, nbr = (d.MR + 255) / 256, nbi = d.NI;
     int blk = blockIdx.x;
