@@ -239,6 +239,13 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
 void xrhip_ba_destroy(xrhip_ba *ctx);
 /* replaces: Solver::solve() over a problem assembled with add_frame_states/add_track_states/add_factor */
 int xrhip_ba_solve(xrhip_ba *ctx, const xrhip_ba_problem *problem, xrhip_ba_summary *summary);
+/* xrhip_ba_solve with a piece of the CALLER's host work run beside the device: host_work(arg) is called exactly once, on the
+ * calling thread, after the solve's first launches are queued and before the library waits for them (before returning, if
+ * the problem needs no launch at all or the solve fails earlier).  It must not touch the problem's arrays or this context; it may
+ * use other contexts (the sliding-window tracker runs the corner selection of the next frame's detection -- an xrhip_klt call and
+ * host logic -- beside localize_newframe's solve, which does not read what that selection appends).  Same results as
+ * xrhip_ba_solve. */
+int xrhip_ba_solve_overlapped(xrhip_ba *ctx, const xrhip_ba_problem *problem, xrhip_ba_summary *summary, void (*host_work)(void *), void *arg);
 
 /* HIP-event profiling of the dominant BA kernel (kb_solve_try: reduced-system Cholesky + trust-region trials),
  * off by default.  flops = algorithmic work of the launches:

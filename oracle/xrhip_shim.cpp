@@ -172,6 +172,12 @@ int xrhip_ba_create(int, int, int, xrhip_ba **out) {
 void xrhip_ba_destroy(xrhip_ba *c) { delete c; }
 int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *begin, const int *count, const double *t_end,
                                 const double *bg, const double *ba, int n_jobs, const double *noise36, int jac, int cov);
+int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *s);
+int xrhip_ba_solve_overlapped(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *s, void (*host_work)(void *), void *arg) {
+    const int rc = xrhip_ba_solve(c, P, s);   // nothing to overlap with on the CPU: the solve, then the caller's work
+    if (host_work) host_work(arg);
+    return rc;
+}
 int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *s) {
     if (c && c->have_deferred && P)   // like the product: a bad frame index is refused before the solve touches anything
         for (int f : c->deferred.frame)

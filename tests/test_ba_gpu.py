@@ -387,6 +387,26 @@ def test_schur_precision_knob_is_a_study_aid_that_resets(ctx, bo):
         ctx.set_schur_precision(7)
 
 
+def test_overlapped_solve_runs_the_host_work_once_and_changes_nothing(ctx):
+    """xrhip_ba_solve_overlapped: the caller's host work runs exactly once beside the device's (the sliding-window tracker puts the
+    next detection's corner selection there), for the single-launch solves, the multi-launch window solves and a problem that needs
+    no launch at all; states and summaries are those of xrhip_ba_solve, bit for bit."""
+    loc = bs.make_localize(seed=9)[0]
+    win = bs.make_window(K=8, L=100, seed=43)[0]
+    fixed = bs.make_localize(seed=9)[0]
+    fixed.frame_fix[:] = 3                      # nothing free: the solve returns without a launch
+    for pd in (loc, win, fixed):
+        a, b = pd.copy(), pd.copy()
+        sa = ctx.solve(a)
+        calls = []
+        sb = ctx.solve(b, host_work=lambda: calls.append(1))
+        assert calls == [1]
+        np.testing.assert_array_equal(a.frame_state, b.frame_state)
+        np.testing.assert_array_equal(a.inv_depth, b.inv_depth)
+        assert (sa.iterations, sa.termination, sa.usable) == (sb.iterations, sb.termination, sb.usable)
+        assert sa.final_cost == sb.final_cost
+
+
 def test_one_preintegration_batch_in_flight_per_context(ctx):
     """A second xrhip_ba_preintegrate_begin without _end is refused (it would overwrite the staging block the first batch's kernel
     writes its record into); xrhip_ba_preintegrate_cancel releases the context; a fresh begin / end then gives the blocking call's

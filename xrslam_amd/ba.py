@@ -8,6 +8,8 @@ from ._lib import check
 
 _L = None
 
+HOST_WORK = C.CFUNCTYPE(None, C.c_void_p)   # void (*host_work)(void *)
+
 
 def configure(lib):
     """Declares the argument types of the plug point's entry points on `lib` (the product library, or -- in tests -- the CPU
@@ -17,6 +19,7 @@ def configure(lib):
     lib.xrhip_ba_destroy.argtypes = [vp]
     lib.xrhip_ba_destroy.restype = None
     lib.xrhip_ba_solve.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary)]
+    lib.xrhip_ba_solve_overlapped.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary), HOST_WORK, vp]
     if hasattr(lib, "xrhip_ba_marginalize"):
         lib.xrhip_ba_marginalize.argtypes = [vp, C.POINTER(abi.MargProblem), vp, vp, vp]
     if hasattr(lib, "xrhip_ba_marginalize_begin"):
@@ -88,11 +91,16 @@ class BaContext:
         except Exception:
             pass
 
-    def solve(self, pd):
-        """Solver::solve(): optimises pd.frame_state / pd.inv_depth in place; returns abi.BaSummary."""
+    def solve(self, pd, host_work=None):
+        """Solver::solve(): optimises pd.frame_state / pd.inv_depth in place; returns abi.BaSummary.
+        host_work: a callable run once beside the device's work (xrhip_ba_solve_overlapped)."""
         s = pd.struct()
         sm = abi.BaSummary()
-        check(self._lib.xrhip_ba_solve(self._h, C.byref(s), C.byref(sm)))
+        if host_work is None:
+            check(self._lib.xrhip_ba_solve(self._h, C.byref(s), C.byref(sm)))
+        else:
+            cb = HOST_WORK(lambda _arg: host_work())
+            check(self._lib.xrhip_ba_solve_overlapped(self._h, C.byref(s), C.byref(sm), cb, None))
         return sm
 
     def marginalize(self, md):

@@ -84,6 +84,8 @@ struct xrhip_ba {
     const uint4 *stage_src = nullptr;      // the staged problem: pinned host block (device-visible address) -> device arena
     uint4 *stage_dst = nullptr;
     size_t stage_n16 = 0;
+    void (*overlap_fn)(void *) = nullptr;   // xrhip_ba_solve_overlapped: pending host work of the caller (run at the first wait)
+    void *overlap_arg = nullptr;
     double *h_out = nullptr;  // pinned readback (states + depths)
     size_t h_out_cap = 0;
     int lds_limit = 150 * 1024;
@@ -572,7 +574,15 @@ static int launch_solve_try(xrhip_ba *c, const BaDims &d, const BaPtrs &p, const
 // Spin on the sequence number kb_solve_try stores (system-scope release) after its results: completion is seen a
 // few microseconds after the kernel's last store, where a blocking hipStreamSynchronize costs 20-30 us.
 // hipStreamQuery is polled now and then so that a faulted kernel turns into an error instead of a hang.
+// xrhip_ba_solve_overlapped: the caller's host work runs here, once, at the solve's first wait
+static void run_overlap(xrhip_ba *c) {
+    if (!c->overlap_fn) return;
+    void (*fn)(void *) = c->overlap_fn;
+    c->overlap_fn = nullptr;
+    fn(c->overlap_arg);
+}
 static int wait_mailbox(xrhip_ba *c, int seq, hipStream_t publisher = nullptr) {
+    run_overlap(c);
     volatile int *flag = c->h_seq;
     for (unsigned long spin = 1;; ++spin) {
         if (*flag == seq) return XRHIP_OK;
@@ -699,6 +709,14 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *sum
     if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: null context");
     const int rc = ba_solve_impl(c, P, summary);
     if (rc) c->preint_deferred = 0;   // a batch staged behind a solve that failed must not ride on the next, unrelated one
+    return rc;
+}
+int xrhip_ba_solve_overlapped(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary, void (*host_work)(void *), void *arg) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_overlapped: null context");
+    c->overlap_fn = host_work;
+    c->overlap_arg = arg;
+    const int rc = xrhip_ba_solve(c, P, summary);
+    run_overlap(c);   // no launch was waited for (trivial problem, early error): the work is still the caller's to get done
     return rc;
 }
 static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary) {

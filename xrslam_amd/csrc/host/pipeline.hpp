@@ -707,7 +707,24 @@ class BaBuilder {
         for (size_t o : const_imu_) imu_i_[o] = frame_copy(imu_i_[o]);
     }
 
-    bool solve(double *elapsed_device_ms = nullptr) {
+    // Host work of the caller that does not depend on this solve, run once beside it (xrhip_ba_solve_overlapped); exceptions it
+    // throws are re-thrown after the solve has returned (the context is never left with a launch nobody waited for).
+    struct Overlap {
+        std::function<void()> fn;
+        bool done = false;
+        std::exception_ptr error;
+        void run() {
+            if (done) return;
+            done = true;
+            try {
+                if (fn) fn();
+            } catch (...) {
+                error = std::current_exception();
+            }
+        }
+        static void trampoline(void *self) { static_cast<Overlap *>(self)->run(); }
+    };
+    bool solve(double *elapsed_device_ms = nullptr, Overlap *overlap = nullptr) {
         xrhip::HostProfScope hp_s(10, "BaBuilder::solve (all)");
         const Config &c = P_.config;
         split_aliased_constants();
@@ -773,7 +790,14 @@ class BaBuilder {
         WallTimer wt_w_solve(P_.times.w_solve);
         if (chain_f_ && chain_f_->ba_gen == gen_)
             chain_queued_ = P_.integrate_after_solve_begin(chain_samples_, chain_t_, chain_f_->ba_index, true, true);
-        hip_check(xrhip_ba_solve(P_.ba, &pb, &sm), "xrhip_ba_solve");
+        if (overlap) {
+            const int rc = xrhip_ba_solve_overlapped(P_.ba, &pb, &sm, &Overlap::trampoline, overlap);
+            overlap->run();
+            if (overlap->error) std::rethrow_exception(overlap->error);
+            hip_check(rc, "xrhip_ba_solve_overlapped");
+        } else {
+            hip_check(xrhip_ba_solve(P_.ba, &pb, &sm), "xrhip_ba_solve");
+        }
         for (int f = 0; f < F; ++f)
             if (fix_[f] != (XRHIP_FIX_POSE | XRHIP_FIX_MOTION)) unpack_state(&state[16 * (size_t)f], frames_[f], fix_[f]);
         for (int l = 0; l < L; ++l)
@@ -1135,11 +1159,11 @@ class SlidingWindowTracker {
         pk.valid = true;
         return pk;
     }
-    void mirror_frame(Map *ft_map, size_t frame_id) {
+    bool mirror_frame(Map *ft_map, size_t frame_id) {
         feature_tracking_map_ = ft_map;
-        mirror_frame(make_mirror_packet(ft_map, frame_id, newest_frame_id()));
+        return mirror_frame(make_mirror_packet(ft_map, frame_id, newest_frame_id()));
     }
-    void mirror_frame(MirrorPacket pk) {
+    bool mirror_frame(MirrorPacket pk) {   // true: the frame is now the newest frame of the window map
         xrhip::HostProfScope hp_m(7, "mirror_frame");
         WallTimer sc_t(P_.times.scope[SC_MIRROR]);
         Frame *keyframe = map->get_frame(map->frame_num() - 1);
@@ -1147,7 +1171,7 @@ class SlidingWindowTracker {
         if (!keyframe->subframes.empty()) new_i = keyframe->subframes.back().get();
         if (!pk.valid || pk.from_id != new_i->id) {
             cancel_prepared();
-            return;
+            return false;
         }
         const size_t frame_id = pk.frame_id;
         std::unique_ptr<Frame> curr = std::move(pk.frame);
@@ -1208,13 +1232,21 @@ class SlidingWindowTracker {
             memo_id_ = nil();
         }
         predict(new_j->preintegration, new_i, new_j);
+        return true;
     }
 
-    bool track() {   // :82-117
+    // `overlap`: host work of the caller that localize_newframe's solve does not depend on (the feature tracker's corner selection
+    // for the frame just mirrored), run beside that solve; done by the time this returns.
+    bool track(BaBuilder::Overlap *overlap = nullptr) {   // :82-117
         if (P_.config.parsac_flag) {
+            if (overlap) {   // (the RD-VIO checks look at every keypoint of the new frame: finish it first)
+                overlap->run();
+                if (overlap->error) std::rethrow_exception(overlap->error);
+                overlap = nullptr;
+            }
             if (judge_track_status()) update_track_status();
         }
-        localize_newframe();
+        localize_newframe(overlap);
         size_t log_id = 0, log_mapped = 0;
         bool log_nt = false;
         if (P_.swt_log.enabled()) {   // the inputs manage_keyframe is about to look at
@@ -1404,7 +1436,7 @@ class SlidingWindowTracker {
     double parsac_th_ = 0.0;
     Map *feature_tracking_map_ = nullptr;
 
-    void localize_newframe() {   // :119-143
+    void localize_newframe(BaBuilder::Overlap *overlap = nullptr) {   // :119-143
         WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
         xrhip::HostProfScope *hp_a = new xrhip::HostProfScope(12, "localize: problem assembly");
         BaBuilder b(P_);
@@ -1417,7 +1449,7 @@ class SlidingWindowTracker {
             if (Track *t = fj->get_track(k))
                 if (t->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) b.add_reprojection_prior(fj, k);
         delete hp_a;
-        b.solve();
+        b.solve(nullptr, overlap);
     }
 
     bool manage_keyframe() {   // :145-223
@@ -2525,7 +2557,16 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
             last->image->release_image_buffer();
         }
         preprocess();
-        if (swt_tag) frame_detect_keypoints(P, frame.get());
+        // Inline mode, tracking: the detection's host half -- waiting for the selection kernel, the greedy min-distance pass, the
+        // Poisson-disk filter: ~30 us -- runs beside localize_newframe's solve instead of in front of it.  That solve reads the
+        // keypoints of the new frame that carry triangulated tracks; the detection only APPENDS keypoints without tracks (their
+        // tracks are created when the next frame is tracked: no id is taken here), so the frame is mirrored first and the new
+        // keypoints are appended to both copies afterwards: the same frames, tracks and ids as detecting first.  (Not with the
+        // decision log on -- its records are written in the reference's order.)
+        static const bool no_overlap = std::getenv("XRSLAM_AMD_NO_DETECT_OVERLAP") != nullptr;   // development switch (A/B, parity)
+        const bool overlap_detect = swt_tag && swt && !pipelined() && !P.swt_log.enabled() && !no_overlap;
+        if (swt_tag && !overlap_detect) frame_detect_keypoints(P, frame.get());
+        Frame *const attached = frame.get();
         map->attach_frame(std::move(frame));
         if (P.swt_log.enabled()) {   // the tracking map's side of mirror_frame: which track every keypoint of the last two frames is on
             std::lock_guard<std::mutex> log_lock(P.swt_log.mu);
@@ -2545,11 +2586,12 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         size_t max_frames = is_initialized ? c.feature_tracker_max_frames : c.feature_tracker_max_init_frames;
         while (map->frame_num() > max_frames && map->get_frame(0)->id < opt_id) map->erase_frame(0);
         P.times.frames++;
-        if (swt_tag) frontend_work(map->get_frame(map->frame_num() - 1)->id);
+        if (swt_tag) frontend_work(map->get_frame(map->frame_num() - 1)->id, overlap_detect ? attached : nullptr);
     }
 
     // -------- FrontendWorker::work (core/frontend_worker.cpp:28-86)
-    void frontend_work(size_t pending_frame_id) {
+    // detect_later: inline tracking mode -- the frame whose detection has not run yet (see feature_tracker_work)
+    void frontend_work(size_t pending_frame_id, Frame *detect_later = nullptr) {
         if (!swt) {
             init.mirror_keyframe_map(ft_map.get(), pending_frame_id);
             if ((swt = init.initialize())) {
@@ -2588,6 +2630,23 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
             }
             inflight_id_ = pending_frame_id;
             inflight_joined_ = false;
+        } else if (detect_later) {
+            const bool mirrored = swt->mirror_frame(ft_map.get(), pending_frame_id);
+            Frame *const copy = mirrored ? swt->map->get_frame(swt->map->frame_num() - 1) : nullptr;
+            BaBuilder::Overlap ov;
+            ov.fn = [this, detect_later, copy] {
+                const size_t n0 = detect_later->keypoint_num();
+                frame_detect_keypoints(P, detect_later);
+                if (copy)
+                    for (size_t k = n0; k < detect_later->keypoint_num(); ++k) copy->append_keypoint(detect_later->get_keypoint(k));
+            };
+            const bool ok = swt->track(&ov);
+            ov.run();   // (a path of track() that never reached the solve)
+            if (ov.error) std::rethrow_exception(ov.error);
+            if (ok) {
+                auto [t, pose, motion] = swt->get_latest_state();
+                frontend_latest_state = {t, pending_frame_id, pose, motion};
+            }
         } else {
             swt->mirror_frame(ft_map.get(), pending_frame_id);
             if (swt->track()) {
