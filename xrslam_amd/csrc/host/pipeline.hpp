@@ -1260,6 +1260,7 @@ class SlidingWindowTracker {
         const bool is_kf = manage_keyframe();
         if (is_kf) {
             P_.times.keyframes++;
+            queue_keyframe_integrations();
             track_landmark();
             refine_window();
             take_mirror_hint();   // the newest frame's biases are final: the next interval integrates beside slide_window
@@ -1283,8 +1284,11 @@ class SlidingWindowTracker {
             std::fprintf(fp, "]}\n");
             std::fflush(fp);
         }
-        speculate_subframes();
-        take_mirror_hint();
+        {
+            xrhip::HostProfScope hp_sp(24, "track: speculate_subframes + hint");
+            speculate_subframes();
+            take_mirror_hint();
+        }
         return true;
     }
 
@@ -1541,13 +1545,12 @@ class SlidingWindowTracker {
         }
     }
 
-    void refine_window() {   // :247-358
-        WallTimer sc_t(P_.times.scope[SC_REFINE_WINDOW]);
-        xrhip::HostProfScope *hp_a = new xrhip::HostProfScope(17, "refine_window: assembly");
-        BaBuilder b(P_);
-        if (!map->marginalization_factor) map->marginalization_factor = create_marginalization_factor(map.get());
-        // the keyframe intervals are re-integrated at the current biases: queued now, the device works on them while the
-        // host walks the tracks below; the records are read when the problem is handed over (BaBuilder::solve)
+    // refine_window's first step, callable ahead of it: nothing between manage_keyframe and the window solve changes the frames,
+    // their samples or their biases (track_landmark triangulates tracks), and the batch (~10 intervals of 20-40 samples, 60-100 us on
+    // the device) was still 37 us short of done when the assembly had finished.
+    std::vector<char> kf_ok_;
+    bool kf_queued_ = false;
+    void queue_keyframe_integrations() {
         std::vector<Pipeline::IntegrateJob> kf_jobs;
         for (size_t j = 1; j < map->frame_num(); ++j) {
             Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
@@ -1559,7 +1562,21 @@ class SlidingWindowTracker {
             }
             kf_jobs.push_back({&fj->keyframe_preintegration, fj->image->t, fi->motion.bg, fi->motion.ba});
         }
-        const std::vector<char> ok = P_.integrate_batch_begin(kf_jobs, true, true);
+        kf_ok_ = P_.integrate_batch_begin(kf_jobs, true, true);
+        kf_queued_ = true;
+    }
+
+    void refine_window() {   // :247-358
+        WallTimer sc_t(P_.times.scope[SC_REFINE_WINDOW]);
+        xrhip::HostProfScope *hp_a = new xrhip::HostProfScope(17, "refine_window: assembly");
+        BaBuilder b(P_);
+        if (!map->marginalization_factor) map->marginalization_factor = create_marginalization_factor(map.get());
+        // the keyframe intervals are re-integrated at the current biases: queued by track() before track_landmark (the device works on
+        // them while the host triangulates and walks the tracks below); the records are read when the problem is handed over
+        // (BaBuilder::solve)
+        if (!kf_queued_) queue_keyframe_integrations();
+        kf_queued_ = false;
+        const std::vector<char> &ok = kf_ok_;
         for (size_t i = 0; i < map->frame_num(); ++i) b.add_frame_states(map->get_frame(i));
         const unsigned long visit = ++P_.ba_generation;   // (a stamp on the track instead of a hash set: ~400 tracks per window)
         for (size_t i = 0; i < map->frame_num(); ++i) {
@@ -1771,7 +1788,11 @@ class SlidingWindowTracker {
             frame->tag(FT_FIX_POSE) = true;
             frame->tag(FT_FIX_MOTION) = true;
             b.add_frame_states(frame);
-            integrate_subframes_begin(frame);
+            {
+                xrhip::HostProfScope hp_i(21, "refine_subwindow: integrate_subframes_begin");
+                integrate_subframes_begin(frame);
+            }
+            xrhip::HostProfScope *hp_l = new xrhip::HostProfScope(22, "refine_subwindow: factor loops");
             for (size_t i = 0; i < frame->subframes.size(); ++i) {
                 Frame *sf = frame->subframes[i].get();
                 b.add_frame_states(sf);
@@ -1790,7 +1811,11 @@ class SlidingWindowTracker {
                     }
                 }
             }
-            P_.integrate_batch_end();
+            delete hp_l;
+            {
+                xrhip::HostProfScope hp_w(23, "refine_subwindow: batch_end wait");
+                P_.integrate_batch_end();
+            }
             chain_mirror_hint(b, frame->subframes.back().get());
             b.solve();
             chained_solve_done(b);

@@ -9,7 +9,7 @@
 namespace xrhip {
 
 struct HostProf {
-    static constexpr int N = 24;
+    static constexpr int N = 32;
     double sec[N] = {0};
     long calls[N] = {0};
     const char *name[N] = {nullptr};
