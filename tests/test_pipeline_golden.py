@@ -10,6 +10,7 @@ import pytest
 from tests.golden import make_pipeline_poses as gen
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_poses.npz")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("mode,name", [(0, "inline"), (1, "pipelined")])
@@ -54,3 +55,40 @@ def test_getters_between_frames_do_not_move_the_pipelined_trajectory():
     s.close()
     np.testing.assert_array_equal(counts, g["pipelined_counts"])
     np.testing.assert_allclose(poses[:, 1:], g["pipelined_poses"][:, 1:], rtol=1e-9, atol=1e-12)
+
+
+def test_overlapped_detection_order_is_the_reference_order_bit_for_bit():
+    """Inline tracking runs the detection's host half (and the rotation-misalignment test that sets FT_NO_TRANSLATION) beside
+    localize_newframe's solve: the frame is mirrored first, the new keypoints and the tag reach both copies afterwards
+    (pipeline.hpp, feature_tracker_work).  XRSLAM_AMD_NO_DETECT_OVERLAP=1 restores the reference's order -- detect, then mirror.
+    Same poses, bit for bit, on a stream with a rotation-only phase (the tag is taken, subframes are merged and re-attached)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from tests.test_swt_model import PausingTrajectory, ORACLE_LIB, SLAM
+from xrslam_amd.harness import runner, scene
+seq = scene.make_sequence(n_frames=150, seed=1, traj=PausingTrajectory(9.0, 10.6))
+s = runner.Session(ORACLE_LIB, seq, slam_yaml=SLAM)
+while s.step():
+    assert not s.error(), s.error()
+s.flush()
+t = s.times()
+np.save(sys.argv[1], np.array(s.poses))
+print(t.frames, t.solves, t.keyframes, t.marginalizations)
+s.close()
+''' % ROOT
+    outs = []
+    for env_extra in ({}, {"XRSLAM_AMD_NO_DETECT_OVERLAP": "1"}):
+        env = dict(os.environ)
+        env.pop("XRSLAM_AMD_DUMP_SWT", None)
+        env.update(env_extra)
+        path = os.path.join(ROOT, "gpurun_out", "overlap_order_%d.npy" % len(outs))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((np.load(path), r.stdout.strip().splitlines()[-1]))
+    assert outs[0][1] == outs[1][1]                      # frames, solves, keyframes, marginalisations
+    assert len(outs[0][0]) >= 100
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])

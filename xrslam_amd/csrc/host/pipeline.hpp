@@ -446,7 +446,10 @@ inline void frame_detect_keypoints(Pipeline &P, Frame *f) {   // frame.cpp:55-72
     for (int i = 0; i < n_new; ++i) f->append_keypoint(remove_k(V2{fresh[2 * i], fresh[2 * i + 1]}, f->K));
 }
 
-inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // frame.cpp:74-174
+// deferred_tag: when given, the rotation-misalignment test that decides the new frame's FT_NO_TRANSLATION tag (an arc cosine per
+// inlier and a sort: ~9 us) is not run here but handed back; the caller runs it -- with the window map's copy of the frame, if one has
+// been made meanwhile -- before anything reads the tag (manage_keyframe does, after localize_newframe).
+inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next, std::function<void(Frame *)> *deferred_tag = nullptr) {   // frame.cpp:74-174
     WallTimer sc_t(P.times.scope[SC_FT_TRACK]);
     const Config &c = P.config;
     const size_t n = cur->keypoint_num();
@@ -504,13 +507,27 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next) {   // f
     }
     xrhip::HostProfScope hp_b(6, "ft_track: angles+poisson+append");
     xrhip::HostProfScope *hp_c = new xrhip::HostProfScope(13, "ft_track: angles");
-    std::vector<double> angles;
-    angles.reserve(mask.size());
-    for (size_t i = 0; i < mask.size(); ++i)
-        if (mask[i]) angles.push_back(std::acos(dot(R * cur->bearings[i], next_bearings[i])) * 180 / M_PI);
-    std::sort(angles.begin(), angles.end());
-    double misalignment = angles.size() > 0 ? angles[angles.size() * 7 / 10] : 0;
-    if (misalignment < c.rotation_misalignment_threshold) next->tag(FT_NO_TRANSLATION) = true;
+    {
+        // (R * cur->bearings[i] and next_bearings[i] of the inliers, in keypoint order: everything the test reads, by value)
+        std::vector<std::pair<V3, V3>> pairs;
+        pairs.reserve(mask.size());
+        for (size_t i = 0; i < mask.size(); ++i)
+            if (mask[i]) pairs.emplace_back(R * cur->bearings[i], next_bearings[i]);
+        const double threshold = c.rotation_misalignment_threshold;
+        auto decide = [pairs = std::move(pairs), threshold, next](Frame *copy) {
+            std::vector<double> angles;
+            angles.reserve(pairs.size());
+            for (const auto &pr : pairs) angles.push_back(std::acos(dot(pr.first, pr.second)) * 180 / M_PI);
+            std::sort(angles.begin(), angles.end());
+            const double misalignment = angles.size() > 0 ? angles[angles.size() * 7 / 10] : 0;
+            if (misalignment < threshold) {
+                next->tag(FT_NO_TRANSLATION) = true;
+                if (copy) copy->tag(FT_NO_TRANSLATION) = true;
+            }
+        };
+        if (deferred_tag) *deferred_tag = std::move(decide);
+        else decide(nullptr);
+    }
 
     delete hp_c;
     hp_c = new xrhip::HostProfScope(14, "ft_track: by_length+poisson");
@@ -892,12 +909,16 @@ inline void marginalize_frame(Pipeline &P, Map *map, size_t index) {   // Map::m
     if (!prior) throw std::logic_error("marginalization_factor is not initialized yet");
     resolve_marginalization(P, prior);   // the previous result is this one's input
     const int K = (int)map->frame_num();
-    std::unordered_map<Frame *, int> fidx;
+    // frame -> index in this problem: BaBuilder's generation stamp on the frame (a hash map here was looked up once per observation,
+    // ~2000 times per marginalisation)
+    const unsigned long gen = ++P.ba_generation;
+    auto fidx_of = [gen](const Frame *f) { return f->ba_gen == gen ? f->ba_index : -1; };
     auto job = std::make_shared<MargJob>();
     std::vector<double> &state = job->state;
     state.resize(16 * (size_t)K);
     for (int i = 0; i < K; ++i) {
-        fidx[map->get_frame(i)] = i;
+        map->get_frame(i)->ba_gen = gen;
+        map->get_frame(i)->ba_index = i;
         BaBuilder::pack_state(map->get_frame(i), &state[16 * (size_t)i]);
     }
     xrhip_marg_problem &mp = job->mp;
@@ -917,7 +938,10 @@ inline void marginalize_frame(Pipeline &P, Map *map, size_t index) {   // Map::m
     mp.sqrt_inv_cov[0] = any->sqrt_inv_cov[0];
     mp.sqrt_inv_cov[1] = any->sqrt_inv_cov[1];
     std::vector<int> &pframes = job->pframes;
-    for (Frame *f : prior->frames) pframes.push_back(fidx.at(f));
+    for (Frame *f : prior->frames) {
+        if (fidx_of(f) < 0) throw std::out_of_range("marginalize_frame: prior frame is not in the window");
+        pframes.push_back(fidx_of(f));
+    }
     mp.prior_n = (int)pframes.size();
     mp.prior_frames = pframes.data();
     // (the prior's arrays are read in place: nothing writes them before resolve_marginalization, which waits for the launch)
@@ -940,23 +964,25 @@ inline void marginalize_frame(Pipeline &P, Map *map, size_t index) {   // Map::m
     std::vector<int> &ot = job->ot, &orf = job->orf, &ol = job->ol;
     std::vector<double> &zt = job->zt, &zr = job->zr, &depth = job->depth;
     Frame *victim = map->get_frame(index);
+    ot.reserve(2048); orf.reserve(2048); ol.reserve(2048); zt.reserve(3 * 2048); zr.reserve(3 * 2048); depth.reserve(512);
     for (size_t j = 0; j < victim->keypoint_num(); ++j) {
         Track *track = victim->get_track(j);
         if (!track || !track->tag(TT_VALID)) continue;
         Frame *ref = track->first_frame();
         if (!ref->tag(FT_KEYFRAME)) continue;
-        const int fr = fidx.at(ref);   // the reference indexes frame_indices.at(frame_ref) unconditionally
+        const int fr = fidx_of(ref);   // the reference indexes frame_indices.at(frame_ref) unconditionally
+        if (fr < 0) throw std::out_of_range("marginalize_frame: reference frame is not in the window");
         const size_t kr = track->keypoint_refs.at(ref);
         int l = -1;
         for (const auto &[tgt, ki] : track->keypoint_refs) {
             if (tgt == ref) continue;
-            auto it = fidx.find(tgt);
-            if (it == fidx.end()) continue;
+            const int ft_i = fidx_of(tgt);
+            if (ft_i < 0) continue;
             if (l < 0) {
                 l = (int)depth.size();
                 depth.push_back(track->landmark.inv_depth);
             }
-            ot.push_back(it->second);
+            ot.push_back(ft_i);
             orf.push_back(fr);
             ol.push_back(l);
             const V3 &a = tgt->get_keypoint(ki), &b = ref->get_keypoint(kr);
@@ -2494,6 +2520,9 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         bool is_initialized = opt_id != nil();
         bool swt_tag = !is_initialized || frame->id % c.sliding_window_tracker_frequent == 0;
         Map *map = ft_map.get();
+        static const bool no_overlap = std::getenv("XRSLAM_AMD_NO_DETECT_OVERLAP") != nullptr;   // development switch (A/B, parity)
+        const bool overlap_detect = swt_tag && swt && !pipelined() && !P.swt_log.enabled() && !no_overlap;   // see below, at the detection
+        std::function<void(Frame *)> deferred_tag;
         if (map->frame_num() > 0) {
             Frame *last = map->get_frame(map->frame_num() - 1);
             if (!last->preintegration.data.empty()) {
@@ -2574,7 +2603,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
             // counter the two maps share (P.ids): mirror_frame's new window-map tracks take their ids before this frame's new
             // tracking-map tracks do, as inline -- ids are reproducible and the counter is never touched by both threads at once.
             if (pipelined()) wait_mirror();
-            frame_track_keypoints(P, last, frame.get());
+            frame_track_keypoints(P, last, frame.get(), overlap_detect ? &deferred_tag : nullptr);
             if (is_initialized) {
                 predict(frame->preintegration, last, frame.get());
                 ft_latest_state = LatestState{frame->image->t, frame->pose, frame->motion};
@@ -2588,8 +2617,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         // tracks are created when the next frame is tracked: no id is taken here), so the frame is mirrored first and the new
         // keypoints are appended to both copies afterwards: the same frames, tracks and ids as detecting first.  (Not with the
         // decision log on -- its records are written in the reference's order.)
-        static const bool no_overlap = std::getenv("XRSLAM_AMD_NO_DETECT_OVERLAP") != nullptr;   // development switch (A/B, parity)
-        const bool overlap_detect = swt_tag && swt && !pipelined() && !P.swt_log.enabled() && !no_overlap;
+        // (The misalignment test that sets the frame's FT_NO_TRANSLATION tag -- read by manage_keyframe, after the solve -- rides along.)
         if (swt_tag && !overlap_detect) frame_detect_keypoints(P, frame.get());
         Frame *const attached = frame.get();
         map->attach_frame(std::move(frame));
@@ -2611,12 +2639,12 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         size_t max_frames = is_initialized ? c.feature_tracker_max_frames : c.feature_tracker_max_init_frames;
         while (map->frame_num() > max_frames && map->get_frame(0)->id < opt_id) map->erase_frame(0);
         P.times.frames++;
-        if (swt_tag) frontend_work(map->get_frame(map->frame_num() - 1)->id, overlap_detect ? attached : nullptr);
+        if (swt_tag) frontend_work(map->get_frame(map->frame_num() - 1)->id, overlap_detect ? attached : nullptr, std::move(deferred_tag));
     }
 
     // -------- FrontendWorker::work (core/frontend_worker.cpp:28-86)
     // detect_later: inline tracking mode -- the frame whose detection has not run yet (see feature_tracker_work)
-    void frontend_work(size_t pending_frame_id, Frame *detect_later = nullptr) {
+    void frontend_work(size_t pending_frame_id, Frame *detect_later = nullptr, std::function<void(Frame *)> deferred_tag = nullptr) {
         if (!swt) {
             init.mirror_keyframe_map(ft_map.get(), pending_frame_id);
             if ((swt = init.initialize())) {
@@ -2659,7 +2687,8 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
             const bool mirrored = swt->mirror_frame(ft_map.get(), pending_frame_id);
             Frame *const copy = mirrored ? swt->map->get_frame(swt->map->frame_num() - 1) : nullptr;
             BaBuilder::Overlap ov;
-            ov.fn = [this, detect_later, copy] {
+            ov.fn = [this, detect_later, copy, &deferred_tag] {
+                if (deferred_tag) deferred_tag(copy);
                 const size_t n0 = detect_later->keypoint_num();
                 frame_detect_keypoints(P, detect_later);
                 if (copy)
