@@ -445,3 +445,26 @@ def test_preintegration_queued_behind_a_solve_cpu_shim():
     np.testing.assert_array_equal(b.frame_state, pd.frame_state)
     ctx.solve(b)                                                                    # and the context is usable again
     ctx.close()
+
+
+def test_overlapped_solve_cpu_shim():
+    """xrhip_ba_solve_overlapped through the CPU shim: the caller's host work runs exactly once and the solve's results are those of
+    xrhip_ba_solve (the device path's half of this is tests/test_ba_gpu.py::test_overlapped_solve_runs_the_host_work_once_...)."""
+    import ctypes
+    from tests import ba_snapshots
+    from xrslam_amd import ba
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libxrslam_oracle.so")
+    if not os.path.exists(shim):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(os.path.dirname(shim))])
+    ctx = ba.BaContext(lib=ba.configure(ctypes.CDLL(shim)))
+    for name, pd, _exp in ba_snapshots.load_all()[:2]:
+        a, b = pd.copy(), pd.copy()
+        sa = ctx.solve(a)
+        calls = []
+        sb = ctx.solve(b, host_work=lambda: calls.append(1))
+        assert calls == [1], name
+        np.testing.assert_array_equal(a.frame_state, b.frame_state, err_msg=name)
+        np.testing.assert_array_equal(a.inv_depth, b.inv_depth, err_msg=name)
+        assert (sa.iterations, sa.termination, sa.final_cost) == (sb.iterations, sb.termination, sb.final_cost)
+    ctx.close()

@@ -54,6 +54,7 @@ struct HipImage {
     Pipeline *owner = nullptr;
     double t = 0;
     int w = 0, hgt = 0;
+    bool preprocessed = false;   // the CLAHE / pyramid / gradient launches were queued when the frame was handed over (Pipeline::make_image)
     ~HipImage();
     void release_image_buffer();
 };

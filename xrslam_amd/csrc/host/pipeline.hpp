@@ -266,6 +266,16 @@ struct Pipeline {
         if (undistort_on_device) hip_check(xrhip_image_upload_distorted(img->h, gray, stride, device_ptr ? 1 : 0), "xrhip_image_upload_distorted");
         else if (device_ptr) hip_check(xrhip_image_upload_device(img->h, gray, stride), "xrhip_image_upload_device");
         else hip_check(xrhip_image_upload(img->h, gray, stride), "xrhip_image_upload");
+        // FeatureTracker::work's first step (feature_tracker.cpp:39) depends on nothing but the frame: its launches are queued here,
+        // behind the frame's DMA, so the device builds the pyramid while the host is still on its way to the tracker (input
+        // synchronisation, frame construction, the interval's pre-integration launch).  Same call, same arguments.
+        {
+            WallTimer wt_w_preprocess(times.w_preprocess);
+            hip_check(xrhip_image_preprocess(img->h, config.feature_tracker_clahe_clip_limit, (int)config.feature_tracker_clahe_width,
+                                             (int)config.feature_tracker_clahe_height),
+                      "xrhip_image_preprocess");
+            img->preprocessed = true;
+        }
         return img;
     }
     // PreIntegrator::integrate (preintegrator.cpp:78-95) on the device
@@ -2509,6 +2519,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         auto preprocess = [&] {
             if (preprocessed) return;
             preprocessed = true;
+            if (frame->image->preprocessed) return;   // queued when the frame arrived (Pipeline::make_image)
             WallTimer wt_w_preprocess(P.times.w_preprocess);
             hip_check(xrhip_image_preprocess(frame->image->h, c.feature_tracker_clahe_clip_limit,
                                              (int)c.feature_tracker_clahe_width, (int)c.feature_tracker_clahe_height),
