@@ -2390,7 +2390,11 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
     }
 
     // -------- Detail (core/detail.cpp:46-177)
-    PoseState track_gyroscope(double t, double x, double y, double z) {
+    // want_pose: Detail::track_gyroscope / track_accelerometer return the propagated pose (detail.cpp:46-100), which
+    // XRSLAMPushSensorData throws away for both sensors (XRSLAMManager.cpp:139-146): the C API passes false and the propagation over the
+    // samples since the last state -- an exponential map per sample, on every one of ~20 pushes per frame -- is not run.  (Its only
+    // side effect, dropping samples older than the state, happens in the next propagation: track_camera's.)
+    PoseState track_gyroscope(double t, double x, double y, double z, bool want_pose = true) {
         if (!accelerometers.empty()) {
             if (t < accelerometers.front().t) {
                 gyroscopes.clear();
@@ -2407,9 +2411,9 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
             }
         }
         gyroscopes.push_back({t, {x, y, z}});
-        return predict_pose(t);
+        return want_pose ? predict_pose(t) : PoseState{};
     }
-    PoseState track_accelerometer(double t, double x, double y, double z) {
+    PoseState track_accelerometer(double t, double x, double y, double z, bool want_pose = true) {
         if (!gyroscopes.empty() && t >= gyroscopes.front().t) {
             if (t > gyroscopes.back().t) {
                 while (gyroscopes.size() > 1) gyroscopes.pop_front();
@@ -2424,7 +2428,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
                 track_imu({t, w, {x, y, z}});
             }
         }
-        return predict_pose(t);
+        return want_pose ? predict_pose(t) : PoseState{};
     }
     PoseState track_camera(std::shared_ptr<HipImage> image) {
         const Config &c = P.config;

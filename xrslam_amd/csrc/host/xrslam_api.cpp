@@ -25,6 +25,7 @@ struct Manager {
     std::string last_error;
     std::vector<uint8_t> gray;
     int device = -1;   // HIP device the instance was created on (the current device is a per-thread setting)
+    bool bound_by_replay = false;   // inside XRSLAMAmdInstanceReplay: the device is current for the whole loop
 };
 
 Manager &mgr() {
@@ -34,6 +35,7 @@ Manager &mgr() {
 
 // The thread that drives an instance need not be the one that created it: make the instance's device current.
 void bind_device(const Manager &m) {
+    if (m.bound_by_replay) return;   // XRSLAMAmdInstanceReplay made the device current once for all the pushes of its loop
     if (m.device >= 0) xrhip_bind_device(m.device);
 }
 
@@ -111,12 +113,12 @@ void impl_push(Manager &m, XRSLAMSensorType type, void *data) {
         }
         case XRSLAM_SENSOR_ACCELERATION: {
             auto *a = static_cast<XRSLAMAcceleration *>(data);
-            m.sys->track_accelerometer(a->timestamp, a->data[0], a->data[1], a->data[2]);
+            m.sys->track_accelerometer(a->timestamp, a->data[0], a->data[1], a->data[2], false);
             break;
         }
         case XRSLAM_SENSOR_GYROSCOPE: {
             auto *g = static_cast<XRSLAMGyroscope *>(data);
-            m.sys->track_gyroscope(g->timestamp, g->data[0], g->data[1], g->data[2]);
+            m.sys->track_gyroscope(g->timestamp, g->data[0], g->data[1], g->data[2], false);
             break;
         }
         default:
@@ -444,6 +446,13 @@ int XRSLAMAmdInstanceReplay(XRSLAMAmdInstance *inst, const double *imu7, int n_i
     if (!inst || !imu7 || !cam_t || !frames || !imu_cursor || !frame_cursor) return -1;
     Manager &m = inst->m;
     int n_poses = 0;
+    // one hipSetDevice for the loop instead of one per pushed sample (~22 per frame); nothing in between runs foreign code on this thread
+    bind_device(m);
+    struct Bound {
+        Manager &m;
+        explicit Bound(Manager &mm) : m(mm) { m.bound_by_replay = true; }
+        ~Bound() { m.bound_by_replay = false; }
+    } bound(m);
     for (int s = 0; s < n_steps && *frame_cursor < n_frames; ++s) {
         const int fk = *frame_cursor;
         const double t = cam_t[fk], lim = t + 1e-9;
