@@ -243,3 +243,19 @@ int gh_essential_parsac(const double *p1, const double *p2, int n, double thr, c
     return cnt;
 }
 }
+
+// PoissonDisk2 (csrc/host_select.hpp): the dense-grid fast path of permit() against the cell-by-cell scan with the hash fallback
+// (a filter constructed without image bounds always takes the latter).  xy: n points, inserted in order into both; returns the
+// number of points on which the two disagree (accepted by one, refused by the other).
+#include "../../xrslam_amd/csrc/host_select.hpp"
+extern "C" int gh_poisson_disagreements(const double *xy, int n, double radius, int w, int h, char *accepted) {
+    xrhip::PoissonDisk2 dense(radius, w, h), sparse(radius);
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        const bool a = dense.insert(xy[2 * i], xy[2 * i + 1]);
+        const bool b = sparse.insert(xy[2 * i], xy[2 * i + 1]);
+        if (accepted) accepted[i] = a ? 1 : 0;
+        bad += a != b;
+    }
+    return bad;
+}

@@ -191,3 +191,20 @@ def test_yaml_config_surface(gh, tmp_path):
     dev = tmp_path / "dev.yaml"
     dev.write_text("%YAML:1.0\ncam0:\n  resolution: [752, 480]\n")
     assert gh.gh_load_config(str(slam).encode(), str(dev).encode(), _p(out)) == -1
+
+
+def test_poisson_disk_dense_scan_equals_the_cell_by_cell_scan(gh):
+    """PoissonDisk2::permit reads the scan box row by row when it lies inside the dense cell array (every point the tracker
+    produces) and cell by cell, with the hash fallback, otherwise: same verdict on every point of random sequences, including
+    points on the image border, outside it, and at spacings around the radius."""
+    import ctypes as C
+    gh.gh_poisson_disagreements.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.RandomState(11)
+    for radius, w, h, n in ((20.0, 752, 480, 1500), (7.5, 320, 240, 3000), (33.0, 1280, 720, 1200)):
+        xy = np.c_[rng.uniform(-40, w + 40, n), rng.uniform(-40, h + 40, n)]
+        xy[: n // 3] = np.clip(xy[: n // 3], 0, [w - 1, h - 1])                    # a third strictly inside
+        xy[n // 3: n // 2] = np.round(xy[n // 3: n // 2])                          # integer pixels (the detector's output)
+        xy = np.ascontiguousarray(xy)
+        acc = np.zeros(n, np.uint8)
+        assert gh.gh_poisson_disagreements(xy.ctypes.data, n, radius, w, h, acc.ctypes.data) == 0
+        assert 0 < acc.sum() < n                                                   # the filter both accepts and refuses here
