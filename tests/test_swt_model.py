@@ -214,3 +214,79 @@ def test_landmark_decisions_match_an_independent_model(tmp_path):
     print("triangulations %d (%d rejected), swept landmarks %d (%d invalid), untriangulated %d" % (n_tri, n_tri_rejected, n_cull, n_invalid, n_untri))
     assert n_tri >= 200 and n_cull >= 2000, (n_tri, n_cull)
     assert n_tri_rejected + n_invalid >= 1, (n_tri_rejected, n_invalid)   # the stream exercised a rejection somewhere
+
+
+def test_localize_problem_is_what_an_independent_track_model_predicts(tmp_path):
+    """localize_newframe's problem assembly (core/sliding_window_tracker.cpp:119-143), so far read but not tested (VERDICT r2, weak
+    #14): ONE free frame (the new one), its predecessor and the landmarks' reference keyframes constant, one pre-integration prior
+    factor, and one reprojection prior factor per key point of the new frame whose track is valid AND triangulated -- depths constant.  The expected
+    factor count comes from a model that never looks at the tracker's tags: it keeps every window-map track's (triangulated, valid)
+    pair from the landmark-sweep records after each window solve (the verdicts test_landmark_decisions_... re-derives with numpy) and
+    reads which track each key point of the new frame is on from mirror_frame's record.  Compared with (a) the count the tracker
+    logs as manage_keyframe's input and (b) the problem the solver actually received (XRSLAM_AMD_DUMP_BA)."""
+    if not os.path.exists(ORACLE_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    import glob
+    from tests import ba_snapshots as snap
+    log = str(tmp_path / "swt.jsonl")
+    dump_dir = tmp_path / "ba"
+    dump_dir.mkdir()
+    os.environ["XRSLAM_AMD_DUMP_SWT"] = log
+    os.environ["XRSLAM_AMD_DUMP_BA"] = str(dump_dir)
+    try:
+        seq = scene.make_sequence(n_frames=110, seed=2)
+        s = runner.Session(ORACLE_LIB, seq, slam_yaml=SLAM)
+        while s.step():
+            assert not s.error(), s.error()
+        s.flush()
+        s.close()
+    finally:
+        del os.environ["XRSLAM_AMD_DUMP_SWT"]
+        del os.environ["XRSLAM_AMD_DUMP_BA"]
+    # ---- the track model over the log
+    state = {}                 # window-map track id -> (triangulated, valid), as of the last landmark sweep that saw it
+    have_snapshot = False
+    expected = {}              # frame id -> predicted number of reprojection prior factors
+    logged = {}
+    order = []
+    for ln in open(log):
+        r = json.loads(ln)
+        if "mirror" in r:
+            if have_snapshot:
+                expected[r["mirror"]] = sum(1 for _kj, tid in r["after"] if state.get(tid, (0, 0)) == (1, 1))
+        elif "cull" in r:
+            state[r["track"]] = (1 if r["triangulated"] else 0, 1 if r["valid"] else 0)
+            have_snapshot = True
+        elif "window" in r:
+            logged[r["frame"]] = r["mapped"]
+            order.append(r["frame"])
+    checked = [f for f in order if f in expected]
+    assert len(checked) >= 60, len(checked)
+    for f in checked:
+        assert expected[f] == logged[f], "frame %d: model predicts %d mapped key points, the tracker counted %d" % (f, expected[f], logged[f])
+    # ---- the problems the solver received: two solves per tracked frame, the first one is localize_newframe's
+    by_count = {}
+    for path in sorted(glob.glob(os.path.join(str(dump_dir), "*.xrba"))):
+        fc = int(os.path.basename(path).split("_f")[1].split("_")[0])
+        by_count.setdefault(fc, []).append(path)
+    groups = [by_count[k] for k in sorted(by_count) if len(by_count[k]) == 2]
+    assert len(groups) >= len(order) - 1                   # (the initialiser's own solves come in other group sizes)
+    groups = groups[-len(order):]
+    n_checked = 0
+    for fid, (first, _second) in zip(order[-len(groups):], groups):
+        d = snap.read_xrba(first)
+        free = np.flatnonzero(d["frame_fix"] != 3)
+        assert len(free) == 1, first                                          # the new frame; its predecessor and the landmarks'
+        assert d["frame_fix"][free[0]] == 0                                   # reference keyframes enter as constants
+        assert np.all(d["obs_ref"] != free[0])
+        assert len(d["imu_i"]) == 1 and d["imu_j"][0] == free[0] and d["imu_i"][0] != free[0]
+        assert len(d["rot_tgt"]) == 0 and len(d["prior_frames"]) == 0
+        assert np.all(d["landmark_fix"] == 1)                                # prior factors: depths are constants
+        assert np.all(d["obs_tgt"] == free[0])
+        assert len(np.unique(d["obs_lm"])) == len(d["obs_lm"])               # one factor per landmark
+        if fid in expected:
+            assert len(d["obs_tgt"]) == expected[fid], "frame %d: %d reprojection prior factors, model predicts %d" % (
+                fid, len(d["obs_tgt"]), expected[fid])
+            n_checked += 1
+    assert n_checked >= 60, n_checked
