@@ -290,3 +290,89 @@ def test_localize_problem_is_what_an_independent_track_model_predicts(tmp_path):
                 fid, len(d["obs_tgt"]), expected[fid])
             n_checked += 1
     assert n_checked >= 60, n_checked
+
+
+def test_window_problem_is_what_an_independent_track_model_predicts(tmp_path):
+    """refine_window's problem assembly (core/sliding_window_tracker.cpp:247-322): every keyframe of the window free, one
+    pre-integration factor between consecutive keyframes, the marginalisation prior, a free inverse depth per valid track anchored in
+    a keyframe, and one reprojection factor per observation of a valid, triangulated track in a keyframe other than its anchor.  The
+    expected counts come from the same tag-free track model as above: (triangulated, valid) pairs from the sweep records of the
+    previous window solves and this keyframe's triangulation records, observations and anchors from this keyframe's sweep records.
+    Compared with the problem the solver received (XRSLAM_AMD_DUMP_BA)."""
+    if not os.path.exists(ORACLE_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    import glob
+    from tests import ba_snapshots as snap
+    log = str(tmp_path / "swt.jsonl")
+    dump_dir = tmp_path / "ba"
+    dump_dir.mkdir()
+    os.environ["XRSLAM_AMD_DUMP_SWT"] = log
+    os.environ["XRSLAM_AMD_DUMP_BA"] = str(dump_dir)
+    try:
+        seq = scene.make_sequence(n_frames=120, seed=2)
+        s = runner.Session(ORACLE_LIB, seq, slam_yaml=SLAM)
+        while s.step():
+            assert not s.error(), s.error()
+        s.flush()
+        s.close()
+    finally:
+        del os.environ["XRSLAM_AMD_DUMP_SWT"]
+        del os.environ["XRSLAM_AMD_DUMP_BA"]
+    state = {}            # track id -> (triangulated, valid) BEFORE the window solve being looked at
+    have_snapshot = False
+    pending = []          # this keyframe's sweep records
+    expected = {}         # frame id -> (reprojection factors, free landmarks)
+    order = []
+    for ln in open(log):
+        r = json.loads(ln)
+        if "triangulate" in r:
+            state[r["track"]] = (1, 1) if r["ok"] else (0, 0)          # track_landmark (:225-245)
+        elif "cull" in r:
+            pending.append(r)
+        elif "window" in r:
+            order.append((r["frame"], r["keyframe"]))
+            if r["keyframe"]:
+                assert pending, r["frame"]
+                if have_snapshot:
+                    m = free = 0
+                    for c in pending:
+                        tri, valid = state.get(c["track"], (0, 0))
+                        kf = [o[10] for o in c["obs"]]
+                        if not valid or not kf or kf[0] != 1:            # not a parameter: invalid, or anchored in a subframe
+                            continue
+                        free += 1
+                        if tri:
+                            m += sum(kf) - 1                             # every keyframe observation but the anchor's own
+                    expected[r["frame"]] = (m, free)
+                for c in pending:                                        # the sweep's verdicts are the next solves' inputs
+                    state[c["track"]] = (1 if c["triangulated"] else 0, 1 if c["valid"] else 0)
+                have_snapshot = True
+                pending = []
+            else:
+                assert not pending
+    by_count = {}
+    for path in sorted(glob.glob(os.path.join(str(dump_dir), "*.xrba"))):
+        fc = int(os.path.basename(path).split("_f")[1].split("_")[0])
+        by_count.setdefault(fc, []).append(path)
+    groups = [by_count[k] for k in sorted(by_count) if len(by_count[k]) == 2][-len(order):]
+    assert len(groups) == len(order)
+    n_checked = 0
+    for (fid, is_kf), (_first, second) in zip(order, groups):
+        if not is_kf or fid not in expected:
+            continue
+        d = snap.read_xrba(second)
+        F = len(d["frame_state"])
+        assert np.all(d["frame_fix"][1:] == 0) and d["frame_fix"][0] in (0, 1), second   # every keyframe free (the oldest keeps the
+                                                                                       # initialiser's pose gauge until it slides out)
+        assert len(d["imu_i"]) == F - 1 and np.all(d["imu_j"] - d["imu_i"] == 1)
+        npf = len(d["prior_frames"])                                         # the prior covers the oldest frames: those that were in the
+        assert 0 < npf <= F - 1 and np.array_equal(d["prior_frames"], np.arange(npf))   # window when it was last rebuilt
+        assert len(d["rot_tgt"]) == 0
+        m, free = expected[fid]
+        assert int((d["landmark_fix"] == 0).sum()) == free, "frame %d: %d free landmarks, model predicts %d" % (
+            fid, int((d["landmark_fix"] == 0).sum()), free)
+        assert len(d["obs_tgt"]) == m, "frame %d: %d reprojection factors, model predicts %d" % (fid, len(d["obs_tgt"]), m)
+        assert np.all(d["obs_tgt"] != d["obs_ref"])
+        n_checked += 1
+    assert n_checked >= 12, n_checked
