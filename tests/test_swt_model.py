@@ -376,3 +376,92 @@ def test_window_problem_is_what_an_independent_track_model_predicts(tmp_path):
         assert np.all(d["obs_tgt"] != d["obs_ref"])
         n_checked += 1
     assert n_checked >= 12, n_checked
+
+
+def test_subwindow_problem_is_what_an_independent_track_model_predicts(tmp_path):
+    """refine_subwindow's problem assembly, translating branch (core/sliding_window_tracker.cpp:414-465): the newest keyframe constant,
+    its subframes free, one pre-integration factor per subframe (chained from the keyframe), and for every subframe one reprojection
+    prior factor per key point whose track is valid, triangulated and anchored in a keyframe.  Expected counts from the tag-free
+    model: the subframe list from the tracker's window record, each subframe's key point -> track assignment from its own
+    mirror_frame record, (triangulated, valid, anchored-in-a-keyframe) from the last landmark sweep.  Compared with the problem the
+    solver received for every non-keyframe frame of a 120-frame run."""
+    if not os.path.exists(ORACLE_LIB):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    import glob
+    from tests import ba_snapshots as snap
+    log = str(tmp_path / "swt.jsonl")
+    dump_dir = tmp_path / "ba"
+    dump_dir.mkdir()
+    os.environ["XRSLAM_AMD_DUMP_SWT"] = log
+    os.environ["XRSLAM_AMD_DUMP_BA"] = str(dump_dir)
+    try:
+        seq = scene.make_sequence(n_frames=120, seed=2)
+        s = runner.Session(ORACLE_LIB, seq, slam_yaml=SLAM)
+        while s.step():
+            assert not s.error(), s.error()
+        s.flush()
+        s.close()
+    finally:
+        del os.environ["XRSLAM_AMD_DUMP_SWT"]
+        del os.environ["XRSLAM_AMD_DUMP_BA"]
+    state = {}        # track id -> [triangulated, valid, [(frame id, is keyframe) of its observations]], as of the last sweep
+    after = {}        # frame id -> [(key point, track id)] when it was mirrored
+    have_snapshot = False
+    expected = {}     # frame id -> (reprojection prior factors, subframes)
+    order = []
+    prev_window = None
+    for ln in open(log):
+        r = json.loads(ln)
+        if "mirror" in r:
+            after[r["mirror"]] = [tuple(x) for x in r["after"]]
+        elif "cull" in r:
+            state[r["track"]] = [1 if r["triangulated"] else 0, 1 if r["valid"] else 0, [(o[15], o[10]) for o in r["obs"]]]
+            have_snapshot = True
+        elif "window" in r:
+            order.append((r["frame"], r["keyframe"]))
+            # frames that left the window since the previous record (slide_window: the oldest keyframe and its subframes) no longer
+            # carry observations: a track anchored there is now anchored in its next observation (Track::remove_keypoint)
+            if prev_window is not None:
+                alive = {kf[0] for kf in r["window"]} | {sid for kf in r["window"] for sid, _nt in kf[2]}
+                gone = ({kf[0] for kf in prev_window} | {sid for kf in prev_window for sid, _nt in kf[2]}) - alive
+                if gone:
+                    for st in state.values():
+                        st[2] = [o for o in st[2] if o[0] not in gone]
+            prev_window = r["window"]
+            newest = r["window"][-1]
+            subs = newest[2]
+            if r["keyframe"] or not have_snapshot or not subs:
+                continue
+            if r["no_translation"] or newest[1] or any(nt for _sid, nt in subs):
+                continue                                    # (the rotation-only branch builds a different problem)
+            m = 0
+            for sid, _nt in subs:
+                assert sid in after, sid
+                for _kj, tid in after[sid]:
+                    st = state.get(tid)
+                    if st and st[0] and st[1] and st[2] and st[2][0][1] == 1:
+                        m += 1
+            expected[r["frame"]] = (m, len(subs))
+    by_count = {}
+    for path in sorted(glob.glob(os.path.join(str(dump_dir), "*.xrba"))):
+        fc = int(os.path.basename(path).split("_f")[1].split("_")[0])
+        by_count.setdefault(fc, []).append(path)
+    groups = [by_count[k] for k in sorted(by_count) if len(by_count[k]) == 2][-len(order):]
+    assert len(groups) == len(order)
+    n_checked = 0
+    for (fid, _is_kf), (_first, second) in zip(order, groups):
+        if fid not in expected:
+            continue
+        m, n_sub = expected[fid]
+        d = snap.read_xrba(second)
+        free = np.flatnonzero(d["frame_fix"] != 3)
+        assert len(free) == n_sub and np.all(d["frame_fix"][free] == 0), second
+        assert len(d["imu_i"]) == n_sub and set(d["imu_j"]) == set(free)      # keyframe -> sub 1 -> sub 2 ...: every subframe is a j once
+        assert len(d["prior_frames"]) == 0 and len(d["rot_tgt"]) == 0
+        assert np.all(d["landmark_fix"] == 1)
+        assert np.all(np.isin(d["obs_tgt"], free)) and not np.any(np.isin(d["obs_ref"], free))
+        assert len(d["obs_tgt"]) == m, "frame %d: %d reprojection prior factors over %d subframes, model predicts %d" % (
+            fid, len(d["obs_tgt"]), n_sub, m)
+        n_checked += 1
+    assert n_checked >= 40, n_checked

@@ -1542,9 +1542,9 @@ class SlidingWindowTracker {
         for (const auto &[f, ki] : t->keypoint_refs) {
             const PoseState pose = f->get_pose(f->camera);
             const V3 z = f->get_keypoint(ki);
-            std::fprintf(fp, "%s[%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %d, %.17g, %.17g, %.17g, %.17g]",
+            std::fprintf(fp, "%s[%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %d, %.17g, %.17g, %.17g, %.17g, %zu]",
                          first ? "" : ", ", pose.q.x, pose.q.y, pose.q.z, pose.q.w, pose.p.x, pose.p.y, pose.p.z, z.x, z.y, z.z,
-                         f->tag(FT_KEYFRAME) ? 1 : 0, f->K.fx, f->K.fy, f->K.cx, f->K.cy);
+                         f->tag(FT_KEYFRAME) ? 1 : 0, f->K.fx, f->K.fy, f->K.cx, f->K.cy, f->id);
             first = false;
         }
         std::fprintf(fp, "]");
