@@ -208,3 +208,57 @@ def test_poisson_disk_dense_scan_equals_the_cell_by_cell_scan(gh):
         acc = np.zeros(n, np.uint8)
         assert gh.gh_poisson_disagreements(xy.ctypes.data, n, radius, w, h, acc.ctypes.data) == 0
         assert 0 < acc.sum() < n                                                   # the filter both accepts and refuses here
+
+
+def test_five_point_returns_every_real_essential_matrix(gh):
+    """Completeness of solve_essential_5pt (geometry/essential.cpp:105-297), independent of its action-matrix / eigen-solver route:
+    a numpy multi-start Gauss-Newton search over the null space E(x, y, z) = x E1 + y E2 + z E3 + E4 of the five epipolar
+    constraints (numpy's own SVD basis) collects the real roots of det E = 0, 2 E E^T E - tr(E E^T) E = 0; every root it finds is
+    among the matrices the solver returned (up to scale and sign), and the solver returned nothing that is not a root."""
+    rng = np.random.RandomState(8)
+
+    def unit(e):
+        e = e / np.linalg.norm(e)
+        return e * np.sign(e.flat[np.argmax(np.abs(e))])
+
+    def residual(e):
+        return np.concatenate([(2 * e @ e.T @ e - np.trace(e @ e.T) * e).ravel(), [np.linalg.det(e)]])
+
+    total_cpp = total_np = 0
+    for trial in range(8):
+        p1, p2, _E, _, _, _ = _two_view(rng, 5, noise=0.0 if trial % 2 else 0.01)     # (noise: no exact geometry behind the points)
+        Es = np.zeros((10, 9))
+        k = gh.gh_essential_5pt(_p(np.ascontiguousarray(p1)), _p(np.ascontiguousarray(p2)), _p(Es))
+        cpp = [unit(e) for e in Es[:k].reshape(-1, 3, 3)]
+        # the solver's own output: every matrix is a root
+        for e in cpp:
+            assert np.abs(residual(e)).max() < 1e-7
+        # independent search
+        h1 = np.column_stack([p1, np.ones(5)]); h2 = np.column_stack([p2, np.ones(5)])
+        A = np.stack([np.outer(h2[i], h1[i]).ravel() for i in range(5)])               # h2^T E h1 = 0, E row-major
+        B = np.linalg.svd(A)[2][5:].reshape(4, 3, 3)
+        roots = []
+        for start in range(480):
+            v = rng.randn(3) * (0.3, 1.0, 3.0, 10.0)[start % 4]
+            for _ in range(60):
+                e = v[0] * B[0] + v[1] * B[1] + v[2] * B[2] + B[3]
+                f = residual(e)
+                J = np.empty((10, 3))
+                for c in range(3):
+                    dv = np.zeros(3); dv[c] = 1e-7
+                    J[:, c] = (residual(e + dv[c] * B[c]) - f) / 1e-7
+                step = np.linalg.lstsq(J, -f, rcond=None)[0]
+                v = v + step
+                if np.linalg.norm(step) < 1e-13 * max(1.0, np.linalg.norm(v)):
+                    break
+            e = v[0] * B[0] + v[1] * B[1] + v[2] * B[2] + B[3]
+            if np.abs(residual(unit(e))).max() < 1e-9 and np.linalg.norm(v) < 1e6:
+                u = unit(e)
+                if not any(np.linalg.norm(u - r) < 1e-6 for r in roots):
+                    roots.append(u)
+        assert roots, trial
+        for u in roots:
+            assert min(np.linalg.norm(u - c) for c in cpp) < 1e-6, "trial %d: a real root the solver did not return" % trial
+        total_cpp += len(cpp)
+        total_np += len(roots)
+    assert total_np >= 0.75 * total_cpp, (total_np, total_cpp)     # (the search is stochastic: it need not find every root, only no extra one)
