@@ -163,6 +163,11 @@ typedef struct XRSLAMAmdCameraConfig {
     int resolution[2];        /* cam0.resolution: width height */
 } XRSLAMAmdCameraConfig;
 void XRSLAMAmdGetCameraConfig(XRSLAMAmdCameraConfig *out);
+/* Every value the two configuration files resolved to (the accessors of xrslam::Config, xrslam/include/xrslam/xrslam.h:36-116 /
+ * yaml_config.cpp:152-362), one "key = value" line each (%.17g), keys as in the yaml files ("cam0.intrinsics", "sliding_window.size",
+ * ...): lets a caller -- and tests/test_config.py -- check that two sets of files mean the same configuration.  Writes at most cap - 1
+ * characters plus the terminator; returns the length the full text needs. */
+int XRSLAMAmdDescribeConfig(char *buf, int cap);
 /* Undistortion on the device.  The reference's readers rectify every frame on the host before pushing it
  * (cv::undistort, xrslam-pc/player/src/IO/euroc_dataset_reader.cpp:62-69; xrslam::extra::ImageUndistorter,
  * IO/tum_dataset_reader.cpp:67-76).  After this call the images handed to XRSLAM_SENSOR_CAMERA / XRSLAMAmdPushImageDevice
@@ -235,6 +240,7 @@ void XRSLAMAmdInstanceSetInitialState(XRSLAMAmdInstance *inst, double t, const d
                                       const double v[3], const double bg[3], const double ba[3]);
 void XRSLAMAmdInstancePushImageDevice(XRSLAMAmdInstance *inst, const void *gray_dev, int stride, double timestamp);
 void XRSLAMAmdInstanceGetCameraConfig(XRSLAMAmdInstance *inst, XRSLAMAmdCameraConfig *out);
+int XRSLAMAmdInstanceDescribeConfig(XRSLAMAmdInstance *inst, char *buf, int cap);
 void XRSLAMAmdInstanceSetDeviceUndistort(XRSLAMAmdInstance *inst, const char *model);
 void XRSLAMAmdInstanceGetTimes(XRSLAMAmdInstance *inst, XRSLAMAmdTimes *out);
 void XRSLAMAmdInstanceSetProfiling(XRSLAMAmdInstance *inst, int enable);

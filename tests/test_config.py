@@ -79,3 +79,51 @@ def test_slam_keys_are_optional(lib, tmp_path):
     assert ok == 1, err
     assert err == ""                                  # a successful create clears the error of the failed ones above
     lib.XRSLAMDestroy()
+
+
+REF_CFG = "/root/reference/configs"
+
+
+def _describe(lib, slam, sensor):
+    ok, err, _ = _create(lib, slam, sensor)
+    assert ok == 1, err
+    lib.XRSLAMAmdDescribeConfig.argtypes = [C.c_char_p, C.c_int]
+    lib.XRSLAMAmdDescribeConfig.restype = C.c_int
+    n = lib.XRSLAMAmdDescribeConfig(None, 0)
+    buf = C.create_string_buffer(n + 1)
+    assert lib.XRSLAMAmdDescribeConfig(buf, n + 1) == n
+    cam = (C.c_double * 16)()
+    lib.XRSLAMAmdGetCameraConfig.argtypes = [C.c_void_p]
+    lib.XRSLAMAmdGetCameraConfig.restype = None
+    lib.XRSLAMAmdGetCameraConfig(cam)
+    lib.XRSLAMDestroy()
+    text = buf.value.decode()
+    return dict(ln.split(" = ") for ln in text.splitlines()), bytes(cam)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_CFG, "euroc_slam.yaml")), reason="the reference tree is not on this box")
+def test_the_reference_yaml_files_load_verbatim_and_mean_the_shipped_configuration(lib):
+    """XRSLAMCreate on /root/reference/configs/euroc_slam.yaml + euroc_sensor.yaml AS SHIPPED BY THE REFERENCE (multi-line flow
+    sequences, the nested T_BS map, keys this library does not read): accepted, and every value it resolves to -- all of
+    xrslam::Config's accessors (XRSLAMAmdDescribeConfig) and the XRSLAMAmdCameraConfig the dataset readers ask for -- equals what
+    the repo's re-formatted copies under configs/ resolve to."""
+    ref, ref_cam = _describe(lib, os.path.join(REF_CFG, "euroc_slam.yaml"), os.path.join(REF_CFG, "euroc_sensor.yaml"))
+    ours, our_cam = _describe(lib, SLAM, SENSOR)
+    assert ref == ours
+    assert ref_cam == our_cam
+    assert len(ref) == 44
+    # spot values straight from the reference's files (configs/euroc_slam.yaml:6-36, euroc_sensor.yaml:40-53)
+    assert ref["sliding_window.size"] == "10" and ref["feature_tracker.max_keypoint_detection"] == "200"
+    assert ref["solver.iteration_limit"] == "30" and ref["rotation.misalignment_threshold"] == "0.02"
+    assert ref["cam0.intrinsics"] == "458.654 457.29599999999999 367.21499999999997 248.375"
+    assert ref["cam0.resolution"] == "752 480" and ref["cam0.noise"] == "0.5 0 0 0.5"
+
+
+def test_describe_config_reports_defaults_for_an_empty_slam_file(lib, tmp_path):
+    empty = tmp_path / "empty_slam.yaml"
+    empty.write_text("%YAML:1.0\n---\n")
+    d, _ = _describe(lib, str(empty), SENSOR)
+    # config.cpp:7-78
+    assert d["sliding_window.size"] == "10" and d["feature_tracker.max_keypoint_detection"] == "150"
+    assert d["solver.iteration_limit"] == "10" and d["rotation.misalignment_threshold"] == "0.10000000000000001"
+    assert d["feature_tracker.max_init_frames"] == "60" and d["initializer.keyframe_num"] == "8"

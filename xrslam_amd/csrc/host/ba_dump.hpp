@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "../../../include/xrslam_hip.h"
 
@@ -76,6 +77,50 @@ struct SwtLogger {
     SwtLogger(const SwtLogger &) = delete;
     SwtLogger &operator=(const SwtLogger &) = delete;
     bool enabled() const { return fp != nullptr; }
+};
+
+// Log of what a frame PRODUCES (test aid): XRSLAM_AMD_DUMP_OUT=<file> appends binary records (little endian) --
+//   'F' (feature tracker, when a frame joins the tracking map):  u64 frame id, f64 t, u32 n, n x {f64 px, f64 py, i64 track id | -1}
+//   'B' (sliding-window tracker, at the end of track()):  u64 newest frame id, u32 keyframe?, f64 state[16] (q xyzw, p, v, bg, ba),
+//        u32 window frames, per frame {u64 id, u32 n_sub, n_sub x u64}, u32 n_kp, n_kp x i64 window-map track id | -1 (newest frame),
+//        u32 n_tracks, n_tracks x {u64 id, u32 tag bits (1 << TrackTag), f64 inv_depth, f64 x, y, z (0 unless triangulated)}
+// each preceded by {u8 tag, u32 payload bytes}.  Unlike the decision log above it changes nothing about the path a frame takes
+// (the overlaps of the inline mode stay on): tests/test_bench_stream_parity.py compares the GPU library's file with the CPU
+// reference pipeline's -- ids and indices exactly, pixels / states / landmarks at north_star's tolerance.
+struct OutLogger {
+    FILE *fp = nullptr;
+    std::mutex mu;   // pipelined mode: 'F' records come from the caller's thread, 'B' records from the backend thread
+    std::vector<unsigned char> buf;
+    OutLogger() {
+        if (const char *p = std::getenv("XRSLAM_AMD_DUMP_OUT")) fp = std::fopen(p, "wb");
+    }
+    ~OutLogger() {
+        if (fp) std::fclose(fp);
+    }
+    OutLogger(const OutLogger &) = delete;
+    OutLogger &operator=(const OutLogger &) = delete;
+    bool enabled() const { return fp != nullptr; }
+    struct Record {   // one record under the lock; written out when it goes out of scope
+        OutLogger &log;
+        std::unique_lock<std::mutex> lk;
+        unsigned char tag;
+        Record(OutLogger &l, unsigned char t) : log(l), lk(l.mu), tag(t) { log.buf.clear(); }
+        template <class T> void put(const T &v) {
+            const unsigned char *p = reinterpret_cast<const unsigned char *>(&v);
+            log.buf.insert(log.buf.end(), p, p + sizeof(T));
+        }
+        void u32(uint32_t v) { put(v); }
+        void u64(uint64_t v) { put(v); }
+        void i64(int64_t v) { put(v); }
+        void f64(double v) { put(v); }
+        ~Record() {
+            const uint32_t n = (uint32_t)log.buf.size();
+            std::fwrite(&tag, 1, 1, log.fp);
+            std::fwrite(&n, sizeof n, 1, log.fp);
+            if (n) std::fwrite(log.buf.data(), 1, n, log.fp);
+            std::fflush(log.fp);
+        }
+    };
 };
 
 // Log of the sensor synchronisation (development / test aid): XRSLAM_AMD_DUMP_SYNC=<file> makes System::feature_tracker_work

@@ -6,6 +6,8 @@
 // flow sequences (possibly spanning lines), which this small reader handles.
 #pragma once
 #include <cctype>
+#include <cstdio>
+#include <initializer_list>
 #include <cstdlib>
 #include <fstream>
 #include <map>
@@ -216,6 +218,75 @@ inline Config load_config(const std::string &slam_path, const std::string &devic
     num("parsac.norm_scale", c.parsac_norm_scale);
     siz("parsac.keyframe_check_size", c.parsac_keyframe_check_size);
     return c;
+}
+
+// "key = value" lines of everything load_config resolved (XRSLAMAmdDescribeConfig), keys as in the yaml files
+inline std::string describe_config(const Config &c) {
+    std::string out;
+    char b[64];
+    auto put = [&](const char *key, std::initializer_list<double> v) {
+        out += key;
+        out += " =";
+        for (double x : v) {
+            std::snprintf(b, sizeof b, " %.17g", x);
+            out += b;
+        }
+        out += "\n";
+    };
+    auto arr = [&](const char *key, const double *v, int n) {
+        out += key;
+        out += " =";
+        for (int i = 0; i < n; ++i) {
+            std::snprintf(b, sizeof b, " %.17g", v[i]);
+            out += b;
+        }
+        out += "\n";
+    };
+    arr("cam0.resolution", c.cam_resolution, 2);
+    put("cam0.intrinsics", {c.K.fx, c.K.fy, c.K.cx, c.K.cy});
+    arr("cam0.distortion", c.cam_distortion, 4);
+    put("cam0.camera_distortion_flag", {(double)c.cam_distortion_flag});
+    put("cam0.time_offset", {c.cam_time_offset});
+    put("cam0.extrinsic.q_bc", {c.q_bc.x, c.q_bc.y, c.q_bc.z, c.q_bc.w});
+    put("cam0.extrinsic.p_bc", {c.p_bc.x, c.p_bc.y, c.p_bc.z});
+    arr("cam0.noise", c.keypoint_noise_cov, 4);
+    put("imu.extrinsic.q_bi", {c.q_bi.x, c.q_bi.y, c.q_bi.z, c.q_bi.w});
+    put("imu.extrinsic.p_bi", {c.p_bi.x, c.p_bi.y, c.p_bi.z});
+    arr("imu.noise.cov_g", c.cov_g, 9);
+    arr("imu.noise.cov_a", c.cov_a, 9);
+    arr("imu.noise.cov_bg", c.cov_bg, 9);
+    arr("imu.noise.cov_ba", c.cov_ba, 9);
+    put("output.q_bo", {c.q_bo.x, c.q_bo.y, c.q_bo.z, c.q_bo.w});
+    put("output.p_bo", {c.p_bo.x, c.p_bo.y, c.p_bo.z});
+    put("sliding_window.size", {(double)c.sliding_window_size});
+    put("sliding_window.subframe_size", {(double)c.sliding_window_subframe_size});
+    put("sliding_window.force_keyframe_landmarks", {(double)c.sliding_window_force_keyframe_landmarks});
+    put("sliding_window.tracker_frequent", {(double)c.sliding_window_tracker_frequent});
+    put("feature_tracker.min_keypoint_distance", {c.feature_tracker_min_keypoint_distance});
+    put("feature_tracker.max_keypoint_detection", {(double)c.feature_tracker_max_keypoint_detection});
+    put("feature_tracker.max_init_frames", {(double)c.feature_tracker_max_init_frames});
+    put("feature_tracker.max_frames", {(double)c.feature_tracker_max_frames});
+    put("feature_tracker.clahe_clip_limit", {c.feature_tracker_clahe_clip_limit});
+    put("feature_tracker.clahe_width", {(double)c.feature_tracker_clahe_width});
+    put("feature_tracker.clahe_height", {(double)c.feature_tracker_clahe_height});
+    put("feature_tracker.predict_keypoints", {c.feature_tracker_predict_keypoints ? 1.0 : 0.0});
+    put("initializer.keyframe_num", {(double)c.initializer_keyframe_num});
+    put("initializer.keyframe_gap", {(double)c.initializer_keyframe_gap});
+    put("initializer.min_matches", {(double)c.initializer_min_matches});
+    put("initializer.min_parallax", {c.initializer_min_parallax});
+    put("initializer.min_triangulation", {(double)c.initializer_min_triangulation});
+    put("initializer.min_landmarks", {(double)c.initializer_min_landmarks});
+    put("initializer.refine_imu", {c.initializer_refine_imu ? 1.0 : 0.0});
+    put("solver.iteration_limit", {(double)c.solver_iteration_limit});
+    put("solver.time_limit", {c.solver_time_limit});
+    put("rotation.misalignment_threshold", {c.rotation_misalignment_threshold});
+    put("rotation.ransac_threshold", {c.rotation_ransac_threshold});
+    put("parsac.parsac_flag", {c.parsac_flag ? 1.0 : 0.0});
+    put("parsac.dynamic_probability", {c.parsac_dynamic_probability});
+    put("parsac.threshold", {c.parsac_threshold});
+    put("parsac.norm_scale", {c.parsac_norm_scale});
+    put("parsac.keyframe_check_size", {(double)c.parsac_keyframe_check_size});
+    return out;
 }
 
 }   // namespace xrh

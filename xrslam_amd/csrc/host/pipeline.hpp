@@ -207,6 +207,7 @@ struct Pipeline {
     SwtLogger swt_log;                 // XRSLAM_AMD_DUMP_SWT=<file>: decisions of the sliding-window tracker (ba_dump.hpp)
     SyncLogger sync_log;               // XRSLAM_AMD_DUMP_SYNC=<file>: IMU samples attached to every frame, poses answered (ba_dump.hpp)
     BaDumper ba_dump;                  // XRSLAM_AMD_DUMP_BA=<dir>: freeze the problems handed to xrhip_ba_solve (ba_dump.hpp)
+    OutLogger out_log;                 // XRSLAM_AMD_DUMP_OUT=<file>: what every frame produces -- key points, track ids, states, landmarks (ba_dump.hpp)
 
     explicit Pipeline(const Config &c) : config(c) {
         hip_check(xrhip_klt_create((int)c.cam_resolution[0], (int)c.cam_resolution[1],
@@ -1325,7 +1326,44 @@ class SlidingWindowTracker {
             speculate_subframes();
             take_mirror_hint();
         }
+        if (P_.out_log.enabled()) log_outputs(is_kf);
         return true;
+    }
+    // XRSLAM_AMD_DUMP_OUT: the 'B' record (ba_dump.hpp) -- the newest frame's state, the window, its key points' tracks, every track
+    void log_outputs(bool is_kf) {
+        const Frame *kf = map->get_frame(map->frame_num() - 1);
+        const Frame *nf = kf->subframes.empty() ? kf : kf->subframes.back().get();
+        OutLogger::Record r(P_.out_log, 'B');
+        r.u64(nf->id);
+        r.u32(is_kf ? 1 : 0);
+        double st[16];
+        BaBuilder::pack_state(nf, st);
+        for (double v : st) r.f64(v);
+        r.u32((uint32_t)map->frame_num());
+        for (size_t i = 0; i < map->frame_num(); ++i) {
+            const Frame *f = map->get_frame(i);
+            r.u64(f->id);
+            r.u32((uint32_t)f->subframes.size());
+            for (const auto &sf : f->subframes) r.u64(sf->id);
+        }
+        r.u32((uint32_t)nf->keypoint_num());
+        for (size_t k = 0; k < nf->keypoint_num(); ++k) r.i64(nf->get_track(k) ? (int64_t)nf->get_track(k)->id : -1);
+        r.u32((uint32_t)map->track_num());
+        for (size_t k = 0; k < map->track_num(); ++k) {
+            const Track *t = map->get_track(k);
+            uint32_t bits = 0;
+            for (int b = 0; b < TT_COUNT; ++b)
+                if (t->tags[b]) bits |= 1u << b;
+            r.u64(t->id);
+            r.u32(bits);
+            r.f64(std::isfinite(t->landmark.inv_depth) ? t->landmark.inv_depth : -1.0);
+            V3 x{0, 0, 0};
+            if (t->tag(TT_TRIANGULATED) && t->keypoint_num() > 0 && std::isfinite(t->landmark.inv_depth) && t->landmark.inv_depth != 0.0)
+                x = t->get_landmark_point();
+            r.f64(x.x);
+            r.f64(x.y);
+            r.f64(x.z);
+        }
     }
 
     // ------------------------------------------------------------------ RD-VIO dynamic-object rejection (:523-790)
@@ -2655,6 +2693,20 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         while (map->frame_num() > max_frames && map->get_frame(0)->id < opt_id) map->erase_frame(0);
         P.times.frames++;
         if (swt_tag) frontend_work(map->get_frame(map->frame_num() - 1)->id, overlap_detect ? attached : nullptr, std::move(deferred_tag));
+        // XRSLAM_AMD_DUMP_OUT: the 'F' record (ba_dump.hpp) -- the key points this frame carries out of the tracker (tracked and newly detected, in
+        // key-point order) and the tracks they are on (new tracks are created when the NEXT frame continues a point)
+        if (P.out_log.enabled()) {
+            OutLogger::Record r(P.out_log, 'F');
+            r.u64(attached->id);
+            r.f64(attached->image->t);
+            r.u32((uint32_t)attached->keypoint_num());
+            for (size_t k = 0; k < attached->keypoint_num(); ++k) {
+                const V2 px = apply_k(attached->get_keypoint(k), attached->K);
+                r.f64(px.x);
+                r.f64(px.y);
+                r.i64(attached->get_track(k) ? (int64_t)attached->get_track(k)->id : -1);
+            }
+        }
     }
 
     // -------- FrontendWorker::work (core/frontend_worker.cpp:28-86)

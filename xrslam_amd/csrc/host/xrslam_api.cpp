@@ -256,6 +256,17 @@ void impl_get_camera_config(Manager &m, XRSLAMAmdCameraConfig *out) {
     out->resolution[1] = (int)c.cam_resolution[1];
 }
 
+int impl_describe_config(Manager &m, char *buf, int cap) {
+    if (!m.sys) return 0;
+    const std::string text = xrh::describe_config(m.config);
+    if (buf && cap > 0) {
+        const size_t n = std::min(text.size(), (size_t)cap - 1);
+        std::memcpy(buf, text.data(), n);
+        buf[n] = 0;
+    }
+    return (int)text.size();
+}
+
 void impl_set_device_undistort(Manager &m, const char *model) {
     if (!m.sys) return;
     bind_device(m);
@@ -361,6 +372,7 @@ void XRSLAMAmdPushImageDevice(const void *gray_dev, int stride, double timestamp
     impl_push_image_device(mgr(), gray_dev, stride, timestamp);
 }
 void XRSLAMAmdGetCameraConfig(XRSLAMAmdCameraConfig *out) { impl_get_camera_config(mgr(), out); }
+int XRSLAMAmdDescribeConfig(char *buf, int cap) { return impl_describe_config(mgr(), buf, cap); }
 void XRSLAMAmdSetDeviceUndistort(const char *model) { impl_set_device_undistort(mgr(), model); }
 void XRSLAMAmdGetTimes(XRSLAMAmdTimes *out) { impl_get_times(mgr(), out); }
 void XRSLAMAmdSetProfiling(int enable) { impl_set_profiling(mgr(), enable); }
@@ -410,6 +422,9 @@ void XRSLAMAmdInstancePushImageDevice(XRSLAMAmdInstance *inst, const void *gray_
 }
 void XRSLAMAmdInstanceGetCameraConfig(XRSLAMAmdInstance *inst, XRSLAMAmdCameraConfig *out) {
     if (inst) impl_get_camera_config(inst->m, out);
+}
+int XRSLAMAmdInstanceDescribeConfig(XRSLAMAmdInstance *inst, char *buf, int cap) {
+    return inst ? impl_describe_config(inst->m, buf, cap) : 0;
 }
 void XRSLAMAmdInstanceSetDeviceUndistort(XRSLAMAmdInstance *inst, const char *model) {
     if (inst) impl_set_device_undistort(inst->m, model);
