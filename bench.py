@@ -80,20 +80,47 @@ def newest_profile(pattern):
         return None
 
 
-def roofline_extras(kernel_rev):
+def roofline_extras(kernel_rev, workload="s1"):
     """Measured peaks of the MI355X the profiles were taken on (tools/peaks.hip) and the HBM-side traffic of the
-    committed rocprofv3 --pmc passes -- the latter only when those passes ran the kernels this library carries."""
+    committed rocprofv3 --pmc passes -- the latter only when those passes ran the kernels this library carries ON THIS WORKLOAD
+    (a counter figure is per launch of a kernel on one stream's problems: S1's 0.22 MB per kb_chain launch says nothing about S3's)."""
     peaks = newest_profile("r*_peaks.json") or {}
     pmc = newest_profile("r*_pmc_traffic.json") or {}
     traffic, note = {}, "no committed PMC pass"
     if pmc:
-        rev = pmc.get("_kernel_rev")
-        if rev == kernel_rev:
+        rev, wl = pmc.get("_kernel_rev"), pmc.get("_workload", "s1")
+        if rev == kernel_rev and wl == workload:
             traffic = {k: round(1024.0 * (v["fetch_kb"] + v["write_kb"]), 1) for k, v in pmc.items() if isinstance(v, dict)}
-            note = "profiles/ PMC passes of kernel revision " + str(rev)
-        else:
+            note = "profiles/ PMC passes of kernel revision %s, workload %s" % (rev, wl)
+        elif rev != kernel_rev:
             note = "committed PMC passes are of kernel revision %s, this library is %s: not shown" % (rev, kernel_rev)
+        else:
+            note = "committed PMC passes are of workload %s, this line is %s: not shown" % (wl, workload)
     return peaks, traffic, note
+
+
+def device_power_state(index):
+    """Shader / memory clock and power cap of the device as the run found them (rocm-smi; amdsmi is not in the image): boxes of the
+    pool differ by up to 30 % on the single-workgroup f64 kernels -- with this in the line a slow box is
+    distinguishable from a regression.  Best effort: {} when the tool is missing or prints something else."""
+    import re
+    import subprocess
+    out = {}
+    try:
+        txt = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--showmaxpower", "--showpower", "--showperflevel"],
+                             capture_output=True, text=True, timeout=20).stdout
+    except (OSError, subprocess.SubprocessError):
+        return out
+    for key, pat in (("sclk_mhz", r"sclk clock level:[^(]*\((\d+)Mhz\)"), ("mclk_mhz", r"mclk clock level:[^(]*\((\d+)Mhz\)"),
+                     ("fclk_mhz", r"fclk clock level:[^(]*\((\d+)Mhz\)"), ("power_cap_w", r"Max Graphics Package Power \(W\):\s*([\d.]+)"),
+                     ("power_w", r"Graphics Package Power \(W\):\s*([\d.]+)")):
+        m = re.search(pat, txt)
+        if m:
+            out[key] = float(m.group(1))
+    m = re.search(r"Performance Level:\s*(\w+)", txt)
+    if m:
+        out["perf_level"] = m.group(1)
+    return out
 
 
 def precision_study():
@@ -237,8 +264,10 @@ def rendezvous_only(args):
     group = RunGroup(backend=args.backend or "gloo")
     group.barrier()
     red = group.reduce_metrics(args.steps, 1.0 + 0.25 * group.rank)
+    rows = group.gather_rows([group.rank, group.local_rank, args.steps / (1.0 + 0.25 * group.rank)])
     if group.rank == 0:
         print(json.dumps({"rendezvous_only": True, "n_gpus": group.world, "frames": red["frames"], "seconds_max": red["seconds"],
+                          "per_rank": [{"rank": int(r[0]), "device": int(r[1]), "frames_per_s": round(r[2], 3)} for r in rows],
                           "note": "no measurement: the launcher / process-group path of bench.py --gpus N exercised without a device"}))
     group.barrier()
     group.close()
@@ -335,13 +364,21 @@ def main():
     from xrslam_amd import _lib
     from xrslam_amd.harness import runner
     from xrslam_amd.harness.dist import RunGroup
-    device_index = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()   # == LOCAL_RANK on a full node
+    local_rank, n_dev = int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count()
+    # one rank per GPU.  More ranks than devices used to wrap around silently (LOCAL_RANK % device_count): two
+    # ranks then shared a GPU and the line still said n_gpus: N.  RCCL refuses that anyway ("Duplicate GPU detected"); only the
+    # gloo backend -- the explicit single-GPU exercise of the multi-process path -- may double up, and the line says so (per_rank).
+    if local_rank >= n_dev and (args.backend or "nccl") != "gloo":
+        raise SystemExit("rank %d of this node has no GPU of its own: %d device(s) visible (--gpus must not exceed them; "
+                         "--backend gloo shares devices on purpose)" % (local_rank, n_dev))
+    device_index = local_rank % n_dev
     torch.cuda.set_device(device_index)
     group = RunGroup(backend=args.backend)  # one process per GPU; "nccl" == RCCL over xGMI
     rank, world = group.rank, group.world
     _lib.set_device(device_index)
     kernel_rev = _lib.kernel_revision()
-    peaks, traffic, traffic_note = roofline_extras(kernel_rev)
+    peaks, traffic, traffic_note = roofline_extras(kernel_rev, args.workload)
+    power0 = device_power_state(device_index)
     common = {"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "kernel_rev": kernel_rev}
 
     if args.workload == "s4":
@@ -434,8 +471,13 @@ def main():
     bst = sess.ba_stats(reset=False)
     for s in sessions:
         s.set_profiling(False)
+    my_elapsed = elapsed
     red = group.reduce_metrics(args.steps * S, elapsed)      # frames: SUM, wall seconds: MAX over ranks
     elapsed, total_frames = red["seconds"], red["frames"]
+    # per-rank diagnostics into rank 0's line: a slow rank (clocked-down device, a device shared by two ranks) is visible there
+    power1 = device_power_state(device_index)
+    rows = group.gather_rows([rank, device_index, args.steps * S / my_elapsed, my_elapsed, power1.get("sclk_mhz", -1.0),
+                              power1.get("mclk_mhz", -1.0), power1.get("power_cap_w", -1.0), power1.get("power_w", -1.0)])
 
     if rank == 0:
         poses = list(sess.poses)
@@ -516,6 +558,11 @@ def main():
                             "algorithmic_bytes_per_launch": round(lk_bytes / n_launch, 1),
                             "launch_us": round(lk_ms * 1e3, 3)},
             "traffic_source": traffic_note,
+            # what every rank measured on its own clock, and the clock / power state of its device right after the timed region
+            "per_rank": [{"rank": int(r[0]), "device": int(r[1]), "frames_per_s": round(r[2], 3), "seconds": round(r[3], 4),
+                          "sclk_mhz": r[4] if r[4] >= 0 else None, "mclk_mhz": r[5] if r[5] >= 0 else None,
+                          "power_cap_w": r[6] if r[6] >= 0 else None, "power_w": r[7] if r[7] >= 0 else None} for r in rows],
+            "device_state": {"before": power0, "after_timed_region": power1},
         })
         if pre_ms:
             # what the untimed pre-roll hides: the first marginalisation of a sequence goes through the eigen path (km_jacobi,

@@ -47,6 +47,7 @@ struct xrhip_ba {
     // results of the asynchronous forms, per context like the product (computed at _begin, handed over at _end)
     std::vector<double> preint_out, marg_si, marg_iv, marg_lin;
     int preint_rc = 0, marg_rc = 0;
+    int preint_pending = 0;   // jobs between _begin and _end (the product's state machine: ba_api.hip, preint_pending)
     // xrhip_ba_preintegrate_after_solve: the batch waits here for the next solve's biases
     struct Deferred {
         std::vector<double> samples, t_end, noise;
@@ -58,6 +59,23 @@ struct xrhip_ba {
 };
 
 static thread_local std::string g_err;
+
+// Fault injection (tests/test_error_recovery.py): the `countdown`-th call from now of the entry point `which` fails with XRHIP_EHIP,
+// the way a device error would surface there.  which: 1 = xrhip_ba_preintegrate_end, 2 = xrhip_ba_solve, 3 = xrhip_image_track,
+// 4 = xrhip_ba_preintegrate_begin.  Process-wide (the tests drive one instance at a time).
+#include <atomic>
+static std::atomic<int> g_fail_which{0}, g_fail_countdown{0};
+static bool injected_failure(int which, const char *name) {
+    if (g_fail_which.load(std::memory_order_relaxed) != which) return false;
+    if (g_fail_countdown.fetch_sub(1) != 1) return false;
+    g_fail_which.store(0);
+    g_err = std::string(name) + ": injected device failure";
+    return true;
+}
+extern "C" void orc_inject_failure(int which, int countdown) {
+    g_fail_countdown.store(countdown);
+    g_fail_which.store(which);
+}
 
 extern "C" {
 
@@ -151,7 +169,7 @@ int xrhip_image_detect(xrhip_image *im, const double *existing, int n_exist, int
                                   min_dist, out_xy);
     return 0;
 }
-int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const double *curr_xy, double *next_xy,
+int xrhip_image_track_impl(const xrhip_image *cur, const xrhip_image *next, const double *curr_xy, double *next_xy,
                       int has_guess, uint8_t *status, int n) {
     if (!cur->have_pyr || !next->have_pyr) {
         g_err = "track: preprocess() has not run";
@@ -159,6 +177,11 @@ int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const dou
     }
     if (n > 0) orc_track_keypoints(cur->pyr, next->pyr, curr_xy, next_xy, has_guess, status, n, nullptr);
     return 0;
+}
+int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const double *curr_xy, double *next_xy, int has_guess,
+                      uint8_t *status, int n) {
+    if (injected_failure(3, "xrhip_image_track")) return XRHIP_EHIP;
+    return xrhip_image_track_impl(cur, next, curr_xy, next_xy, has_guess, status, n);
 }
 int xrhip_klt_set_profiling(xrhip_klt *, int) { return 0; }
 int xrhip_klt_get_stats(xrhip_klt *, xrhip_klt_stats *out, int) {
@@ -179,6 +202,10 @@ int xrhip_ba_solve_overlapped(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_s
     return rc;
 }
 int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *s) {
+    if (injected_failure(2, "xrhip_ba_solve")) {
+        if (c) c->have_deferred = false;   // the product drops a batch staged behind a solve that failed
+        return XRHIP_EHIP;
+    }
     if (c && c->have_deferred && P)   // like the product: a bad frame index is refused before the solve touches anything
         for (int f : c->deferred.frame)
             if (f < 0 || f >= P->n_frames) {
@@ -236,8 +263,14 @@ int xrhip_ba_preintegrate_batch(xrhip_ba *c, const double *samples, const int *b
 // asynchronous form: the CPU reference computes at _begin and hands the records over at _end
 int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *begin, const int *count, const double *t_end,
                                 const double *bg, const double *ba, int n_jobs, const double *noise36, int jac, int cov) {
+    if (c->preint_pending || c->have_deferred) {   // the product's rule: one batch between _begin and _end per context
+        g_err = "xrhip_ba_preintegrate_begin: a batch is already in flight on this context";
+        return XRHIP_ESTATE;
+    }
+    if (injected_failure(4, "xrhip_ba_preintegrate_begin")) return XRHIP_EHIP;
     c->preint_out.assign((size_t)XRHIP_IMU_DIM * n_jobs, 0.0);
     c->preint_rc = xrhip_ba_preintegrate_batch(c, samples, begin, count, t_end, bg, ba, n_jobs, noise36, jac, cov, c->preint_out.data());
+    c->preint_pending = n_jobs;
     return 0;
 }
 int xrhip_ba_preintegrate_after_solve(xrhip_ba *c, const double *samples, const int *begin, const int *count, const double *t_end,
@@ -245,6 +278,10 @@ int xrhip_ba_preintegrate_after_solve(xrhip_ba *c, const double *samples, const 
     if (!c || !samples || !begin || !count || !t_end || !bias_frame || !noise36 || n_jobs <= 0) {
         g_err = "xrhip_ba_preintegrate_after_solve: bad arguments";
         return XRHIP_EINVAL;
+    }
+    if (c->preint_pending || c->have_deferred) {
+        g_err = "xrhip_ba_preintegrate_after_solve: a batch is already in flight on this context";
+        return XRHIP_ESTATE;
     }
     int total = 0;
     for (int k = 0; k < n_jobs; ++k) total = std::max(total, begin[k] + count[k]);
@@ -264,6 +301,7 @@ int xrhip_ba_preintegrate_cancel(xrhip_ba *c) {
     if (!c) return XRHIP_EINVAL;
     c->have_deferred = false;
     c->preint_rc = 0;
+    c->preint_pending = 0;
     return 0;
 }
 int xrhip_ba_preintegrate_end(xrhip_ba *c, double *out) {
@@ -272,6 +310,12 @@ int xrhip_ba_preintegrate_end(xrhip_ba *c, double *out) {
         g_err = "xrhip_ba_preintegrate_end: the batch waits for a solve that never ran";
         return XRHIP_ESTATE;
     }
+    if (!c->preint_pending) {
+        g_err = "xrhip_ba_preintegrate_end: nothing in flight";
+        return XRHIP_ESTATE;
+    }
+    c->preint_pending = 0;
+    if (injected_failure(1, "xrhip_ba_preintegrate_end")) return XRHIP_EHIP;
     if (c->preint_rc) return c->preint_rc;
     std::memcpy(out, c->preint_out.data(), sizeof(double) * c->preint_out.size());
     return 0;

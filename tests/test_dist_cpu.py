@@ -56,6 +56,9 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["frames"] == 14      # SUM over both ranks
     assert out["seconds_max"] == 1.25                      # MAX over ranks (rank 1 reports 1.25)
+    # what each rank measured, gathered into rank 0's line (the measuring path prints the same field: a slow rank shows)
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and [r["device"] for r in out["per_rank"]] == [0, 1]
+    assert out["per_rank"][0]["frames_per_s"] == 7.0 and out["per_rank"][1]["frames_per_s"] == 5.6
 
 
 def test_bench_refuses_a_gpus_flag_that_contradicts_the_launcher():

@@ -1,0 +1,81 @@
+#!/bin/bash
+# One parametrised GPU call (run through gpurun); everything lands under gpurun_out/.  Replaces the one-off gpu_*.sh scripts of
+# rounds 1-3 (git history has them): every measurement of a round is a list of steps of this script.
+#   gpurun --timeout 1500 -- tools/gpu.sh TAG step [step ...]
+# steps (NAME or NAME:ARGS; ARGS are passed on verbatim):
+#   tests[:pytest args]     the GPU suite (default: tests)              smoke              __graft_entry__.smoke()
+#   bench[:bench.py args]   one bench.py line + a one-line digest       driver             the driver's --steps 20 --warmup 5 line
+#   multi:S [args]          bench.py --sequences-per-gpu S              procs:N Q          N one-sequence processes on this GPU (gloo), Q HW queues each
+#   trace[:bench.py args]   rocprofv3 --kernel-trace --stats + per-kernel averages         pmc[:args]   MFMA / FETCH_SIZE / WRITE_SIZE passes
+#   ab:VARIANT              default library vs lib/libxrslam_hip_VARIANT.so, alternating (S1 line and S4 replay)
+#   abenv:VAR [reps]        the default bench line with VAR unset / =1, interleaved
+#   hostprof                XRHIP_HOSTPROF scope accumulators of the S1 stream             kprint[:PATTERN]   in-kernel printf timers (kprint variant)
+#   peaks                   tools/peaks.hip micro-benchmarks            clocks             rocm-smi clock / power state
+set -uo pipefail
+R="$(cd "$(dirname "$0")/.." && pwd)"
+TAG="${1:?tag}"; shift
+O="$R/gpurun_out"; mkdir -p "$O"; cd "$R"
+BENCH_PROF="--steps 100 --warmup 40 --cpu-frames 0 --variant-frames 0 --no-profile"
+digest() { python - "$1" <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+except Exception as e:
+    print("no bench line:", repr(e)); sys.exit(0)
+print("value", d.get("value"), d.get("unit"), "ms/step", d.get("ms_per_step"), "variants", {k: v["value"] for k, v in d.get("variants", {}).items() if isinstance(v, dict)})
+if "roofline" in d:
+    print("chain_us", d["roofline"]["launch_us"], "solve_try_us", d["roofline_solve"]["launch_us"], "lk_us", d["roofline_lk"]["launch_us"], "ba_it_ms", d.get("ms_per_ba_iteration"), "ate", d.get("ate_rmse_m"))
+    print(d.get("host_scope_ms_per_frame")); print(d.get("host_wall_ms_per_frame"))
+for k in ("group", "per_rank", "cpu_baseline"):
+    if k in d: print(k, d[k])
+PY
+}
+kernel_avgs() { python - "$1" <<'PY'
+import sqlite3, sys, collections, glob
+db = glob.glob(sys.argv[1] + "/*results.db")
+if not db: print("no results db under", sys.argv[1]); sys.exit(0)
+c = sqlite3.connect(db[0]); tot = collections.defaultdict(lambda: [0, 0])
+for n, s, e in c.execute("select name,start,end from kernels"):
+    k = n.split("(")[0].replace("void ", "").replace("xrhip::", ""); tot[k][0] += 1; tot[k][1] += e - s
+print("  ".join("%s %d x %.1f" % (k[:24], n, t / n / 1e3) for k, (n, t) in sorted(tot.items(), key=lambda x: -x[1][1])[:30]))
+PY
+}
+n=0
+for step in "$@"; do
+  n=$((n+1)); name="${step%%:*}"; arg=""; [ "$step" != "$name" ] && arg="${step#*:}"
+  echo "--- [$n] $step"
+  case "$name" in
+    tests)  timeout 1500 python -m pytest ${arg:-tests} -m gpu -x -q > "$O/tests_${TAG}_$n.log" 2>&1; tail -3 "$O/tests_${TAG}_$n.log" ;;
+    smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke_$TAG.log" 2>&1; tail -2 "$O/smoke_$TAG.log" ;;
+    bench)  timeout 500 python bench.py $arg > "$O/bench_${TAG}_$n.json" 2> "$O/bench_${TAG}_$n.err"; digest "$O/bench_${TAG}_$n.json"; tail -2 "$O/bench_${TAG}_$n.err" ;;
+    driver) timeout 240 python bench.py --steps 20 --warmup 5 > "$O/bench_${TAG}_driver.json" 2> "$O/bench_${TAG}_driver.err"; digest "$O/bench_${TAG}_driver.json" ;;
+    multi)  set -- $arg; S="$1"; shift
+            timeout 500 python bench.py --sequences-per-gpu "$S" --steps 200 --warmup 50 --cpu-frames 0 "$@" > "$O/bench_${TAG}_multi${S}_$n.json" 2> "$O/bench_${TAG}_multi${S}_$n.err"
+            digest "$O/bench_${TAG}_multi${S}_$n.json"; tail -2 "$O/bench_${TAG}_multi${S}_$n.err" ;;
+    procs)  set -- $arg; N="$1"; Q="${2:-2}"
+            GPU_MAX_HW_QUEUES=$Q OMP_NUM_THREADS=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((29500 + N + Q)) bench.py --gpus "$N" --backend gloo --steps 200 --warmup 50 --cpu-frames 0 --variant-frames 0 > "$O/procs_${TAG}_${N}_$Q.json" 2> "$O/procs_${TAG}_${N}_$Q.err"
+            digest "$O/procs_${TAG}_${N}_$Q.json" ;;
+    trace)  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof_${TAG}_$n" -o full -- python "$R/bench.py" ${arg:-$BENCH_PROF} > "$O/prof_${TAG}_$n.log" 2>&1); kernel_avgs "$O/prof_${TAG}_$n" ;;
+    pmc)    (cd /tmp && export TMPDIR=/tmp
+             timeout 150 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$O/pmc_$TAG/MFMA" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --no-profile $arg > "$O/pmc_${TAG}_MFMA.log" 2>&1
+             for C in FETCH_SIZE WRITE_SIZE; do timeout 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$O/pmc_$TAG/$C" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --no-profile $arg > "$O/pmc_${TAG}_$C.log" 2>&1; done); ls "$O/pmc_$TAG" ;;
+    ab)     lib="$R/xrslam_amd/lib/libxrslam_hip_$arg.so"
+            for rep in 1 2; do for v in default "$arg"; do
+              e="XR_DUMMY=0"; [ "$v" != default ] && e="XRSLAM_HIP_LIB=$lib"
+              env $e timeout 200 python bench.py --steps 300 --warmup 50 --cpu-frames 0 --variant-frames 0 2>/dev/null > "$O/ab_${TAG}_${v}_$rep.json"; echo "$v rep$rep:"; digest "$O/ab_${TAG}_${v}_$rep.json" | head -2
+            done; done
+            for v in default "$arg"; do e="XR_DUMMY=0"; [ "$v" != default ] && e="XRSLAM_HIP_LIB=$lib"
+              env $e timeout 200 python bench.py --workload s4 --steps 100 2>/dev/null | python -c "
+import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('$v S4:', '  '.join('%s %.4f' % (s['snapshot'], s['ms_per_solve']) for s in d['snapshots']))"; done ;;
+    abenv)  set -- $arg; VAR="$1"; REPS="${2:-3}"
+            for r in $(seq "$REPS"); do for mode in off on; do
+              if [ $mode = on ]; then export "$VAR"=1; else unset "$VAR"; fi
+              timeout 200 python bench.py --steps 300 --warmup 50 --cpu-frames 0 --variant-frames 0 2>/dev/null > "$O/abenv_${TAG}_${mode}_$r.json"; echo "$VAR $mode rep $r:"; digest "$O/abenv_${TAG}_${mode}_$r.json" | head -1
+            done; done; unset "$VAR" ;;
+    hostprof) XRHIP_HOSTPROF=1 timeout 300 python bench.py --steps 150 --warmup 50 --cpu-frames 0 --variant-frames 0 --threading inline > "$O/hostprof_$TAG.json" 2> "$O/hostprof_$TAG.txt"; grep hostprof "$O/hostprof_$TAG.txt" | cut -c1-130 | tail -40 ;;
+    kprint) XRSLAM_HIP_LIB="$R/xrslam_amd/lib/libxrslam_hip_kprint.so" timeout 200 python bench.py --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --threading inline 2>/dev/null | grep -v '^{' > "$O/blocks_$TAG.txt"; grep "${arg:-kb_}" "$O/blocks_$TAG.txt" | tail -12 ;;
+    peaks)  "$R/xrslam_amd/bin/xr-peaks" > "$O/peaks_$TAG.json" 2> "$O/peaks_$TAG.err"; cat "$O/peaks_$TAG.json" ;;
+    clocks) rocm-smi --showclocks --showpower --showmaxpower --showperflevel > "$O/clocks_$TAG.txt" 2>&1; grep -i "clock level\|power\|level" "$O/clocks_$TAG.txt" | head -12 ;;
+    *)      echo "unknown step $step" ;;
+  esac
+done

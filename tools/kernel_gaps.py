@@ -1,5 +1,5 @@
 """Where does the frame time go between kernels?  Reads the rocprofv3 kernel-trace database of a profiling call
-(gpurun_out/prof_TAG/full_results.db, written by tools/gpu_profile.sh) and reports, over the whole trace:
+(gpurun_out/prof_TAG/full_results.db, written by tools/gpu.sh TAG trace) and reports, over the whole trace:
 
   * busy time (union of all kernel intervals -- kernels on the auxiliary streams overlap the main chain),
   * idle time between kernels, split by the length of the gap (dispatch gaps of a few microseconds inside a solve versus

@@ -5,7 +5,7 @@ On the GPU box (one gpurun call; PMC passes are separate runs without any other 
     rocprofv3 --kernel-trace --memory-copy-trace --stats -d $R/gpurun_out/prof_TAG -o full -- python $R/bench.py --steps 100 --warmup 40 --cpu-frames 0 --no-profile
     for C in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_TAG/$C -o pmc -- python $R/bench.py --steps 60 --warmup 40 --cpu-frames 0 --no-profile; done
     python $R/bench.py > $R/gpurun_out/bench_TAG.json
-(tools/gpu_profile.sh TAG is that command sequence.)  Here:
+(tools/gpu.sh TAG tests bench trace peaks pmc is that command sequence.)  Here:
     python tools/make_profile_summary.py TAG v13 "one-line description of this version"
 XR_ROUND (default r01) is the prefix of the files written under profiles/ (r02 in round 2, ...); the PMC header text is
 taken from the newest existing r*_pmc_traffic.md.
@@ -79,7 +79,8 @@ if os.path.isdir(pmc_dir):
         out[n] = {"launches": f[1], "fetch_kb": round(fk, 2), "write_kb": round(wk, 2)}
         head += "| `%s` | %d | %.1f | %.1f |\n" % (n, f[1], fk, wk)
     open(md, "w").write(head)
-    out["_kernel_rev"] = bj.get("kernel_rev")   # bench.py shows these numbers only beside timings of the same kernels
+    out["_kernel_rev"] = bj.get("kernel_rev")   # bench.py shows these numbers only beside timings of the same kernels ...
+    out["_workload"] = os.environ.get("XR_WORKLOAD", "s1")   # ... on the same workload (a per-launch figure depends on the problems)
     json.dump(out, open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd), "w"), indent=1)
 print("\n".join(lines[5:22]))
 print(bj["roofline"])

@@ -19,7 +19,8 @@ def configure(lib):
     lib.xrhip_ba_destroy.argtypes = [vp]
     lib.xrhip_ba_destroy.restype = None
     lib.xrhip_ba_solve.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary)]
-    lib.xrhip_ba_solve_overlapped.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary), HOST_WORK, vp]
+    if hasattr(lib, "xrhip_ba_solve_overlapped"):
+        lib.xrhip_ba_solve_overlapped.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary), HOST_WORK, vp]
     if hasattr(lib, "xrhip_ba_marginalize"):
         lib.xrhip_ba_marginalize.argtypes = [vp, C.POINTER(abi.MargProblem), vp, vp, vp]
     if hasattr(lib, "xrhip_ba_marginalize_begin"):
@@ -99,8 +100,18 @@ class BaContext:
         if host_work is None:
             check(self._lib.xrhip_ba_solve(self._h, C.byref(s), C.byref(sm)))
         else:
-            cb = HOST_WORK(lambda _arg: host_work())
-            check(self._lib.xrhip_ba_solve_overlapped(self._h, C.byref(s), C.byref(sm), cb, None))
+            raised = []   # ctypes only PRINTS what a callback raises: keep it and re-raise once the solve has returned
+
+            def run(_arg):
+                try:
+                    host_work()
+                except BaseException as e:   # noqa: BLE001  (re-raised below)
+                    raised.append(e)
+            cb = HOST_WORK(run)
+            rc = self._lib.xrhip_ba_solve_overlapped(self._h, C.byref(s), C.byref(sm), cb, None)
+            if raised:
+                raise raised[0]
+            check(rc)
         return sm
 
     def marginalize(self, md):

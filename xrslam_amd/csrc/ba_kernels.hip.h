@@ -50,7 +50,7 @@ struct BaCtl {   // device-resident solver state (one per context)
     long long prof[32];   // accumulated 100 MHz ticks per kernel phase (only written by -DXRHIP_KPROF builds)
 };
 // -DXRHIP_KPROF: phase sums in BaCtl::prof (tools/kprof_run.sh); -DXRHIP_KPROF_PRINT: per-workgroup timers of the multi-workgroup
-// kernels, printed from the device (tools/gpu_kprof_print.sh) -- how the load imbalances of kb_landmark_vision / kb_schur_aux /
+// kernels, printed from the device (tools/gpu.sh kprint) -- how the load imbalances of kb_landmark_vision / kb_schur_aux /
 // kb_trials_wide were found in round 3
 #ifdef XRHIP_KPROF
 #define KPROF_BEGIN() long long kp_t = wall_clock64()

@@ -490,7 +490,7 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next, std::fun
                   "xrhip_image_track");
     }
     xrhip::HostProfScope hp_post(4, "ft_track: after LK (all)");
-    xrhip::HostProfScope *hp_a = new xrhip::HostProfScope(5, "ft_track: bearings");
+    std::optional<xrhip::HostProfScope> hp_a(std::in_place, 5, "ft_track: bearings");
     std::vector<char> status(st8.begin(), st8.begin() + n), mask;
     std::vector<V2> cur_h, next_h;
     std::vector<V3> next_bearings;
@@ -504,7 +504,7 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next, std::fun
         next_h.push_back({nb.x / nb.z, nb.y / nb.z});
         next_bearings.push_back(nb);
     }
-    delete hp_a;
+    hp_a.reset();
     {
         WallTimer sc_e(P.times.scope[SC_RANSAC_E]);
         find_essential_matrix(cur_h, next_h, mask, 1.0);
@@ -517,7 +517,7 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next, std::fun
         R = find_rotation_matrix(cur->bearings, next_bearings, mask, (M_PI / 180.0) * c.rotation_ransac_threshold);
     }
     xrhip::HostProfScope hp_b(6, "ft_track: angles+poisson+append");
-    xrhip::HostProfScope *hp_c = new xrhip::HostProfScope(13, "ft_track: angles");
+    std::optional<xrhip::HostProfScope> hp_c(std::in_place, 13, "ft_track: angles");
     {
         // (R * cur->bearings[i] and next_bearings[i] of the inliers, in keypoint order: everything the test reads, by value)
         std::vector<std::pair<V3, V3>> pairs;
@@ -540,8 +540,7 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next, std::fun
         else decide(nullptr);
     }
 
-    delete hp_c;
-    hp_c = new xrhip::HostProfScope(14, "ft_track: by_length+poisson");
+    hp_c.emplace(14, "ft_track: by_length+poisson");
     std::vector<std::pair<size_t, size_t>> by_length;
     by_length.reserve(n);
     for (size_t i = 0; i < n; ++i) {
@@ -561,7 +560,7 @@ inline void frame_track_keypoints(Pipeline &P, Frame *cur, Frame *next, std::fun
             status[ki] = 0;
         }
     }
-    delete hp_c;
+    hp_c.reset();
     xrhip::HostProfScope hp_d(15, "ft_track: append");
     for (size_t i = 0; i < n; ++i) {
         if (status[i]) {
@@ -1090,6 +1089,21 @@ class SlidingWindowTracker {
     size_t prepared_id_ = nil(), prepared_from_ = nil(), prepared_samples_ = 0;
     bool prepared_ = false;
     long mirror_prepared_ = 0, mirror_total_ = 0, mirror_chained_ = 0;
+    // Error unwind (System::recover_after_error): the device side of every queued integration has been cancelled
+    // (Pipeline::cancel_integrations); this is the host side -- nothing is "prepared", "chained", "queued" or "speculated" any more,
+    // so no later call tries to collect a batch that is gone (xrhip_ba_preintegrate_end: "nothing in flight").
+    void forget_queued_work() noexcept {
+        prepared_id_ = nil();
+        prepared_ = false;
+        chained_id_ = nil();
+        kf_queued_ = false;
+        kf_ok_.clear();
+        spec_jobs_ = 0;
+        spec_.clear();
+        memo_id_ = nil();
+        std::lock_guard<std::mutex> lk(hint_mutex_);
+        hint_.reset();
+    }
 
     // Pipelined mode (System::set_threading): the window map belongs to the backend thread while the feature tracker works on
     // the next frame, so mirror_prepare cannot be called from there.  The feature tracker posts what it knows -- the samples of
@@ -1516,7 +1530,7 @@ class SlidingWindowTracker {
 
     void localize_newframe(BaBuilder::Overlap *overlap = nullptr) {   // :119-143
         WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
-        xrhip::HostProfScope *hp_a = new xrhip::HostProfScope(12, "localize: problem assembly");
+        std::optional<xrhip::HostProfScope> hp_a(std::in_place, 25, "localize: problem assembly");
         BaBuilder b(P_);
         Frame *fi = map->get_frame(map->frame_num() - 2);
         if (!fi->subframes.empty()) fi = fi->subframes.back().get();
@@ -1526,7 +1540,7 @@ class SlidingWindowTracker {
         for (size_t k = 0; k < fj->keypoint_num(); ++k)
             if (Track *t = fj->get_track(k))
                 if (t->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) b.add_reprojection_prior(fj, k);
-        delete hp_a;
+        hp_a.reset();
         b.solve(nullptr, overlap);
     }
 
@@ -1642,7 +1656,7 @@ class SlidingWindowTracker {
 
     void refine_window() {   // :247-358
         WallTimer sc_t(P_.times.scope[SC_REFINE_WINDOW]);
-        xrhip::HostProfScope *hp_a = new xrhip::HostProfScope(17, "refine_window: assembly");
+        std::optional<xrhip::HostProfScope> hp_a(std::in_place, 17, "refine_window: assembly");
         BaBuilder b(P_);
         if (!map->marginalization_factor) map->marginalization_factor = create_marginalization_factor(map.get());
         // the keyframe intervals are re-integrated at the current biases: queued by track() before track_landmark (the device works on
@@ -1682,7 +1696,7 @@ class SlidingWindowTracker {
                     b.add_preintegration_error(map->get_frame(j - 1), fj, fj->keyframe_preintegration);
                 }
         }
-        delete hp_a;
+        hp_a.reset();
         {
             xrhip::HostProfScope hp_w(18, "refine_window: batch_end wait");
             P_.integrate_batch_end();
@@ -1866,7 +1880,7 @@ class SlidingWindowTracker {
                 xrhip::HostProfScope hp_i(21, "refine_subwindow: integrate_subframes_begin");
                 integrate_subframes_begin(frame);
             }
-            xrhip::HostProfScope *hp_l = new xrhip::HostProfScope(22, "refine_subwindow: factor loops");
+            std::optional<xrhip::HostProfScope> hp_l(std::in_place, 22, "refine_subwindow: factor loops");
             for (size_t i = 0; i < frame->subframes.size(); ++i) {
                 Frame *sf = frame->subframes[i].get();
                 b.add_frame_states(sf);
@@ -1885,7 +1899,7 @@ class SlidingWindowTracker {
                     }
                 }
             }
-            delete hp_l;
+            hp_l.reset();
             {
                 xrhip::HostProfScope hp_w(23, "refine_subwindow: batch_end wait");
                 P_.integrate_batch_end();
@@ -2407,8 +2421,65 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
         if (inflight_id_ == nil() || inflight_joined_) return;
         inflight_joined_ = true;   // set first: if the job threw, wait() rethrows and the job must not be waited for twice
         WallTimer wt(P.times.w_join);
-        worker->wait();
+        try {
+            worker->wait();
+        } catch (...) {
+            backend_failed_ = true;   // the window map may be half way through a frame: recover_after_error() goes back to the initialiser
+            throw;
+        }
     }
+    // The unwind of the C API's catch-all (xrslam_api.cpp: guarded()).  An exception has left the pipeline somewhere inside a frame:
+    //  * pipelined mode: the backend's contexts (P.ba, P.ba_aux) belong to its thread while a job runs -- JOIN it before anything
+    //    of its is touched (an error on the API thread, e.g. an unsupported image, must not race the running job);
+    //  * no pre-integration batch stays between begin and end on any context (device side), and nothing on the host still believes
+    //    one is (prepared / chained / queued / speculated batches, Pipeline::pending_pre_): the frames that follow are not refused;
+    //  * if the error came out of the sliding-window tracker (mirror_frame / track, inline or as the backend job), its map may have
+    //    taken half a frame: FrontendWorker::work's failure branch (core/frontend_worker.cpp:75-81) -- the tracker is dropped, a fresh
+    //    initialiser takes over, the published state is cleared.  Externally supplied initial states are kept.
+    // tests/test_error_recovery.py injects failures through the CPU shim and requires the stream to go on tracking.
+    void recover_after_error() noexcept {
+        if (inflight_id_ != nil() && !inflight_joined_) {
+            try {
+                sync();
+            } catch (...) {
+            }
+        }
+        try {
+            P.marg_launch_wait();
+        } catch (...) {
+            backend_failed_ = true;   // a prior whose marginalisation was never launched cannot be resolved
+        }
+        P.cancel_integrations();
+        P.pending_pre_.clear();
+        if (swt) swt->forget_queued_work();
+        mirror_done_.store(true, std::memory_order_release);
+        if (backend_failed_) {
+            backend_failed_ = false;
+            inflight_id_ = nil();
+            inflight_joined_ = false;
+            inflight_ok_ = false;
+            last_mirrored_id_ = nil();
+            frontend_latest_state = {0.0, nil(), PoseState{}, MotionState{}};
+            if (swt && swt->map && swt->map->marginalization_factor) {   // a marginalisation still on the device: drain its context
+                try {
+                    resolve_marginalization(P, swt->map->marginalization_factor.get());
+                } catch (...) {
+                }
+            }
+            swt.reset();
+            init.map.reset();
+        }
+    }
+    // marks the region in which an exception means "the window map is suspect" (inline mode; the pipelined job reports through sync())
+    struct BackendScope {
+        System &s;
+        int pending = std::uncaught_exceptions();
+        explicit BackendScope(System &sys) : s(sys) {}
+        ~BackendScope() {
+            if (std::uncaught_exceptions() > pending) s.backend_failed_ = true;
+        }
+    };
+    bool backend_failed_ = false;
     // join + publish: the hand-off proper
     void publish_backend_state() {
         if (inflight_id_ == nil()) return;
@@ -2751,6 +2822,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
             inflight_id_ = pending_frame_id;
             inflight_joined_ = false;
         } else if (detect_later) {
+            BackendScope backend_scope(*this);
             const bool mirrored = swt->mirror_frame(ft_map.get(), pending_frame_id);
             Frame *const copy = mirrored ? swt->map->get_frame(swt->map->frame_num() - 1) : nullptr;
             BaBuilder::Overlap ov;
@@ -2769,6 +2841,7 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
                 frontend_latest_state = {t, pending_frame_id, pose, motion};
             }
         } else {
+            BackendScope backend_scope(*this);
             swt->mirror_frame(ft_map.get(), pending_frame_id);
             if (swt->track()) {
                 auto [t, pose, motion] = swt->get_latest_state();

@@ -45,9 +45,10 @@ template <class F> void guarded(Manager &m, F &&f) {
     } catch (const std::exception &e) {
         m.last_error = e.what();
         std::fprintf(stderr, "[xrslam_hip] %s\n", e.what());
-        // whoever threw may have left a pre-integration batch between begin and end: release the contexts so that the frames
-        // that follow are not refused (an error raised on the backend thread surfaces here, in sync(), with that thread idle)
-        if (m.sys) m.sys->P.cancel_integrations();
+        // whoever threw may have left work between a begin and its end, on the device and in the host's bookkeeping, and -- in
+        // pipelined mode -- a backend job running: System::recover_after_error joins it, unwinds both sides and, if the sliding-window
+        // tracker was interrupted, falls back to the initialiser like the reference's tracking-failure branch
+        if (m.sys) m.sys->recover_after_error();
     }
 }
 

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <optional>
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -593,7 +594,7 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
     xrhip_klt *c = im->ctx;
     const int w = c->w, h = c->h;
     HostProfScope hp_all(0, "detect: whole call");
-    HostProfScope *hp_gpu = new HostProfScope(1, "detect: launch+D2H waits");
+    std::optional<HostProfScope> hp_gpu(std::in_place, 1, "detect: launch+D2H waits");
     if (!im->detect_seq) {
         int rc = launch_detect(im);
         if (rc) return rc;
@@ -612,7 +613,7 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
     }
     const int nc = c->h_sel->n_candidates, n_top = c->h_sel->n_top;
     if (nc > c->cand_cap) return xr_fail(XRHIP_EOVERFLOW, "xrhip_image_detect: corner candidate buffer overflow");
-    delete hp_gpu;
+    hp_gpu.reset();
     HostProfScope hp_sel(2, "detect: host selection");
     // total order: response desc, then linear index desc (cv greaterThanPtr).  The greedy spacing pass usually
     // stops after a few hundred candidates (max_points corners), so the order is produced lazily from a heap.

@@ -42,6 +42,17 @@ class RunGroup:
         return dict(frames=int(round(s[0].item())), seconds=float(m[0].item()), sq_err_sum=float(s[1].item()),
                     n_poses=int(round(s[2].item())))
 
+    def gather_rows(self, row):
+        """Every rank's `row` (a short list of floats), in rank order, on every rank: the per-rank diagnostics of a run
+        (frames/s, device index, clocks) that make a slow rank visible in rank 0's line.  One all_gather of len(row) doubles."""
+        if self.dist is None:
+            return [list(map(float, row))]
+        import torch
+        mine = torch.tensor([float(v) for v in row], dtype=torch.float64, device=self.device)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [[float(v) for v in t.tolist()] for t in out]
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
