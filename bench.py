@@ -4,7 +4,8 @@
   python bench.py --gpus N --steps K --warmup W        (one JSON line on rank 0; N > 1 without a launcher: re-executes
                                                         itself as N ranks under torch.distributed.run, one per GPU)
   python bench.py --workload {s1,s2,s3,s4}             (default s1 == BASELINE config 2; the others are extra lines)
-  python bench.py --sequences-per-gpu S                (S independent sequences on each GPU, one host thread each)
+  python bench.py --sequences-per-gpu S                (S independent sequences on each GPU, one host thread each, their per-frame
+                                                        launches issued together: an instance group; --no-group: S lone instances)
 
 A "step" is one camera frame of one sequence pushed through the whole hot path behind the reference's C API
 (include/XRSLAM.h, the player's call sequence of xrslam-pc/player/src/main.cpp:116-169): ~10 gyro + ~10 accel samples,
@@ -284,6 +285,9 @@ def main():
                          "rectified on the GPU, self-initialising like the reference; reports ATE against its ground truth")
     ap.add_argument("--sequences-per-gpu", type=int, default=1,
                     help="independent sequences per GPU, one host thread each (instance-scoped entry points)")
+    ap.add_argument("--no-group", action="store_true",
+                    help="with --sequences-per-gpu S: S lone instances (every sequence launches for itself, round 3's form) instead of "
+                         "one instance group whose members share launches (XRSLAMAmdGroup)")
     ap.add_argument("--cpu-frames", type=int, default=240,
                     help="most frames of the bounded CPU-reference sample (0 = skip); the first 40 are its warm-up")
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
@@ -394,6 +398,7 @@ def main():
     resident = args.image == "resident"
     native = not args.python_loop or S > 1
     sessions, keep = [], []
+    igroup = runner.Group(_lib.LIB_PATH) if (S > 1 and not args.no_group) else None
     for seq in seqs:
         dev = torch.from_numpy(seq["frames"]).cuda()     # the `resident` legs read their frames from here
         keep.append(dev)
@@ -401,7 +406,7 @@ def main():
         sessions.append(runner.Session(_lib.LIB_PATH, seq, slam_yaml=slam_yaml, sensor_yaml=sensor_yaml,
                                        device_frames=(dev.data_ptr(), h * w, w) if resident else None, instance=native,
                                        init_frames=0 if real is not None else 60, threading=1 if pipelined else 0,
-                                       device_undistort="cv_undistort" if real is not None else None))
+                                       device_undistort="cv_undistort" if real is not None else None, group=igroup))
     torch.cuda.synchronize()
     sess, seq = sessions[0], sessions[0].seq
     dev_frames0 = (keep[0].data_ptr(), seq["frames"].shape[1] * seq["frames"].shape[2], seq["frames"].shape[2])
@@ -457,6 +462,9 @@ def main():
         s.ba_stats(reset=True)
         if not args.no_profile:
             s.set_profiling(True)
+    if igroup is not None:
+        igroup.stats(reset=True)
+        igroup.set_profiling(not args.no_profile)
     barrier()
     del step_ms[:]
     t0 = time.perf_counter()
@@ -469,6 +477,11 @@ def main():
     t_e = sess.times()
     st = sess.klt_stats(reset=False)
     bst = sess.ba_stats(reset=False)
+    all_klt = [s.klt_stats(reset=False) for s in sessions] if S > 1 else [st]
+    gstats = None
+    if igroup is not None:
+        igroup.set_profiling(False)
+        gstats = igroup.stats()
     for s in sessions:
         s.set_profiling(False)
     my_elapsed = elapsed
@@ -558,12 +571,26 @@ def main():
                             "algorithmic_bytes_per_launch": round(lk_bytes / n_launch, 1),
                             "launch_us": round(lk_ms * 1e3, 3)},
             "traffic_source": traffic_note,
+            # the whole GPU against the HBM roofline: ALGORITHMIC bytes of the tracker stage (B_trk = CLAHE + pyramid +
+            # Scharr + Harris passes of every frame + the LK templates and iterations the kernels counted) of ALL sequences of this
+            # rank over the timed wall clock.  (The BA's ~0.1-0.6 MB per iteration are not in it: a lower bound.)
+            "hbm_whole_gpu": (lambda px, pyr: (lambda b: {"algorithmic_bytes": round(b, 1), "achieved": round(b / my_elapsed / 1e9, 4),
+                                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / my_elapsed / 1e9 / HBM_PEAK_GBS, 8),
+                                                          "scope": "tracker stage of %d sequence(s) on this GPU; timed wall clock" % S})(
+                sum(args.steps * (3.0 * px + (pyr - px / 64.0) + (pyr - px) + 5.0 * pyr + 5.0 * px) + 2420.0 * k.lk_templates + 484.0 * k.lk_iterations
+                    for k in all_klt)))(float(wl["w"] * wl["h"]), float(sum(((wl["w"] + (1 << l) - 1) >> l) * ((wl["h"] + (1 << l) - 1) >> l) for l in range(4)))),
             # what every rank measured on its own clock, and the clock / power state of its device right after the timed region
             "per_rank": [{"rank": int(r[0]), "device": int(r[1]), "frames_per_s": round(r[2], 3), "seconds": round(r[3], 4),
                           "sclk_mhz": r[4] if r[4] >= 0 else None, "mclk_mhz": r[5] if r[5] >= 0 else None,
                           "power_cap_w": r[6] if r[6] >= 0 else None, "power_w": r[7] if r[7] >= 0 else None} for r in rows],
             "device_state": {"before": power0, "after_timed_region": power1},
         })
+        if gstats is not None:
+            # the instance group: requests per batch = sequences one launch served; ms = HIP events around a batch's kernels
+            out["group"] = {k: dict(v, requests_per_batch=round(v["requests"] / max(1, v["batches"]), 2),
+                                    us_per_batch=round(1e3 * v["ms"] / max(1, v["timed"]), 2)) for k, v in gstats.items()}
+        elif S > 1:
+            out["group"] = "off (--no-group): every sequence launches for itself"
         if pre_ms:
             # what the untimed pre-roll hides: the first marginalisation of a sequence goes through the eigen path (km_jacobi,
             # DESIGN.md section 6) -- once per sequence; stated as the longest pre-roll frame against the pre-roll's median frame
@@ -659,6 +686,8 @@ def main():
     group.barrier()
     for s in sessions:
         s.close()
+    if igroup is not None:
+        igroup.close()
     group.close()
 
 

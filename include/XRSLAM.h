@@ -250,6 +250,22 @@ void XRSLAMAmdInstanceGetInitReport(XRSLAMAmdInstance *inst, XRSLAMAmdInitReport
 const char *XRSLAMAmdInstanceLastError(XRSLAMAmdInstance *inst);
 void XRSLAMAmdInstanceSetThreading(XRSLAMAmdInstance *inst, int mode);
 void XRSLAMAmdInstanceFlush(XRSLAMAmdInstance *inst);
+/* ---- instance groups (additive) ----
+ * S independent sequences on one GPU leave it waiting on its own front end: every sequence issues ~26 small dependent launches per
+ * frame.  Instances that have joined a group keep their state, ids and results to themselves but share launches: the library issues
+ * ONE launch per kernel of the per-frame path (frame upload, CLAHE / pyramid, LK, Harris, pre-integration, the localisation and
+ * sub-window solves) for all members that are waiting for it at that moment.  The trajectory of a member is the one it has alone,
+ * bit for bit.  Usage: create the group on the device, create the instances, join each before its first frame, drive every instance
+ * from a thread of its own (XRSLAMAmdInstanceReplay or the per-sample entry points); destroy the instances (or leave: group NULL)
+ * before the group.  Returns 1 on success, 0 otherwise (XRSLAMAmdLastError / XRSLAMAmdInstanceLastError).
+ * XRSLAMAmdGroupGetStats fills an xrhip_group_stats (xrslam_hip.h): batches and requests per kind -- requests / batches is the
+ * number of sequences a launch served. */
+typedef struct XRSLAMAmdGroup XRSLAMAmdGroup;
+int XRSLAMAmdGroupCreate(XRSLAMAmdGroup **out);
+int XRSLAMAmdGroupDestroy(XRSLAMAmdGroup *group);
+int XRSLAMAmdInstanceJoinGroup(XRSLAMAmdInstance *inst, XRSLAMAmdGroup *group);
+void XRSLAMAmdGroupSetProfiling(XRSLAMAmdGroup *group, int enable);
+void XRSLAMAmdGroupGetStats(XRSLAMAmdGroup *group, void *xrhip_group_stats_out, int reset);
 /* The player's loop (xrslam-pc/player/src/main.cpp:116-169) over a pre-staged sequence for the next `n_steps` camera frames:
  * IMU samples up to each frame's time (gyroscope before accelerometer, IO/async_dataset_reader.cpp:41-48), the frame,
  * XRSLAMRunOneFrame, state / body-pose query.  imu7: [n_imu][7] = t, gyroscope xyz, accelerometer xyz; cam_t: [n_frames];

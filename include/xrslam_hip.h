@@ -308,6 +308,41 @@ int xrhip_ba_preintegrate_after_solve(xrhip_ba *ctx, const double *samples, cons
                                       const double *t_end, const int *bias_frame, int n_jobs, const double *noise_cov36,
                                       int compute_jacobian, int compute_covariance);
 
+/* ------------------------------------------------------------------------
+ * Instance group: several sequences on one GPU served by shared launches.
+ *
+ * replaces: nothing the reference has -- its process-global state (XRSLAMManager singleton, xrslam-interface/src/XRSLAMManager.cpp:6-9;
+ * static id counters, xrslam/src/xrslam/utility/identifiable.h:23-30) allows ONE sequence per process, and BASELINE config 4 puts
+ * eleven sequences on eight GPUs.  Contexts that have joined a group hand the launches of the per-frame path (frame upload, CLAHE /
+ * pyramid, LK, Harris, pre-integration, the single-launch solves) to the group's submission thread, which issues ONE launch per
+ * kernel for all requests pending at that moment (blockIdx.z = request); window solves and marginalisations keep the context's
+ * own stream.  Results are those of the context running alone, bit for bit (same kernels, same per-request block mapping and
+ * summation order); every entry point keeps its meaning, including the blocking ones (they wait on the context's own mailbox).
+ * A context may be driven by one thread at a time as before; different contexts of a group from different threads.
+ * Join right after creation, before the context's first use; leave (group = NULL) or destroy the context before the group.
+ * ---------------------------------------------------------------------- */
+typedef struct xrhip_group xrhip_group;
+int xrhip_group_create(xrhip_group **out);
+int xrhip_group_destroy(xrhip_group *group);   /* XRHIP_ESTATE while contexts are still joined */
+int xrhip_klt_join_group(xrhip_klt *ctx, xrhip_group *group);
+int xrhip_ba_join_group(xrhip_ba *ctx, xrhip_group *group);
+/* request kinds of the statistics below */
+#define XRHIP_GK_CALL 0        /* un-batched calls run in queue order (rare paths: parity aids, the five-launch pyramid) */
+#define XRHIP_GK_UPLOAD 1      /* k_upload */
+#define XRHIP_GK_PREPROCESS 2  /* k_clahe_lut + k_pyr_a + k_pyr_b */
+#define XRHIP_GK_TRACK 3       /* k_lk_track (+ the prefetched Harris pass of the target image) */
+#define XRHIP_GK_DETECT 4      /* k_harris + k_harris_nms + k_harris_select */
+#define XRHIP_GK_CHAIN 5       /* kb_stage + kb_chain (+ kp_preintegrate queued behind the solve) */
+#define XRHIP_GK_PREINT 6      /* kp_preintegrate */
+typedef struct xrhip_group_stats {
+    long long batches[8];   /* batches launched, per request kind */
+    long long entries[8];   /* requests they served (entries / batches = sequences per launch) */
+    double ms[8];           /* HIP-event duration of the timed batches, first to last kernel (xrhip_group_set_profiling) */
+    long long timed[8];     /* batches that contributed to ms */
+} xrhip_group_stats;
+int xrhip_group_set_profiling(xrhip_group *group, int enable);
+int xrhip_group_get_stats(xrhip_group *group, xrhip_group_stats *out, int reset);
+
 /* parity/testing aids (not part of the reference interface): the unreduced normal equations of one
  * linearisation, and the MFMA Schur product kernel on arbitrary inputs. */
 int xrhip_ba_debug_linearize(xrhip_ba *ctx, const xrhip_ba_problem *problem, double *H, double *g, double *hll,

@@ -32,7 +32,9 @@ int orc_preintegrate(const double *samples, int n, double t_end, const double *b
                      const double *noise36, int jac, int cv, double *out);
 }
 
+struct xrhip_group;
 struct xrhip_klt {
+    xrhip_group *group = nullptr;
     int w, h;
     std::vector<uint32_t> undist_map;   // packed 1/32-pixel map, empty = frames arrive rectified
 };
@@ -43,6 +45,7 @@ struct xrhip_image {
     bool have_raw, have_pyr;
 };
 struct xrhip_ba {
+    xrhip_group *group = nullptr;
     int unused = 0;
     // results of the asynchronous forms, per context like the product (computed at _begin, handed over at _end)
     std::vector<double> preint_out, marg_si, marg_iv, marg_lin;
@@ -93,10 +96,13 @@ int xrhip_klt_create(int width, int height, int, xrhip_klt **out) {
     // XR_ORACLE_THREADS: threads of the image / point loops (OpenCV's parallel_for_ in the reference); the solver stays
     // single-threaded like the reference's num_threads = 1 (estimation/solver.cpp:185)
     if (const char *e = getenv("XR_ORACLE_THREADS")) orc_set_threads(atoi(e));
-    *out = new xrhip_klt{width, height};
+    *out = new xrhip_klt();
+    (*out)->w = width;
+    (*out)->h = height;
     return 0;
 }
 void xrhip_klt_destroy(xrhip_klt *c) {
+    if (c && c->group) xrhip_klt_join_group(c, nullptr);
     delete c;
     xrhip::hostprof_dump();   // XRHIP_HOSTPROF=1: the host pipeline's named wall-clock accumulators, like the product library
 }
@@ -188,11 +194,47 @@ int xrhip_klt_get_stats(xrhip_klt *, xrhip_klt_stats *out, int) {
     std::memset(out, 0, sizeof(*out));
     return 0;
 }
+// instance groups: nothing to batch on the CPU -- a group is a membership count
+struct xrhip_group {
+    std::atomic<int> members{0};
+};
+int xrhip_group_create(xrhip_group **out) {
+    *out = new xrhip_group();
+    return 0;
+}
+int xrhip_group_destroy(xrhip_group *g) {
+    if (g && g->members.load() != 0) {
+        g_err = "xrhip_group_destroy: contexts are still joined to this group";
+        return XRHIP_ESTATE;
+    }
+    delete g;
+    return 0;
+}
+int xrhip_group_set_profiling(xrhip_group *, int) { return 0; }
+int xrhip_group_get_stats(xrhip_group *, xrhip_group_stats *out, int) {
+    if (out) std::memset(out, 0, sizeof(*out));
+    return 0;
+}
+int xrhip_klt_join_group(xrhip_klt *c, xrhip_group *g) {
+    if (c->group) c->group->members.fetch_sub(1);
+    c->group = g;
+    if (g) g->members.fetch_add(1);
+    return 0;
+}
+int xrhip_ba_join_group(xrhip_ba *c, xrhip_group *g) {
+    if (c->group) c->group->members.fetch_sub(1);
+    c->group = g;
+    if (g) g->members.fetch_add(1);
+    return 0;
+}
 int xrhip_ba_create(int, int, int, xrhip_ba **out) {
     *out = new xrhip_ba();
     return 0;
 }
-void xrhip_ba_destroy(xrhip_ba *c) { delete c; }
+void xrhip_ba_destroy(xrhip_ba *c) {
+    if (c && c->group) xrhip_ba_join_group(c, nullptr);
+    delete c;
+}
 int xrhip_ba_preintegrate_begin(xrhip_ba *c, const double *samples, const int *begin, const int *count, const double *t_end,
                                 const double *bg, const double *ba, int n_jobs, const double *noise36, int jac, int cov);
 int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *s);

@@ -4,7 +4,12 @@ The reference is a process singleton (xrslam-interface/src/XRSLAMManager.cpp:6-9
 CLAHE / GFTT objects, id counters and RD-VIO statistics in statics; here that state lives in the instance.
 The tests drive two instances from two threads, interleaved with each other, and require every sequence to come out
 exactly as it does alone through the reference's six global symbols.  CPU: the host pipeline over the oracle;
-GPU: the product library (kernels of the two instances overlap on the device)."""
+GPU: the product library (kernels of the two instances overlap on the device).
+
+Round 4: instance GROUPS (XRSLAMAmdGroup): the members' per-frame launches are issued together -- one launch per kernel with
+blockIdx.z = member (csrc/group.hip.h).  Which members share a launch depends on timing; what a member computes must not: four and
+eight grouped instances, each driven from its own thread, reproduce their solo trajectories bit for bit, in both threading modes,
+and the group's statistics show that launches were in fact shared."""
 import os
 import threading
 
@@ -68,6 +73,87 @@ def test_two_instances_in_one_process_cpu():
 def test_two_instances_in_one_process_gpu():
     from xrslam_amd import _lib
     _check(*_alone_and_together(_lib.LIB_PATH))
+
+
+def _grouped(lib_path, seeds, mode=0, n=N):
+    """The sequences of `seeds` alone (global instance, one after the other) and as members of one group, a thread each."""
+    seqs = [scene.make_sequence(n_frames=n, seed=sd) for sd in seeds]
+    alone = [_drain(runner.Session(lib_path, q, threading=mode)) for q in seqs]
+    group = runner.Group(lib_path)
+    sessions = [runner.Session(lib_path, q, instance=True, threading=mode, group=group) for q in seqs]
+    res, errs = [None] * len(seqs), []
+
+    def work(i):
+        try:
+            res[i] = _drain(sessions[i])
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(seqs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    stats = group.stats()
+    group.close()           # every member has been destroyed by _drain: the group goes last
+    assert not errs, errs
+    return alone, res, stats
+
+
+def test_grouped_instances_cpu():
+    """The CPU reference build has nothing to batch; the group entry points still have to exist, count their members and leave the
+    trajectories alone."""
+    alone, res, _ = _grouped(ORACLE_LIB, (1, 2, 3))
+    _check(alone, res)
+    lib = runner.load(ORACLE_LIB)
+    import ctypes as C
+    g = C.c_void_p()
+    assert lib.XRSLAMAmdGroupCreate(C.byref(g)) == 1
+    seq = scene.make_sequence(n_frames=3, seed=1)
+    s = runner.Session(ORACLE_LIB, seq, instance=True)
+    assert lib.XRSLAMAmdInstanceJoinGroup(s._handle, g) == 1
+    assert lib.XRSLAMAmdGroupDestroy(g) == 0                     # a member is still joined: refused, the group stays
+    assert "still joined" in lib.XRSLAMAmdLastError().decode()
+    assert lib.XRSLAMAmdInstanceJoinGroup(s._handle, None) == 1   # leave
+    assert lib.XRSLAMAmdGroupDestroy(g) == 1
+    s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("members,mode", [(4, 0), (8, 0), (4, 1)], ids=["4-inline", "8-inline", "4-pipelined"])
+def test_grouped_instances_match_their_solo_runs_gpu(members, mode):
+    """Members of a group share launches (blockIdx.z = member); each reproduces its solo trajectory and counters bit for bit."""
+    from xrslam_amd import _lib
+    alone, res, stats = _grouped(_lib.LIB_PATH, tuple(range(1, members + 1)), mode=mode, n=72)
+    for (pa, ca), (pt, ct) in zip(alone, res):
+        assert ca == ct
+        np.testing.assert_array_equal(pa, pt)
+    # the launches were shared: fewer batches than requests for the kernels every frame of every member needs
+    for kind in ("preprocess", "track", "chain", "preint"):
+        assert stats[kind]["requests"] >= members * 20, (kind, stats)
+        assert stats[kind]["batches"] < stats[kind]["requests"], (kind, stats)
+    import json
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "group_stats_%d_%s.json" % (members, "pipelined" if mode else "inline")), "w") as fh:
+        json.dump(stats, fh, indent=1)
+
+
+@pytest.mark.gpu
+def test_a_group_of_one_and_leaving_a_group_gpu():
+    """A lone member (every batch has one entry) and a member that leaves half way both keep the solo trajectory."""
+    from xrslam_amd import _lib
+    seq = scene.make_sequence(n_frames=64, seed=4)
+    want = _drain(runner.Session(_lib.LIB_PATH, seq))
+    group = runner.Group(_lib.LIB_PATH)
+    s = runner.Session(_lib.LIB_PATH, seq, instance=True, group=group)
+    for _ in range(50):
+        assert s.step()
+    assert s.lib.XRSLAMAmdInstanceJoinGroup(s._handle, None) == 1      # between two frames
+    got = _drain(s)
+    st = group.stats()
+    group.close()
+    assert got[1] == want[1]
+    np.testing.assert_array_equal(got[0], want[0])
+    assert st["track"]["batches"] == st["track"]["requests"] >= 40
 
 
 def test_instance_create_reports_errors():

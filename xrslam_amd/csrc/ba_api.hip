@@ -8,6 +8,7 @@
 #include "ba_chain.hip.h"
 #include "marg_kernels.hip.h"
 #include "common.hip.h"
+#include "group.hip.h"
 
 #include <cstdlib>
 #include <chrono>
@@ -32,10 +33,27 @@ struct Arena {   // bump allocator over one device buffer mirrored by a pinned h
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// What a single-launch solve carries as a request: the staged problem's copy, the solve, and -- when an integration was queued
+// behind the solve (xrhip_ba_preintegrate_after_solve) -- that batch, launched right behind it on the same stream
+struct ChainPayload {
+    StageArgs stage;
+    ChainArgs chain;
+    size_t lds = 0;
+    bool with_preint = false;
+    PreintArgs preint;
+};
+
 }   // namespace
 
 struct xrhip_ba {
     hipStream_t stream = nullptr;
+    // instance group (group.hip.h): the single-launch solves and the pre-integration batches travel as requests
+    xrhip_group *group = nullptr;
+    GroupRequest rq_chain, rq_preint;
+    ChainPayload a_chain;
+    PreintArgs a_preint;
+    GroupRequest *preint_rq = nullptr;   // the request that carries the batch in flight (grouped), and the stream it runs on
+    hipStream_t preint_stream = nullptr;
     Arena in;         // inputs (uploaded every solve)
     char *work = nullptr;   // device-only workspace
     size_t work_cap = 0;
@@ -145,10 +163,72 @@ static int validate(const xrhip_ba_problem *P) {
 
 static int launch_stage_copy(xrhip_ba *c) {
     const int blocks = (int)std::min<size_t>((c->stage_n16 + 255) / 256, 128);
-    hipLaunchKernelGGL(kb_stage, dim3(blocks), dim3(256), 0, c->stream, c->stage_src, c->stage_dst, c->stage_n16);
+    Batch<StageArgs> b;
+    std::memset(&b, 0, sizeof(b));
+    b.e[0] = StageArgs{c->stage_src, c->stage_dst, c->stage_n16};
+    hipLaunchKernelGGL(kb_stage, dim3(blocks, 1, 1), dim3(256), 0, c->stream, b);
     XR_HIP(hipGetLastError());
     return XRHIP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- batched launches (group.hip.h)
+static int launch_preint_batch(GroupRequest **r, int n, hipStream_t s) {
+    for (int base = 0; base < n; base += XB) {
+        const int m = std::min(XB, n - base);
+        Batch<PreintArgs> b;
+        std::memset(&b, 0, sizeof(b));
+        int most = 1;
+        for (int i = 0; i < m; ++i) {
+            b.e[i] = *static_cast<const PreintArgs *>(r[base + i]->payload);
+            most = std::max(most, b.e[i].n_jobs);
+        }
+        hipLaunchKernelGGL(kp_preintegrate, dim3(most, 1, m), dim3(64), 0, s, b);
+    }
+    XR_HIP(hipGetLastError());
+    return XRHIP_OK;
+}
+
+static int launch_chain_batch(GroupRequest **r, int n, hipStream_t s) {
+    for (int base = 0; base < n; base += XB) {
+        const int m = std::min(XB, n - base);
+        Batch<StageArgs> bs;
+        Batch<ChainArgs> bc;
+        Batch<PreintArgs> bp;
+        std::memset(&bs, 0, sizeof(bs));
+        std::memset(&bc, 0, sizeof(bc));
+        std::memset(&bp, 0, sizeof(bp));
+        size_t lds = 0, most16 = 0;
+        int np = 0, most_jobs = 1;
+        for (int i = 0; i < m; ++i) {
+            const ChainPayload &p = *static_cast<const ChainPayload *>(r[base + i]->payload);
+            bs.e[i] = p.stage;
+            bc.e[i] = p.chain;
+            lds = std::max(lds, p.lds);
+            most16 = std::max(most16, p.stage.n16);
+            if (p.with_preint) {
+                most_jobs = std::max(most_jobs, p.preint.n_jobs);
+                bp.e[np++] = p.preint;
+            }
+        }
+        // the device pulls the staged problems from the pinned arenas (16 bytes per lane, <= 128 workgroups per problem) ...
+        hipLaunchKernelGGL(kb_stage, dim3((int)std::min<size_t>((most16 + 255) / 256, 128), 1, m), dim3(256), 0, s, bs);
+        // ... one workgroup solves each of them (dynamic LDS: the largest entry's layout) ...
+        hipLaunchKernelGGL(kb_chain, dim3(1, 1, m), dim3(CHAIN_THREADS), lds, s, bc);
+        // ... and the integrations that start from a solve's biases read them where it left them
+        if (np) hipLaunchKernelGGL(kp_preintegrate, dim3(most_jobs, 1, np), dim3(64), 0, s, bp);
+    }
+    XR_HIP(hipGetLastError());
+    return XRHIP_OK;
+}
+
+namespace {
+struct RegisterBaLaunchers {
+    RegisterBaLaunchers() {
+        group_register(GK_PREINT, launch_preint_batch);
+        group_register(GK_CHAIN, launch_chain_batch);
+    }
+} g_register_ba_launchers;
+}   // namespace
 
 // Packs the problem + gather indices into the input arena, carves the workspace and fills dims/ptrs.
 // defer_copy: do not queue the kb_stage launch; the caller hands the copy (c->stage_src / stage_dst / stage_n16) to a
@@ -581,20 +661,9 @@ static void run_overlap(xrhip_ba *c) {
     c->overlap_fn = nullptr;
     fn(c->overlap_arg);
 }
-static int wait_mailbox(xrhip_ba *c, int seq, hipStream_t publisher = nullptr) {
+static int wait_mailbox(xrhip_ba *c, int seq, hipStream_t publisher = nullptr, GroupRequest *rq = nullptr) {
     run_overlap(c);
-    volatile int *flag = c->h_seq;
-    for (unsigned long spin = 1;; ++spin) {
-        if (*flag == seq) return XRHIP_OK;
-        if ((spin & 0x3FFF) == 0) {
-            const hipError_t q = hipStreamQuery(publisher ? publisher : c->stream);
-            if (q == hipSuccess) {
-                if (*flag == seq) return XRHIP_OK;
-                return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: trial kernel retired without publishing its result");
-            }
-            if (q != hipErrorNotReady) return xr_fail(XRHIP_EHIP, "xrhip_ba_solve: stream error while waiting for the trial kernel");
-        }
-    }
+    return wait_flag(c->h_seq, seq, publisher ? publisher : c->stream, rq, "xrhip_ba_solve");
 }
 
 static long long g_kprof[32];   // accumulated in-kernel phase ticks (all zero unless built with -DXRHIP_KPROF)
@@ -675,8 +744,36 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
     return XRHIP_OK;
 }
 
+int xrhip_ba_join_group(xrhip_ba *c, xrhip_group *g) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_join_group: null context");
+    if (c->group == g) return XRHIP_OK;
+    if (c->preint_pending) {   // a batch between begin and end: it completes where it was queued and stays collectable
+        if (c->preint_rq) {
+            int rc = group_wait_launched(c->preint_rq);
+            if (rc) return rc;
+        }
+        XR_HIP(hipStreamSynchronize(c->preint_stream ? c->preint_stream : c->stream));
+        c->preint_rq = nullptr;
+        c->preint_stream = c->stream;
+    }
+    XR_HIP(hipStreamSynchronize(c->stream));
+    if (c->group) {
+        int rc = group_drain(c->group, GQ_CHAIN, c);
+        if (!rc) rc = group_drain(c->group, GQ_PREINT, c);
+        if (rc) return rc;
+        group_member_remove(c->group);
+    }
+    c->group = g;
+    if (g) group_member_add(g);
+    return XRHIP_OK;
+}
+
 void xrhip_ba_destroy(xrhip_ba *c) {
     if (!c) return;
+    if (c->group) {
+        xrhip_ba_preintegrate_cancel(c);
+        xrhip_ba_join_group(c, nullptr);
+    }
     hipStreamSynchronize(c->stream);
     if (c->stream2) hipStreamSynchronize(c->stream2);
     if (std::getenv("XRHIP_HOSTPROF") && c->spec_launched)
@@ -703,6 +800,7 @@ void xrhip_ba_destroy(xrhip_ba *c) {
 }
 
 static int preint_launch_deferred(xrhip_ba *c, const xrhip_ba_problem *P, const double *state_dev);   // defined with the pre-integration entry points
+static int preint_fill_deferred(xrhip_ba *c, const xrhip_ba_problem *P, const double *state_dev, PreintArgs *out, bool *have);
 
 static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary);
 int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
@@ -760,8 +858,10 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     size_t chain_lds = 0;
     int chain_tile = 0;
     const bool use_chain = chain(d, (size_t)c->lds_limit, &chain_lds, &chain_tile);
-    rc = launch_stage_copy(c);
-    if (rc) return rc;
+    if (!use_chain) {   // (the single-launch solve carries the copy of its staged problem itself)
+        rc = launch_stage_copy(c);
+        if (rc) return rc;
+    }
     HostProfScope hp_rounds(9, "ba_solve: rounds (launch+wait)");
     if (!d.nla) d.lm_rows = 0;
     const double sx = P->sqrt_inv_cov[0], sy = P->sqrt_inv_cov[1];
@@ -771,28 +871,68 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     int mode = 1, iter_seen = 0;
     if (use_chain) {   // the whole solve in one launch, LDS-resident (kb_chain)
         const int seq = ++c->seq;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (c->profiling) {
-            if (!c->free_events.empty()) {
-                e0 = c->free_events.back().first;
-                e1 = c->free_events.back().second;
-                c->free_events.pop_back();
-            } else {
-                XR_HIP(hipEventCreate(&e0));
-                XR_HIP(hipEventCreate(&e1));
-            }
-            XR_HIP(hipEventRecord(e0, s));
+        if (c->group) {
+            rc = group_wait_launched(&c->rq_chain);   // (its argument block is about to be rewritten)
+            if (rc) return rc;
         }
-        hipLaunchKernelGGL(kb_chain, dim3(1), dim3(CHAIN_THREADS), chain_lds, s, c->tiny_args, seq, 4 * (P->max_iterations + 8), chain_tile);
-        XR_HIP(hipGetLastError());
-        if (c->profiling) XR_HIP(hipEventRecord(e1, s));
+        ChainPayload &cp = c->a_chain;
+        cp.stage = StageArgs{c->stage_src, c->stage_dst, c->stage_n16};
+        cp.chain = ChainArgs{c->tiny_args, seq, 4 * (P->max_iterations + 8), chain_tile};
+        cp.lds = chain_lds;
         // a pre-integration that starts from this solve's biases runs right behind it, reading them where the kernel leaves them
-        rc = preint_launch_deferred(c, P, p.state);
+        cp.with_preint = false;
+        rc = preint_fill_deferred(c, P, p.state, &cp.preint, &cp.with_preint);
         if (rc) return rc;
-        rc = wait_mailbox(c, seq);
+        c->rq_chain.kind = GK_CHAIN;
+        c->rq_chain.owner = c;
+        c->rq_chain.payload = &cp;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hipStream_t ps = s;
+        if (c->group) {
+            ps = group_stream(c->group, GQ_CHAIN);
+            rc = group_submit(c->group, GQ_CHAIN, &c->rq_chain);
+            if (rc) return rc;
+        } else {
+            if (c->profiling) {
+                if (!c->free_events.empty()) {
+                    e0 = c->free_events.back().first;
+                    e1 = c->free_events.back().second;
+                    c->free_events.pop_back();
+                } else {
+                    XR_HIP(hipEventCreate(&e0));
+                    XR_HIP(hipEventCreate(&e1));
+                }
+            }
+            // launched here: kb_stage, [event] kb_chain [event], the queued integration -- the events bracket kb_chain alone
+            Batch<StageArgs> bs;
+            Batch<ChainArgs> bc;
+            std::memset(&bs, 0, sizeof(bs));
+            std::memset(&bc, 0, sizeof(bc));
+            bs.e[0] = cp.stage;
+            bc.e[0] = cp.chain;
+            hipLaunchKernelGGL(kb_stage, dim3((int)std::min<size_t>((cp.stage.n16 + 255) / 256, 128), 1, 1), dim3(256), 0, s, bs);
+            if (e0) XR_HIP(hipEventRecord(e0, s));
+            hipLaunchKernelGGL(kb_chain, dim3(1, 1, 1), dim3(CHAIN_THREADS), chain_lds, s, bc);
+            XR_HIP(hipGetLastError());
+            if (e1) XR_HIP(hipEventRecord(e1, s));
+            if (cp.with_preint) {
+                GroupRequest one;
+                one.payload = &cp.preint;
+                GroupRequest *pone = &one;
+                rc = launch_preint_batch(&pone, 1, s);
+                if (rc) return rc;
+            }
+        }
+        if (cp.with_preint) {   // the batch is in flight from here on (xrhip_ba_preintegrate_end collects it)
+            c->preint_pending = c->preint_deferred;
+            c->preint_deferred = 0;
+            c->preint_rq = c->group ? &c->rq_chain : nullptr;
+            c->preint_stream = ps;
+        }
+        rc = wait_mailbox(c, seq, ps, c->group ? &c->rq_chain : nullptr);
         if (rc) return rc;
         if (c->h_ctl->status != ST_DONE) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: trust-region loop did not terminate");
-        if (c->profiling) {   // algorithmic bytes of this launch: rounds = accepted steps + 1 linearisations, `iteration` candidates
+        if (e0) {   // algorithmic bytes of this launch: rounds = accepted steps + 1 linearisations, `iteration` candidates
             const double nf = (double)d.M + d.MR, rounds = c->h_ctl->successful_steps + 1.0, trials = c->h_ctl->iteration;
             const double bytes = rounds * (384.0 * nf + 8.0 * (double)d.na * d.na + 2248.0 * d.NI) + trials * (280.0 * nf + 2248.0 * d.NI);
             c->pending_chain.push_back({e0, e1, bytes});
@@ -1285,21 +1425,61 @@ static int preint_stage(xrhip_ba *c, const double *samples, const int *sample_be
     return XRHIP_OK;
 }
 
-static int preint_launch(xrhip_ba *c, int n_jobs, int jac, int cov, const double *state_dev) {
+static int preint_args(xrhip_ba *c, int n_jobs, int jac, int cov, const double *state_dev, PreintArgs *a) {
     char *Dv = nullptr;
     XR_HIP(hipHostGetDevicePointer((void **)&Dv, c->h_stage, 0));
-    hipLaunchKernelGGL(kp_preintegrate, dim3(n_jobs), dim3(64), 0, c->stream, (const PreintJob *)(Dv + c->preint_o_jobs),
-                       (const double *)(Dv + c->preint_o_smp), (const double *)(Dv + c->preint_o_noise), jac ? 1 : 0, cov ? 1 : 0,
-                       (double *)(Dv + c->preint_o_out), (int *)(Dv + c->preint_o_st), state_dev);
-    XR_HIP(hipGetLastError());
+    *a = PreintArgs{(const PreintJob *)(Dv + c->preint_o_jobs), (const double *)(Dv + c->preint_o_smp), (const double *)(Dv + c->preint_o_noise),
+                    jac ? 1 : 0, cov ? 1 : 0, (double *)(Dv + c->preint_o_out), (int *)(Dv + c->preint_o_st), state_dev, n_jobs};
+    return XRHIP_OK;
+}
+
+static int preint_launch(xrhip_ba *c, int n_jobs, int jac, int cov, const double *state_dev) {
+    if (c->group) {
+        int rc = group_wait_launched(&c->rq_preint);   // (its argument block is about to be rewritten)
+        if (rc) return rc;
+    }
+    int rc = preint_args(c, n_jobs, jac, cov, state_dev, &c->a_preint);
+    if (rc) return rc;
+    c->rq_preint.kind = GK_PREINT;
+    c->rq_preint.owner = c;
+    c->rq_preint.payload = &c->a_preint;
+    if (c->group) {
+        rc = group_submit(c->group, GQ_PREINT, &c->rq_preint);
+        c->preint_rq = &c->rq_preint;
+        c->preint_stream = group_stream(c->group, GQ_PREINT);
+    } else {
+        GroupRequest *one = &c->rq_preint;
+        rc = launch_preint_batch(&one, 1, c->stream);
+        c->preint_rq = nullptr;
+        c->preint_stream = c->stream;
+    }
+    if (rc) return rc;
     c->preint_pending = n_jobs;
     c->preint_deferred = 0;
     return XRHIP_OK;
 }
 
-// The deferred batch of xrhip_ba_preintegrate_after_solve, launched by xrhip_ba_solve.  state_dev: the solve's frame states on
-// the device, final once everything queued on the stream so far has run (the single-launch path), or nullptr: the solve has
-// returned its states to the host already (P->frame_state), the biases go into the jobs by value.
+// The deferred batch of xrhip_ba_preintegrate_after_solve, as the argument set of a launch right behind the solve's kernel
+// (state_dev: the solve's frame states on the device, final once that kernel has run).  *have = false: nothing was staged.
+static int preint_fill_deferred(xrhip_ba *c, const xrhip_ba_problem *P, const double *state_dev, PreintArgs *out, bool *have) {
+    *have = false;
+    if (!c->preint_deferred) return XRHIP_OK;
+    const int n_jobs = c->preint_deferred;
+    const PreintJob *jobs = (const PreintJob *)(c->h_stage + c->preint_o_jobs);
+    for (int k = 0; k < n_jobs; ++k)
+        if (jobs[k].bias_frame < 0 || jobs[k].bias_frame >= P->n_frames) {
+            c->preint_deferred = 0;
+            return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_after_solve: bias frame is not a frame of the solve");
+        }
+    int rc = preint_args(c, n_jobs, c->preint_def_jac, c->preint_def_cov, state_dev, out);
+    if (rc) return rc;
+    *have = true;
+    return XRHIP_OK;
+}
+
+// The deferred batch of xrhip_ba_preintegrate_after_solve, launched by xrhip_ba_solve on the paths that have returned the solve's
+// states to the host already (P->frame_state): the biases go into the jobs by value.  (The single-launch solve launches it itself,
+// behind its kernel: preint_fill_deferred.)
 static int preint_launch_deferred(xrhip_ba *c, const xrhip_ba_problem *P, const double *state_dev) {
     if (!c->preint_deferred) return XRHIP_OK;
     const int n_jobs = c->preint_deferred;
@@ -1349,7 +1529,8 @@ int xrhip_ba_preintegrate_after_solve(xrhip_ba *c, const double *samples, const 
 int xrhip_ba_preintegrate_cancel(xrhip_ba *c) {
     if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_cancel: null context");
     if (c->preint_pending) {   // its kernel writes the staging block: wait before anybody reuses it
-        XR_HIP(hipStreamSynchronize(c->stream));
+        if (c->preint_rq) group_wait_launched(c->preint_rq);
+        XR_HIP(hipStreamSynchronize(c->preint_stream ? c->preint_stream : c->stream));
         c->preint_pending = 0;
     }
     c->preint_deferred = 0;
@@ -1367,10 +1548,14 @@ int xrhip_ba_preintegrate_end(xrhip_ba *c, double *out) {
     c->preint_pending = 0;
     char *H = c->h_stage;
     volatile int *st = (volatile int *)(H + c->preint_o_st);
+    if (c->preint_rq) {   // grouped: the stream below is shared -- idle says nothing before the request has been launched
+        const int rc = group_wait_launched(c->preint_rq);
+        if (rc) return rc;
+    }
     for (int k = 0; k < n_jobs; ++k)
         for (unsigned long spin = 1; st[k] == 0; ++spin)
             if ((spin & 0x3FFF) == 0) {
-                const hipError_t q = hipStreamQuery(c->stream);
+                const hipError_t q = hipStreamQuery(c->preint_stream ? c->preint_stream : c->stream);
                 if (q == hipSuccess && st[k] == 0) return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate: kernel retired without publishing");
                 if (q != hipSuccess && q != hipErrorNotReady) return xr_fail(XRHIP_EHIP, "xrhip_ba_preintegrate: stream error");
             }

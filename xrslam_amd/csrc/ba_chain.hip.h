@@ -133,7 +133,15 @@ __device__ __forceinline__ double obs_eval_cached(const BaDims &d, const double 
     return d.robust ? 0.5 * log(1.0 + s) : 0.5 * s;
 }
 
-__global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(const TinyArgs *__restrict__ args, int seq, int max_rounds, int opts) {
+// One workgroup per solve; a launch carries up to XB solves (blockIdx.z = entry: the solves of several sequences of an instance
+// group, group.hip.h), each with its own staged problem, mailbox and options.  The dynamic LDS of the launch is the largest entry's.
+struct ChainArgs {
+    const TinyArgs *args;
+    int seq, max_rounds, opts;
+};
+__global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch) {
+    const TinyArgs *__restrict__ args = batch.e[blockIdx.z].args;
+    const int seq = batch.e[blockIdx.z].seq, max_rounds = batch.e[blockIdx.z].max_rounds, opts = batch.e[blockIdx.z].opts;
     const BaDims &d = args->d;
     const BaPtrs &p = args->p;
     const Ext &cam = args->cam, &imu = args->imu;

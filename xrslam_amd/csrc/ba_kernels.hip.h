@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "ba_math.hip.h"
+#include "batch.hip.h"
 #include "dense_lds.hip.h"
 
 namespace xrhip {
@@ -2552,8 +2553,14 @@ __global__ __launch_bounds__(256) void kb_tiny(const TinyArgs *__restrict__ args
 // The staged problem (a few tens of KB) is pulled from the pinned host arena by the device itself, 16 bytes per
 // lane: a kernel in the solve's own stream starts within a few microseconds, where a copy-engine transfer adds
 // its scheduling latency in front of the first linearisation.
-__global__ __launch_bounds__(256) void kb_stage(const uint4 *__restrict__ src_host, uint4 *__restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src_host[i];
+struct StageArgs {
+    const uint4 *src_host;
+    uint4 *dst;
+    size_t n16;
+};
+__global__ __launch_bounds__(256) void kb_stage(Batch<StageArgs> b) {   // blockIdx.z = entry (one staged problem each)
+    const StageArgs &a = b.e[blockIdx.z];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n16; i += (size_t)gridDim.x * 256) a.dst[i] = a.src_host[i];
 }
 
 }   // namespace xrhip

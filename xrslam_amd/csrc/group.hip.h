@@ -1,0 +1,67 @@
+// group.hip.h -- instance group: one launch serves several sequences.
+//
+// The reference runs one sequence per process (process-global XRSLAMManager, xrslam-interface/src/XRSLAMManager.cpp:6-9; static id
+// counters, utility/identifiable.h:23-30).  Here a process holds many instances, and on one GPU their per-frame kernels are small
+// and latency-bound: S sequences driven independently retire ~100 k dependent launches per second through the command processor
+// whatever the number of queues (profiles/r03_multi_sequence.md) -- the device idles behind its own front end.  Contexts that
+// join an xrhip_group stop launching for themselves: every launch of the per-frame path becomes a REQUEST (its argument block, built
+// by the owning context exactly as for a launch of its own), and the group's one submission thread turns all pending requests of a
+// kind into ONE launch whose blockIdx.z selects the request (klt_kernels.hip.h: Batch<Args>).
+//
+//   * Three in-order queues with a stream each: GQ_KLT (frame upload, CLAHE / pyramid, LK + Harris), GQ_CHAIN (the single-launch
+//     solves: kb_stage + kb_chain [+ the integration queued behind the solve]), GQ_PREINT (pre-integration batches of every BA
+//     context).  Requests of one context reach the device in the order it submitted them; dependencies BETWEEN queues are
+//     host-mediated in the pipeline already (a solve is only assembled once the integrations it reads have been collected).
+//   * One batch in flight per queue: while it runs, requests accumulate; when it retires, everything pending of the head's kind
+//     goes out together.  An idle device launches a lone request at once, a busy one forms bigger batches -- nobody waits for a
+//     straggler, and a sequence on a keyframe frame (1.5 ms of window solve on its own stream) does not hold the others back.
+//   * Per-entry arithmetic is untouched (same kernels, same block-to-work mapping, same summation order): results do not depend
+//     on the batch a request happened to travel in -- tests/test_instances.py holds grouped runs to the solo runs bit for bit.
+//   * Completion stays per context: every kernel publishes into its owner's pinned mailbox as before; the owner's thread spins on it.
+// Window solves and marginalisations (one frame in five) keep their own streams.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <functional>
+
+#include "../../include/xrslam_hip.h"
+
+namespace xrhip {
+
+enum GroupQueue { GQ_KLT = 0, GQ_CHAIN, GQ_PREINT, GQ_COUNT };
+enum GroupKind { GK_CALL = 0, GK_UPLOAD, GK_PREPROCESS, GK_TRACK, GK_DETECT, GK_CHAIN, GK_PREINT, GK_COUNT };
+
+struct GroupRequest {
+    int kind = GK_CALL;
+    void *owner = nullptr;     // the submitting context: its requests are launched in submission order
+    void *payload = nullptr;   // kind-specific argument block; owned by the submitter, read when the batch is launched
+    std::function<int(hipStream_t)> call;   // GK_CALL: anything that is not batched, run alone by the submission thread in queue order
+    std::atomic<int> state{0};   // 0 idle, 1 queued, 2 launched (its kernels are on the queue's stream)
+    int rc = 0;                  // what the launch returned
+    char err[256] = {0};
+};
+
+// Turns `n` pending requests of one kind into launches on `s` (chunks of XB entries); registered once per kind by the translation
+// unit that owns the kernels.  Returns an XRHIP_* code (the text is taken from the calling thread's xr_err_buf).
+typedef int (*GroupLaunchFn)(GroupRequest **reqs, int n, hipStream_t s);
+void group_register(int kind, GroupLaunchFn fn);
+
+// the owner's thread: hand a request over / wait until its kernels are on the stream (returns its rc, error text copied)
+int group_submit(xrhip_group *g, int queue, GroupRequest *r);
+int group_wait_launched(GroupRequest *r);
+// a request that is run alone, in order: fn(stream) on the submission thread; returns when it has been issued
+int group_call(xrhip_group *g, int queue, void *owner, std::function<int(hipStream_t)> fn);
+// ... and when everything submitted to `queue` before it has completed on the device
+int group_drain(xrhip_group *g, int queue, void *owner);
+hipStream_t group_stream(xrhip_group *g, int queue);
+void group_member_add(xrhip_group *g);
+void group_member_remove(xrhip_group *g);
+void group_count_entries(xrhip_group *g, int kind, int n);
+
+// Spin until *flag == seq (a kernel's last store into pinned memory).  The stream is polled now and then so that a faulted kernel
+// becomes an error instead of a hang -- once the request (if any) is known to be launched: a shared stream may be idle while the
+// request still waits in the group's queue.
+int wait_flag(volatile int *flag, int seq, hipStream_t s, GroupRequest *req, const char *what);
+
+}   // namespace xrhip

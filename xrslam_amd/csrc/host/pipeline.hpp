@@ -237,7 +237,20 @@ struct Pipeline {
         if (klt) xrhip_klt_destroy(klt);
     }
     void ensure_ft_context() {
-        if (!ba_ft) hip_check(xrhip_ba_create(32, 2048, 16384, &ba_ft), "xrhip_ba_create");
+        if (ba_ft) return;
+        hip_check(xrhip_ba_create(32, 2048, 16384, &ba_ft), "xrhip_ba_create");
+        if (group) hip_check(xrhip_ba_join_group(ba_ft, group), "xrhip_ba_join_group");
+    }
+    // Instance group (include/xrslam_hip.h): the per-frame launches of this sequence -- frame upload, CLAHE / pyramid, LK, Harris,
+    // pre-integrations, the single-launch solves -- are issued by the group together with the other members' (one launch per kernel
+    // for all of them); window solves stay on `ba`'s own stream, the marginalisation keeps its own context.  Between frames only.
+    xrhip_group *group = nullptr;
+    void join_group(xrhip_group *g) {
+        marg_launch_wait();
+        hip_check(xrhip_klt_join_group(klt, g), "xrhip_klt_join_group");
+        for (xrhip_ba *c : {ba, ba_aux, ba_ft})
+            if (c) hip_check(xrhip_ba_join_group(c, g), "xrhip_ba_join_group");
+        group = g;
     }
     xrhip_image *acquire_image() {
         {

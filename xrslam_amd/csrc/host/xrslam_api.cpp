@@ -351,6 +351,11 @@ void impl_get_init_report(Manager &m, XRSLAMAmdInitReport *out) {
 struct XRSLAMAmdInstance {
     Manager m;
 };
+// ... and for a group of instances on one GPU whose per-frame launches are issued together (xrslam_hip.h: xrhip_group)
+struct XRSLAMAmdGroup {
+    xrhip_group *g = nullptr;
+    int device = -1;
+};
 
 extern "C" {
 
@@ -451,6 +456,49 @@ void XRSLAMAmdInstanceSetThreading(XRSLAMAmdInstance *inst, int mode) {
 }
 void XRSLAMAmdInstanceFlush(XRSLAMAmdInstance *inst) {
     if (inst) impl_flush(inst->m);
+}
+
+// ---- instance groups
+int XRSLAMAmdGroupCreate(XRSLAMAmdGroup **out) {
+    if (!out) return 0;
+    *out = nullptr;
+    XRSLAMAmdGroup *grp = new (std::nothrow) XRSLAMAmdGroup();
+    if (!grp) return 0;
+    if (xrhip_get_device(&grp->device) != 0) grp->device = -1;
+    if (xrhip_group_create(&grp->g) != 0) {
+        mgr().last_error = xrhip_last_error();
+        delete grp;
+        return 0;
+    }
+    *out = grp;
+    return 1;
+}
+int XRSLAMAmdGroupDestroy(XRSLAMAmdGroup *grp) {
+    if (!grp) return 1;
+    if (grp->device >= 0) xrhip_bind_device(grp->device);
+    if (xrhip_group_destroy(grp->g) != 0) {   // instances are still joined: the group stays
+        mgr().last_error = xrhip_last_error();
+        return 0;
+    }
+    delete grp;
+    return 1;
+}
+int XRSLAMAmdInstanceJoinGroup(XRSLAMAmdInstance *inst, XRSLAMAmdGroup *grp) {
+    if (!inst || !inst->m.sys) return 0;
+    int ok = 0;
+    bind_device(inst->m);
+    guarded(inst->m, [&] {
+        inst->m.sys->sync();
+        inst->m.sys->P.join_group(grp ? grp->g : nullptr);
+        ok = 1;
+    });
+    return ok;
+}
+void XRSLAMAmdGroupSetProfiling(XRSLAMAmdGroup *grp, int enable) {
+    if (grp) xrhip_group_set_profiling(grp->g, enable);
+}
+void XRSLAMAmdGroupGetStats(XRSLAMAmdGroup *grp, void *out, int reset) {
+    if (grp && out) xrhip_group_get_stats(grp->g, static_cast<xrhip_group_stats *>(out), reset);
 }
 
 // The player's loop (xrslam-pc/player/src/main.cpp:116-169) for n_steps camera frames of a pre-staged sequence, without a

@@ -3,6 +3,7 @@
 // context's stream, and the order-defining selections (host_select.hpp).
 #include "../../include/xrslam_hip.h"
 #include "common.hip.h"
+#include "group.hip.h"
 #include "host_select.hpp"
 #include "klt_kernels.hip.h"
 
@@ -30,12 +31,37 @@ struct LevelBuf {
     short2 *der = nullptr;    // pixel (0,0)
 };
 
+// What a request of each kind carries: the argument sets of its kernels, built by the owning context exactly as for a launch of its own
+struct PrePayload {
+    ClaheLutArgs lut;
+    PyrAArgs pa;
+    PyrBArgs pb;
+};
+struct DetectPayload {
+    HarrisArgs hr;
+    HarrisNmsArgs nms;
+    HarrisSelectArgs sel;
+};
+struct TrackPayload {
+    LkTrackArgs lk;
+    bool detect = false;   // the Harris pass of the target image rides behind the tracking launch (xrhip_image_prefetch_detect)
+    DetectPayload det;
+};
+
 }   // namespace
 
 struct xrhip_klt {
     int device = 0;
     int w = 0, h = 0, max_points = 0;
     hipStream_t stream = nullptr;
+    // instance group (group.hip.h): when set, the per-frame launches travel as requests -- one outstanding request of a kind per context
+    xrhip_group *group = nullptr;
+    GroupRequest rq_upload, rq_pre, rq_track, rq_detect;
+    UploadArgs a_upload;
+    PrePayload a_pre;
+    TrackPayload a_track;
+    DetectPayload a_detect;
+    int uploads_unsynced = 0;   // grouped: uploads since the last point the KLT queue is known to have drained (pinned ring safety)
     // scratch shared by the images of this sequence
     uint8_t *lut = nullptr;          // tiles*256
     int lut_tiles = 0;
@@ -155,7 +181,7 @@ struct ProfScope {
     int cat;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ProfScope(xrhip_klt *c_, int cat_) : c(c_), cat(cat_) {
-        if (!c->profiling) return;
+        if (!c->profiling || c->group) return;   // grouped: the launch is the group's (xrhip_group_get_stats times the batches)
         if (c->pending.size() >= 8192) resolve_pending(c);
         if (!c->free_events.empty()) {
             e0 = c->free_events.back().first;
@@ -168,7 +194,7 @@ struct ProfScope {
         hipEventRecord(e0, c->stream);
     }
     void finish() {
-        if (c->profiling && e0) {
+        if (c->profiling && e0 && !c->group) {
             hipEventRecord(e1, c->stream);
             c->pending.push_back({e0, e1, cat});
         }
@@ -178,7 +204,179 @@ struct ProfScope {
     }
 };
 
+// ---------------------------------------------------------------------------------------------- batched launches
+// One function per request kind turns n requests into launches on `s`, XB entries per launch (blockIdx.z = entry).  A context
+// that launches for itself calls the same function with its one request and its own stream.
+template <class Args, class Fill> static void for_chunks(int n, Fill fill) {
+    for (int base = 0; base < n; base += XB) {
+        const int m = std::min(XB, n - base);
+        Batch<Args> b;
+        std::memset(&b, 0, sizeof(b));
+        fill(b, base, m);
+    }
+}
+
+static int launch_upload_batch(GroupRequest **r, int n, hipStream_t s) {
+    for_chunks<UploadArgs>(n, [&](Batch<UploadArgs> &b, int base, int m) {
+        size_t most = 0;
+        for (int i = 0; i < m; ++i) {
+            b.e[i] = *static_cast<const UploadArgs *>(r[base + i]->payload);
+            most = std::max(most, (size_t)b.e[i].w * b.e[i].h);
+        }
+        const int blocks = (int)std::min<size_t>((most / 16 + 255) / 256, 64);   // 64 workgroups per frame saturate the host link
+        hipLaunchKernelGGL(k_upload, dim3(std::max(blocks, 1), 1, m), dim3(256), 0, s, b);
+    });
+    XR_HIP(hipGetLastError());
+    return XRHIP_OK;
+}
+
+static int launch_preprocess_batch(GroupRequest **r, int n, hipStream_t s) {
+    for (int base = 0; base < n; base += XB) {
+        const int m = std::min(XB, n - base);
+        Batch<ClaheLutArgs> bl;
+        Batch<PyrAArgs> ba;
+        Batch<PyrBArgs> bb;
+        std::memset(&bl, 0, sizeof(bl));
+        std::memset(&ba, 0, sizeof(ba));
+        std::memset(&bb, 0, sizeof(bb));
+        int gl = 1, ga = 1, gb = 1;
+        for (int i = 0; i < m; ++i) {
+            const PrePayload &p = *static_cast<const PrePayload *>(r[base + i]->payload);
+            bl.e[i] = p.lut;
+            ba.e[i] = p.pa;
+            bb.e[i] = p.pb;
+            gl = std::max(gl, p.lut.tiles);
+            ga = std::max(ga, p.pa.blocks);
+            gb = std::max(gb, p.pb.blocks);
+        }
+        hipLaunchKernelGGL(k_clahe_lut, dim3(gl, 1, m), dim3(CL_THREADS), 0, s, bl);
+        hipLaunchKernelGGL(k_pyr_a, dim3(ga, 1, m), dim3(PF_THREADS), 0, s, ba);
+        hipLaunchKernelGGL(k_pyr_b, dim3(gb, 1, m), dim3(PF_THREADS), 0, s, bb);
+    }
+    XR_HIP(hipGetLastError());
+    return XRHIP_OK;
+}
+
+static void launch_detect_chunk(const DetectPayload *const *d, int m, hipStream_t s) {
+    Batch<HarrisArgs> bh;
+    Batch<HarrisNmsArgs> bn;
+    Batch<HarrisSelectArgs> bs;
+    std::memset(&bh, 0, sizeof(bh));
+    std::memset(&bn, 0, sizeof(bn));
+    std::memset(&bs, 0, sizeof(bs));
+    int gx = 1, gy = 1;
+    for (int i = 0; i < m; ++i) {
+        bh.e[i] = d[i]->hr;
+        bn.e[i] = d[i]->nms;
+        bs.e[i] = d[i]->sel;
+        gx = std::max(gx, d[i]->hr.gx);
+        gy = std::max(gy, d[i]->hr.gy);
+    }
+    hipLaunchKernelGGL(k_harris, dim3(gx, gy, m), dim3(256), 0, s, bh);
+    hipLaunchKernelGGL(k_harris_nms, dim3(gx, gy, m), dim3(256), 0, s, bn);
+    hipLaunchKernelGGL(k_harris_select, dim3(1, 1, m), dim3(1024), 0, s, bs);
+}
+
+static int launch_detect_batch(GroupRequest **r, int n, hipStream_t s) {
+    for (int base = 0; base < n; base += XB) {
+        const int m = std::min(XB, n - base);
+        const DetectPayload *d[XB];
+        for (int i = 0; i < m; ++i) d[i] = static_cast<const DetectPayload *>(r[base + i]->payload);
+        launch_detect_chunk(d, m, s);
+    }
+    XR_HIP(hipGetLastError());
+    return XRHIP_OK;
+}
+
+static int launch_track_batch(GroupRequest **r, int n, hipStream_t s) {
+    for (int base = 0; base < n; base += XB) {
+        const int m = std::min(XB, n - base);
+        Batch<LkTrackArgs> b;
+        std::memset(&b, 0, sizeof(b));
+        int most = 1;
+        for (int i = 0; i < m; ++i) {
+            b.e[i] = static_cast<const TrackPayload *>(r[base + i]->payload)->lk;
+            most = std::max(most, b.e[i].n);
+        }
+        hipLaunchKernelGGL(k_lk_track, dim3(most, 1, m), dim3(LK_THREADS), 0, s, b);
+    }
+    XR_HIP(hipGetLastError());
+    // the Harris passes of the target images do not depend on the tracking result: right behind it
+    const DetectPayload *d[XB];
+    int nd = 0;
+    for (int i = 0; i < n; ++i) {
+        const TrackPayload *t = static_cast<const TrackPayload *>(r[i]->payload);
+        if (!t->detect) continue;
+        d[nd++] = &t->det;
+        if (nd == XB) {
+            launch_detect_chunk(d, nd, s);
+            nd = 0;
+        }
+    }
+    if (nd) launch_detect_chunk(d, nd, s);
+    XR_HIP(hipGetLastError());
+    return XRHIP_OK;
+}
+
+namespace {
+struct RegisterKltLaunchers {
+    RegisterKltLaunchers() {
+        group_register(GK_UPLOAD, launch_upload_batch);
+        group_register(GK_PREPROCESS, launch_preprocess_batch);
+        group_register(GK_TRACK, launch_track_batch);
+        group_register(GK_DETECT, launch_detect_batch);
+    }
+} g_register_klt_launchers;
+}   // namespace
+
+// a request of `kind` with `payload`: to the group's queue, or launched here and now on the context's own stream
+static int klt_issue(xrhip_klt *c, GroupRequest &rq, int kind, void *payload, GroupLaunchFn fn) {
+    rq.kind = kind;
+    rq.owner = c;
+    rq.payload = payload;
+    if (c->group) return group_submit(c->group, GQ_KLT, &rq);
+    GroupRequest *one = &rq;
+    return fn(&one, 1, c->stream);
+}
+static hipStream_t klt_stream(const xrhip_klt *c) { return c->group ? group_stream(c->group, GQ_KLT) : c->stream; }
+// fn(stream) in the context's launch order (rare, un-batched paths), then wait for everything issued so far
+static int klt_run_sync(xrhip_klt *c, std::function<int(hipStream_t)> fn) {
+    if (!c->group) {
+        int rc = fn(c->stream);
+        if (rc) return rc;
+        XR_HIP(hipStreamSynchronize(c->stream));
+        return XRHIP_OK;
+    }
+    int rc = group_call(c->group, GQ_KLT, c, std::move(fn));
+    if (rc) return rc;
+    XR_HIP(hipStreamSynchronize(group_stream(c->group, GQ_KLT)));
+    c->uploads_unsynced = 0;
+    return XRHIP_OK;
+}
+static int klt_run(xrhip_klt *c, std::function<int(hipStream_t)> fn) {   // same without the wait
+    if (!c->group) return fn(c->stream);
+    return group_call(c->group, GQ_KLT, c, std::move(fn));
+}
+
 extern "C" {
+
+int xrhip_klt_join_group(xrhip_klt *c, xrhip_group *g) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_klt_join_group: null context");
+    if (c->group == g) return XRHIP_OK;
+    // whatever the context has queued so far completes where it was queued
+    if (c->group) {
+        int rc = group_drain(c->group, GQ_KLT, c);
+        if (rc) return rc;
+        group_member_remove(c->group);
+    } else {
+        XR_HIP(hipStreamSynchronize(c->stream));
+    }
+    c->group = g;
+    c->uploads_unsynced = 0;
+    for (int i = 0; i < xrhip_klt::UP_SLOTS; ++i) c->up_busy[i] = false;
+    if (g) group_member_add(g);
+    return XRHIP_OK;
+}
 
 int xrhip_klt_create(int width, int height, int max_points, xrhip_klt **out) {
     if (!out || width < 64 || height < 64 || max_points < 0) return xr_fail(XRHIP_EINVAL, "xrhip_klt_create: bad arguments");
@@ -195,6 +393,10 @@ int xrhip_klt_create(int width, int height, int max_points, xrhip_klt **out) {
     XR_HIP(hipMalloc(&c->resp, sizeof(float) * (size_t)width * height));
     XR_HIP(hipMalloc(&c->max_key, sizeof(int) * 2));
     c->cand_count = c->max_key + 1;
+    {   // running maximum (as an order-preserving int key) and candidate counter: k_harris_select leaves them reset for the next pass
+        const int init[2] = {(int)0x80000000, 0};
+        XR_HIP(hipMemcpy(c->max_key, init, sizeof(init), hipMemcpyHostToDevice));
+    }
     c->cand_cap = width * height / 2;
     XR_HIP(hipMalloc(&c->cand, sizeof(HarrisCand) * (size_t)c->cand_cap));
     XR_HIP(hipHostMalloc(&c->h_cand, sizeof(HarrisCand) * (size_t)c->cand_cap, hipHostMallocDefault));
@@ -222,6 +424,7 @@ int xrhip_klt_create(int width, int height, int max_points, xrhip_klt **out) {
 void xrhip_klt_destroy(xrhip_klt *c) {
     if (!c) return;
     hostprof_dump();
+    if (c->group) xrhip_klt_join_group(c, nullptr);
     hipStreamSynchronize(c->stream);
     hipFree(c->lut);
     hipFree(c->undist_map);
@@ -281,12 +484,14 @@ int xrhip_image_create(xrhip_klt *c, xrhip_image **out) {
         w = (w + 1) / 2;
         h = (h + 1) / 2;
     }
+    XR_HIP(hipStreamSynchronize(c->stream));   // (the planes are cleared before any queue -- the context's or a group's -- can reach them)
     *out = im;
     return XRHIP_OK;
 }
 
 void xrhip_image_destroy(xrhip_image *im) {
     if (!im) return;
+    if (im->ctx->group) group_drain(im->ctx->group, GQ_KLT, im->ctx);
     hipStreamSynchronize(im->ctx->stream);
     hipFree(im->raw);
     for (int l = 0; l < KLT_LEVELS; ++l) {
@@ -334,6 +539,26 @@ static void copy_to_pinned(uint8_t *dst, const uint8_t *src, size_t n) {
 static int stage_host_frame(xrhip_klt *c, const uint8_t *gray, int stride, uint8_t *dst) {
     const int slot = c->up_next;
     c->up_next = (slot + 1) % xrhip_klt::UP_SLOTS;
+    if (c->group) {
+        // the slot was read by the upload launched three frames ago; the pipeline has waited for two tracking results since (same
+        // queue, in order).  A caller that uploads without ever waiting is held here instead.
+        if (c->uploads_unsynced >= xrhip_klt::UP_SLOTS - 1) {
+            int rc = group_drain(c->group, GQ_KLT, c);
+            if (rc) return rc;
+            c->uploads_unsynced = 0;
+        }
+        int rc = group_wait_launched(&c->rq_upload);   // (its argument block is about to be rewritten)
+        if (rc) return rc;
+        uint8_t *buf = c->up_buf[slot];
+        if (stride == c->w) copy_to_pinned(buf, gray, (size_t)c->w * c->h);
+        else
+            for (int y = 0; y < c->h; ++y) std::memcpy(buf + (size_t)y * c->w, gray + (size_t)y * stride, (size_t)c->w);
+        uint8_t *dbuf = nullptr;
+        XR_HIP(hipHostGetDevicePointer((void **)&dbuf, buf, 0));
+        c->a_upload = UploadArgs{dbuf, c->w, dst, c->w, c->h};
+        c->uploads_unsynced++;
+        return klt_issue(c, c->rq_upload, GK_UPLOAD, &c->a_upload, launch_upload_batch);
+    }
     if (c->up_busy[slot]) XR_HIP(hipEventSynchronize(c->up_done[slot]));   // three uploads ago: long done unless nothing consumed them
     uint8_t *buf = c->up_buf[slot];
     if (stride == c->w) {
@@ -371,8 +596,11 @@ int xrhip_klt_set_undistort_map(xrhip_klt *c, const uint32_t *map2) {
         XR_HIP(hipMalloc(&c->undist_map, bytes));
         XR_HIP(hipMalloc(&c->undist_src, (size_t)c->w * c->h));
     }
-    XR_HIP(hipMemcpyAsync(c->undist_map, map2, bytes, hipMemcpyHostToDevice, c->stream));
-    XR_HIP(hipStreamSynchronize(c->stream));
+    int rc = klt_run_sync(c, [&](hipStream_t st) {
+        XR_HIP(hipMemcpyAsync(c->undist_map, map2, bytes, hipMemcpyHostToDevice, st));
+        return XRHIP_OK;
+    });
+    if (rc) return rc;
     c->have_undist = true;
     return XRHIP_OK;
 }
@@ -389,9 +617,15 @@ int xrhip_image_upload_distorted(xrhip_image *im, const void *gray, int stride, 
         src = c->undist_src;
         sstride = c->w;
     }
-    hipLaunchKernelGGL(k_undistort, dim3((c->w + 63) / 64, (c->h + 3) / 4), dim3(256), 0, c->stream, src, sstride,
-                       (const uint2 *)c->undist_map, im->raw, c->w, c->w, c->h);
-    XR_HIP(hipGetLastError());
+    {   // (not batched: a remap per frame on a path the bench's resident / rectified inputs do not take)
+        int rc = klt_run(c, [=](hipStream_t st) {
+            hipLaunchKernelGGL(k_undistort, dim3((c->w + 63) / 64, (c->h + 3) / 4), dim3(256), 0, st, src, sstride,
+                               (const uint2 *)c->undist_map, im->raw, c->w, c->w, c->h);
+            XR_HIP(hipGetLastError());
+            return XRHIP_OK;
+        });
+        if (rc) return rc;
+    }
     // (a host buffer may be reused by the caller as soon as we return: stage_host_frame has copied it)
     im->have_raw = true;
     im->have_pyramid = false;
@@ -415,10 +649,11 @@ int xrhip_debug_get_level_padded(const xrhip_image *im, int level, uint8_t *out,
     *cols = L.w + 2 * KLT_PAD;
     if (!out) return XRHIP_OK;
     xrhip_klt *c = im->ctx;
-    XR_HIP(hipMemcpy2DAsync(out, (size_t)*cols, L.img - (ptrdiff_t)KLT_PAD * L.istride - KLT_PAD, L.istride, (size_t)*cols, (size_t)*rows,
-                            hipMemcpyDeviceToHost, c->stream));
-    XR_HIP(hipStreamSynchronize(c->stream));
-    return XRHIP_OK;
+    return klt_run_sync(c, [&](hipStream_t st) {
+        XR_HIP(hipMemcpy2DAsync(out, (size_t)*cols, L.img - (ptrdiff_t)KLT_PAD * L.istride - KLT_PAD, L.istride, (size_t)*cols, (size_t)*rows,
+                                hipMemcpyDeviceToHost, st));
+        return XRHIP_OK;
+    });
 }
 
 /* parity aid: the 8-bit frame preprocess() will read (after an upload / the device undistortion) */
@@ -426,15 +661,24 @@ int xrhip_debug_get_raw(xrhip_image *im, uint8_t *out) {
     if (!im || !out) return xr_fail(XRHIP_EINVAL, "xrhip_debug_get_raw: null argument");
     if (!im->have_raw) return xr_fail(XRHIP_ESTATE, "xrhip_debug_get_raw: no image uploaded");
     xrhip_klt *c = im->ctx;
-    XR_HIP(hipMemcpyAsync(out, im->raw, (size_t)c->w * c->h, hipMemcpyDeviceToHost, c->stream));
-    XR_HIP(hipStreamSynchronize(c->stream));
-    return XRHIP_OK;
+    return klt_run_sync(c, [&](hipStream_t st) {
+        XR_HIP(hipMemcpyAsync(out, im->raw, (size_t)c->w * c->h, hipMemcpyDeviceToHost, st));
+        return XRHIP_OK;
+    });
 }
 
 int xrhip_image_upload_device(xrhip_image *im, const void *gray_dev, int stride) {
     if (!im || !gray_dev || stride < im->ctx->w) return xr_fail(XRHIP_EINVAL, "xrhip_image_upload_device: bad arguments");
     xrhip_klt *c = im->ctx;
-    XR_HIP(hipMemcpy2DAsync(im->raw, c->w, gray_dev, stride, c->w, c->h, hipMemcpyDeviceToDevice, c->stream));
+    if (c->group) {
+        int rc = group_wait_launched(&c->rq_upload);
+        if (rc) return rc;
+        c->a_upload = UploadArgs{static_cast<const uint8_t *>(gray_dev), stride, im->raw, c->w, c->h};
+        rc = klt_issue(c, c->rq_upload, GK_UPLOAD, &c->a_upload, launch_upload_batch);
+        if (rc) return rc;
+    } else {
+        XR_HIP(hipMemcpy2DAsync(im->raw, c->w, gray_dev, stride, c->w, c->h, hipMemcpyDeviceToDevice, c->stream));
+    }
     im->have_raw = true;
     im->have_pyramid = false;
     im->want_detect = false;
@@ -465,14 +709,19 @@ int xrhip_image_preprocess(xrhip_image *im, double clip_limit, int tiles_x, int 
         if (clip < 1) clip = 1;
     }
     ProfScope prof(c, CAT_PRE);
-    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles), dim3(CL_THREADS), 0, c->stream, im->raw, w, w, h, tw, th, tiles_x, clip,
-                       lut_scale, c->lut);
-    // the pyramid and its derivatives: two launches (k_pyr_a, k_pyr_b) when every level is large enough for its border to be one
-    // reflection away, else (or with the development switch) the five launches they replace
+    // the pyramid and its derivatives: two launches (k_pyr_a, k_pyr_b) behind the LUT kernel when every level is large enough for its
+    // border to be one reflection away, else (or with the development switch) the five launches they replace
     bool fused = c->fused_pyramid;
     for (int l = 0; l < KLT_LEVELS; ++l) fused = fused && im->lv[l].w >= 2 * KLT_PAD + 2 && im->lv[l].h >= 2 * KLT_PAD + 2;
+    ClaheLutArgs la{im->raw, w, w, h, tw, th, tiles_x, clip, lut_scale, c->lut, tiles};
     if (fused) {
-        PyrAArgs pa;
+        if (c->group) {
+            int rc = group_wait_launched(&c->rq_pre);   // (its argument block is about to be rewritten)
+            if (rc) return rc;
+        }
+        PrePayload &pp = c->a_pre;
+        pp.lut = la;
+        PyrAArgs &pa = pp.pa;
         pa.raw = im->raw;
         pa.rstride = w;
         pa.tw = tw;
@@ -486,8 +735,8 @@ int xrhip_image_preprocess(xrhip_image *im, double clip_limit, int tiles_x, int 
         pa.w0 = im->lv[0].w; pa.h0 = im->lv[0].h; pa.s0 = im->lv[0].istride;
         pa.w1 = im->lv[1].w; pa.h1 = im->lv[1].h; pa.s1 = im->lv[1].istride;
         pa.tiles_across = (w + PA_T - 1) / PA_T;
-        hipLaunchKernelGGL(k_pyr_a, dim3(pa.tiles_across * ((h + PA_T - 1) / PA_T)), dim3(PF_THREADS), 0, c->stream, pa);
-        PyrBArgs pb;
+        pa.blocks = pa.tiles_across * ((h + PA_T - 1) / PA_T);
+        PyrBArgs &pb = pp.pb;
         for (int l = 0; l < KLT_LEVELS; ++l) {
             pb.img[l] = im->lv[l].img;
             pb.der[l] = im->lv[l].der;
@@ -496,38 +745,46 @@ int xrhip_image_preprocess(xrhip_image *im, double clip_limit, int tiles_x, int 
             pb.istride[l] = im->lv[l].istride;
         }
         pb.tiles_across = (pb.w[1] + PB_T - 1) / PB_T;
-        hipLaunchKernelGGL(k_pyr_b, dim3(pb.tiles_across * ((pb.h[1] + PB_T - 1) / PB_T)), dim3(PF_THREADS), 0, c->stream, pb);
-        XR_HIP(hipGetLastError());
+        pb.blocks = pb.tiles_across * ((pb.h[1] + PB_T - 1) / PB_T);
+        int rc = klt_issue(c, c->rq_pre, GK_PREPROCESS, &pp, launch_preprocess_batch);
+        if (rc) return rc;
         prof.finish();
         im->have_pyramid = true;
         return XRHIP_OK;
     }
-    {
-        LevelBuf &L = im->lv[0];
-        dim3 blk(64, 4);
-        dim3 grd((w + 2 * KLT_PAD + 63) / 64, (h + 2 * KLT_PAD + 3) / 4);
-        hipLaunchKernelGGL(k_clahe_apply, grd, blk, 0, c->stream, im->raw, w, w, h, tw, th, tiles_x, tiles_y, c->lut,
-                           L.img, L.istride);
-    }
-    PyrView pv = make_view(im);
-    for (int l = 1; l < KLT_LEVELS; ++l) {
-        LevelBuf &D = im->lv[l];
-        dim3 blk(64, 4);
-        dim3 grd((D.w + 2 * KLT_PAD + 63) / 64, (D.h + 2 * KLT_PAD + 3) / 4);
-        hipLaunchKernelGGL(k_pyrdown, grd, blk, 0, c->stream, pv.lv[l - 1], D.img, D.w, D.h, D.istride);
-    }
-    ScharrArgs sa;
-    int off = 0;
-    for (int l = 0; l < KLT_LEVELS; ++l) {
-        sa.lv[l] = pv.lv[l];
-        sa.out[l] = im->lv[l].der;
-        sa.blk_off[l] = off;
-        sa.blk_w[l] = (im->lv[l].w + 63) / 64;
-        off += sa.blk_w[l] * ((im->lv[l].h + 3) / 4);
-    }
-    sa.blk_off[KLT_LEVELS] = off;
-    hipLaunchKernelGGL(k_scharr, dim3(off), dim3(256), 0, c->stream, sa);
-    XR_HIP(hipGetLastError());
+    int rc = klt_run(c, [=](hipStream_t st) {   // the five-launch form (tiny images, A/B reference), un-batched
+        Batch<ClaheLutArgs> bl;
+        std::memset(&bl, 0, sizeof(bl));
+        bl.e[0] = la;
+        hipLaunchKernelGGL(k_clahe_lut, dim3(tiles, 1, 1), dim3(CL_THREADS), 0, st, bl);
+        {
+            const LevelBuf &L = im->lv[0];
+            dim3 blk(64, 4);
+            dim3 grd((w + 2 * KLT_PAD + 63) / 64, (h + 2 * KLT_PAD + 3) / 4);
+            hipLaunchKernelGGL(k_clahe_apply, grd, blk, 0, st, im->raw, w, w, h, tw, th, tiles_x, tiles_y, c->lut, L.img, L.istride);
+        }
+        PyrView pv = make_view(im);
+        for (int l = 1; l < KLT_LEVELS; ++l) {
+            const LevelBuf &D = im->lv[l];
+            dim3 blk(64, 4);
+            dim3 grd((D.w + 2 * KLT_PAD + 63) / 64, (D.h + 2 * KLT_PAD + 3) / 4);
+            hipLaunchKernelGGL(k_pyrdown, grd, blk, 0, st, pv.lv[l - 1], D.img, D.w, D.h, D.istride);
+        }
+        ScharrArgs sa;
+        int off = 0;
+        for (int l = 0; l < KLT_LEVELS; ++l) {
+            sa.lv[l] = pv.lv[l];
+            sa.out[l] = im->lv[l].der;
+            sa.blk_off[l] = off;
+            sa.blk_w[l] = (im->lv[l].w + 63) / 64;
+            off += sa.blk_w[l] * ((im->lv[l].h + 3) / 4);
+        }
+        sa.blk_off[KLT_LEVELS] = off;
+        hipLaunchKernelGGL(k_scharr, dim3(off), dim3(256), 0, st, sa);
+        XR_HIP(hipGetLastError());
+        return XRHIP_OK;
+    });
+    if (rc) return rc;
     prof.finish();
     im->have_pyramid = true;
     return XRHIP_OK;
@@ -541,7 +798,9 @@ int xrhip_image_release(xrhip_image *im) {
     return XRHIP_OK;
 }
 
-static int run_harris(xrhip_image *im) {
+// The argument sets of one detection: Harris response, NMS, strongest-candidate selection; results land in the pinned top
+// block / header under a fresh sequence number (one detection in flight per context)
+static int fill_detect(xrhip_image *im, DetectPayload &d, int seq) {
     xrhip_klt *c = im->ctx;
     PyrView pv = make_view(im);
     const int w = c->w, h = c->h;
@@ -549,32 +808,30 @@ static int run_harris(xrhip_image *im) {
     scale *= 255.0;
     scale = 1.0 / scale;
     const float s2 = (float)(scale * scale);
-    const int init[2] = {(int)0x80000000, 0};
-    XR_HIP(hipMemcpyAsync(c->max_key, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_harris, dim3((w + 63) / 64, (h + 15) / 16), dim3(256), 0, c->stream, pv.lv[0], 0.04, s2,
-                       c->resp, c->max_key);
-    return XRHIP_OK;
-}
-
-// Harris response, NMS and strongest-candidate selection of `im`, asynchronous; results land in the pinned top
-// block / header under a fresh sequence number (one detection in flight per context)
-static int launch_detect(xrhip_image *im) {
-    xrhip_klt *c = im->ctx;
-    const int w = c->w, h = c->h;
-    ProfScope prof(c, CAT_DETECT);
-    int rc = run_harris(im);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_harris_nms, dim3((w + 63) / 64, (h + 15) / 16), dim3(256), 0, c->stream, c->resp, w, h,
-                       c->max_key, 1.0e-3, c->cand, c->cand_count, c->cand_cap);
-    XR_HIP(hipGetLastError());
     HarrisCand *d_top = nullptr;
     SelectHeader *d_sel = nullptr;
     XR_HIP(hipHostGetDevicePointer((void **)&d_top, c->h_top, 0));
     XR_HIP(hipHostGetDevicePointer((void **)&d_sel, c->h_sel, 0));
+    const int gx = (w + 63) / 64, gy = (h + 15) / 16;
+    d.hr = HarrisArgs{pv.lv[0], 0.04, s2, c->resp, c->max_key, gx, gy};
+    d.nms = HarrisNmsArgs{c->resp, w, h, c->max_key, 1.0e-3, c->cand, c->cand_count, c->cand_cap, gx, gy};
+    d.sel = HarrisSelectArgs{c->cand, c->cand_count, c->cand_cap, c->max_key, 1.0e-3, d_top, c->top_cap, d_sel, seq};
+    return XRHIP_OK;
+}
+
+// a detection of its own (no tracking launch to ride behind): asynchronous
+static int launch_detect(xrhip_image *im) {
+    xrhip_klt *c = im->ctx;
+    ProfScope prof(c, CAT_DETECT);
+    if (c->group) {
+        int rc = group_wait_launched(&c->rq_detect);
+        if (rc) return rc;
+    }
     const int seq = ++c->sel_seq;
-    hipLaunchKernelGGL(k_harris_select, dim3(1), dim3(1024), 0, c->stream, c->cand, c->cand_count, c->cand_cap, c->max_key,
-                       1.0e-3, d_top, c->top_cap, d_sel, seq);
-    XR_HIP(hipGetLastError());
+    int rc = fill_detect(im, c->a_detect, seq);
+    if (rc) return rc;
+    rc = klt_issue(c, c->rq_detect, GK_DETECT, &c->a_detect, launch_detect_batch);
+    if (rc) return rc;
     prof.finish();
     im->detect_seq = seq;
     return XRHIP_OK;
@@ -595,21 +852,20 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
     const int w = c->w, h = c->h;
     HostProfScope hp_all(0, "detect: whole call");
     std::optional<HostProfScope> hp_gpu(std::in_place, 1, "detect: launch+D2H waits");
+    bool own_launch = false;
     if (!im->detect_seq) {
         int rc = launch_detect(im);
         if (rc) return rc;
+        own_launch = true;
     }
     const int seq = im->detect_seq;
     im->detect_seq = 0;
     im->want_detect = false;
-    {
-        volatile int *flag = &c->h_sel->seq;
-        for (unsigned long spin = 1; *flag != seq; ++spin)
-            if ((spin & 0x3FFF) == 0) {
-                const hipError_t q = hipStreamQuery(c->stream);
-                if (q == hipSuccess && *flag != seq) return xr_fail(XRHIP_ESTATE, "xrhip_image_detect: selection kernel did not publish");
-                if (q != hipSuccess && q != hipErrorNotReady) return xr_fail(XRHIP_EHIP, "xrhip_image_detect: stream error");
-            }
+    {   // (a detection that rode behind a tracking launch: that request has been waited for by xrhip_image_track)
+        GroupRequest *rq = c->group ? (own_launch ? &c->rq_detect : &c->rq_track) : nullptr;
+        int rc = wait_flag(&c->h_sel->seq, seq, klt_stream(c), rq, "xrhip_image_detect");
+        if (rc) return rc;
+        c->uploads_unsynced = 0;
     }
     const int nc = c->h_sel->n_candidates, n_top = c->h_sel->n_top;
     if (nc > c->cand_cap) return xr_fail(XRHIP_EOVERFLOW, "xrhip_image_detect: corner candidate buffer overflow");
@@ -657,8 +913,11 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
     if (need_all) {
         HostProfScope hp_fb(12, "detect: full candidate list fallback");
         c->stats.detect_full_list += 1;
-        XR_HIP(hipMemcpyAsync(c->h_cand, c->cand, sizeof(HarrisCand) * (size_t)nc, hipMemcpyDeviceToHost, c->stream));
-        XR_HIP(hipStreamSynchronize(c->stream));
+        int rc = klt_run_sync(c, [&](hipStream_t st) {
+            XR_HIP(hipMemcpyAsync(c->h_cand, c->cand, sizeof(HarrisCand) * (size_t)nc, hipMemcpyDeviceToHost, st));
+            return XRHIP_OK;
+        });
+        if (rc) return rc;
         corners = select_from(c->h_cand, c->h_cand + nc);
     }
     int n = 0;
@@ -708,30 +967,50 @@ int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const dou
     XR_HIP(hipHostGetDevicePointer((void **)&d_seq, c->h_trk_seq, 0));
     double2 *dv_curr = (double2 *)d_pts, *dv_next = dv_curr + c->h_pts_cap;
     uint8_t *dv_status = (uint8_t *)(dv_next + c->h_pts_cap);
-    PyrView A = make_view(cur), B = make_view(next);
+    if (c->group) {
+        rc = group_wait_launched(&c->rq_track);   // (its argument block is about to be rewritten)
+        if (rc) return rc;
+    }
     ProfScope prof(c, CAT_TRACK);
     const int seq = ++c->trk_seq;
     c->done_base += (unsigned)n;
-    hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(LK_THREADS), 0, c->stream, A, B, dv_curr, dv_next, has_guess ? 1 : 0, dv_status, n,
-                       c->profiling ? c->d_counters : (LkCounters *)nullptr, c->d_done, c->done_base, d_seq, seq);
-    XR_HIP(hipGetLastError());
-    prof.finish();
-    c->stats.lk_points += n;
-    // the Harris pass of `next` does not depend on the tracking result: queue it now so that it runs while the host
-    // digests the tracks (the wait below is on the tracking kernel's own mailbox, not on the stream)
-    if (next->want_detect && !next->detect_seq) {
-        rc = launch_detect(const_cast<xrhip_image *>(next));
+    TrackPayload &tp = c->a_track;
+    tp.lk = LkTrackArgs{make_view(cur), make_view(next), dv_curr, dv_next, has_guess ? 1 : 0, dv_status, n,
+                        c->profiling ? c->d_counters : (LkCounters *)nullptr, c->d_done, c->done_base, d_seq, seq};
+    // the Harris pass of `next` does not depend on the tracking result: it rides right behind the tracking launch so that it runs
+    // while the host digests the tracks (the wait below is on the tracking kernel's own mailbox, not on the stream)
+    tp.detect = next->want_detect && !next->detect_seq;
+    int det_seq = 0;
+    if (tp.detect) {
+        det_seq = ++c->sel_seq;
+        rc = fill_detect(const_cast<xrhip_image *>(next), tp.det, det_seq);
         if (rc) return rc;
     }
-    {
-        volatile int *flag = c->h_trk_seq;
-        for (unsigned long spin = 1; *flag != seq; ++spin)
-            if ((spin & 0x3FFF) == 0) {
-                const hipError_t q = hipStreamQuery(c->stream);
-                if (q == hipSuccess && *flag != seq) return xr_fail(XRHIP_ESTATE, "xrhip_image_track: kernel retired without publishing");
-                if (q != hipSuccess && q != hipErrorNotReady) return xr_fail(XRHIP_EHIP, "xrhip_image_track: stream error");
-            }
+    if (c->group) {
+        rc = klt_issue(c, c->rq_track, GK_TRACK, &tp, launch_track_batch);
+        if (rc) return rc;
+        prof.finish();
+        if (tp.detect) c->stats.n_detect++;
+    } else {   // launched here: the two halves keep their own event pairs (bench.py's roofline_lk is the LK kernel alone)
+        const bool with_detect = tp.detect;
+        tp.detect = false;
+        rc = klt_issue(c, c->rq_track, GK_TRACK, &tp, launch_track_batch);
+        if (rc) return rc;
+        prof.finish();
+        if (with_detect) {
+            ProfScope prof_d(c, CAT_DETECT);
+            const DetectPayload *d = &tp.det;
+            launch_detect_chunk(&d, 1, c->stream);
+            XR_HIP(hipGetLastError());
+            prof_d.finish();
+        }
+        tp.detect = with_detect;
     }
+    c->stats.lk_points += n;
+    if (tp.detect) const_cast<xrhip_image *>(next)->detect_seq = det_seq;
+    rc = wait_flag(c->h_trk_seq, seq, klt_stream(c), c->group ? &c->rq_track : nullptr, "xrhip_image_track");
+    if (rc) return rc;
+    c->uploads_unsynced = 0;
     // results: status first, positions only where status != 0 (reference semantics)
     for (int i = 0; i < n; ++i) {
         status[i] = h_status[i];
@@ -752,15 +1031,16 @@ int xrhip_image_lk(const xrhip_image *prev, const xrhip_image *next, const float
     xrhip_klt *c = prev->ctx;
     int rc = ensure_points(c, n);
     if (rc) return rc;
-    XR_HIP(hipMemcpyAsync(c->d_fprev, prev_xy, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
-    XR_HIP(hipMemcpyAsync(c->d_fnext, next_xy_inout, sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
-    PyrView A = make_view(prev), B = make_view(next);
-    hipLaunchKernelGGL(k_lk_plain, dim3(n), dim3(LK_THREADS), 0, c->stream, A, B, c->d_fprev, c->d_fnext, c->d_status, n);
-    XR_HIP(hipGetLastError());
-    XR_HIP(hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
-    XR_HIP(hipMemcpyAsync(next_xy_inout, c->d_fnext, sizeof(float2) * n, hipMemcpyDeviceToHost, c->stream));
-    XR_HIP(hipStreamSynchronize(c->stream));
-    return XRHIP_OK;
+    return klt_run_sync(c, [&](hipStream_t st) {
+        XR_HIP(hipMemcpyAsync(c->d_fprev, prev_xy, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+        XR_HIP(hipMemcpyAsync(c->d_fnext, next_xy_inout, sizeof(float2) * n, hipMemcpyHostToDevice, st));
+        PyrView A = make_view(prev), B = make_view(next);
+        hipLaunchKernelGGL(k_lk_plain, dim3(n), dim3(LK_THREADS), 0, st, A, B, c->d_fprev, c->d_fnext, c->d_status, n);
+        XR_HIP(hipGetLastError());
+        XR_HIP(hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, st));
+        XR_HIP(hipMemcpyAsync(next_xy_inout, c->d_fnext, sizeof(float2) * n, hipMemcpyDeviceToHost, st));
+        return XRHIP_OK;
+    });
 }
 
 int xrhip_image_level_dims(const xrhip_image *im, int level, int *w, int *h) {
@@ -775,25 +1055,32 @@ int xrhip_image_download_level(const xrhip_image *im, int level, uint8_t *img_ou
     if (!im->have_pyramid) return xr_fail(XRHIP_ESTATE, "xrhip_image_download_level: preprocess() has not run");
     const LevelBuf &L = im->lv[level];
     xrhip_klt *c = im->ctx;
-    if (img_out)
-        XR_HIP(hipMemcpy2DAsync(img_out, L.w, L.img, L.istride, L.w, L.h, hipMemcpyDeviceToHost, c->stream));
-    if (deriv_out)
-        XR_HIP(hipMemcpy2DAsync(deriv_out, (size_t)L.w * 4, L.der, (size_t)L.istride * 4, (size_t)L.w * 4, L.h,
-                                hipMemcpyDeviceToHost, c->stream));
-    XR_HIP(hipStreamSynchronize(c->stream));
-    return XRHIP_OK;
+    return klt_run_sync(c, [&](hipStream_t st) {
+        if (img_out) XR_HIP(hipMemcpy2DAsync(img_out, L.w, L.img, L.istride, L.w, L.h, hipMemcpyDeviceToHost, st));
+        if (deriv_out)
+            XR_HIP(hipMemcpy2DAsync(deriv_out, (size_t)L.w * 4, L.der, (size_t)L.istride * 4, (size_t)L.w * 4, L.h, hipMemcpyDeviceToHost, st));
+        return XRHIP_OK;
+    });
 }
 
 int xrhip_image_download_harris(xrhip_image *im, float *resp_out) {
     if (!im || !resp_out) return xr_fail(XRHIP_EINVAL, "xrhip_image_download_harris: bad arguments");
     if (!im->have_pyramid) return xr_fail(XRHIP_ESTATE, "xrhip_image_download_harris: preprocess() has not run");
     xrhip_klt *c = im->ctx;
-    int rc = run_harris(im);
+    DetectPayload d;
+    int rc = fill_detect(im, d, 0);
     if (rc) return rc;
-    XR_HIP(hipGetLastError());
-    XR_HIP(hipMemcpyAsync(resp_out, c->resp, sizeof(float) * (size_t)c->w * c->h, hipMemcpyDeviceToHost, c->stream));
-    XR_HIP(hipStreamSynchronize(c->stream));
-    return XRHIP_OK;
+    return klt_run_sync(c, [&](hipStream_t st) {   // the response plane alone; the running maximum goes back to its reset state
+        Batch<HarrisArgs> bh;
+        std::memset(&bh, 0, sizeof(bh));
+        bh.e[0] = d.hr;
+        hipLaunchKernelGGL(k_harris, dim3(d.hr.gx, d.hr.gy, 1), dim3(256), 0, st, bh);
+        XR_HIP(hipGetLastError());
+        XR_HIP(hipMemcpyAsync(resp_out, c->resp, sizeof(float) * (size_t)c->w * c->h, hipMemcpyDeviceToHost, st));
+        static const int init[2] = {(int)0x80000000, 0};
+        XR_HIP(hipMemcpyAsync(c->max_key, init, sizeof(init), hipMemcpyHostToDevice, st));
+        return XRHIP_OK;
+    });
 }
 
 int xrhip_klt_set_profiling(xrhip_klt *c, int enable) {
@@ -806,21 +1093,28 @@ int xrhip_klt_get_stats(xrhip_klt *c, xrhip_klt_stats *out, int reset) {
     if (!c || !out) return xr_fail(XRHIP_EINVAL, "xrhip_klt_get_stats: null");
     int rc = resolve_pending(c);
     if (rc) return rc;
-    XR_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(LkCounters), hipMemcpyDeviceToHost, c->stream));
-    XR_HIP(hipStreamSynchronize(c->stream));
+    rc = klt_run_sync(c, [&](hipStream_t st) {
+        XR_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(LkCounters), hipMemcpyDeviceToHost, st));
+        return XRHIP_OK;
+    });
+    if (rc) return rc;
     c->stats.lk_templates = (long long)c->h_counters->templates;
     c->stats.lk_iterations = (long long)c->h_counters->iterations;
     *out = c->stats;
     if (reset) {
         c->stats = xrhip_klt_stats{};
-        XR_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(LkCounters), c->stream));
-        XR_HIP(hipStreamSynchronize(c->stream));
+        rc = klt_run_sync(c, [&](hipStream_t st) {
+            XR_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(LkCounters), st));
+            return XRHIP_OK;
+        });
+        if (rc) return rc;
     }
     return XRHIP_OK;
 }
 
 int xrhip_klt_synchronize(xrhip_klt *c) {
     if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_klt_synchronize: null");
+    if (c->group) return group_drain(c->group, GQ_KLT, c);
     XR_HIP(hipStreamSynchronize(c->stream));
     return XRHIP_OK;
 }

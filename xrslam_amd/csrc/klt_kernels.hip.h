@@ -22,6 +22,8 @@
 // flight together.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "batch.hip.h"
 #include <stdint.h>
 
 namespace xrhip {
@@ -43,6 +45,8 @@ struct PyrView {
     LevelView lv[KLT_LEVELS];
 };
 
+// Every front-end kernel takes its arguments as Batch<Args> (batch.hip.h): up to XB argument sets, one per blockIdx.z.
+
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (n == 1) return 0;
     while (i < 0 || i >= n) {
@@ -56,9 +60,9 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // One workgroup per tile: LDS histogram, clip + redistribute, inclusive scan,
 // LUT.  (cv::CLAHE_CalcLut_Body restated; integer exact.)
 constexpr int CL_THREADS = 1024;   // sixteen wavefronts count a tile's pixels (one batch of loads each), four of them finish the LUT
-__global__ __launch_bounds__(CL_THREADS) void k_clahe_lut(const uint8_t *__restrict__ src, int sstride, int w, int h,
-                                                          int tw, int th, int tiles_x, int clip, float lut_scale,
-                                                          uint8_t *__restrict__ lut) {
+__device__ __forceinline__ void d_clahe_lut(const uint8_t *__restrict__ src, int sstride, int w, int h,
+                                            int tw, int th, int tiles_x, int clip, float lut_scale,
+                                            uint8_t *__restrict__ lut) {
     __shared__ int hist[CL_THREADS / 64][256];   // one histogram per wavefront: neighbouring pixels share grey levels, a single one serialises its atomics
     __shared__ int scan[2][256];
     const int tid = threadIdx.x, wv = tid >> 6;
@@ -126,6 +130,18 @@ __global__ __launch_bounds__(CL_THREADS) void k_clahe_lut(const uint8_t *__restr
     int v = __float2int_rn((float)sum * lut_scale);
     v = v < 0 ? 0 : (v > 255 ? 255 : v);
     lut[(size_t)blockIdx.x * 256 + t] = (uint8_t)v;
+}
+struct ClaheLutArgs {
+    const uint8_t *src;
+    int sstride, w, h, tw, th, tiles_x, clip;
+    float lut_scale;
+    uint8_t *lut;
+    int tiles;   // blocks of this entry
+};
+__global__ __launch_bounds__(CL_THREADS) void k_clahe_lut(Batch<ClaheLutArgs> b) {
+    const ClaheLutArgs &a = b.e[blockIdx.z];
+    if ((int)blockIdx.x >= a.tiles) return;
+    d_clahe_lut(a.src, a.sstride, a.w, a.h, a.tw, a.th, a.tiles_x, a.clip, a.lut_scale, a.lut);
 }
 
 // -------------------------------------------------------------- CLAHE apply
@@ -316,8 +332,9 @@ struct PyrAArgs {
     short2 *der0;
     int w0, h0, s0, w1, h1, s1;
     int tiles_across;
+    int blocks;   // tiles of this entry
 };
-__global__ __launch_bounds__(PF_THREADS) void k_pyr_a(PyrAArgs a) {
+__device__ __forceinline__ void d_pyr_a(const PyrAArgs &a) {
     __shared__ uint8_t T0[PA_R0 * PA_P0], T1[PA_R1 * PA_P1];
     __shared__ int cs[PA_R0], ci1[PA_R0], ci2[PA_R0], rs[PA_R0], rp1[PA_R0], rp2[PA_R0];
     __shared__ float cxa[PA_R0], cxa1[PA_R0], rya[PA_R0], rya1[PA_R0];
@@ -390,6 +407,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_pyr_a(PyrAArgs a) {
     pf_down<PA_R1, PA_P1, 0, PA_T / 2, PA_R0, PA_P0, PA_LO0>(T0, T1, X0 >> 1, Y0 >> 1, a.w1, a.h1, a.img1, a.s1, tid);
     pf_scharr<PA_P0, PA_LO0, PA_T>(T0, X0, Y0, w, h, a.der0, a.s0, tid);
 }
+__global__ __launch_bounds__(PF_THREADS) void k_pyr_a(Batch<PyrAArgs> b) {
+    const PyrAArgs &a = b.e[blockIdx.z];
+    if ((int)blockIdx.x >= a.blocks) return;
+    d_pyr_a(a);
+}
 
 constexpr int PB_T = 32;                                  // k_pyr_b: level-1 tile = 16x16 of level 2 = 8x8 of level 3
 constexpr int PB_R1 = 49, PB_R2 = 23, PB_R3 = 10;        // LDS tile extents
@@ -400,8 +422,9 @@ struct PyrBArgs {
     short2 *der[KLT_LEVELS];
     int w[KLT_LEVELS], h[KLT_LEVELS], istride[KLT_LEVELS];
     int tiles_across;
+    int blocks;   // tiles of this entry
 };
-__global__ __launch_bounds__(PF_THREADS) void k_pyr_b(PyrBArgs a) {
+__device__ __forceinline__ void d_pyr_b(const PyrBArgs &a) {
     __shared__ uint8_t T1[PB_R1 * PB_P1], T2[PB_R2 * PB_P2], T3[PB_R3 * PB_P3];
     const int tid = threadIdx.x;
     const int bx = blockIdx.x % a.tiles_across, by = blockIdx.x / a.tiles_across;
@@ -433,6 +456,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_pyr_b(PyrBArgs a) {
     __syncthreads();
     pf_scharr<PB_P3, PB_LO3, PB_T / 4>(T3, X1 >> 2, Y1 >> 2, a.w[3], a.h[3], a.der[3], a.istride[3], tid);
 }
+__global__ __launch_bounds__(PF_THREADS) void k_pyr_b(Batch<PyrBArgs> b) {
+    const PyrBArgs &a = b.e[blockIdx.z];
+    if ((int)blockIdx.x >= a.blocks) return;
+    d_pyr_b(a);
+}
 
 // ------------------------------------------------------------------- Harris
 __device__ __forceinline__ int float_order_key(float f) {
@@ -446,8 +474,8 @@ __device__ __forceinline__ float float_from_key(int k) {
 // cv::cornerHarris(8U, block 3, ksize 3, k) on the CLAHE image (pyramid level 0).
 // 64x16 output tile per workgroup; Sobel dx/dy staged in LDS as int16, the 3x3
 // window sums are exact int32.  Also reduces the global maximum.
-__global__ __launch_bounds__(256) void k_harris(LevelView L, double kk, float s2, float *__restrict__ resp,
-                                                int *__restrict__ max_key) {
+__device__ __forceinline__ void d_harris(LevelView L, double kk, float s2, float *__restrict__ resp,
+                                         int *__restrict__ max_key) {
     __shared__ short sdx[18][66];
     __shared__ short sdy[18][66];
     const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * 16;
@@ -494,6 +522,19 @@ __global__ __launch_bounds__(256) void k_harris(LevelView L, double kk, float s2
     for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
     if ((tid & 63) == 0) atomicMax(max_key, float_order_key(best));
 }
+struct HarrisArgs {
+    LevelView L;
+    double kk;
+    float s2;
+    float *resp;
+    int *max_key;
+    int gx, gy;   // tile grid of this entry
+};
+__global__ __launch_bounds__(256) void k_harris(Batch<HarrisArgs> b) {
+    const HarrisArgs &a = b.e[blockIdx.z];
+    if ((int)blockIdx.x >= a.gx || (int)blockIdx.y >= a.gy) return;
+    d_harris(a.L, a.kk, a.s2, a.resp, a.max_key);
+}
 
 struct HarrisCand {
     float v;
@@ -505,10 +546,10 @@ struct HarrisCand {
 // per workgroup (a per-pixel atomic on a single counter serialises at ~100
 // atomics/us on this chip).  Order is arbitrary; the host orders candidates by
 // the total order (v desc, idx desc).
-__global__ __launch_bounds__(256) void k_harris_nms(const float *__restrict__ resp, int w, int h,
-                                                    const int *__restrict__ max_key, double quality,
-                                                    HarrisCand *__restrict__ cand, int *__restrict__ count,
-                                                    int capacity) {
+__device__ __forceinline__ void d_harris_nms(const float *__restrict__ resp, int w, int h,
+                                             const int *__restrict__ max_key, double quality,
+                                             HarrisCand *__restrict__ cand, int *__restrict__ count,
+                                             int capacity) {
     __shared__ HarrisCand local[1024];
     __shared__ int nlocal;
     __shared__ int base;
@@ -542,6 +583,21 @@ __global__ __launch_bounds__(256) void k_harris_nms(const float *__restrict__ re
         if (slot < capacity) cand[slot] = local[i];
     }
 }
+struct HarrisNmsArgs {
+    const float *resp;
+    int w, h;
+    const int *max_key;
+    double quality;
+    HarrisCand *cand;
+    int *count;
+    int capacity;
+    int gx, gy;
+};
+__global__ __launch_bounds__(256) void k_harris_nms(Batch<HarrisNmsArgs> b) {
+    const HarrisNmsArgs &a = b.e[blockIdx.z];
+    if ((int)blockIdx.x >= a.gx || (int)blockIdx.y >= a.gy) return;
+    d_harris_nms(a.resp, a.w, a.h, a.max_key, a.quality, a.cand, a.count, a.capacity);
+}
 
 // The host's greedy spacing pass visits candidates in (response desc, index desc) order and normally stops
 // after a few hundred of the ~10^4 NMS survivors.  This kernel hands it a superset of the SEL_K strongest:
@@ -559,9 +615,9 @@ struct SelectHeader {
     int seq;            // written last
 };
 
-__global__ __launch_bounds__(1024) void k_harris_select(const HarrisCand *__restrict__ cand, const int *__restrict__ count,
-                                                        int capacity, const int *__restrict__ max_key, double quality,
-                                                        HarrisCand *top_out, int top_cap, SelectHeader *hdr, int seq) {
+__device__ __forceinline__ void d_harris_select(const HarrisCand *__restrict__ cand, int *__restrict__ count,
+                                                int capacity, int *__restrict__ max_key, double quality,
+                                                HarrisCand *top_out, int top_cap, SelectHeader *hdr, int seq) {
     __shared__ unsigned hist[SEL_BINS];
     __shared__ HarrisCand sorted_buf[SEL_SORT];
     __shared__ unsigned part[64];
@@ -738,10 +794,29 @@ __global__ __launch_bounds__(1024) void k_harris_select(const HarrisCand *__rest
         hdr->n_top = n_top;
         hdr->boundary_bin = bin;
         hdr->sorted = sorted;
+        // this kernel is the last reader of the pass's running maximum and candidate counter: it leaves both reset for the context's
+        // next detection (a host-side reset in front of k_harris was a copy command of its own per frame and per sequence)
+        *max_key = (int)0x80000000;
+        *count = 0;
         __threadfence_system();
         *reinterpret_cast<volatile int *>(&hdr->seq) = seq;
     }
     (void)lane;
+}
+struct HarrisSelectArgs {
+    const HarrisCand *cand;
+    int *count;
+    int capacity;
+    int *max_key;
+    double quality;
+    HarrisCand *top_out;
+    int top_cap;
+    SelectHeader *hdr;
+    int seq;
+};
+__global__ __launch_bounds__(1024) void k_harris_select(Batch<HarrisSelectArgs> b) {
+    const HarrisSelectArgs &a = b.e[blockIdx.z];
+    d_harris_select(a.cand, a.count, a.capacity, a.max_key, a.quality, a.top_out, a.top_cap, a.hdr, a.seq);
 }
 
 // ----------------------------------------------------------------------- LK
@@ -1113,11 +1188,11 @@ __device__ __forceinline__ void lk_lane_layout(int lane, int (&wx)[LK_SLOTS], in
 // the kernel reads and writes them over the host link itself.  done / done_target / host_seq implement the
 // completion mailbox: every wavefront publishes its result (system-scope fence), bumps `done`, and the one that
 // reaches done_target stores `seq` where the host is spinning.
-__global__ __launch_bounds__(LK_THREADS) void k_lk_track(PyrView A, PyrView B, const double2 *__restrict__ curr,
-                                                 double2 *__restrict__ next_io, int has_guess,
-                                                 uint8_t *__restrict__ status_out, int n,
-                                                 LkCounters *__restrict__ counters, unsigned *done, unsigned done_target,
-                                                 int *host_seq, int seq) {
+__device__ __forceinline__ void d_lk_track(const PyrView &A, const PyrView &B, const double2 *__restrict__ curr,
+                                           double2 *__restrict__ next_io, int has_guess,
+                                           uint8_t *__restrict__ status_out, int n,
+                                           LkCounters *__restrict__ counters, unsigned *done, unsigned done_target,
+                                           int *host_seq, int seq) {
     const int pt = blockIdx.x;
     if (pt >= n) return;
     const int lane = threadIdx.x;
@@ -1164,6 +1239,48 @@ __global__ __launch_bounds__(LK_THREADS) void k_lk_track(PyrView A, PyrView B, c
                 __threadfence_system();
                 *reinterpret_cast<volatile int *>(host_seq) = seq;
             }
+        }
+    }
+}
+struct LkTrackArgs {
+    PyrView A, B;
+    const double2 *curr;
+    double2 *next_io;
+    int has_guess;
+    uint8_t *status_out;
+    int n;   // points of this entry (blocks beyond them return at once)
+    LkCounters *counters;
+    unsigned *done;
+    unsigned done_target;
+    int *host_seq;
+    int seq;
+};
+__global__ __launch_bounds__(LK_THREADS) void k_lk_track(Batch<LkTrackArgs> b) {
+    const LkTrackArgs &a = b.e[blockIdx.z];
+    d_lk_track(a.A, a.B, a.curr, a.next_io, a.has_guess, a.status_out, a.n, a.counters, a.done, a.done_target, a.host_seq, a.seq);
+}
+
+// A host (pinned, device-mapped) or device frame into the dense plane the preprocessing reads: the upload of a group's frames is one
+// launch (a copy-engine transfer per frame is a command of its own on the queue; on this stack it runs as a blit kernel anyway).
+struct UploadArgs {
+    const uint8_t *src;
+    int sstride;
+    uint8_t *dst;   // dense w x h
+    int w, h;
+};
+__global__ __launch_bounds__(256) void k_upload(Batch<UploadArgs> b) {
+    const UploadArgs &a = b.e[blockIdx.z];
+    if (!a.src) return;
+    const size_t total = (size_t)a.w * a.h;
+    if (a.sstride == a.w && (total & 15) == 0 && ((reinterpret_cast<uintptr_t>(a.src) | reinterpret_cast<uintptr_t>(a.dst)) & 15) == 0) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(a.src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(a.dst);
+        const size_t n16 = total >> 4;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) d4[i] = s4[i];
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const size_t y = i / a.w, x = i - y * a.w;
+            a.dst[i] = a.src[y * (size_t)a.sstride + x];
         }
     }
 }

@@ -449,11 +449,27 @@ __device__ __forceinline__ void preint_publish(int *status, int code) {
     if (threadIdx.x == 0) *reinterpret_cast<volatile int *>(status + blockIdx.x) = code;
 }
 
-__global__ __launch_bounds__(64) void kp_preintegrate(const PreintJob *__restrict__ jobs,
-                                                      const double *__restrict__ samples,
-                                                      const double *__restrict__ noise_host, int want_jac, int want_cov,
-                                                      double *__restrict__ out, int *__restrict__ status,
-                                                      const double *__restrict__ state_dev) {
+// blockIdx.x = job of an entry, blockIdx.z = entry: a launch carries the batches of up to XB contexts (group.hip.h)
+struct PreintArgs {
+    const PreintJob *jobs;
+    const double *samples;
+    const double *noise_host;
+    int want_jac, want_cov;
+    double *out;
+    int *status;
+    const double *state_dev;
+    int n_jobs;
+};
+__global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
+    const PreintArgs &ea = batch.e[blockIdx.z];
+    if ((int)blockIdx.x >= ea.n_jobs) return;
+    const PreintJob *__restrict__ jobs = ea.jobs;
+    const double *__restrict__ samples = ea.samples;
+    const double *__restrict__ noise_host = ea.noise_host;
+    const int want_jac = ea.want_jac, want_cov = ea.want_cov;
+    double *__restrict__ out = ea.out;
+    int *__restrict__ status = ea.status;
+    const double *__restrict__ state_dev = ea.state_dev;
     __shared__ double cov[15][15], Tm[9][9], inv[15][15];
     __shared__ double Jac[5][9], Jnew[5][9];   // dq_dbg, dp_dbg, dp_dba, dv_dbg, dv_dba
     __shared__ double sA[PI_CHUNK][81], sG[PI_CHUNK][81];

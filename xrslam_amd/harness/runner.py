@@ -38,6 +38,13 @@ class XRSLAMAmdTimes(C.Structure):
                 ("wall_frame", C.c_double), ("wall_scope", C.c_double * 16)]
 
 
+class GroupStats(C.Structure):   # xrhip_group_stats (include/xrslam_hip.h)
+    _fields_ = [("batches", C.c_longlong * 8), ("entries", C.c_longlong * 8), ("ms", C.c_double * 8), ("timed", C.c_longlong * 8)]
+
+
+GROUP_KINDS = ("call", "upload", "preprocess", "track", "detect", "chain", "preint")
+
+
 class XRSLAMAmdInitReport(C.Structure):
     _fields_ = [("attempts", C.c_long), ("successes", C.c_long), ("sfm_candidate", C.c_int),
                 ("sfm_triangulated", C.c_int), ("scale", C.c_double), ("gravity", C.c_double * 3),
@@ -97,7 +104,41 @@ def load(lib_path):
         lib.XRSLAMAmdInstanceReplay.argtypes = [H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                                 C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p]
         lib.XRSLAMAmdInstanceReplay.restype = C.c_int
+    if hasattr(lib, "XRSLAMAmdGroupCreate"):
+        lib.XRSLAMAmdGroupCreate.argtypes = [C.POINTER(C.c_void_p)]
+        lib.XRSLAMAmdGroupDestroy.argtypes = [C.c_void_p]
+        lib.XRSLAMAmdInstanceJoinGroup.argtypes = [C.c_void_p, C.c_void_p]
+        lib.XRSLAMAmdGroupSetProfiling.argtypes = [C.c_void_p, C.c_int]
+        lib.XRSLAMAmdGroupSetProfiling.restype = None
+        lib.XRSLAMAmdGroupGetStats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.XRSLAMAmdGroupGetStats.restype = None
     return lib
+
+
+class Group:
+    """An instance group (XRSLAMAmdGroup, include/XRSLAM.h): the sessions created with group=<this> share their per-frame launches."""
+
+    def __init__(self, lib_path):
+        self.lib = load(lib_path)
+        self.handle = C.c_void_p()
+        if self.lib.XRSLAMAmdGroupCreate(C.byref(self.handle)) != 1:
+            raise RuntimeError("XRSLAMAmdGroupCreate failed: %s" % self.lib.XRSLAMAmdLastError().decode())
+
+    def set_profiling(self, on):
+        self.lib.XRSLAMAmdGroupSetProfiling(self.handle, 1 if on else 0)
+
+    def stats(self, reset=False):
+        """-> {kind: {"batches", "requests", "ms", "timed"}} for the kinds that saw traffic"""
+        st = GroupStats()
+        self.lib.XRSLAMAmdGroupGetStats(self.handle, C.byref(st), 1 if reset else 0)
+        return {name: {"batches": int(st.batches[i]), "requests": int(st.entries[i]), "ms": float(st.ms[i]), "timed": int(st.timed[i])}
+                for i, name in enumerate(GROUP_KINDS) if st.batches[i]}
+
+    def close(self):
+        if self.handle:
+            if self.lib.XRSLAMAmdGroupDestroy(self.handle) != 1:
+                raise RuntimeError("XRSLAMAmdGroupDestroy failed: %s" % self.lib.XRSLAMAmdLastError().decode())
+            self.handle = None
 
 
 class _Api:
@@ -130,7 +171,7 @@ class Session:
     instance=True -- an XRSLAMAmdInstance of its own, so that several sessions can live in one process."""
 
     def __init__(self, lib_path, seq, slam_yaml=SLAM_YAML, sensor_yaml=SENSOR_YAML, device_frames=None,
-                 init_frames=60, instance=False, device_undistort=None, threading=0):
+                 init_frames=60, instance=False, device_undistort=None, threading=0, group=None):
         self.lib = load(lib_path)
         self.seq = seq
         cfg = C.c_void_p()
@@ -141,6 +182,8 @@ class Session:
                 raise RuntimeError("XRSLAMAmdInstanceCreate failed: %s" % self.lib.XRSLAMAmdLastError().decode())
             self.api = _Api(self.lib, handle)
             self._handle = handle
+            if group is not None and self.lib.XRSLAMAmdInstanceJoinGroup(handle, group.handle) != 1:
+                raise RuntimeError("XRSLAMAmdInstanceJoinGroup failed: %s" % self.api.last_error().decode())
         else:
             ok = self.lib.XRSLAMCreate(slam_yaml.encode(), sensor_yaml.encode(), b"", b"xrslam_amd", C.byref(cfg))
             if ok != 1:
