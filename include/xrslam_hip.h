@@ -295,6 +295,13 @@ int xrhip_ba_preintegrate_begin(xrhip_ba *ctx, const double *samples, const int 
                                 const double *t_end, const double *bg, const double *ba, int n_jobs,
                                 const double *noise_cov36, int compute_jacobian, int compute_covariance);
 int xrhip_ba_preintegrate_end(xrhip_ba *ctx, double *out);
+/* Between _begin and _end: the DELTA of job `job` -- doubles [0..10] of its record: dt, dq, dp, dv -- as soon as the kernel has it,
+ * i.e. before the covariance / Jacobian / sqrt_inv_cov part of the record exists.  The delta does not depend on compute_jacobian /
+ * compute_covariance (same expressions): FeatureTracker::work's integrate(t, bg, ba, false, false) of an interval
+ * (core/feature_tracker.cpp:75-77) and mirror_frame's integrate(t, bg, ba, true, true) of the same samples at the same biases
+ * (sliding_window_tracker.cpp:54-56) are ONE launch here; the tracker takes the delta early, the backend collects the record with
+ * _end.  The batch stays in flight. */
+int xrhip_ba_preintegrate_early(xrhip_ba *ctx, int job, double *out_delta11);
 /* the unwind path of an owner that cannot reach _end (an error between the two calls): waits for the batch's kernel and
  * forgets it, staged-behind-a-solve batches included.  A second _begin without _end or _cancel fails with XRHIP_ESTATE. */
 int xrhip_ba_preintegrate_cancel(xrhip_ba *ctx);

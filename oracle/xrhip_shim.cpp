@@ -346,6 +346,15 @@ int xrhip_ba_preintegrate_cancel(xrhip_ba *c) {
     c->preint_pending = 0;
     return 0;
 }
+int xrhip_ba_preintegrate_early(xrhip_ba *c, int job, double *out) {
+    if (!c->preint_pending || job < 0 || job >= c->preint_pending) {
+        g_err = "xrhip_ba_preintegrate_early: no such job in flight";
+        return XRHIP_ESTATE;
+    }
+    if (c->preint_rc) return c->preint_rc;
+    std::memcpy(out, c->preint_out.data() + (size_t)XRHIP_IMU_DIM * job, sizeof(double) * 11);
+    return 0;
+}
 int xrhip_ba_preintegrate_end(xrhip_ba *c, double *out) {
     if (c->have_deferred) {
         c->have_deferred = false;

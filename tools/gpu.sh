@@ -10,7 +10,7 @@
 #   ab:VARIANT              default library vs lib/libxrslam_hip_VARIANT.so, alternating (S1 line and S4 replay)
 #   abenv:VAR [reps]        the default bench line with VAR unset / =1, interleaved
 #   hostprof                XRHIP_HOSTPROF scope accumulators of the S1 stream             kprint[:PATTERN]   in-kernel printf timers (kprint variant)
-#   peaks                   tools/peaks.hip micro-benchmarks            clocks             rocm-smi clock / power state
+#   peaks                   tools/peaks.hip micro-benchmarks            clocks / host      rocm-smi clock / power state; CPU cores
 set -uo pipefail
 R="$(cd "$(dirname "$0")/.." && pwd)"
 TAG="${1:?tag}"; shift
@@ -49,8 +49,9 @@ for step in "$@"; do
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke_$TAG.log" 2>&1; tail -2 "$O/smoke_$TAG.log" ;;
     bench)  timeout 500 python bench.py $arg > "$O/bench_${TAG}_$n.json" 2> "$O/bench_${TAG}_$n.err"; digest "$O/bench_${TAG}_$n.json"; tail -2 "$O/bench_${TAG}_$n.err" ;;
     driver) timeout 240 python bench.py --steps 20 --warmup 5 > "$O/bench_${TAG}_driver.json" 2> "$O/bench_${TAG}_driver.err"; digest "$O/bench_${TAG}_driver.json" ;;
-    multi)  set -- $arg; S="$1"; shift
-            timeout 500 python bench.py --sequences-per-gpu "$S" --steps 200 --warmup 50 --cpu-frames 0 "$@" > "$O/bench_${TAG}_multi${S}_$n.json" 2> "$O/bench_${TAG}_multi${S}_$n.err"
+    multi)  set -- $arg; S="$1"; shift; ENVS=""; ARGS=""   # multi:S [VAR=VALUE ...] [bench.py args]
+            for t in "$@"; do case "$t" in -*) ARGS="$ARGS $t" ;; *=*) ENVS="$ENVS $t" ;; *) ARGS="$ARGS $t" ;; esac; done
+            env $ENVS timeout 500 python bench.py --sequences-per-gpu "$S" --steps 200 --warmup 50 --cpu-frames 0 $ARGS > "$O/bench_${TAG}_multi${S}_$n.json" 2> "$O/bench_${TAG}_multi${S}_$n.err"
             digest "$O/bench_${TAG}_multi${S}_$n.json"; tail -2 "$O/bench_${TAG}_multi${S}_$n.err" ;;
     procs)  set -- $arg; N="$1"; Q="${2:-2}"
             GPU_MAX_HW_QUEUES=$Q OMP_NUM_THREADS=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((29500 + N + Q)) bench.py --gpus "$N" --backend gloo --steps 200 --warmup 50 --cpu-frames 0 --variant-frames 0 > "$O/procs_${TAG}_${N}_$Q.json" 2> "$O/procs_${TAG}_${N}_$Q.err"
@@ -75,6 +76,7 @@ import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); p
     hostprof) XRHIP_HOSTPROF=1 timeout 300 python bench.py --steps 150 --warmup 50 --cpu-frames 0 --variant-frames 0 --threading inline > "$O/hostprof_$TAG.json" 2> "$O/hostprof_$TAG.txt"; grep hostprof "$O/hostprof_$TAG.txt" | cut -c1-130 | tail -40 ;;
     kprint) XRSLAM_HIP_LIB="$R/xrslam_amd/lib/libxrslam_hip_kprint.so" timeout 200 python bench.py --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --threading inline 2>/dev/null | grep -v '^{' > "$O/blocks_$TAG.txt"; grep "${arg:-kb_}" "$O/blocks_$TAG.txt" | tail -12 ;;
     peaks)  "$R/xrslam_amd/bin/xr-peaks" > "$O/peaks_$TAG.json" 2> "$O/peaks_$TAG.err"; cat "$O/peaks_$TAG.json" ;;
+    host)   echo "nproc $(nproc)  affinity $(python -c 'import os; print(len(os.sched_getaffinity(0)))')"; lscpu | grep -E "Model name|Socket|Thread|Core" | head -5 ;;
     clocks) rocm-smi --showclocks --showpower --showmaxpower --showperflevel > "$O/clocks_$TAG.txt" 2>&1; grep -i "clock level\|power\|level" "$O/clocks_$TAG.txt" | head -12 ;;
     *)      echo "unknown step $step" ;;
   esac

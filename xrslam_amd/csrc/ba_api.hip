@@ -761,10 +761,10 @@ int xrhip_ba_join_group(xrhip_ba *c, xrhip_group *g) {
         int rc = group_drain(c->group, GQ_CHAIN, c);
         if (!rc) rc = group_drain(c->group, GQ_PREINT, c);
         if (rc) return rc;
-        group_member_remove(c->group);
+        group_member_remove(c->group, false);
     }
     c->group = g;
-    if (g) group_member_add(g);
+    if (g) group_member_add(g, false);
     return XRHIP_OK;
 }
 
@@ -869,6 +869,11 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16 + 1)), dim3(256), 0, s, d.np, p.pS, p.pLam, p.pinfo, p.pc0);
     bool done = false, relinearise = true;
     int mode = 1, iter_seen = 0;
+    struct BusyElsewhere {   // a solve on the context's own stream: the group's linger does not wait for this member meanwhile
+        xrhip_group *g;
+        explicit BusyElsewhere(xrhip_group *gg) : g(gg) { group_busy_elsewhere(g, 1); }
+        ~BusyElsewhere() { group_busy_elsewhere(g, -1); }
+    } busy_elsewhere(use_chain ? nullptr : c->group);
     if (use_chain) {   // the whole solve in one launch, LDS-resident (kb_chain)
         const int seq = ++c->seq;
         if (c->group) {
@@ -1398,7 +1403,7 @@ static int preint_stage(xrhip_ba *c, const double *samples, const int *sample_be
     const size_t b_jobs = sizeof(PreintJob) * n_jobs, b_smp = D8 * 7 * (size_t)total, b_noise = D8 * 36;
     const size_t o_jobs = 0, o_smp = (b_jobs + 255) & ~size_t(255), o_noise = (o_smp + b_smp + 255) & ~size_t(255);
     const size_t o_out = (o_noise + b_noise + 255) & ~size_t(255), o_st = o_out + D8 * XRHIP_IMU_DIM * (size_t)n_jobs;
-    const size_t bytes = o_st + sizeof(int) * n_jobs + 256;
+    const size_t bytes = o_st + 2 * sizeof(int) * n_jobs + 256;   // status words, then the early-delta words
     int rc = ensure_work2(c, 0, bytes);
     if (rc) return rc;
     char *H = c->h_stage;
@@ -1416,7 +1421,7 @@ static int preint_stage(xrhip_ba *c, const double *samples, const int *sample_be
     }
     std::memcpy(H + o_smp, samples, b_smp);
     std::memcpy(H + o_noise, noise_cov36, b_noise);
-    std::memset(H + o_st, 0, sizeof(int) * n_jobs);
+    std::memset(H + o_st, 0, 2 * sizeof(int) * n_jobs);
     c->preint_o_jobs = o_jobs;
     c->preint_o_smp = o_smp;
     c->preint_o_noise = o_noise;
@@ -1429,7 +1434,8 @@ static int preint_args(xrhip_ba *c, int n_jobs, int jac, int cov, const double *
     char *Dv = nullptr;
     XR_HIP(hipHostGetDevicePointer((void **)&Dv, c->h_stage, 0));
     *a = PreintArgs{(const PreintJob *)(Dv + c->preint_o_jobs), (const double *)(Dv + c->preint_o_smp), (const double *)(Dv + c->preint_o_noise),
-                    jac ? 1 : 0, cov ? 1 : 0, (double *)(Dv + c->preint_o_out), (int *)(Dv + c->preint_o_st), state_dev, n_jobs};
+                    jac ? 1 : 0, cov ? 1 : 0, (double *)(Dv + c->preint_o_out), (int *)(Dv + c->preint_o_st),
+                    (int *)(Dv + c->preint_o_st) + n_jobs, state_dev, n_jobs};
     return XRHIP_OK;
 }
 
@@ -1534,6 +1540,27 @@ int xrhip_ba_preintegrate_cancel(xrhip_ba *c) {
         c->preint_pending = 0;
     }
     c->preint_deferred = 0;
+    return XRHIP_OK;
+}
+
+int xrhip_ba_preintegrate_early(xrhip_ba *c, int job, double *out_delta11) {
+    if (!c || !out_delta11 || job < 0) return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_early: bad arguments");
+    if (!c->preint_pending || job >= c->preint_pending)
+        return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate_early: no such job in flight");
+    char *H = c->h_stage;
+    const int n_jobs = c->preint_pending;
+    volatile int *early = (volatile int *)(H + c->preint_o_st) + n_jobs;
+    if (c->preint_rq) {
+        const int rc = group_wait_launched(c->preint_rq);
+        if (rc) return rc;
+    }
+    for (unsigned long spin = 1; early[job] == 0; ++spin)
+        if ((spin & 0x3FFF) == 0) {
+            const hipError_t q = hipStreamQuery(c->preint_stream ? c->preint_stream : c->stream);
+            if (q == hipSuccess && early[job] == 0) return xr_fail(XRHIP_ESTATE, "xrhip_ba_preintegrate_early: kernel retired without publishing");
+            if (q != hipSuccess && q != hipErrorNotReady) return xr_fail(XRHIP_EHIP, "xrhip_ba_preintegrate_early: stream error");
+        }
+    std::memcpy(out_delta11, H + c->preint_o_out + sizeof(double) * XRHIP_IMU_DIM * (size_t)job, sizeof(double) * 11);
     return XRHIP_OK;
 }
 

@@ -55,9 +55,10 @@ int group_call(xrhip_group *g, int queue, void *owner, std::function<int(hipStre
 // ... and when everything submitted to `queue` before it has completed on the device
 int group_drain(xrhip_group *g, int queue, void *owner);
 hipStream_t group_stream(xrhip_group *g, int queue);
-void group_member_add(xrhip_group *g);
-void group_member_remove(xrhip_group *g);
-void group_count_entries(xrhip_group *g, int kind, int n);
+void group_member_add(xrhip_group *g, bool front_end);   // front_end: a KLT context, i.e. one more sequence in the group
+void group_member_remove(xrhip_group *g, bool front_end);
+// a member enters (+1) / leaves (-1) a stretch of work on its own stream (a window solve): the group does not wait for it
+void group_busy_elsewhere(xrhip_group *g, int delta);
 
 // Spin until *flag == seq (a kernel's last store into pinned memory).  The stream is polled now and then so that a faulted kernel
 // becomes an error instead of a hang -- once the request (if any) is known to be launched: a shared stream may be idle while the

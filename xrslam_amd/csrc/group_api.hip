@@ -42,6 +42,12 @@ struct xrhip_group {
     std::atomic<bool> quit{false};
     std::atomic<int> members{0};
     std::atomic<bool> profiling{false};
+    std::atomic<int> busy_elsewhere{0};   // members inside a window solve (their own stream): they will not submit for a while
+    std::atomic<int> sequences{0};        // front-end contexts joined == sequences in the group
+    int linger_us = 0;                    // hold a batch back this long for the members that have not submitted yet (XRHIP_GROUP_LINGER_US)
+    int linger_queues = 7;                // bit k: queue k lingers (XRHIP_GROUP_LINGER_QUEUES)
+    std::chrono::steady_clock::time_point first_seen[GQ_COUNT];
+    bool lingering[GQ_COUNT] = {false};
     std::thread th;
     // submission thread only
     bool inflight[GQ_COUNT] = {false};
@@ -65,16 +71,37 @@ struct xrhip_group {
     }
 
     // the head request and every later one of its kind whose owner has nothing older still waiting in this queue
-    void take(int k, std::vector<GroupRequest *> &batch) {
+    // -> false: requests are pending but held back (linger): the caller comes back
+    bool take(int k, std::vector<GroupRequest *> &batch) {
         batch.clear();
         std::lock_guard<std::mutex> lk(m);
         std::deque<GroupRequest *> &dq = q[k];
-        if (dq.empty()) return;
+        if (dq.empty()) {
+            lingering[k] = false;
+            return true;
+        }
         const int kind = dq.front()->kind;
+        if (linger_us > 0 && kind != GK_CALL && ((linger_queues >> k) & 1)) {
+            // Members run the same frame loop: when some have submitted this kind and the others are about to, a short wait turns
+            // several small launches into one -- and members that travelled in one batch come back together.  Never longer than
+            // linger_us past the first pending request, and not at all for members that are busy with a window solve.
+            int same = 0;
+            for (GroupRequest *r : dq) same += r->kind == kind ? 1 : 0;
+            const int expected = std::max(1, sequences.load(std::memory_order_relaxed) - busy_elsewhere.load(std::memory_order_relaxed));
+            if (same < expected) {
+                const auto now = std::chrono::steady_clock::now();
+                if (!lingering[k]) {
+                    lingering[k] = true;
+                    first_seen[k] = now;
+                }
+                if (now - first_seen[k] < std::chrono::microseconds(linger_us)) return false;
+            }
+            lingering[k] = false;
+        }
         if (kind == GK_CALL) {
             batch.push_back(dq.front());
             dq.pop_front();
-            return;
+            return true;
         }
         void *blocked[64];
         int nb = 0;
@@ -91,6 +118,7 @@ struct xrhip_group {
                 ++it;
             }
         }
+        return true;
     }
 
     void launch(int k, std::vector<GroupRequest *> &batch) {
@@ -143,7 +171,10 @@ struct xrhip_group {
                     inflight[k] = false;
                     finish_timing(k);
                 }
-                take(k, batch);
+                if (!take(k, batch)) {   // held back for a few microseconds: stay awake
+                    active = true;
+                    continue;
+                }
                 if (batch.empty()) continue;
                 launch(k, batch);
                 inflight[k] = true;
@@ -227,9 +258,17 @@ int group_drain(xrhip_group *g, int queue, void *owner) {
 }
 
 hipStream_t group_stream(xrhip_group *g, int queue) { return g->stream[queue]; }
-void group_member_add(xrhip_group *g) { g->members.fetch_add(1); }
-void group_member_remove(xrhip_group *g) { g->members.fetch_sub(1); }
-void group_count_entries(xrhip_group *, int, int) {}
+void group_member_add(xrhip_group *g, bool front_end) {
+    g->members.fetch_add(1);
+    if (front_end) g->sequences.fetch_add(1);
+}
+void group_member_remove(xrhip_group *g, bool front_end) {
+    g->members.fetch_sub(1);
+    if (front_end) g->sequences.fetch_sub(1);
+}
+void group_busy_elsewhere(xrhip_group *g, int delta) {
+    if (g) g->busy_elsewhere.fetch_add(delta, std::memory_order_relaxed);
+}
 
 int wait_flag(volatile int *flag, int seq, hipStream_t s, GroupRequest *req, const char *what) {
     if (req) {
@@ -265,7 +304,19 @@ int xrhip_group_create(xrhip_group **out) {
     xrhip_group *g = new xrhip_group();
     std::memset(&g->stats, 0, sizeof(g->stats));
     hipGetDevice(&g->device);
-    for (int k = 0; k < GQ_COUNT; ++k) XR_HIP(hipStreamCreateWithFlags(&g->stream[k], hipStreamNonBlocking));
+    if (const char *e = std::getenv("XRHIP_GROUP_LINGER_US")) g->linger_us = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("XRHIP_GROUP_LINGER_QUEUES")) g->linger_queues = std::atoi(e);
+    // The group's streams carry every member's per-frame critical path; the members' own streams carry window solves and
+    // marginalisations (long, one frame in five).  The runtime multiplexes a process's streams over a few hardware queues PER
+    // PRIORITY LEVEL, in order within a queue: at the default priority a batch would queue behind whichever member's 100 us
+    // factorisation shares its hardware queue.  Highest priority gives the three group streams hardware queues of their own.
+    int prio_low = 0, prio_high = 0;
+    const bool use_prio = std::getenv("XRHIP_GROUP_NO_PRIORITY") == nullptr &&
+                          hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) == hipSuccess && prio_high != prio_low;
+    for (int k = 0; k < GQ_COUNT; ++k) {
+        if (use_prio) XR_HIP(hipStreamCreateWithPriority(&g->stream[k], hipStreamNonBlocking, prio_high));
+        else XR_HIP(hipStreamCreateWithFlags(&g->stream[k], hipStreamNonBlocking));
+    }
     g->th = std::thread([g] { g->run(); });
     *out = g;
     return XRHIP_OK;

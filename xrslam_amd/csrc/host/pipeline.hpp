@@ -352,6 +352,12 @@ struct Pipeline {
         for (xrhip_ba *c : {ba, ba_aux, ba_ft})
             if (c) xrhip_ba_preintegrate_cancel(c);
     }
+    // the delta (dt, dq, dp, dv) of job 0 of the batch in flight on `ba`, as soon as the kernel has it (the batch stays in flight)
+    void integrate_early(PreInt &pre) {
+        WallTimer wt_w_preintegrate(times.w_preintegrate);
+        hip_check(xrhip_ba_preintegrate_early(ba, 0, pre.rec), "xrhip_ba_preintegrate_early");
+        pre.valid = true;
+    }
     void integrate_end(PreInt &pre, xrhip_ba *ctx = nullptr) {
         WallTimer wt_w_preintegrate(preintegrate_slot(ctx));
         hip_check(xrhip_ba_preintegrate_end(ctx ? ctx : ba, pre.rec), "xrhip_ba_preintegrate_end");
@@ -1062,12 +1068,19 @@ class SlidingWindowTracker {
 
     // Early start of mirror_frame's pre-integration for a frame that is about to be tracked (not yet in ft_map): the
     // samples between the last window frame and `incoming`, at the biases of the last window frame.
-    void mirror_prepare(Map *ft_map, Frame *incoming) {
+    // -> true when `tracker_from` is given and the integration queued here IS the feature tracker's own of the incoming frame's
+    // interval (FeatureTracker::work integrates it without Jacobians from tracker_from's biases, feature_tracker.cpp:75-77): no frame
+    // skipped in between, the same biases bit for bit.  The tracker then reads the delta out of this launch
+    // (Pipeline::integrate_early) instead of integrating the interval a second time.
+    bool mirror_prepare(Map *ft_map, Frame *incoming, const Frame *tracker_from = nullptr) {
         cancel_prepared();
         Frame *keyframe = map->get_frame(map->frame_num() - 1);
         Frame *new_i = keyframe->subframes.empty() ? keyframe : keyframe->subframes.back().get();
         const size_t idx_i = ft_map->frame_index_by_id(new_i->id);
-        if (idx_i == nil()) return;
+        if (idx_i == nil()) return false;
+        if (tracker_from && !(idx_i + 1 == ft_map->frame_num() && tracker_from->id == new_i->id && same3(tracker_from->motion.bg, new_i->motion.bg) &&
+                              same3(tracker_from->motion.ba, new_i->motion.ba)))
+            return false;   // not the same integration: nothing queued, the caller goes the two-launch way
         std::vector<ImuData> nd = incoming->preintegration.data;
         for (size_t index = ft_map->frame_num() - 1; index > idx_i; --index) {
             const std::vector<ImuData> &od = ft_map->get_frame(index)->preintegration.data;
@@ -1077,6 +1090,7 @@ class SlidingWindowTracker {
         prepared_id_ = incoming->id;
         prepared_from_ = new_i->id;
         prepared_samples_ = nd.size();
+        return prepared_ && tracker_from != nullptr;
     }
     void cancel_prepared() {   // a queued integration nobody will collect must still be drained
         if (prepared_id_ != nil() && prepared_) {
@@ -2723,7 +2737,22 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
                     ft_latest_state.reset();   // "SWT cannot catch up."
                 }
             }
-            if (!integrated &&
+            // Inline mode: the backend will pre-integrate the same interval with Jacobians and covariance when it mirrors this frame
+            // (mirror_frame: same samples, the biases of the window's newest frame -- which are `last`'s, just published).  That
+            // integration is queued FIRST and the tracker takes its delta out of it as soon as the kernel has it: one launch and
+            // one wait per frame instead of two of each (round 4; XRSLAM_AMD_NO_SHARED_INTEGRATION=1: the two-launch form).  The
+            // rest of the record is collected by mirror_frame: it runs beside the LK kernel and the RANSAC gates.
+            static const bool no_share = std::getenv("XRSLAM_AMD_NO_SHARED_INTEGRATION") != nullptr;   // development switch (A/B, parity)
+            const bool backend_mirrors = swt && swt_tag && is_initialized && !pipelined();
+            bool shared = false;
+            if (!integrated && backend_mirrors && !no_share && !frame->preintegration.data.empty()) {
+                shared = swt->mirror_prepare(map, frame.get(), last);
+                if (shared) {
+                    preprocess();
+                    P.integrate_early(frame->preintegration);
+                }
+            }
+            if (!integrated && !shared &&
                 P.integrate_begin(frame->preintegration.data, frame->image->t, last->motion.bg, last->motion.ba, false, false,
                                   ft_ctx)) {
                 preprocess();
@@ -2731,10 +2760,9 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
             }
             preprocess();
             if (swt_tag) hip_check(xrhip_image_prefetch_detect(frame->image->h), "xrhip_image_prefetch_detect");
-            // the backend will pre-integrate the same interval with Jacobians and covariance when it mirrors this frame:
-            // queued now, it runs beside the LK kernel and the RANSAC gates instead of in front of localize_newframe
-            // (inline mode only: in pipelined mode the window map belongs to the backend thread until the hand-off)
-            if (swt && swt_tag && is_initialized && !pipelined()) swt->mirror_prepare(map, frame.get());
+            // (otherwise the backend's integration is queued now: inline mode only -- in pipelined mode the window map belongs to
+            // the backend thread until the hand-off)
+            if (backend_mirrors && !shared) swt->mirror_prepare(map, frame.get());
             // pipelined mode: the backend may still be writing changed trash tags into this map's tracks (its half of
             // mirror_frame); nothing above looks at tracks, everything from here on does.  The wait also orders the track-id
             // counter the two maps share (P.ids): mirror_frame's new window-map tracks take their ids before this frame's new

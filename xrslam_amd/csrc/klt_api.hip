@@ -367,14 +367,14 @@ int xrhip_klt_join_group(xrhip_klt *c, xrhip_group *g) {
     if (c->group) {
         int rc = group_drain(c->group, GQ_KLT, c);
         if (rc) return rc;
-        group_member_remove(c->group);
+        group_member_remove(c->group, true);
     } else {
         XR_HIP(hipStreamSynchronize(c->stream));
     }
     c->group = g;
     c->uploads_unsynced = 0;
     for (int i = 0; i < xrhip_klt::UP_SLOTS; ++i) c->up_busy[i] = false;
-    if (g) group_member_add(g);
+    if (g) group_member_add(g, true);
     return XRHIP_OK;
 }
 

@@ -457,6 +457,7 @@ struct PreintArgs {
     int want_jac, want_cov;
     double *out;
     int *status;
+    int *early;   // per job: 1 once the delta part of its record (doubles 0..10) is in `out` (the full record follows; `status` says when)
     const double *state_dev;
     int n_jobs;
 };
@@ -596,6 +597,18 @@ __global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
             sp3[0] = pv.x; sp3[1] = pv.y; sp3[2] = pv.z;
             sv3[0] = vv.x; sv3[1] = vv.y; sv3[2] = vv.z;
             sdt = T;
+            // The delta (dt, dq, dp, dv) is final with the last chunk's chains -- the covariance recursion, the bias Jacobians and the
+            // 15x15 factorisation below do not touch it.  It is published now, with a mailbox of its own: the feature tracker reads the
+            // delta of the interval the backend's integration covers (same samples, same biases) as soon as it exists, instead of
+            // integrating the interval a second time without Jacobians (xrhip_ba_preintegrate_early).  Same values as at the end.
+            if (n0 + PI_CHUNK >= job.sample_count) {
+                o[0] = T;
+                o[1] = sq[0]; o[2] = sq[1]; o[3] = sq[2]; o[4] = sq[3];
+                o[5] = pv.x; o[6] = pv.y; o[7] = pv.z;
+                o[8] = vv.x; o[9] = vv.y; o[10] = vv.z;
+                __threadfence_system();
+                *reinterpret_cast<volatile int *>(ea.early + blockIdx.x) = 1;
+            }
         }
         // ---- P5 (all lane -> matrix-entry mappings are loop invariants, computed before the sample loop)
         if (want_cov || want_jac) {
