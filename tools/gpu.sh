@@ -10,6 +10,7 @@
 #   ab:VARIANT              default library vs lib/libxrslam_hip_VARIANT.so, alternating (S1 line and S4 replay)
 #   abenv:VAR [reps]        the default bench line with VAR unset / =1, interleaved
 #   hostprof                XRHIP_HOSTPROF scope accumulators of the S1 stream             kprint[:PATTERN]   in-kernel printf timers (kprint variant)
+#   multiq[:Q ...]          tools/multiq.hip: small dependent kernels from 1..16 host threads, per GPU_MAX_HW_QUEUES
 #   peaks                   tools/peaks.hip micro-benchmarks            clocks / host      rocm-smi clock / power state; CPU cores
 set -uo pipefail
 R="$(cd "$(dirname "$0")/.." && pwd)"
@@ -75,6 +76,15 @@ import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); p
             done; done; unset "$VAR" ;;
     hostprof) XRHIP_HOSTPROF=1 timeout 300 python bench.py --steps 150 --warmup 50 --cpu-frames 0 --variant-frames 0 --threading inline > "$O/hostprof_$TAG.json" 2> "$O/hostprof_$TAG.txt"; grep hostprof "$O/hostprof_$TAG.txt" | cut -c1-130 | tail -40 ;;
     kprint) XRSLAM_HIP_LIB="$R/xrslam_amd/lib/libxrslam_hip_kprint.so" timeout 200 python bench.py --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --threading inline 2>/dev/null | grep -v '^{' > "$O/blocks_$TAG.txt"; grep "${arg:-kb_}" "$O/blocks_$TAG.txt" | tail -12 ;;
+    multiq) for Q in ${arg:-4 8}; do echo "GPU_MAX_HW_QUEUES=$Q"; GPU_MAX_HW_QUEUES=$Q timeout 300 "$R/xrslam_amd/bin/xr-multiq" 1500 > "$O/multiq_${TAG}_q$Q.jsonl" 2> "$O/multiq_${TAG}_q$Q.err"; python - "$O/multiq_${TAG}_q$Q.jsonl" <<'PY'
+import json, sys
+rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
+for m in sorted({r["mode"] for r in rows}):
+    for c in sorted({r["chain"] for r in rows}):
+        rr = [r for r in rows if r["mode"] == m and r["chain"] == c]
+        print("mode %d chain %d: " % (m, c) + "  ".join("T%d %.1fus %.0fk/s" % (r["threads"], r["round_us"], r["kernels_per_s_all"] / 1e3) for r in rr))
+PY
+            done ;;
     peaks)  "$R/xrslam_amd/bin/xr-peaks" > "$O/peaks_$TAG.json" 2> "$O/peaks_$TAG.err"; cat "$O/peaks_$TAG.json" ;;
     host)   echo "nproc $(nproc)  affinity $(python -c 'import os; print(len(os.sched_getaffinity(0)))')"; lscpu | grep -E "Model name|Socket|Thread|Core" | head -5 ;;
     clocks) rocm-smi --showclocks --showpower --showmaxpower --showperflevel > "$O/clocks_$TAG.txt" 2>&1; grep -i "clock level\|power\|level" "$O/clocks_$TAG.txt" | head -12 ;;

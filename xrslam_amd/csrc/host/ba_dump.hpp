@@ -7,6 +7,7 @@
 #pragma once
 #include <mutex>
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -118,6 +119,67 @@ struct OutLogger {
             std::fwrite(&tag, 1, 1, log.fp);
             std::fwrite(&n, sizeof n, 1, log.fp);
             if (n) std::fwrite(log.buf.data(), 1, n, log.fp);
+            std::fflush(log.fp);
+        }
+    };
+};
+
+// Decision log of the initialiser and of the RD-VIO filters (test aid): XRSLAM_AMD_DUMP_INIT=<file> appends one JSON line per
+// decision with everything the decision looked at (%.17g) -- the key frames Initializer::mirror_keyframe_map picked, the two-view
+// matches / model matrices / eight (R, T) hypotheses / triangulation vote of init_sfm, the per-interval quantities of the three
+// alignment solves of init_imu with their answers, the scale gates, apply_init's rotation; and for parsac.parsac_flag the inputs and
+// verdicts of judge_track_status and of every PARSAC run.  tests/init_model.py and tests/parsac_model.py re-derive every answer from
+// the inputs in numpy, written from core/initializer.cpp:22-571, utility/parsac.h and utility/imu_parsac.h (rows f3 / f4).
+struct InitLogger {
+    FILE *fp = nullptr;
+    std::mutex mu;
+    InitLogger() {
+        if (const char *p = std::getenv("XRSLAM_AMD_DUMP_INIT")) fp = std::fopen(p, "w");
+    }
+    ~InitLogger() {
+        if (fp) std::fclose(fp);
+    }
+    InitLogger(const InitLogger &) = delete;
+    InitLogger &operator=(const InitLogger &) = delete;
+    bool enabled() const { return fp != nullptr; }
+    // a record under construction: key / value pairs appended as JSON, written as one line when it goes out of scope
+    struct Line {
+        InitLogger &log;
+        std::unique_lock<std::mutex> lk;
+        std::string s;
+        Line(InitLogger &l, const char *what) : log(l), lk(l.mu) {
+            s = "{\"what\": \"";
+            s += what;
+            s += "\"";
+        }
+        void key(const char *k) {
+            s += ", \"";
+            s += k;
+            s += "\": ";
+        }
+        void num(double v) {
+            char b[40];
+            if (std::isfinite(v)) std::snprintf(b, sizeof b, "%.17g", v);
+            else std::snprintf(b, sizeof b, "null");
+            s += b;
+        }
+        void put(const char *k, double v) {
+            key(k);
+            num(v);
+        }
+        void put(const char *k, const double *v, size_t n) {
+            key(k);
+            s += "[";
+            for (size_t i = 0; i < n; ++i) {
+                if (i) s += ", ";
+                num(v[i]);
+            }
+            s += "]";
+        }
+        void put(const char *k, const std::vector<double> &v) { put(k, v.data(), v.size()); }
+        ~Line() {
+            s += "}\n";
+            std::fwrite(s.data(), 1, s.size(), log.fp);
             std::fflush(log.fp);
         }
     };

@@ -207,6 +207,7 @@ struct Pipeline {
     SwtLogger swt_log;                 // XRSLAM_AMD_DUMP_SWT=<file>: decisions of the sliding-window tracker (ba_dump.hpp)
     SyncLogger sync_log;               // XRSLAM_AMD_DUMP_SYNC=<file>: IMU samples attached to every frame, poses answered (ba_dump.hpp)
     BaDumper ba_dump;                  // XRSLAM_AMD_DUMP_BA=<dir>: freeze the problems handed to xrhip_ba_solve (ba_dump.hpp)
+    InitLogger init_log;               // XRSLAM_AMD_DUMP_INIT=<file>: decisions of the initialiser and of the RD-VIO filters with their inputs (ba_dump.hpp)
     OutLogger out_log;                 // XRSLAM_AMD_DUMP_OUT=<file>: what every frame produces -- key points, track ids, states, landmarks (ba_dump.hpp)
 
     explicit Pipeline(const Config &c) : config(c) {
@@ -2019,6 +2020,35 @@ class Initializer {
                 nj->preintegration.data.insert(nj->preintegration.data.end(), od.begin(), od.end());
             }
         }
+        if (P_.init_log.enabled()) {   // what the pick looked at (the tracking map's frames) and what it made of it
+            InitLogger::Line ln(P_.init_log, "keyframes");
+            ln.put("init_frame_id", (double)init_frame_id);
+            ln.put("keyframe_num", (double)c.initializer_keyframe_num);
+            ln.put("keyframe_gap", (double)c.initializer_keyframe_gap);
+            std::vector<double> ids, ns, t0, t1, pid, pns, pt0, pt1, links;
+            for (size_t i = 0; i < ft_map->frame_num(); ++i) {
+                const Frame *f = ft_map->get_frame(i);
+                ids.push_back((double)f->id);
+                ns.push_back((double)f->preintegration.data.size());
+                t0.push_back(f->preintegration.data.empty() ? -1.0 : f->preintegration.data.front().t);
+                t1.push_back(f->preintegration.data.empty() ? -1.0 : f->preintegration.data.back().t);
+            }
+            for (size_t j = 0; j < map->frame_num(); ++j) {
+                const Frame *f = map->get_frame(j);
+                pid.push_back((double)f->id);
+                pns.push_back((double)f->preintegration.data.size());
+                pt0.push_back(f->preintegration.data.empty() ? -1.0 : f->preintegration.data.front().t);
+                pt1.push_back(f->preintegration.data.empty() ? -1.0 : f->preintegration.data.back().t);
+                size_t nl = 0;
+                if (j + 1 < map->frame_num())
+                    for (size_t k = 0; k < f->keypoint_num(); ++k)
+                        if (Track *t = f->get_track(k)) nl += t->has_keypoint(map->get_frame(j + 1)) ? 1 : 0;
+                links.push_back((double)nl);
+            }
+            ln.put("ft_ids", ids); ln.put("ft_samples", ns); ln.put("ft_t0", t0); ln.put("ft_t1", t1);
+            ln.put("picked", pid); ln.put("picked_samples", pns); ln.put("picked_t0", pt0); ln.put("picked_t1", pt1);
+            ln.put("links_to_next", links);
+        }
     }
 
     const InitialState *lookup(double t) const {
@@ -2204,6 +2234,36 @@ class Initializer {
         }
         sfm_candidate = (int)best;
         sfm_triangulated = counts[best];
+        if (P_.init_log.enabled()) {   // the two-view stage: matches, models, the eight hypotheses, the vote
+            InitLogger::Line ln(P_.init_log, "sfm_vote");
+            std::vector<double> a, b2, rs, ts, cn, sc, pb, sb;
+            for (size_t k = 0; k < n; ++k) {
+                a.push_back(pi[k].x); a.push_back(pi[k].y);
+                b2.push_back(pj[k].x); b2.push_back(pj[k].y);
+            }
+            for (size_t h = 0; h < Rs.size(); ++h) {
+                rs.insert(rs.end(), Rs[h].m, Rs[h].m + 9);
+                for (int r = 0; r < 3; ++r) ts.push_back(Ts[h][r]);
+                cn.push_back((double)counts[h]);
+                sc.push_back(scores[h]);
+            }
+            for (size_t k = 0; k < n; ++k) {
+                sb.push_back(status[best][k] ? 1.0 : 0.0);
+                for (int r = 0; r < 3; ++r) pb.push_back(status[best][k] ? pts[best][k][r] : 0.0);
+            }
+            ln.put("pi", a); ln.put("pj", b2);
+            ln.put("parallax", parallax);
+            ln.put("fx", fi->K.fx);
+            ln.put("min_matches", (double)c.initializer_min_matches);
+            ln.put("min_parallax", c.initializer_min_parallax);
+            ln.put("min_triangulation", (double)c.initializer_min_triangulation);
+            ln.put("H", H.m, 9); ln.put("E", E.m, 9);
+            const double nn[6] = {nH1.x, nH1.y, nH1.z, nH2.x, nH2.y, nH2.z};
+            ln.put("nH", nn, 6);
+            ln.put("Rs", rs); ln.put("Ts", ts); ln.put("counts", cn); ln.put("scores", sc);
+            ln.put("best", (double)best);
+            ln.put("points_best", pb); ln.put("status_best", sb);
+        }
         if (std::getenv("XRSLAM_AMD_DEBUG_INIT")) {   // development aid: the vote over the eight (R, T) hypotheses
             std::fprintf(stderr, "[init] %d matches, parallax %.1f px; (count, sum of errors) per hypothesis:", common, parallax);
             for (size_t h = 0; h < Rs.size(); ++h) std::fprintf(stderr, " %zu:(%zu, %.3g)", h, counts[h], scores[h]);
@@ -2264,8 +2324,21 @@ class Initializer {
 
     // -------------------------------------------------------------------- IMU alignment (:386-571)
     bool init_imu() {
+        const bool ok = init_imu_steps();
+        if (P_.init_log.enabled()) {
+            InitLogger::Line ln(P_.init_log, "imu_result");
+            ln.put("ok", ok ? 1.0 : 0.0);
+            ln.put("scale", scale);
+            ln.put("refine_imu", P_.config.initializer_refine_imu ? 1.0 : 0.0);
+            ln.put("min_landmarks", (double)P_.config.initializer_min_landmarks);
+            ln.put("final_points", (double)final_points_);
+        }
+        return ok;
+    }
+    bool init_imu_steps() {
         bg = ba = gravity = V3{0, 0, 0};
         scale = 1;
+        final_points_ = 0;
         velocities.assign(map->frame_num(), V3{0, 0, 0});
         solve_gyro_bias();
         solve_gravity_scale_velocity();
@@ -2275,6 +2348,7 @@ class Initializer {
         if (scale < 0.001 || scale > 1.0) return false;
         return apply_init();
     }
+    size_t final_points_ = 0;
 
     void preintegrate() {
         std::vector<Pipeline::IntegrateJob> jobs;
@@ -2300,6 +2374,22 @@ class Initializer {
             rhs = rhs + Jt * logmap((pi.q * fj->preintegration.dq()).conjugate() * pj.q);
         }
         bg = svd_solve3(A, rhs);
+        if (P_.init_log.enabled()) {   // per interval: IMU poses of its two frames, dq, dq_dbg (integrated at zero biases) -> the bias
+            InitLogger::Line ln(P_.init_log, "gyro_bias");
+            std::vector<double> qi, qj, dq, jac;
+            for (size_t j = 1; j < map->frame_num(); ++j) {
+                const Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
+                const PoseState pi = fi->get_pose(fi->imu), pj = fj->get_pose(fj->imu);
+                const Quat d = fj->preintegration.dq();
+                for (double v : {pi.q.x, pi.q.y, pi.q.z, pi.q.w}) qi.push_back(v);
+                for (double v : {pj.q.x, pj.q.y, pj.q.z, pj.q.w}) qj.push_back(v);
+                for (double v : {d.x, d.y, d.z, d.w}) dq.push_back(v);
+                for (int k = 0; k < 9; ++k) jac.push_back(fj->preintegration.rec[11 + k]);
+            }
+            ln.put("q_i", qi); ln.put("q_j", qj); ln.put("dq", dq); ln.put("dq_dbg", jac);
+            const double out[3] = {bg.x, bg.y, bg.z};
+            ln.put("bg", out, 3);
+        }
     }
 
     // rows per interval (i, j = i+1), unknowns [g | s | v_0 .. v_{N-1}] (or [dg(2) | s | v] with the gravity
@@ -2354,6 +2444,36 @@ class Initializer {
         gravity = normalized(V3{x[0], x[1], x[2]}) * kGravityNominal;
         scale = x[3];
         for (size_t i = 0; i < map->frame_num(); ++i) velocities[i] = V3{x[4 + 3 * i], x[5 + 3 * i], x[6 + 3 * i]};
+        log_alignment("gravity_scale_velocity", V3{0, 0, 0});
+    }
+    // XRSLAM_AMD_DUMP_INIT: what an alignment solve looked at, per interval -- dt, dp, dv (integrated at the gyroscope bias found
+    // before), the camera positions and body rotations of its two frames, the camera lever arm -- and what it answered
+    void log_alignment(const char *what, V3 gravity_before) {
+        if (!P_.init_log.enabled()) return;
+        InitLogger::Line ln(P_.init_log, what);
+        std::vector<double> dt, dp, dv, ci, cj, qi, qj, vel;
+        for (size_t j = 1; j < map->frame_num(); ++j) {
+            const Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
+            const PreInt &d = fj->preintegration;
+            const PoseState a = fi->get_pose(fi->camera), b = fj->get_pose(fj->camera);
+            dt.push_back(d.dt());
+            for (int r = 0; r < 3; ++r) {
+                dp.push_back(d.dp()[r]);
+                dv.push_back(d.dv()[r]);
+                ci.push_back(a.p[r]);
+                cj.push_back(b.p[r]);
+            }
+            for (double v : {fi->pose.q.x, fi->pose.q.y, fi->pose.q.z, fi->pose.q.w}) qi.push_back(v);
+            for (double v : {fj->pose.q.x, fj->pose.q.y, fj->pose.q.z, fj->pose.q.w}) qj.push_back(v);
+        }
+        for (const V3 &v : velocities)
+            for (int r = 0; r < 3; ++r) vel.push_back(v[r]);
+        const Frame *f0 = map->get_frame(0);
+        const double pcs[3] = {f0->camera.p_cs.x, f0->camera.p_cs.y, f0->camera.p_cs.z};
+        const double gb[3] = {gravity_before.x, gravity_before.y, gravity_before.z}, ga[3] = {gravity.x, gravity.y, gravity.z};
+        ln.put("dt", dt); ln.put("dp", dp); ln.put("dv", dv); ln.put("cam_p_i", ci); ln.put("cam_p_j", cj);
+        ln.put("body_q_i", qi); ln.put("body_q_j", qj); ln.put("p_cs", pcs, 3);
+        ln.put("gravity_before", gb, 3); ln.put("gravity", ga, 3); ln.put("scale", scale); ln.put("velocities", vel);
     }
 
     void refine_scale_velocity_via_gravity() {   // one damped step of the gravity direction on the sphere |g| = 9.80665
@@ -2365,24 +2485,41 @@ class Initializer {
         std::vector<double> x = lstsq_qr(A, rhs);
         V3 t1, t2;
         s2_tangential_basis(gravity, t1, t2);
+        const V3 gravity_before = gravity;
         gravity = normalized(gravity + (t1 * x[0] + t2 * x[1]) * damp) * kGravityNominal;
         scale = x[2];
         for (size_t i = 0; i < map->frame_num(); ++i) velocities[i] = V3{x[3 + 3 * i], x[4 + 3 * i], x[5 + 3 * i]};
+        log_alignment("refine_via_gravity", gravity_before);
     }
 
     bool apply_init() {   // rotate gravity onto -z, apply the metric scale, set velocities and the gyroscope bias
         Quat q = quat_from_two_vectors(gravity, V3{0, 0, -kGravityNominal});
+        std::vector<double> before, after, vel;
         for (size_t i = 0; i < map->frame_num(); ++i) {
             Frame *f = map->get_frame(i);
             PoseState ip = f->get_pose(f->imu);
+            for (double v : {ip.q.x, ip.q.y, ip.q.z, ip.q.w, ip.p.x, ip.p.y, ip.p.z}) before.push_back(v);
             ip.q = q * ip.q;
             ip.p = (q * ip.p) * scale;
             f->set_pose(f->imu, ip);
             f->motion.v = q * velocities[i];
             f->motion.bg = bg;
             f->motion.ba = ba;
+            const PoseState np = f->get_pose(f->imu);
+            for (double v : {np.q.x, np.q.y, np.q.z, np.q.w, np.p.x, np.p.y, np.p.z}) after.push_back(v);
+            for (int r = 0; r < 3; ++r) vel.push_back(f->motion.v[r]);
         }
-        return retriangulate() >= P_.config.initializer_min_landmarks;
+        final_points_ = retriangulate();
+        if (P_.init_log.enabled()) {
+            InitLogger::Line ln(P_.init_log, "apply_init");
+            const double g[3] = {gravity.x, gravity.y, gravity.z};
+            std::vector<double> vin;
+            for (const V3 &v : velocities)
+                for (int r = 0; r < 3; ++r) vin.push_back(v[r]);
+            ln.put("gravity", g, 3); ln.put("scale", scale); ln.put("velocities", vin);
+            ln.put("imu_pose_before", before); ln.put("imu_pose_after", after); ln.put("v_after", vel);
+        }
+        return final_points_ >= P_.config.initializer_min_landmarks;
     }
 
   public:
