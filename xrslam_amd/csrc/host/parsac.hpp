@@ -21,9 +21,17 @@
 #include <cfloat>
 #include <cstdlib>
 
+#include "ba_dump.hpp"
 #include "epnp.hpp"
 
 namespace xrh {
+
+// XRSLAM_AMD_DUMP_INIT (ba_dump.hpp): while set, every PARSAC run appends what it looked at and what it decided -- the tracker points
+// this at its pipeline's logger around judge_track_status / update_track_status (tests/parsac_model.py re-derives the decisions)
+inline InitLogger *&parsac_trace() {
+    static thread_local InitLogger *t = nullptr;
+    return t;
+}
 
 struct ParsacState {
     std::vector<float> essential_bins = std::vector<float>(400, 0.5f);
@@ -184,7 +192,13 @@ bool solve(const std::vector<S1> &d1, const std::vector<S2> &d2, const std::vect
     std::vector<float> conf;
     size_t iter_max = max_iteration;
     float score_max = prior_mask ? -FLT_MAX : 0.f;
+    // the run's record (only with the decision log on): inputs now, one entry per scored hypothesis, the outcome at the end
+    InitLogger *trace = parsac_trace() && parsac_trace()->enabled() ? parsac_trace() : nullptr;
+    const std::vector<float> bins_before = bin_conf;
+    std::vector<double> t_iter, t_counted, t_score, t_best, t_itermax, t_masks, t_samples;
+    size_t iterations_run = 0;
     for (size_t iter = 0; iter < iter_max; ++iter) {
+        iterations_run = iter + 1;
         std::array<S1, DoF> s1;
         std::array<S2, DoF> s2;
         lotbox.refill_all();
@@ -193,6 +207,7 @@ bool solve(const std::vector<S1> &d1, const std::vector<S2> &d2, const std::vect
             const size_t idx = grid.nvalid > 20 ? sampler.draw_by_weight() : lotbox.draw_without_replacement();
             s1[si] = d1[idx];
             s2[si] = d2[idx];
+            if (trace) t_samples.push_back((double)idx);
         }
         for (const Model &cur : solver(s1, s2)) {
             size_t cur_count = 0;
@@ -212,7 +227,15 @@ bool solve(const std::vector<S1> &d1, const std::vector<S2> &d2, const std::vect
             }
             const std::vector<size_t> bins = grid.inliers_per_bin(cur_mask);
             const float score = grid.score(bins, conf, prior_mask ? dynamic_probability : -1.0);
-            if (score > score_max || (score == score_max && counted > inlier_count)) {
+            const bool takes_over = score > score_max || (score == score_max && counted > inlier_count);
+            if (trace) {
+                t_iter.push_back((double)iter);
+                t_counted.push_back((double)counted);
+                t_score.push_back((double)score);
+                t_best.push_back(takes_over ? 1.0 : 0.0);
+                for (char m : cur_mask) t_masks.push_back((double)m);
+            }
+            if (takes_over) {
                 score_max = score;
                 model = cur;
                 inlier_count = counted;
@@ -222,13 +245,39 @@ bool solve(const std::vector<S1> &d1, const std::vector<S2> &d2, const std::vect
                 const double N = K / std::log(1 - std::pow(ratio, 5));
                 if (N < (double)iter_max) iter_max = (size_t)std::ceil(N);
             }
+            if (trace) t_itermax.push_back((double)iter_max);
         }
     }
-    if (prior_mask && inlier_count < DoF) return false;
-    if (best_bins.size() != grid.nvalid) best_bins.assign(grid.nvalid, 0);   // no hypothesis scored: all-zero confidences
-    grid.score(best_bins, conf, prior_mask ? dynamic_probability : -1.0);
-    grid.write_back(conf, bin_conf);
-    return true;
+    const bool gave_up = prior_mask && inlier_count < DoF;
+    if (!gave_up) {
+        if (best_bins.size() != grid.nvalid) best_bins.assign(grid.nvalid, 0);   // no hypothesis scored: all-zero confidences
+        grid.score(best_bins, conf, prior_mask ? dynamic_probability : -1.0);
+        grid.write_back(conf, bin_conf);
+    }
+    if (trace) {
+        InitLogger::Line ln(*trace, "parsac_run");
+        std::vector<double> gp, ln_len, pm, bb(bins_before.begin(), bins_before.end()), ba(bin_conf.begin(), bin_conf.end()),
+            ac(acc.begin(), acc.end()), fm;
+        for (const V2 &p : grid_pts) {
+            gp.push_back(p.x);
+            gp.push_back(p.y);
+        }
+        if (lens)
+            for (size_t v : *lens) ln_len.push_back((double)v);
+        if (prior_mask)
+            for (char m : *prior_mask) pm.push_back((double)m);
+        for (char m : inlier_mask) fm.push_back((double)m);
+        ln.put("dof", (double)DoF); ln.put("imu", prior_mask ? 1.0 : 0.0); ln.put("size", (double)size);
+        ln.put("threshold", threshold); ln.put("confidence", confidence); ln.put("max_iteration", (double)max_iteration);
+        ln.put("dynamic_probability", dynamic_probability); ln.put("norm_scale", norm_scale);
+        ln.put("grid_pts", gp); ln.put("lens", ln_len); ln.put("prior_mask", pm);
+        ln.put("bins_before", bb); ln.put("accumulated_prior", ac); ln.put("nvalid", (double)grid.nvalid);
+        ln.put("samples", t_samples); ln.put("cand_iter", t_iter); ln.put("cand_counted", t_counted); ln.put("cand_score", t_score);
+        ln.put("cand_takes_over", t_best); ln.put("cand_iter_max_after", t_itermax); ln.put("cand_masks", t_masks);
+        ln.put("iterations_run", (double)iterations_run); ln.put("gave_up", gave_up ? 1.0 : 0.0);
+        ln.put("inlier_count", (double)inlier_count); ln.put("final_mask", fm); ln.put("bins_after", ba);
+    }
+    return !gave_up;
 }
 
 }   // namespace parsac_detail

@@ -1323,6 +1323,10 @@ class SlidingWindowTracker {
                 if (overlap->error) std::rethrow_exception(overlap->error);
                 overlap = nullptr;
             }
+            struct Trace {   // XRSLAM_AMD_DUMP_INIT: the PARSAC runs of this frame go into the pipeline's decision log
+                explicit Trace(InitLogger *l) { parsac_trace() = l; }
+                ~Trace() { parsac_trace() = nullptr; }
+            } trace(P_.init_log.enabled() ? &P_.init_log : nullptr);
             if (judge_track_status()) update_track_status();
         }
         localize_newframe(overlap);
@@ -1484,11 +1488,25 @@ class SlidingWindowTracker {
             const double err = epipolar_dist(F, p1, p2) + epipolar_dist(Ft, p2, p1);
             (mask[index[i]] ? d_in : d_out).push_back(err);
         }
-        if (d_in.size() < 20 || d_out.size() < 20) return false;
-        std::sort(d_in.begin(), d_in.end());
-        std::sort(d_out.begin(), d_out.end());
-        const double th1 = d_in[size_t(d_in.size() * 0.5)], th2 = d_out[size_t(d_out.size() * 0.5)];
-        if (th2 < th1 * 2) return false;   // the two groups are not separated: ambiguous
+        bool separated = false;
+        double th1 = 0, th2 = 0;
+        if (d_in.size() >= 20 && d_out.size() >= 20) {
+            std::sort(d_in.begin(), d_in.end());
+            std::sort(d_out.begin(), d_out.end());
+            th1 = d_in[size_t(d_in.size() * 0.5)];
+            th2 = d_out[size_t(d_out.size() * 0.5)];
+            separated = !(th2 < th1 * 2);   // otherwise the two groups are not separated: ambiguous
+        }
+        if (P_.init_log.enabled()) {   // what the verdict looked at: the epipolar distances of the PnP consensus' inliers / outliers
+            InitLogger::Line ln(P_.init_log, "judge_track_status");
+            ln.put("frame", (double)curr->id);
+            ln.put("d_in", d_in); ln.put("d_out", d_out);
+            ln.put("separated", separated ? 1.0 : 0.0);
+            ln.put("threshold", separated ? (th1 + th2) / 2 : 0.0);
+            std::vector<double> m(mask.begin(), mask.end());
+            ln.put("mask", m);
+        }
+        if (!separated) return false;
         parsac_th_ = (th1 + th2) / 2;
         for (size_t k = 0; k < curr->keypoint_num(); ++k)
             if (Track *tr = curr->get_track(k))
