@@ -247,6 +247,21 @@ int xrhip_ba_solve(xrhip_ba *ctx, const xrhip_ba_problem *problem, xrhip_ba_summ
  * xrhip_ba_solve. */
 int xrhip_ba_solve_overlapped(xrhip_ba *ctx, const xrhip_ba_problem *problem, xrhip_ba_summary *summary, void (*host_work)(void *), void *arg);
 
+/* Two solves of which the second starts from a state the first produces.  replaces: Solver::solve() of localize_newframe immediately
+ * followed by the one of refine_subwindow (sliding_window_tracker.cpp:99 and :114 through :119-143, :370-465): the second problem
+ * contains the frame the first one has just localised, and nothing else of it depends on the first solve (manage_keyframe in
+ * between reads tags and counts only, :145-223; the sub-window's factors and integrations use the biases of the frames before).
+ * Frame `link_second` of `second` takes its whole state (16 doubles) from frame `link_first` of `first` as the first solve leaves it;
+ * what second->frame_state holds for that frame on entry is ignored.  Both problems come back solved in place, each with its
+ * summary (ms_solve: the pair's wall clock is booked on the first).  When both are single-launch solves the hand-over happens on
+ * the device -- one submission and ONE host wait for the pair -- otherwise the two run one after the other with the state handed
+ * over on the host: the same results bit for bit.  host_work (may be NULL): as xrhip_ba_solve_overlapped, beside both solves.
+ * The contexts must be distinct (each holds one staged problem); a batch staged by xrhip_ba_preintegrate_after_solve on
+ * ctx_second starts from the second solve's biases, as after xrhip_ba_solve. */
+int xrhip_ba_solve_chained(xrhip_ba *ctx_first, const xrhip_ba_problem *first, xrhip_ba_summary *summary_first, int link_first,
+                           xrhip_ba *ctx_second, const xrhip_ba_problem *second, xrhip_ba_summary *summary_second, int link_second,
+                           void (*host_work)(void *), void *arg);
+
 /* HIP-event profiling of the dominant BA kernel (kb_solve_try: reduced-system Cholesky + trust-region trials),
  * off by default.  flops = algorithmic work of the launches:
  * na^3/3 + 2 na^2 per launch + (450 M + 3000 NI + 2 np^2) per trial costed. */

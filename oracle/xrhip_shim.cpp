@@ -276,6 +276,18 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *s) 
     }
     return rc;
 }
+int xrhip_ba_solve_chained(xrhip_ba *c1, const xrhip_ba_problem *P1, xrhip_ba_summary *s1, int link_first, xrhip_ba *c2,
+                           const xrhip_ba_problem *P2, xrhip_ba_summary *s2, int link_second, void (*host_work)(void *), void *arg) {
+    if (!c1 || !c2 || c1 == c2 || !P1 || !P2 || link_first < 0 || link_first >= P1->n_frames || link_second < 0 || link_second >= P2->n_frames) {
+        g_err = "xrhip_ba_solve_chained: bad arguments";
+        return XRHIP_EINVAL;
+    }
+    int rc = xrhip_ba_solve(c1, P1, s1);   // on the CPU: one after the other, the state handed over in between
+    if (host_work) host_work(arg);
+    if (rc) return rc;
+    std::memcpy(P2->frame_state + 16 * (size_t)link_second, P1->frame_state + 16 * (size_t)link_first, sizeof(double) * 16);
+    return xrhip_ba_solve(c2, P2, s2);
+}
 int xrhip_ba_marginalize(xrhip_ba *, const xrhip_marg_problem *M, double *a, double *b, double *c) {
     int rc = orc_ba_marginalize(M, a, b, c);
     if (rc) g_err = "marginalize failed";

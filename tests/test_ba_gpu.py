@@ -407,6 +407,76 @@ def test_overlapped_solve_runs_the_host_work_once_and_changes_nothing(ctx):
         assert sa.final_cost == sb.final_cost
 
 
+def test_chained_solves_equal_one_after_the_other(ctx):
+    """xrhip_ba_solve_chained (localize_newframe + refine_subwindow as one submission): the second problem's linked frame starts from
+    the first solve's result ON THE DEVICE.  Same bits as solving the first, copying the frame's state over on the host and solving
+    the second -- for the pipeline's own frozen pair of problems, with the host work run once, with an integration queued behind the
+    second solve, and through the general form when a problem is not a single-launch solve."""
+    from tests import ba_snapshots
+    from xrslam_amd import ba as _ba
+    snaps = {name: pd for name, pd, _ in ba_snapshots.load_all()}
+    loc, sub, win = snaps["s1_localize"], snaps["s1_subwindow"], snaps["s1_window"]
+    ctx2 = _ba.BaContext(max_frames=32, max_landmarks=2048, max_obs=16384)
+    _, truth = bs.make_window(K=5, L=20, seed=31)
+    smp, t_end = truth["samples"][1], truth["times"][2]
+    try:
+        free_loc = [f for f in range(len(loc.frame_state)) if loc.frame_fix[f] != 3][-1]
+        free_sub = [f for f in range(len(sub.frame_state)) if sub.frame_fix[f] != 3][-1]
+        for first, lf, second, ls in ((loc, free_loc, sub, free_sub), (loc, free_loc, win, len(win.frame_state) - 1),
+                                      (sub, free_sub, loc, free_loc)):
+            a1, a2 = first.copy(), second.copy()
+            m1 = ctx.solve(a1)
+            a2.frame_state[ls] = a1.frame_state[lf]
+            m2 = ctx.solve(a2)
+            b1, b2 = first.copy(), second.copy()
+            b2.frame_state[ls] = 123.0                      # whatever the linked frame holds on entry is ignored
+            calls = []
+            n1, n2 = ctx2.solve_chained(b1, lf, ctx, b2, ls, host_work=lambda: calls.append(1))
+            assert calls == [1]
+            np.testing.assert_array_equal(b1.frame_state, a1.frame_state)
+            np.testing.assert_array_equal(b2.frame_state, a2.frame_state)
+            np.testing.assert_array_equal(b2.inv_depth, a2.inv_depth)
+            assert (m1.iterations, m1.termination, m1.final_cost) == (n1.iterations, n1.termination, n1.final_cost)
+            assert (m2.iterations, m2.termination, m2.final_cost) == (n2.iterations, n2.termination, n2.final_cost)
+            assert not np.array_equal(a2.frame_state[ls], second.frame_state[ls])     # and the hand-over mattered
+        # an integration queued behind the pair starts from the SECOND solve's biases
+        a1, a2 = loc.copy(), sub.copy()
+        ctx.solve(a1)
+        a2.frame_state[free_sub] = a1.frame_state[free_loc]
+        ctx.solve(a2)
+        direct = ctx.preintegrate(smp, t_end, a2.frame_state[free_sub, 10:13], a2.frame_state[free_sub, 13:16], bs.NOISE36)
+        b1, b2 = loc.copy(), sub.copy()
+        ctx.preintegrate_after_solve(smp, t_end, free_sub, bs.NOISE36)
+        ctx2.solve_chained(b1, free_loc, ctx, b2, free_sub)
+        np.testing.assert_array_equal(ctx.preintegrate_end(), direct)
+        np.testing.assert_array_equal(b2.frame_state, a2.frame_state)
+        with pytest.raises(Exception):
+            ctx.solve_chained(loc.copy(), free_loc, ctx, sub.copy(), free_sub)      # two distinct contexts are needed
+        with pytest.raises(Exception):
+            ctx2.solve_chained(loc.copy(), len(loc.frame_state), ctx, sub.copy(), free_sub)
+    finally:
+        ctx2.close()
+
+
+def test_early_delta_of_a_queued_integration(ctx):
+    """xrhip_ba_preintegrate_early: the delta (dt, dq, dp, dv) of a queued integration is available before the record's covariance
+    part and equals -- bit for bit -- both the finished record's and the Jacobian-free integration of the same samples (what
+    FeatureTracker::work and mirror_frame used to compute in two launches)."""
+    _, truth = bs.make_window(K=5, L=20, seed=31)
+    for k in (1, 2, 3):
+        smp, t_end = truth["samples"][k], truth["times"][k + 1]
+        bg, ba_ = np.array([1e-3, -2e-3, 5e-4]), np.array([0.02, -0.01, 0.03])
+        plain = ctx.preintegrate(smp, t_end, bg, ba_, bs.NOISE36, jac=False, cov=False)
+        ctx.preintegrate_begin(smp, t_end, bg, ba_, bs.NOISE36)
+        early = ctx.preintegrate_early(0)
+        full = ctx.preintegrate_end()
+        np.testing.assert_array_equal(early, full[:11])
+        np.testing.assert_array_equal(early, plain[:11])
+        assert np.abs(full[56:]).max() > 0
+    with pytest.raises(Exception):
+        ctx.preintegrate_early(0)                  # nothing in flight
+
+
 def test_one_preintegration_batch_in_flight_per_context(ctx):
     """A second xrhip_ba_preintegrate_begin without _end is refused (it would overwrite the staging block the first batch's kernel
     writes its record into); xrhip_ba_preintegrate_cancel releases the context; a fresh begin / end then gives the blocking call's

@@ -32,6 +32,11 @@ def configure(lib):
         lib.xrhip_ba_preintegrate_begin.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int]
     if hasattr(lib, "xrhip_ba_preintegrate_end"):
         lib.xrhip_ba_preintegrate_end.argtypes = [vp, vp]
+    if hasattr(lib, "xrhip_ba_preintegrate_early"):
+        lib.xrhip_ba_preintegrate_early.argtypes = [vp, C.c_int, vp]
+    if hasattr(lib, "xrhip_ba_solve_chained"):
+        lib.xrhip_ba_solve_chained.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary), C.c_int, vp,
+                                               C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary), C.c_int, HOST_WORK, vp]
     if hasattr(lib, "xrhip_ba_preintegrate_cancel"):
         lib.xrhip_ba_preintegrate_cancel.argtypes = [vp]
     if hasattr(lib, "xrhip_ba_preintegrate_after_solve"):
@@ -113,6 +118,42 @@ class BaContext:
                 raise raised[0]
             check(rc)
         return sm
+
+    def solve_chained(self, pd_first, link_first, second_ctx, pd_second, link_second, host_work=None):
+        """xrhip_ba_solve_chained: pd_first on this context, pd_second on second_ctx starting from pd_first's result for the linked
+        frame; both solved in place.  -> (summary_first, summary_second)"""
+        s1, s2 = pd_first.struct(), pd_second.struct()
+        m1, m2 = abi.BaSummary(), abi.BaSummary()
+        raised = []
+
+        def run(_arg):
+            try:
+                if host_work is not None:
+                    host_work()
+            except BaseException as e:   # noqa: BLE001  (re-raised below)
+                raised.append(e)
+        cb = HOST_WORK(run)
+        rc = self._lib.xrhip_ba_solve_chained(self._h, C.byref(s1), C.byref(m1), int(link_first), second_ctx._h, C.byref(s2),
+                                              C.byref(m2), int(link_second), cb, None)
+        if raised:
+            raise raised[0]
+        check(rc)
+        return m1, m2
+
+    def preintegrate_begin(self, samples, t_end, bg, ba, noise36, jac=True, cov=True):
+        """One interval queued (xrhip_ba_preintegrate_begin); preintegrate_early() / preintegrate_end() collect it."""
+        samples = np.ascontiguousarray(samples, np.float64).reshape(-1, 7)
+        bg, ba, noise36 = [np.ascontiguousarray(v, np.float64) for v in (bg, ba, noise36)]
+        begin, count = (np.array([v], np.int32) for v in (0, len(samples)))
+        t = np.array([t_end], np.float64)
+        check(self._lib.xrhip_ba_preintegrate_begin(self._h, _p(samples), _p(begin), _p(count), _p(t), _p(bg), _p(ba), 1, _p(noise36),
+                                                    int(jac), int(cov)))
+
+    def preintegrate_early(self, job=0):
+        """The delta (dt, dq, dp, dv) of a queued job as soon as the kernel has it (xrhip_ba_preintegrate_early)."""
+        out = np.zeros(11)
+        check(self._lib.xrhip_ba_preintegrate_early(self._h, int(job), _p(out)))
+        return out
 
     def marginalize(self, md):
         s = md.struct()

@@ -39,6 +39,11 @@ struct ChainPayload {
     StageArgs stage;
     ChainArgs chain;
     size_t lds = 0;
+    // xrhip_ba_solve_chained: a second solve (another context's staged problem) that starts from this one's result, right behind it
+    bool with_second = false;
+    StageArgs stage2;
+    ChainArgs chain2;
+    size_t lds2 = 0;
     bool with_preint = false;
     PreintArgs preint;
 };
@@ -189,33 +194,56 @@ static int launch_preint_batch(GroupRequest **r, int n, hipStream_t s) {
 }
 
 static int launch_chain_batch(GroupRequest **r, int n, hipStream_t s) {
-    for (int base = 0; base < n; base += XB) {
-        const int m = std::min(XB, n - base);
-        Batch<StageArgs> bs;
-        Batch<ChainArgs> bc;
-        Batch<PreintArgs> bp;
-        std::memset(&bs, 0, sizeof(bs));
-        std::memset(&bc, 0, sizeof(bc));
-        std::memset(&bp, 0, sizeof(bp));
-        size_t lds = 0, most16 = 0;
-        int np = 0, most_jobs = 1;
-        for (int i = 0; i < m; ++i) {
-            const ChainPayload &p = *static_cast<const ChainPayload *>(r[base + i]->payload);
-            bs.e[i] = p.stage;
-            bc.e[i] = p.chain;
-            lds = std::max(lds, p.lds);
-            most16 = std::max(most16, p.stage.n16);
-            if (p.with_preint) {
-                most_jobs = std::max(most_jobs, p.preint.n_jobs);
-                bp.e[np++] = p.preint;
-            }
+    // In stream order: every staged problem is pulled from its pinned arena (16 bytes per lane, <= 128 workgroups per problem) --
+    // those of the second solves too, they do not depend on the first ones --, one workgroup solves each first problem (dynamic
+    // LDS: the largest entry's layout), then the second solves start from what the first ones left on the device, and last the
+    // integrations that start from a solve's biases read them where it left them.
+    std::vector<StageArgs> stages;
+    std::vector<std::pair<ChainArgs, size_t>> first, second;
+    std::vector<PreintArgs> preints;
+    for (int i = 0; i < n; ++i) {
+        const ChainPayload &p = *static_cast<const ChainPayload *>(r[i]->payload);
+        stages.push_back(p.stage);
+        first.emplace_back(p.chain, p.lds);
+        if (p.with_second) {
+            stages.push_back(p.stage2);
+            second.emplace_back(p.chain2, p.lds2);
         }
-        // the device pulls the staged problems from the pinned arenas (16 bytes per lane, <= 128 workgroups per problem) ...
+        if (p.with_preint) preints.push_back(p.preint);
+    }
+    for (size_t base = 0; base < stages.size(); base += XB) {
+        const int m = (int)std::min<size_t>(XB, stages.size() - base);
+        Batch<StageArgs> bs;
+        std::memset(&bs, 0, sizeof(bs));
+        size_t most16 = 0;
+        for (int i = 0; i < m; ++i) {
+            bs.e[i] = stages[base + i];
+            most16 = std::max(most16, bs.e[i].n16);
+        }
         hipLaunchKernelGGL(kb_stage, dim3((int)std::min<size_t>((most16 + 255) / 256, 128), 1, m), dim3(256), 0, s, bs);
-        // ... one workgroup solves each of them (dynamic LDS: the largest entry's layout) ...
-        hipLaunchKernelGGL(kb_chain, dim3(1, 1, m), dim3(CHAIN_THREADS), lds, s, bc);
-        // ... and the integrations that start from a solve's biases read them where it left them
-        if (np) hipLaunchKernelGGL(kp_preintegrate, dim3(most_jobs, 1, np), dim3(64), 0, s, bp);
+    }
+    for (const auto *list : {&first, &second})
+        for (size_t base = 0; base < list->size(); base += XB) {
+            const int m = (int)std::min<size_t>(XB, list->size() - base);
+            Batch<ChainArgs> bc;
+            std::memset(&bc, 0, sizeof(bc));
+            size_t lds = 0;
+            for (int i = 0; i < m; ++i) {
+                bc.e[i] = (*list)[base + i].first;
+                lds = std::max(lds, (*list)[base + i].second);
+            }
+            hipLaunchKernelGGL(kb_chain, dim3(1, 1, m), dim3(CHAIN_THREADS), lds, s, bc);
+        }
+    for (size_t base = 0; base < preints.size(); base += XB) {
+        const int m = (int)std::min<size_t>(XB, preints.size() - base);
+        Batch<PreintArgs> bp;
+        std::memset(&bp, 0, sizeof(bp));
+        int most_jobs = 1;
+        for (int i = 0; i < m; ++i) {
+            bp.e[i] = preints[base + i];
+            most_jobs = std::max(most_jobs, bp.e[i].n_jobs);
+        }
+        hipLaunchKernelGGL(kp_preintegrate, dim3(most_jobs, 1, m), dim3(64), 0, s, bp);
     }
     XR_HIP(hipGetLastError());
     return XRHIP_OK;
@@ -817,6 +845,156 @@ int xrhip_ba_solve_overlapped(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_s
     run_overlap(c);   // no launch was waited for (trivial problem, early error): the work is still the caller's to get done
     return rc;
 }
+// ---- two solves in one go (xrhip_ba_solve_chained)
+static bool any_free_block(const xrhip_ba_problem *P) {
+    for (int f = 0; f < P->n_frames; ++f)
+        if ((P->frame_fix[f] & 3) != 3) return true;
+    return false;
+}
+static void fill_summary(const BaCtl &ctl, float ms, xrhip_ba_summary *sm) {
+    if (!sm) return;
+    std::memset(sm, 0, sizeof(*sm));
+    sm->iterations = ctl.iteration;
+    sm->successful_steps = ctl.successful_steps;
+    sm->termination = ctl.termination;
+    sm->usable = ctl.termination != XRHIP_BA_FAILURE;
+    sm->initial_cost = ctl.initial_cost;
+    sm->final_cost = ctl.x_cost;
+    sm->ms_solve = ms;
+}
+int xrhip_ba_solve_chained(xrhip_ba *c1, const xrhip_ba_problem *P1, xrhip_ba_summary *s1, int link_first, xrhip_ba *c2,
+                           const xrhip_ba_problem *P2, xrhip_ba_summary *s2, int link_second, void (*host_work)(void *), void *arg) {
+    if (!c1 || !c2 || c1 == c2 || !P1 || !P2) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_chained: two distinct contexts and two problems are needed");
+    int rc = validate(P1);
+    if (!rc) rc = validate(P2);
+    if (rc) return rc;
+    if (link_first < 0 || link_first >= P1->n_frames || link_second < 0 || link_second >= P2->n_frames)
+        return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_chained: linked frame is not a frame of its problem");
+    // The general form: one after the other with the state handed over on the host -- taken whenever one of the problems is not a
+    // single-launch solve (free landmarks, a prior, too many free frames), a batch waits behind the first solve, or the contexts
+    // do not launch into the same queue.  Same results either way.
+    auto sequential = [&]() {
+        int r = xrhip_ba_solve_overlapped(c1, P1, s1, host_work, arg);
+        if (r) return r;
+        std::memcpy(P2->frame_state + 16 * (size_t)link_second, P1->frame_state + 16 * (size_t)link_first, sizeof(double) * 16);
+        return xrhip_ba_solve(c2, P2, s2);
+    };
+    static const bool off = std::getenv("XRHIP_NO_CHAINED_SOLVES") != nullptr;   // development switch (A/B, parity)
+    if (off || c1->group != c2->group || c1->preint_deferred || !any_free_block(P1) || !any_free_block(P2)) return sequential();
+    const auto t_begin = std::chrono::steady_clock::now();
+    BaDims d1, d2;
+    BaPtrs p1, p2;
+    Ext cam1, imu1, cam2, imu2;
+    rc = stage_problem(c1, P1, d1, p1, cam1, imu1, true);
+    if (rc) return rc;
+    size_t lds1 = 0, lds2 = 0;
+    int tile1 = 0, tile2 = 0;
+    if (!chain(d1, (size_t)c1->lds_limit, &lds1, &tile1)) return sequential();
+    rc = stage_problem(c2, P2, d2, p2, cam2, imu2, true);
+    if (rc) return rc;
+    if (!chain(d2, (size_t)c2->lds_limit, &lds2, &tile2)) return sequential();
+    if (c2->preint_deferred) {   // refuse a bad frame index before anything is queued (as xrhip_ba_solve does)
+        const PreintJob *jobs = (const PreintJob *)(c2->h_stage + c2->preint_o_jobs);
+        for (int k = 0; k < c2->preint_deferred; ++k)
+            if (jobs[k].bias_frame < 0 || jobs[k].bias_frame >= P2->n_frames) {
+                c2->preint_deferred = 0;
+                return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_after_solve: bias frame is not a frame of the solve");
+            }
+    }
+    if (c1->group) {
+        rc = group_wait_launched(&c1->rq_chain);   // (its argument block is about to be rewritten)
+        if (rc) return rc;
+    }
+    const int seq1 = ++c1->seq, seq2 = ++c2->seq;
+    ChainPayload &cp = c1->a_chain;
+    cp.stage = StageArgs{c1->stage_src, c1->stage_dst, c1->stage_n16};
+    cp.chain = ChainArgs{c1->tiny_args, seq1, 4 * (P1->max_iterations + 8), tile1, nullptr, -1};
+    cp.lds = lds1;
+    cp.with_second = true;
+    cp.stage2 = StageArgs{c2->stage_src, c2->stage_dst, c2->stage_n16};
+    cp.chain2 = ChainArgs{c2->tiny_args, seq2, 4 * (P2->max_iterations + 8), tile2, static_cast<const double *>(p1.state) + 16 * (size_t)link_first,
+                          link_second};
+    cp.lds2 = lds2;
+    cp.with_preint = false;
+    rc = preint_fill_deferred(c2, P2, p2.state, &cp.preint, &cp.with_preint);
+    if (rc) return rc;
+    c1->rq_chain.kind = GK_CHAIN;
+    c1->rq_chain.owner = c1;
+    c1->rq_chain.payload = &cp;
+    hipStream_t ps = c1->stream;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (c1->group) {
+        ps = group_stream(c1->group, GQ_CHAIN);
+        rc = group_submit(c1->group, GQ_CHAIN, &c1->rq_chain);
+        if (rc) return rc;
+    } else {
+        if (c1->profiling)
+            for (int k = 0; k < 4; k += 2) {   // an event pair around each of the two solve kernels
+                if (!c1->free_events.empty()) {
+                    ev[k] = c1->free_events.back().first;
+                    ev[k + 1] = c1->free_events.back().second;
+                    c1->free_events.pop_back();
+                } else {
+                    XR_HIP(hipEventCreate(&ev[k]));
+                    XR_HIP(hipEventCreate(&ev[k + 1]));
+                }
+            }
+        Batch<StageArgs> bs;
+        Batch<ChainArgs> bc;
+        std::memset(&bs, 0, sizeof(bs));
+        bs.e[0] = cp.stage;
+        bs.e[1] = cp.stage2;
+        const size_t most16 = std::max(cp.stage.n16, cp.stage2.n16);
+        hipLaunchKernelGGL(kb_stage, dim3((int)std::min<size_t>((most16 + 255) / 256, 128), 1, 2), dim3(256), 0, ps, bs);
+        std::memset(&bc, 0, sizeof(bc));
+        bc.e[0] = cp.chain;
+        if (ev[0]) XR_HIP(hipEventRecord(ev[0], ps));
+        hipLaunchKernelGGL(kb_chain, dim3(1, 1, 1), dim3(CHAIN_THREADS), lds1, ps, bc);
+        if (ev[1]) XR_HIP(hipEventRecord(ev[1], ps));
+        bc.e[0] = cp.chain2;
+        if (ev[2]) XR_HIP(hipEventRecord(ev[2], ps));
+        hipLaunchKernelGGL(kb_chain, dim3(1, 1, 1), dim3(CHAIN_THREADS), lds2, ps, bc);
+        XR_HIP(hipGetLastError());
+        if (ev[3]) XR_HIP(hipEventRecord(ev[3], ps));
+        if (cp.with_preint) {
+            GroupRequest one;
+            one.payload = &cp.preint;
+            GroupRequest *pone = &one;
+            rc = launch_preint_batch(&pone, 1, ps);
+            if (rc) return rc;
+        }
+    }
+    if (cp.with_preint) {   // the batch queued behind the second solve is in flight from here on
+        c2->preint_pending = c2->preint_deferred;
+        c2->preint_deferred = 0;
+        c2->preint_rq = c1->group ? &c1->rq_chain : nullptr;
+        c2->preint_stream = ps;
+    }
+    if (host_work) host_work(arg);   // the caller's work that neither solve depends on, beside both of them
+    rc = wait_flag(c2->h_seq, seq2, ps, c1->group ? &c1->rq_chain : nullptr, "xrhip_ba_solve_chained");
+    if (!rc) rc = wait_flag(c1->h_seq, seq1, ps, nullptr, "xrhip_ba_solve_chained");   // (published before the second solve started)
+    if (rc) return rc;
+    if (c1->h_ctl->status != ST_DONE || c2->h_ctl->status != ST_DONE)
+        return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve_chained: trust-region loop did not terminate");
+    std::memcpy(P1->frame_state, c1->h_out, sizeof(double) * 16 * d1.F);
+    std::memcpy(P2->frame_state, c2->h_out, sizeof(double) * 16 * d2.F);
+    if (ev[0]) {
+        auto bytes_of = [](const BaDims &d, const BaCtl &ctl) {
+            const double nf = (double)d.M + d.MR, rounds = ctl.successful_steps + 1.0, trials = ctl.iteration;
+            return rounds * (384.0 * nf + 8.0 * (double)d.na * d.na + 2248.0 * d.NI) + trials * (280.0 * nf + 2248.0 * d.NI);
+        };
+        c1->pending_chain.push_back({ev[0], ev[1], bytes_of(d1, *c1->h_ctl)});
+        c1->pending_chain.push_back({ev[2], ev[3], bytes_of(d2, *c2->h_ctl)});
+    }
+    c1->stats.n_tiny += 2;
+    const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    fill_summary(*c1->h_ctl, ms, s1);      // the wall clock of the pair is booked on the first solve
+    fill_summary(*c2->h_ctl, 0.f, s2);
+    c1->dims = d1; c1->ptrs = p1; c1->have_lin = true;
+    c2->dims = d2; c2->ptrs = p2; c2->have_lin = true;
+    return XRHIP_OK;
+}
+
 static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
     int rc = validate(P);
     if (rc) return rc;
@@ -882,8 +1060,9 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
         }
         ChainPayload &cp = c->a_chain;
         cp.stage = StageArgs{c->stage_src, c->stage_dst, c->stage_n16};
-        cp.chain = ChainArgs{c->tiny_args, seq, 4 * (P->max_iterations + 8), chain_tile};
+        cp.chain = ChainArgs{c->tiny_args, seq, 4 * (P->max_iterations + 8), chain_tile, nullptr, -1};
         cp.lds = chain_lds;
+        cp.with_second = false;
         // a pre-integration that starts from this solve's biases runs right behind it, reading them where the kernel leaves them
         cp.with_preint = false;
         rc = preint_fill_deferred(c, P, p.state, &cp.preint, &cp.with_preint);

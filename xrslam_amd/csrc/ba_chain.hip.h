@@ -135,13 +135,20 @@ __device__ __forceinline__ double obs_eval_cached(const BaDims &d, const double 
 
 // One workgroup per solve; a launch carries up to XB solves (blockIdx.z = entry: the solves of several sequences of an instance
 // group, group.hip.h), each with its own staged problem, mailbox and options.  The dynamic LDS of the launch is the largest entry's.
+// link_src / link_frame (xrhip_ba_solve_chained): frame `link_frame` of this problem starts from the 16 doubles at link_src -- where the
+// solve launched in front of this one on the same stream left one of ITS frames (localize_newframe's result is refine_subwindow's
+// starting point for the new frame) -- instead of from what was staged; link_frame < 0: none.
 struct ChainArgs {
     const TinyArgs *args;
     int seq, max_rounds, opts;
+    const double *link_src;
+    int link_frame;
 };
 __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch) {
     const TinyArgs *__restrict__ args = batch.e[blockIdx.z].args;
     const int seq = batch.e[blockIdx.z].seq, max_rounds = batch.e[blockIdx.z].max_rounds, opts = batch.e[blockIdx.z].opts;
+    const double *link_src = batch.e[blockIdx.z].link_src;
+    const int link_frame = batch.e[blockIdx.z].link_src ? batch.e[blockIdx.z].link_frame : -1;
     const BaDims &d = args->d;
     const BaPtrs &p = args->p;
     const Ext &cam = args->cam, &imu = args->imu;
@@ -215,8 +222,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
         const int a = tid + nt * m;
         act[m] = (worker && a < n) ? p.act_inv[a] : -1;
     }
-    for (int e = wtid; e < 16 * F; e += nt) X[e] = p.state[e];
-    for (int e = wtid; e < 6 * NI; e += nt) bref[e] = p.bias_ref[e];
+    for (int e = wtid; e < 16 * F; e += nt) X[e] = (e >> 4) == link_frame ? link_src[e & 15] : p.state[e];
+    // (the bias reference of an IMU factor is the bias of its first frame as the solve starts: the linked frame's comes with its state)
+    for (int e = wtid; e < 6 * NI; e += nt) bref[e] = p.imu_i[e / 6] == link_frame ? link_src[10 + e % 6] : p.bias_ref[e];
     for (int e = wtid; e < XRHIP_IMU_DIM * NI; e += nt) recs[e] = p.imu_data[e];
     for (int e = wtid; e < NI * IMU_SCR; e += nt) scr[e] = 0.0;   // the blocks a linearisation writes are the same every round
     __syncthreads();

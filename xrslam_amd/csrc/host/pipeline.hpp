@@ -174,6 +174,7 @@ struct Pipeline {
     xrhip_ba *ba_marg = nullptr;   // marginalisation has a context (buffers, stream) of its own: it runs beside the next frame
     xrhip_ba *ba_aux = nullptr;    // speculative pre-integration batches (started a frame ahead), same reason
     xrhip_ba *ba_ft = nullptr;     // pipelined mode: the feature tracker's pre-integrations (its thread must not touch `ba`)
+    xrhip_ba *ba_sub = nullptr;    // localize_newframe's problem when it is solved together with refine_subwindow's (`ba` holds that one)
     std::mutex pool_mutex;         // image buffers return from whichever thread drops the last reference
     // xrhip_ba_marginalize_begin is ~20 API calls (staging, a memset, sixteen launches, three copies: 0.14 ms) whose result nobody
     // reads for several frames: they are issued by a thread of their own, on the marginalisation's context, while the caller goes
@@ -217,6 +218,7 @@ struct Pipeline {
         hip_check(xrhip_ba_create(32, 2048, 16384, &ba), "xrhip_ba_create");
         hip_check(xrhip_ba_create(32, 2048, 16384, &ba_marg), "xrhip_ba_create");
         hip_check(xrhip_ba_create(32, 2048, 16384, &ba_aux), "xrhip_ba_create");
+        hip_check(xrhip_ba_create(8, 1024, 4096, &ba_sub), "xrhip_ba_create");
         for (int i = 0; i < 9; ++i) {
             noise36[i] = c.cov_g[i];
             noise36[9 + i] = c.cov_a[i];
@@ -235,6 +237,7 @@ struct Pipeline {
         if (ba_marg) xrhip_ba_destroy(ba_marg);
         if (ba_aux) xrhip_ba_destroy(ba_aux);
         if (ba_ft) xrhip_ba_destroy(ba_ft);
+        if (ba_sub) xrhip_ba_destroy(ba_sub);
         if (klt) xrhip_klt_destroy(klt);
     }
     void ensure_ft_context() {
@@ -249,7 +252,7 @@ struct Pipeline {
     void join_group(xrhip_group *g) {
         marg_launch_wait();
         hip_check(xrhip_klt_join_group(klt, g), "xrhip_klt_join_group");
-        for (xrhip_ba *c : {ba, ba_aux, ba_ft})
+        for (xrhip_ba *c : {ba, ba_aux, ba_ft, ba_sub})
             if (c) hip_check(xrhip_ba_join_group(c, g), "xrhip_ba_join_group");
         group = g;
     }
@@ -757,12 +760,24 @@ class BaBuilder {
     // Host work of the caller that does not depend on this solve, run once beside it (xrhip_ba_solve_overlapped); exceptions it
     // throws are re-thrown after the solve has returned (the context is never left with a launch nobody waited for).
     struct Overlap {
+        std::function<void()> early;   // the part manage_keyframe must see done (the new frame's FT_NO_TRANSLATION tag): run first
         std::function<void()> fn;
-        bool done = false;
+        bool done = false, early_done = false;
         std::exception_ptr error;
+        void run_early() {
+            if (early_done) return;
+            early_done = true;
+            try {
+                if (early) early();
+            } catch (...) {
+                error = std::current_exception();
+            }
+        }
         void run() {
+            run_early();
             if (done) return;
             done = true;
+            if (error) return;
             try {
                 if (fn) fn();
             } catch (...) {
@@ -771,16 +786,19 @@ class BaBuilder {
         }
         static void trampoline(void *self) { static_cast<Overlap *>(self)->run(); }
     };
-    bool solve(double *elapsed_device_ms = nullptr, Overlap *overlap = nullptr) {
-        xrhip::HostProfScope hp_s(10, "BaBuilder::solve (all)");
+    // The problem as xrhip_ba_solve takes it, built from what was added (the arrays it points into live in this builder); states and
+    // pre-integration records are read NOW.
+    void prepare() {
         const Config &c = P_.config;
         split_aliased_constants();
         drop_unreferenced_blocks();
         const int F = (int)frames_.size(), L = (int)tracks_.size();
-        std::vector<double> state(16 * (size_t)F), depth(std::max(L, 1));
+        std::vector<double> &state = state_, &depth = depth_;
+        state.assign(16 * (size_t)F, 0.0);
+        depth.assign(std::max(L, 1), 0.0);
         for (int f = 0; f < F; ++f) pack_state(frames_[f], &state[16 * (size_t)f]);
         for (int l = 0; l < L; ++l) depth[l] = tracks_[l]->landmark.inv_depth;
-        xrhip_ba_problem pb;
+        xrhip_ba_problem &pb = pb_;
         std::memset(&pb, 0, sizeof(pb));
         pb.n_frames = F;
         pb.frame_state = state.data();
@@ -819,7 +837,8 @@ class BaBuilder {
         for (size_t k = 0; k < imu_pre_.size(); ++k)
             std::memcpy(&imu_data_[(size_t)XRHIP_IMU_DIM * k], imu_pre_[k]->rec, sizeof(double) * XRHIP_IMU_DIM);
         pb.imu_data = imu_data_.data();
-        std::vector<int> pframes;
+        std::vector<int> &pframes = pframes_;
+        pframes.clear();
         if (prior_) {
             resolve_marginalization(P_, prior_);
             for (Frame *f : prior_->frames) pframes.push_back(frame_index(f, false));
@@ -833,27 +852,60 @@ class BaBuilder {
         }
         pb.max_iterations = (int)c.solver_iteration_limit;
         if (P_.ba_dump.enabled()) P_.ba_dump.maybe_dump(pb, P_.times.frames);
-        xrhip_ba_summary sm;
-        WallTimer wt_w_solve(P_.times.w_solve);
-        if (chain_f_ && chain_f_->ba_gen == gen_)
-            chain_queued_ = P_.integrate_after_solve_begin(chain_samples_, chain_t_, chain_f_->ba_index, true, true);
-        if (overlap) {
-            const int rc = xrhip_ba_solve_overlapped(P_.ba, &pb, &sm, &Overlap::trampoline, overlap);
-            overlap->run();
-            if (overlap->error) std::rethrow_exception(overlap->error);
-            hip_check(rc, "xrhip_ba_solve_overlapped");
-        } else {
-            hip_check(xrhip_ba_solve(P_.ba, &pb, &sm), "xrhip_ba_solve");
-        }
+        prepared_ = true;
+    }
+    // the solved states back into the frames / tracks they came from, the counters of the run
+    bool finish(const xrhip_ba_summary &sm, double *elapsed_device_ms = nullptr) {
+        const int F = (int)frames_.size(), L = (int)tracks_.size();
         for (int f = 0; f < F; ++f)
-            if (fix_[f] != (XRHIP_FIX_POSE | XRHIP_FIX_MOTION)) unpack_state(&state[16 * (size_t)f], frames_[f], fix_[f]);
+            if (fix_[f] != (XRHIP_FIX_POSE | XRHIP_FIX_MOTION)) unpack_state(&state_[16 * (size_t)f], frames_[f], fix_[f]);
         for (int l = 0; l < L; ++l)
-            if (!lfix_[l]) tracks_[l]->landmark.inv_depth = depth[l];
+            if (!lfix_[l]) tracks_[l]->landmark.inv_depth = depth_[l];
         P_.times.solves++;
         P_.times.solve_iterations += sm.iterations;
         P_.times.ba_device_ms += sm.ms_solve;
         if (elapsed_device_ms) *elapsed_device_ms = sm.ms_solve;
         return sm.usable != 0;
+    }
+    bool solve(double *elapsed_device_ms = nullptr, Overlap *overlap = nullptr) {
+        xrhip::HostProfScope hp_s(10, "BaBuilder::solve (all)");
+        if (!prepared_) prepare();
+        xrhip_ba_summary sm;
+        WallTimer wt_w_solve(P_.times.w_solve);
+        if (chain_f_ && chain_f_->ba_gen == gen_)
+            chain_queued_ = P_.integrate_after_solve_begin(chain_samples_, chain_t_, chain_f_->ba_index, true, true);
+        if (overlap) {
+            const int rc = xrhip_ba_solve_overlapped(P_.ba, &pb_, &sm, &Overlap::trampoline, overlap);
+            overlap->run();
+            if (overlap->error) std::rethrow_exception(overlap->error);
+            hip_check(rc, "xrhip_ba_solve_overlapped");
+        } else {
+            hip_check(xrhip_ba_solve(P_.ba, &pb_, &sm), "xrhip_ba_solve");
+        }
+        return finish(sm, elapsed_device_ms);
+    }
+    // Two problems in one go (xrhip_ba_solve_chained): `second` contains frame `link`, which `first` optimises; it starts from the
+    // first solve's result for that frame (on the device: one submission, one wait for the pair).  Both builders must be prepared
+    // in order -- first, then whatever decides the second's structure, then second; `link_in_first` is link's index in the first
+    // problem (its stamp has been overwritten by the second builder since).  The first problem is staged on Pipeline::ba_sub, the
+    // second on Pipeline::ba (where an integration queued behind it -- chain_integration -- is collected from).
+    static bool solve_chained(BaBuilder &first, int link_in_first, BaBuilder &second, Frame *link, Overlap *overlap) {
+        xrhip::HostProfScope hp_s(10, "BaBuilder::solve (all)");
+        Pipeline &P = first.P_;
+        if (!first.prepared_ || !second.prepared_ || link->ba_gen != second.gen_) throw std::logic_error("solve_chained: builders are not prepared");
+        xrhip_ba_summary sm1, sm2;
+        WallTimer wt_w_solve(P.times.w_solve);
+        if (second.chain_f_ && second.chain_f_->ba_gen == second.gen_)
+            second.chain_queued_ = P.integrate_after_solve_begin(second.chain_samples_, second.chain_t_, second.chain_f_->ba_index, true, true);
+        const int rc = xrhip_ba_solve_chained(P.ba_sub, &first.pb_, &sm1, link_in_first, P.ba, &second.pb_, &sm2, link->ba_index,
+                                              overlap ? &Overlap::trampoline : nullptr, overlap);
+        if (overlap) {
+            overlap->run();
+            if (overlap->error) std::rethrow_exception(overlap->error);
+        }
+        hip_check(rc, "xrhip_ba_solve_chained");
+        first.finish(sm1);
+        return second.finish(sm2);
     }
 
     static void pack_state(const Frame *f, double *s) {
@@ -904,6 +956,10 @@ class BaBuilder {
     std::vector<const PreInt *> imu_pre_;
     std::vector<size_t> const_obs_, const_rot_, const_imu_;   // factors whose reference side is a constant use
     MargPrior *prior_ = nullptr;
+    std::vector<double> state_, depth_;
+    std::vector<int> pframes_;
+    xrhip_ba_problem pb_;
+    bool prepared_ = false;
     Frame *chain_f_ = nullptr;
     std::vector<ImuData> chain_samples_;
     double chain_t_ = 0;
@@ -1329,18 +1385,67 @@ class SlidingWindowTracker {
             } trace(P_.init_log.enabled() ? &P_.init_log : nullptr);
             if (judge_track_status()) update_track_status();
         }
-        localize_newframe(overlap);
+        // localize_newframe, manage_keyframe, then refine_window (keyframe) or refine_subwindow (:96-116).  On a non-keyframe frame
+        // the two solves are ONE submission (round 4): manage_keyframe reads tags and counts only (:145-223), and refine_subwindow's
+        // problem depends on localize_newframe's result through nothing but the new frame's starting state (its factors, its
+        // integrations and the other subframes' states are those of the frames before) -- so both problems are assembled first, the
+        // keyframe decision is taken in between, and the second solve picks the new frame's state up on the device where the first
+        // leaves it (BaBuilder::solve_chained): one wait instead of two, the sub-window's assembly off the critical path.  Same
+        // problems, same results.  Not with the decision log / the problem dump on (their records are written solve by solve), nor
+        // with the RD-VIO filters; XRSLAM_AMD_NO_CHAINED_SOLVES=1: one solve after the other.
+        static const bool no_pair = std::getenv("XRSLAM_AMD_NO_CHAINED_SOLVES") != nullptr;   // development switch (A/B, parity)
+        const bool pair_ok = !no_pair && !P_.config.parsac_flag && !P_.swt_log.enabled() && !P_.ba_dump.enabled();
         size_t log_id = 0, log_mapped = 0;
         bool log_nt = false;
-        if (P_.swt_log.enabled()) {   // the inputs manage_keyframe is about to look at
-            const Frame *nf = map->get_frame(map->frame_num() - 1);
-            log_id = nf->id;
-            log_nt = nf->tag(FT_NO_TRANSLATION);
-            for (size_t k = 0; k < nf->keypoint_num(); ++k)
-                if (Track *t = nf->get_track(k))
-                    if (t->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) log_mapped++;
+        bool is_kf = false, subwindow_done = false;
+        if (pair_ok) {
+            std::optional<BaBuilder> a;
+            Frame *const fj = map->get_frame(map->frame_num() - 1);
+            int link_a = -1;
+            {
+                WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
+                a.emplace(P_);
+                localize_assemble(*a);
+                a->prepare();
+                link_a = fj->ba_index;
+            }
+            if (overlap) {   // manage_keyframe reads the new frame's FT_NO_TRANSLATION tag
+                overlap->run_early();
+                if (overlap->error) std::rethrow_exception(overlap->error);
+            }
+            is_kf = manage_keyframe();
+            if (is_kf) {
+                WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
+                a->solve(nullptr, overlap);
+            } else {
+                BaBuilder b(P_);
+                bool have_b;
+                {
+                    WallTimer sc_t(P_.times.scope[SC_REFINE_SUBWINDOW]);
+                    have_b = refine_subwindow_assemble(b);
+                    if (have_b) b.prepare();
+                }
+                WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
+                if (have_b) {
+                    BaBuilder::solve_chained(*a, link_a, b, fj, overlap);
+                    refine_subwindow_finish(b);
+                } else {
+                    a->solve(nullptr, overlap);
+                }
+                subwindow_done = true;
+            }
+        } else {
+            localize_newframe(overlap);
+            if (P_.swt_log.enabled()) {   // the inputs manage_keyframe is about to look at
+                const Frame *nf = map->get_frame(map->frame_num() - 1);
+                log_id = nf->id;
+                log_nt = nf->tag(FT_NO_TRANSLATION);
+                for (size_t k = 0; k < nf->keypoint_num(); ++k)
+                    if (Track *t = nf->get_track(k))
+                        if (t->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) log_mapped++;
+            }
+            is_kf = manage_keyframe();
         }
-        const bool is_kf = manage_keyframe();
         if (is_kf) {
             P_.times.keyframes++;
             queue_keyframe_integrations();
@@ -1349,7 +1454,7 @@ class SlidingWindowTracker {
             take_mirror_hint();   // the newest frame's biases are final: the next interval integrates beside slide_window
             slide_window();
         } else {
-            refine_subwindow();
+            if (!subwindow_done) refine_subwindow();
             take_mirror_hint();
         }
         if (P_.swt_log.enabled()) {
@@ -1576,8 +1681,12 @@ class SlidingWindowTracker {
 
     void localize_newframe(BaBuilder::Overlap *overlap = nullptr) {   // :119-143
         WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
-        std::optional<xrhip::HostProfScope> hp_a(std::in_place, 25, "localize: problem assembly");
         BaBuilder b(P_);
+        localize_assemble(b);
+        b.solve(nullptr, overlap);
+    }
+    void localize_assemble(BaBuilder &b) {   // the problem of :119-143 (called before manage_keyframe: the new frame is the map's last)
+        xrhip::HostProfScope hp_a(25, "localize: problem assembly");
         Frame *fi = map->get_frame(map->frame_num() - 2);
         if (!fi->subframes.empty()) fi = fi->subframes.back().get();
         Frame *fj = map->get_frame(map->frame_num() - 1);
@@ -1586,8 +1695,6 @@ class SlidingWindowTracker {
         for (size_t k = 0; k < fj->keypoint_num(); ++k)
             if (Track *t = fj->get_track(k))
                 if (t->all_tagged({TT_VALID, TT_TRIANGULATED, TT_STATIC})) b.add_reprojection_prior(fj, k);
-        hp_a.reset();
-        b.solve(nullptr, overlap);
     }
 
     bool manage_keyframe() {   // :145-223
@@ -1901,8 +2008,22 @@ class SlidingWindowTracker {
 
     void refine_subwindow() {   // :370-465
         WallTimer sc_t(P_.times.scope[SC_REFINE_SUBWINDOW]);
+        BaBuilder b(P_);
+        if (!refine_subwindow_assemble(b)) return;
+        b.solve();
+        refine_subwindow_finish(b);
+    }
+    void refine_subwindow_finish(BaBuilder &b) {
+        chained_solve_done(b);
         Frame *frame = map->get_frame(map->frame_num() - 1);
-        if (frame->subframes.empty()) return;
+        frame->tag(FT_FIX_POSE) = false;
+        frame->tag(FT_FIX_MOTION) = false;
+    }
+    // everything of :370-465 up to the solve: the subframe merging of the rotation-only branch, the re-integrations, the factors.
+    // false: no subframe, nothing to solve
+    bool refine_subwindow_assemble(BaBuilder &b) {
+        Frame *frame = map->get_frame(map->frame_num() - 1);
+        if (frame->subframes.empty()) return false;
         if (frame->subframes[0]->tag(FT_NO_TRANSLATION)) {
             if (frame->subframes.size() >= 9) {
                 for (size_t i = frame->subframes.size() / 3; i > 0; --i) {
@@ -1917,8 +2038,7 @@ class SlidingWindowTracker {
                     tgt->preintegration.data.insert(tgt->preintegration.data.begin(), imu.begin(), imu.end());
                 }
             }
-            xrhip::HostProfScope hp_sa(20, "refine_subwindow: assembly..solve");
-            BaBuilder b(P_);
+            xrhip::HostProfScope hp_sa(20, "refine_subwindow: assembly");
             frame->tag(FT_FIX_POSE) = true;
             frame->tag(FT_FIX_MOTION) = true;
             b.add_frame_states(frame);
@@ -1951,13 +2071,8 @@ class SlidingWindowTracker {
                 P_.integrate_batch_end();
             }
             chain_mirror_hint(b, frame->subframes.back().get());
-            b.solve();
-            chained_solve_done(b);
-            frame->tag(FT_FIX_POSE) = false;
-            frame->tag(FT_FIX_MOTION) = false;
         } else {
-            xrhip::HostProfScope hp_sa(20, "refine_subwindow: assembly..solve");
-            BaBuilder b(P_);
+            xrhip::HostProfScope hp_sa(20, "refine_subwindow: assembly");
             frame->tag(FT_FIX_POSE) = true;
             frame->tag(FT_FIX_MOTION) = true;
             b.add_frame_states(frame);
@@ -1980,11 +2095,8 @@ class SlidingWindowTracker {
             }
             P_.integrate_batch_end();
             chain_mirror_hint(b, frame->subframes.back().get());
-            b.solve();
-            chained_solve_done(b);
-            frame->tag(FT_FIX_POSE) = false;
-            frame->tag(FT_FIX_MOTION) = false;
         }
+        return true;
     }
 
     LatestState get_latest_state() const {
@@ -3022,8 +3134,10 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
             const bool mirrored = swt->mirror_frame(ft_map.get(), pending_frame_id);
             Frame *const copy = mirrored ? swt->map->get_frame(swt->map->frame_num() - 1) : nullptr;
             BaBuilder::Overlap ov;
-            ov.fn = [this, detect_later, copy, &deferred_tag] {
+            ov.early = [copy, &deferred_tag] {
                 if (deferred_tag) deferred_tag(copy);
+            };
+            ov.fn = [this, detect_later, copy] {
                 const size_t n0 = detect_later->keypoint_num();
                 frame_detect_keypoints(P, detect_later);
                 if (copy)
