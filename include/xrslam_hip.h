@@ -261,6 +261,23 @@ int xrhip_ba_solve_overlapped(xrhip_ba *ctx, const xrhip_ba_problem *problem, xr
 int xrhip_ba_solve_chained(xrhip_ba *ctx_first, const xrhip_ba_problem *first, xrhip_ba_summary *summary_first, int link_first,
                            xrhip_ba *ctx_second, const xrhip_ba_problem *second, xrhip_ba_summary *summary_second, int link_second,
                            void (*host_work)(void *), void *arg);
+/* The same in three steps, so that the caller can ASSEMBLE the second problem while the device works on the first (the keyframe
+ * decision and refine_subwindow's problem assembly, ~50 us of host work, run beside localize_newframe's kernel):
+ *   xrhip_ba_solve_begin(ctx, first)    queues the solve and returns 1 -- or 0 without having done anything when the problem is not a
+ *                                       single-launch solve (free landmarks, a prior, too many free frames): use xrhip_ba_solve then;
+ *                                       `first` (its arrays) must stay alive and untouched until xrhip_ba_solve_end
+ *   xrhip_ba_solve_linked(ctx2, second, summary2, link_second, ctx, link_first, host_work, arg)
+ *                                       solves `second` on ctx2, its frame link_second starting from frame link_first of the solve
+ *                                       begun on ctx as that solve leaves it (handed over on the device when `second` is a
+ *                                       single-launch solve too, on the host otherwise); returns with `second` solved in place
+ *   xrhip_ba_solve_end(ctx, summary)    waits for the begun solve and writes its states into first->frame_state
+ * xrhip_ba_solve_chained is begin + linked + end. */
+int xrhip_ba_solve_begin(xrhip_ba *ctx, const xrhip_ba_problem *first);
+int xrhip_ba_solve_linked(xrhip_ba *ctx_second, const xrhip_ba_problem *second, xrhip_ba_summary *summary_second, int link_second,
+                          xrhip_ba *ctx_first, int link_first, void (*host_work)(void *), void *arg);
+int xrhip_ba_solve_end(xrhip_ba *ctx, xrhip_ba_summary *summary);
+/* the unwind path of an owner that cannot reach _end: waits for a begun solve and forgets it (nothing is written back) */
+int xrhip_ba_solve_abort(xrhip_ba *ctx);
 
 /* HIP-event profiling of the dominant BA kernel (kb_solve_try: reduced-system Cholesky + trust-region trials),
  * off by default.  flops = algorithmic work of the launches:

@@ -46,6 +46,9 @@ struct xrhip_image {
 };
 struct xrhip_ba {
     xrhip_group *group = nullptr;
+    const xrhip_ba_problem *begun_P = nullptr;   // xrhip_ba_solve_begin .. _end
+    xrhip_ba_summary begun_sm;
+    int begun_rc = 0;
     int unused = 0;
     // results of the asynchronous forms, per context like the product (computed at _begin, handed over at _end)
     std::vector<double> preint_out, marg_si, marg_iv, marg_lin;
@@ -275,6 +278,48 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *s) 
                                     d.noise.data(), d.jac, d.cov);
     }
     return rc;
+}
+// begin / linked / end: the CPU solves at begin (in place: the caller does not look before end) and hands the state over on the host
+int xrhip_ba_solve_begin(xrhip_ba *c, const xrhip_ba_problem *P) {
+    if (!c || !P) {
+        g_err = "xrhip_ba_solve_begin: null argument";
+        return XRHIP_EINVAL;
+    }
+    if (c->begun_P) {
+        g_err = "xrhip_ba_solve_begin: a solve is already in flight on this context";
+        return XRHIP_ESTATE;
+    }
+    // like the product: only the problems its single-launch kernel takes (no free landmark, no prior) are begun
+    for (int l = 0; l < P->n_landmarks; ++l)
+        if (!(P->landmark_fix && P->landmark_fix[l])) return 0;
+    if (P->prior_n > 0 || c->have_deferred) return 0;
+    c->begun_rc = xrhip_ba_solve(c, P, &c->begun_sm);
+    c->begun_P = P;
+    return 1;
+}
+int xrhip_ba_solve_end(xrhip_ba *c, xrhip_ba_summary *s) {
+    if (!c || !c->begun_P) {
+        g_err = "xrhip_ba_solve_end: nothing in flight";
+        return XRHIP_ESTATE;
+    }
+    c->begun_P = nullptr;
+    if (s) *s = c->begun_sm;
+    return c->begun_rc;
+}
+int xrhip_ba_solve_abort(xrhip_ba *c) {
+    if (c) c->begun_P = nullptr;
+    return 0;
+}
+int xrhip_ba_solve_linked(xrhip_ba *c2, const xrhip_ba_problem *P2, xrhip_ba_summary *s2, int link_second, xrhip_ba *c1, int link_first,
+                          void (*host_work)(void *), void *arg) {
+    if (!c1 || !c2 || c1 == c2 || !P2 || !c1->begun_P || link_first < 0 || link_first >= c1->begun_P->n_frames || link_second < 0 ||
+        link_second >= P2->n_frames) {
+        g_err = "xrhip_ba_solve_linked: bad arguments / no solve in flight on the first context";
+        return XRHIP_EINVAL;
+    }
+    if (c1->begun_rc) return c1->begun_rc;
+    std::memcpy(P2->frame_state + 16 * (size_t)link_second, c1->begun_P->frame_state + 16 * (size_t)link_first, sizeof(double) * 16);
+    return xrhip_ba_solve_overlapped(c2, P2, s2, host_work, arg);
 }
 int xrhip_ba_solve_chained(xrhip_ba *c1, const xrhip_ba_problem *P1, xrhip_ba_summary *s1, int link_first, xrhip_ba *c2,
                            const xrhip_ba_problem *P2, xrhip_ba_summary *s2, int link_second, void (*host_work)(void *), void *arg) {

@@ -450,6 +450,25 @@ def test_chained_solves_equal_one_after_the_other(ctx):
         ctx2.solve_chained(b1, free_loc, ctx, b2, free_sub)
         np.testing.assert_array_equal(ctx.preintegrate_end(), direct)
         np.testing.assert_array_equal(b2.frame_state, a2.frame_state)
+        # begin / end on their own: a single-launch problem is queued and collected with xrhip_ba_solve's result; a window problem is
+        # not begun; a begun solve blocks the context until it is collected or aborted
+        a, b = loc.copy(), loc.copy()
+        ma = ctx.solve(a)
+        assert ctx2.solve_begin(b) is True
+        with pytest.raises(Exception):
+            ctx2.solve(loc.copy())
+        mb = ctx2.solve_end()
+        np.testing.assert_array_equal(a.frame_state, b.frame_state)
+        assert (ma.iterations, ma.final_cost) == (mb.iterations, mb.final_cost)
+        assert ctx2.solve_begin(win.copy()) is False
+        with pytest.raises(Exception):
+            ctx2.solve_end()                                  # nothing in flight
+        c = loc.copy()
+        assert ctx2.solve_begin(c) is True
+        ctx2.solve_abort()
+        np.testing.assert_array_equal(c.frame_state, loc.frame_state)      # an aborted solve writes nothing back
+        ctx2.solve(c)
+        np.testing.assert_array_equal(c.frame_state, a.frame_state)
         with pytest.raises(Exception):
             ctx.solve_chained(loc.copy(), free_loc, ctx, sub.copy(), free_sub)      # two distinct contexts are needed
         with pytest.raises(Exception):

@@ -37,6 +37,10 @@ def configure(lib):
     if hasattr(lib, "xrhip_ba_solve_chained"):
         lib.xrhip_ba_solve_chained.argtypes = [vp, C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary), C.c_int, vp,
                                                C.POINTER(abi.BaProblem), C.POINTER(abi.BaSummary), C.c_int, HOST_WORK, vp]
+    if hasattr(lib, "xrhip_ba_solve_begin"):
+        lib.xrhip_ba_solve_begin.argtypes = [vp, C.POINTER(abi.BaProblem)]
+        lib.xrhip_ba_solve_end.argtypes = [vp, C.POINTER(abi.BaSummary)]
+        lib.xrhip_ba_solve_abort.argtypes = [vp]
     if hasattr(lib, "xrhip_ba_preintegrate_cancel"):
         lib.xrhip_ba_preintegrate_cancel.argtypes = [vp]
     if hasattr(lib, "xrhip_ba_preintegrate_after_solve"):
@@ -139,6 +143,24 @@ class BaContext:
             raise raised[0]
         check(rc)
         return m1, m2
+
+    def solve_begin(self, pd):
+        """xrhip_ba_solve_begin: True = queued (solve_end() collects it into pd), False = not a single-launch problem, nothing done."""
+        self._begun = (pd, pd.struct())      # the problem must stay alive until solve_end
+        rc = self._lib.xrhip_ba_solve_begin(self._h, C.byref(self._begun[1]))
+        if rc < 0:
+            check(rc)
+        return rc == 1
+
+    def solve_end(self):
+        sm = abi.BaSummary()
+        check(self._lib.xrhip_ba_solve_end(self._h, C.byref(sm)))
+        self._begun = None
+        return sm
+
+    def solve_abort(self):
+        check(self._lib.xrhip_ba_solve_abort(self._h))
+        self._begun = None
 
     def preintegrate_begin(self, samples, t_end, bg, ba, noise36, jac=True, cov=True):
         """One interval queued (xrhip_ba_preintegrate_begin); preintegrate_early() / preintegrate_end() collect it."""

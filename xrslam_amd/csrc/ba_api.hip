@@ -38,12 +38,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct ChainPayload {
     StageArgs stage;
     ChainArgs chain;
-    size_t lds = 0;
-    // xrhip_ba_solve_chained: a second solve (another context's staged problem) that starts from this one's result, right behind it
-    bool with_second = false;
-    StageArgs stage2;
-    ChainArgs chain2;
-    size_t lds2 = 0;
+    size_t lds = 0;   // (chain.link_src != null: a solve that starts from a state an earlier request's solve leaves on the device)
     bool with_preint = false;
     PreintArgs preint;
 };
@@ -59,6 +54,17 @@ struct xrhip_ba {
     PreintArgs a_preint;
     GroupRequest *preint_rq = nullptr;   // the request that carries the batch in flight (grouped), and the stream it runs on
     hipStream_t preint_stream = nullptr;
+    struct Begun {   // a single-launch solve queued by xrhip_ba_solve_begin, collected by xrhip_ba_solve_end
+        bool active = false;
+        const xrhip_ba_problem *P = nullptr;
+        BaDims d{};
+        BaPtrs p{};
+        int seq = 0;
+        hipStream_t stream = nullptr;
+        GroupRequest *rq = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        std::chrono::steady_clock::time_point t0;
+    } begun;
     Arena in;         // inputs (uploaded every solve)
     char *work = nullptr;   // device-only workspace
     size_t work_cap = 0;
@@ -177,7 +183,7 @@ static int launch_stage_copy(xrhip_ba *c) {
 }
 
 // ---------------------------------------------------------------------------------------------- batched launches (group.hip.h)
-static int launch_preint_batch(GroupRequest **r, int n, hipStream_t s) {
+static int launch_preint_batch(GroupRequest **r, int n, hipStream_t s, hipStream_t = nullptr) {
     for (int base = 0; base < n; base += XB) {
         const int m = std::min(XB, n - base);
         Batch<PreintArgs> b;
@@ -193,22 +199,19 @@ static int launch_preint_batch(GroupRequest **r, int n, hipStream_t s) {
     return XRHIP_OK;
 }
 
-static int launch_chain_batch(GroupRequest **r, int n, hipStream_t s) {
-    // In stream order: every staged problem is pulled from its pinned arena (16 bytes per lane, <= 128 workgroups per problem) --
-    // those of the second solves too, they do not depend on the first ones --, one workgroup solves each first problem (dynamic
-    // LDS: the largest entry's layout), then the second solves start from what the first ones left on the device, and last the
-    // integrations that start from a solve's biases read them where it left them.
+static int launch_chain_batch(GroupRequest **r, int n, hipStream_t s, hipStream_t = nullptr) {
+    // In stream order: every staged problem is pulled from its pinned arena (16 bytes per lane, <= 128 workgroups per problem); one
+    // workgroup solves each problem (dynamic LDS: the largest entry's layout) -- the solves that start from another request's
+    // result (xrhip_ba_solve_linked) in a second launch, behind the first: the request they depend on is in this batch or an earlier
+    // one (it was submitted first, and a queue launches in submission order); last the integrations that start from a solve's
+    // biases read them where it left them.
     std::vector<StageArgs> stages;
     std::vector<std::pair<ChainArgs, size_t>> first, second;
     std::vector<PreintArgs> preints;
     for (int i = 0; i < n; ++i) {
         const ChainPayload &p = *static_cast<const ChainPayload *>(r[i]->payload);
         stages.push_back(p.stage);
-        first.emplace_back(p.chain, p.lds);
-        if (p.with_second) {
-            stages.push_back(p.stage2);
-            second.emplace_back(p.chain2, p.lds2);
-        }
+        (p.chain.link_src ? second : first).emplace_back(p.chain, p.lds);   // a linked solve runs behind the one it starts from
         if (p.with_preint) preints.push_back(p.preint);
     }
     for (size_t base = 0; base < stages.size(); base += XB) {
@@ -798,6 +801,7 @@ int xrhip_ba_join_group(xrhip_ba *c, xrhip_group *g) {
 
 void xrhip_ba_destroy(xrhip_ba *c) {
     if (!c) return;
+    if (c->begun.active) xrhip_ba_solve_abort(c);
     if (c->group) {
         xrhip_ba_preintegrate_cancel(c);
         xrhip_ba_join_group(c, nullptr);
@@ -833,6 +837,7 @@ static int preint_fill_deferred(xrhip_ba *c, const xrhip_ba_problem *P, const do
 static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary);
 int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
     if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve: null context");
+    if (c->begun.active) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve: a solve begun on this context has not been collected (xrhip_ba_solve_end)");
     const int rc = ba_solve_impl(c, P, summary);
     if (rc) c->preint_deferred = 0;   // a batch staged behind a solve that failed must not ride on the next, unrelated one
     return rc;
@@ -862,36 +867,131 @@ static void fill_summary(const BaCtl &ctl, float ms, xrhip_ba_summary *sm) {
     sm->final_cost = ctl.x_cost;
     sm->ms_solve = ms;
 }
-int xrhip_ba_solve_chained(xrhip_ba *c1, const xrhip_ba_problem *P1, xrhip_ba_summary *s1, int link_first, xrhip_ba *c2,
-                           const xrhip_ba_problem *P2, xrhip_ba_summary *s2, int link_second, void (*host_work)(void *), void *arg) {
-    if (!c1 || !c2 || c1 == c2 || !P1 || !P2) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_chained: two distinct contexts and two problems are needed");
-    int rc = validate(P1);
-    if (!rc) rc = validate(P2);
+static double chain_bytes(const BaDims &d, const BaCtl &ctl) {   // algorithmic bytes of a single-launch solve
+    const double nf = (double)d.M + d.MR, rounds = ctl.successful_steps + 1.0, trials = ctl.iteration;
+    return rounds * (384.0 * nf + 8.0 * (double)d.na * d.na + 2248.0 * d.NI) + trials * (280.0 * nf + 2248.0 * d.NI);
+}
+static void take_event_pair(xrhip_ba *c, hipEvent_t *e0, hipEvent_t *e1) {
+    if (!c->free_events.empty()) {
+        *e0 = c->free_events.back().first;
+        *e1 = c->free_events.back().second;
+        c->free_events.pop_back();
+    } else {
+        hipEventCreate(e0);
+        hipEventCreate(e1);
+    }
+}
+
+// 1: queued (xrhip_ba_solve_end collects it), 0: not a single-launch solve -- nothing was queued, solve it with xrhip_ba_solve
+int xrhip_ba_solve_begin(xrhip_ba *c, const xrhip_ba_problem *P) {
+    if (!c || !P) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_begin: null argument");
+    if (c->begun.active) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve_begin: a solve is already in flight on this context");
+    int rc = validate(P);
     if (rc) return rc;
-    if (link_first < 0 || link_first >= P1->n_frames || link_second < 0 || link_second >= P2->n_frames)
-        return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_chained: linked frame is not a frame of its problem");
-    // The general form: one after the other with the state handed over on the host -- taken whenever one of the problems is not a
-    // single-launch solve (free landmarks, a prior, too many free frames), a batch waits behind the first solve, or the contexts
-    // do not launch into the same queue.  Same results either way.
-    auto sequential = [&]() {
-        int r = xrhip_ba_solve_overlapped(c1, P1, s1, host_work, arg);
-        if (r) return r;
-        std::memcpy(P2->frame_state + 16 * (size_t)link_second, P1->frame_state + 16 * (size_t)link_first, sizeof(double) * 16);
-        return xrhip_ba_solve(c2, P2, s2);
-    };
     static const bool off = std::getenv("XRHIP_NO_CHAINED_SOLVES") != nullptr;   // development switch (A/B, parity)
-    if (off || c1->group != c2->group || c1->preint_deferred || !any_free_block(P1) || !any_free_block(P2)) return sequential();
-    const auto t_begin = std::chrono::steady_clock::now();
-    BaDims d1, d2;
-    BaPtrs p1, p2;
-    Ext cam1, imu1, cam2, imu2;
-    rc = stage_problem(c1, P1, d1, p1, cam1, imu1, true);
+    if (off || c->preint_deferred || !any_free_block(P)) return 0;
+    xrhip_ba::Begun &B = c->begun;
+    B.t0 = std::chrono::steady_clock::now();
+    Ext cam, imu;
+    rc = stage_problem(c, P, B.d, B.p, cam, imu, true);
     if (rc) return rc;
-    size_t lds1 = 0, lds2 = 0;
-    int tile1 = 0, tile2 = 0;
-    if (!chain(d1, (size_t)c1->lds_limit, &lds1, &tile1)) return sequential();
+    size_t lds = 0;
+    int tile = 0;
+    if (!chain(B.d, (size_t)c->lds_limit, &lds, &tile)) return 0;
+    if (c->group) {
+        rc = group_wait_launched(&c->rq_chain);   // (its argument block is about to be rewritten)
+        if (rc) return rc;
+    }
+    B.seq = ++c->seq;
+    B.P = P;
+    ChainPayload &cp = c->a_chain;
+    cp.stage = StageArgs{c->stage_src, c->stage_dst, c->stage_n16};
+    cp.chain = ChainArgs{c->tiny_args, B.seq, 4 * (P->max_iterations + 8), tile, nullptr, -1};
+    cp.lds = lds;
+    cp.with_preint = false;
+    c->rq_chain.kind = GK_CHAIN;
+    c->rq_chain.owner = c;
+    c->rq_chain.payload = &cp;
+    B.e0 = B.e1 = nullptr;
+    if (c->group) {
+        B.stream = group_stream(c->group, GQ_CHAIN);
+        B.rq = &c->rq_chain;
+        rc = group_submit(c->group, GQ_CHAIN, &c->rq_chain);
+        if (rc) return rc;
+    } else {
+        B.stream = c->stream;
+        B.rq = nullptr;
+        if (c->profiling) take_event_pair(c, &B.e0, &B.e1);
+        Batch<StageArgs> bs;
+        Batch<ChainArgs> bc;
+        std::memset(&bs, 0, sizeof(bs));
+        std::memset(&bc, 0, sizeof(bc));
+        bs.e[0] = cp.stage;
+        bc.e[0] = cp.chain;
+        hipLaunchKernelGGL(kb_stage, dim3((int)std::min<size_t>((cp.stage.n16 + 255) / 256, 128), 1, 1), dim3(256), 0, B.stream, bs);
+        if (B.e0) XR_HIP(hipEventRecord(B.e0, B.stream));
+        hipLaunchKernelGGL(kb_chain, dim3(1, 1, 1), dim3(CHAIN_THREADS), lds, B.stream, bc);
+        XR_HIP(hipGetLastError());
+        if (B.e1) XR_HIP(hipEventRecord(B.e1, B.stream));
+    }
+    B.active = true;
+    return 1;
+}
+
+int xrhip_ba_solve_end(xrhip_ba *c, xrhip_ba_summary *summary) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_end: null context");
+    xrhip_ba::Begun &B = c->begun;
+    if (!B.active) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve_end: nothing in flight");
+    B.active = false;
+    int rc = wait_flag(c->h_seq, B.seq, B.stream, B.rq, "xrhip_ba_solve_end");
+    if (rc) return rc;
+    if (c->h_ctl->status != ST_DONE) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve_end: trust-region loop did not terminate");
+    std::memcpy(B.P->frame_state, c->h_out, sizeof(double) * 16 * B.d.F);
+    if (B.e0) c->pending_chain.push_back({B.e0, B.e1, chain_bytes(B.d, *c->h_ctl)});
+    c->stats.n_tiny++;
+    fill_summary(*c->h_ctl, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - B.t0).count(), summary);
+    c->dims = B.d;
+    c->ptrs = B.p;
+    c->have_lin = true;
+    return XRHIP_OK;
+}
+
+int xrhip_ba_solve_abort(xrhip_ba *c) {   // the unwind path: wait for a begun solve and forget it (its problem may be gone)
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_abort: null context");
+    xrhip_ba::Begun &B = c->begun;
+    if (!B.active) return XRHIP_OK;
+    B.active = false;
+    if (B.rq) group_wait_launched(B.rq);
+    XR_HIP(hipStreamSynchronize(B.stream));
+    if (B.e0) c->free_events.push_back({B.e0, B.e1});
+    return XRHIP_OK;
+}
+
+int xrhip_ba_solve_linked(xrhip_ba *c2, const xrhip_ba_problem *P2, xrhip_ba_summary *s2, int link_second, xrhip_ba *c1, int link_first,
+                          void (*host_work)(void *), void *arg) {
+    if (!c1 || !c2 || c1 == c2 || !P2) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_linked: two distinct contexts and a problem are needed");
+    xrhip_ba::Begun &A = c1->begun;
+    if (!A.active) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve_linked: the first context has no solve in flight (xrhip_ba_solve_begin)");
+    int rc = validate(P2);
+    if (rc) return rc;
+    if (link_first < 0 || link_first >= A.d.F || link_second < 0 || link_second >= P2->n_frames)
+        return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_linked: linked frame is not a frame of its problem");
+    // the general form: wait for the first solve, hand the state over on the host, solve the second like any other problem
+    auto sequential = [&]() {
+        int r = wait_flag(c1->h_seq, A.seq, A.stream, A.rq, "xrhip_ba_solve_linked");
+        if (r) return r;
+        std::memcpy(P2->frame_state + 16 * (size_t)link_second, c1->h_out + 16 * (size_t)link_first, sizeof(double) * 16);
+        return xrhip_ba_solve_overlapped(c2, P2, s2, host_work, arg);
+    };
+    if (c1->group != c2->group || c2->begun.active || !any_free_block(P2)) return sequential();
+    const auto t_begin = std::chrono::steady_clock::now();
+    BaDims d2;
+    BaPtrs p2;
+    Ext cam2, imu2;
     rc = stage_problem(c2, P2, d2, p2, cam2, imu2, true);
     if (rc) return rc;
+    size_t lds2 = 0;
+    int tile2 = 0;
     if (!chain(d2, (size_t)c2->lds_limit, &lds2, &tile2)) return sequential();
     if (c2->preint_deferred) {   // refuse a bad frame index before anything is queued (as xrhip_ba_solve does)
         const PreintJob *jobs = (const PreintJob *)(c2->h_stage + c2->preint_o_jobs);
@@ -901,98 +1001,89 @@ int xrhip_ba_solve_chained(xrhip_ba *c1, const xrhip_ba_problem *P1, xrhip_ba_su
                 return xr_fail(XRHIP_EINVAL, "xrhip_ba_preintegrate_after_solve: bias frame is not a frame of the solve");
             }
     }
-    if (c1->group) {
-        rc = group_wait_launched(&c1->rq_chain);   // (its argument block is about to be rewritten)
+    if (c2->group) {
+        rc = group_wait_launched(&c2->rq_chain);   // (its argument block is about to be rewritten)
         if (rc) return rc;
     }
-    const int seq1 = ++c1->seq, seq2 = ++c2->seq;
-    ChainPayload &cp = c1->a_chain;
-    cp.stage = StageArgs{c1->stage_src, c1->stage_dst, c1->stage_n16};
-    cp.chain = ChainArgs{c1->tiny_args, seq1, 4 * (P1->max_iterations + 8), tile1, nullptr, -1};
-    cp.lds = lds1;
-    cp.with_second = true;
-    cp.stage2 = StageArgs{c2->stage_src, c2->stage_dst, c2->stage_n16};
-    cp.chain2 = ChainArgs{c2->tiny_args, seq2, 4 * (P2->max_iterations + 8), tile2, static_cast<const double *>(p1.state) + 16 * (size_t)link_first,
-                          link_second};
-    cp.lds2 = lds2;
+    const int seq2 = ++c2->seq;
+    ChainPayload &cp = c2->a_chain;
+    cp.stage = StageArgs{c2->stage_src, c2->stage_dst, c2->stage_n16};
+    cp.chain = ChainArgs{c2->tiny_args, seq2, 4 * (P2->max_iterations + 8), tile2, static_cast<const double *>(A.p.state) + 16 * (size_t)link_first,
+                         link_second};
+    cp.lds = lds2;
     cp.with_preint = false;
     rc = preint_fill_deferred(c2, P2, p2.state, &cp.preint, &cp.with_preint);
     if (rc) return rc;
-    c1->rq_chain.kind = GK_CHAIN;
-    c1->rq_chain.owner = c1;
-    c1->rq_chain.payload = &cp;
-    hipStream_t ps = c1->stream;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (c1->group) {
-        ps = group_stream(c1->group, GQ_CHAIN);
-        rc = group_submit(c1->group, GQ_CHAIN, &c1->rq_chain);
+    c2->rq_chain.kind = GK_CHAIN;
+    c2->rq_chain.owner = c2;
+    c2->rq_chain.payload = &cp;
+    hipStream_t ps = A.stream;   // behind the first solve, on ITS stream (grouped: the queue both were submitted to, in this order)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c2->group) {
+        rc = group_submit(c2->group, GQ_CHAIN, &c2->rq_chain);
         if (rc) return rc;
     } else {
-        if (c1->profiling)
-            for (int k = 0; k < 4; k += 2) {   // an event pair around each of the two solve kernels
-                if (!c1->free_events.empty()) {
-                    ev[k] = c1->free_events.back().first;
-                    ev[k + 1] = c1->free_events.back().second;
-                    c1->free_events.pop_back();
-                } else {
-                    XR_HIP(hipEventCreate(&ev[k]));
-                    XR_HIP(hipEventCreate(&ev[k + 1]));
-                }
-            }
+        if (c1->profiling) take_event_pair(c1, &e0, &e1);
+        GroupRequest *one = &c2->rq_chain;
         Batch<StageArgs> bs;
         Batch<ChainArgs> bc;
         std::memset(&bs, 0, sizeof(bs));
-        bs.e[0] = cp.stage;
-        bs.e[1] = cp.stage2;
-        const size_t most16 = std::max(cp.stage.n16, cp.stage2.n16);
-        hipLaunchKernelGGL(kb_stage, dim3((int)std::min<size_t>((most16 + 255) / 256, 128), 1, 2), dim3(256), 0, ps, bs);
         std::memset(&bc, 0, sizeof(bc));
+        bs.e[0] = cp.stage;
         bc.e[0] = cp.chain;
-        if (ev[0]) XR_HIP(hipEventRecord(ev[0], ps));
-        hipLaunchKernelGGL(kb_chain, dim3(1, 1, 1), dim3(CHAIN_THREADS), lds1, ps, bc);
-        if (ev[1]) XR_HIP(hipEventRecord(ev[1], ps));
-        bc.e[0] = cp.chain2;
-        if (ev[2]) XR_HIP(hipEventRecord(ev[2], ps));
+        hipLaunchKernelGGL(kb_stage, dim3((int)std::min<size_t>((cp.stage.n16 + 255) / 256, 128), 1, 1), dim3(256), 0, ps, bs);
+        if (e0) XR_HIP(hipEventRecord(e0, ps));
         hipLaunchKernelGGL(kb_chain, dim3(1, 1, 1), dim3(CHAIN_THREADS), lds2, ps, bc);
         XR_HIP(hipGetLastError());
-        if (ev[3]) XR_HIP(hipEventRecord(ev[3], ps));
+        if (e1) XR_HIP(hipEventRecord(e1, ps));
+        (void)one;
         if (cp.with_preint) {
-            GroupRequest one;
-            one.payload = &cp.preint;
-            GroupRequest *pone = &one;
-            rc = launch_preint_batch(&pone, 1, ps);
+            GroupRequest pr;
+            pr.payload = &cp.preint;
+            GroupRequest *ppr = &pr;
+            rc = launch_preint_batch(&ppr, 1, ps);
             if (rc) return rc;
         }
     }
-    if (cp.with_preint) {   // the batch queued behind the second solve is in flight from here on
+    if (cp.with_preint) {   // the batch queued behind this solve is in flight from here on
         c2->preint_pending = c2->preint_deferred;
         c2->preint_deferred = 0;
-        c2->preint_rq = c1->group ? &c1->rq_chain : nullptr;
+        c2->preint_rq = c2->group ? &c2->rq_chain : nullptr;
         c2->preint_stream = ps;
     }
     if (host_work) host_work(arg);   // the caller's work that neither solve depends on, beside both of them
-    rc = wait_flag(c2->h_seq, seq2, ps, c1->group ? &c1->rq_chain : nullptr, "xrhip_ba_solve_chained");
-    if (!rc) rc = wait_flag(c1->h_seq, seq1, ps, nullptr, "xrhip_ba_solve_chained");   // (published before the second solve started)
+    rc = wait_flag(c2->h_seq, seq2, ps, c2->group ? &c2->rq_chain : nullptr, "xrhip_ba_solve_linked");
     if (rc) return rc;
-    if (c1->h_ctl->status != ST_DONE || c2->h_ctl->status != ST_DONE)
-        return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve_chained: trust-region loop did not terminate");
-    std::memcpy(P1->frame_state, c1->h_out, sizeof(double) * 16 * d1.F);
+    if (c2->h_ctl->status != ST_DONE) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve_linked: trust-region loop did not terminate");
     std::memcpy(P2->frame_state, c2->h_out, sizeof(double) * 16 * d2.F);
-    if (ev[0]) {
-        auto bytes_of = [](const BaDims &d, const BaCtl &ctl) {
-            const double nf = (double)d.M + d.MR, rounds = ctl.successful_steps + 1.0, trials = ctl.iteration;
-            return rounds * (384.0 * nf + 8.0 * (double)d.na * d.na + 2248.0 * d.NI) + trials * (280.0 * nf + 2248.0 * d.NI);
-        };
-        c1->pending_chain.push_back({ev[0], ev[1], bytes_of(d1, *c1->h_ctl)});
-        c1->pending_chain.push_back({ev[2], ev[3], bytes_of(d2, *c2->h_ctl)});
-    }
-    c1->stats.n_tiny += 2;
-    const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    fill_summary(*c1->h_ctl, ms, s1);      // the wall clock of the pair is booked on the first solve
-    fill_summary(*c2->h_ctl, 0.f, s2);
-    c1->dims = d1; c1->ptrs = p1; c1->have_lin = true;
-    c2->dims = d2; c2->ptrs = p2; c2->have_lin = true;
+    if (e0) c1->pending_chain.push_back({e0, e1, chain_bytes(d2, *c2->h_ctl)});
+    c2->stats.n_tiny++;
+    fill_summary(*c2->h_ctl, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), s2);
+    c2->dims = d2;
+    c2->ptrs = p2;
+    c2->have_lin = true;
     return XRHIP_OK;
+}
+
+int xrhip_ba_solve_chained(xrhip_ba *c1, const xrhip_ba_problem *P1, xrhip_ba_summary *s1, int link_first, xrhip_ba *c2,
+                           const xrhip_ba_problem *P2, xrhip_ba_summary *s2, int link_second, void (*host_work)(void *), void *arg) {
+    if (!c1 || !c2 || c1 == c2 || !P1 || !P2) return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_chained: two distinct contexts and two problems are needed");
+    int rc = validate(P1);
+    if (!rc) rc = validate(P2);
+    if (rc) return rc;
+    if (link_first < 0 || link_first >= P1->n_frames || link_second < 0 || link_second >= P2->n_frames)
+        return xr_fail(XRHIP_EINVAL, "xrhip_ba_solve_chained: linked frame is not a frame of its problem");
+    const int begun = xrhip_ba_solve_begin(c1, P1);
+    if (begun < 0) return begun;
+    if (begun == 0) {   // not a single-launch solve: one after the other, the state handed over on the host
+        rc = xrhip_ba_solve_overlapped(c1, P1, s1, host_work, arg);
+        if (rc) return rc;
+        std::memcpy(P2->frame_state + 16 * (size_t)link_second, P1->frame_state + 16 * (size_t)link_first, sizeof(double) * 16);
+        return xrhip_ba_solve(c2, P2, s2);
+    }
+    rc = xrhip_ba_solve_linked(c2, P2, s2, link_second, c1, link_first, host_work, arg);
+    const int rc1 = xrhip_ba_solve_end(c1, s1);   // (collected in any case: the context must not stay "in flight")
+    return rc ? rc : rc1;
 }
 
 static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *summary) {
@@ -1062,7 +1153,6 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
         cp.stage = StageArgs{c->stage_src, c->stage_dst, c->stage_n16};
         cp.chain = ChainArgs{c->tiny_args, seq, 4 * (P->max_iterations + 8), chain_tile, nullptr, -1};
         cp.lds = chain_lds;
-        cp.with_second = false;
         // a pre-integration that starts from this solve's biases runs right behind it, reading them where the kernel leaves them
         cp.with_preint = false;
         rc = preint_fill_deferred(c, P, p.state, &cp.preint, &cp.with_preint);

@@ -12,9 +12,11 @@
 //     solves: kb_stage + kb_chain [+ the integration queued behind the solve]), GQ_PREINT (pre-integration batches of every BA
 //     context).  Requests of one context reach the device in the order it submitted them; dependencies BETWEEN queues are
 //     host-mediated in the pipeline already (a solve is only assembled once the integrations it reads have been collected).
-//   * One batch in flight per queue: while it runs, requests accumulate; when it retires, everything pending of the head's kind
-//     goes out together.  An idle device launches a lone request at once, a busy one forms bigger batches -- nobody waits for a
-//     straggler, and a sequence on a keyframe frame (1.5 ms of window solve on its own stream) does not hold the others back.
+//   * One batch OF A KIND in flight per queue: while it runs, requests of that kind accumulate; when it retires, everything pending
+//     of it goes out together.  An idle device launches a lone request at once, a busy one forms bigger batches -- nobody waits
+//     for a straggler, and a sequence on a keyframe frame (1.5 ms of window solve on its own stream) does not hold the others
+//     back.  Batches of different kinds follow each other on the queue's in-order stream without a wait (frame -> pyramid ->
+//     tracking is one pipeline).  One submission thread per queue.
 //   * Per-entry arithmetic is untouched (same kernels, same block-to-work mapping, same summation order): results do not depend
 //     on the batch a request happened to travel in -- tests/test_instances.py holds grouped runs to the solo runs bit for bit.
 //   * Completion stays per context: every kernel publishes into its owner's pinned mailbox as before; the owner's thread spins on it.
@@ -44,7 +46,9 @@ struct GroupRequest {
 
 // Turns `n` pending requests of one kind into launches on `s` (chunks of XB entries); registered once per kind by the translation
 // unit that owns the kernels.  Returns an XRHIP_* code (the text is taken from the calling thread's xr_err_buf).
-typedef int (*GroupLaunchFn)(GroupRequest **reqs, int n, hipStream_t s);
+// `side`: a second stream of the queue (may be null) for the part of a batch nobody waits for before the queue's next batch -- the
+// launch function orders it behind what it depends on with an event (the front end's Harris passes behind the tracking launch).
+typedef int (*GroupLaunchFn)(GroupRequest **reqs, int n, hipStream_t s, hipStream_t side);
 void group_register(int kind, GroupLaunchFn fn);
 
 // the owner's thread: hand a request over / wait until its kernels are on the stream (returns its rc, error text copied)
@@ -55,6 +59,7 @@ int group_call(xrhip_group *g, int queue, void *owner, std::function<int(hipStre
 // ... and when everything submitted to `queue` before it has completed on the device
 int group_drain(xrhip_group *g, int queue, void *owner);
 hipStream_t group_stream(xrhip_group *g, int queue);
+hipStream_t group_side_stream(xrhip_group *g, int queue);
 void group_member_add(xrhip_group *g, bool front_end);   // front_end: a KLT context, i.e. one more sequence in the group
 void group_member_remove(xrhip_group *g, bool front_end);
 // a member enters (+1) / leaves (-1) a stretch of work on its own stream (a window solve): the group does not wait for it
@@ -63,6 +68,7 @@ void group_busy_elsewhere(xrhip_group *g, int delta);
 // Spin until *flag == seq (a kernel's last store into pinned memory).  The stream is polled now and then so that a faulted kernel
 // becomes an error instead of a hang -- once the request (if any) is known to be launched: a shared stream may be idle while the
 // request still waits in the group's queue.
-int wait_flag(volatile int *flag, int seq, hipStream_t s, GroupRequest *req, const char *what);
+// (s2: a second stream the publishing kernel may be on)
+int wait_flag(volatile int *flag, int seq, hipStream_t s, GroupRequest *req, const char *what, hipStream_t s2 = nullptr);
 
 }   // namespace xrhip

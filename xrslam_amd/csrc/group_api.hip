@@ -1,4 +1,4 @@
-// group_api.hip -- the instance group's submission thread and its C ABI (group.hip.h says what it is for).
+// group_api.hip -- the instance group's submission threads and its C ABI (group.hip.h says what it is for).
 #include "group.hip.h"
 
 #include "common.hip.h"
@@ -31,57 +31,92 @@ constexpr int MAX_BATCH = 32;   // requests one batch takes (the launch function
 
 }   // namespace
 
-struct xrhip_group {
-    int device = 0;
-    hipStream_t stream[GQ_COUNT] = {nullptr};
-    std::mutex m;   // the queues, `sleeping`
+// One queue: its requests, its stream (and a side stream for work that need not hold up the next batch), its submission thread.
+struct GroupQueueState {
+    int index = 0;
+    hipStream_t stream = nullptr, side = nullptr;
+    std::mutex m;   // the request list, `sleeping`
     std::condition_variable cv;
-    std::deque<GroupRequest *> q[GQ_COUNT];
+    std::deque<GroupRequest *> q;
     bool sleeping = false;
     std::atomic<long> submitted{0};
-    std::atomic<bool> quit{false};
-    std::atomic<int> members{0};
-    std::atomic<bool> profiling{false};
-    std::atomic<int> busy_elsewhere{0};   // members inside a window solve (their own stream): they will not submit for a while
-    std::atomic<int> sequences{0};        // front-end contexts joined == sequences in the group
-    int linger_us = 0;                    // hold a batch back this long for the members that have not submitted yet (XRHIP_GROUP_LINGER_US)
-    int linger_queues = 7;                // bit k: queue k lingers (XRHIP_GROUP_LINGER_QUEUES)
-    std::chrono::steady_clock::time_point first_seen[GQ_COUNT];
-    bool lingering[GQ_COUNT] = {false};
     std::thread th;
     // submission thread only
-    bool inflight[GQ_COUNT] = {false};
-    int inflight_kind[GQ_COUNT] = {0};
-    hipEvent_t ev0[GQ_COUNT] = {nullptr}, ev1[GQ_COUNT] = {nullptr};
-    bool timed[GQ_COUNT] = {false};
+    struct Inflight {
+        int kind;
+        hipEvent_t begin, end;
+    };
+    std::deque<Inflight> inflight;   // batches on the stream, oldest first (an in-order stream retires them in that order)
+    std::vector<hipEvent_t> free_events;
+    std::chrono::steady_clock::time_point first_seen;
+    bool lingering = false;
+};
+
+struct xrhip_group {
+    int device = 0;
+    GroupQueueState qs[GQ_COUNT];
+    std::atomic<bool> quit{false};
+    std::atomic<int> members{0};
+    std::atomic<int> sequences{0};        // front-end contexts joined == sequences in the group
+    std::atomic<bool> profiling{false};
+    std::atomic<int> busy_elsewhere{0};   // members inside a window solve (their own stream): they will not submit for a while
+    int linger_us = 0;                    // hold a batch back this long for the members that have not submitted yet (XRHIP_GROUP_LINGER_US)
+    int linger_queues = 7;                // bit k: queue k lingers (XRHIP_GROUP_LINGER_QUEUES)
+    bool per_kind = true;                 // a batch waits for the previous batch OF ITS KIND only (XRHIP_GROUP_PER_KIND=0: for any batch)
     std::mutex stats_m;
     xrhip_group_stats stats;
 
-    void finish_timing(int k) {
-        if (!timed[k]) return;
-        timed[k] = false;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev0[k], ev1[k]) == hipSuccess) {
-            std::lock_guard<std::mutex> lk(stats_m);
-            stats.ms[inflight_kind[k]] += ms;
-            stats.timed[inflight_kind[k]] += 1;
-        } else {
-            (void)hipGetLastError();
+    hipEvent_t take_event(GroupQueueState &Q) {
+        if (!Q.free_events.empty()) {
+            hipEvent_t e = Q.free_events.back();
+            Q.free_events.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        hipEventCreate(&e);
+        return e;
+    }
+
+    // batches whose last kernel has finished leave the in-flight list (in order); their duration goes into the statistics
+    void retire(GroupQueueState &Q) {
+        while (!Q.inflight.empty()) {
+            GroupQueueState::Inflight &f = Q.inflight.front();
+            const hipError_t qr = hipEventQuery(f.end);
+            if (qr == hipErrorNotReady) return;
+            if (qr != hipSuccess) (void)hipGetLastError();   // a fault surfaces at the owners' mailbox waits
+            if (f.begin) {
+                float ms = 0.f;
+                if (qr == hipSuccess && hipEventElapsedTime(&ms, f.begin, f.end) == hipSuccess) {
+                    std::lock_guard<std::mutex> lk(stats_m);
+                    stats.ms[f.kind] += ms;
+                    stats.timed[f.kind] += 1;
+                } else {
+                    (void)hipGetLastError();
+                }
+                Q.free_events.push_back(f.begin);
+            }
+            Q.free_events.push_back(f.end);
+            Q.inflight.pop_front();
         }
     }
 
-    // the head request and every later one of its kind whose owner has nothing older still waiting in this queue
-    // -> false: requests are pending but held back (linger): the caller comes back
-    bool take(int k, std::vector<GroupRequest *> &batch) {
+    // The head request and every later one of its kind whose owner has nothing older still waiting in this queue -- once no batch
+    // of that kind is in flight any more: while one runs, requests of its kind accumulate and leave together.  Batches of
+    // DIFFERENT kinds follow each other on the stream without a wait in between (frame -> pyramid -> tracking of the same members
+    // is one pipeline on an in-order stream: nothing is gained by holding its stages apart).
+    // -> false: requests are pending but held back: the caller comes back
+    bool take(GroupQueueState &Q, std::vector<GroupRequest *> &batch) {
         batch.clear();
-        std::lock_guard<std::mutex> lk(m);
-        std::deque<GroupRequest *> &dq = q[k];
+        std::lock_guard<std::mutex> lk(Q.m);
+        std::deque<GroupRequest *> &dq = Q.q;
         if (dq.empty()) {
-            lingering[k] = false;
+            Q.lingering = false;
             return true;
         }
         const int kind = dq.front()->kind;
-        if (linger_us > 0 && kind != GK_CALL && ((linger_queues >> k) & 1)) {
+        for (const GroupQueueState::Inflight &f : Q.inflight)
+            if (!per_kind || f.kind == kind || kind == GK_CALL || f.kind == GK_CALL) return false;
+        if (linger_us > 0 && kind != GK_CALL && ((linger_queues >> Q.index) & 1)) {
             // Members run the same frame loop: when some have submitted this kind and the others are about to, a short wait turns
             // several small launches into one -- and members that travelled in one batch come back together.  Never longer than
             // linger_us past the first pending request, and not at all for members that are busy with a window solve.
@@ -90,13 +125,13 @@ struct xrhip_group {
             const int expected = std::max(1, sequences.load(std::memory_order_relaxed) - busy_elsewhere.load(std::memory_order_relaxed));
             if (same < expected) {
                 const auto now = std::chrono::steady_clock::now();
-                if (!lingering[k]) {
-                    lingering[k] = true;
-                    first_seen[k] = now;
+                if (!Q.lingering) {
+                    Q.lingering = true;
+                    Q.first_seen = now;
                 }
-                if (now - first_seen[k] < std::chrono::microseconds(linger_us)) return false;
+                if (now - Q.first_seen < std::chrono::microseconds(linger_us)) return false;
             }
-            lingering[k] = false;
+            Q.lingering = false;
         }
         if (kind == GK_CALL) {
             batch.push_back(dq.front());
@@ -121,30 +156,25 @@ struct xrhip_group {
         return true;
     }
 
-    void launch(int k, std::vector<GroupRequest *> &batch) {
+    void launch(GroupQueueState &Q, std::vector<GroupRequest *> &batch) {
         const int kind = batch[0]->kind, n = (int)batch.size();
-        const bool prof = profiling.load(std::memory_order_relaxed);
-        if (prof) {
-            if (!ev0[k]) {
-                hipEventCreate(&ev0[k]);
-                hipEventCreate(&ev1[k]);
-            }
-            hipEventRecord(ev0[k], stream[k]);
+        GroupQueueState::Inflight f{kind, nullptr, nullptr};
+        if (profiling.load(std::memory_order_relaxed)) {
+            f.begin = take_event(Q);
+            hipEventRecord(f.begin, Q.stream);
         }
         int rc;
-        if (kind == GK_CALL) rc = batch[0]->call ? batch[0]->call(stream[k]) : XRHIP_OK;
-        else if (g_launch[kind]) rc = g_launch[kind](batch.data(), n, stream[k]);
+        if (kind == GK_CALL) rc = batch[0]->call ? batch[0]->call(Q.stream) : XRHIP_OK;
+        else if (g_launch[kind]) rc = g_launch[kind](batch.data(), n, Q.stream, Q.side);
         else rc = xr_fail(XRHIP_ESTATE, "instance group: no launcher registered for this request kind");
-        if (prof) {
-            hipEventRecord(ev1[k], stream[k]);
-            timed[k] = true;
-        }
+        f.end = take_event(Q);
+        hipEventRecord(f.end, Q.stream);
+        Q.inflight.push_back(f);
         {
             std::lock_guard<std::mutex> lk(stats_m);
             stats.batches[kind] += 1;
             stats.entries[kind] += n;
         }
-        inflight_kind[k] = kind;
         const char *text = rc ? xr_err_buf() : "";
         for (GroupRequest *r : batch) {
             r->rc = rc;
@@ -153,31 +183,18 @@ struct xrhip_group {
         }
     }
 
-    void run() {
+    void run(GroupQueueState &Q) {
         hipSetDevice(device);
         std::vector<GroupRequest *> batch;
         batch.reserve(MAX_BATCH);
         auto idle_since = std::chrono::steady_clock::now();
         for (;;) {
-            bool active = false;
-            for (int k = 0; k < GQ_COUNT; ++k) {
-                if (inflight[k]) {
-                    const hipError_t qr = hipStreamQuery(stream[k]);
-                    if (qr == hipErrorNotReady) {
-                        active = true;
-                        continue;
-                    }
-                    if (qr != hipSuccess) (void)hipGetLastError();   // a fault surfaces at the owners' mailbox waits
-                    inflight[k] = false;
-                    finish_timing(k);
-                }
-                if (!take(k, batch)) {   // held back for a few microseconds: stay awake
-                    active = true;
-                    continue;
-                }
-                if (batch.empty()) continue;
-                launch(k, batch);
-                inflight[k] = true;
+            retire(Q);
+            bool active = !Q.inflight.empty();
+            if (!take(Q, batch)) {
+                active = true;   // held back (a batch of the kind in flight, or lingering): stay awake
+            } else if (!batch.empty()) {
+                launch(Q, batch);
                 active = true;
             }
             if (active) {
@@ -185,28 +202,24 @@ struct xrhip_group {
                 continue;
             }
             if (quit.load(std::memory_order_acquire)) {
-                std::lock_guard<std::mutex> lk(m);
-                bool empty = true;
-                for (int k = 0; k < GQ_COUNT; ++k) empty = empty && q[k].empty();
-                if (empty) return;
+                std::lock_guard<std::mutex> lk(Q.m);
+                if (Q.q.empty()) return;
                 continue;
             }
             // nothing queued, nothing in flight: spin on the wake word for a while (a frame is a fraction of a millisecond), then sleep
-            const long seen = submitted.load(std::memory_order_acquire);
+            const long seen = Q.submitted.load(std::memory_order_acquire);
             bool woke = false;
             for (int spin = 0; spin < 4096 && !woke; ++spin) {
                 relax();
-                woke = submitted.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_relaxed);
+                woke = Q.submitted.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_relaxed);
             }
             if (woke) continue;
             if (std::chrono::steady_clock::now() - idle_since < std::chrono::milliseconds(3)) continue;
-            std::unique_lock<std::mutex> lk(m);
-            bool empty = true;
-            for (int k = 0; k < GQ_COUNT; ++k) empty = empty && q[k].empty();
-            if (!empty || quit.load(std::memory_order_relaxed)) continue;
-            sleeping = true;
-            cv.wait_for(lk, std::chrono::milliseconds(20));
-            sleeping = false;
+            std::unique_lock<std::mutex> lk(Q.m);
+            if (!Q.q.empty() || quit.load(std::memory_order_relaxed)) continue;
+            Q.sleeping = true;
+            Q.cv.wait_for(lk, std::chrono::milliseconds(20));
+            Q.sleeping = false;
         }
     }
 };
@@ -221,14 +234,15 @@ int group_submit(xrhip_group *g, int queue, GroupRequest *r) {
     while (r->state.load(std::memory_order_acquire) == 1) relax();   // its previous use is still queued
     r->rc = 0;
     r->state.store(1, std::memory_order_release);
+    GroupQueueState &Q = g->qs[queue];
     bool wake;
     {
-        std::lock_guard<std::mutex> lk(g->m);
-        g->q[queue].push_back(r);
-        wake = g->sleeping;
+        std::lock_guard<std::mutex> lk(Q.m);
+        Q.q.push_back(r);
+        wake = Q.sleeping;
     }
-    g->submitted.fetch_add(1, std::memory_order_release);
-    if (wake) g->cv.notify_one();
+    Q.submitted.fetch_add(1, std::memory_order_release);
+    if (wake) Q.cv.notify_one();
     return XRHIP_OK;
 }
 
@@ -253,11 +267,13 @@ int group_call(xrhip_group *g, int queue, void *owner, std::function<int(hipStre
 int group_drain(xrhip_group *g, int queue, void *owner) {
     int rc = group_call(g, queue, owner, [](hipStream_t) { return XRHIP_OK; });
     if (rc) return rc;
-    XR_HIP(hipStreamSynchronize(g->stream[queue]));
+    XR_HIP(hipStreamSynchronize(g->qs[queue].stream));
+    if (g->qs[queue].side) XR_HIP(hipStreamSynchronize(g->qs[queue].side));
     return XRHIP_OK;
 }
 
-hipStream_t group_stream(xrhip_group *g, int queue) { return g->stream[queue]; }
+hipStream_t group_stream(xrhip_group *g, int queue) { return g->qs[queue].stream; }
+hipStream_t group_side_stream(xrhip_group *g, int queue) { return g->qs[queue].side; }
 void group_member_add(xrhip_group *g, bool front_end) {
     g->members.fetch_add(1);
     if (front_end) g->sequences.fetch_add(1);
@@ -270,7 +286,7 @@ void group_busy_elsewhere(xrhip_group *g, int delta) {
     if (g) g->busy_elsewhere.fetch_add(delta, std::memory_order_relaxed);
 }
 
-int wait_flag(volatile int *flag, int seq, hipStream_t s, GroupRequest *req, const char *what) {
+int wait_flag(volatile int *flag, int seq, hipStream_t s, GroupRequest *req, const char *what, hipStream_t s2) {
     if (req) {
         const int rc = group_wait_launched(req);
         if (rc) return rc;
@@ -278,7 +294,8 @@ int wait_flag(volatile int *flag, int seq, hipStream_t s, GroupRequest *req, con
     for (unsigned long spin = 1;; ++spin) {
         if (*flag == seq) return XRHIP_OK;
         if ((spin & 0x3FFF) == 0) {
-            const hipError_t q = hipStreamQuery(s);
+            hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess && s2) q = hipStreamQuery(s2);
             if (q == hipSuccess) {
                 if (*flag == seq) return XRHIP_OK;
                 std::snprintf(xr_err_buf(), 512, "%s: kernel retired without publishing its result", what);
@@ -306,18 +323,27 @@ int xrhip_group_create(xrhip_group **out) {
     hipGetDevice(&g->device);
     if (const char *e = std::getenv("XRHIP_GROUP_LINGER_US")) g->linger_us = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("XRHIP_GROUP_LINGER_QUEUES")) g->linger_queues = std::atoi(e);
-    // The group's streams carry every member's per-frame critical path; the members' own streams carry window solves and
-    // marginalisations (long, one frame in five).  The runtime multiplexes a process's streams over a few hardware queues PER
-    // PRIORITY LEVEL, in order within a queue: at the default priority a batch would queue behind whichever member's 100 us
-    // factorisation shares its hardware queue.  Highest priority gives the three group streams hardware queues of their own.
+    if (const char *e = std::getenv("XRHIP_GROUP_PER_KIND")) g->per_kind = std::atoi(e) != 0;
+    // (Stream priorities were tried: the runtime gives a priority level hardware queues of its own, so the group's batches no longer
+    // queue behind a member's 100 us factorisation -- but more than ~4 hardware queues in use at once stretch EVERY kernel by 20-27 us
+    // on this part, tools/multiq.hip; measured 4026 against 4260 frames/s at 8 sequences.  XRHIP_GROUP_PRIORITY=1 switches them on.)
     int prio_low = 0, prio_high = 0;
-    const bool use_prio = std::getenv("XRHIP_GROUP_NO_PRIORITY") == nullptr &&
+    const bool use_prio = std::getenv("XRHIP_GROUP_PRIORITY") != nullptr &&
                           hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) == hipSuccess && prio_high != prio_low;
+    const bool side_stream = std::getenv("XRHIP_GROUP_NO_SIDE_STREAM") == nullptr;
     for (int k = 0; k < GQ_COUNT; ++k) {
-        if (use_prio) XR_HIP(hipStreamCreateWithPriority(&g->stream[k], hipStreamNonBlocking, prio_high));
-        else XR_HIP(hipStreamCreateWithFlags(&g->stream[k], hipStreamNonBlocking));
+        GroupQueueState &Q = g->qs[k];
+        Q.index = k;
+        if (use_prio) XR_HIP(hipStreamCreateWithPriority(&Q.stream, hipStreamNonBlocking, prio_high));
+        else XR_HIP(hipStreamCreateWithFlags(&Q.stream, hipStreamNonBlocking));
+        // the front end's Harris passes ride behind a tracking launch but nobody waits for them before the next frame's tracks have
+        // been digested: on a stream of their own they do not hold up the next batch of frames / tracking launches
+        if (k == GQ_KLT && side_stream) XR_HIP(hipStreamCreateWithFlags(&Q.side, hipStreamNonBlocking));
     }
-    g->th = std::thread([g] { g->run(); });
+    for (int k = 0; k < GQ_COUNT; ++k) {
+        GroupQueueState *Q = &g->qs[k];
+        Q->th = std::thread([g, Q] { g->run(*Q); });
+    }
     *out = g;
     return XRHIP_OK;
 }
@@ -326,17 +352,26 @@ int xrhip_group_destroy(xrhip_group *g) {
     if (!g) return XRHIP_OK;
     if (g->members.load() != 0) return xr_fail(XRHIP_ESTATE, "xrhip_group_destroy: contexts are still joined to this group");
     g->quit.store(true, std::memory_order_release);
-    g->submitted.fetch_add(1, std::memory_order_release);
-    {
-        std::lock_guard<std::mutex> lk(g->m);
-    }
-    g->cv.notify_all();
-    g->th.join();
     for (int k = 0; k < GQ_COUNT; ++k) {
-        hipStreamSynchronize(g->stream[k]);
-        hipStreamDestroy(g->stream[k]);
-        if (g->ev0[k]) hipEventDestroy(g->ev0[k]);
-        if (g->ev1[k]) hipEventDestroy(g->ev1[k]);
+        GroupQueueState &Q = g->qs[k];
+        Q.submitted.fetch_add(1, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(Q.m);
+        }
+        Q.cv.notify_all();
+    }
+    for (int k = 0; k < GQ_COUNT; ++k) {
+        GroupQueueState &Q = g->qs[k];
+        Q.th.join();
+        hipStreamSynchronize(Q.stream);
+        if (Q.side) hipStreamSynchronize(Q.side);
+        for (auto &f : Q.inflight) {
+            if (f.begin) hipEventDestroy(f.begin);
+            hipEventDestroy(f.end);
+        }
+        for (hipEvent_t e : Q.free_events) hipEventDestroy(e);
+        hipStreamDestroy(Q.stream);
+        if (Q.side) hipStreamDestroy(Q.side);
     }
     delete g;
     return XRHIP_OK;

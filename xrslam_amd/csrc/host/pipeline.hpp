@@ -352,9 +352,10 @@ struct Pipeline {
                   "xrhip_ba_preintegrate_after_solve");
         return true;
     }
-    void cancel_integrations() noexcept {   // error unwind: no batch stays between begin and end on any context
+    void cancel_integrations() noexcept {   // error unwind: no batch stays between begin and end on any context, no solve begun
         for (xrhip_ba *c : {ba, ba_aux, ba_ft})
             if (c) xrhip_ba_preintegrate_cancel(c);
+        if (ba_sub) xrhip_ba_solve_abort(ba_sub);
     }
     // the delta (dt, dq, dp, dv) of job 0 of the batch in flight on `ba`, as soon as the kernel has it (the batch stays in flight)
     void integrate_early(PreInt &pre) {
@@ -889,23 +890,56 @@ class BaBuilder {
     // in order -- first, then whatever decides the second's structure, then second; `link_in_first` is link's index in the first
     // problem (its stamp has been overwritten by the second builder since).  The first problem is staged on Pipeline::ba_sub, the
     // second on Pipeline::ba (where an integration queued behind it -- chain_integration -- is collected from).
-    static bool solve_chained(BaBuilder &first, int link_in_first, BaBuilder &second, Frame *link, Overlap *overlap) {
+    // xrhip_ba_solve_begin on `ctx`: true = the solve is running on the device (end() / solve_linked() collect it), false = not a
+    // single-launch problem, nothing was queued (solve() it)
+    bool begin(xrhip_ba *ctx) {
+        if (!prepared_) prepare();
+        WallTimer wt_w_solve(P_.times.w_solve);
+        const int rc = xrhip_ba_solve_begin(ctx, &pb_);
+        if (rc < 0) hip_check(rc, "xrhip_ba_solve_begin");
+        return rc == 1;
+    }
+    bool end(xrhip_ba *ctx, Overlap *overlap = nullptr) {
+        xrhip_ba_summary sm;
+        WallTimer wt_w_solve(P_.times.w_solve);
+        if (overlap) {
+            overlap->run();
+            if (overlap->error) {
+                xrhip_ba_solve_abort(ctx);
+                std::rethrow_exception(overlap->error);
+            }
+        }
+        hip_check(xrhip_ba_solve_end(ctx, &sm), "xrhip_ba_solve_end");
+        return finish(sm);
+    }
+    // `first` has been begun on Pipeline::ba_sub; `second` -- prepared while the device worked on it -- contains frame `link`, which
+    // `first` optimises: it is solved on Pipeline::ba starting from the first solve's result for that frame, handed over on the
+    // device (xrhip_ba_solve_linked); then both are collected.  link_in_first: link's index in the first problem (its stamp has been
+    // overwritten by the second builder since).  An integration queued behind the second solve (chain_integration) is collected
+    // from Pipeline::ba as after solve().
+    static bool solve_linked(BaBuilder &first, int link_in_first, BaBuilder &second, Frame *link, Overlap *overlap) {
         xrhip::HostProfScope hp_s(10, "BaBuilder::solve (all)");
         Pipeline &P = first.P_;
-        if (!first.prepared_ || !second.prepared_ || link->ba_gen != second.gen_) throw std::logic_error("solve_chained: builders are not prepared");
+        if (!first.prepared_ || !second.prepared_ || link->ba_gen != second.gen_) throw std::logic_error("solve_linked: builders are not prepared");
         xrhip_ba_summary sm1, sm2;
         WallTimer wt_w_solve(P.times.w_solve);
         if (second.chain_f_ && second.chain_f_->ba_gen == second.gen_)
             second.chain_queued_ = P.integrate_after_solve_begin(second.chain_samples_, second.chain_t_, second.chain_f_->ba_index, true, true);
-        const int rc = xrhip_ba_solve_chained(P.ba_sub, &first.pb_, &sm1, link_in_first, P.ba, &second.pb_, &sm2, link->ba_index,
-                                              overlap ? &Overlap::trampoline : nullptr, overlap);
-        if (overlap) {
-            overlap->run();
-            if (overlap->error) std::rethrow_exception(overlap->error);
+        const int rc = xrhip_ba_solve_linked(P.ba, &second.pb_, &sm2, link->ba_index, P.ba_sub, link_in_first,
+                                             overlap ? &Overlap::trampoline : nullptr, overlap);
+        if (overlap) overlap->run();
+        if (rc || (overlap && overlap->error)) {
+            xrhip_ba_solve_abort(P.ba_sub);
+            if (overlap && overlap->error) std::rethrow_exception(overlap->error);
+            hip_check(rc, "xrhip_ba_solve_linked");
         }
-        hip_check(rc, "xrhip_ba_solve_chained");
+        hip_check(xrhip_ba_solve_end(P.ba_sub, &sm1), "xrhip_ba_solve_end");
         first.finish(sm1);
         return second.finish(sm2);
+    }
+    // the starting state of `f` again, from the frame (a problem prepared before another solve moved the frame)
+    void repack(Frame *f) {
+        if (prepared_ && f->ba_gen == gen_) pack_state(f, &state_[16 * (size_t)f->ba_index]);
     }
 
     static void pack_state(const Frame *f, double *s) {
@@ -1402,37 +1436,52 @@ class SlidingWindowTracker {
             std::optional<BaBuilder> a;
             Frame *const fj = map->get_frame(map->frame_num() - 1);
             int link_a = -1;
+            bool begun = false;
             {
                 WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
                 a.emplace(P_);
                 localize_assemble(*a);
                 a->prepare();
                 link_a = fj->ba_index;
+                begun = a->begin(P_.ba_sub);   // the device works on it from here on
             }
+            struct AbortBegun {   // (an exception below must not leave the solve "in flight": its problem dies with the builder)
+                Pipeline &P;
+                bool &armed;
+                ~AbortBegun() {
+                    if (armed) xrhip_ba_solve_abort(P.ba_sub);
+                }
+            } abort_begun{P_, begun};
             if (overlap) {   // manage_keyframe reads the new frame's FT_NO_TRANSLATION tag
                 overlap->run_early();
                 if (overlap->error) std::rethrow_exception(overlap->error);
             }
             is_kf = manage_keyframe();
-            if (is_kf) {
-                WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
-                a->solve(nullptr, overlap);
+            BaBuilder b(P_);
+            bool have_b = false;
+            if (!is_kf) {   // ... and assembles the second problem meanwhile
+                WallTimer sc_t(P_.times.scope[SC_REFINE_SUBWINDOW]);
+                have_b = refine_subwindow_assemble(b);
+                if (have_b) b.prepare();
+                subwindow_done = true;
+            }
+            WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
+            if (have_b && begun) {
+                begun = false;   // (solve_linked collects or aborts it)
+                BaBuilder::solve_linked(*a, link_a, b, fj, overlap);
+                refine_subwindow_finish(b);
             } else {
-                BaBuilder b(P_);
-                bool have_b;
-                {
-                    WallTimer sc_t(P_.times.scope[SC_REFINE_SUBWINDOW]);
-                    have_b = refine_subwindow_assemble(b);
-                    if (have_b) b.prepare();
-                }
-                WallTimer sc_t(P_.times.scope[SC_LOCALIZE]);
-                if (have_b) {
-                    BaBuilder::solve_chained(*a, link_a, b, fj, overlap);
-                    refine_subwindow_finish(b);
+                if (begun) {
+                    begun = false;
+                    a->end(P_.ba_sub, overlap);
                 } else {
                     a->solve(nullptr, overlap);
                 }
-                subwindow_done = true;
+                if (have_b) {   // (localize_newframe was not a single-launch problem: the second solve starts from the frame as it is now)
+                    b.repack(fj);
+                    b.solve();
+                    refine_subwindow_finish(b);
+                }
             }
         } else {
             localize_newframe(overlap);

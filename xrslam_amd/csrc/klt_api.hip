@@ -33,6 +33,8 @@ struct LevelBuf {
 
 // What a request of each kind carries: the argument sets of its kernels, built by the owning context exactly as for a launch of its own
 struct PrePayload {
+    bool with_upload = false;   // the frame's copy into HBM travels with its preprocessing (grouped contexts: one request per frame)
+    UploadArgs up;
     ClaheLutArgs lut;
     PyrAArgs pa;
     PyrBArgs pb;
@@ -62,6 +64,7 @@ struct xrhip_klt {
     TrackPayload a_track;
     DetectPayload a_detect;
     int uploads_unsynced = 0;   // grouped: uploads since the last point the KLT queue is known to have drained (pinned ring safety)
+    bool upload_pending = false;   // grouped: a_upload describes a copy that has not been submitted yet (xrhip_image_preprocess takes it along)
     // scratch shared by the images of this sequence
     uint8_t *lut = nullptr;          // tiles*256
     int lut_tiles = 0;
@@ -216,7 +219,7 @@ template <class Args, class Fill> static void for_chunks(int n, Fill fill) {
     }
 }
 
-static int launch_upload_batch(GroupRequest **r, int n, hipStream_t s) {
+static int launch_upload_batch(GroupRequest **r, int n, hipStream_t s, hipStream_t) {
     for_chunks<UploadArgs>(n, [&](Batch<UploadArgs> &b, int base, int m) {
         size_t most = 0;
         for (int i = 0; i < m; ++i) {
@@ -230,7 +233,7 @@ static int launch_upload_batch(GroupRequest **r, int n, hipStream_t s) {
     return XRHIP_OK;
 }
 
-static int launch_preprocess_batch(GroupRequest **r, int n, hipStream_t s) {
+static int launch_preprocess_batch(GroupRequest **r, int n, hipStream_t s, hipStream_t) {
     for (int base = 0; base < n; base += XB) {
         const int m = std::min(XB, n - base);
         Batch<ClaheLutArgs> bl;
@@ -240,6 +243,17 @@ static int launch_preprocess_batch(GroupRequest **r, int n, hipStream_t s) {
         std::memset(&ba, 0, sizeof(ba));
         std::memset(&bb, 0, sizeof(bb));
         int gl = 1, ga = 1, gb = 1;
+        Batch<UploadArgs> bu;
+        std::memset(&bu, 0, sizeof(bu));
+        size_t most = 0;
+        for (int i = 0; i < m; ++i) {
+            const PrePayload &p = *static_cast<const PrePayload *>(r[base + i]->payload);
+            if (p.with_upload) {
+                bu.e[i] = p.up;
+                most = std::max(most, (size_t)p.up.w * p.up.h);
+            }
+        }
+        if (most) hipLaunchKernelGGL(k_upload, dim3((int)std::max<size_t>(1, std::min<size_t>((most / 16 + 255) / 256, 64)), 1, m), dim3(256), 0, s, bu);
         for (int i = 0; i < m; ++i) {
             const PrePayload &p = *static_cast<const PrePayload *>(r[base + i]->payload);
             bl.e[i] = p.lut;
@@ -277,7 +291,7 @@ static void launch_detect_chunk(const DetectPayload *const *d, int m, hipStream_
     hipLaunchKernelGGL(k_harris_select, dim3(1, 1, m), dim3(1024), 0, s, bs);
 }
 
-static int launch_detect_batch(GroupRequest **r, int n, hipStream_t s) {
+static int launch_detect_batch(GroupRequest **r, int n, hipStream_t s, hipStream_t) {
     for (int base = 0; base < n; base += XB) {
         const int m = std::min(XB, n - base);
         const DetectPayload *d[XB];
@@ -288,7 +302,7 @@ static int launch_detect_batch(GroupRequest **r, int n, hipStream_t s) {
     return XRHIP_OK;
 }
 
-static int launch_track_batch(GroupRequest **r, int n, hipStream_t s) {
+static int launch_track_batch(GroupRequest **r, int n, hipStream_t s, hipStream_t side) {
     for (int base = 0; base < n; base += XB) {
         const int m = std::min(XB, n - base);
         Batch<LkTrackArgs> b;
@@ -301,19 +315,34 @@ static int launch_track_batch(GroupRequest **r, int n, hipStream_t s) {
         hipLaunchKernelGGL(k_lk_track, dim3(most, 1, m), dim3(LK_THREADS), 0, s, b);
     }
     XR_HIP(hipGetLastError());
-    // the Harris passes of the target images do not depend on the tracking result: right behind it
+    // The Harris passes of the target images do not depend on the tracking result: right behind the tracking launch -- on the queue's
+    // side stream when there is one (ordered behind this batch by an event: they read the pyramids the stream has built), so that
+    // the queue's next batch does not wait for three kernels nobody needs before the tracks have been digested.
     const DetectPayload *d[XB];
     int nd = 0;
+    bool any = false;
+    for (int i = 0; i < n && !any; ++i) any = static_cast<const TrackPayload *>(r[i]->payload)->detect;
+    if (!any) return XRHIP_OK;
+    hipStream_t ds = s;
+    if (side) {
+        static thread_local hipEvent_t fork[8] = {nullptr};
+        static thread_local unsigned fork_next = 0;
+        hipEvent_t &e = fork[fork_next++ & 7];
+        if (!e) XR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        XR_HIP(hipEventRecord(e, s));
+        XR_HIP(hipStreamWaitEvent(side, e, 0));
+        ds = side;
+    }
     for (int i = 0; i < n; ++i) {
         const TrackPayload *t = static_cast<const TrackPayload *>(r[i]->payload);
         if (!t->detect) continue;
         d[nd++] = &t->det;
         if (nd == XB) {
-            launch_detect_chunk(d, nd, s);
+            launch_detect_chunk(d, nd, ds);
             nd = 0;
         }
     }
-    if (nd) launch_detect_chunk(d, nd, s);
+    if (nd) launch_detect_chunk(d, nd, ds);
     XR_HIP(hipGetLastError());
     return XRHIP_OK;
 }
@@ -336,11 +365,21 @@ static int klt_issue(xrhip_klt *c, GroupRequest &rq, int kind, void *payload, Gr
     rq.payload = payload;
     if (c->group) return group_submit(c->group, GQ_KLT, &rq);
     GroupRequest *one = &rq;
-    return fn(&one, 1, c->stream);
+    return fn(&one, 1, c->stream, nullptr);
 }
 static hipStream_t klt_stream(const xrhip_klt *c) { return c->group ? group_stream(c->group, GQ_KLT) : c->stream; }
+// a frame copy that was waiting for its preprocessing request goes out on its own (something else is about to read the plane)
+static int flush_upload(xrhip_klt *c) {
+    if (!c->upload_pending) return XRHIP_OK;
+    c->upload_pending = false;
+    return klt_issue(c, c->rq_upload, GK_UPLOAD, &c->a_upload, launch_upload_batch);
+}
 // fn(stream) in the context's launch order (rare, un-batched paths), then wait for everything issued so far
 static int klt_run_sync(xrhip_klt *c, std::function<int(hipStream_t)> fn) {
+    {
+        const int rc = flush_upload(c);
+        if (rc) return rc;
+    }
     if (!c->group) {
         int rc = fn(c->stream);
         if (rc) return rc;
@@ -354,6 +393,10 @@ static int klt_run_sync(xrhip_klt *c, std::function<int(hipStream_t)> fn) {
     return XRHIP_OK;
 }
 static int klt_run(xrhip_klt *c, std::function<int(hipStream_t)> fn) {   // same without the wait
+    {
+        const int rc = flush_upload(c);
+        if (rc) return rc;
+    }
     if (!c->group) return fn(c->stream);
     return group_call(c->group, GQ_KLT, c, std::move(fn));
 }
@@ -364,6 +407,10 @@ int xrhip_klt_join_group(xrhip_klt *c, xrhip_group *g) {
     if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_klt_join_group: null context");
     if (c->group == g) return XRHIP_OK;
     // whatever the context has queued so far completes where it was queued
+    {
+        const int rc = flush_upload(c);
+        if (rc) return rc;
+    }
     if (c->group) {
         int rc = group_drain(c->group, GQ_KLT, c);
         if (rc) return rc;
@@ -555,9 +602,12 @@ static int stage_host_frame(xrhip_klt *c, const uint8_t *gray, int stride, uint8
             for (int y = 0; y < c->h; ++y) std::memcpy(buf + (size_t)y * c->w, gray + (size_t)y * stride, (size_t)c->w);
         uint8_t *dbuf = nullptr;
         XR_HIP(hipHostGetDevicePointer((void **)&dbuf, buf, 0));
+        rc = flush_upload(c);   // (an earlier frame nobody preprocessed)
+        if (rc) return rc;
         c->a_upload = UploadArgs{dbuf, c->w, dst, c->w, c->h};
         c->uploads_unsynced++;
-        return klt_issue(c, c->rq_upload, GK_UPLOAD, &c->a_upload, launch_upload_batch);
+        c->upload_pending = true;   // submitted with the frame's preprocessing (xrhip_image_preprocess), or by whoever reads the plane first
+        return XRHIP_OK;
     }
     if (c->up_busy[slot]) XR_HIP(hipEventSynchronize(c->up_done[slot]));   // three uploads ago: long done unless nothing consumed them
     uint8_t *buf = c->up_buf[slot];
@@ -673,9 +723,10 @@ int xrhip_image_upload_device(xrhip_image *im, const void *gray_dev, int stride)
     if (c->group) {
         int rc = group_wait_launched(&c->rq_upload);
         if (rc) return rc;
-        c->a_upload = UploadArgs{static_cast<const uint8_t *>(gray_dev), stride, im->raw, c->w, c->h};
-        rc = klt_issue(c, c->rq_upload, GK_UPLOAD, &c->a_upload, launch_upload_batch);
+        rc = flush_upload(c);
         if (rc) return rc;
+        c->a_upload = UploadArgs{static_cast<const uint8_t *>(gray_dev), stride, im->raw, c->w, c->h};
+        c->upload_pending = true;
     } else {
         XR_HIP(hipMemcpy2DAsync(im->raw, c->w, gray_dev, stride, c->w, c->h, hipMemcpyDeviceToDevice, c->stream));
     }
@@ -720,6 +771,14 @@ int xrhip_image_preprocess(xrhip_image *im, double clip_limit, int tiles_x, int 
             if (rc) return rc;
         }
         PrePayload &pp = c->a_pre;
+        pp.with_upload = c->upload_pending && c->a_upload.dst == im->raw;
+        if (pp.with_upload) {
+            pp.up = c->a_upload;
+            c->upload_pending = false;
+        } else {
+            int rc = flush_upload(c);
+            if (rc) return rc;
+        }
         pp.lut = la;
         PyrAArgs &pa = pp.pa;
         pa.raw = im->raw;
@@ -863,7 +922,7 @@ int xrhip_image_detect(xrhip_image *im, const double *existing_xy, int n_exist, 
     im->want_detect = false;
     {   // (a detection that rode behind a tracking launch: that request has been waited for by xrhip_image_track)
         GroupRequest *rq = c->group ? (own_launch ? &c->rq_detect : &c->rq_track) : nullptr;
-        int rc = wait_flag(&c->h_sel->seq, seq, klt_stream(c), rq, "xrhip_image_detect");
+        int rc = wait_flag(&c->h_sel->seq, seq, klt_stream(c), rq, "xrhip_image_detect", c->group ? group_side_stream(c->group, GQ_KLT) : nullptr);
         if (rc) return rc;
         c->uploads_unsynced = 0;
     }
@@ -967,6 +1026,8 @@ int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const dou
     XR_HIP(hipHostGetDevicePointer((void **)&d_seq, c->h_trk_seq, 0));
     double2 *dv_curr = (double2 *)d_pts, *dv_next = dv_curr + c->h_pts_cap;
     uint8_t *dv_status = (uint8_t *)(dv_next + c->h_pts_cap);
+    rc = flush_upload(c);
+    if (rc) return rc;
     if (c->group) {
         rc = group_wait_launched(&c->rq_track);   // (its argument block is about to be rewritten)
         if (rc) return rc;
