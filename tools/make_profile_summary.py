@@ -22,7 +22,19 @@ tag, ver, desc = sys.argv[1], sys.argv[2], sys.argv[3]
 rnd = os.environ.get("XR_ROUND", "r01")
 go = os.path.join(ROOT, "gpurun_out")
 
-c = sqlite3.connect(os.path.join(go, "prof_%s" % tag, "full_results.db"))
+import glob
+
+
+def first(*patterns):
+    """the first existing path among the glob patterns (tools/gpu.sh numbers its outputs by step: prof_TAG_3, bench_TAG_2.json)"""
+    for pat in patterns:
+        hits = sorted(glob.glob(os.path.join(go, pat)))
+        if hits:
+            return hits[0]
+    raise SystemExit("nothing matches " + " / ".join(patterns))
+
+
+c = sqlite3.connect(first("prof_%s/full_results.db" % tag, "prof_%s_*/full_results.db" % tag))
 rows = c.execute("select name,start,end from kernels order by start").fetchall()
 tot = collections.defaultdict(lambda: [0, 0])
 for n, s, e in rows:
@@ -32,7 +44,7 @@ for n, s, e in rows:
     tot[k][0] += e - s
     tot[k][1] += 1
 total = sum(t for t, _ in tot.values())
-b = open(os.path.join(go, "bench_%s.json" % tag)).read().strip().splitlines()[-1]
+b = [ln for ln in open(os.environ.get("XR_BENCH_JSON") or first("bench_%s.json" % tag, "bench_%s_[0-9]*.json" % tag)) if ln.startswith("{")][-1].strip()
 bj = json.loads(b)
 frames = max(1, tot["xrhip::k_clahe_lut"][1])   # one CLAHE pass per camera frame: counts the frames the traced command processed
 lines = ["# round %d, full pipeline %s (%s)" % (int(rnd[1:]), ver, desc), "",

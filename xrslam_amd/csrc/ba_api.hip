@@ -106,6 +106,7 @@ struct xrhip_ba {
     // speculative linearisation of window solves (spec_state_block): second stream, second set of linearisation buffers
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_mid = nullptr, ev_spec = nullptr;
+    hipEvent_t ev_marg = nullptr;   // behind a marginalisation's last copy: collecting waits for THIS work, not for the stream
     char *work_spec = nullptr;
     size_t work_spec_cap = 0;
     bool spec_outstanding = false;         // stream2 may still be writing work_spec / reading the input arena
@@ -193,7 +194,7 @@ static int launch_preint_batch(GroupRequest **r, int n, hipStream_t s, hipStream
             b.e[i] = *static_cast<const PreintArgs *>(r[base + i]->payload);
             most = std::max(most, b.e[i].n_jobs);
         }
-        hipLaunchKernelGGL(kp_preintegrate, dim3(most, 1, m), dim3(64), 0, s, b);
+        hipLaunchKernelGGL(kp_preintegrate, dim3(most, 1, m), dim3(PI_NT), 0, s, b);
     }
     XR_HIP(hipGetLastError());
     return XRHIP_OK;
@@ -246,7 +247,7 @@ static int launch_chain_batch(GroupRequest **r, int n, hipStream_t s, hipStream_
             bp.e[i] = preints[base + i];
             most_jobs = std::max(most_jobs, bp.e[i].n_jobs);
         }
-        hipLaunchKernelGGL(kp_preintegrate, dim3(most_jobs, 1, m), dim3(64), 0, s, bp);
+        hipLaunchKernelGGL(kp_preintegrate, dim3(most_jobs, 1, m), dim3(PI_NT), 0, s, bp);
     }
     XR_HIP(hipGetLastError());
     return XRHIP_OK;
@@ -812,6 +813,7 @@ void xrhip_ba_destroy(xrhip_ba *c) {
         std::fprintf(stderr, "[hostprof] speculative linearisations: %ld launched, %ld taken\n", c->spec_launched, c->spec_taken);
     hipFree(c->work_spec);
     if (c->ev_mid) hipEventDestroy(c->ev_mid);
+    if (c->ev_marg) hipEventDestroy(c->ev_marg);
     if (c->ev_spec) hipEventDestroy(c->ev_spec);
     if (c->stream2) hipStreamDestroy(c->stream2);
     hipFree(c->in.dev);
@@ -1572,6 +1574,8 @@ static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     XR_HIP(hipMemcpyAsync(hs, dsi, D8 * (size_t)R * R, hipMemcpyDeviceToHost, s));
     XR_HIP(hipMemcpyAsync(hs + (size_t)R * R, div, D8 * R, hipMemcpyDeviceToHost, s));
     XR_HIP(hipMemcpyAsync(hs + (size_t)R * R + R, dst, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+    if (!c->ev_marg) XR_HIP(hipEventCreateWithFlags(&c->ev_marg, hipEventDisableTiming));
+    XR_HIP(hipEventRecord(c->ev_marg, s));
     xrhip_ba::MargPending &mp = c->marg;
     mp.pending = true;
     mp.K = K;
@@ -1599,7 +1603,7 @@ static int marg_collect(xrhip_ba *c, double *out_sqrt_info, double *out_infovec,
     const size_t D8 = sizeof(double);
     const int R = mp.R, K = mp.K;
     double *hs = (double *)c->h_stage;
-    XR_HIP(hipStreamSynchronize(s));
+    XR_HIP(hipEventSynchronize(c->ev_marg));
     int hst[8];
     std::memcpy(hst, hs + (size_t)R * R + R, sizeof(hst));
     if (hst[0]) return xr_fail(XRHIP_ESTATE, "xrhip_ba_marginalize: singular victim block");

@@ -2780,6 +2780,11 @@ class System {   // XRSLAM::Detail + FeatureTracker + FrontendWorker: inline, or
     //    taken half a frame: FrontendWorker::work's failure branch (core/frontend_worker.cpp:75-81) -- the tracker is dropped, a fresh
     //    initialiser takes over, the published state is cleared.  Externally supplied initial states are kept.
     // tests/test_error_recovery.py injects failures through the CPU shim and requires the stream to go on tracking.
+    // Joining / leaving a group mid-sequence: nothing of this instance stays on the device across it.
+    void resolve_device_work() {
+        sync();
+        if (swt && swt->map && swt->map->marginalization_factor) resolve_marginalization(P, swt->map->marginalization_factor.get());
+    }
     void recover_after_error() noexcept {
         if (inflight_id_ != nil() && !inflight_joined_) {
             try {

@@ -315,6 +315,7 @@ void impl_set_profiling(Manager &m, int enable) {
         bind_device(m);
         xrhip_klt_set_profiling(m.sys->P.klt, enable);
         xrhip_ba_set_profiling(m.sys->P.ba, enable);
+        xrhip_ba_set_profiling(m.sys->P.ba_sub, enable);   // (localize_newframe's problem when it is solved together with refine_subwindow's)
     }
 }
 
@@ -322,7 +323,15 @@ void impl_get_ba_stats(Manager &m, void *out, int reset) {
     if (!m.sys || !out) return;
     impl_flush(m);
     bind_device(m);
-    guarded(m, [&] { xrh::hip_check(xrhip_ba_get_stats(m.sys->P.ba, static_cast<xrhip_ba_stats *>(out), reset), "xrhip_ba_get_stats"); });
+    guarded(m, [&] {
+        xrhip_ba_stats *o = static_cast<xrhip_ba_stats *>(out), sub;
+        xrh::hip_check(xrhip_ba_get_stats(m.sys->P.ba, o, reset), "xrhip_ba_get_stats");
+        xrh::hip_check(xrhip_ba_get_stats(m.sys->P.ba_sub, &sub, reset), "xrhip_ba_get_stats");
+        o->n_tiny += sub.n_tiny;   // the single-launch solves of the pair are booked on the context that began the first
+        o->n_chain_timed += sub.n_chain_timed;
+        o->ms_chain += sub.ms_chain;
+        o->bytes_chain += sub.bytes_chain;
+    });
 }
 
 void impl_get_klt_stats(Manager &m, void *out, int reset) {
@@ -488,7 +497,7 @@ int XRSLAMAmdInstanceJoinGroup(XRSLAMAmdInstance *inst, XRSLAMAmdGroup *grp) {
     int ok = 0;
     bind_device(inst->m);
     guarded(inst->m, [&] {
-        inst->m.sys->sync();
+        inst->m.sys->resolve_device_work();
         inst->m.sys->P.join_group(grp ? grp->g : nullptr);
         ok = 1;
     });

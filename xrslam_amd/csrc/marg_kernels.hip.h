@@ -420,18 +420,30 @@ __global__ __launch_bounds__(512) void km_chol(const int *__restrict__ sup_n, in
 }
 
 // ------------------------------------------------------------------------------------------------------
-// IMU pre-integration (PreIntegrator::integrate, estimation/preintegrator.cpp:7-100).  One wavefront per
-// integration; blockIdx.x selects the job.  Euler integration is a recurrence over the samples, but most of
-// its arithmetic is not: per chunk of PI_CHUNK samples
+// IMU pre-integration (PreIntegrator::integrate, estimation/preintegrator.cpp:7-100).  One workgroup of four wavefronts per
+// integration; blockIdx.x selects the job.  Euler integration is a recurrence over the samples, but most of its arithmetic is
+// not: per chunk of PI_CHUNK samples
 //   P1  lane = sample: bias-corrected rates, expmap(w dt), its transpose matrix E and the right Jacobian Jr
-//   P2  lane 0: the quaternion chain q_{n+1} = normalize(q_n * expmap_n)   (the only transcendental-free serial part)
-//   P3  lane = sample: R_n, R_n hat(a_n), q_n a_n, the 9x9 transition A_n and the noise term G_n = B_n (Q/dt) B_n^T
-//   P4  lane 0: position / velocity chain
-//   P5  lanes = matrix entries: Sigma <- A_n Sigma A_n^T + G_n and the five 3x3 bias Jacobians, sample by sample,
-//       two wavefront-local barriers per sample
-// followed by the 15x15 inverse + Cholesky of the covariance.  Samples and results live in pinned host memory
-// mapped into the device (zero-copy): an integration is a handful of doubles, so a copy engine round trip would
-// cost more than the kernel.
+//   P2  lane 0: the quaternion chain q_{n+1} = normalize(q_n * expmap_n)
+//   P3  lane = sample: R_n, R_n hat(a_n), q_n a_n and the sample's LEAF (below)
+//   P4  one lane of the last wavefront: position / velocity chain (and the early delta), beside
+//   P5  the other three wavefronts: the covariance and the bias Jacobians as a TREE over the samples
+// followed by the 15x15 inverse + Cholesky of the covariance.
+//
+// P5.  The reference adds a sample at a time (preintegrator.cpp:22-76): Sigma <- A_n Sigma A_n^T + G_n and, for the bias Jacobians
+// J = [dq_dbg 0; dp_dbg dp_dba; dv_dbg dv_dba], J <- A_n J - B_n, with A_n = [E 0 0; P I h I; V 0 I] (E = expmap(w h)^T as a matrix,
+// P = -h^2/2 R hat(a), V = -h R hat(a)).  As a loop that is two dependent 9x9 products per sample -- 0.95 us of pure latency each
+// (in-kernel timers, profiles/r04_preintegrate.md), 10 us of a 28 us kernel at eleven samples, 50 of 93 at fifty-five.  Each sample
+// is an affine map X -> A X (A^T) + (G | C); affine maps compose associatively:
+//     (A2, G2, C2) o (A1, G1, C1) = (A2 A1, A2 G1 A2^T + G2, A2 C1 + C2)
+// and the block structure of A survives the product (E = E2 E1, P = P2 E1 + P1 + t2 V1, V = V2 E1 + V1, t = t1 + t2).  So the
+// samples of a chunk are combined pairwise, level by level (log2 levels, every entry of every pair a work item of its own), and the
+// chunk's map is applied to the running one.  Same mathematics, another order of the additions: the record agrees with the
+// reference's loop to rounding (tests/test_ba_gpu.py::test_preintegration_parity: Jacobians 1e-10, sqrt_inv_cov 1e-7 -- unchanged
+// tolerances; the oracle keeps the reference's order).  The delta (dt, dq, dp, dv) is still the reference's chain, operation for
+// operation.
+// Samples and results live in pinned host memory mapped into the device (zero-copy): an integration is a handful of doubles, so a
+// copy engine round trip would cost more than the kernel.
 struct PreintJob {
     int sample_begin, sample_count;   // into samples [.][7] = t, w, a
     double t_end;
@@ -439,7 +451,11 @@ struct PreintJob {
     int bias_frame, pad_;             // >= 0: the biases are those of this frame in `state_dev` ([.][16], bg at 10, ba at 13) instead
 };
 
-constexpr int PI_CHUNK = 32;
+constexpr int PI_CHUNK = 16;
+constexpr int PI_NT = 256;        // four wavefronts
+constexpr int PI_TREE_NT = 192;   // the first three combine the tree while one lane of the fourth runs the position / velocity chain
+// a node of the tree (doubles): E, P, V (3x3 row-major), t, C = the five 3x3 blocks dq_dbg, dp_dbg, dp_dba, dv_dbg, dv_dba, G (9x9)
+constexpr int PN_E = 0, PN_P = 9, PN_V = 18, PN_T = 27, PN_C = 28, PN_G = 73, PN_SIZE = 154;
 
 // completion mailbox: the job's status word (pinned host memory) is its last store -- 1 = record complete,
 // 3 = covariance not positive definite; the host spins on it instead of synchronising the stream
@@ -447,6 +463,89 @@ __device__ __forceinline__ void preint_publish(int *status, int code) {
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) *reinterpret_cast<volatile int *>(status + blockIdx.x) = code;
+}
+
+// One level of the tree: out[k] = in[2k+1] o in[2k] for the pairs, an odd last node is carried over.  Work items are ordered by
+// kind (all pairs' entries of a kind are neighbours), so a wavefront rarely holds two kinds.  Two barriers; every thread calls.
+__device__ __forceinline__ void preint_tree_level(const double *__restrict__ in, int m, double *__restrict__ out,
+                                                  double *__restrict__ Tt, bool want_jac, bool want_cov, int tid) {
+    const int pairs = m >> 1;
+    // ---- stage 1: T = A2 G1 (81 per pair) | E, P, V (27 per pair) | t | the carried-over node
+    const int nT = want_cov ? 81 * pairs : 0, nA = 27 * pairs;
+    if (tid < PI_TREE_NT) {
+        for (int it = tid; it < nT + nA + pairs; it += PI_TREE_NT) {
+            if (it < nT) {
+                const int k = it / 81, e = it - 81 * k, i = e / 9, j = e - 9 * i, blk = i / 3;
+                const double *n1 = in + (size_t)(2 * k) * PN_SIZE, *n2 = n1 + PN_SIZE;
+                const double *a = n2 + 9 * blk + 3 * (i - 3 * blk), *G1 = n1 + PN_G;   // row i of A2's first block column
+                double v = (a[0] * G1[j] + a[1] * G1[9 + j]) + a[2] * G1[18 + j];
+                if (blk == 1) v = (v + G1[9 * i + j]) + n2[PN_T] * G1[9 * (i + 3) + j];
+                else if (blk == 2) v = v + G1[9 * i + j];
+                Tt[81 * k + e] = v;
+            } else if (it < nT + nA) {
+                const int q = it - nT, k = q / 27, e = q - 27 * k, blk = e / 9, rc = e - 9 * blk, r = rc / 3, c = rc - 3 * r;
+                const double *n1 = in + (size_t)(2 * k) * PN_SIZE, *n2 = n1 + PN_SIZE;
+                const double *a = n2 + 9 * blk + 3 * r, *E1 = n1 + PN_E;
+                double v = (a[0] * E1[c] + a[1] * E1[3 + c]) + a[2] * E1[6 + c];
+                if (blk == 1) v = (v + n1[PN_P + rc]) + n2[PN_T] * n1[PN_V + rc];
+                else if (blk == 2) v = v + n1[PN_V + rc];
+                out[(size_t)k * PN_SIZE + e] = v;
+            } else {
+                const int k = it - nT - nA;
+                const double *n1 = in + (size_t)(2 * k) * PN_SIZE;
+                out[(size_t)k * PN_SIZE + PN_T] = n1[PN_T] + n1[PN_SIZE + PN_T];
+            }
+        }
+        if (m & 1)
+            for (int e = tid; e < PN_SIZE; e += PI_TREE_NT) out[(size_t)pairs * PN_SIZE + e] = in[(size_t)(m - 1) * PN_SIZE + e];
+    }
+    __syncthreads();
+    // ---- stage 2: G = T A2^T + G2 (lower triangle, mirrored: 45 per pair) | C = A2 C1 + C2 (45 per pair)
+    const int nG = want_cov ? 45 * pairs : 0, nC = want_jac ? 45 * pairs : 0;
+    if (tid < PI_TREE_NT) {
+        for (int it = tid; it < nG + nC; it += PI_TREE_NT) {
+            if (it < nG) {
+                const int k = it / 45;
+                int li = 0, lj = it - 45 * k;
+                while (lj > li) {
+                    lj -= li + 1;
+                    ++li;
+                }
+                const double *n2 = in + (size_t)(2 * k + 1) * PN_SIZE, *T = Tt + 81 * k + 9 * li;
+                const int blk = lj / 3;
+                const double *a = n2 + 9 * blk + 3 * (lj - 3 * blk);   // row lj of A2's first block column
+                double v = (T[0] * a[0] + T[1] * a[1]) + T[2] * a[2];
+                if (blk == 1) v = (v + T[lj]) + T[lj + 3] * n2[PN_T];
+                else if (blk == 2) v = v + T[lj];
+                v += n2[PN_G + 9 * li + lj];
+                double *Go = out + (size_t)k * PN_SIZE + PN_G;
+                Go[9 * li + lj] = v;
+                Go[9 * lj + li] = v;
+            } else {
+                const int q = it - nG, k = q / 45, e = q - 45 * k, blk = e / 9, rc = e - 9 * blk, r = rc / 3, c = rc - 3 * r;
+                const double *n1 = in + (size_t)(2 * k) * PN_SIZE, *n2 = n1 + PN_SIZE;
+                const double *C1 = n1 + PN_C, *C2 = n2 + PN_C;
+                const double t2 = n2[PN_T];
+                double v;
+                if (blk == 0) {          // dq_dbg = E2 dq_dbg + .
+                    const double *a = n2 + PN_E + 3 * r;
+                    v = ((a[0] * C1[c] + a[1] * C1[3 + c]) + a[2] * C1[6 + c]) + C2[rc];
+                } else if (blk == 1) {   // dp_dbg = P2 dq_dbg + dp_dbg + t2 dv_dbg + .
+                    const double *a = n2 + PN_P + 3 * r;
+                    v = ((((a[0] * C1[c] + a[1] * C1[3 + c]) + a[2] * C1[6 + c]) + C1[9 + rc]) + t2 * C1[27 + rc]) + C2[9 + rc];
+                } else if (blk == 2) {   // dp_dba = dp_dba + t2 dv_dba + .
+                    v = (C1[18 + rc] + t2 * C1[36 + rc]) + C2[18 + rc];
+                } else if (blk == 3) {   // dv_dbg = V2 dq_dbg + dv_dbg + .
+                    const double *a = n2 + PN_V + 3 * r;
+                    v = (((a[0] * C1[c] + a[1] * C1[3 + c]) + a[2] * C1[6 + c]) + C1[27 + rc]) + C2[27 + rc];
+                } else {                 // dv_dba = dv_dba + .
+                    v = C1[36 + rc] + C2[36 + rc];
+                }
+                out[(size_t)k * PN_SIZE + PN_C + e] = v;
+            }
+        }
+    }
+    __syncthreads();
 }
 
 // blockIdx.x = job of an entry, blockIdx.z = entry: a launch carries the batches of up to XB contexts (group.hip.h)
@@ -461,7 +560,7 @@ struct PreintArgs {
     const double *state_dev;
     int n_jobs;
 };
-__global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
+__global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch) {
     const PreintArgs &ea = batch.e[blockIdx.z];
     if ((int)blockIdx.x >= ea.n_jobs) return;
     const PreintJob *__restrict__ jobs = ea.jobs;
@@ -471,20 +570,20 @@ __global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
     double *__restrict__ out = ea.out;
     int *__restrict__ status = ea.status;
     const double *__restrict__ state_dev = ea.state_dev;
-    __shared__ double cov[15][15], Tm[9][9], inv[15][15];
-    __shared__ double Jac[5][9], Jnew[5][9];   // dq_dbg, dp_dbg, dp_dba, dv_dbg, dv_dba
-    __shared__ double sA[PI_CHUNK][81], sG[PI_CHUNK][81];
-    __shared__ double sE[PI_CHUNK][9], sJr[PI_CHUNK][9], sR[PI_CHUNK][9], sRa[PI_CHUNK][9];
+    __shared__ double cov[15][15], inv[15][15];
+    __shared__ double nodeA[(PI_CHUNK + 1) * PN_SIZE], nodeB[((PI_CHUNK + 2) / 2) * PN_SIZE], Tt[((PI_CHUNK + 1) / 2) * 81];
+    __shared__ double sE[PI_CHUNK][9], sJr[PI_CHUNK][9];
     __shared__ double sEq[PI_CHUNK][4], sQ[PI_CHUNK][4], sQa[PI_CHUNK][3], sDt[PI_CHUNK];
     __shared__ double sq[4], sp3[3], sv3[3], sdt;
     __shared__ double Dinv[CH_NB][CH_NB + 1];
     __shared__ double noise36[36];   // the inputs live in pinned host memory: fetch each of them exactly once
+    __shared__ int s_pd;
     const PreintJob job = jobs[blockIdx.x];
     const int tid = threadIdx.x;
     if (tid < 36) noise36[tid] = noise_host[tid];
     double *o = out + (size_t)blockIdx.x * XRHIP_IMU_DIM;
-    for (int e = tid; e < 225; e += 64) cov[e / 15][e % 15] = 0.0;
-    if (tid < 45) Jac[tid / 9][tid % 9] = 0.0;
+    // the running map starts as the identity: E = I, P = V = 0, t = 0, C = 0, G = 0
+    for (int e = tid; e < PN_SIZE; e += PI_NT) nodeA[e] = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
     if (tid == 0) {
         sq[0] = sq[1] = sq[2] = 0.0;
         sq[3] = 1.0;
@@ -496,19 +595,47 @@ __global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
     const V3 bg = bsrc ? v3(bsrc[0], bsrc[1], bsrc[2]) : v3(job.bg[0], job.bg[1], job.bg[2]);
     const V3 ba = bsrc ? v3(bsrc[3], bsrc[4], bsrc[5]) : v3(job.ba[0], job.ba[1], job.ba[2]);
     double walk = 0.0;   // lanes 46..63: one entry of the two 3x3 bias random-walk blocks
+    const int wb = (tid - 46) / 9, wr = (tid - 46) - 9 * wb;
+    // this lane's sample of the first chunk (t, w, a, the next sample's t); the next chunk's is fetched a chunk ahead -- a read of
+    // pinned host memory is ~2 us, paid once instead of once per chunk
+    double cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tid < min(PI_CHUNK, job.sample_count)) {
+        const double *smp = samples + (size_t)(job.sample_begin + tid) * 7;
+        for (int i = 0; i < 7; ++i) cur[i] = smp[i];
+        cur[7] = (tid + 1 < job.sample_count) ? smp[7] : job.t_end;
+    }
     __syncthreads();
+#ifdef XRHIP_KPROF_PRINT
+    long long kt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kt0 = wall_clock64(), ktl = kt0;
+#define PI_T(k)                                \
+    do {                                       \
+        const long long n_ = wall_clock64();   \
+        kt[k] += n_ - ktl;                     \
+        ktl = n_;                              \
+    } while (0)
+#else
+#define PI_T(k) \
+    do {        \
+    } while (0)
+#endif
+    const double wnoise = (tid >= 46 && tid < 64) ? noise36[18 + 9 * wb + wr] : 0.0;
+    double *res = nodeA;   // where the running map is
     for (int n0 = 0; n0 < job.sample_count; n0 += PI_CHUNK) {
         const int nc = min(PI_CHUNK, job.sample_count - n0);
         // ---- P1
         V3 a = v3(0, 0, 0);
         double dt = 0.0;
-        if (tid < nc) {
-            const int n = n0 + tid;
+        double nxt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (tid < PI_CHUNK && n0 + PI_CHUNK + tid < job.sample_count) {
+            const int n = n0 + PI_CHUNK + tid;
             const double *smp = samples + (size_t)(job.sample_begin + n) * 7;
-            const double t1 = (n + 1 < job.sample_count) ? smp[7] : job.t_end;
-            dt = t1 - smp[0];
-            const V3 w = v3(smp[1], smp[2], smp[3]) - bg;
-            a = v3(smp[4], smp[5], smp[6]) - ba;
+            for (int i = 0; i < 7; ++i) nxt[i] = smp[i];
+            nxt[7] = (n + 1 < job.sample_count) ? smp[7] : job.t_end;
+        }
+        if (tid < nc) {
+            dt = cur[7] - cur[0];
+            const V3 w = v3(cur[1], cur[2], cur[3]) - bg;
+            a = v3(cur[4], cur[5], cur[6]) - ba;
             const Q4 e = expmap(w * dt);
             sEq[tid][0] = e.x; sEq[tid][1] = e.y; sEq[tid][2] = e.z; sEq[tid][3] = e.w;
             sDt[tid] = dt;
@@ -521,6 +648,7 @@ __global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
             }
         }
         __syncthreads();
+        PI_T(0);
         // ---- P2
         if (tid == 0) {
             Q4 q = Q4{sq[0], sq[1], sq[2], sq[3]};
@@ -529,30 +657,34 @@ __global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
                 q = q_normalized(q_mul(q, Q4{sEq[n][0], sEq[n][1], sEq[n][2], sEq[n][3]}));
             }
             sq[0] = q.x; sq[1] = q.y; sq[2] = q.z; sq[3] = q.w;
+        } else if (tid >= 64 && res != nodeA) {
+            // the running map moves to the head of the level-0 list (the wavefronts that are not on the quaternion chain do it)
+            for (int e = tid - 64; e < PN_SIZE; e += PI_NT - 64) nodeA[e] = res[e];
         }
         __syncthreads();
-        // ---- P3
+        PI_T(1);
+        // ---- P3: the leaf of sample n = tid is node 1 + tid of the level-0 list
         if (tid < nc) {
             const Q4 q = Q4{sQ[tid][0], sQ[tid][1], sQ[tid][2], sQ[tid][3]};
             const V3 qa = q_rot(q, a);
             sQa[tid][0] = qa.x; sQa[tid][1] = qa.y; sQa[tid][2] = qa.z;
             if (want_cov || want_jac) {
+                double *leaf = nodeA + (size_t)(1 + tid) * PN_SIZE;
                 const M3 R = q_mat(q), ra = R * hat(a);
+                const double hh = 0.5 * dt * dt;
                 for (int i = 0; i < 9; ++i) {
-                    sR[tid][i] = R.m[i];
-                    sRa[tid][i] = ra.m[i];
+                    leaf[PN_E + i] = sE[tid][i];
+                    leaf[PN_P + i] = -hh * ra.m[i];
+                    leaf[PN_V + i] = -dt * ra.m[i];
+                    leaf[PN_C + i] = -dt * sJr[tid][i];
+                    leaf[PN_C + 9 + i] = 0.0;
+                    leaf[PN_C + 18 + i] = -hh * R.m[i];
+                    leaf[PN_C + 27 + i] = 0.0;
+                    leaf[PN_C + 36 + i] = -dt * R.m[i];
                 }
+                leaf[PN_T] = dt;
                 if (want_cov) {
                     double Bm[9][6];
-                    for (int i = 0; i < 9; ++i)
-                        for (int j = 0; j < 9; ++j) {
-                            double v = (i == j) ? 1.0 : 0.0;
-                            if (i < 3 && j < 3) v = sE[tid][3 * i + j];                                // (ES_Q, ES_Q)
-                            if (i >= 6 && j < 3) v = -dt * ra.m[3 * (i - 6) + j];                      // (ES_V, ES_Q)
-                            if (i >= 3 && i < 6 && j < 3) v = -0.5 * dt * dt * ra.m[3 * (i - 3) + j];  // (ES_P, ES_Q)
-                            if (i >= 3 && i < 6 && j >= 6) v = (i - 3 == j - 6) ? dt : 0.0;            // (ES_P, ES_V)
-                            sA[tid][9 * i + j] = v;
-                        }
                     for (int i = 0; i < 9; ++i)
                         for (int j = 0; j < 6; ++j) {
                             double v = 0.0;
@@ -577,14 +709,15 @@ __global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
                         for (int j = 0; j < 9; ++j) {
                             double u = 0;
                             for (int k = 0; k < 6; ++k) u += Um[i][k] * Bm[j][k];
-                            sG[tid][9 * i + j] = u;
+                            leaf[PN_G + 9 * i + j] = u;
                         }
                 }
             }
         }
         __syncthreads();
-        // ---- P4
-        if (tid == 0) {
+        PI_T(2);
+        // ---- P4 (one lane of the last wavefront, beside the tree)
+        if (tid == PI_TREE_NT) {
             V3 pv = v3(sp3[0], sp3[1], sp3[2]), vv = v3(sv3[0], sv3[1], sv3[2]);
             double T = sdt;
             for (int n = 0; n < nc; ++n) {
@@ -597,8 +730,8 @@ __global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
             sp3[0] = pv.x; sp3[1] = pv.y; sp3[2] = pv.z;
             sv3[0] = vv.x; sv3[1] = vv.y; sv3[2] = vv.z;
             sdt = T;
-            // The delta (dt, dq, dp, dv) is final with the last chunk's chains -- the covariance recursion, the bias Jacobians and the
-            // 15x15 factorisation below do not touch it.  It is published now, with a mailbox of its own: the feature tracker reads the
+            // The delta (dt, dq, dp, dv) is final with the last chunk's chains -- the covariance, the bias Jacobians and the 15x15
+            // factorisation below do not touch it.  It is published now, with a mailbox of its own: the feature tracker reads the
             // delta of the interval the backend's integration covers (same samples, same biases) as soon as it exists, instead of
             // integrating the interval a second time without Jacobians (xrhip_ba_preintegrate_early).  Same values as at the end.
             if (n0 + PI_CHUNK >= job.sample_count) {
@@ -610,74 +743,23 @@ __global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
                 *reinterpret_cast<volatile int *>(ea.early + blockIdx.x) = 1;
             }
         }
-        // ---- P5 (all lane -> matrix-entry mappings are loop invariants, computed before the sample loop)
+        // ---- P5: the chunk's leaves behind the running map, combined level by level (A -> B -> A ...)
         if (want_cov || want_jac) {
-            // Tm = A cov: entries e0 = tid and (for tid < 17) e1 = tid + 64 of the 9x9 product
-            const int i0 = tid / 9, j0 = tid - 9 * i0;
-            const int e1 = tid + 64, i1 = e1 / 9, j1 = e1 - 9 * i1;
-            const bool has1 = e1 < 81;
-            // cov = Tm A^T + G: lower-triangle entry (li, lj <= li) for tid < 45
-            int li = 0, lj = tid;
-            while (lj > li) {
-                lj -= li + 1;
-                ++li;
+            if (want_cov && tid >= 46 && tid < 64)
+                for (int n = 0; n < nc; ++n) walk += wnoise * sDt[n];
+            const double *in = nodeA;
+            double *outb = nodeB;
+            for (int m = nc + 1; m > 1; m = (m + 1) >> 1) {
+                preint_tree_level(in, m, outb, Tt, want_jac, want_cov, tid);
+                double *t = const_cast<double *>(in);
+                in = outb;
+                outb = t;
             }
-            const bool low = tid < 45;
-            const int wb = (tid - 46) / 9, wr = (tid - 46) - 9 * wb;
-            const double wnoise = (tid >= 46) ? noise36[18 + 9 * wb + wr] : 0.0;
-            const int jm = tid / 9, ji = (tid % 9) / 3, jj = tid % 3;
-            for (int n = 0; n < nc; ++n) {
-                const double h = sDt[n];
-                const double *An = sA[n];
-                if (want_cov) {
-                    // A = [E 0 0; P I dt I; V 0 I] (3x3 blocks): three products with the rotation rows of cov plus the
-                    // identity / dt terms, in the order of the dense row sum
-                    {
-                        const double *a = An + 9 * i0;
-                        double s2 = (a[0] * cov[0][j0] + a[1] * cov[1][j0]) + a[2] * cov[2][j0];
-                        if (i0 >= 3 && i0 < 6) s2 = (s2 + cov[i0][j0]) + h * cov[i0 + 3][j0];
-                        else if (i0 >= 6) s2 = s2 + cov[i0][j0];
-                        Tm[i0][j0] = s2;
-                    }
-                    if (has1) {
-                        const double *a = An + 9 * i1;
-                        double s2 = (a[0] * cov[0][j1] + a[1] * cov[1][j1]) + a[2] * cov[2][j1];
-                        if (i1 >= 3 && i1 < 6) s2 = (s2 + cov[i1][j1]) + h * cov[i1 + 3][j1];
-                        else if (i1 >= 6) s2 = s2 + cov[i1][j1];
-                        Tm[i1][j1] = s2;
-                    }
-                    walk += wnoise * h;
-                }
-                if (want_jac && low) {
-                    const double *Ra = sRa[n], *E = sE[n], *dR = sR[n], *Jr = sJr[n];
-                    double radq = 0, edq = 0;   // (dR hat(a) dq_dbg)_ij and (E dq_dbg)_ij
-                    for (int k = 0; k < 3; ++k) {
-                        radq += Ra[3 * ji + k] * Jac[0][3 * k + jj];
-                        edq += E[3 * ji + k] * Jac[0][3 * k + jj];
-                    }
-                    double v;
-                    if (jm == 1) v = Jac[1][3 * ji + jj] + h * Jac[3][3 * ji + jj] - 0.5 * h * h * radq;        // dp_dbg
-                    else if (jm == 2) v = Jac[2][3 * ji + jj] + h * Jac[4][3 * ji + jj] - 0.5 * h * h * dR[3 * ji + jj];   // dp_dba
-                    else if (jm == 3) v = Jac[3][3 * ji + jj] - h * radq;                                       // dv_dbg
-                    else if (jm == 4) v = Jac[4][3 * ji + jj] - h * dR[3 * ji + jj];                            // dv_dba
-                    else v = edq - h * Jr[3 * ji + jj];                                                         // dq_dbg
-                    Jnew[jm][3 * ji + jj] = v;
-                }
-                __syncthreads();
-                if (want_cov && low) {
-                    const double *a = An + 9 * lj;   // row lj of A
-                    double s2 = (Tm[li][0] * a[0] + Tm[li][1] * a[1]) + Tm[li][2] * a[2];
-                    if (lj >= 3 && lj < 6) s2 = (s2 + Tm[li][lj]) + Tm[li][lj + 3] * h;
-                    else if (lj >= 6) s2 = s2 + Tm[li][lj];
-                    s2 += sG[n][9 * li + lj];
-                    cov[li][lj] = s2;
-                    cov[lj][li] = s2;
-                }
-                if (want_jac && low) Jac[jm][3 * ji + jj] = Jnew[jm][3 * ji + jj];
-                __syncthreads();
-            }
+            res = const_cast<double *>(in);
         }
+        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
         __syncthreads();
+        PI_T(4);
     }
     // outputs
     if (tid == 0) {
@@ -688,23 +770,25 @@ __global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
             o[8 + i] = sv3[i];
         }
     }
-    if (tid < 45) o[11 + tid] = Jac[tid / 9][tid % 9];
+    if (tid < 45) o[11 + tid] = want_jac ? res[PN_C + tid] : 0.0;
     if (!want_cov) {
-        for (int e = tid; e < 225; e += 64) o[56 + e] = 0.0;
+        for (int e = tid; e < 225; e += PI_NT) o[56 + e] = 0.0;
         preint_publish(status, 1);
         return;
     }
-    if (tid >= 46) {
-        const int e = tid - 46, blk = e / 9, r = e - 9 * blk;
-        cov[9 + 3 * blk + r / 3][9 + 3 * blk + r % 3] = walk;
+    for (int e = tid; e < 225; e += PI_NT) {
+        const int i = e / 15, j = e - 15 * i;
+        cov[i][j] = (i < 9 && j < 9) ? res[PN_G + 9 * i + j] : 0.0;
     }
+    __syncthreads();
+    if (tid >= 46 && tid < 64) cov[9 + 3 * wb + wr / 3][9 + 3 * wb + wr % 3] = walk;
     // sqrt_inv_cov = LLT(cov^-1).matrixL().transpose().  With J the index reversal and J cov J = Lr Lr^T,
     // cov^-1 = (J Lr^-T J)(J Lr^-1 J) and J Lr^-T J is lower triangular with a positive diagonal, i.e. it IS that
     // Cholesky factor: sqrt_inv_cov = J Lr^-1 J.  One register-resident 15x15 factorisation + triangular inverse
     // (chol_diag_wave) instead of a pivoted Gauss-Jordan inverse followed by a Cholesky.
     __syncthreads();
     double *Pr = &inv[0][0];   // packed lower triangle of J cov J
-    for (int e = tid; e < 120; e += 64) {
+    for (int e = tid; e < 120; e += PI_NT) {
         int i = 0, j = e;
         while (j > i) {
             j -= i + 1;
@@ -713,17 +797,28 @@ __global__ __launch_bounds__(64) void kp_preintegrate(Batch<PreintArgs> batch) {
         Pr[tri_idx(i, j)] = cov[14 - i][14 - j];
     }
     __syncthreads();
-    const bool pd = chol_diag_wave(Pr, 0, 15, Dinv, tid);
+    PI_T(5);
+    if (tid < 64) {
+        const bool pd = chol_diag_wave(Pr, 0, 15, Dinv, tid);
+        if (tid == 0) s_pd = pd ? 1 : 0;
+    }
     __syncthreads();
-    if (!pd) {
+    PI_T(6);
+    if (!s_pd) {
         preint_publish(status, 3);
         return;
     }
-    for (int e = tid; e < 225; e += 64) {
+    for (int e = tid; e < 225; e += PI_NT) {
         const int i = e / 15, j = e - 15 * i;
         o[56 + e] = (j >= i) ? Dinv[14 - i][14 - j] : 0.0;   // upper triangular, row-major
     }
     preint_publish(status, 1);
+#ifdef XRHIP_KPROF_PRINT
+    PI_T(7);
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.z == 0)
+        printf("kp_preintegrate samples %d jac %d: P1 %lld P2 %lld P3 %lld tree+P4 %lld pack %lld chol %lld out %lld total %lld x10ns\n",
+               job.sample_count, want_jac, kt[0], kt[1], kt[2], kt[4], kt[5], kt[6], kt[7], wall_clock64() - kt0);
+#endif
 }
 
 }   // namespace xrhip
