@@ -1708,7 +1708,9 @@ static int preint_args(xrhip_ba *c, int n_jobs, int jac, int cov, const double *
     XR_HIP(hipHostGetDevicePointer((void **)&Dv, c->h_stage, 0));
     *a = PreintArgs{(const PreintJob *)(Dv + c->preint_o_jobs), (const double *)(Dv + c->preint_o_smp), (const double *)(Dv + c->preint_o_noise),
                     jac ? 1 : 0, cov ? 1 : 0, (double *)(Dv + c->preint_o_out), (int *)(Dv + c->preint_o_st),
-                    (int *)(Dv + c->preint_o_st) + n_jobs, state_dev, n_jobs};
+                    (int *)(Dv + c->preint_o_st) + n_jobs, state_dev, n_jobs, {}};
+    const PreintJob *hj = (const PreintJob *)(c->h_stage + c->preint_o_jobs);
+    for (int k = 0; k < std::min(n_jobs, PI_HEAD); ++k) a->head[k] = hj[k];
     return XRHIP_OK;
 }
 

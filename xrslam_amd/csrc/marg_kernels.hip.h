@@ -421,27 +421,31 @@ __global__ __launch_bounds__(512) void km_chol(const int *__restrict__ sup_n, in
 
 // ------------------------------------------------------------------------------------------------------
 // IMU pre-integration (PreIntegrator::integrate, estimation/preintegrator.cpp:7-100).  One workgroup of four wavefronts per
-// integration; blockIdx.x selects the job.  Euler integration is a recurrence over the samples, but most of its arithmetic is
-// not: per chunk of PI_CHUNK samples
-//   P1  lane = sample: bias-corrected rates, expmap(w dt), its transpose matrix E and the right Jacobian Jr
-//   P2  lane 0: the quaternion chain q_{n+1} = normalize(q_n * expmap_n)
-//   P3  lane = sample: R_n, R_n hat(a_n), q_n a_n and the sample's LEAF (below)
-//   P4  one lane of the last wavefront: position / velocity chain (and the early delta), beside
-//   P5  the other three wavefronts: the covariance and the bias Jacobians as a TREE over the samples
+// integration; blockIdx.x selects the job.  Euler integration is a recurrence over the samples, but only two short chains of it
+// are: per chunk of PI_CHUNK samples
+//   P1  lane = sample: bias-corrected rates, expmap(w dt) and the right Jacobian Jr
+//   P2  one lane: the quaternion chain q_{n+1} = normalize(q_n * expmap_n) interleaved with the position / velocity chain (and the
+//       early delta)
+//   P3  lane = sample: R_n, R_{n+1} Jr_n
+//   P5  covariance and bias Jacobians in CLOSED FORM over the samples (below): rows of the samples' terms, then a sum over samples
 // followed by the 15x15 inverse + Cholesky of the covariance.
 //
-// P5.  The reference adds a sample at a time (preintegrator.cpp:22-76): Sigma <- A_n Sigma A_n^T + G_n and, for the bias Jacobians
-// J = [dq_dbg 0; dp_dbg dp_dba; dv_dbg dv_dba], J <- A_n J - B_n, with A_n = [E 0 0; P I h I; V 0 I] (E = expmap(w h)^T as a matrix,
-// P = -h^2/2 R hat(a), V = -h R hat(a)).  As a loop that is two dependent 9x9 products per sample -- 0.95 us of pure latency each
-// (in-kernel timers, profiles/r04_preintegrate.md), 10 us of a 28 us kernel at eleven samples, 50 of 93 at fifty-five.  Each sample
-// is an affine map X -> A X (A^T) + (G | C); affine maps compose associatively:
-//     (A2, G2, C2) o (A1, G1, C1) = (A2 A1, A2 G1 A2^T + G2, A2 C1 + C2)
-// and the block structure of A survives the product (E = E2 E1, P = P2 E1 + P1 + t2 V1, V = V2 E1 + V1, t = t1 + t2).  So the
-// samples of a chunk are combined pairwise, level by level (log2 levels, every entry of every pair a work item of its own), and the
-// chunk's map is applied to the running one.  Same mathematics, another order of the additions: the record agrees with the
-// reference's loop to rounding (tests/test_ba_gpu.py::test_preintegration_parity: Jacobians 1e-10, sqrt_inv_cov 1e-7 -- unchanged
-// tolerances; the oracle keeps the reference's order).  The delta (dt, dq, dp, dv) is still the reference's chain, operation for
-// operation.
+// P5.  The reference adds a sample at a time (preintegrator.cpp:22-76): Sigma <- A_n Sigma A_n^T + B_n (Q / h_n) B_n^T and, for the
+// bias Jacobians J = [dq_dbg 0; dp_dbg dp_dba; dv_dbg dv_dba], J <- A_n J - B_n, with A_n = [E_n 0 0; -h^2/2 R_n hat(a_n), I, h I;
+// -h R_n hat(a_n), 0, I], E_n = expmap(w_n h_n)^T as a matrix, B_n = [h Jr_n, 0; 0, h^2/2 R_n; 0, h R_n].  As a loop that is two
+// dependent 9x9 products per sample -- 0.95 us of latency each (in-kernel timers, profiles/r04_preintegrate.md): 10 us of a 28 us
+// kernel at eleven samples, 50 of 93 at fifty-five.  Unrolled, Sigma_N = sum_n Phi_n B_n (Q / h_n) B_n^T Phi_n^T and
+// J_N = -sum_n Phi_n B_n with Phi_n = A_{N-1} ... A_{n+1} -- and that product has a closed form in quantities the two chains
+// produce anyway: with R_{m+1} = R_m expmap(w_m h_m) and R hat(a) R^T = hat(R a),
+//     Phi_n = [ R_N^T R_s, 0, 0;  -hat(dp) R_s, I, tau I;  -hat(dv) R_s, 0, I ],   s = n + 1,
+//     tau = t_N - t_s,  dv = v_N - v_s,  dp = p_N - p_s - v_s tau
+// (the sums over m of h_m R_m a_m and of h_m (v_m - v_s) + h_m^2/2 R_m a_m ARE the velocity and position chains).  So every sample's
+// D_n = Phi_n B_n (9x6, five non-zero 3x3 blocks) is independent of the others: one work item per (sample, row), then one per
+// entry of Sigma / J summing over the samples.  A job longer than a chunk composes its chunks' maps (A, G, C) like the reference
+// composes samples ((A2, G2, C2) o (A1, G1, C1) = (A2 A1, A2 G1 A2^T + G2, A2 C1 + C2), preint_compose).  Same mathematics, another
+// order of operations: the record agrees with the reference's loop to rounding (tests/test_ba_gpu.py::test_preintegration_parity:
+// Jacobians 1e-10, sqrt_inv_cov 1e-7 -- unchanged tolerances; the oracle keeps the reference's loop).  The delta (dt, dq, dp, dv) is
+// still the reference's chain, operation for operation.
 // Samples and results live in pinned host memory mapped into the device (zero-copy): an integration is a handful of doubles, so a
 // copy engine round trip would cost more than the kernel.
 struct PreintJob {
@@ -451,10 +455,12 @@ struct PreintJob {
     int bias_frame, pad_;             // >= 0: the biases are those of this frame in `state_dev` ([.][16], bg at 10, ba at 13) instead
 };
 
-constexpr int PI_CHUNK = 16;
+constexpr int PI_CHUNK = 32;
 constexpr int PI_NT = 256;        // four wavefronts
-constexpr int PI_TREE_NT = 192;   // the first three combine the tree while one lane of the fourth runs the position / velocity chain
-// a node of the tree (doubles): E, P, V (3x3 row-major), t, C = the five 3x3 blocks dq_dbg, dp_dbg, dp_dba, dv_dbg, dv_dba, G (9x9)
+constexpr int PI_TREE_NT = 192;   // preint_compose runs on the first three
+constexpr int PI_HEAD = 2;        // jobs carried in the argument block (a batch is one or two jobs, bar the initialiser's)
+constexpr int PI_NE = 111;        // per-chunk sums: 45 (gyroscope part of Sigma, lower triangle) + 21 (accelerometer part: p, v rows) + 45 (J)
+// a map (doubles): E, P, V (3x3 row-major), t, C = the five 3x3 blocks dq_dbg, dp_dbg, dp_dba, dv_dbg, dv_dba, G (9x9)
 constexpr int PN_E = 0, PN_P = 9, PN_V = 18, PN_T = 27, PN_C = 28, PN_G = 73, PN_SIZE = 154;
 
 // completion mailbox: the job's status word (pinned host memory) is its last store -- 1 = record complete,
@@ -465,9 +471,9 @@ __device__ __forceinline__ void preint_publish(int *status, int code) {
     if (threadIdx.x == 0) *reinterpret_cast<volatile int *>(status + blockIdx.x) = code;
 }
 
-// One level of the tree: out[k] = in[2k+1] o in[2k] for the pairs, an odd last node is carried over.  Work items are ordered by
-// kind (all pairs' entries of a kind are neighbours), so a wavefront rarely holds two kinds.  Two barriers; every thread calls.
-__device__ __forceinline__ void preint_tree_level(const double *__restrict__ in, int m, double *__restrict__ out,
+// out[k] = in[2k+1] o in[2k] for the pairs of a list of maps (an odd last one is carried over); the kernel composes a chunk's map with
+// the running one (m = 2).  Work items are ordered by kind, so a wavefront rarely holds two kinds.  Two barriers; every thread calls.
+__device__ __forceinline__ void preint_compose(const double *__restrict__ in, int m, double *__restrict__ out,
                                                   double *__restrict__ Tt, bool want_jac, bool want_cov, int tid) {
     const int pairs = m >> 1;
     // ---- stage 1: T = A2 G1 (81 per pair) | E, P, V (27 per pair) | t | the carried-over node
@@ -559,6 +565,9 @@ struct PreintArgs {
     int *early;   // per job: 1 once the delta part of its record (doubles 0..10) is in `out` (the full record follows; `status` says when)
     const double *state_dev;
     int n_jobs;
+    // the first jobs of the batch again, by value: they arrive with the kernel arguments, so their samples can be requested at once
+    // instead of behind a read of `jobs` over the host link (two dependent ~2 us round trips became one)
+    PreintJob head[PI_HEAD];
 };
 __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch) {
     const PreintArgs &ea = batch.e[blockIdx.z];
@@ -567,23 +576,27 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
     const double *__restrict__ samples = ea.samples;
     const double *__restrict__ noise_host = ea.noise_host;
     const int want_jac = ea.want_jac, want_cov = ea.want_cov;
+    const bool cj = want_cov || want_jac;
     double *__restrict__ out = ea.out;
     int *__restrict__ status = ea.status;
     const double *__restrict__ state_dev = ea.state_dev;
-    __shared__ double cov[15][15], inv[15][15];
-    __shared__ double nodeA[(PI_CHUNK + 1) * PN_SIZE], nodeB[((PI_CHUNK + 2) / 2) * PN_SIZE], Tt[((PI_CHUNK + 1) / 2) * 81];
-    __shared__ double sE[PI_CHUNK][9], sJr[PI_CHUNK][9];
-    __shared__ double sEq[PI_CHUNK][4], sQ[PI_CHUNK][4], sQa[PI_CHUNK][3], sDt[PI_CHUNK];
-    __shared__ double sq[4], sp3[3], sv3[3], sdt;
+    __shared__ double inv[15][15], sWalk[18];
+    __shared__ double maps[2][2 * PN_SIZE], Tt[81];   // [buffer][running map | this chunk's map]
+    __shared__ double sJr[PI_CHUNK][9], sRn[PI_CHUNK][9], sM[PI_CHUNK][9];
+    __shared__ double sDg[PI_CHUNK][27], sUg[PI_CHUNK][27], sDa[PI_CHUNK][18], sUa[PI_CHUNK][18];
+    __shared__ double sPart[2][PI_NE];
+    __shared__ double sEq[PI_CHUNK][4], sQ[PI_CHUNK][4], sAc[PI_CHUNK][3], sDt[PI_CHUNK];
+    __shared__ double sVn[PI_CHUNK][3], sPn[PI_CHUNK][3], sTn[PI_CHUNK];   // v, p, t AFTER sample n
+    __shared__ double sq[4], sp3[3], sv3[3], sdt, s0v[3], s0p[3], s0t, sRN[9];
     __shared__ double Dinv[CH_NB][CH_NB + 1];
     __shared__ double noise36[36];   // the inputs live in pinned host memory: fetch each of them exactly once
     __shared__ int s_pd;
-    const PreintJob job = jobs[blockIdx.x];
+    const PreintJob job = (blockIdx.x < PI_HEAD) ? ea.head[blockIdx.x] : jobs[blockIdx.x];
     const int tid = threadIdx.x;
     if (tid < 36) noise36[tid] = noise_host[tid];
     double *o = out + (size_t)blockIdx.x * XRHIP_IMU_DIM;
-    // the running map starts as the identity: E = I, P = V = 0, t = 0, C = 0, G = 0
-    for (int e = tid; e < PN_SIZE; e += PI_NT) nodeA[e] = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
+    // the running map starts as the identity: E = I, P = V = 0, t = 0, C = 0, G = 0 (what a job without samples reports)
+    for (int e = tid; e < PN_SIZE; e += PI_NT) maps[0][e] = (e == 0 || e == 4 || e == 8) ? 1.0 : 0.0;
     if (tid == 0) {
         sq[0] = sq[1] = sq[2] = 0.0;
         sq[3] = 1.0;
@@ -619,12 +632,11 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
     } while (0)
 #endif
     const double wnoise = (tid >= 46 && tid < 64) ? noise36[18 + 9 * wb + wr] : 0.0;
-    double *res = nodeA;   // where the running map is
+    const bool several = job.sample_count > PI_CHUNK;   // chunks are composed: their maps need the A part too
+    int rb = 0;   // maps[rb][0 ..] is the running map
     for (int n0 = 0; n0 < job.sample_count; n0 += PI_CHUNK) {
         const int nc = min(PI_CHUNK, job.sample_count - n0);
         // ---- P1
-        V3 a = v3(0, 0, 0);
-        double dt = 0.0;
         double nxt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (tid < PI_CHUNK && n0 + PI_CHUNK + tid < job.sample_count) {
             const int n = n0 + PI_CHUNK + tid;
@@ -633,100 +645,45 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
             nxt[7] = (n + 1 < job.sample_count) ? smp[7] : job.t_end;
         }
         if (tid < nc) {
-            dt = cur[7] - cur[0];
+            const double dt = cur[7] - cur[0];
             const V3 w = v3(cur[1], cur[2], cur[3]) - bg;
-            a = v3(cur[4], cur[5], cur[6]) - ba;
+            const V3 a = v3(cur[4], cur[5], cur[6]) - ba;
             const Q4 e = expmap(w * dt);
             sEq[tid][0] = e.x; sEq[tid][1] = e.y; sEq[tid][2] = e.z; sEq[tid][3] = e.w;
+            sAc[tid][0] = a.x; sAc[tid][1] = a.y; sAc[tid][2] = a.z;
             sDt[tid] = dt;
-            if (want_cov || want_jac) {
-                const M3 Em = q_mat(q_conj(e)), J = right_jacobian(w * dt);
-                for (int i = 0; i < 9; ++i) {
-                    sE[tid][i] = Em.m[i];
-                    sJr[tid][i] = J.m[i];
-                }
+            if (cj) {
+                const M3 J = right_jacobian(w * dt);
+                for (int i = 0; i < 9; ++i) sJr[tid][i] = J.m[i];
             }
         }
         __syncthreads();
         PI_T(0);
-        // ---- P2
+        // ---- P2: the two chains, ONE lane.  The quaternion chain and the position / velocity chain are independent streams of
+        // dependent double-precision operations (q_{n+1} and q_n a_n both hang off q_n only); a lone lane issues a dependent
+        // instruction every ~34 cycles and an independent one every ~8, so interleaved they cost what the longer one does
+        // alone (they were 3.6 + 2.8 us one after the other at eleven samples).  Each chain's operations and their order are
+        // the reference's.
         if (tid == 0) {
             Q4 q = Q4{sq[0], sq[1], sq[2], sq[3]};
-            for (int n = 0; n < nc; ++n) {
-                sQ[n][0] = q.x; sQ[n][1] = q.y; sQ[n][2] = q.z; sQ[n][3] = q.w;
-                q = q_normalized(q_mul(q, Q4{sEq[n][0], sEq[n][1], sEq[n][2], sEq[n][3]}));
-            }
-            sq[0] = q.x; sq[1] = q.y; sq[2] = q.z; sq[3] = q.w;
-        } else if (tid >= 64 && res != nodeA) {
-            // the running map moves to the head of the level-0 list (the wavefronts that are not on the quaternion chain do it)
-            for (int e = tid - 64; e < PN_SIZE; e += PI_NT - 64) nodeA[e] = res[e];
-        }
-        __syncthreads();
-        PI_T(1);
-        // ---- P3: the leaf of sample n = tid is node 1 + tid of the level-0 list
-        if (tid < nc) {
-            const Q4 q = Q4{sQ[tid][0], sQ[tid][1], sQ[tid][2], sQ[tid][3]};
-            const V3 qa = q_rot(q, a);
-            sQa[tid][0] = qa.x; sQa[tid][1] = qa.y; sQa[tid][2] = qa.z;
-            if (want_cov || want_jac) {
-                double *leaf = nodeA + (size_t)(1 + tid) * PN_SIZE;
-                const M3 R = q_mat(q), ra = R * hat(a);
-                const double hh = 0.5 * dt * dt;
-                for (int i = 0; i < 9; ++i) {
-                    leaf[PN_E + i] = sE[tid][i];
-                    leaf[PN_P + i] = -hh * ra.m[i];
-                    leaf[PN_V + i] = -dt * ra.m[i];
-                    leaf[PN_C + i] = -dt * sJr[tid][i];
-                    leaf[PN_C + 9 + i] = 0.0;
-                    leaf[PN_C + 18 + i] = -hh * R.m[i];
-                    leaf[PN_C + 27 + i] = 0.0;
-                    leaf[PN_C + 36 + i] = -dt * R.m[i];
-                }
-                leaf[PN_T] = dt;
-                if (want_cov) {
-                    double Bm[9][6];
-                    for (int i = 0; i < 9; ++i)
-                        for (int j = 0; j < 6; ++j) {
-                            double v = 0.0;
-                            if (i < 3 && j < 3) v = dt * sJr[tid][3 * i + j];                          // (ES_Q, bg)
-                            if (i >= 6 && j >= 3) v = dt * R.m[3 * (i - 6) + (j - 3)];                 // (ES_V, ba)
-                            if (i >= 3 && i < 6 && j >= 3) v = 0.5 * dt * dt * R.m[3 * (i - 3) + (j - 3)];   // (ES_P, ba)
-                            Bm[i][j] = v;
-                        }
-                    const double inv_dt = 1.0 / fmax(dt, 1.0e-7);
-                    double Um[9][6];
-                    for (int i = 0; i < 9; ++i)
-                        for (int j = 0; j < 6; ++j) {
-                            double u = 0;
-                            if (j < 3) {
-                                for (int k = 0; k < 3; ++k) u += Bm[i][k] * (noise36[3 * k + j] * inv_dt);
-                            } else {
-                                for (int k = 0; k < 3; ++k) u += Bm[i][3 + k] * (noise36[9 + 3 * k + (j - 3)] * inv_dt);
-                            }
-                            Um[i][j] = u;
-                        }
-                    for (int i = 0; i < 9; ++i)
-                        for (int j = 0; j < 9; ++j) {
-                            double u = 0;
-                            for (int k = 0; k < 6; ++k) u += Um[i][k] * Bm[j][k];
-                            leaf[PN_G + 9 * i + j] = u;
-                        }
-                }
-            }
-        }
-        __syncthreads();
-        PI_T(2);
-        // ---- P4 (one lane of the last wavefront, beside the tree)
-        if (tid == PI_TREE_NT) {
             V3 pv = v3(sp3[0], sp3[1], sp3[2]), vv = v3(sv3[0], sv3[1], sv3[2]);
             double T = sdt;
+            s0p[0] = pv.x; s0p[1] = pv.y; s0p[2] = pv.z;
+            s0v[0] = vv.x; s0v[1] = vv.y; s0v[2] = vv.z;
+            s0t = T;
             for (int n = 0; n < nc; ++n) {
+                sQ[n][0] = q.x; sQ[n][1] = q.y; sQ[n][2] = q.z; sQ[n][3] = q.w;
                 const double h = sDt[n];
-                const V3 qa = v3(sQa[n][0], sQa[n][1], sQa[n][2]);
+                const V3 qa = q_rot(q, v3(sAc[n][0], sAc[n][1], sAc[n][2]));
+                q = q_normalized(q_mul(q, Q4{sEq[n][0], sEq[n][1], sEq[n][2], sEq[n][3]}));
                 pv = pv + vv * h + qa * (0.5 * h * h);
                 vv = vv + qa * h;
                 T = T + h;
+                sPn[n][0] = pv.x; sPn[n][1] = pv.y; sPn[n][2] = pv.z;
+                sVn[n][0] = vv.x; sVn[n][1] = vv.y; sVn[n][2] = vv.z;
+                sTn[n] = T;
             }
+            sq[0] = q.x; sq[1] = q.y; sq[2] = q.z; sq[3] = q.w;
             sp3[0] = pv.x; sp3[1] = pv.y; sp3[2] = pv.z;
             sv3[0] = vv.x; sv3[1] = vv.y; sv3[2] = vv.z;
             sdt = T;
@@ -736,31 +693,151 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
             // integrating the interval a second time without Jacobians (xrhip_ba_preintegrate_early).  Same values as at the end.
             if (n0 + PI_CHUNK >= job.sample_count) {
                 o[0] = T;
-                o[1] = sq[0]; o[2] = sq[1]; o[3] = sq[2]; o[4] = sq[3];
+                o[1] = q.x; o[2] = q.y; o[3] = q.z; o[4] = q.w;
                 o[5] = pv.x; o[6] = pv.y; o[7] = pv.z;
                 o[8] = vv.x; o[9] = vv.y; o[10] = vv.z;
                 __threadfence_system();
                 *reinterpret_cast<volatile int *>(ea.early + blockIdx.x) = 1;
             }
         }
-        // ---- P5: the chunk's leaves behind the running map, combined level by level (A -> B -> A ...)
-        if (want_cov || want_jac) {
-            if (want_cov && tid >= 46 && tid < 64)
-                for (int n = 0; n < nc; ++n) walk += wnoise * sDt[n];
-            const double *in = nodeA;
-            double *outb = nodeB;
-            for (int m = nc + 1; m > 1; m = (m + 1) >> 1) {
-                preint_tree_level(in, m, outb, Tt, want_jac, want_cov, tid);
-                double *t = const_cast<double *>(in);
-                in = outb;
-                outb = t;
+        __syncthreads();
+        PI_T(1);
+        // ---- P3: lane = sample: R_n and M_n = R_{n+1} Jr_n; one more lane: R_N of this chunk
+        if (cj) {
+            if (tid < nc) {
+                const M3 R = q_mat(Q4{sQ[tid][0], sQ[tid][1], sQ[tid][2], sQ[tid][3]});
+                for (int i = 0; i < 9; ++i) sRn[tid][i] = R.m[i];
+                const double *qn = (tid + 1 < nc) ? sQ[tid + 1] : sq;
+                const M3 R1 = q_mat(Q4{qn[0], qn[1], qn[2], qn[3]});
+                M3 J;
+                for (int i = 0; i < 9; ++i) J.m[i] = sJr[tid][i];
+                const M3 M = R1 * J;
+                for (int i = 0; i < 9; ++i) sM[tid][i] = M.m[i];
+            } else if (tid == 64) {
+                const M3 R = q_mat(Q4{sq[0], sq[1], sq[2], sq[3]});
+                for (int i = 0; i < 9; ++i) sRN[i] = R.m[i];
             }
-            res = const_cast<double *>(in);
+        }
+        if (want_cov && tid >= 46 && tid < 64)
+            for (int n = 0; n < nc; ++n) walk += wnoise * sDt[n];
+        __syncthreads();
+        PI_T(3);
+        if (cj) {
+            double *chunk = (n0 == 0) ? maps[rb] : maps[rb] + PN_SIZE;   // the first chunk's map IS the running map
+            const V3 vN = v3(sv3[0], sv3[1], sv3[2]), pN = v3(sp3[0], sp3[1], sp3[2]);
+            const double tN = sdt;
+            // ---- P5a: row i of D_n = Phi_n B_n and of U_n = D_n (Q / h_n); rows 0..8 the gyroscope columns, 9..14 the accelerometer's
+            for (int it = tid; it < 15 * nc; it += PI_NT) {
+                const int n = it / 15, i = it - 15 * n;
+                const double h = sDt[n], inv_dt = 1.0 / fmax(h, 1.0e-7);
+                const double tau = tN - sTn[n];
+                if (i < 9) {
+                    const double *M = sM[n];
+                    double d0, d1, d2;
+                    if (i < 3) {
+                        d0 = (sRN[i] * M[0] + sRN[3 + i] * M[3]) + sRN[6 + i] * M[6];
+                        d1 = (sRN[i] * M[1] + sRN[3 + i] * M[4]) + sRN[6 + i] * M[7];
+                        d2 = (sRN[i] * M[2] + sRN[3 + i] * M[5]) + sRN[6 + i] * M[8];
+                        d0 = h * d0;
+                        d1 = h * d1;
+                        d2 = h * d2;
+                    } else {
+                        const V3 vs = v3(sVn[n][0], sVn[n][1], sVn[n][2]);
+                        V3 x = vN - vs;
+                        if (i < 6) x = (pN - v3(sPn[n][0], sPn[n][1], sPn[n][2])) - vs * tau;
+                        const int r = (i < 6) ? i - 3 : i - 6;
+                        // row r of hat(x): the two other components with signs; (hat(x) M)[r][c] = xa * M[ka][c] + xb * M[kb][c]
+                        const int ka = (r + 1) % 3, kb = (r + 2) % 3;
+                        const double xa = -get(x, kb), xb = get(x, ka);
+                        d0 = -h * (xa * M[3 * ka] + xb * M[3 * kb]);
+                        d1 = -h * (xa * M[3 * ka + 1] + xb * M[3 * kb + 1]);
+                        d2 = -h * (xa * M[3 * ka + 2] + xb * M[3 * kb + 2]);
+                    }
+                    double *D = sDg[n] + 3 * i, *U = sUg[n] + 3 * i;
+                    D[0] = d0; D[1] = d1; D[2] = d2;
+                    for (int k = 0; k < 3; ++k)
+                        U[k] = (d0 * (noise36[k] * inv_dt) + d1 * (noise36[3 + k] * inv_dt)) + d2 * (noise36[6 + k] * inv_dt);
+                } else {
+                    const int r = i - 9, rr = (r < 3) ? r : r - 3;
+                    const double coef = (r < 3) ? (0.5 * h * h + tau * h) : h;
+                    const double *R = sRn[n] + 3 * rr;
+                    const double d0 = coef * R[0], d1 = coef * R[1], d2 = coef * R[2];
+                    double *D = sDa[n] + 3 * r, *U = sUa[n] + 3 * r;
+                    D[0] = d0; D[1] = d1; D[2] = d2;
+                    for (int k = 0; k < 3; ++k)
+                        U[k] = (d0 * (noise36[9 + k] * inv_dt) + d1 * (noise36[12 + k] * inv_dt)) + d2 * (noise36[15 + k] * inv_dt);
+                }
+            }
+            __syncthreads();
+            // ---- P5b: the sums over the samples, two halves per entry
+            const int half = (nc + 1) >> 1;
+            if (tid < 2 * PI_NE) {
+                const int part = tid / PI_NE, e = tid - PI_NE * part;
+                const int nb = part ? half : 0, ne = part ? nc : half;
+                double acc = 0.0;
+                if (e < 66) {
+                    if (want_cov) {
+                        const bool gy = e < 45;
+                        int li = 0, lj = gy ? e : e - 45;
+                        while (lj > li) {
+                            lj -= li + 1;
+                            ++li;
+                        }
+                        for (int n = nb; n < ne; ++n) {
+                            const double *U = (gy ? sUg[n] : sUa[n]) + 3 * li, *D = (gy ? sDg[n] : sDa[n]) + 3 * lj;
+                            acc += (U[0] * D[0] + U[1] * D[1]) + U[2] * D[2];
+                        }
+                    }
+                } else if (want_jac) {
+                    const int q = e - 66, blk = q / 9, rc = q - 9 * blk;   // dq_dbg, dp_dbg, dp_dba, dv_dbg, dv_dba
+                    const bool gy = blk != 2 && blk != 4;
+                    const int off = (blk == 0) ? rc : (blk == 1) ? 9 + rc : (blk == 2) ? rc : (blk == 3) ? 18 + rc : 9 + rc;
+                    for (int n = nb; n < ne; ++n) acc += gy ? sDg[n][off] : sDa[n][off];
+                }
+                sPart[part][e] = acc;
+            }
+            __syncthreads();
+            // ---- P5c: this chunk's map
+            if (tid < 81) {
+                const int i = tid / 9, j = tid - 9 * i, li = max(i, j), lj = min(i, j);
+                double g = sPart[0][li * (li + 1) / 2 + lj] + sPart[1][li * (li + 1) / 2 + lj];
+                if (lj >= 3) {
+                    const int ai = li - 3, aj = lj - 3;
+                    g += sPart[0][45 + ai * (ai + 1) / 2 + aj] + sPart[1][45 + ai * (ai + 1) / 2 + aj];
+                }
+                chunk[PN_G + tid] = g;
+            } else if (tid < 81 + 45) {
+                const int e = tid - 81;
+                chunk[PN_C + e] = -(sPart[0][66 + e] + sPart[1][66 + e]);
+            } else if (tid < 81 + 45 + 27 && several) {
+                // A part = Phi at the chunk's first state: [R_N^T R_0, 0, 0; -hat(dp) R_0, I, tau I; -hat(dv) R_0, 0, I]
+                const int e = tid - 126, blk = e / 9, rc = e - 9 * blk, r = rc / 3, c = rc - 3 * r;
+                const double *R0 = sRn[0];
+                const V3 v0 = v3(s0v[0], s0v[1], s0v[2]);
+                const double tau = tN - s0t;
+                double v;
+                if (blk == 0) {
+                    v = (sRN[r] * R0[c] + sRN[3 + r] * R0[3 + c]) + sRN[6 + r] * R0[6 + c];
+                } else {
+                    V3 x = vN - v0;
+                    if (blk == 1) x = (pN - v3(s0p[0], s0p[1], s0p[2])) - v0 * tau;
+                    const int ka = (r + 1) % 3, kb = (r + 2) % 3;
+                    v = -(-get(x, kb) * R0[3 * ka + c] + get(x, ka) * R0[3 * kb + c]);
+                }
+                chunk[e] = v;
+            } else if (tid == 81 + 45 + 27 && several) {
+                chunk[PN_T] = tN - s0t;
+            }
+            __syncthreads();
+            if (n0 > 0) {   // running <- chunk o running
+                preint_compose(maps[rb], 2, maps[rb ^ 1], Tt, want_jac, want_cov, tid);
+                rb ^= 1;
+            }
         }
         for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
-        __syncthreads();
         PI_T(4);
     }
+    const double *res = maps[rb];
     // outputs
     if (tid == 0) {
         o[0] = sdt;
@@ -776,25 +853,24 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
         preint_publish(status, 1);
         return;
     }
-    for (int e = tid; e < 225; e += PI_NT) {
-        const int i = e / 15, j = e - 15 * i;
-        cov[i][j] = (i < 9 && j < 9) ? res[PN_G + 9 * i + j] : 0.0;
-    }
-    __syncthreads();
-    if (tid >= 46 && tid < 64) cov[9 + 3 * wb + wr / 3][9 + 3 * wb + wr % 3] = walk;
+    if (tid >= 46 && tid < 64) sWalk[tid - 46] = walk;
     // sqrt_inv_cov = LLT(cov^-1).matrixL().transpose().  With J the index reversal and J cov J = Lr Lr^T,
     // cov^-1 = (J Lr^-T J)(J Lr^-1 J) and J Lr^-T J is lower triangular with a positive diagonal, i.e. it IS that
     // Cholesky factor: sqrt_inv_cov = J Lr^-1 J.  One register-resident 15x15 factorisation + triangular inverse
     // (chol_diag_wave) instead of a pivoted Gauss-Jordan inverse followed by a Cholesky.
     __syncthreads();
-    double *Pr = &inv[0][0];   // packed lower triangle of J cov J
+    double *Pr = &inv[0][0];   // packed lower triangle of J cov J; cov = [G 0; 0 blockdiag(walk_bg, walk_ba)]
     for (int e = tid; e < 120; e += PI_NT) {
         int i = 0, j = e;
         while (j > i) {
             j -= i + 1;
             ++i;
         }
-        Pr[tri_idx(i, j)] = cov[14 - i][14 - j];
+        const int a = 14 - i, b = 14 - j;   // a <= b
+        double v = 0.0;
+        if (b < 9) v = res[PN_G + 9 * a + b];
+        else if (a >= 9 && (a - 9) / 3 == (b - 9) / 3) v = sWalk[9 * ((a - 9) / 3) + 3 * ((a - 9) % 3) + (b - 9) % 3];
+        Pr[tri_idx(i, j)] = v;
     }
     __syncthreads();
     PI_T(5);
@@ -816,8 +892,8 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
 #ifdef XRHIP_KPROF_PRINT
     PI_T(7);
     if (tid == 0 && blockIdx.x == 0 && blockIdx.z == 0)
-        printf("kp_preintegrate samples %d jac %d: P1 %lld P2 %lld P3 %lld tree+P4 %lld pack %lld chol %lld out %lld total %lld x10ns\n",
-               job.sample_count, want_jac, kt[0], kt[1], kt[2], kt[4], kt[5], kt[6], kt[7], wall_clock64() - kt0);
+        printf("kp_preintegrate samples %d jac %d: P1 %lld chains %lld P3 %lld - %lld P5 %lld pack %lld chol %lld out %lld total %lld x10ns\n",
+               job.sample_count, want_jac, kt[0], kt[1], kt[2], kt[3], kt[4], kt[5], kt[6], kt[7], wall_clock64() - kt0);
 #endif
 }
 
