@@ -328,7 +328,11 @@ def main():
         # Every instance owns several HIP streams; the runtime multiplexes them over this many hardware queues.  MORE is not better:
         # measured at 8 sequences (profiles/r03_multi_sequence.md) 8 queues 3590 frames/s, 16: 3528, 24: 2557, 32: 2040, 48: 1438 --
         # beyond a handful the scheduler time-slices the queues and every kernel stretches (k_pyrdown 4.7 -> 22 us at 24 queues).
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        # With the instance group (round 4) the launches that matter are batched on the group's own streams and the right number is
+        # the smallest: 2 queues per priority level, the group's streams at high priority -- two hardware queues for the batches of
+        # all members, two for the members' own window solves and marginalisations (xrslam_amd/csrc/group_api.hip;
+        # profiles/r04_multi_sequence.md: 10 sequences 5690 frames/s, against 4960 with 4 unprioritised queues).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if args.no_group else "2")
     rank, world = int(os.environ.get("RANK", "0")), int(env_world or "1")
 
     from xrslam_amd.harness import scene

@@ -1232,7 +1232,12 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     }
     // ---- speculative linearisation (window solves, see spec_state_block in ba_kernels.hip.h): the second buffer set mirrors the workspace
     static const bool spec_off = std::getenv("XRHIP_NO_SPEC") != nullptr;   // development switch
-    const bool spec = !spec_off && !use_chain && wide_first(d);
+    static const bool spec_in_group = std::getenv("XRHIP_GROUP_SPEC") != nullptr;   // development switch (A/B)
+    // Not in an instance group: the speculation buys one sequence ~0.1 ms per keyframe with a second stream and four extra launches per
+    // round -- with several sequences on the device those launches take queue turns from the other members' kernels (8 sequences:
+    // 3996 -> 4326 frames/s without it, profiles/r04_multi_sequence.md).  (Same results either way: the speculated linearisation is
+    // the one the round would have computed.)
+    const bool spec = !spec_off && !use_chain && wide_first(d) && !(c->group && !spec_in_group);
     BaPtrs p2 = p;
     if (spec) {
         const size_t extra = sizeof(double) * (16 * (size_t)d.F + (size_t)std::max(d.L, 1)) + sizeof(BaCtl) + 1024;

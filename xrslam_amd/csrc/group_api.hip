@@ -62,6 +62,7 @@ struct xrhip_group {
     std::atomic<int> busy_elsewhere{0};   // members inside a window solve (their own stream): they will not submit for a while
     int linger_us = 0;                    // hold a batch back this long for the members that have not submitted yet (XRHIP_GROUP_LINGER_US)
     int linger_queues = 7;                // bit k: queue k lingers (XRHIP_GROUP_LINGER_QUEUES)
+    int preint_shares = -1;               // >= 0: the pre-integration queue launches into that queue's stream
     bool per_kind = true;                 // a batch waits for the previous batch OF ITS KIND only (XRHIP_GROUP_PER_KIND=0: for any batch)
     std::mutex stats_m;
     xrhip_group_stats stats;
@@ -324,21 +325,40 @@ int xrhip_group_create(xrhip_group **out) {
     if (const char *e = std::getenv("XRHIP_GROUP_LINGER_US")) g->linger_us = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("XRHIP_GROUP_LINGER_QUEUES")) g->linger_queues = std::atoi(e);
     if (const char *e = std::getenv("XRHIP_GROUP_PER_KIND")) g->per_kind = std::atoi(e) != 0;
-    // (Stream priorities were tried: the runtime gives a priority level hardware queues of its own, so the group's batches no longer
-    // queue behind a member's 100 us factorisation -- but more than ~4 hardware queues in use at once stretch EVERY kernel by 20-27 us
-    // on this part, tools/multiq.hip; measured 4026 against 4260 frames/s at 8 sequences.  XRHIP_GROUP_PRIORITY=1 switches them on.)
+    // Hardware queues.  The device runs about four of them side by side; with more in use every kernel of every queue waits 20-27 us
+    // for its queue's turn (tools/multiq.hip), with fewer the runtime maps unrelated streams onto one queue and they wait for each
+    // other.  The runtime gives every stream PRIORITY LEVEL a pool of GPU_MAX_HW_QUEUES queues of its own -- so with
+    // GPU_MAX_HW_QUEUES=2 (set before the process's first HIP call; bench.py does) and the group's streams at high
+    // priority the four queues are split by role: two carry the batched per-frame launches of all members, two the members' own
+    // window solves and marginalisations (a batch no longer queues behind a member's 100 us factorisation, and nothing is
+    // time-sliced).  Measured at 10 sequences: 5690 frames/s against 4960 with four unprioritised queues and 4186 with priorities
+    // on top of four (eight in use) -- profiles/r04_multi_sequence.md.  Hence: priorities on exactly when the pool is that small
+    // (XRHIP_GROUP_PRIORITY=0/1 overrides).  The inverse split (members' streams high) starves the batches: 4078.
     int prio_low = 0, prio_high = 0;
-    const bool use_prio = std::getenv("XRHIP_GROUP_PRIORITY") != nullptr &&
-                          hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) == hipSuccess && prio_high != prio_low;
-    const bool side_stream = std::getenv("XRHIP_GROUP_NO_SIDE_STREAM") == nullptr;
+    const char *qe = std::getenv("GPU_MAX_HW_QUEUES"), *pe = std::getenv("XRHIP_GROUP_PRIORITY");
+    const bool want_prio = pe ? std::atoi(pe) != 0 : (qe && std::atoi(qe) > 0 && std::atoi(qe) <= 2);
+    const bool use_prio = want_prio && hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) == hipSuccess && prio_high != prio_low;
+    // XRHIP_GROUP_SIDE_STREAM=1: the front end's Harris passes on a second stream of the KLT queue (nobody waits for them before the
+    // next frame's tracks have been digested).  Off by default: one more stream competing for the hardware queues cost more than the
+    // overlap gave (10 sequences: 5272 with, 5518 without).
+    const bool side_stream = std::getenv("XRHIP_GROUP_SIDE_STREAM") != nullptr;
     for (int k = 0; k < GQ_COUNT; ++k) {
         GroupQueueState &Q = g->qs[k];
         Q.index = k;
         if (use_prio) XR_HIP(hipStreamCreateWithPriority(&Q.stream, hipStreamNonBlocking, prio_high));
         else XR_HIP(hipStreamCreateWithFlags(&Q.stream, hipStreamNonBlocking));
-        // the front end's Harris passes ride behind a tracking launch but nobody waits for them before the next frame's tracks have
-        // been digested: on a stream of their own they do not hold up the next batch of frames / tracking launches
         if (k == GQ_KLT && side_stream) XR_HIP(hipStreamCreateWithFlags(&Q.side, hipStreamNonBlocking));
+    }
+    // XRHIP_GROUP_PREINT_STREAM=klt|chain: the pre-integration queue launches into that queue's stream instead of one of its own (its
+    // thread, its batches and its gate stay): with two hardware queues for the group's three streams the runtime pairs two of them
+    // anyway -- this picks the pair.
+    if (const char *e = std::getenv("XRHIP_GROUP_PREINT_STREAM")) {
+        const int to = !std::strcmp(e, "klt") ? GQ_KLT : (!std::strcmp(e, "chain") ? GQ_CHAIN : -1);
+        if (to >= 0) {
+            hipStreamDestroy(g->qs[GQ_PREINT].stream);
+            g->qs[GQ_PREINT].stream = g->qs[to].stream;
+            g->preint_shares = to;
+        }
     }
     for (int k = 0; k < GQ_COUNT; ++k) {
         GroupQueueState *Q = &g->qs[k];
@@ -363,14 +383,15 @@ int xrhip_group_destroy(xrhip_group *g) {
     for (int k = 0; k < GQ_COUNT; ++k) {
         GroupQueueState &Q = g->qs[k];
         Q.th.join();
-        hipStreamSynchronize(Q.stream);
+        const bool own_stream = !(k == GQ_PREINT && g->preint_shares >= 0);
+        if (own_stream) hipStreamSynchronize(Q.stream);
         if (Q.side) hipStreamSynchronize(Q.side);
         for (auto &f : Q.inflight) {
             if (f.begin) hipEventDestroy(f.begin);
             hipEventDestroy(f.end);
         }
         for (hipEvent_t e : Q.free_events) hipEventDestroy(e);
-        hipStreamDestroy(Q.stream);
+        if (own_stream) hipStreamDestroy(Q.stream);
         if (Q.side) hipStreamDestroy(Q.side);
     }
     delete g;
