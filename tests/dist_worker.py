@@ -15,9 +15,11 @@ from xrslam_amd.harness.dist import RunGroup  # noqa: E402
 
 
 def eleven():
-    """BASELINE config 4 in miniature: 11 independent sequences round-robined over the ranks, each rank driving its share
-    two at a time through instance-scoped entry points (some GPUs of the 8-GPU node carry two sequences), here with the
-    CPU reference build of the library; the only communication is the barrier pair and the metrics reduction."""
+    """BASELINE config 4 in miniature: 11 independent sequences round-robined over the ranks; a rank's share runs as the members of
+    ONE instance group (XRSLAMAmdGroup: on a GPU they share their per-frame launches; a rank of the 8-GPU node carries one or two
+    sequences, a rank of a smaller world more), every member on a thread of its own through the instance-scoped entry points --
+    here with the CPU reference build of the library (same API; its group has nothing to batch); the only communication is the
+    barrier pair and the metrics reduction."""
     import threading
 
     from xrslam_amd.harness import runner, scene
@@ -31,8 +33,11 @@ def eleven():
     t0 = time.perf_counter()
     stats = {}
 
+    grp = runner.Group(lib)
+
     def work(k):
-        s = runner.Session(lib, seqs[k], slam_yaml=os.path.join(ROOT, "configs", "bench_slam_150.yaml"), sensor_yaml=sensor, instance=True)
+        s = runner.Session(lib, seqs[k], slam_yaml=os.path.join(ROOT, "configs", "bench_slam_150.yaml"), sensor_yaml=sensor, instance=True,
+                           group=grp)
         while s.step():
             pass
         s.flush()
@@ -43,12 +48,12 @@ def eleven():
         P = P[np.abs(P[:, 4:8]).sum(1) > 0]        # results before the first tracked frame are the all-zero pose (detail.cpp:165-168)
         idx = np.clip(np.searchsorted(seqs[k]["cam_t"], P[:, 0] - 1e-6), 0, n - 1)
         stats[k] = (len(P), float(((P[:, 1:4] - seqs[k]["states"][idx, 4:7]) ** 2).sum()))
-    for i in range(0, len(mine), 2):               # two live instances per rank at a time
-        th = [threading.Thread(target=work, args=(k,)) for k in mine[i:i + 2]]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+    th = [threading.Thread(target=work, args=(k,)) for k in mine]      # the rank's whole share: one group, a thread per member
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    grp.close()
     g.barrier()
     sec = time.perf_counter() - t0
     assert sorted(stats) == sorted(mine)

@@ -164,6 +164,58 @@ def test_rotation_prior_factors_parity(ctx, bo):
     _solve_both(ctx, bo, p2, "rot")
 
 
+def _stiff_prior(pd, rng, residual_scale):
+    """a dense upper-triangular sqrt_info whose rows span six decades (bias / velocity rows of a long-lived prior), linearised a
+    millimetre away from the current state, with an infovec that leaves only `residual_scale` of S delta standing: the state is close
+    to the prior's minimiser, S delta and infovec cancel"""
+    K = len(pd.frame_state)
+    n = 15 * (K - 1)
+    lin = pd.frame_state[:K - 1].copy()
+    lin[:, 4:16] -= 1.0e-3 * rng.randn(K - 1, 12)
+    delta = np.zeros((K - 1, 15))
+    delta[:, 3:] = pd.frame_state[:K - 1, 4:16] - lin[:, 4:16]        # p, v, bg, ba: plain differences; rotations coincide
+    S = np.triu(rng.randn(n, n)) * np.logspace(0, 6, n)[rng.permutation(n), None]
+    S[np.arange(n), np.arange(n)] += np.sign(S[np.arange(n), np.arange(n)]) * np.abs(S).sum(1) * 0.05
+    Sd = S @ delta.ravel()
+    infovec = -Sd + residual_scale * np.abs(Sd).max() * rng.randn(n)
+    return dict(frames=np.arange(K - 1), sqrt_info=S, infovec=infovec, lin=lin), S, delta.ravel(), infovec
+
+
+def test_prior_gradient_of_a_stiff_prior_near_its_minimum(ctx, bo):
+    """ADVICE r3 (low, ba_kernels.hip.h: prior row blocks): the prior's gradient is formed as t = Lambda delta + c0 (Lambda = S^T S,
+    c0 = S^T infovec, once per solve) instead of S^T (S delta + infovec).  Equal on paper; near the prior's minimum S delta ~ -infovec
+    and the first form's rounding error is ~eps |S|^T |S| |delta| where the second's is ~eps |S|^T |r|.  This pins what that costs:
+    (a) prior-only problem, gradient against the direct product in extended precision: within the first form's own forward bound,
+    and the loss against the direct form stays below 1e-6 of the gradient's scale; (b) a window problem carrying such a prior:
+    the trust-region record (iterations, accepted steps, termination) and the states are the oracle's, which forms S^T r."""
+    rng = np.random.RandomState(7)
+    pd, _ = bs.make_window(K=5, L=40, seed=11)
+    prior, S, delta, infovec = _stiff_prior(pd, rng, 1.0e-7)
+    K = len(pd.frame_state)
+    only = abi.BaProblemData(pd.frame_state, np.zeros(K, np.uint8), bs.CAM_EXT, bs.IMU_EXT, bs.SQRT_INV_COV, np.zeros(0), None,
+                             obs=None, imu=None, prior=prior)
+    dev = ctx.debug_linearize(only)
+    L_ = np.longdouble
+    r = S.astype(L_) @ delta.astype(L_) + infovec.astype(L_)
+    g_ref = np.asarray(S.astype(L_).T @ r, np.float64)
+    g_dev = dev["g"][:15 * (K - 1)]
+    sel = np.concatenate([15 * f + np.arange(3, 15) for f in range(K - 1)])      # p, v, bg, ba rows (identity Jacobians)
+    eps = np.finfo(np.float64).eps
+    n = S.shape[0]
+    bound_lambda = 4 * n * eps * (np.abs(S).T @ (np.abs(S) @ np.abs(delta)) + np.abs(S).T @ np.abs(infovec))
+    err = np.abs(g_dev - g_ref)[sel]
+    assert np.all(err <= bound_lambda[sel]), (err.max(), bound_lambda[sel].min())
+    scale = np.abs(g_ref[sel]).max()
+    assert err.max() <= 1.0e-6 * scale, (err.max(), scale)
+    np.testing.assert_allclose(dev["cost"], 0.5 * float(r @ r), rtol=1e-9)
+    # (b) the same kind of prior inside a window solve
+    pd2, _ = bs.make_window(K=6, L=60, seed=12)
+    prior2, _, _, _ = _stiff_prior(pd2, rng, 1.0e-4)
+    pd2._set_prior(prior2)
+    sm_o, sm_h = _solve_both(ctx, bo, pd2, "stiff_prior", rtol=1e-6)
+    assert sm_h.iterations >= 2
+
+
 def test_trivial_and_invalid_problems(ctx):
     from xrslam_amd._lib import XrhipError
     pd, _ = bs.make_window(K=4, L=30, seed=10)

@@ -699,6 +699,14 @@ static int wait_mailbox(xrhip_ba *c, int seq, hipStream_t publisher = nullptr, G
 }
 
 static long long g_kprof[32];   // accumulated in-kernel phase ticks (all zero unless built with -DXRHIP_KPROF)
+// development aid: XRHIP_KPROF_MIN_NA / _MAX_NA restrict the accumulated phase timers to solves of that many active unknowns
+static void kprof_accumulate(const BaCtl &ctl, int na) {
+    static const int min_na = std::getenv("XRHIP_KPROF_MIN_NA") ? std::atoi(std::getenv("XRHIP_KPROF_MIN_NA")) : 0;
+    static const int max_na = std::getenv("XRHIP_KPROF_MAX_NA") ? std::atoi(std::getenv("XRHIP_KPROF_MAX_NA")) : 1 << 30;
+    if (na < min_na || na > max_na) return;
+    for (int i = 0; i < 31; ++i) g_kprof[i] += ctl.prof[i];
+    g_kprof[31] += 1;   // solves counted
+}
 
 extern "C" {
 
@@ -891,7 +899,11 @@ int xrhip_ba_solve_begin(xrhip_ba *c, const xrhip_ba_problem *P) {
     int rc = validate(P);
     if (rc) return rc;
     static const bool off = std::getenv("XRHIP_NO_CHAINED_SOLVES") != nullptr;   // development switch (A/B, parity)
-    if (off || c->preint_deferred || !any_free_block(P)) return 0;
+    // Not for a member of an instance group: there the pair travels as ONE request, and a batch that carries pairs holds the chain
+    // queue for two kernels (216 us) while the next batch waits -- two single batches with the host round trip in between serve
+    // ten sequences better (5718 -> 5861 frames/s, profiles/r04_multi_sequence.md).  The caller falls back to xrhip_ba_solve.
+    static const bool in_group = std::getenv("XRHIP_GROUP_CHAINED_SOLVES") != nullptr;   // development switch (A/B)
+    if (off || (c->group && !in_group) || c->preint_deferred || !any_free_block(P)) return 0;
     xrhip_ba::Begun &B = c->begun;
     B.t0 = std::chrono::steady_clock::now();
     Ext cam, imu;
@@ -951,6 +963,7 @@ int xrhip_ba_solve_end(xrhip_ba *c, xrhip_ba_summary *summary) {
     std::memcpy(B.P->frame_state, c->h_out, sizeof(double) * 16 * B.d.F);
     if (B.e0) c->pending_chain.push_back({B.e0, B.e1, chain_bytes(B.d, *c->h_ctl)});
     c->stats.n_tiny++;
+    kprof_accumulate(*c->h_ctl, B.d.na);
     fill_summary(*c->h_ctl, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - B.t0).count(), summary);
     c->dims = B.d;
     c->ptrs = B.p;
@@ -1060,6 +1073,7 @@ int xrhip_ba_solve_linked(xrhip_ba *c2, const xrhip_ba_problem *P2, xrhip_ba_sum
     std::memcpy(P2->frame_state, c2->h_out, sizeof(double) * 16 * d2.F);
     if (e0) c1->pending_chain.push_back({e0, e1, chain_bytes(d2, *c2->h_ctl)});
     c2->stats.n_tiny++;
+    kprof_accumulate(*c2->h_ctl, d2.na);
     fill_summary(*c2->h_ctl, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), s2);
     c2->dims = d2;
     c2->ptrs = p2;
@@ -1338,14 +1352,7 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     if (rc) return rc;
     const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     const BaCtl &ctl = *c->h_ctl;
-    {   // development aid: XRHIP_KPROF_MIN_NA restricts the accumulated phase timers to solves of at least that size
-        static const int min_na = std::getenv("XRHIP_KPROF_MIN_NA") ? std::atoi(std::getenv("XRHIP_KPROF_MIN_NA")) : 0;
-        static const int max_na = std::getenv("XRHIP_KPROF_MAX_NA") ? std::atoi(std::getenv("XRHIP_KPROF_MAX_NA")) : 1 << 30;
-        if (d.na >= min_na && d.na <= max_na) {
-            for (int i = 0; i < 32; ++i) g_kprof[i] += ctl.prof[i];
-            g_kprof[31] += 1;   // solves counted
-        }
-    }
+    kprof_accumulate(ctl, d.na);
     sm.iterations = ctl.iteration;
     sm.successful_steps = ctl.successful_steps;
     sm.termination = ctl.termination;
