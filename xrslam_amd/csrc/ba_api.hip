@@ -64,6 +64,10 @@ struct xrhip_ba {
         GroupRequest *rq = nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         std::chrono::steady_clock::time_point t0;
+        // set when a linked solve took over (xrhip_ba_solve_linked): the summary's time runs to here -- the linked solve's own clock
+        // covers the rest, so the two do not count the same wall time twice
+        bool handed_over = false;
+        std::chrono::steady_clock::time_point t_hand;
     } begun;
     Arena in;         // inputs (uploaded every solve)
     char *work = nullptr;   // device-only workspace
@@ -949,6 +953,7 @@ int xrhip_ba_solve_begin(xrhip_ba *c, const xrhip_ba_problem *P) {
         if (B.e1) XR_HIP(hipEventRecord(B.e1, B.stream));
     }
     B.active = true;
+    B.handed_over = false;
     return 1;
 }
 
@@ -964,7 +969,9 @@ int xrhip_ba_solve_end(xrhip_ba *c, xrhip_ba_summary *summary) {
     if (B.e0) c->pending_chain.push_back({B.e0, B.e1, chain_bytes(B.d, *c->h_ctl)});
     c->stats.n_tiny++;
     kprof_accumulate(*c->h_ctl, B.d.na);
-    fill_summary(*c->h_ctl, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - B.t0).count(), summary);
+    fill_summary(*c->h_ctl, std::chrono::duration<float, std::milli>((B.handed_over ? B.t_hand : std::chrono::steady_clock::now()) - B.t0).count(),
+                 summary);
+    B.handed_over = false;
     c->dims = B.d;
     c->ptrs = B.p;
     c->have_lin = true;
@@ -1000,6 +1007,8 @@ int xrhip_ba_solve_linked(xrhip_ba *c2, const xrhip_ba_problem *P2, xrhip_ba_sum
     };
     if (c1->group != c2->group || c2->begun.active || !any_free_block(P2)) return sequential();
     const auto t_begin = std::chrono::steady_clock::now();
+    A.handed_over = true;
+    A.t_hand = t_begin;
     BaDims d2;
     BaPtrs p2;
     Ext cam2, imu2;

@@ -2,25 +2,29 @@
 //
 // The reference runs one sequence per process (process-global XRSLAMManager, xrslam-interface/src/XRSLAMManager.cpp:6-9; static id
 // counters, utility/identifiable.h:23-30).  Here a process holds many instances, and on one GPU their per-frame kernels are small
-// and latency-bound: S sequences driven independently retire ~100 k dependent launches per second through the command processor
-// whatever the number of queues (profiles/r03_multi_sequence.md) -- the device idles behind its own front end.  Contexts that
-// join an xrhip_group stop launching for themselves: every launch of the per-frame path becomes a REQUEST (its argument block, built
-// by the owning context exactly as for a launch of its own), and the group's one submission thread turns all pending requests of a
-// kind into ONE launch whose blockIdx.z selects the request (klt_kernels.hip.h: Batch<Args>).
+// and latency-bound.  What bounds S independent sequences is the hardware-queue scheduler (tools/multiq.hip,
+// profiles/r04_multi_sequence.md): with more than ~4 hardware queues busy every kernel of every queue waits 20-27 us for its queue's
+// turn, and the device runs about one kernel per busy queue.  Contexts that join an xrhip_group stop launching the per-frame path for
+// themselves: every such launch becomes a REQUEST (its argument block, built by the owning context exactly as for a launch of its
+// own), and the group's submission threads turn all pending requests of a kind into ONE launch whose blockIdx.z selects the request
+// (batch.hip.h: Batch<Args>).
 //
-//   * Three in-order queues with a stream each: GQ_KLT (frame upload, CLAHE / pyramid, LK + Harris), GQ_CHAIN (the single-launch
-//     solves: kb_stage + kb_chain [+ the integration queued behind the solve]), GQ_PREINT (pre-integration batches of every BA
-//     context).  Requests of one context reach the device in the order it submitted them; dependencies BETWEEN queues are
-//     host-mediated in the pipeline already (a solve is only assembled once the integrations it reads have been collected).
+//   * Three in-order queues with a stream and a submission thread each: GQ_KLT (frame upload, CLAHE / pyramid, LK + Harris),
+//     GQ_CHAIN (the single-launch solves: kb_stage + kb_chain [+ the integration queued behind the solve]), GQ_PREINT
+//     (pre-integration batches of every BA context).  Requests of one context reach the device in the order it submitted them;
+//     dependencies BETWEEN queues are host-mediated in the pipeline already (a solve is only assembled once the integrations it reads
+//     have been collected).
 //   * One batch OF A KIND in flight per queue: while it runs, requests of that kind accumulate; when it retires, everything pending
 //     of it goes out together.  An idle device launches a lone request at once, a busy one forms bigger batches -- nobody waits
-//     for a straggler, and a sequence on a keyframe frame (1.5 ms of window solve on its own stream) does not hold the others
-//     back.  Batches of different kinds follow each other on the queue's in-order stream without a wait (frame -> pyramid ->
-//     tracking is one pipeline).  One submission thread per queue.
+//     for a straggler.  Batches of different kinds follow each other on the queue's in-order stream without a wait (frame ->
+//     pyramid -> tracking is one pipeline).
 //   * Per-entry arithmetic is untouched (same kernels, same block-to-work mapping, same summation order): results do not depend
 //     on the batch a request happened to travel in -- tests/test_instances.py holds grouped runs to the solo runs bit for bit.
 //   * Completion stays per context: every kernel publishes into its owner's pinned mailbox as before; the owner's thread spins on it.
-// Window solves and marginalisations (one frame in five) keep their own streams.
+//   * Hardware queues: the group's streams are created at high priority when the runtime has two queues per priority level
+//     (GPU_MAX_HW_QUEUES=2): two queues for the batches of all members, two for the members' own work (group_api.hip).
+// Window solves and marginalisations (one frame in five) stay per-member launches on the members' own streams (without the
+// speculative linearisation, and with localize -> sub-window as two requests: ba_api.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
