@@ -506,6 +506,24 @@ def main():
         lk_ms = st.ms_track / n_launch
         achieved = (lk_bytes / n_launch) / (lk_ms * 1e-3) / 1e9 if lk_ms > 0 else 0.0
         ba_tflops = bst.flops_solve_try / (bst.ms_solve_try * 1e-3) / 1e12 if bst.ms_solve_try > 0 else 0.0
+        # kb_chain / k_lk_track of a GROUP: the members do not time their own launches, the group times the batch they travel in
+        # (first to last kernel: kb_stage + kb_chain for all entries; LK + the Harris passes that ride along).  bytes = all members'
+        # algorithmic bytes (every member accounts its own), time = the batches': the rate of the batched launch.
+        chain_bytes_, chain_ms_, chain_n_, chain_note = bst.bytes_chain, bst.ms_chain, bst.n_chain_timed, None
+        lk_note = None
+        if gstats is not None and not args.no_profile:
+            allb = [s_.ba_stats(reset=False) for s_ in sessions]
+            gc, gt = gstats.get("chain", {}), gstats.get("track", {})
+            if gc.get("timed"):
+                chain_bytes_, chain_ms_, chain_n_ = sum(b.bytes_chain for b in allb), gc["ms"], gc["timed"]
+                chain_note = ("group: %d batches served %d solves of all members; launch_us = kb_stage + kb_chain of a batch, "
+                              "bytes = the batch's entries'" % (gc["timed"], gc["requests"]))
+            if gt.get("timed"):
+                lk_all = sum(2420.0 * k.lk_templates + 484.0 * k.lk_iterations for k in all_klt)
+                lk_bytes, n_launch, lk_ms = lk_all, gt["timed"], gt["ms"] / gt["timed"]
+                achieved = (lk_bytes / n_launch) / (lk_ms * 1e-3) / 1e9
+                lk_note = ("group: %d batches served %d tracking requests; launch_us = k_lk_track AND the Harris passes of the batch "
+                           "(one stream): a lower bound of the LK kernel's rate" % (gt["timed"], gt["requests"]))
         hbm_meas, mfma_meas = peaks.get("stream_read_gbs"), peaks.get("mfma_f64_16x16x4_tflops")
         out = dict(common)
         out.update({
@@ -553,13 +571,15 @@ def main():
             # observation records: HBM-bound per SURVEY.md 8d).  achieved = algorithmic bytes per launch / HIP-event
             # duration of that kernel on the BA stream.
             "roofline": {"kernel": "kb_chain", "bound": "hbm",
-                         "achieved": round(bst.bytes_chain / max(1e-9, bst.ms_chain * 1e-3) / 1e9, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(bst.bytes_chain / max(1e-9, bst.ms_chain * 1e-3) / 1e9 / HBM_PEAK_GBS, 8),
-                         "traffic": traffic.get("kb_chain"),
+                         "achieved": round(chain_bytes_ / max(1e-9, chain_ms_ * 1e-3) / 1e9, 4) if chain_ms_ > 0 else 0.0,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(chain_bytes_ / max(1e-9, chain_ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 8) if chain_ms_ > 0 else 0.0,
+                         "traffic": traffic.get("kb_chain") if chain_note is None else None,
                          "peak_measured": hbm_meas,
-                         "frac_of_measured": round(bst.bytes_chain / max(1e-9, bst.ms_chain * 1e-3) / 1e9 / hbm_meas, 8) if hbm_meas else None,
-                         "algorithmic_bytes_per_launch": round(bst.bytes_chain / max(1, bst.n_chain_timed), 1),
-                         "launch_us": round(1e3 * bst.ms_chain / max(1, bst.n_chain_timed), 3), "launches": int(bst.n_chain_timed)},
+                         "frac_of_measured": round(chain_bytes_ / max(1e-9, chain_ms_ * 1e-3) / 1e9 / hbm_meas, 8) if hbm_meas and chain_ms_ > 0 else None,
+                         "algorithmic_bytes_per_launch": round(chain_bytes_ / max(1, chain_n_), 1),
+                         "launch_us": round(1e3 * chain_ms_ / max(1, chain_n_), 3), "launches": int(chain_n_),
+                         **({"batched": chain_note} if chain_note else {})},
             # the window solve's factorisation kernel: reduced-system Cholesky on the f64 matrix cores (+ substitutions); flops =
             # algorithmic; launch_us = HIP events around that kernel alone
             "roofline_solve": {"kernel": "kb_solve_try", "bound": "mfma", "achieved": round(ba_tflops, 6),
@@ -573,7 +593,7 @@ def main():
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic.get("k_lk_track"),
                             "peak_measured": hbm_meas, "frac_of_measured": round(achieved / hbm_meas, 6) if hbm_meas else None,
                             "algorithmic_bytes_per_launch": round(lk_bytes / n_launch, 1),
-                            "launch_us": round(lk_ms * 1e3, 3)},
+                            "launch_us": round(lk_ms * 1e3, 3), **({"batched": lk_note} if lk_note else {})},
             "traffic_source": traffic_note,
             # the whole GPU against the HBM roofline: ALGORITHMIC bytes of the tracker stage (B_trk = CLAHE + pyramid +
             # Scharr + Harris passes of every frame + the LK templates and iterations the kernels counted) of ALL sequences of this

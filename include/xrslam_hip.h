@@ -291,7 +291,9 @@ typedef struct xrhip_ba_stats {
     long n_tiny;             /* solves that ran as ONE launch (kb_chain / kb_tiny: no free landmark, a few free frames); not in the above */
     /* the single-launch solves (kb_chain): HIP-event durations of the launches made while profiling was on, and their
      * ALGORITHMIC bytes (384 B per reprojection factor and linearisation, 280 B per factor and candidate
-     * costed, the packed reduced system once per round) -- what bench.py divides by the HBM peak */
+     * costed, the packed reduced system once per round) -- what bench.py divides by the HBM peak.  A member of an instance group does
+     * not time its own launches (xrhip_group_stats has the batches' durations): its solves still count here -- n_chain_timed and
+     * bytes_chain grow, ms_chain does not. */
     long n_chain_timed;
     double ms_chain;
     double bytes_chain;

@@ -881,6 +881,14 @@ static void fill_summary(const BaCtl &ctl, float ms, xrhip_ba_summary *sm) {
     sm->final_cost = ctl.x_cost;
     sm->ms_solve = ms;
 }
+// A member of a group does not time its own single-launch solves (the group times the batch they travel in, xrhip_group_stats): with
+// profiling on it still accounts their algorithmic bytes -- n_chain_timed / bytes_chain grow, ms_chain does not -- and bench.py
+// divides the members' bytes by the group's batch time.
+static void chain_account_untimed(xrhip_ba *c, double bytes) {
+    if (!c->profiling || !c->group) return;
+    c->stats.n_chain_timed++;
+    c->stats.bytes_chain += bytes;
+}
 static double chain_bytes(const BaDims &d, const BaCtl &ctl) {   // algorithmic bytes of a single-launch solve
     const double nf = (double)d.M + d.MR, rounds = ctl.successful_steps + 1.0, trials = ctl.iteration;
     return rounds * (384.0 * nf + 8.0 * (double)d.na * d.na + 2248.0 * d.NI) + trials * (280.0 * nf + 2248.0 * d.NI);
@@ -967,6 +975,7 @@ int xrhip_ba_solve_end(xrhip_ba *c, xrhip_ba_summary *summary) {
     if (c->h_ctl->status != ST_DONE) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve_end: trust-region loop did not terminate");
     std::memcpy(B.P->frame_state, c->h_out, sizeof(double) * 16 * B.d.F);
     if (B.e0) c->pending_chain.push_back({B.e0, B.e1, chain_bytes(B.d, *c->h_ctl)});
+    else chain_account_untimed(c, chain_bytes(B.d, *c->h_ctl));
     c->stats.n_tiny++;
     kprof_accumulate(*c->h_ctl, B.d.na);
     fill_summary(*c->h_ctl, std::chrono::duration<float, std::milli>((B.handed_over ? B.t_hand : std::chrono::steady_clock::now()) - B.t0).count(),
@@ -1081,6 +1090,7 @@ int xrhip_ba_solve_linked(xrhip_ba *c2, const xrhip_ba_problem *P2, xrhip_ba_sum
     if (c2->h_ctl->status != ST_DONE) return xr_fail(XRHIP_ESTATE, "xrhip_ba_solve_linked: trust-region loop did not terminate");
     std::memcpy(P2->frame_state, c2->h_out, sizeof(double) * 16 * d2.F);
     if (e0) c1->pending_chain.push_back({e0, e1, chain_bytes(d2, *c2->h_ctl)});
+    else chain_account_untimed(c2, chain_bytes(d2, *c2->h_ctl));
     c2->stats.n_tiny++;
     kprof_accumulate(*c2->h_ctl, d2.na);
     fill_summary(*c2->h_ctl, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), s2);
@@ -1235,6 +1245,8 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
             const double nf = (double)d.M + d.MR, rounds = c->h_ctl->successful_steps + 1.0, trials = c->h_ctl->iteration;
             const double bytes = rounds * (384.0 * nf + 8.0 * (double)d.na * d.na + 2248.0 * d.NI) + trials * (280.0 * nf + 2248.0 * d.NI);
             c->pending_chain.push_back({e0, e1, bytes});
+        } else {
+            chain_account_untimed(c, chain_bytes(d, *c->h_ctl));
         }
         c->stats.n_tiny++;
         done = true;
