@@ -108,8 +108,14 @@ void impl_push(Manager &m, XRSLAMSensorType type, void *data) {
             } else if (im->channel != 1) {
                 throw std::runtime_error("Image channel is not supported!");
             }
-            std::lock_guard<std::mutex> lk(m.input_mutex);
-            m.cur_image = m.sys->P.make_image(src, stride, im->timeStamp, false);
+            try {
+                std::lock_guard<std::mutex> lk(m.input_mutex);
+                m.cur_image = m.sys->P.make_image(src, stride, im->timeStamp, false);
+            } catch (...) {   // this frame did not arrive: XRSLAMRunOneFrame must not track the previous image a second time
+                std::lock_guard<std::mutex> lk(m.input_mutex);
+                m.cur_image.reset();
+                throw;
+            }
             break;
         }
         case XRSLAM_SENSOR_ACCELERATION: {
@@ -236,8 +242,14 @@ void impl_push_image_device(Manager &m, const void *gray_dev, int stride, double
     if (!m.sys) return;
     bind_device(m);
     guarded(m, [&] {
-        std::lock_guard<std::mutex> lk(m.input_mutex);
-        m.cur_image = m.sys->P.make_image(static_cast<const uint8_t *>(gray_dev), stride, timestamp, true);
+        try {
+            std::lock_guard<std::mutex> lk(m.input_mutex);
+            m.cur_image = m.sys->P.make_image(static_cast<const uint8_t *>(gray_dev), stride, timestamp, true);
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(m.input_mutex);
+            m.cur_image.reset();
+            throw;
+        }
     });
 }
 
