@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with `pytest -m gpu` via gpurun)")
+    # The synthetic sequences are rendered by forked workers where that is safe: on a host without a GPU (nothing in the process will
+    # touch the HIP runtime -- forking after it has started is not).  Same pixels either way (harness/scene.py); the CPU suite is
+    # ~10 minutes with one renderer, of which rendering is the larger part.
+    if not os.path.exists("/dev/kfd"):
+        os.environ.setdefault("XRSLAM_AMD_RENDER_WORKERS", str(max(1, min(8, len(os.sched_getaffinity(0))))))
 
 
 def _pair(name):

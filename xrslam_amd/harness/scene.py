@@ -1,5 +1,7 @@
 """Synthetic S1 "EuRoC MH_01-like" stream: a textured box room rendered through the EuRoC cam0 pinhole
 model along the analytic trajectory, with 200 Hz IMU.  Seeded, no external data."""
+import os
+
 import numpy as np
 
 from .trajectory import Trajectory, qmat, qmul, qrot
@@ -138,11 +140,13 @@ def _render_range(lo_hi):
 
 
 def make_sequence(n_frames=120, w=752, h=480, seed=1, cam_hz=20.0, imu_hz=200.0, t0=5.0, noise=True, traj=None, K=K_EUROC, dist=None, moving_object=None,
-                  workers=1):
+                  workers=None):
     """Returns dict(frames uint8 [n,h,w], cam_t [n], imu [m,7] (t, w, a), states [n,16] ground truth body states).
     A sequence of n frames is a prefix of every longer one with the same arguments (the random draws are sequential in
     time and the frames are rendered independently).  workers > 1: the frames are rendered by that many forked processes
     (same pixels; call it before anything in the process has touched the GPU runtime)."""
+    if workers is None:   # XRSLAM_AMD_RENDER_WORKERS: the default for callers that do not say (tests/conftest.py sets it on GPU-less hosts)
+        workers = int(os.environ.get("XRSLAM_AMD_RENDER_WORKERS", "1"))
     rng = np.random.RandomState(seed)
     traj = traj or Trajectory()
     room = BoxRoom(seed=seed)
