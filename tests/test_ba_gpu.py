@@ -419,6 +419,29 @@ def test_preintegration_parity(ctx, bo):
                                bo.preintegrate(long, truth["times"][3], bg, ba, bs.NOISE36)[:56], rtol=1e-9, atol=1e-13)
 
 
+@pytest.mark.parametrize("n", [31, 32, 33, 64, 65, 100, 161])
+def test_preintegration_parity_across_chunk_boundaries(ctx, bo, n):
+    """kp_preintegrate works through a job in chunks of 32 samples and composes the chunks' maps (preint_compose): segment lengths
+    around the chunk boundaries and several chunks long, with Jacobians and covariance, against the oracle's sample-by-sample loop."""
+    rng = np.random.RandomState(100 + n)
+    smp = np.zeros((n, 7))
+    smp[:, 0] = 2.0 + 0.005 * np.arange(n)
+    smp[:, 1:4] = 0.3 * rng.randn(n, 3) + np.array([0.2, -0.1, 0.4])
+    smp[:, 4:7] = np.array([0.3, -0.2, 9.7]) + 0.5 * rng.randn(n, 3)
+    t_end = float(smp[-1, 0] + 0.003)
+    bg, ba = 1e-3 * rng.randn(3), 1e-2 * rng.randn(3)
+    o = bo.preintegrate(smp, t_end, bg, ba, bs.NOISE36, True, True)
+    h = ctx.preintegrate(smp, t_end, bg, ba, bs.NOISE36, True, True)
+    np.testing.assert_allclose(h[:11], o[:11], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(h[11:56], o[11:56], rtol=1e-9, atol=1e-12)
+    U_o, U_h = o[56:].reshape(15, 15), h[56:].reshape(15, 15)
+    assert np.abs(U_h - U_o).max() <= 1e-7 * np.abs(U_o).max()
+    assert np.abs(U_h.T @ U_h - U_o.T @ U_o).max() <= 1e-8 * np.abs(U_o.T @ U_o).max()
+    # the covariance-free forms the tracker uses
+    np.testing.assert_allclose(ctx.preintegrate(smp, t_end, bg, ba, bs.NOISE36, False, False)[:11], o[:11], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(ctx.preintegrate(smp, t_end, bg, ba, bs.NOISE36, True, False)[:56], o[:56], rtol=1e-9, atol=1e-12)
+
+
 def test_schur_precision_knob_is_a_study_aid_that_resets(ctx, bo):
     """xrhip_ba_debug_set_schur_precision (BASELINE config 5's study): f32 operands move the result of a window solve by ~1e-7, and
     mode 0 afterwards is the product's f64 path again -- bit for bit."""
