@@ -138,6 +138,20 @@ def test_grouped_instances_match_their_solo_runs_gpu(members, mode):
 
 
 @pytest.mark.gpu
+def test_grouped_instances_with_the_groups_streams_at_high_priority_gpu(monkeypatch):
+    """The configuration bench.py runs groups in (GPU_MAX_HW_QUEUES=2 switches it on; here forced with XRHIP_GROUP_PRIORITY=1, which
+    xrhip_group_create reads): the group's streams come from the runtime's high-priority queue pool.  Which queue a launch travels
+    on cannot change a result: same bits as the solo runs."""
+    from xrslam_amd import _lib
+    monkeypatch.setenv("XRHIP_GROUP_PRIORITY", "1")
+    alone, res, stats = _grouped(_lib.LIB_PATH, (1, 2, 3, 4), mode=0, n=72)
+    for (pa, ca), (pt, ct) in zip(alone, res):
+        assert ca == ct
+        np.testing.assert_array_equal(pa, pt)
+    assert stats["chain"]["batches"] < stats["chain"]["requests"]
+
+
+@pytest.mark.gpu
 def test_a_group_of_one_and_leaving_a_group_gpu():
     """A lone member (every batch has one entry) and a member that leaves half way both keep the solo trajectory."""
     from xrslam_amd import _lib
