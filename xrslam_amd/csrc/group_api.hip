@@ -345,9 +345,17 @@ int xrhip_group_create(xrhip_group **out) {
     for (int k = 0; k < GQ_COUNT; ++k) {
         GroupQueueState &Q = g->qs[k];
         Q.index = k;
-        if (use_prio) XR_HIP(hipStreamCreateWithPriority(&Q.stream, hipStreamNonBlocking, prio_high));
-        else XR_HIP(hipStreamCreateWithFlags(&Q.stream, hipStreamNonBlocking));
-        if (k == GQ_KLT && side_stream) XR_HIP(hipStreamCreateWithFlags(&Q.side, hipStreamNonBlocking));
+        hipError_t e = use_prio ? hipStreamCreateWithPriority(&Q.stream, hipStreamNonBlocking, prio_high)
+                                : hipStreamCreateWithFlags(&Q.stream, hipStreamNonBlocking);
+        if (e == hipSuccess && k == GQ_KLT && side_stream) e = hipStreamCreateWithFlags(&Q.side, hipStreamNonBlocking);
+        if (e != hipSuccess) {   // no thread has been started yet: give back what exists and report
+            for (int j = 0; j <= k; ++j) {
+                if (g->qs[j].stream) hipStreamDestroy(g->qs[j].stream);
+                if (g->qs[j].side) hipStreamDestroy(g->qs[j].side);
+            }
+            delete g;
+            return xr_fail_hip(e, "hipStreamCreate (instance group queue)", __FILE__, __LINE__);
+        }
     }
     // XRHIP_GROUP_PREINT_STREAM=klt|chain: the pre-integration queue launches into that queue's stream instead of one of its own (its
     // thread, its batches and its gate stay): with two hardware queues for the group's three streams the runtime pairs two of them
