@@ -5,7 +5,8 @@
 # steps (NAME or NAME:ARGS; ARGS are passed on verbatim):
 #   tests[:pytest args]     the GPU suite (default: tests)              smoke              __graft_entry__.smoke()
 #   bench[:bench.py args]   one bench.py line + a one-line digest       driver             the driver's --steps 20 --warmup 5 line
-#   multi:S [args]          bench.py --sequences-per-gpu S              procs:N Q          N one-sequence processes on this GPU (gloo), Q HW queues each
+#   multi:S [args]          bench.py --sequences-per-gpu S              procs:N Q [S]      N processes on this GPU (gloo), Q HW queues each, S grouped sequences in each
+#   rccl1                   RunGroup's collectives over nccl (= RCCL) with one rank (tools/check_rccl.py)
 #   trace[:bench.py args]   rocprofv3 --kernel-trace --stats + per-kernel averages         pmc[:args]   MFMA / FETCH_SIZE / WRITE_SIZE passes
 #   ab:VARIANT              default library vs lib/libxrslam_hip_VARIANT.so, alternating (S1 line and S4 replay)
 #   abenv:VAR [reps]        the default bench line with VAR unset / =1, interleaved
@@ -54,9 +55,10 @@ for step in "$@"; do
             for t in "$@"; do case "$t" in -*) ARGS="$ARGS $t" ;; *=*) ENVS="$ENVS $t" ;; *) ARGS="$ARGS $t" ;; esac; done
             env $ENVS timeout 500 python bench.py --sequences-per-gpu "$S" --steps 200 --warmup 50 --cpu-frames 0 $ARGS > "$O/bench_${TAG}_multi${S}_$n.json" 2> "$O/bench_${TAG}_multi${S}_$n.err"
             digest "$O/bench_${TAG}_multi${S}_$n.json"; tail -2 "$O/bench_${TAG}_multi${S}_$n.err" ;;
-    procs)  set -- $arg; N="$1"; Q="${2:-2}"
-            GPU_MAX_HW_QUEUES=$Q OMP_NUM_THREADS=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((29500 + N + Q)) bench.py --gpus "$N" --backend gloo --steps 200 --warmup 50 --cpu-frames 0 --variant-frames 0 > "$O/procs_${TAG}_${N}_$Q.json" 2> "$O/procs_${TAG}_${N}_$Q.err"
-            digest "$O/procs_${TAG}_${N}_$Q.json" ;;
+    procs)  set -- $arg; N="$1"; Q="${2:-2}"; S="${3:-1}"   # procs:N Q [S]: N processes on this GPU (gloo), Q hardware queues each, S grouped sequences in each
+            GPU_MAX_HW_QUEUES=$Q OMP_NUM_THREADS=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((29500 + N + Q + S)) bench.py --gpus "$N" --backend gloo --sequences-per-gpu "$S" --steps 200 --warmup 50 --cpu-frames 0 --variant-frames 0 > "$O/procs_${TAG}_${N}_${Q}_$S.json" 2> "$O/procs_${TAG}_${N}_${Q}_$S.err"
+            digest "$O/procs_${TAG}_${N}_${Q}_$S.json"; tail -2 "$O/procs_${TAG}_${N}_${Q}_$S.err" ;;
+    rccl1)  timeout 120 python tools/check_rccl.py > "$O/rccl1_$TAG.txt" 2>&1; tail -2 "$O/rccl1_$TAG.txt" ;;
     trace)  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof_${TAG}_$n" -o full -- python "$R/bench.py" ${arg:-$BENCH_PROF} > "$O/prof_${TAG}_$n.log" 2>&1); kernel_avgs "$O/prof_${TAG}_$n" ;;
     pmc)    (cd /tmp && export TMPDIR=/tmp
              timeout 150 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$O/pmc_$TAG/MFMA" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --no-profile $arg > "$O/pmc_${TAG}_MFMA.log" 2>&1

@@ -5,22 +5,31 @@ import os
 
 
 class RunGroup:
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, force_init=False):
+        """force_init: join a process group even when the world is one rank (tools/check_rccl.py: the same code path the
+        multi-GPU run takes, exercised on a single-GPU box)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = "cpu"
-        if self.world > 1:
+        if self.world > 1 or force_init:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
-            dist.init_process_group(backend=backend)
+            kw = {}
+            if backend == "nccl":
+                # bind the communicator to the device the caller selected (torch.cuda.set_device before this constructor): no
+                # guessing from the global rank, and the barrier runs on that device
+                self.device = torch.device("cuda", torch.cuda.current_device())
+                kw["device_id"] = self.device
+            if force_init:
+                kw.update(rank=self.rank, world_size=self.world)
+            dist.init_process_group(backend=backend, **kw)
             self.dist = dist
-            self.device = "cuda" if backend == "nccl" else "cpu"
 
     def assign(self, items):
         """Round-robin sharding of independent sequences over the ranks."""
