@@ -90,9 +90,18 @@ def roofline_extras(kernel_rev, workload="s1"):
     traffic, note = {}, "no committed PMC pass"
     if pmc:
         rev, wl = pmc.get("_kernel_rev"), pmc.get("_workload", "s1")
-        if rev == kernel_rev and wl == workload:
-            traffic = {k: round(1024.0 * (v["fetch_kb"] + v["write_kb"]), 1) for k, v in pmc.items() if isinstance(v, dict)}
+        # A later revision whose kernels are the SAME MACHINE CODE bar a named few (tools/kernel_isa_diff.py compares the instruction
+        # streams of the two builds; the listing is committed beside the passes): the figures of the unchanged kernels stand, the
+        # rewritten ones are not shown.
+        same = pmc.get("_same_machine_code_in", {}).get(kernel_rev) if rev != kernel_rev else None
+        if (rev == kernel_rev or same) and wl == workload:
+            skip = set(same["except"]) if same else set()
+            traffic = {k: round(1024.0 * (v["fetch_kb"] + v["write_kb"]), 1) for k, v in pmc.items()
+                       if isinstance(v, dict) and not k.startswith("_") and k not in skip}
             note = "profiles/ PMC passes of kernel revision %s, workload %s" % (rev, wl)
+            if same:
+                note += "; this library is %s: identical machine code except %s (%s), which are not shown" % (
+                    kernel_rev, ", ".join(sorted(skip)), same["evidence"].split(" ")[0])
         elif rev != kernel_rev:
             note = "committed PMC passes are of kernel revision %s, this library is %s: not shown" % (rev, kernel_rev)
         else:

@@ -472,24 +472,63 @@ __device__ __forceinline__ float float_from_key(int k) {
 }
 
 // cv::cornerHarris(8U, block 3, ksize 3, k) on the CLAHE image (pyramid level 0).
-// 64x16 output tile per workgroup; Sobel dx/dy staged in LDS as int16, the 3x3
-// window sums are exact int32.  Also reduces the global maximum.
+// 64x16 output tile per workgroup; the Sobel dx/dy of the tile and its one-pixel ring are staged in LDS as int16, the
+// 3x3 window sums are exact int32.  Also reduces the global maximum.
+//
+// Round 4 (last change of the round), two things the kernel's 22 us were made of:
+//  * the maximum went to ONE word through an atomicMax per WAVEFRONT -- 1440 same-address atomics that arrive together (all 360
+//    workgroups are resident at once and take the same time) and retire at ~100 per microsecond: a ~14 us tail.  Now the four
+//    wavefronts of a workgroup combine in LDS and the workgroup issues one (max is order-independent: same result);
+//  * every Sobel element gathered its 8 neighbours as single bytes from global memory, five dependent round trips per thread.  Now the
+//    pixels the tile needs (20 rows x 72 columns, whole dwords, coalesced) are fetched once into LDS and the Sobel reads them there.
+//    Border semantics unchanged: the 3x3 box reflects the Sobel CENTRE (BORDER_REFLECT_101 of the covariance planes), the
+//    Sobel itself reads the centre's neighbours from the padded plane (BORDER_REFLECT_101 of the image) -- a reflected centre and
+//    its neighbours lie inside the fetched rectangle for every element a valid output reads; the others are clamped into it
+//    (their values are never used).
+constexpr int HR_TW = 72, HR_TH = 20;   // pixel columns X0-4 .. X0+67 (dword-aligned), rows Y0-2 .. Y0+17
 __device__ __forceinline__ void d_harris(LevelView L, double kk, float s2, float *__restrict__ resp,
                                          int *__restrict__ max_key) {
     __shared__ short sdx[18][66];
     __shared__ short sdy[18][66];
+    __shared__ uint32_t pix4[HR_TH * HR_TW / 4];
+    __shared__ float wmax[4];
     const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * 16;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 18 * 66; i += 256) {
-        int cy = i / 66, cx = i - cy * 66;
-        int px = reflect101(X0 - 1 + cx, L.w), py = reflect101(Y0 - 1 + cy, L.h);
-        const uint8_t *r0 = L.img + (ptrdiff_t)(py - 1) * L.istride + px;
-        const uint8_t *r1 = r0 + L.istride;
-        const uint8_t *r2 = r1 + L.istride;
-        int dx = (r0[1] - r0[-1]) + 2 * (r1[1] - r1[-1]) + (r2[1] - r2[-1]);
-        int dy = (r2[-1] - r0[-1]) + 2 * (r2[0] - r0[0]) + (r2[1] - r0[1]);
-        sdx[cy][cx] = (short)dx;
-        sdy[cy][cx] = (short)dy;
+    const bool staged = L.w >= 4 && L.h >= 4;   // (smaller planes: more than one reflection of a centre is possible; gather as before)
+    if (staged) {
+        for (int i = tid; i < HR_TH * HR_TW / 4; i += 256) {
+            const int r = i / (HR_TW / 4), c4 = i - r * (HR_TW / 4);
+            // rows / dwords beyond the padded plane are never part of a valid output's footprint: clamp the address
+            const int y = min(max(Y0 - 2 + r, -KLT_PAD), L.h + KLT_PAD - 1);
+            const int x = min(max(X0 - 4 + 4 * c4, -KLT_PADX), L.istride - KLT_PADX - 4);
+            pix4[i] = *reinterpret_cast<const uint32_t *>(L.img + (ptrdiff_t)y * L.istride + x);
+        }
+        __syncthreads();
+        const uint8_t *pix = reinterpret_cast<const uint8_t *>(pix4);
+        for (int i = tid; i < 18 * 66; i += 256) {
+            const int cy = i / 66, cx = i - cy * 66;
+            const int px = reflect101(X0 - 1 + cx, L.w), py = reflect101(Y0 - 1 + cy, L.h);
+            const int lx = min(max(px - (X0 - 4), 1), HR_TW - 2), ly = min(max(py - (Y0 - 2), 1), HR_TH - 2);
+            const uint8_t *r0 = pix + (ly - 1) * HR_TW + lx;
+            const uint8_t *r1 = r0 + HR_TW;
+            const uint8_t *r2 = r1 + HR_TW;
+            const int dx = (r0[1] - r0[-1]) + 2 * (r1[1] - r1[-1]) + (r2[1] - r2[-1]);
+            const int dy = (r2[-1] - r0[-1]) + 2 * (r2[0] - r0[0]) + (r2[1] - r0[1]);
+            sdx[cy][cx] = (short)dx;
+            sdy[cy][cx] = (short)dy;
+        }
+    } else {
+        for (int i = tid; i < 18 * 66; i += 256) {
+            int cy = i / 66, cx = i - cy * 66;
+            int px = reflect101(X0 - 1 + cx, L.w), py = reflect101(Y0 - 1 + cy, L.h);
+            const uint8_t *r0 = L.img + (ptrdiff_t)(py - 1) * L.istride + px;
+            const uint8_t *r1 = r0 + L.istride;
+            const uint8_t *r2 = r1 + L.istride;
+            int dx = (r0[1] - r0[-1]) + 2 * (r1[1] - r1[-1]) + (r2[1] - r2[-1]);
+            int dy = (r2[-1] - r0[-1]) + 2 * (r2[0] - r0[0]) + (r2[1] - r0[1]);
+            sdx[cy][cx] = (short)dx;
+            sdy[cy][cx] = (short)dy;
+        }
     }
     __syncthreads();
     const int lx = tid & 63, ly0 = tid >> 6;
@@ -518,9 +557,11 @@ __device__ __forceinline__ void d_harris(LevelView L, double kk, float s2, float
             best = fmaxf(best, r);
         }
     }
-    // wave max then one atomic per wave
+    // wavefront max, workgroup max through LDS, one atomic per workgroup
     for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
-    if ((tid & 63) == 0) atomicMax(max_key, float_order_key(best));
+    if ((tid & 63) == 0) wmax[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) atomicMax(max_key, float_order_key(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 struct HarrisArgs {
     LevelView L;
@@ -558,16 +599,29 @@ __device__ __forceinline__ void d_harris_nms(const float *__restrict__ resp, int
     __syncthreads();
     const float maxv = float_from_key(*max_key);
     const float thr = (float)((double)maxv * quality);
+    // The tile's responses and their one-pixel ring go to LDS in one batch of coalesced loads (a pixel above the threshold used to
+    // fetch its eight neighbours in a second, dependent round trip -- per row of the tile, four times per thread).  Only interior
+    // pixels are tested, so every neighbour that is compared lies inside the plane; positions outside it are clamped (never compared).
+    __shared__ float t[18][66];
+    const int X0 = blockIdx.x * 64, Y0 = blockIdx.y * 16;
+#pragma unroll
+    for (int k = 0; k < (18 * 66 + 255) / 256; ++k) {
+        const int i = min(tid + 256 * k, 18 * 66 - 1);
+        const int cy = i / 66, cx = i - cy * 66;
+        const int gx = min(max(X0 - 1 + cx, 0), w - 1), gy = min(max(Y0 - 1 + cy, 0), h - 1);
+        t[cy][cx] = resp[(size_t)gy * w + gx];
+    }
+    __syncthreads();
     const int lx = tid & 63, ly0 = tid >> 6;
     for (int q = 0; q < 4; ++q) {
-        const int x = blockIdx.x * 64 + lx;
-        const int y = blockIdx.y * 16 + ly0 + 4 * q;
+        const int ly = ly0 + 4 * q;
+        const int x = X0 + lx;
+        const int y = Y0 + ly;
         if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
-        const float *p = resp + (size_t)y * w + x;
-        const float v = p[0];
+        const float v = t[ly + 1][lx + 1];
         if (!(v > thr) || v == 0.f) continue;
-        bool ok = v >= p[-1] && v >= p[1] && v >= p[-w - 1] && v >= p[-w] && v >= p[-w + 1] && v >= p[w - 1] &&
-                  v >= p[w] && v >= p[w + 1];
+        bool ok = v >= t[ly + 1][lx] && v >= t[ly + 1][lx + 2] && v >= t[ly][lx] && v >= t[ly][lx + 1] && v >= t[ly][lx + 2] &&
+                  v >= t[ly + 2][lx] && v >= t[ly + 2][lx + 1] && v >= t[ly + 2][lx + 2];
         if (!ok) continue;
         int slot = atomicAdd(&nlocal, 1);
         local[slot].v = v;
