@@ -75,51 +75,83 @@ class LotBox {
 // ------------------------------------------------------------------- 5-point essential solver
 namespace fivept {
 
-// cubic polynomials in (x,y,z) stored densely by exponent triple; index = ex*16 + ey*4 + ez, degree <= 3
-struct Poly {
-    double c[64];
+// Polynomials in (x,y,z) of a known degree bound D <= 3, stored compactly: the coefficient of x^ex y^ey z^ez sits at the rank of its
+// dense index ex*16 + ey*4 + ez among the monomials of degree <= D (SUP<D>: ascending dense index).  The entries of E are linear,
+// E E^T quadratic, the ten constraints cubic.
+// Arithmetic contract: a product accumulates its terms in the order of a dense double loop over the two factors' coefficient arrays
+// (i ascending, then j ascending, zero coefficients skipped), a sum is a + sb * b coefficient by coefficient -- the operations and
+// the order the solver has had since round 1 (dense 64-slot arrays then: the polynomial algebra was 17 of the solver's 40 us; the
+// results are bit-identical, tests/test_host_geometry.py pins them).
+inline constexpr int pidx(int ex, int ey, int ez) { return ex * 16 + ey * 4 + ez; }
+template <int D> struct Sup;
+template <> struct Sup<1> {
+    static constexpr int N = 4;
+    static constexpr unsigned char idx[4] = {0, 1, 4, 16};
+};
+template <> struct Sup<2> {
+    static constexpr int N = 10;
+    static constexpr unsigned char idx[10] = {0, 1, 2, 4, 5, 8, 16, 17, 20, 32};
+};
+template <> struct Sup<3> {
+    static constexpr int N = 20;
+    static constexpr unsigned char idx[20] = {0, 1, 2, 3, 4, 5, 6, 8, 9, 12, 16, 17, 18, 20, 21, 24, 32, 33, 36, 48};
+};
+template <int D> inline constexpr int rank_of(int dense) {   // position of a dense index in Sup<D>::idx
+    for (int k = 0; k < Sup<D>::N; ++k)
+        if (Sup<D>::idx[k] == dense) return k;
+    return -1;
+}
+template <int D> struct Poly {
+    double c[Sup<D>::N];
     Poly() {
         for (double &v : c) v = 0.0;
     }
+    double at(int ex, int ey, int ez) const { return c[rank_of<D>(pidx(ex, ey, ez))]; }
+    double &at(int ex, int ey, int ez) { return c[rank_of<D>(pidx(ex, ey, ez))]; }
 };
-inline int pidx(int ex, int ey, int ez) { return ex * 16 + ey * 4 + ez; }
-inline Poly padd(const Poly &a, const Poly &b, double sb = 1.0) {
-    Poly r;
-    for (int i = 0; i < 64; ++i) r.c[i] = a.c[i] + sb * b.c[i];
+template <int D> inline Poly<D> padd(const Poly<D> &a, const Poly<D> &b, double sb = 1.0) {
+    Poly<D> r;
+    for (int k = 0; k < Sup<D>::N; ++k) r.c[k] = a.c[k] + sb * b.c[k];
     return r;
 }
-inline Poly pscale(const Poly &a, double s) {
-    Poly r;
-    for (int i = 0; i < 64; ++i) r.c[i] = a.c[i] * s;
+template <int D> inline Poly<D> pscale(const Poly<D> &a, double s) {
+    Poly<D> r;
+    for (int k = 0; k < Sup<D>::N; ++k) r.c[k] = a.c[k] * s;
     return r;
 }
-inline Poly pmul(const Poly &a, const Poly &b) {
-    // same accumulation order as the dense double loop (i ascending, then j ascending), visiting non-zeros only
-    int ia[64], ib[64], na = 0, nb = 0;
-    for (int i = 0; i < 64; ++i) {
-        if (a.c[i] != 0.0) ia[na++] = i;
-        if (b.c[i] != 0.0) ib[nb++] = i;
+template <int DA, int DB> struct MulTable {   // rank of monomial(p) * monomial(q) in Sup<DA + DB> (dense indices add: no exponent exceeds 3)
+    unsigned char t[Sup<DA>::N][Sup<DB>::N];
+    constexpr MulTable() : t() {
+        for (int p = 0; p < Sup<DA>::N; ++p)
+            for (int q = 0; q < Sup<DB>::N; ++q) t[p][q] = (unsigned char)rank_of<DA + DB>(Sup<DA>::idx[p] + Sup<DB>::idx[q]);
     }
-    Poly r;
-    for (int p = 0; p < na; ++p) {
-        const int i = ia[p];
-        const int ax = i >> 4, ay = (i >> 2) & 3, az = i & 3;
-        const double av = a.c[i];
-        for (int q = 0; q < nb; ++q) {
-            const int j = ib[q];
-            const int ex = ax + (j >> 4), ey = ay + ((j >> 2) & 3), ez = az + (j & 3);
-            if (ex + ey + ez > 3) continue;   // never happens for the products formed below
-            r.c[pidx(ex, ey, ez)] += av * b.c[j];
+};
+template <int DA, int DB> inline Poly<DA + DB> pmul(const Poly<DA> &a, const Poly<DB> &b) {
+    static constexpr MulTable<DA, DB> T{};
+    Poly<DA + DB> r;
+    for (int p = 0; p < Sup<DA>::N; ++p) {
+        const double av = a.c[p];
+        if (av == 0.0) continue;
+        for (int q = 0; q < Sup<DB>::N; ++q) {
+            const double bv = b.c[q];
+            if (bv == 0.0) continue;
+            r.c[T.t[p][q]] += av * bv;
         }
     }
     return r;
 }
 
 // monomial order of the reference (GRevLex): xxx xxy xyy yyy xxz xyz yyz xzz yzz zzz xx xy yy xz yz zz x y z 1
-static const int MONO[20][3] = {{3, 0, 0}, {2, 1, 0}, {1, 2, 0}, {0, 3, 0}, {2, 0, 1}, {1, 1, 1}, {0, 2, 1},
+static constexpr int MONO[20][3] = {{3, 0, 0}, {2, 1, 0}, {1, 2, 0}, {0, 3, 0}, {2, 0, 1}, {1, 1, 1}, {0, 2, 1},
                                 {1, 0, 2}, {0, 1, 2}, {0, 0, 3}, {2, 0, 0}, {1, 1, 0}, {0, 2, 0}, {1, 0, 1},
                                 {0, 1, 1}, {0, 0, 2}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
 enum { XXX = 0, XXY, XYY, YYY, XXZ, XYZ, YYZ, XZZ, YZZ, ZZZ, XX, XY, YY, XZ, YZ, ZZ, X, Y, Z, I };
+struct MonoRank {   // where the reference's m-th monomial sits in a Poly<3>
+    unsigned char r[20];
+    constexpr MonoRank() : r() {
+        for (int m = 0; m < 20; ++m) r[m] = (unsigned char)rank_of<3>(pidx(MONO[m][0], MONO[m][1], MONO[m][2]));
+    }
+};
 
 }   // namespace fivept
 
@@ -142,35 +174,39 @@ inline std::vector<M3> solve_essential_5pt(const std::array<V2, 5> &p1, const st
     for (int b = 0; b < 4; ++b)
         for (int col = 0; col < 3; ++col)
             for (int row = 0; row < 3; ++row) B[b][row][col] = V(col * 3 + row, 5 + b);
-    Poly E[3][3];
+    Poly<1> E[3][3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
-            E[i][j].c[pidx(1, 0, 0)] = B[0][i][j];
-            E[i][j].c[pidx(0, 1, 0)] = B[1][i][j];
-            E[i][j].c[pidx(0, 0, 1)] = B[2][i][j];
-            E[i][j].c[pidx(0, 0, 0)] = B[3][i][j];
+            E[i][j].at(1, 0, 0) = B[0][i][j];
+            E[i][j].at(0, 1, 0) = B[1][i][j];
+            E[i][j].at(0, 0, 1) = B[2][i][j];
+            E[i][j].at(0, 0, 0) = B[3][i][j];
         }
-    Poly EEt[3][3];
+    Poly<2> EEt[3][3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
-            Poly s;
+            Poly<2> s;
             for (int k = 0; k < 3; ++k) s = padd(s, pmul(E[i][k], E[j][k]));
             EEt[i][j] = s;
         }
-    Poly tr = padd(padd(EEt[0][0], EEt[1][1]), EEt[2][2]);
+    const Poly<2> tr = padd(padd(EEt[0][0], EEt[1][1]), EEt[2][2]);
+    const Poly<2> half_tr = pscale(tr, 0.5);
     Dense polys(10, 20);
+    static constexpr MonoRank MR{};
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
-            Poly s;
+            Poly<3> s;
             for (int k = 0; k < 3; ++k) s = padd(s, pmul(EEt[i][k], E[k][j]));
-            s = padd(s, pmul(pscale(tr, 0.5), E[i][j]), -1.0);
-            for (int m = 0; m < 20; ++m) polys(i * 3 + j, m) = s.c[pidx(MONO[m][0], MONO[m][1], MONO[m][2])];
+            s = padd(s, pmul(half_tr, E[i][j]), -1.0);
+            for (int m = 0; m < 20; ++m) polys(i * 3 + j, m) = s.c[MR.r[m]];
         }
     {
-        Poly d = padd(padd(pmul(E[0][0], padd(pmul(E[1][1], E[2][2]), pmul(E[1][2], E[2][1]), -1.0)),
-                           pmul(E[0][1], padd(pmul(E[1][0], E[2][2]), pmul(E[1][2], E[2][0]), -1.0)), -1.0),
-                      pmul(E[0][2], padd(pmul(E[1][0], E[2][1]), pmul(E[1][1], E[2][0]), -1.0)));
-        for (int m = 0; m < 20; ++m) polys(9, m) = d.c[pidx(MONO[m][0], MONO[m][1], MONO[m][2])];
+        auto minor = [&](int r0, int c0, int r1, int c1, int r2, int c2, int r3, int c3) {   // E[r0][c0] E[r1][c1] - E[r2][c2] E[r3][c3]
+            return padd(pmul(E[r0][c0], E[r1][c1]), pmul(E[r2][c2], E[r3][c3]), -1.0);
+        };
+        const Poly<3> d = padd(padd(pmul(E[0][0], minor(1, 1, 2, 2, 1, 2, 2, 1)), pmul(E[0][1], minor(1, 0, 2, 2, 1, 2, 2, 0)), -1.0),
+                               pmul(E[0][2], minor(1, 0, 2, 1, 1, 1, 2, 0)));
+        for (int m = 0; m < 20; ++m) polys(9, m) = d.c[MR.r[m]];
     }
     // Gauss-Jordan with the reference's row-permutation pivoting (essential.cpp:151-200)
     std::array<int, 10> perm;
@@ -265,6 +301,7 @@ M3 ransac_solve(const std::vector<Sample1> &d1, const std::vector<Sample2> &d2, 
         return model;
     }
     size_t iter_max = max_iteration;
+    std::vector<char> cur_mask;
     for (size_t iter = 0; iter < iter_max; ++iter) {
         std::array<Sample1, DoF> s1;
         std::array<Sample2, DoF> s2;
@@ -276,8 +313,11 @@ M3 ransac_solve(const std::vector<Sample1> &d1, const std::vector<Sample2> &d2, 
         }
         std::vector<M3> models = solver(s1, s2);
         for (const M3 &cur : models) {
+            // every sample is an inlier of the model held: no later model can count MORE (the update below is strict), and the
+            // update that found it has already cut iter_max to zero -- nothing that follows changes the result
+            if (inlier_count == size) break;
             size_t cur_count = 0;
-            std::vector<char> cur_mask(size, 0);
+            cur_mask.assign(size, 0);
             auto eval = make_eval(cur);
             for (size_t i = 0; i < size; ++i) {
                 double err = eval(d1[i], d2[i]);

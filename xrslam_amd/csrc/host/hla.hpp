@@ -127,27 +127,51 @@ struct Dense {
 // One-sided Jacobi SVD  A (m x n) = U diag(s) V^T.  Returns V (n x n) and singular values sorted
 // descending; columns of V belonging to (numerically) zero singular values span the null space.
 // Plays the role of Eigen::JacobiSVD(ComputeFullV) in stereo.h:84-94, essential.cpp:105-117, wahba.h:17-18.
-inline void jacobi_svd(const Dense &A_in, std::vector<double> &s, Dense &V, Dense *U = nullptr) {
-    const int m = A_in.r, n = A_in.c;
-    Dense A = A_in;
-    V = Dense(n, n);
-    for (int i = 0; i < n; ++i) V(i, i) = 1.0;
+//
+// jacobi_sweeps is the rotation loop on caller-provided row-major storage (A: m x n, V: n x n = identity on entry); MT / NT are the
+// dimensions as compile-time constants (0: taken from m / n at run time).  The shapes the per-frame path meets -- the 5 x 9 epipolar
+// system of the 5-point solver, the 3 x 3 covariance of the 2-point rotation -- get instances whose loops the compiler unrolls; every
+// instance executes the same floating-point operations in the same order, so the result does not depend on the instance.
+template <int MT, int NT> inline void jacobi_sweeps(double *A, double *V, int m_rt, int n_rt) {
+    const int m = MT ? MT : m_rt, n = NT ? NT : n_rt;
     double fro2 = 0.0;
-    for (double v : A.a) fro2 += v * v;
+    for (int i = 0; i < m * n; ++i) fro2 += A[i] * A[i];
     // a column whose norm has dropped below 1e-15 |A|_F is a converged null-space direction: rotating it further
     // only chases rounding noise (rank-deficient inputs -- the 5x9 epipolar system, a 2-point covariance -- would
     // otherwise burn every sweep on such columns)
     const double null2 = 1e-30 * fro2;
+    // squared column norms are recomputed only for columns a rotation has touched since they were last formed (the same sum of the
+    // same entries gives the same value: a cached norm IS the recomputed one)
+    constexpr int NC = NT ? NT : 1;
+    double st_norm[NC];
+    bool st_ok[NC];
+    std::vector<double> heap_norm;
+    std::vector<char> heap_ok;
+    double *norm2 = st_norm;
+    bool *have = st_ok;
+    if (!NT) {
+        heap_norm.resize(n);
+        heap_ok.resize(n);
+        norm2 = heap_norm.data();
+        have = reinterpret_cast<bool *>(heap_ok.data());
+    }
+    for (int j = 0; j < n; ++j) have[j] = false;
+    auto col_norm2 = [&](int j) {
+        if (!have[j]) {
+            double t = 0;
+            for (int i = 0; i < m; ++i) t += A[i * n + j] * A[i * n + j];
+            norm2[j] = t;
+            have[j] = true;
+        }
+        return norm2[j];
+    };
     for (int sweep = 0; sweep < 60; ++sweep) {
         bool rotated = false;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
-                double al = 0, be = 0, ga = 0;
-                for (int i = 0; i < m; ++i) {
-                    al += A(i, p) * A(i, p);
-                    be += A(i, q) * A(i, q);
-                    ga += A(i, p) * A(i, q);
-                }
+                const double al = col_norm2(p), be = col_norm2(q);
+                double ga = 0;
+                for (int i = 0; i < m; ++i) ga += A[i * n + p] * A[i * n + q];
                 if (ga == 0.0 || std::fabs(ga) <= 1e-16 * std::sqrt(al * be) || std::min(al, be) <= null2) continue;
                 rotated = true;
                 double zeta = (be - al) / (2.0 * ga);
@@ -155,18 +179,28 @@ inline void jacobi_svd(const Dense &A_in, std::vector<double> &s, Dense &V, Dens
                 if (zeta < 0) t = -t;
                 double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
                 for (int i = 0; i < m; ++i) {
-                    double x = A(i, p), y = A(i, q);
-                    A(i, p) = cs * x - sn * y;
-                    A(i, q) = sn * x + cs * y;
+                    double x = A[i * n + p], y = A[i * n + q];
+                    A[i * n + p] = cs * x - sn * y;
+                    A[i * n + q] = sn * x + cs * y;
                 }
+                have[p] = have[q] = false;
                 for (int i = 0; i < n; ++i) {
-                    double x = V(i, p), y = V(i, q);
-                    V(i, p) = cs * x - sn * y;
-                    V(i, q) = sn * x + cs * y;
+                    double x = V[i * n + p], y = V[i * n + q];
+                    V[i * n + p] = cs * x - sn * y;
+                    V[i * n + q] = sn * x + cs * y;
                 }
             }
         if (!rotated) break;
     }
+}
+inline void jacobi_svd(const Dense &A_in, std::vector<double> &s, Dense &V, Dense *U = nullptr) {
+    const int m = A_in.r, n = A_in.c;
+    Dense A = A_in;
+    V = Dense(n, n);
+    for (int i = 0; i < n; ++i) V(i, i) = 1.0;
+    if (m == 5 && n == 9) jacobi_sweeps<5, 9>(A.a.data(), V.a.data(), m, n);
+    else if (m == 3 && n == 3) jacobi_sweeps<3, 3>(A.a.data(), V.a.data(), m, n);
+    else jacobi_sweeps<0, 0>(A.a.data(), V.a.data(), m, n);
     std::vector<double> nrm(n);
     std::vector<int> idx(n);
     for (int j = 0; j < n; ++j) {
@@ -191,12 +225,33 @@ inline void jacobi_svd(const Dense &A_in, std::vector<double> &s, Dense &V, Dens
 // Eigenvalues of a general real n x n matrix (Hessenberg reduction + shifted QR, EISPACK elmhes/hqr scheme),
 // and for every real eigenvalue an eigenvector by inverse iteration.  Plays the role of
 // Eigen::EigenSolver in essential.cpp:202-218.
-inline void real_eigen(const Dense &M, std::vector<double> &wr, std::vector<double> &wi,
-                       std::vector<std::vector<double>> &vecs) {
-    const int n = M.r;
-    Dense a = M;
-    for (double v : M.a)
-        if (!std::isfinite(v)) {   // Eigen::EigenSolver yields NaN eigenvalues here; no real eigenpair is reported
+// real_eigen_core<NT>: the routine on row-major storage, NT = n as a compile-time constant (0: run time).  The 10 x 10 action matrix
+// of the 5-point solver gets an instance with stack storage and unrolled loops; every instance performs the same operations in the
+// same order.
+template <int NT>
+inline void real_eigen_core(const double *Mbuf, int n_rt, std::vector<double> &wr, std::vector<double> &wi,
+                            std::vector<std::vector<double>> &vecs) {
+    const int n = NT ? NT : n_rt;
+    double st_a[NT ? NT * NT : 1], st_b[NT ? NT * NT : 1], st_v[NT ? NT : 1];
+    int st_piv[NT ? NT : 1];
+    std::vector<double> heap_d;
+    std::vector<int> heap_i;
+    double *abuf = st_a, *bbuf = st_b, *v = st_v;
+    int *piv = st_piv;
+    if (!NT) {
+        heap_d.resize((size_t)2 * n * n + n);
+        heap_i.resize(n);
+        abuf = heap_d.data();
+        bbuf = abuf + (size_t)n * n;
+        v = bbuf + (size_t)n * n;
+        piv = heap_i.data();
+    }
+    for (int k = 0; k < n * n; ++k) abuf[k] = Mbuf[k];
+    auto a = [abuf, n](int i, int j) -> double & { return abuf[i * n + j]; };
+    auto B = [bbuf, n](int i, int j) -> double & { return bbuf[i * n + j]; };
+    auto M = [Mbuf, n](int i, int j) -> double { return Mbuf[i * n + j]; };
+    for (int k = 0; k < n * n; ++k)
+        if (!std::isfinite(Mbuf[k])) {   // Eigen::EigenSolver yields NaN eigenvalues here; no real eigenpair is reported
             wr.assign(n, std::numeric_limits<double>::quiet_NaN());
             wi.assign(n, std::numeric_limits<double>::quiet_NaN());
             vecs.assign(n, std::vector<double>());
@@ -356,7 +411,6 @@ inline void real_eigen(const Dense &M, std::vector<double> &wr, std::vector<doub
     for (int e = 0; e < n; ++e) {
         if (std::fabs(wi[e]) >= 1.0e-10) continue;
         const double lam = wr[e];
-        Dense B(n, n);
         double scale = 0;
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) {
@@ -366,7 +420,6 @@ inline void real_eigen(const Dense &M, std::vector<double> &wr, std::vector<doub
         const double eps = std::max(scale, 1.0) * 1e-13;
         for (int i = 0; i < n; ++i) B(i, i) += eps * (1 + i % 3);   // keep the shifted matrix invertible
         // LU with partial pivoting
-        std::vector<int> piv(n);
         for (int k = 0; k < n; ++k) {
             int pk = k;
             for (int i = k + 1; i < n; ++i)
@@ -380,7 +433,7 @@ inline void real_eigen(const Dense &M, std::vector<double> &wr, std::vector<doub
                 for (int j = k + 1; j < n; ++j) B(i, j) -= B(i, k) * B(k, j);
             }
         }
-        std::vector<double> v(n, 1.0);
+        for (int k = 0; k < n; ++k) v[k] = 1.0;
         for (int it = 0; it < 4; ++it) {
             for (int k = 0; k < n; ++k) {
                 if (piv[k] != k) std::swap(v[k], v[piv[k]]);
@@ -391,13 +444,18 @@ inline void real_eigen(const Dense &M, std::vector<double> &wr, std::vector<doub
                 v[i] /= B(i, i);
             }
             double nrm = 0;
-            for (double t2 : v) nrm += t2 * t2;
+            for (int k = 0; k < n; ++k) nrm += v[k] * v[k];
             nrm = std::sqrt(nrm);
             if (!(nrm > 0) || !std::isfinite(nrm)) break;
-            for (double &t2 : v) t2 /= nrm;
+            for (int k = 0; k < n; ++k) v[k] /= nrm;
         }
-        vecs[e] = v;
+        vecs[e].assign(v, v + n);
     }
+}
+inline void real_eigen(const Dense &M, std::vector<double> &wr, std::vector<double> &wi,
+                       std::vector<std::vector<double>> &vecs) {
+    if (M.r == 10) real_eigen_core<10>(M.a.data(), M.r, wr, wi, vecs);
+    else real_eigen_core<0>(M.a.data(), M.r, wr, wi, vecs);
 }
 
 }   // namespace xrh
