@@ -119,3 +119,28 @@ def test_reference_player_loop_compiles_and_runs_against_our_header(tmp_path):
     assert res["tracked"] == len(poses) and res["tracked"] >= 10
     assert abs(res["t"] - poses[-1][0]) < 1e-9
     np.testing.assert_allclose(res["p"], poses[-1][1:4], rtol=0, atol=1e-8)
+
+
+def test_library_carries_gfx950_machine_code_for_every_kernel():
+    """The shared object holds gfx950 code objects (nothing else: no second architecture, no host fallback) with the kernels of
+    the hot path in them; tools/kernel_isa_diff.py, the tool that decides whether committed per-kernel counter figures survive a new
+    kernel revision, reports a library as identical to itself."""
+    import importlib.util
+    import shutil
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") or shutil.which("g++") is None:
+        pytest.skip("no ROCm llvm-objdump here")
+    spec = importlib.util.spec_from_file_location("kernel_isa_diff", os.path.join(ROOT, "tools", "kernel_isa_diff.py"))
+    kid = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kid)
+    from xrslam_amd import _lib
+    ks = kid.kernels(_lib.LIB_PATH)
+    names = {kid.short(k) for k in ks}
+    for need in ("k_clahe_lut", "k_pyr_a", "k_pyr_b", "k_lk_track", "k_harris", "k_harris_nms", "k_harris_select", "k_undistort",
+                 "kp_preintegrate", "kb_chain", "kb_lin_all", "kb_landmark_vision", "kb_assemble", "kb_schur_aux", "kb_schur_mfma",
+                 "kb_solve_try<512, true>", "kb_trials_wide", "km_chol", "km_jacobi", "kb_stage", "k_upload"):
+        assert need in names, need
+    assert all(len(body) > 20 for body in ks.values())
+    # the matrix cores are used where DESIGN.md says they are: f64 MFMA in the Schur contraction and the factorisations
+    for k, body in ks.items():
+        if kid.short(k) in ("kb_schur_mfma", "kb_solve_try<512, true>", "km_chol"):
+            assert any("v_mfma_f64_16x16x4" in ln for ln in body), k
