@@ -247,9 +247,9 @@ inline void real_eigen_core(const double *Mbuf, int n_rt, std::vector<double> &w
         piv = heap_i.data();
     }
     for (int k = 0; k < n * n; ++k) abuf[k] = Mbuf[k];
-    auto a = [abuf, n](int i, int j) -> double & { return abuf[i * n + j]; };
-    auto B = [bbuf, n](int i, int j) -> double & { return bbuf[i * n + j]; };
-    auto M = [Mbuf, n](int i, int j) -> double { return Mbuf[i * n + j]; };
+    auto a = [=](int i, int j) -> double & { return abuf[i * n + j]; };
+    auto B = [=](int i, int j) -> double & { return bbuf[i * n + j]; };
+    auto M = [=](int i, int j) -> double { return Mbuf[i * n + j]; };
     for (int k = 0; k < n * n; ++k)
         if (!std::isfinite(Mbuf[k])) {   // Eigen::EigenSolver yields NaN eigenvalues here; no real eigenpair is reported
             wr.assign(n, std::numeric_limits<double>::quiet_NaN());
