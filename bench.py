@@ -304,6 +304,10 @@ def main():
     ap.add_argument("--variant-frames", type=int, default=100,
                     help="frames of each extra leg on the same stream after the timed region -- resident / pipelined / "
                          "pipelined_resident (0 = skip; one sequence on one GPU only)")
+    ap.add_argument("--sustained-frames", type=int, default=150,
+                    help="frames of the `sustained` leg: the HEADLINE mode itself continued on the same stream right after the timed "
+                         "region (a --steps 20 line is a 12 ms sample; this is the same call over a longer one; 0 = skip; one "
+                         "sequence on one GPU only)")
     ap.add_argument("--image", default="host", choices=["host", "resident"],
                     help="host (default): the reference-shaped camera call, a host image uploaded inside XRSLAMPushSensorData; "
                          "resident: frames already in HBM (XRSLAMAmdPushImageDevice)")
@@ -347,14 +351,15 @@ def main():
     from xrslam_amd.harness import scene
     from xrslam_amd.harness.trajectory import Trajectory
     wl = dict(WORKLOADS[args.workload]) if args.workload != "s4" else None
-    seqs, real, preroll, n_frames, variant_frames, slam_yaml, sensor_yaml = [], None, 0, 0, 0, None, None
+    seqs, real, preroll, n_frames, variant_frames, sustained_frames, slam_yaml, sensor_yaml = [], None, 0, 0, 0, 0, None, None
     if wl is not None:
         # steady state (window full, first marginalisation done) from frame 4 * window + 16 on: a shorter warmup is preceded by
         # the missing frames as an untimed pre-roll (module docstring)
         preroll = max(0, 4 * wl["window"] + 16 - args.warmup)
         slam_yaml, sensor_yaml = os.path.join(CFG, wl["slam"]), os.path.join(CFG, wl["sensor"])
         variant_frames = args.variant_frames if (S == 1 and world == 1) else 0
-        n_frames = preroll + args.warmup + args.steps + 3 * variant_frames
+        sustained_frames = args.sustained_frames if (S == 1 and world == 1) else 0
+        n_frames = preroll + args.warmup + args.steps + sustained_frames + 3 * variant_frames
         if args.euroc:
             from xrslam_amd.harness import euroc
             if S != 1 or world != 1:
@@ -650,6 +655,25 @@ def main():
             out["kprof_ms"] = [round(v / 1e5, 3) for v in buf]    # 100 MHz ticks -> ms (whole run incl. warmup)
             for slot in (19, 27, 31):                             # counters: trust-region trials, single-launch rounds, solves
                 out["kprof_ms"][slot] = int(buf[slot])
+        if sustained_frames > 0:
+            # the headline mode itself over a longer sample of the same stream (same call, same threading, same image path)
+            sess.sync()
+            torch.cuda.synchronize()
+            k0, m0 = sess.times(), time.perf_counter()
+            if native:
+                sess.step_n(sustained_frames)
+            else:
+                for _ in range(sustained_frames):
+                    sess.step()
+            sess.sync()
+            torch.cuda.synchronize()
+            dt_s, k1 = time.perf_counter() - m0, sess.times()
+            out["sustained"] = {"value": round(sustained_frames / dt_s, 3), "unit": "frames/s", "frames": sustained_frames,
+                                "ms_per_step": round(1e3 * dt_s / sustained_frames, 4),
+                                "keyframes": int(k1.keyframes - k0.keyframes),
+                                "ms_per_ba_iteration": round((k1.ba_device_ms - k0.ba_device_ms) /
+                                                             max(1, k1.solve_iterations - k0.solve_iterations), 4),
+                                "note": "the timed region's mode continued for %d more frames of the same stream" % sustained_frames}
         if variant_frames > 0:
             # the same stream continued through the other three combinations of {host, resident} x {inline, pipelined}
             def leg(thr, res):
@@ -691,27 +715,44 @@ def main():
                 for _ in range(40):
                     cpu.step()
                 cpu.sync()
+                import ctypes
+                clk = (ctypes.c_double * 5)()
+                has_clk = hasattr(cpu.lib, "orc_shim_clocks")
+                if has_clk:
+                    cpu.lib.orc_shim_clocks(clk, 1)     # the checker's own solve / marginalisation clocks, reset behind the warm-up
                 c0, done = time.perf_counter(), 0
                 while done < nc - 40 and time.perf_counter() - c0 < args.cpu_seconds:
                     cpu.step()
                     done += 1
                 cpu.sync()
                 ct = time.perf_counter() - c0
+                if has_clk:
+                    cpu.lib.orc_shim_clocks(clk, 0)
                 cpu.close()
-                return round(done / ct, 3), done
+                ba = None
+                if has_clk and clk[2] > 0:
+                    ba = {"ms_per_ba_iteration": round(clk[0] / clk[2], 4), "solves": int(clk[1]), "iterations": int(clk[2]),
+                          "ms_per_solve": round(clk[0] / max(1.0, clk[1]), 4),
+                          "ms_per_marginalization": round(clk[3] / clk[4], 4) if clk[4] > 0 else None, "marginalizations": int(clk[4])}
+                return round(done / ct, 3), done, ba
 
             sample = ("frames 40..%d of the same stream (host images, the six reference symbols) through the same host pipeline linked "
                       "against the CPU oracle (oracle/_build/libxrslam_oracle.so, gcc -O2; our restatement, not the XRSLAM binary)")
             # the reference-faithful figure: solver num_threads = 1 (estimation/solver.cpp:185), image loops on one core
-            v1, d1 = cpu_leg(1)
+            v1, d1, ba1 = cpu_leg(1)
             out["cpu_baseline"] = {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": sample % (40 + d1) + ", single thread, inline"}
+            if ba1:
+                # the second half of BASELINE.json's metric on the same host and the same frames: wall clock of the checker's own
+                # Solver::solve / marginalize restatements (estimation/solver.cpp:176-190), all solves of the sample
+                out["cpu_baseline"].update({"ms_per_ba_iteration": ba1["ms_per_ba_iteration"],
+                                            "ms_per_marginalization": ba1["ms_per_marginalization"], "ba": ba1})
             # OpenCV spreads the image / LK point loops with parallel_for_: same sample with those loops on the host's
             # cores (capped at 16), solver and marginalisation still single-threaded like the reference, and the backend on a
             # thread of its own (the strongest CPU configuration this port has)
             cores = min(16, len(os.sched_getaffinity(0)))
             if cores > 1:
-                vm, dm = cpu_leg(cores, 1)
+                vm, dm, bam = cpu_leg(cores, 1)
                 out["cpu_baseline_mt"] = {"value": vm, "unit": "frames/s", "cores": cores, "kind": "port",
                                           "sample": sample % (40 + dm) + ", image and LK point loops on %d OpenMP threads, backend "
                                                     "thread beside the feature tracker (pipelined mode)" % cores}

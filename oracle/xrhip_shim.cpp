@@ -83,6 +83,31 @@ extern "C" void orc_inject_failure(int which, int countdown) {
     g_fail_which.store(which);
 }
 
+// The checker's own solve / marginalisation clocks (bench.py's cpu_baseline leg: BASELINE.json's metric is "frames/sec + ms/BA-iteration";
+// the reference times Solver::solve, estimation/solver.cpp:176-190).  Wall clock of orc_ba_solve / orc_ba_marginalize, process-wide,
+// nanoseconds; out[0..4] = solve ms, solves, dogleg iterations, marginalisation ms, marginalisations.
+#include <chrono>
+static std::atomic<long long> g_clk_solve_ns{0}, g_clk_solves{0}, g_clk_iters{0}, g_clk_marg_ns{0}, g_clk_margs{0};
+static inline long long clk_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+extern "C" void orc_shim_clocks(double *out5, int reset) {
+    if (out5) {
+        out5[0] = 1e-6 * (double)g_clk_solve_ns.load();
+        out5[1] = (double)g_clk_solves.load();
+        out5[2] = (double)g_clk_iters.load();
+        out5[3] = 1e-6 * (double)g_clk_marg_ns.load();
+        out5[4] = (double)g_clk_margs.load();
+    }
+    if (reset) {
+        g_clk_solve_ns = 0;
+        g_clk_solves = 0;
+        g_clk_iters = 0;
+        g_clk_marg_ns = 0;
+        g_clk_margs = 0;
+    }
+}
+
 extern "C" {
 
 const char *xrhip_last_error(void) { return g_err.c_str(); }
@@ -258,7 +283,17 @@ int xrhip_ba_solve(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summary *s) 
                 g_err = "xrhip_ba_preintegrate_after_solve: bias frame is not a frame of the solve";
                 return XRHIP_EINVAL;
             }
+    const long long t_solve = clk_ns();
     int rc = orc_ba_solve(P, s);
+    {
+        const long long dt = clk_ns() - t_solve;
+        g_clk_solve_ns += dt;
+        g_clk_solves += 1;
+        if (rc == 0 && s) {
+            g_clk_iters += s->iterations;
+            s->ms_solve = 1e-6 * (double)dt;   // like the product's summary: wall clock of the whole solve
+        }
+    }
     if (rc == 0 && c && c->have_deferred) {   // the deferred batch starts from the biases this solve produced
         c->have_deferred = false;
         const xrhip_ba::Deferred &d = c->deferred;
@@ -334,7 +369,10 @@ int xrhip_ba_solve_chained(xrhip_ba *c1, const xrhip_ba_problem *P1, xrhip_ba_su
     return xrhip_ba_solve(c2, P2, s2);
 }
 int xrhip_ba_marginalize(xrhip_ba *, const xrhip_marg_problem *M, double *a, double *b, double *c) {
+    const long long t_marg = clk_ns();
     int rc = orc_ba_marginalize(M, a, b, c);
+    g_clk_marg_ns += clk_ns() - t_marg;
+    g_clk_margs += 1;
     if (rc) g_err = "marginalize failed";
     return rc ? XRHIP_ESTATE : 0;
 }

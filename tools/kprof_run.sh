@@ -9,7 +9,7 @@ TAG="${1:?tag}"
 lib="$PWD/xrslam_amd/lib/libxrslam_hip_kprof.so"
 [ -f "$lib" ] || XR_VARIANT=kprof bash xrslam_amd/csrc/build.sh -DXRHIP_KPROF
 mkdir -p gpurun_out
-run() { env XRSLAM_HIP_LIB="$lib" "$@" python bench.py --steps 300 --warmup 50 --cpu-frames 0 --variant-frames 0 --threading inline 2>/dev/null | grep '^{' ; }
+run() { env XRSLAM_HIP_LIB="$lib" "$@" python bench.py --steps 300 --warmup 50 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --threading inline 2>/dev/null | grep '^{' ; }
 run XRHIP_KPROF_MAX_NA=16 > gpurun_out/kprof_${TAG}_tiny.json
 run XRHIP_KPROF_MIN_NA=17 XRHIP_KPROF_MAX_NA=99 > gpurun_out/kprof_${TAG}_mid.json
 run XRHIP_KPROF_MIN_NA=100 > gpurun_out/kprof_${TAG}_window.json
@@ -21,7 +21,7 @@ PY
 done
 # the instrumented library's own kernel durations (what the phase sums must be compared with)
 cd /tmp && export TMPDIR=/tmp
-XRSLAM_HIP_LIB="$lib" timeout 200 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_kprof_$TAG" -o full -- python "$R/bench.py" --steps 100 --warmup 40 --cpu-frames 0 --variant-frames 0 --no-profile > "$R/gpurun_out/prof_kprof_$TAG.log" 2>&1
+XRSLAM_HIP_LIB="$lib" timeout 200 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_kprof_$TAG" -o full -- python "$R/bench.py" --steps 100 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --no-profile > "$R/gpurun_out/prof_kprof_$TAG.log" 2>&1
 python - "$R/gpurun_out/prof_kprof_$TAG/full_results.db" <<'PY'
 import sqlite3, sys, collections
 c = sqlite3.connect(sys.argv[1])

@@ -37,26 +37,30 @@ def first(*patterns):
 c = sqlite3.connect(first("prof_%s/full_results.db" % tag, "prof_%s_*/full_results.db" % tag))
 rows = c.execute("select name,start,end from kernels order by start").fetchall()
 tot = collections.defaultdict(lambda: [0, 0])
+durs = collections.defaultdict(list)   # per kernel: every launch's duration (ns) -- an average hides one-offs (km_jacobi: one 3.9 ms run + 26 empty ones)
 for n, s, e in rows:
     k = n.split("(")[0]
     if k.startswith("void "):
         k = k[5:]
     tot[k][0] += e - s
     tot[k][1] += 1
+    durs[k].append(e - s)
 total = sum(t for t, _ in tot.values())
 b = [ln for ln in open(os.environ.get("XR_BENCH_JSON") or first("bench_%s.json" % tag, "bench_%s_[0-9]*.json" % tag)) if ln.startswith("{")][-1].strip()
 bj = json.loads(b)
 frames = max(1, tot["xrhip::k_clahe_lut"][1])   # one CLAHE pass per camera frame: counts the frames the traced command processed
 lines = ["# round %d, full pipeline %s (%s)" % (int(rnd[1:]), ver, desc), "",
-         "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 40 --cpu-frames 0 --variant-frames 0 --no-profile` (the reference-shaped call: inline, host image) on one MI355X",
+         "`rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --no-profile` (the reference-shaped call: inline, host image) on one MI355X",
          "(gfx950, ROCm 7.2); kernel-trace statistics from the results database.", "",
          ("Total kernel time %.2f ms over %d frames (%.3f ms / frame); default `python bench.py` on the same box: %.1f frames/s, "
           "%.4f ms/frame, %.4f ms/BA-iteration, CPU reference %.1f frames/s on 1 core (`" + rnd + "_full_%s_bench.json`).") %
          (total / 1e6, frames, total / 1e6 / frames, bj["value"], bj["ms_per_step"], bj["ms_per_ba_iteration"],
           bj.get("cpu_baseline", {}).get("value", float("nan")), ver), "",
-         "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+         "| kernel | calls | total ms | avg us | min / median / max us | % |", "|---|---|---|---|---|---|"]
 for k, (t, n) in sorted(tot.items(), key=lambda x: -x[1][0]):
-    lines.append("| `%s` | %d | %.2f | %.2f | %.1f |" % (k, n, t / 1e6, t / 1e3 / n, 100 * t / total))
+    d = sorted(durs[k])
+    lines.append("| `%s` | %d | %.2f | %.2f | %.1f / %.1f / %.1f | %.1f |" % (k, n, t / 1e6, t / 1e3 / n, d[0] / 1e3, d[len(d) // 2] / 1e3, d[-1] / 1e3,
+                                                                   100 * t / total))
 open(os.path.join(ROOT, "profiles", "%s_full_%s_kernel_stats.md" % (rnd, ver)), "w").write("\n".join(lines) + "\n")
 open(os.path.join(ROOT, "profiles", "%s_full_%s_bench.json" % (rnd, ver)), "w").write(b + "\n")
 
@@ -118,20 +122,27 @@ if os.path.exists(mf):
                 seen.add(key)
                 agg[n]["_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
                 agg[n]["_launches"] += 1
-    peaks = {}
+    peaks, peak_src = {}, None
     try:
         peaks = json.load(open(os.path.join(go, "peaks_%s.json" % tag)))
         json.dump(peaks, open(os.path.join(ROOT, "profiles", "%s_peaks.json" % rnd), "w"))
+        peak_src = "measured in the same call (`tools/peaks.hip`, `%s_peaks.json`)" % rnd
     except (OSError, ValueError):
-        pass
-    pk = peaks.get("mfma_f64_16x16x4_tflops", 78.6)
+        old_peaks = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_peaks.json")))
+        if old_peaks:       # the newest committed micro-benchmark of another box of the pool: say so
+            peaks = json.load(open(old_peaks[-1]))
+            peak_src = "measured on ANOTHER box of the pool (`%s`)" % os.path.basename(old_peaks[-1])
+    if "mfma_f64_16x16x4_tflops" in peaks:
+        pk, pk_label = peaks["mfma_f64_16x16x4_tflops"], "of measured peak"
+    else:
+        pk, pk_label, peak_src = 78.6, "of vendor peak", "NOT measured: the vendor figure"
     clock_ghz, simds = peaks.get("clock_mhz", 2400) / 1e3, peaks.get("cus", 256) * 4
     L = ["# round %d: f64 MFMA utilisation per kernel (%s)" % (int(rnd[1:]), ver), "",
          "`rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace` (own pass, no other",
          "trace domain) of `python bench.py --steps 60 --warmup 40 --cpu-frames 0 --no-profile`.  flop = MOPS_F64 x 512; TFLOP/s = flop / kernel",
-         "duration of the same pass; `of peak` against the f64 MFMA micro-kernel measured on the same box (%.1f TFLOP/s, `tools/peaks.hip`;" % pk,
-         "vendor figure 78.6); `pipe busy` = SQ_VALU_MFMA_BUSY_CYCLES / (duration x %.1f GHz x %d SIMDs)." % (clock_ghz, simds), "",
-         "| kernel | launches | avg us | MFMA flop / launch | TFLOP/s | of measured peak | pipe busy |", "|---|---|---|---|---|---|---|"]
+         "duration of the same pass; `%s` against the f64 MFMA rate %.1f TFLOP/s -- %s;" % (pk_label, pk, peak_src),
+         "the vendor figure is 78.6; `pipe busy` = SQ_VALU_MFMA_BUSY_CYCLES / (duration x %.1f GHz x %d SIMDs)." % (clock_ghz, simds), "",
+         "| kernel | launches | avg us | MFMA flop / launch | TFLOP/s | %s | pipe busy |" % pk_label, "|---|---|---|---|---|---|---|"]
     out = {}
     for n, a in sorted(agg.items(), key=lambda x: -x[1].get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0)):
         mops = a.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
