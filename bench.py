@@ -323,6 +323,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events around the KLT kernels")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl == RCCL); 'gloo' lets two "
                     "ranks share one GPU when the multi-process path is exercised on a single-GPU box")
+    ap.add_argument("--dump-poses", default=None, metavar="DIR",
+                    help="every rank writes the poses of each of its sequences (all frames up to the end of the timed region) to "
+                         "DIR/poses_rank<R>_seq<I>.npy -- tests compare them with solo runs of the same streams")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="exercise only the launcher / process-group path (no device needed, prints no measurement)")
     args = ap.parse_args()
@@ -503,6 +506,10 @@ def main():
     for s in sessions:
         s.set_profiling(False)
     my_elapsed = elapsed
+    if args.dump_poses:
+        os.makedirs(args.dump_poses, exist_ok=True)
+        for i, s in enumerate(sessions):
+            np.save(os.path.join(args.dump_poses, "poses_rank%d_seq%d.npy" % (rank, i)), np.array(s.poses))
     red = group.reduce_metrics(args.steps * S, elapsed)      # frames: SUM, wall seconds: MAX over ranks
     elapsed, total_frames = red["seconds"], red["frames"]
     # per-rank diagnostics into rank 0's line: a slow rank (clocked-down device, a device shared by two ranks) is visible there

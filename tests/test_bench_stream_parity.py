@@ -185,13 +185,20 @@ def test_gpu_matches_cpu_reference_on_the_s1_bench_stream(s1_seq, s1_cpu, mode):
 S2_MARKS = (76, 126, 176)
 
 
+@pytest.fixture(scope="module")
+def s2_seq():
+    return scene.make_sequence(n_frames=N_S2, seed=1, traj=Trajectory(amp=1.5, speed=1.0, rot=0.8), workers=WORKERS)
+
+
 @pytest.mark.gpu
-def test_gpu_matches_cpu_reference_on_the_s2_bench_stream():
+@pytest.mark.parametrize("mode", [0, 1], ids=["inline", "pipelined"])
+def test_gpu_matches_cpu_reference_on_the_s2_bench_stream(s2_seq, mode):
+    """Round 5: the pipelined mode -- whose `variants` the S2 line prints -- under the same output-log parity."""
     from xrslam_amd import _lib
-    seq = scene.make_sequence(n_frames=N_S2, seed=1, traj=Trajectory(amp=1.5, speed=1.0, rot=0.8), workers=WORKERS)
-    want = _run(ORACLE_LIB, seq, STRESS_YAML, 0, S2_MARKS)
+    want = _run(ORACLE_LIB, s2_seq, STRESS_YAML, mode, S2_MARKS)
     assert want[1][3] >= 20 and want[1][0] == N_S2         # marginalising: the 15-keyframe window is full by frame 76
-    _assert_same_run(_run(_lib.LIB_PATH, seq, STRESS_YAML, 0, S2_MARKS), want, seq, 0.06, "s2_inline")
+    _assert_same_run(_run(_lib.LIB_PATH, s2_seq, STRESS_YAML, mode, S2_MARKS), want, s2_seq, 0.06,
+                     "s2_%s" % ("pipelined" if mode else "inline"))
 
 
 # ------------------------------------------------------------------------------------------------ S3 (BASELINE config 5)
@@ -203,9 +210,26 @@ def s3_seq():
     return scene.make_sequence(n_frames=N_S3, seed=1, w=1280, h=720, K=(780.0, 778.0, 640.0, 360.0), workers=WORKERS)
 
 
+class _Lazy(dict):
+    """CPU reference runs by threading mode, computed on first use (the CPU-only suite needs the inline run only)."""
+
+    def __init__(self, make):
+        super().__init__()
+        self._make = make
+
+    def __missing__(self, mode):
+        self[mode] = self._make(mode)
+        return self[mode]
+
+
 @pytest.fixture(scope="module")
-def s3_cpu(s3_seq):
-    return _run(ORACLE_LIB, s3_seq, LARGE_YAML, 0, S3_MARKS, sensor_yaml=LARGE_SENSOR)
+def s3_cpu_by_mode(s3_seq):
+    return _Lazy(lambda mode: _run(ORACLE_LIB, s3_seq, LARGE_YAML, mode, S3_MARKS, sensor_yaml=LARGE_SENSOR))
+
+
+@pytest.fixture(scope="module")
+def s3_cpu(s3_cpu_by_mode):
+    return s3_cpu_by_mode[0]
 
 
 def test_cpu_pipeline_s3_stream_has_a_full_window_over_the_timed_frames(s3_seq, s3_cpu):
@@ -222,7 +246,8 @@ def test_cpu_pipeline_s3_stream_has_a_full_window_over_the_timed_frames(s3_seq, 
 
 
 @pytest.mark.gpu
-def test_gpu_matches_cpu_reference_on_the_s3_bench_stream(s3_seq, s3_cpu):
+@pytest.mark.parametrize("mode", [0, 1], ids=["inline", "pipelined"])
+def test_gpu_matches_cpu_reference_on_the_s3_bench_stream(s3_seq, s3_cpu_by_mode, mode):
     from xrslam_amd import _lib
-    got = _run(_lib.LIB_PATH, s3_seq, LARGE_YAML, 0, S3_MARKS, sensor_yaml=LARGE_SENSOR)
-    _assert_same_run(got, s3_cpu, s3_seq, 0.05, "s3_inline")
+    got = _run(_lib.LIB_PATH, s3_seq, LARGE_YAML, mode, S3_MARKS, sensor_yaml=LARGE_SENSOR)
+    _assert_same_run(got, s3_cpu_by_mode[mode], s3_seq, 0.05, "s3_%s" % ("pipelined" if mode else "inline"))

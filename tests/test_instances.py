@@ -177,3 +177,95 @@ def test_instance_create_reports_errors():
     assert lib.XRSLAMAmdInstanceCreate(b"/nonexistent/slam.yaml", b"/nonexistent/sensor.yaml", C.byref(h), C.byref(cfg)) == 0
     assert not h.value
     assert lib.XRSLAMAmdLastError().decode() != ""
+
+
+# ------------------------------------------------------------------------------------- grouped members under the output-log parity
+# Round 5: the grouped figures bench.py quotes time frames 56..256 and beyond of the S1 bench stream
+# (configs/bench_slam_150.yaml, seeds 1..S); the 72-frame test above compares poses and five counters.  Here eight members run 320
+# frames of that stream each and every member's WHOLE output log (tests/outlog.py: key points, track ids, pose / velocity / biases,
+# window, tags, inverse depths, landmarks) must equal its solo run's byte for byte -- a group shares launches, it must not change a bit.
+def _run_logged(lib_path, seq, yaml, group=None, start=None):
+    """One instance session with XRSLAM_AMD_DUMP_OUT; -> (session, path).  The variable is read when the pipeline is constructed."""
+    import tempfile
+    fd, out_path = tempfile.mkstemp(prefix="xr_out_", suffix=".bin")
+    os.close(fd)
+    os.environ["XRSLAM_AMD_DUMP_OUT"] = out_path
+    try:
+        s = runner.Session(lib_path, seq, slam_yaml=yaml, instance=True, group=group)
+    finally:
+        del os.environ["XRSLAM_AMD_DUMP_OUT"]
+    return s, out_path
+
+
+def _grouped_output_logs(lib_path, seeds, n, yaml, workers=8):
+    from tests import outlog
+    seqs = [scene.make_sequence(n_frames=n, seed=sd, workers=workers) for sd in seeds]
+    solo = []
+    for q in seqs:
+        s, path = _run_logged(lib_path, q, yaml)
+        res = _drain(s)
+        solo.append((res, outlog.read(path)))
+        os.unlink(path)
+    group = runner.Group(lib_path)
+    members = [_run_logged(lib_path, q, yaml, group=group) for q in seqs]
+    res, errs = [None] * len(seqs), []
+
+    def work(i):
+        try:
+            res[i] = _drain(members[i][0])
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(seqs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    stats = group.stats()
+    group.close()
+    assert not errs, errs
+    logs = []
+    for _, path in members:
+        logs.append(outlog.read(path))
+        os.unlink(path)
+    return solo, list(zip(res, logs)), stats
+
+
+def _assert_logs_identical(solo, grouped, min_frames):
+    from tests import outlog
+    digest = []
+    for i, ((ra, la), (rg, lg)) in enumerate(zip(solo, grouped)):
+        assert ra[1] == rg[1], "member %d: counters" % i
+        np.testing.assert_array_equal(ra[0], rg[0])
+        st = outlog.compare(lg, la, rtol=0, atol_px=0, atol_state=0, atol_point=0)
+        assert st["frames"] >= min_frames and st["backend_frames"] >= min_frames - 60
+        assert st["keypoints_bit_identical"] == st["keypoints"] > 50 * st["frames"]
+        assert st["landmarks_bit_identical"] == st["landmarks"] > 50 * st["backend_frames"]
+        assert st["states_bit_identical"] == st["backend_frames"]
+        assert st["max_px_diff"] == 0.0 and st["max_state_rel"] == 0.0
+        st["member"], st["marginalizations"] = i, int(ra[1][3])
+        digest.append(st)
+    return digest
+
+
+def test_grouped_members_write_their_solo_output_logs_cpu():
+    """The comparison itself, on the CPU reference build (nothing is batched there): three members, 64 frames."""
+    bench_yaml = os.path.join(ROOT, "configs", "bench_slam_150.yaml")
+    solo, grouped, _ = _grouped_output_logs(ORACLE_LIB, (1, 2, 3), 64, bench_yaml, workers=max(1, min(8, len(os.sched_getaffinity(0)))))
+    _assert_logs_identical(solo, grouped, 64)
+
+
+@pytest.mark.gpu
+def test_eight_grouped_members_write_their_solo_output_logs_on_the_bench_stream_gpu():
+    """8 members x 320 frames of the S1 bench stream (seeds 1..8: bench.py --sequences-per-gpu 8), >= 50 marginalisations each."""
+    import json
+    from xrslam_amd import _lib
+    bench_yaml = os.path.join(ROOT, "configs", "bench_slam_150.yaml")
+    solo, grouped, stats = _grouped_output_logs(_lib.LIB_PATH, tuple(range(1, 9)), 320, bench_yaml,
+                                                workers=max(1, min(16, len(os.sched_getaffinity(0)))))
+    digest = _assert_logs_identical(solo, grouped, 320)
+    assert all(d["marginalizations"] >= 50 for d in digest)
+    for kind in ("preprocess", "track", "chain", "preint"):
+        assert stats[kind]["batches"] < stats[kind]["requests"], (kind, stats)     # launches were in fact shared
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "group_outlog_parity_8x320.json"), "w") as fh:
+        json.dump({"members": digest, "group": stats}, fh, indent=1)
