@@ -71,7 +71,9 @@ void xrhip_klt_destroy(xrhip_klt *ctx);
 int xrhip_image_create(xrhip_klt *ctx, xrhip_image **out);
 int xrhip_image_upload(xrhip_image *img, const uint8_t *gray, int stride_bytes);
 /* same, but `gray_dev` already lives in HBM (device pointer; used by bench.py so
- * the timed region starts with inputs resident on the device). */
+ * the timed region starts with inputs resident on the device).  The copy is stream-ordered and, for a member of a
+ * group, submitted with the frame's preprocessing: `gray_dev` must stay valid until xrhip_image_preprocess (or the
+ * first call that reads the plane) has returned. */
 int xrhip_image_upload_device(xrhip_image *img, const void *gray_dev, int stride_bytes);
 /* Undistortion on the device.  replaces: cv::undistort in the dataset reader
  * (xrslam-pc/player/src/IO/euroc_dataset_reader.cpp:62-69) / xrslam::extra::ImageUndistorter::undistort_image

@@ -47,6 +47,7 @@ struct ChainPayload {
 
 struct xrhip_ba {
     hipStream_t stream = nullptr;
+    int device = 0;   // the device the context was created on (a group of another device is refused)
     // instance group (group.hip.h): the single-launch solves and the pre-integration batches travel as requests
     xrhip_group *group = nullptr;
     GroupRequest rq_chain, rq_preint;
@@ -766,6 +767,7 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
     int rc = xr_require_device();
     if (rc) return rc;
     xrhip_ba *c = new xrhip_ba();
+    XR_HIP(hipGetDevice(&c->device));
     XR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     XR_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     XR_HIP(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
@@ -791,6 +793,8 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
 int xrhip_ba_join_group(xrhip_ba *c, xrhip_group *g) {
     if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_join_group: null context");
     if (c->group == g) return XRHIP_OK;
+    if (g && group_device(g) != c->device)
+        return xr_fail(XRHIP_EINVAL, "xrhip_ba_join_group: the context and the group live on different devices");
     if (c->preint_pending) {   // a batch between begin and end: it completes where it was queued and stays collectable
         if (c->preint_rq) {
             int rc = group_wait_launched(c->preint_rq);
@@ -1015,9 +1019,7 @@ int xrhip_ba_solve_linked(xrhip_ba *c2, const xrhip_ba_problem *P2, xrhip_ba_sum
         return xrhip_ba_solve_overlapped(c2, P2, s2, host_work, arg);
     };
     if (c1->group != c2->group || c2->begun.active || !any_free_block(P2)) return sequential();
-    const auto t_begin = std::chrono::steady_clock::now();
-    A.handed_over = true;
-    A.t_hand = t_begin;
+    const auto t_begin = std::chrono::steady_clock::now();   // the first solve's clock stops here ONCE the linked request is out (below)
     BaDims d2;
     BaPtrs p2;
     Ext cam2, imu2;
@@ -1078,6 +1080,8 @@ int xrhip_ba_solve_linked(xrhip_ba *c2, const xrhip_ba_problem *P2, xrhip_ba_sum
             if (rc) return rc;
         }
     }
+    A.handed_over = true;   // submitted: the first solve's summary time runs to t_begin, this solve's clock covers the rest
+    A.t_hand = t_begin;
     if (cp.with_preint) {   // the batch queued behind this solve is in flight from here on
         c2->preint_pending = c2->preint_deferred;
         c2->preint_deferred = 0;

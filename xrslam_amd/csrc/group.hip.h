@@ -63,6 +63,7 @@ int group_call(xrhip_group *g, int queue, void *owner, std::function<int(hipStre
 // ... and when everything submitted to `queue` before it has completed on the device
 int group_drain(xrhip_group *g, int queue, void *owner);
 hipStream_t group_stream(xrhip_group *g, int queue);
+int group_device(xrhip_group *g);   // the device the group's streams live on: a context of another device must not join
 hipStream_t group_side_stream(xrhip_group *g, int queue);
 void group_member_add(xrhip_group *g, bool front_end);   // front_end: a KLT context, i.e. one more sequence in the group
 void group_member_remove(xrhip_group *g, bool front_end);

@@ -3,6 +3,7 @@
 
 #include "common.hip.h"
 
+#include <cstdio>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -200,6 +201,7 @@ struct xrhip_group {
             }
             if (active) {
                 idle_since = std::chrono::steady_clock::now();
+                relax();   // a batch in flight or a held-back request: poll, but leave the core's issue slots to the members' threads
                 continue;
             }
             if (quit.load(std::memory_order_acquire)) {
@@ -274,6 +276,7 @@ int group_drain(xrhip_group *g, int queue, void *owner) {
 }
 
 hipStream_t group_stream(xrhip_group *g, int queue) { return g->qs[queue].stream; }
+int group_device(xrhip_group *g) { return g->device; }
 hipStream_t group_side_stream(xrhip_group *g, int queue) { return g->qs[queue].side; }
 void group_member_add(xrhip_group *g, bool front_end) {
     g->members.fetch_add(1);
@@ -338,6 +341,15 @@ int xrhip_group_create(xrhip_group **out) {
     const char *qe = std::getenv("GPU_MAX_HW_QUEUES"), *pe = std::getenv("XRHIP_GROUP_PRIORITY");
     const bool want_prio = pe ? std::atoi(pe) != 0 : (qe && std::atoi(qe) > 0 && std::atoi(qe) <= 2);
     const bool use_prio = want_prio && hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) == hipSuccess && prio_high != prio_low;
+    // The split above rests on a process-global knob an embedding application may not know about: say so once instead of silently
+    // running the slower arrangement (XRHIP_GROUP_QUIET=1 silences it; the group works either way, bit for bit).
+    if (!(qe && std::atoi(qe) > 0 && std::atoi(qe) <= 2) && !std::getenv("XRHIP_GROUP_QUIET")) {
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true))
+            std::fprintf(stderr, "xrslam_hip: instance group created with GPU_MAX_HW_QUEUES=%s: the group's queue split (two hardware queues for "
+                                 "the batches, two for the members' window solves) needs GPU_MAX_HW_QUEUES=2 in the environment BEFORE the "
+                                 "process's first HIP call; without it grouped throughput is ~15 %% lower (DESIGN.md 4.9)\n", qe ? qe : "unset");
+    }
     // XRHIP_GROUP_SIDE_STREAM=1: the front end's Harris passes on a second stream of the KLT queue (nobody waits for them before the
     // next frame's tracks have been digested).  Off by default: one more stream competing for the hardware queues cost more than the
     // overlap gave (10 sequences: 5272 with, 5518 without).

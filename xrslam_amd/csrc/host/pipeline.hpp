@@ -251,9 +251,24 @@ struct Pipeline {
     xrhip_group *group = nullptr;
     void join_group(xrhip_group *g) {
         marg_launch_wait();
-        hip_check(xrhip_klt_join_group(klt, g), "xrhip_klt_join_group");
-        for (xrhip_ba *c : {ba, ba_aux, ba_ft, ba_sub})
-            if (c) hip_check(xrhip_ba_join_group(c, g), "xrhip_ba_join_group");
+        // All or nothing: if a context refuses, the ones already moved return to the group they came from, so that the
+        // instance is never half-joined (ensure_ft_context would otherwise create ba_ft outside the group its siblings are in).
+        xrhip_group *const old = group;
+        bool klt_moved = false;
+        std::vector<xrhip_ba *> moved;
+        try {
+            hip_check(xrhip_klt_join_group(klt, g), "xrhip_klt_join_group");
+            klt_moved = true;
+            for (xrhip_ba *c : {ba, ba_aux, ba_ft, ba_sub})
+                if (c) {
+                    hip_check(xrhip_ba_join_group(c, g), "xrhip_ba_join_group");
+                    moved.push_back(c);
+                }
+        } catch (...) {
+            for (xrhip_ba *c : moved) xrhip_ba_join_group(c, old);   // best effort: the original error is the one reported
+            if (klt_moved) xrhip_klt_join_group(klt, old);
+            throw;
+        }
         group = g;
     }
     xrhip_image *acquire_image() {

@@ -406,6 +406,8 @@ extern "C" {
 int xrhip_klt_join_group(xrhip_klt *c, xrhip_group *g) {
     if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_klt_join_group: null context");
     if (c->group == g) return XRHIP_OK;
+    if (g && group_device(g) != c->device)
+        return xr_fail(XRHIP_EINVAL, "xrhip_klt_join_group: the context and the group live on different devices");
     // whatever the context has queued so far completes where it was queued
     {
         const int rc = flush_upload(c);
@@ -538,6 +540,9 @@ int xrhip_image_create(xrhip_klt *c, xrhip_image **out) {
 
 void xrhip_image_destroy(xrhip_image *im) {
     if (!im) return;
+    // a grouped upload that nobody has submitted yet and that writes THIS plane: dropped, not submitted later into freed memory
+    // (the context's teardown flushes whatever is pending)
+    if (im->ctx->upload_pending && im->ctx->a_upload.dst == im->raw) im->ctx->upload_pending = false;
     if (im->ctx->group) group_drain(im->ctx->group, GQ_KLT, im->ctx);
     hipStreamSynchronize(im->ctx->stream);
     hipFree(im->raw);

@@ -846,6 +846,10 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
             o[5 + i] = sp3[i];
             o[8 + i] = sv3[i];
         }
+        if (job.sample_count <= 0) {   // no chunk ran, so nobody published the early delta: it is the identity just written
+            __threadfence_system();
+            *reinterpret_cast<volatile int *>(ea.early + blockIdx.x) = 1;
+        }
     }
     if (tid < 45) o[11 + tid] = want_jac ? res[PN_C + tid] : 0.0;
     if (!want_cov) {
