@@ -1501,13 +1501,7 @@ extern "C" {
 // reported that the Cholesky path does not apply, and hands the prior out.
 // status words of a marginalisation (device, 8 ints): [0] singular victim block, [1] support size, [2] Cholesky failed (later: the
 // sweeps of the eigen path), [3] eigenvalue guard failed, [4] the eigen path was taken, [5] the support size km_jacobi sees
-__global__ void kx_marg_gate(int *st) {
-    if (threadIdx.x == 0) {
-        const int need = (st[2] != 0 || st[3] != 0) ? 1 : 0;
-        st[4] = need;
-        st[5] = need ? st[1] : 0;
-    }
-}
+// (round 5: the gate -- st[4] = the eigen path is needed, st[5] = its support size -- is the tail of km_chol, marg_kernels.hip.h)
 
 static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     if (c->marg.pending) return xr_fail(XRHIP_ESTATE, "xrhip_ba_marginalize: a marginalisation is already in flight");
@@ -1595,18 +1589,19 @@ static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     const int lds_doubles = c->lds_limit / (int)D8;
     hipLaunchKernelGGL(km_support, dim3(1), dim3(512), 0, s, R, A, bp, dsup, dsn, As, bs);
     // fast path: Cholesky factor of the compacted matrix as sqrt_info (valid when no eigenvalue is near the 1e-8 floor)
-    hipLaunchKernelGGL(km_chol, dim3(1), dim3(512), (size_t)c->lds_limit, s, dsn, lds_doubles, As, bs, Ss, ivs,
+    hipLaunchKernelGGL(km_chol, dim3(1), dim3(512), (size_t)c->lds_limit, s, dsn, lds_doubles, As, bs, dsup, R, dsi, div,
                        (double *)(W2 + o_lam), dst);
     XR_HIP(hipGetLastError());
     // The eigen path (the reference's SelfAdjointEigenSolver route, km_jacobi: milliseconds) is needed when the Cholesky
     // factor failed or an eigenvalue sits near the 1e-8 floor -- typically the first marginalisation of a sequence.  It used to
     // be started by the HOST when it collected the result, i.e. on the critical path of the next refine_window.  Now the
-    // device decides: kx_marg_gate hands km_jacobi the support size if the fast path's status words ask for the fallback, and 0
+    // device decides: km_chol's tail hands km_jacobi the support size if the fast path's status words ask for the fallback, and 0
     // otherwise (km_jacobi returns at once on an empty support), so the fallback runs behind the fast path on this context's
     // own stream like the rest of the marginalisation.  Then one expansion of whichever factor is in place, and the copies.
-    hipLaunchKernelGGL(kx_marg_gate, dim3(1), dim3(64), 0, s, dst);
-    hipLaunchKernelGGL(km_jacobi, dim3(1), dim3(1024), (size_t)c->lds_limit, s, dst + 5, lds_doubles, As, bs, B, V, Ss, ivs, 60, dst + 2);
-    hipLaunchKernelGGL(km_expand, dim3((R * R + 255) / 256), dim3(256), 0, s, R, dsup, dsn, Ss, ivs, dsi, div);
+    // round 5: km_chol ends with the gate and has already expanded its own factor; km_jacobi (an empty launch unless the gate asks for
+    // it) expands its own -- two launches instead of five behind the factorisation
+    hipLaunchKernelGGL(km_jacobi, dim3(1), dim3(1024), (size_t)c->lds_limit, s, dst + 5, lds_doubles, As, bs, B, V, Ss, ivs, 60, dst + 2,
+                       dsup, R, dsi, div);
     XR_HIP(hipGetLastError());
     XR_HIP(hipMemcpyAsync(hs, dsi, D8 * (size_t)R * R, hipMemcpyDeviceToHost, s));
     XR_HIP(hipMemcpyAsync(hs + (size_t)R * R, div, D8 * R, hipMemcpyDeviceToHost, s));

@@ -33,78 +33,6 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-// ---- DPP64 broadcasts (round 5).  The diagonal-block routines below are bound by the instructions ONE wavefront issues (~1000 per 16x16
-// block: 303 v_readlane, 465 f64 operations, 70 s_nop -- profiles/r03_ab_variants.md), two thirds of them the rank-1 updates: per
-// (column c, later column k) a v_readlane pair that carries L[k][c] through scalar registers and a multiply + subtract per half (rows /
-// inverse).  gfx90a+ has 64-bit DPP with `row_newbcast:n` (lane n of every 16-lane row to all lanes of that row) on v_mov_b64 and
-// v_fmac_f64: the whole update `X[k] -= L[k][c] * X[c]` is ONE instruction, v_fmac_f64_dpp X[k], X[c]{lane k}, -X[c] -- no scalar round
-// trip, no hazard nops of the readlane -> VALU path.  The product is now fused into the subtraction (one rounding instead of two): results
-// move in the last bit against rounds 1-4 (and stay as far from the CPU oracle's plain Cholesky as before, tests/ tolerances unchanged).
-// A broadcast only reaches its own 16-lane row, so every row of the wavefront carries the same block (redundant lanes are free).
-// (Inline asm: the compiler's hazard recogniser does not look inside, hence the explicit two wait states in front of a DPP read.)
-template <int K> __device__ __forceinline__ double row_bcast64(double v) {
-    double r;
-    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
-    return r;
-}
-// acc += (value of `src` in lane K of this lane's row) * mul.  `src` must have passed through dpp_fence() since it was last written.
-template <int K> __device__ __forceinline__ void fmac_bcast64(double &acc, double src, double mul) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
-}
-// The two wait states between a VALU write of a register and DPP reads of it, paid once per value instead of once per read: every
-// later DPP reader takes the value from this statement's output, so the scheduler cannot move one in front of it.
-__device__ __forceinline__ void dpp_fence(double &v) { asm("s_nop 1" : "+v"(v)); }
-// sqrt(d) and 1/sqrt(d) together from the hardware reciprocal square root (v_rsq_f64, ~24 bits) and two coupled Newton steps -- the
-// library sqrt followed by a division is ~3x as long, and this sits on the serial chain of every pivot.  Pivots here are O(1) after
-// Jacobi scaling (1e30 at most, in the marginalisation): no denormals.
-__device__ __forceinline__ void sqrt_rsqrt(double dcc, double &dd, double &dinv) {
-    const double r0 = __builtin_amdgcn_rsq(dcc);
-    dd = dcc * r0;
-    double hh = 0.5 * r0;
-    double e = fma(-hh, dd, 0.5);
-    dd = fma(dd, e, dd);
-    hh = fma(hh, e, hh);
-    e = fma(-hh, dd, 0.5);
-    dd = fma(dd, e, dd);
-    hh = fma(hh, e, hh);
-    const double res = fma(-dd, dd, dcc);
-    dd = fma(res, hh, dd);
-    dinv = hh + hh;
-}
-// Columns C+1 .. 15 of a 16x16 block take the rank-1 update of column C: X (rows of the block, lane = row) and, if WITH_INV, Y (the
-// forward substitution of the unit vectors, lane = column of the inverse) -- compile-time recursion: the DPP lane is an immediate.
-template <int C, int K, bool WITH_INV> struct DiagUpdate {
-    static __device__ __forceinline__ void run(double (&X)[16], double (&Y)[16], double nxc, double nyc) {
-        if constexpr (K < 16) {
-            fmac_bcast64<K>(X[K], X[C], nxc);                   // A[l][K] -= L[K][C] L[l][C]
-            if constexpr (WITH_INV) fmac_bcast64<K>(Y[K], X[C], nyc);   // acc[K] -= L[K][C] Linv[C][m]
-            DiagUpdate<C, K + 1, WITH_INV>::run(X, Y, nxc, nyc);
-        }
-    }
-};
-// All 16 columns of a block whose rows sit in X (lane & 15 = row, upper triangle zero): L in place; Y (start: the unit vectors, Y[k] =
-// delta(k, lane & 15)) ends as the columns of L^-1, Y[r] = Linv[r][lane & 15].  nb: rows that are pivots (the others ride along).
-template <int C, bool WITH_INV> struct DiagColumns {
-    static __device__ __forceinline__ void run(double (&X)[16], double (&Y)[16], double (&dinv)[16], int nb, int l16, bool &ok) {
-        if constexpr (C < 16) {
-            double dcc = row_bcast64<C>(X[C]);
-            if (C >= nb) dcc = 1.0;   // not a pivot: the row only rides along
-            if (!(dcc > 0.0) || !isfinite(dcc)) {
-                ok = false;
-                dcc = 1.0;
-            }
-            double dd, di;
-            sqrt_rsqrt(dcc, dd, di);
-            dinv[C] = di;
-            X[C] = (l16 == C) ? dd : X[C] * di;                 // L[l][C] = x / d (the pivot row itself: d)
-            if constexpr (WITH_INV) Y[C] = Y[C] * di;           // Linv[C][m] = acc / d
-            if constexpr (C < 15) dpp_fence(X[C]);
-            DiagUpdate<C, C + 1, WITH_INV>::run(X, Y, -X[C], WITH_INV ? -Y[C] : 0.0);
-            DiagColumns<C + 1, WITH_INV>::run(X, Y, dinv, nb, l16, ok);
-        }
-    }
-};
-
 #ifdef XRHIP_KPROF
 #define CHPROF(slot)                                  \
     do {                                              \
@@ -141,60 +69,6 @@ typedef double chol_d4 __attribute__((ext_vector_type(4)));
     do {             \
     } while (0)
 #endif
-#ifndef XRHIP_DIAG_READLANE
-template <bool WITH_RHS>
-__device__ __forceinline__ bool chol_diag_wave_t(double *A, int j0, int nb, double (*Dinv)[CH_NB + 1], int lane, double *rhs,
-                                                 long long *dprof = nullptr) {
-#ifdef XRHIP_KPROF
-    long long t_dg = wall_clock64();
-#endif
-    // Every 16-lane row of the wavefront holds the block (lane & 15 = row; rows >= nb are identity rows): the DPP broadcasts of the
-    // column operations stay inside a row (see row_bcast64).  Y: the inverse under construction, lane & 15 = its column.
-    const int l16 = lane & 15;
-    double x[CH_NB], y[CH_NB], dinv[CH_NB];
-#pragma unroll
-    for (int k = 0; k < CH_NB; ++k) {
-        x[k] = (l16 < nb && k <= l16) ? A[tri_idx(j0 + l16, j0 + k)] : ((k == l16) ? 1.0 : 0.0);
-        y[k] = (k == l16) ? 1.0 : 0.0;
-    }
-    DGPROF(4);   // block load
-    bool ok = true;
-    DiagColumns<0, !WITH_RHS>::run(x, y, dinv, CH_NB, l16, ok);
-    ok = __all(ok);
-    DGPROF(5);   // factorisation (+ inverse)
-    if (WITH_RHS) {
-        double r = (l16 < nb) ? rhs[j0 + l16] : 0.0;
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c) {
-            const double xc = lane_bcast(r, c) * dinv[c];
-            if (l16 == c) r = xc;
-            else if (l16 > c) r -= x[c] * xc;   // L[lane][c]
-        }
-        if (lane < nb) {
-            rhs[j0 + lane] = r;
-#pragma unroll
-            for (int k = 0; k < CH_NB; ++k)
-                if (k <= lane) A[tri_idx(j0 + lane, j0 + k)] = x[k];
-        }
-        return ok;
-    }
-    // Lanes 0-15 store their row of L, lanes 16-31 their column of the inverse (the same values sit in every row of the wavefront);
-    // the others aim at the padding column of Dinv.
-    {
-        const bool is_inv = lane >= CH_NB && lane < 2 * CH_NB;
-        const int col = is_inv ? l16 : CH_NB;
-#pragma unroll
-        for (int r = 0; r < CH_NB; ++r) Dinv[r][col] = y[r];
-    }
-    if (lane < CH_NB) {
-#pragma unroll
-        for (int k = 0; k < CH_NB; ++k)
-            if (lane < nb && k <= lane) A[tri_idx(j0 + lane, j0 + k)] = x[k];
-    }
-    DGPROF(6);   // write-back
-    return ok;
-}
-#else   // rounds 1-4: broadcasts through v_readlane, multiply and subtract as two operations (A/B build: -DXRHIP_DIAG_READLANE)
 template <bool WITH_RHS>
 __device__ __forceinline__ bool chol_diag_wave_t(double *A, int j0, int nb, double (*Dinv)[CH_NB + 1], int lane, double *rhs,
                                                  long long *dprof = nullptr) {
@@ -285,7 +159,6 @@ __device__ __forceinline__ bool chol_diag_wave_t(double *A, int j0, int nb, doub
     DGPROF(6);   // write-back
     return ok;
 }
-#endif
 __device__ __forceinline__ bool chol_diag_wave(double *A, int j0, int nb, double (*Dinv)[CH_NB + 1], int lane,
                                                double *rhs = nullptr, long long *dprof = nullptr) {
     return rhs ? chol_diag_wave_t<true>(A, j0, nb, Dinv, lane, rhs, dprof) : chol_diag_wave_t<false>(A, j0, nb, Dinv, lane, nullptr, dprof);
@@ -482,6 +355,69 @@ __device__ __forceinline__ void trsv_lower_t(const double *A, int n, double *y) 
 }
 
 
+// X <- L^-1 for a packed lower-triangular L (n x n, tri_idx) in LDS; X is a second packed triangle.  All threads must call.
+// Used by the marginalisation's eigenvalue guard (km_chol): |L^-1|_F^2 = trace(A^-1).  Round 4 did one forward substitution per THREAD
+// (column j of the inverse: a dependent chain of up to n^2 / 2 multiply-adds on one lane -- most of km_chol's 126 us); here 16-wide
+// blocks: the diagonal blocks by one wavefront each (lane = column, the block's entries are wave-uniform LDS reads), then block row
+// after block row X_ij = -X_ii (sum_{k=j}^{i-1} L_ik X_kj) on the f64 matrix cores, one 16x16 tile per wavefront at a time.
+__device__ __forceinline__ void tri_inverse_blocked(const double *L, double *X, int n) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int T = (n + 15) >> 4;
+    for (int b = wave; b < T; b += nw) {
+        const int j0 = 16 * b, nb = min(16, n - j0);
+        double y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double acc = (r == r16) ? 1.0 : 0.0;
+            const bool row = r < nb;
+            const double *Lr = L + tri_idx(j0 + (row ? r : 0), j0);
+#pragma unroll
+            for (int k = 0; k < r; ++k) acc = fma(-(row ? Lr[k] : 0.0), y[k], acc);
+            y[r] = row ? acc / Lr[r] : acc;
+        }
+        if (lane < nb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (r >= lane && r < nb) X[tri_idx(j0 + r, j0 + lane)] = y[r];
+        }
+    }
+    __syncthreads();
+    for (int i = 1; i < T; ++i) {
+        for (int j = wave; j < i; j += nw) {
+            chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const int gi = 16 * i + r16;
+            const bool vi = gi < n;
+            for (int k = j; k < i; ++k) {
+                const double *pa = L + tri_idx(vi ? gi : 0, 16 * k + q);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int kk = 4 * s4 + q;   // row of X_kj, column of L_ik
+                    const double av = vi ? pa[4 * s4] : 0.0;
+                    const bool vb = (k > j) || (r16 <= kk);   // X_jj is lower triangular
+                    const double bv = vb ? X[tri_idx(16 * k + kk, 16 * j + (vb ? r16 : 0))] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+            }
+            // S[(q + 4 r)][r16] sits in acc[r]: exactly the B operand (k = 4 s4 + q, n = r16) of the second product's step s4 = r
+            chol_d4 out = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int kk = 4 * s4 + q;
+                const bool va = vi && kk <= r16;
+                const double av = va ? X[tri_idx(gi, 16 * i + kk)] : 0.0;   // X_ii[r16][kk]
+                out = __builtin_amdgcn_mfma_f64_16x16x4f64(av, acc[s4], out, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oi = 16 * i + q + 4 * r;
+                if (oi < n) X[tri_idx(oi, 16 * j + r16)] = -out[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // =====================================================================================================================
 // Tiled variant (round 3) -- for systems that live in LDS.
 //
@@ -522,52 +458,6 @@ __device__ __forceinline__ void tl_clear(double *A, int n, int nrows) {
 // Wavefront 0.  Factors the diagonal tile `tile` (in place: L in the lower triangle), leaves the block's inverse in Dinv (for the
 // panel product) and, transposed, in the tile's upper triangle + dinv16 (for the back-substitution).  nb: rows of the block that are
 // matrix rows; rows nb.. (a right-hand-side row, padding) take part in the column operations but are never pivots.
-#ifndef XRHIP_DIAG_READLANE
-__device__ __forceinline__ bool tl_diag_wave(double *tile, int nb, double (*Dinv)[CH_NB + 1], double *dinv16, int lane,
-                                             long long *dprof = nullptr) {
-#ifdef XRHIP_KPROF
-    long long t_dg = wall_clock64();
-#endif
-    // Round 5: every 16-lane row of the wavefront holds the block's rows in X (lane & 15 = row) and the forward substitution of the unit
-    // vectors in Y (lane & 15 = column of the inverse); the column operations are DPP broadcasts inside a row (DiagColumns).  The four
-    // rows of the wavefront then share the write-back: row 0 stores L, row 1 the inverse for the panel product, row 2 its transpose into
-    // the tile's upper triangle, row 3 the inverse's diagonal.
-    const int l16 = lane & 15, grp = lane >> 4;
-    double X[CH_NB], Y[CH_NB], dinv[CH_NB];
-#pragma unroll
-    for (int k = 0; k < CH_NB; ++k) {
-        const double v = tile[k * TL_LD + l16];
-        X[k] = k <= l16 ? v : 0.0;
-        Y[k] = (k == l16) ? 1.0 : 0.0;
-    }
-    DGPROF(4);   // block load
-    bool ok = true;
-    DiagColumns<0, true>::run(X, Y, dinv, nb, l16, ok);
-    ok = __all(ok);
-    DGPROF(5);   // factorisation + inverse
-    // write-back.  Row lane l: L[l][k], k <= l, to (l, k).  Inverse lane m (Y[r] = Linv[r][m], r >= m): Dinv[r][m] for the panel product;
-    // transposed into the strictly upper triangle, (m, r) for r > m; the diagonal to dinv16.
-    double *dummy = &Dinv[0][CH_NB];   // padding column: a harmless target for lanes that have nothing to store
-#pragma unroll
-    for (int k = 0; k < CH_NB; ++k) {
-        double *dst = dummy;
-        double v = Y[k];
-        if (grp == 0) {
-            v = X[k];
-            if (k <= l16) dst = tile + k * TL_LD + l16;
-        } else if (grp == 1) {
-            dst = &Dinv[k][l16];
-        } else if (grp == 2) {
-            if (k > l16) dst = tile + k * TL_LD + l16;
-        } else if (k == l16) {
-            dst = dinv16 + l16;
-        }
-        *dst = v;
-    }
-    DGPROF(6);   // write-back
-    return ok;
-}
-#else   // rounds 3-4 (A/B build: -DXRHIP_DIAG_READLANE)
 __device__ __forceinline__ bool tl_diag_wave(double *tile, int nb, double (*Dinv)[CH_NB + 1], double *dinv16, int lane,
                                              long long *dprof = nullptr) {
 #ifdef XRHIP_KPROF
@@ -644,7 +534,6 @@ __device__ __forceinline__ bool tl_diag_wave(double *tile, int nb, double (*Dinv
     return ok;
 }
 
-#endif
 // tile (ti, tj) -= P_ti P_tj^T with the panel tiles of tile column tc; computed as the TRANSPOSED product (operands swapped) so that
 // the accumulator's lane layout, D[(lane >> 4) + 4 r][lane & 15], is a column-major store
 __device__ __forceinline__ void tl_trailing_tile(double *A, int tc, int ti, int tj, int r16, int q) {

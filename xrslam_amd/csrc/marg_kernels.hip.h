@@ -293,7 +293,8 @@ __global__ __launch_bounds__(1024) void km_jacobi(const int *__restrict__ sup_n,
                                                   const double *__restrict__ As, const double *__restrict__ bs,
                                                   double *__restrict__ Bg, double *__restrict__ Vg,
                                                   double *__restrict__ Ss, double *__restrict__ ivs, int max_sweeps,
-                                                  int *__restrict__ sweeps_out) {
+                                                  int *__restrict__ sweeps_out, const int *__restrict__ sup_idx = nullptr, int Rf = 0,
+                                                  double *__restrict__ sqrt_info_full = nullptr, double *__restrict__ infovec_full = nullptr) {
     extern __shared__ double lds[];
     __shared__ int rotated;
     const int R = *sup_n;
@@ -327,6 +328,30 @@ __global__ __launch_bounds__(1024) void km_jacobi(const int *__restrict__ sup_n,
         for (int e = lane; e < R; e += 64) Ss[(size_t)i * R + e] = sl * v[e];
         if (lane == 0) ivs[i] = sli * vb;
     }
+    // round 5: the expansion into the full-size prior (km_expand's scatter) in the same launch -- this kernel runs once per sequence
+    if (sqrt_info_full) {
+        __threadfence_block();
+        __syncthreads();
+        for (int e = tid; e < Rf * Rf; e += nt) {
+            const int i = e / Rf, j = e - i * Rf;
+            double v = 0.0;
+            if (i < R) {
+                int lo = 0, hi = R - 1;
+                while (lo <= hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int sj = sup_idx[mid];
+                    if (sj == j) {
+                        v = Ss[(size_t)i * R + mid];
+                        break;
+                    }
+                    if (sj < j) lo = mid + 1;
+                    else hi = mid - 1;
+                }
+            }
+            sqrt_info_full[e] = v;
+        }
+        for (int i = tid; i < Rf; i += nt) infovec_full[i] = i < R ? ivs[i] : 0.0;
+    }
 }
 
 // Cholesky fast path of "create marginalization factor" (marginalization_factor.h:440-455).  When every
@@ -335,60 +360,58 @@ __global__ __launch_bounds__(1024) void km_jacobi(const int *__restrict__ sup_n,
 // reproduce Lambda = S^T S and eta = S^T infovec exactly like diag(sqrt(lambda)) V^T would.  The kernel
 // factors A in LDS and bounds lambda_min from above by inverse iteration; the caller falls back to the
 // Jacobi eigen-solver (km_jacobi) when the factorisation fails or the bound is not comfortably above the floor.
-__global__ __launch_bounds__(512) void km_chol(const int *__restrict__ sup_n, int lds_doubles,
-                                               const double *__restrict__ A, const double *__restrict__ bp,
-                                               double *__restrict__ sqrt_info, double *__restrict__ infovec,
-                                               double *__restrict__ lam_est, int *__restrict__ status) {
-    extern __shared__ double lds[];
-    __shared__ double Dblk[CH_NB][CH_NB + 1];
-    __shared__ double scratch[8];
-    __shared__ int fail;
+// Round 5: the guard's inverse is blocked (tri_inverse_blocked, matrix cores) instead of one forward substitution per thread; the kernel
+// also takes over what three launches behind it did on 26 of 27 marginalisations -- the gate (status[4], status[5]: does the eigen path
+// have to run, and on what support) and the expansion of its own factor into the full-size prior (km_expand's scatter, straight from
+// LDS) -- so that in steady state km_jacobi is one empty launch behind this one and nothing else.
+__device__ __forceinline__ bool km_chol_body(int R, int lds_doubles, const double *__restrict__ A, const double *__restrict__ bp,
+                                             const int *__restrict__ sup_idx, int Rf, double *__restrict__ sqrt_info_full,
+                                             double *__restrict__ infovec_full, double *__restrict__ lam_est, int *__restrict__ status,
+                                             double *lds, double (*Dblk)[CH_NB + 1], double *scratch, int *fail, int *s_pos) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int R = *sup_n;
     if (R == 0 || 2 * ((R + 1) & ~1) + R * (R + 1) / 2 > lds_doubles) {
         if (tid == 0) status[2] = 1;   // does not fit: take the Jacobi path
-        return;
+        return false;
     }
     double *x = lds, *y = lds + ((R + 1) & ~1), *Lp = y + ((R + 1) & ~1);
     for (int e = tid; e < R * R; e += nt) {
         const int i = e / R, j = e - i * R;
         if (j <= i) Lp[tri_idx(i, j)] = A[e];
     }
+    for (int j = tid; j < Rf; j += nt) s_pos[j] = -1;
     __syncthreads();
-    if (!chol_blocked(Lp, R, R, Dblk, &fail)) {
+    for (int m = tid; m < R; m += nt) s_pos[sup_idx[m]] = m;   // column of the full matrix -> column of the compact one
+    if (!chol_blocked(Lp, R, R, Dblk, fail)) {
         if (tid == 0) status[2] = 1;
-        return;
+        return false;
     }
     for (int i = tid; i < R; i += nt) y[i] = bp[i];
     __syncthreads();
     trsv_lower(Lp, R, y);
-    for (int i = tid; i < R; i += nt) infovec[i] = y[i];
-    for (int e = tid; e < R * R; e += nt) {
-        const int i = e / R, j = e - i * R;
-        sqrt_info[e] = (j >= i) ? Lp[tri_idx(j, i)] : 0.0;
+    // the full-size factor: row i = row i of the compact factor L^T (rows >= R are zero), columns scattered over the support
+    for (int i = tid; i < Rf; i += nt) infovec_full[i] = i < R ? y[i] : 0.0;
+    for (int e = tid; e < Rf * Rf; e += nt) {
+        const int i = e / Rf, j = e - i * Rf;
+        double v = 0.0;
+        if (i < R) {
+            const int m = s_pos[j];
+            if (m >= i) v = Lp[tri_idx(m, i)];
+        }
+        sqrt_info_full[e] = v;
     }
     // Guard of the fast path: every eigenvalue must lie above the reference's 1e-8 clamp.  When a second triangle
     // fits in LDS the bound is rigorous and cheap: trace(A^-1) = |L^-1|_F^2 = sum 1/lambda_i >= 1/lambda_min, so
-    // lambda_min >= 1 / trace(A^-1); column j of L^-1 is a forward substitution done by thread j.  Otherwise fall
-    // back to inverse iteration (1 / |A^-1 x| for unit x is an upper bound of lambda_min that converges to it) and
-    // demand a 100x margin.
+    // lambda_min >= 1 / trace(A^-1).  Otherwise fall back to inverse iteration (1 / |A^-1 x| for unit x is an upper bound of
+    // lambda_min that converges to it) and demand a 100x margin.
     double lam = 0;
     bool rigorous = false;
     if (2 * ((R + 1) & ~1) + R * (R + 1) <= lds_doubles) {
         rigorous = true;
-        double *X = Lp + R * (R + 1) / 2;   // column-major packed: column j holds rows j .. R-1
+        double *X = Lp + R * (R + 1) / 2;   // packed like L
+        __syncthreads();
+        tri_inverse_blocked(Lp, X, R);
         double tr = 0;
-        for (int j = tid; j < R; j += nt) {
-            double *xc = X + (size_t)j * R - (size_t)j * (j - 1) / 2 - j;   // xc[i], i >= j
-            for (int i = j; i < R; ++i) {
-                double sacc = (i == j) ? 1.0 : 0.0;
-                const double *Li = Lp + tri_idx(i, 0);
-                for (int k = j; k < i; ++k) sacc -= Li[k] * xc[k];
-                const double v = sacc / Li[i];
-                xc[i] = v;
-                tr += v * v;
-            }
-        }
+        for (int e = tid; e < R * (R + 1) / 2; e += nt) tr += X[e] * X[e];
         tr = block_sum(tr, scratch);
         lam = 1.0 / tr;
     } else {
@@ -413,9 +436,29 @@ __global__ __launch_bounds__(512) void km_chol(const int *__restrict__ sup_n, in
             __syncthreads();
         }
     }
+    const bool good = isfinite(lam) && lam > (rigorous ? 1.0e-8 : 1.0e-6);
     if (tid == 0) {
         lam_est[0] = lam;
-        status[3] = (isfinite(lam) && lam > (rigorous ? 1.0e-8 : 1.0e-6)) ? 0 : 1;
+        status[3] = good ? 0 : 1;
+    }
+    return good;
+}
+__global__ __launch_bounds__(512) void km_chol(const int *__restrict__ sup_n, int lds_doubles,
+                                               const double *__restrict__ A, const double *__restrict__ bp,
+                                               const int *__restrict__ sup_idx, int Rf, double *__restrict__ sqrt_info_full,
+                                               double *__restrict__ infovec_full, double *__restrict__ lam_est,
+                                               int *__restrict__ status) {
+    extern __shared__ double lds[];
+    __shared__ double Dblk[CH_NB][CH_NB + 1];
+    __shared__ double scratch[8];
+    __shared__ int fail, s_pos[512];
+    const int R = *sup_n;
+    const bool fast = km_chol_body(R, lds_doubles, A, bp, sup_idx, Rf, sqrt_info_full, infovec_full, lam_est, status, lds, Dblk, scratch,
+                                   &fail, s_pos);
+    // the gate (round 2's kx_marg_gate): the eigen path runs on the support iff the fast path does not stand
+    if (threadIdx.x == 0) {
+        status[4] = fast ? 0 : 1;
+        status[5] = fast ? 0 : R;
     }
 }
 
