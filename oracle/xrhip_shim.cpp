@@ -243,6 +243,8 @@ int xrhip_group_get_stats(xrhip_group *, xrhip_group_stats *out, int) {
     if (out) std::memset(out, 0, sizeof(*out));
     return 0;
 }
+int xrhip_klt_frame_gate(xrhip_klt *) { return 0; }          // nothing is launched on the CPU: nothing to line up
+int xrhip_klt_group_busy(xrhip_klt *, int) { return 0; }
 int xrhip_klt_join_group(xrhip_klt *c, xrhip_group *g) {
     if (c->group) c->group->members.fetch_sub(1);
     c->group = g;

@@ -70,6 +70,20 @@ void group_member_remove(xrhip_group *g, bool front_end);
 // a member enters (+1) / leaves (-1) a stretch of work on its own stream (a window solve): the group does not wait for it
 void group_busy_elsewhere(xrhip_group *g, int delta);
 
+// Frame gate (round 5).  Which requests share a launch used to be a matter of coincidence (1.1 - 2 requests per launch at 8 members,
+// profiles/r04_multi_sequence.md; a plain linger makes it worse: nothing keeps the members in phase, profiles/r05_multi_sequence.md).
+// The members run the same frame loop; if they START their frames together, their uploads, pyramids, tracking launches and solves
+// arrive within microseconds of each other and one launch carries all of them.  group_gate_arrive is called by a sequence's front end
+// (`owner`: its KLT context) when a new frame is about to be uploaded: it returns once every member that is expected has arrived --
+// expected: registered, not marked busy (a keyframe's window solve and marginalisation take several ordinary frames: that member tells
+// the group and rejoins at a later frame boundary), not absent (a member that failed to show up within the timeout -- a stream that has
+// ended, a driver that is not running -- stops being waited for until it comes back).  Purely a matter of WHEN launches are issued:
+// what a member computes does not change (tests/test_instances.py holds members to their solo runs bit for bit).
+void group_gate_register(xrhip_group *g, void *owner);
+void group_gate_unregister(xrhip_group *g, void *owner);
+void group_gate_busy(xrhip_group *g, void *owner, bool busy);
+void group_gate_arrive(xrhip_group *g, void *owner);
+
 // Spin until *flag == seq (a kernel's last store into pinned memory).  The stream is polled now and then so that a faulted kernel
 // becomes an error instead of a hang -- once the request (if any) is known to be launched: a shared stream may be idle while the
 // request still waits in the group's queue.

@@ -61,12 +61,59 @@ struct xrhip_group {
     std::atomic<int> sequences{0};        // front-end contexts joined == sequences in the group
     std::atomic<bool> profiling{false};
     std::atomic<int> busy_elsewhere{0};   // members inside a window solve (their own stream): they will not submit for a while
-    int linger_us = 0;                    // hold a batch back this long for the members that have not submitted yet (XRHIP_GROUP_LINGER_US)
+    std::atomic<int> linger_us{0};        // hold a batch back this long for the members that have not submitted yet (XRHIP_GROUP_LINGER_US)
     int linger_queues = 7;                // bit k: queue k lingers (XRHIP_GROUP_LINGER_QUEUES)
     int preint_shares = -1;               // >= 0: the pre-integration queue launches into that queue's stream
     bool per_kind = true;                 // a batch waits for the previous batch OF ITS KIND only (XRHIP_GROUP_PER_KIND=0: for any batch)
     std::mutex stats_m;
     xrhip_group_stats stats;
+
+    // frame gate (group.hip.h)
+    struct GateMember {
+        void *owner = nullptr;
+        bool busy = false, absent = false;
+        unsigned arrived_gen = ~0u;   // the generation this member is waiting in
+    };
+    std::mutex gate_m;                      // gate_members, and every transition of the words below
+    std::vector<GateMember> gate_members;
+    std::atomic<unsigned> gate_gen{0};      // bumped when the gate opens
+    std::atomic<int> gate_active{0};        // members that are neither busy nor absent
+    std::atomic<int> gate_waiting{0};       // ... of which at the gate right now
+    std::atomic<bool> gate_used{false};     // somebody has been through the gate: the linger below counts with it
+    bool gate_on = true;                    // XRHIP_GROUP_GATE=0 / too many timeouts in a row: members are not driven concurrently
+    int gate_timeout_us = 250;              // XRHIP_GROUP_GATE_TIMEOUT_US
+    int gate_timeouts_in_a_row = 0;
+    long long gate_opens = 0, gate_full = 0, gate_timeouts = 0;
+
+    void gate_recount_locked() {
+        int a = 0, w = 0;
+        const unsigned gen = gate_gen.load(std::memory_order_relaxed);
+        for (const GateMember &m : gate_members) {
+            if (m.busy || m.absent) continue;
+            ++a;
+            if (m.arrived_gen == gen) ++w;
+        }
+        gate_active.store(a, std::memory_order_relaxed);
+        gate_waiting.store(w, std::memory_order_relaxed);
+    }
+    // every expected member is here (and at least one is)
+    bool gate_ready_locked() const {
+        const unsigned gen = gate_gen.load(std::memory_order_relaxed);
+        bool any = false;
+        for (const GateMember &m : gate_members) {
+            if (m.arrived_gen == gen) {
+                any = true;
+                continue;
+            }
+            if (!m.busy && !m.absent) return false;
+        }
+        return any;
+    }
+    void gate_open_locked() {
+        gate_opens++;
+        gate_gen.fetch_add(1, std::memory_order_release);
+        gate_recount_locked();
+    }
 
     hipEvent_t take_event(GroupQueueState &Q) {
         if (!Q.free_events.empty()) {
@@ -118,20 +165,25 @@ struct xrhip_group {
         const int kind = dq.front()->kind;
         for (const GroupQueueState::Inflight &f : Q.inflight)
             if (!per_kind || f.kind == kind || kind == GK_CALL || f.kind == GK_CALL) return false;
-        if (linger_us > 0 && kind != GK_CALL && ((linger_queues >> Q.index) & 1)) {
+        const int linger_now = linger_us.load(std::memory_order_relaxed);
+        if (linger_now > 0 && kind != GK_CALL && ((linger_queues >> Q.index) & 1)) {
             // Members run the same frame loop: when some have submitted this kind and the others are about to, a short wait turns
             // several small launches into one -- and members that travelled in one batch come back together.  Never longer than
             // linger_us past the first pending request, and not at all for members that are busy with a window solve.
             int same = 0;
             for (GroupRequest *r : dq) same += r->kind == kind ? 1 : 0;
-            const int expected = std::max(1, sequences.load(std::memory_order_relaxed) - busy_elsewhere.load(std::memory_order_relaxed));
+            // with the frame gate in use: the members that started this frame together (neither busy with a keyframe, nor absent, nor
+            // waiting at the gate for the next frame); without it: everybody who is not inside a window solve
+            const int expected = gate_used.load(std::memory_order_relaxed)
+                                     ? std::max(1, gate_active.load(std::memory_order_relaxed) - gate_waiting.load(std::memory_order_relaxed))
+                                     : std::max(1, sequences.load(std::memory_order_relaxed) - busy_elsewhere.load(std::memory_order_relaxed));
             if (same < expected) {
                 const auto now = std::chrono::steady_clock::now();
                 if (!Q.lingering) {
                     Q.lingering = true;
                     Q.first_seen = now;
                 }
-                if (now - Q.first_seen < std::chrono::microseconds(linger_us)) return false;
+                if (now - Q.first_seen < std::chrono::microseconds(linger_now)) return false;
             }
             Q.lingering = false;
         }
@@ -290,6 +342,78 @@ void group_busy_elsewhere(xrhip_group *g, int delta) {
     if (g) g->busy_elsewhere.fetch_add(delta, std::memory_order_relaxed);
 }
 
+void group_gate_register(xrhip_group *g, void *owner) {
+    std::lock_guard<std::mutex> lk(g->gate_m);
+    for (const xrhip_group::GateMember &m : g->gate_members)
+        if (m.owner == owner) return;
+    xrhip_group::GateMember m;
+    m.owner = owner;
+    m.absent = true;   // counted from its first arrival on
+    g->gate_members.push_back(m);
+    g->gate_recount_locked();
+}
+void group_gate_unregister(xrhip_group *g, void *owner) {
+    std::lock_guard<std::mutex> lk(g->gate_m);
+    for (size_t i = 0; i < g->gate_members.size(); ++i)
+        if (g->gate_members[i].owner == owner) {
+            g->gate_members.erase(g->gate_members.begin() + (long)i);
+            break;
+        }
+    if (g->gate_ready_locked()) g->gate_open_locked();   // (the others may have been waiting for this one)
+    else g->gate_recount_locked();
+}
+void group_gate_busy(xrhip_group *g, void *owner, bool busy) {
+    if (!g) return;
+    std::lock_guard<std::mutex> lk(g->gate_m);
+    for (xrhip_group::GateMember &m : g->gate_members)
+        if (m.owner == owner) m.busy = busy;
+    if (busy && g->gate_ready_locked()) g->gate_open_locked();
+    else g->gate_recount_locked();
+}
+void group_gate_arrive(xrhip_group *g, void *owner) {
+    if (!g || !g->gate_on) return;
+    unsigned my_gen;
+    {
+        std::lock_guard<std::mutex> lk(g->gate_m);
+        xrhip_group::GateMember *me = nullptr;
+        for (xrhip_group::GateMember &m : g->gate_members)
+            if (m.owner == owner) me = &m;
+        if (!me || !g->gate_on) return;
+        g->gate_used.store(true, std::memory_order_relaxed);
+        me->absent = false;
+        my_gen = g->gate_gen.load(std::memory_order_relaxed);
+        me->arrived_gen = my_gen;
+        if (g->gate_ready_locked()) {
+            g->gate_full++;
+            g->gate_timeouts_in_a_row = 0;
+            g->gate_open_locked();
+            return;
+        }
+        g->gate_recount_locked();
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 1;; ++spin) {
+        if (g->gate_gen.load(std::memory_order_acquire) != my_gen) return;
+        relax();
+        if ((spin & 63) != 0) continue;
+        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(g->gate_timeout_us)) continue;
+        // Somebody who was expected has not come: stop waiting for them (they rejoin when they arrive).  A group whose gate times
+        // out again and again is not being driven by concurrent threads (one thread feeding its sequences in turn): the gate goes.
+        std::lock_guard<std::mutex> lk(g->gate_m);
+        if (g->gate_gen.load(std::memory_order_relaxed) != my_gen) return;
+        for (xrhip_group::GateMember &m : g->gate_members)
+            if (!m.busy && !m.absent && m.arrived_gen != my_gen) m.absent = true;
+        g->gate_timeouts++;
+        if (++g->gate_timeouts_in_a_row >= 16) {
+            g->gate_on = false;
+            g->gate_used.store(false, std::memory_order_relaxed);
+            g->linger_us.store(0, std::memory_order_relaxed);
+        }
+        g->gate_open_locked();
+        return;
+    }
+}
+
 int wait_flag(volatile int *flag, int seq, hipStream_t s, GroupRequest *req, const char *what, hipStream_t s2) {
     if (req) {
         const int rc = group_wait_launched(req);
@@ -325,7 +449,12 @@ int xrhip_group_create(xrhip_group **out) {
     xrhip_group *g = new xrhip_group();
     std::memset(&g->stats, 0, sizeof(g->stats));
     hipGetDevice(&g->device);
-    if (const char *e = std::getenv("XRHIP_GROUP_LINGER_US")) g->linger_us = std::max(0, std::atoi(e));
+    // the frame gate (group.hip.h) lines the members' frames up; behind it a short linger collects the requests of the members that
+    // started the frame together (they arrive within microseconds of each other)
+    if (const char *e = std::getenv("XRHIP_GROUP_GATE")) g->gate_on = std::atoi(e) != 0;
+    if (const char *e = std::getenv("XRHIP_GROUP_GATE_TIMEOUT_US")) g->gate_timeout_us = std::max(1, std::atoi(e));
+    g->linger_us.store(g->gate_on ? 40 : 0);
+    if (const char *e = std::getenv("XRHIP_GROUP_LINGER_US")) g->linger_us.store(std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("XRHIP_GROUP_LINGER_QUEUES")) g->linger_queues = std::atoi(e);
     if (const char *e = std::getenv("XRHIP_GROUP_PER_KIND")) g->per_kind = std::atoi(e) != 0;
     // Hardware queues.  The device runs about four of them side by side; with more in use every kernel of every queue waits 20-27 us
@@ -426,9 +555,18 @@ int xrhip_group_set_profiling(xrhip_group *g, int enable) {
 
 int xrhip_group_get_stats(xrhip_group *g, xrhip_group_stats *out, int reset) {
     if (!g || !out) return xr_fail(XRHIP_EINVAL, "xrhip_group_get_stats: null argument");
-    std::lock_guard<std::mutex> lk(g->stats_m);
-    *out = g->stats;
-    if (reset) std::memset(&g->stats, 0, sizeof(g->stats));
+    {
+        std::lock_guard<std::mutex> lk(g->stats_m);
+        *out = g->stats;
+        if (reset) std::memset(&g->stats, 0, sizeof(g->stats));
+    }
+    // slot 7: the frame gate -- times it opened / with every expected member present / by timeout
+    std::lock_guard<std::mutex> lk(g->gate_m);
+    out->batches[7] = g->gate_opens;
+    out->entries[7] = g->gate_full;
+    out->timed[7] = g->gate_timeouts;
+    out->ms[7] = g->gate_on ? 1.0 : 0.0;
+    if (reset) g->gate_opens = g->gate_full = g->gate_timeouts = 0;
     return XRHIP_OK;
 }
 

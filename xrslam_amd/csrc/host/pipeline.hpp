@@ -296,6 +296,8 @@ struct Pipeline {
         img->t = t;
         img->w = (int)config.cam_resolution[0];
         img->hgt = (int)config.cam_resolution[1];
+        // a member of an instance group starts its frame together with the other members (timing only: xrslam_hip.h, frame gate)
+        if (group) xrhip_klt_frame_gate(klt);
         if (undistort_on_device) hip_check(xrhip_image_upload_distorted(img->h, gray, stride, device_ptr ? 1 : 0), "xrhip_image_upload_distorted");
         else if (device_ptr) hip_check(xrhip_image_upload_device(img->h, gray, stride), "xrhip_image_upload_device");
         else hip_check(xrhip_image_upload(img->h, gray, stride), "xrhip_image_upload");
@@ -1512,6 +1514,17 @@ class SlidingWindowTracker {
         }
         if (is_kf) {
             P_.times.keyframes++;
+            // a keyframe's window solve and marginalisation take several ordinary frames: the group's other members do not wait
+            // for this one at the frame gate meanwhile (it rejoins them at its next frame)
+            struct GroupBusy {
+                Pipeline &P;
+                explicit GroupBusy(Pipeline &p) : P(p) {
+                    if (P.group) xrhip_klt_group_busy(P.klt, 1);
+                }
+                ~GroupBusy() {
+                    if (P.group) xrhip_klt_group_busy(P.klt, 0);
+                }
+            } group_busy(P_);
             queue_keyframe_integrations();
             track_landmark();
             refine_window();

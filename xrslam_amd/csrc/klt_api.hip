@@ -46,6 +46,8 @@ struct DetectPayload {
 };
 struct TrackPayload {
     LkTrackArgs lk;
+    int n_inline = 0;       // > 0: `inl` holds the points as floats (the kernel's own conversion), for a launch that carries this entry alone
+    LkInlinePoints inl;
     bool detect = false;   // the Harris pass of the target image rides behind the tracking launch (xrhip_image_prefetch_detect)
     DetectPayload det;
 };
@@ -305,6 +307,13 @@ static int launch_detect_batch(GroupRequest **r, int n, hipStream_t s, hipStream
 static int launch_track_batch(GroupRequest **r, int n, hipStream_t s, hipStream_t side) {
     for (int base = 0; base < n; base += XB) {
         const int m = std::min(XB, n - base);
+        if (m == 1 && n == 1) {   // a lone entry whose points fit the argument block: no read of the pinned list at kernel start
+            const TrackPayload *tp1 = static_cast<const TrackPayload *>(r[base]->payload);
+            if (tp1->n_inline > 0) {
+                hipLaunchKernelGGL(k_lk_track_inl, dim3(std::max(1, tp1->lk.n), 1, 1), dim3(LK_THREADS), 0, s, tp1->lk, tp1->inl);
+                continue;
+            }
+        }
         Batch<LkTrackArgs> b;
         std::memset(&b, 0, sizeof(b));
         int most = 1;
@@ -416,6 +425,7 @@ int xrhip_klt_join_group(xrhip_klt *c, xrhip_group *g) {
     if (c->group) {
         int rc = group_drain(c->group, GQ_KLT, c);
         if (rc) return rc;
+        group_gate_unregister(c->group, c);
         group_member_remove(c->group, true);
     } else {
         XR_HIP(hipStreamSynchronize(c->stream));
@@ -423,7 +433,21 @@ int xrhip_klt_join_group(xrhip_klt *c, xrhip_group *g) {
     c->group = g;
     c->uploads_unsynced = 0;
     for (int i = 0; i < xrhip_klt::UP_SLOTS; ++i) c->up_busy[i] = false;
-    if (g) group_member_add(g, true);
+    if (g) {
+        group_member_add(g, true);
+        group_gate_register(g, c);
+    }
+    return XRHIP_OK;
+}
+
+int xrhip_klt_frame_gate(xrhip_klt *c) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_klt_frame_gate: null context");
+    if (c->group) group_gate_arrive(c->group, c);
+    return XRHIP_OK;
+}
+int xrhip_klt_group_busy(xrhip_klt *c, int busy) {
+    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_klt_group_busy: null context");
+    if (c->group) group_gate_busy(c->group, c, busy != 0);
     return XRHIP_OK;
 }
 
@@ -1043,6 +1067,15 @@ int xrhip_image_track(const xrhip_image *cur, const xrhip_image *next, const dou
     TrackPayload &tp = c->a_track;
     tp.lk = LkTrackArgs{make_view(cur), make_view(next), dv_curr, dv_next, has_guess ? 1 : 0, dv_status, n,
                         c->profiling ? c->d_counters : (LkCounters *)nullptr, c->d_done, c->done_base, d_seq, seq};
+    static const bool no_inline = std::getenv("XRHIP_LK_NO_INLINE") != nullptr;   // development switch (A/B)
+    tp.n_inline = 0;
+    if (!no_inline && n <= LK_INLINE) {
+        for (int i = 0; i < n; ++i) {
+            const float cx = (float)curr_xy[2 * i], cy = (float)curr_xy[2 * i + 1];   // the kernel's own double -> float conversions
+            tp.inl.p[i] = has_guess ? make_float4(cx, cy, (float)next_xy_inout[2 * i], (float)next_xy_inout[2 * i + 1]) : make_float4(cx, cy, cx, cy);
+        }
+        tp.n_inline = n;
+    }
     // the Harris pass of `next` does not depend on the tracking result: it rides right behind the tracking launch so that it runs
     // while the host digests the tracks (the wait below is on the tracking kernel's own mailbox, not on the stream)
     tp.detect = next->want_detect && !next->detect_seq;

@@ -1242,24 +1242,37 @@ __device__ __forceinline__ void lk_lane_layout(int lane, int (&wx)[LK_SLOTS], in
 // the kernel reads and writes them over the host link itself.  done / done_target / host_seq implement the
 // completion mailbox: every wavefront publishes its result (system-scope fence), bumps `done`, and the one that
 // reaches done_target stores `seq` where the host is spinning.
+// inl: the point (and guess), already converted to float by the host with the same rounding, delivered in the kernel-argument block
+// (k_lk_track_inl) -- a workgroup's first instruction then no longer waits for a read of the pinned point list over the host link.
 __device__ __forceinline__ void d_lk_track(const PyrView &A, const PyrView &B, const double2 *__restrict__ curr,
                                            double2 *__restrict__ next_io, int has_guess,
                                            uint8_t *__restrict__ status_out, int n,
                                            LkCounters *__restrict__ counters, unsigned *done, unsigned done_target,
-                                           int *host_seq, int seq) {
+                                           int *host_seq, int seq, const float4 *inl = nullptr) {
     const int pt = blockIdx.x;
     if (pt >= n) return;
     const int lane = threadIdx.x;
     int wx[LK_SLOTS], wy[LK_SLOTS];
     bool wvalid[LK_SLOTS];
     lk_lane_layout(lane, wx, wy, wvalid);
-    const double2 c = curr[pt];
-    const float cx = (float)c.x, cy = (float)c.y;   // to_opencv(): double -> float
-    float nx = cx, ny = cy;
-    if (has_guess) {
-        const double2 g = next_io[pt];
-        nx = (float)g.x;
-        ny = (float)g.y;
+    float cx, cy, nx, ny;
+    if (inl) {
+        const float4 v = inl[pt];   // (current x, y, guess x, y): the guess equals the current position when there is none
+        cx = v.x;
+        cy = v.y;
+        nx = v.z;
+        ny = v.w;
+    } else {
+        const double2 c = curr[pt];
+        cx = (float)c.x;
+        cy = (float)c.y;   // to_opencv(): double -> float
+        nx = cx;
+        ny = cy;
+        if (has_guess) {
+            const double2 g = next_io[pt];
+            nx = (float)g.x;
+            ny = (float)g.y;
+        }
     }
     unsigned n_templates = 0, n_iters = 0;
     __shared__ uint32_t tile[LK_TILE_DWORDS];
@@ -1312,6 +1325,14 @@ struct LkTrackArgs {
 __global__ __launch_bounds__(LK_THREADS) void k_lk_track(Batch<LkTrackArgs> b) {
     const LkTrackArgs &a = b.e[blockIdx.z];
     d_lk_track(a.A, a.B, a.curr, a.next_io, a.has_guess, a.status_out, a.n, a.counters, a.done, a.done_target, a.host_seq, a.seq);
+}
+// One entry (a sequence that launches for itself) with up to LK_INLINE points: the points travel in the argument block (2.5 KB of the 4 KB).
+constexpr int LK_INLINE = 160;
+struct LkInlinePoints {
+    float4 p[LK_INLINE];
+};
+__global__ __launch_bounds__(LK_THREADS) void k_lk_track_inl(LkTrackArgs a, LkInlinePoints pts) {
+    d_lk_track(a.A, a.B, a.curr, a.next_io, a.has_guess, a.status_out, a.n, a.counters, a.done, a.done_target, a.host_seq, a.seq, pts.p);
 }
 
 // A host (pinned, device-mapped) or device frame into the dense plane the preprocessing reads: the upload of a group's frames is one

@@ -42,7 +42,7 @@ class GroupStats(C.Structure):   # xrhip_group_stats (include/xrslam_hip.h)
     _fields_ = [("batches", C.c_longlong * 8), ("entries", C.c_longlong * 8), ("ms", C.c_double * 8), ("timed", C.c_longlong * 8)]
 
 
-GROUP_KINDS = ("call", "upload", "preprocess", "track", "detect", "chain", "preint")
+GROUP_KINDS = ("call", "upload", "preprocess", "track", "detect", "chain", "preint", "gate")   # gate: openings / all present / timeouts
 
 
 class XRSLAMAmdInitReport(C.Structure):
