@@ -370,7 +370,7 @@ int xrhip_group_destroy(xrhip_group *group);   /* XRHIP_ESTATE while contexts ar
 int xrhip_klt_join_group(xrhip_klt *ctx, xrhip_group *group);
 int xrhip_ba_join_group(xrhip_ba *ctx, xrhip_group *group);
 /* Frame gate (round 5): a sequence calls xrhip_klt_frame_gate when it is about to upload a new frame; the call returns when every
- * member of the group that is expected to start a frame has arrived (or after a timeout, default 250 us: members that do not come stop
+ * member of the group that is expected to start a frame has arrived (or after a timeout, default 2.5 ms: members that do not come stop
  * being waited for until they do).  Members whose frames start together issue their uploads, pyramids, tracking launches and solves
  * together, so one launch carries all of them.  xrhip_klt_group_busy(ctx, 1 / 0) brackets a stretch during which the sequence will
  * not start a frame (a keyframe's window solve and marginalisation): the others go on without it.  No-ops outside a group; timing only --
