@@ -79,6 +79,11 @@ void group_busy_elsewhere(xrhip_group *g, int delta);
 // the group and rejoins at a later frame boundary), not absent (a member that failed to show up within the timeout -- a stream that has
 // ended, a driver that is not running -- stops being waited for until it comes back).  Purely a matter of WHEN launches are issued:
 // what a member computes does not change (tests/test_instances.py holds members to their solo runs bit for bit).
+// MEASURED (profiles/r05_multi_sequence.md): with the gate a launch carries 4.9 frames (pyramid), 3.8 (tracking), 2.9 (solves) instead of
+// 1.1 / 1.5 / 2.0 at 8 members, a member's frame drops from 1.32 to 1.09 ms -- and the members then spend 0.42 ms per frame AT the gate:
+// 5302 frames/s against 5599 without.  A keyframe (one frame in four) keeps a member away for ~2.8 ms of un-batched window rounds and
+// marginalisation, i.e. 44 % of the members are not in the cohort at any moment, and the cohort waits for its slowest member every
+// frame.  Off by default (XRHIP_GROUP_GATE=1 switches it on); what would make it pay is batching the window rounds as well.
 void group_gate_register(xrhip_group *g, void *owner);
 void group_gate_unregister(xrhip_group *g, void *owner);
 void group_gate_busy(xrhip_group *g, void *owner, bool busy);

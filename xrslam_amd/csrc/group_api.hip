@@ -80,7 +80,8 @@ struct xrhip_group {
     std::atomic<int> gate_active{0};        // members that are neither busy nor absent
     std::atomic<int> gate_waiting{0};       // ... of which at the gate right now
     std::atomic<bool> gate_used{false};     // somebody has been through the gate: the linger below counts with it
-    bool gate_on = true;                    // XRHIP_GROUP_GATE=0 / too many timeouts in a row: members are not driven concurrently
+    bool gate_on = false;                   // XRHIP_GROUP_GATE=1 switches it on (measured: bigger batches, no more frames per second -- group.hip.h);
+                                            // too many timeouts in a row switch it off again: members are not driven concurrently
     int gate_timeout_us = 2500;             // XRHIP_GROUP_GATE_TIMEOUT_US: longer than a frame -- members that are out of phase (at the start, after a
                                             // straggler) meet at the gate within one frame; a member that is really gone costs the others this once
     int gate_timeouts_in_a_row = 0;

@@ -1186,21 +1186,28 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
                 }
             }
             n_iters++;
-            double db1 = wave_sum_i32_exact(sb1), db2 = wave_sum_i32_exact(sb2);
+            // The wavefront's sums of the low (unsigned) and high (signed) 16-bit halves, each below 2^22; round 5: the four wavefronts
+            // exchange THESE integers (one 16-byte store, four 16-byte loads, integer adds) and the halves are recombined in double
+            // precision once -- rounds 1-4 recombined per wavefront and added four doubles per sum, two dependent conversions and three
+            // dependent f64 additions on every iteration's serial path.  Every partial sum is an exact integer either way: the same
+            // double, the same float.
+            int h4[4] = {dpp_scan_add_i32(sb1 & 0xffff), dpp_scan_add_i32(sb1 >> 16), dpp_scan_add_i32(sb2 & 0xffff), dpp_scan_add_i32(sb2 >> 16)};
             if (LK_WAVES > 1) {
-                if ((threadIdx.x & 63) == 0) {
-                    xch[xpar][wave_id][0] = db1;
-                    xch[xpar][wave_id][1] = db2;
-                }
+                int4 *slots = reinterpret_cast<int4 *>(&xch[xpar][0][0]);   // one 32-byte slot per wavefront: its first 16 bytes
+                if ((threadIdx.x & 63) == 0) slots[2 * wave_id] = make_int4(h4[0], h4[1], h4[2], h4[3]);
                 __syncthreads();
-                db1 = db2 = 0.0;
+                h4[0] = h4[1] = h4[2] = h4[3] = 0;
 #pragma unroll
                 for (int w = 0; w < LK_WAVES; ++w) {
-                    db1 += xch[xpar][w][0];
-                    db2 += xch[xpar][w][1];
+                    const int4 v = slots[2 * w];
+                    h4[0] += v.x;
+                    h4[1] += v.y;
+                    h4[2] += v.z;
+                    h4[3] += v.w;
                 }
                 xpar ^= 1;
             }
+            const double db1 = (double)h4[1] * 65536.0 + (double)h4[0], db2 = (double)h4[3] * 65536.0 + (double)h4[2];
             const float b1 = (float)db1 * FLT_SCALE;
             const float b2 = (float)db2 * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
