@@ -53,6 +53,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+LEG_SETTLE = 6          # untimed frames in front of every variant leg: the first switch to the pipelined mode creates a thread, a BA context
+                        # and its device buffers (tens of milliseconds once -- a 100-frame leg that paid it read 810-940 frames/s)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (MI355X_MICROARCH.md)
 CFG = os.path.join(ROOT, "configs")
@@ -362,7 +364,7 @@ def main():
         slam_yaml, sensor_yaml = os.path.join(CFG, wl["slam"]), os.path.join(CFG, wl["sensor"])
         variant_frames = args.variant_frames if (S == 1 and world == 1) else 0
         sustained_frames = args.sustained_frames if (S == 1 and world == 1) else 0
-        n_frames = preroll + args.warmup + args.steps + sustained_frames + 3 * variant_frames
+        n_frames = preroll + args.warmup + args.steps + sustained_frames + 3 * (variant_frames + (LEG_SETTLE if variant_frames else 0))
         if args.euroc:
             from xrslam_amd.harness import euroc
             if S != 1 or world != 1:
@@ -686,6 +688,11 @@ def main():
             def leg(thr, res):
                 sess.api.set_threading(1 if thr else 0)
                 sess.device_frames = dev_frames0 if res else None
+                if native:
+                    sess.step_n(LEG_SETTLE)      # the mode's one-off costs (thread, contexts, buffers) stay out of the leg
+                else:
+                    for _ in range(LEG_SETTLE):
+                        sess.step()
                 sess.sync()
                 torch.cuda.synchronize()
                 kf0 = sess.times().keyframes

@@ -8,6 +8,7 @@
 #   multi:S [args]          bench.py --sequences-per-gpu S              procs:N Q [S]      N processes on this GPU (gloo), Q HW queues each, S grouped sequences in each
 #   rccl1                   RunGroup's collectives over nccl (= RCCL) with one rank (tools/check_rccl.py)
 #   trace[:bench.py args]   rocprofv3 --kernel-trace --stats + per-kernel averages         pmc[:args]   MFMA / FETCH_SIZE / WRITE_SIZE passes
+#   pmcg[:S]                FETCH_SIZE / WRITE_SIZE passes of S grouped sequences (default 8)
 #   ab:VARIANT              default library vs lib/libxrslam_hip_VARIANT.so, alternating (S1 line and S4 replay)
 #   abenv:VAR [reps]        the default bench line with VAR unset / =1, interleaved
 #   hostprof                XRHIP_HOSTPROF scope accumulators of the S1 stream             kprint[:PATTERN]   in-kernel printf timers (kprint variant)
@@ -63,6 +64,10 @@ for step in "$@"; do
     pmc)    (cd /tmp && export TMPDIR=/tmp
              timeout 150 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$O/pmc_$TAG/MFMA" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --sustained-frames 0 --no-profile $arg > "$O/pmc_${TAG}_MFMA.log" 2>&1
              for C in FETCH_SIZE WRITE_SIZE; do timeout 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$O/pmc_$TAG/$C" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --sustained-frames 0 --no-profile $arg > "$O/pmc_${TAG}_$C.log" 2>&1; done); ls "$O/pmc_$TAG" ;;
+    pmcg)   # the grouped run's counters (S = ${arg:-8} members): a batched launch should move ~S times a solo launch's bytes in about the time of one
+            S="${arg:-8}"
+            (cd /tmp && export TMPDIR=/tmp
+             for C in FETCH_SIZE WRITE_SIZE; do timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$O/pmc_${TAG}_group/$C" -o pmc -- python "$R/bench.py" --sequences-per-gpu "$S" --steps 40 --warmup 20 --cpu-frames 0 --no-profile > "$O/pmc_${TAG}_group_$C.log" 2>&1; done); ls "$O/pmc_${TAG}_group" ;;
     ab)     lib="$R/xrslam_amd/lib/libxrslam_hip_$arg.so"
             for rep in 1 2; do for v in default "$arg"; do
               e="XR_DUMMY=0"; [ "$v" != default ] && e="XRSLAM_HIP_LIB=$lib"
