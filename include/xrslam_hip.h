@@ -238,12 +238,6 @@ typedef struct xrhip_marg_problem {
 
 typedef struct xrhip_ba xrhip_ba;
 int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **out);
-/* Background context (round 5): on != 0 moves the context's streams to the runtime's LOW-priority pool of hardware queues, 0 back to
- * the normal one.  The runtime maps streams onto a few hardware queues per priority level and a hardware queue runs its kernels in
- * order, so work nobody waits for (a marginalisation: ~20 launches and three copies per keyframe) must not share a queue with the
- * frame's critical path -- localize_newframe's launch sat behind the previous keyframe's marginalisation for ~70 us on every
- * frame that followed a keyframe (profiles/r05_ab_variants.md).  The context must be idle (nothing begun or in flight). */
-int xrhip_ba_set_background(xrhip_ba *ctx, int on);
 void xrhip_ba_destroy(xrhip_ba *ctx);
 /* replaces: Solver::solve() over a problem assembled with add_frame_states/add_track_states/add_factor */
 int xrhip_ba_solve(xrhip_ba *ctx, const xrhip_ba_problem *problem, xrhip_ba_summary *summary);

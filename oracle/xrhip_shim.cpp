@@ -261,7 +261,6 @@ int xrhip_ba_create(int, int, int, xrhip_ba **out) {
     *out = new xrhip_ba();
     return 0;
 }
-int xrhip_ba_set_background(xrhip_ba *, int) { return 0; }   // no queues on the CPU
 void xrhip_ba_destroy(xrhip_ba *c) {
     if (c && c->group) xrhip_ba_join_group(c, nullptr);
     delete c;

@@ -48,7 +48,6 @@ struct ChainPayload {
 struct xrhip_ba {
     hipStream_t stream = nullptr;
     int device = 0;   // the device the context was created on (a group of another device is refused)
-    bool background = false;   // streams in the low-priority queue pool (xrhip_ba_set_background)
     // instance group (group.hip.h): the single-launch solves and the pre-integration batches travel as requests
     xrhip_group *group = nullptr;
     GroupRequest rq_chain, rq_preint;
@@ -133,10 +132,6 @@ struct xrhip_ba {
 };
 
 static int ensure_arena(xrhip_ba *c, size_t in_bytes, size_t work_bytes, size_t out_doubles) {
-    static const bool tell = std::getenv("XRHIP_HOSTPROF") != nullptr;
-    if (tell && (in_bytes > c->in.cap || work_bytes > c->work_cap || out_doubles > c->h_out_cap))
-        std::fprintf(stderr, "[hostprof] ensure_arena grows: in %zu > %zu, work %zu > %zu, out %zu > %zu\n", in_bytes, c->in.cap, work_bytes,
-                     c->work_cap, out_doubles, c->h_out_cap);
     if (in_bytes > c->in.cap) {
         if (c->in.dev) hipFree(c->in.dev);
         if (c->in.host) hipHostFree(c->in.host);
@@ -792,35 +787,6 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
     rc = ensure_arena(c, in_guess, in_guess * 4, (size_t)16 * max_frames + max_landmarks + 8);
     if (rc) return rc;
     *out = c;
-    return XRHIP_OK;
-}
-
-int xrhip_ba_set_background(xrhip_ba *c, int on) {
-    if (!c) return xr_fail(XRHIP_EINVAL, "xrhip_ba_set_background: null context");
-    if (c->begun.active || c->preint_pending)
-        return xr_fail(XRHIP_ESTATE, "xrhip_ba_set_background: the context has work in flight");
-    // (a marginalisation that has been queued but not collected is complete after the synchronisation below: its result sits in the
-    // staging block and its event has fired)
-    if ((on != 0) == c->background) return XRHIP_OK;
-    int least = 0, greatest = 0;
-    XR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    if (least == greatest) return XRHIP_OK;   // no priority levels on this device: nothing to separate
-    XR_HIP(hipStreamSynchronize(c->stream));
-    if (c->stream2) XR_HIP(hipStreamSynchronize(c->stream2));
-    hipStream_t s1 = nullptr, s2 = nullptr;
-    if (on) {
-        XR_HIP(hipStreamCreateWithPriority(&s1, hipStreamNonBlocking, least));
-        XR_HIP(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, least));
-    } else {
-        XR_HIP(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
-        XR_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-    }
-    hipStreamDestroy(c->stream);
-    if (c->stream2) hipStreamDestroy(c->stream2);
-    c->stream = s1;
-    c->stream2 = s2;
-    c->preint_stream = nullptr;
-    c->background = on != 0;
     return XRHIP_OK;
 }
 
@@ -1511,9 +1477,6 @@ int xrhip_ba_debug_schur(xrhip_ba *c, const double *W, const double *w, int L, i
 }   // extern "C"
 
 static int ensure_work2(xrhip_ba *c, size_t dev_bytes, size_t host_bytes) {
-    static const bool tell = std::getenv("XRHIP_HOSTPROF") != nullptr;
-    if (tell && (dev_bytes > c->work2_cap || host_bytes > c->h_stage_cap))
-        std::fprintf(stderr, "[hostprof] ensure_work2 grows: dev %zu > %zu, host %zu > %zu\n", dev_bytes, c->work2_cap, host_bytes, c->h_stage_cap);
     if (dev_bytes > c->work2_cap) {
         if (c->work2) hipFree(c->work2);
         c->work2 = nullptr;

@@ -172,7 +172,6 @@ struct Pipeline {
     xrhip_klt *klt = nullptr;
     xrhip_ba *ba = nullptr;
     xrhip_ba *ba_marg = nullptr;   // marginalisation has a context (buffers, stream) of its own: it runs beside the next frame
-    bool marg_background = true;   // ... on a hardware queue of the low-priority pool (outside a group)
     xrhip_ba *ba_aux = nullptr;    // speculative pre-integration batches (started a frame ahead), same reason
     xrhip_ba *ba_ft = nullptr;     // pipelined mode: the feature tracker's pre-integrations (its thread must not touch `ba`)
     xrhip_ba *ba_sub = nullptr;    // localize_newframe's problem when it is solved together with refine_subwindow's (`ba` holds that one)
@@ -218,10 +217,6 @@ struct Pipeline {
                   "xrhip_klt_create");
         hip_check(xrhip_ba_create(32, 2048, 16384, &ba), "xrhip_ba_create");
         hip_check(xrhip_ba_create(32, 2048, 16384, &ba_marg), "xrhip_ba_create");
-        // nobody waits for a marginalisation before the next keyframe: its ~20 launches go to a hardware queue of the low-priority
-        // pool, where they cannot sit in front of the next frame's localize_newframe (xrslam_hip.h: xrhip_ba_set_background)
-        marg_background = std::getenv("XRSLAM_AMD_MARG_NORMAL_PRIORITY") == nullptr;   // (development switch, A/B)
-        if (marg_background) hip_check(xrhip_ba_set_background(ba_marg, 1), "xrhip_ba_set_background");
         hip_check(xrhip_ba_create(32, 2048, 16384, &ba_aux), "xrhip_ba_create");
         hip_check(xrhip_ba_create(8, 1024, 4096, &ba_sub), "xrhip_ba_create");
         for (int i = 0; i < 9; ++i) {
@@ -259,9 +254,6 @@ struct Pipeline {
         // All or nothing: if a context refuses, the ones already moved return to the group they came from, so that the
         // instance is never half-joined (ensure_ft_context would otherwise create ba_ft outside the group its siblings are in).
         xrhip_group *const old = group;
-        // a group splits the hardware queues by priority itself (two for the batches, two for the members' own work: group_api.hip);
-        // a third pool for the marginalisations measured worse there (profiles/r04_multi_sequence.md): back to the normal pool
-        if (ba_marg && marg_background) hip_check(xrhip_ba_set_background(ba_marg, g ? 0 : 1), "xrhip_ba_set_background");
         bool klt_moved = false;
         std::vector<xrhip_ba *> moved;
         try {
