@@ -679,7 +679,8 @@ def main():
             dt_s, k1 = time.perf_counter() - m0, sess.times()
             out["sustained"] = {"value": round(sustained_frames / dt_s, 3), "unit": "frames/s", "frames": sustained_frames,
                                 "ms_per_step": round(1e3 * dt_s / sustained_frames, 4),
-                                "keyframes": int(k1.keyframes - k0.keyframes),
+                                "keyframes": int(k1.keyframes - k0.keyframes), "solves": int(k1.solves - k0.solves),
+                                "ba_iterations": int(k1.solve_iterations - k0.solve_iterations),
                                 "ms_per_ba_iteration": round((k1.ba_device_ms - k0.ba_device_ms) /
                                                              max(1, k1.solve_iterations - k0.solve_iterations), 4),
                                 "note": "the timed region's mode continued for %d more frames of the same stream" % sustained_frames}
@@ -695,7 +696,8 @@ def main():
                         sess.step()
                 sess.sync()
                 torch.cuda.synchronize()
-                kf0 = sess.times().keyframes
+                tt0 = sess.times()
+                kf0, it0, sv0 = tt0.keyframes, tt0.solve_iterations, tt0.solves
                 v0 = time.perf_counter()
                 if native:
                     sess.step_n(variant_frames)
@@ -705,7 +707,9 @@ def main():
                 sess.sync()
                 torch.cuda.synchronize()
                 dt_leg = time.perf_counter() - v0
-                return round(variant_frames / dt_leg, 3), int(sess.times().keyframes - kf0)
+                tt1 = sess.times()
+                return round(variant_frames / dt_leg, 3), {"keyframes": int(tt1.keyframes - kf0), "solves": int(tt1.solves - sv0),
+                                                           "ba_iterations": int(tt1.solve_iterations - it0)}
 
             var = {}
             for name, thr, res in (("resident", False, True), ("pipelined", True, False), ("pipelined_resident", True, True)):
@@ -713,8 +717,9 @@ def main():
                     thr, res, name = False, False, "inline_host"   # the timed region was that combination: this leg is the default one
                 v_leg, kf_leg = leg(thr, res)
                 # every leg runs over ITS OWN stretch of the stream: a keyframe costs several ordinary frames (S3: ~9 ms against ~1 ms),
-                # so legs are comparable only at equal keyframe counts -- stated per leg
-                var[name] = {"value": v_leg, "unit": "frames/s", "frames": variant_frames, "keyframes": kf_leg}
+                # and a window solve that runs into the iteration cap costs four ordinary ones: legs are comparable only at equal
+                # keyframe AND iteration counts -- both stated per leg
+                var[name] = dict({"value": v_leg, "unit": "frames/s", "frames": variant_frames}, **kf_leg)
             var["note"] = ("same stream continued after the timed region; resident = frame already in HBM (XRSLAMAmdPushImageDevice), "
                            "pipelined = XRSLAMAmdSetThreading(1), the reference's XRSLAM_ENABLE_THREADING build with deterministic "
                            "hand-offs (a different, reproducible trajectory: the backend is one frame late)")
