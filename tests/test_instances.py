@@ -152,6 +152,20 @@ def test_grouped_instances_with_the_groups_streams_at_high_priority_gpu(monkeypa
 
 
 @pytest.mark.gpu
+def test_grouped_instances_behind_the_frame_gate_gpu(monkeypatch):
+    """Round 5: XRHIP_GROUP_GATE=1 lines the members' frames up (a member waits at the start of a frame for the others, keyframe members
+    step aside) and the group then collects the cohort's requests for a few microseconds -- WHEN launches are issued and who shares
+    them changes completely, what a member computes must not: same bits as the solo runs, and the gate did open."""
+    from xrslam_amd import _lib
+    monkeypatch.setenv("XRHIP_GROUP_GATE", "1")
+    alone, res, stats = _grouped(_lib.LIB_PATH, (1, 2, 3, 4), mode=0, n=72)
+    for (pa, ca), (pt, ct) in zip(alone, res):
+        assert ca == ct
+        np.testing.assert_array_equal(pa, pt)
+    assert stats["gate"]["batches"] >= 40, stats      # openings (slot 7 of the statistics: openings / everybody present / timeouts)
+
+
+@pytest.mark.gpu
 def test_a_group_of_one_and_leaving_a_group_gpu():
     """A lone member (every batch has one entry) and a member that leaves half way both keep the solo trajectory."""
     from xrslam_amd import _lib
