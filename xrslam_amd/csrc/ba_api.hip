@@ -578,7 +578,7 @@ static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, cons
     hipLaunchKernelGGL(kb_landmark_vision, dim3(d.lm_rows + d.F * d.F * VIS_CH), dim3(64), 0, s, d, p);
     if (for_solver && small_mid(d)) return;   // kb_small_mid (launch_solve_try) assembles what the solve reads
     hipLaunchKernelGGL(kb_assemble, dim3((d.n * d.n + 255) / 256), dim3(256), 0, s, d, p);
-    if (for_solver) hipLaunchKernelGGL(kb_cost_prepare, dim3(1), dim3(256), 0, s, d, p);
+    if (for_solver) hipLaunchKernelGGL(kb_prepare, dim3(1), dim3(256), 0, s, d, p);   // (cost + gradient norm: the last block of kb_schur_aux)
     else hipLaunchKernelGGL(kb_sum_cost, dim3(1), dim3(256), 0, s, d, p);
 }
 
@@ -615,7 +615,7 @@ static void launch_schur_aux(const BaDims &d, const BaPtrs &p, hipStream_t s) {
     const int tiles = d.PF / 16;
     const int nrest = (d.na * d.na + 255) / 256;   // blocks that write the Schur-free entries of the reduced system
     hipLaunchKernelGGL(kb_schur_aux, dim3(nrest + (d.nla ? tiles * tiles + aux_quad_blocks_n(d.n, d.L) + aux_wog_blocks(d.F)
-                                                        : aux_quad_blocks_n(d.n, d.L))),
+                                                        : aux_quad_blocks_n(d.n, d.L)) + 1),   // + 1: total cost and gradient max-norm
                        dim3(256), 0, s, d, p);
 }
 

@@ -61,12 +61,7 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
     L.cs = take(16 * F);
     L.Hp = take(na * (na + 1) / 2);
     L.gp = take(na);
-    // the reduced system with its right-hand-side row: packed triangle (<= 16 unknowns: one wavefront's block), tiled above that (round 5:
-    // dense_lds.hip.h's tl_* layout -- tiles + the substituted vector + the block inverses' diagonals)
-    {
-        const int packed = (na + 1) * (na + 2) / 2, tiled = na > CH_NB ? tl_doubles(na + 1) + 32 * tl_tile_rows(na + 1) : 0;
-        L.A = take(packed > tiled ? packed : tiled);
-    }
+    L.A = take((na + 1) * (na + 2) / 2);
     L.scr = take(NI * IMU_SCR);   // raw IMU residuals / Jacobians: a region of its own, so that its zero pattern survives the rounds
     L.sp = take(na);
     L.D = take(na);
@@ -94,13 +89,6 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
 constexpr int CHAIN_VIS_TILE = 27 * 257;   // doubles of LDS behind the layout when `opts & CHAIN_OPT_TILE`
 constexpr int CHAIN_OBS_CACHE = 16;        // doubles per reprojection factor behind that when `opts & CHAIN_OPT_CACHE`
 enum { CHAIN_OPT_TILE = 1, CHAIN_OPT_CACHE = 2 };
-// -DXRHIP_CHAIN_PACKED (build variant, A/B): rounds 1-4's packed-triangle factorisation of the 17..90-unknown systems -- compiled in
-// instead of, not beside, the tiled one (both inlined cost the kernel its last free registers: 164 bytes of scratch)
-#ifdef XRHIP_CHAIN_PACKED
-constexpr bool CHAIN_TILED = false;
-#else
-constexpr bool CHAIN_TILED = true;
-#endif
 __host__ __device__ __forceinline__ int chain_cache_stride(int M) { return (M + 1) & ~1; }
 
 // A reprojection factor of these problems sees a constant landmark and -- mostly -- a constant reference frame: its tangent basis,
@@ -642,18 +630,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
                 gt[i] = s * (gsv / (Dv * Dv));
             }
             __syncthreads();
-            // -------------------- reduced system S = sp H sp + mu D^2 and Q(g~, g~).  Round 5: in the TILED layout (16x16 tiles,
-            // conflict-free strides, the rhs as row na, identity padding; dense_lds.hip.h) -- these 17..90-unknown systems used the packed
-            // triangle of rounds 1-2, whose factorisation is ~8 % and whose back-substitution is 2.5x slower (tools/chol_test.hip,
-            // n = 45: 13.1 + 5.2 us against 12.1 + 2.0).  Same entries, another order of the trailing updates' additions inside a tile
-            // row -- the last-bit difference the window solves have had against the packed form since round 3.
-            constexpr bool tiled = CHAIN_TILED;
-            const int Tt = tl_tile_rows(na + 1);
-            double *const yv = A + tl_doubles(na + 1), *const dinv16 = yv + 16 * Tt;
-            if constexpr (tiled) {
-                tl_clear(A, na, na + 1);
-                __syncthreads();
-            }
+            // -------------------- reduced system S = sp H sp + mu D^2 (packed, the rhs as row na) and Q(g~, g~)
             for (int e = wtid; e < na * (na + 1) / 2; e += nt) {
                 int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
                 while (i * (i + 1) / 2 > e) --i;
@@ -661,10 +638,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
                 const int j = e - i * (i + 1) / 2;
                 double v = Hp[e] * (sp[i] * sp[j]);
                 if (i == j) v += mu * Dg[i] * Dg[i];
-                A[tiled ? tl_idx(i, j) : e] = v;
+                A[e] = v;
             }
-            double *const y = tiled ? yv : A + na * (na + 1) / 2;
-            for (int i = wtid; i < na; i += nt) (tiled ? A[tl_idx(na, i)] : y[i]) = gp[i] * sp[i];
+            double *y = A + na * (na + 1) / 2;
+            for (int i = wtid; i < na; i += nt) y[i] = gp[i] * sp[i];
             double qacc = 0;
             for (int i = wave; i < na; i += 4) {
                 double t = 0;
@@ -674,17 +651,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
             const double qgg = block_sum(qacc, scratch);   // (block_sum ends with a barrier: A and y are complete)
             CPROF(6);   // preparation, reduced system, Q(g~, g~)
             // -------------------- Cholesky + substitution (solve_block)
-            if constexpr (tiled) lin_ok = tl_chol(A, na, na + 1, Dblk, dinv16, &s_fail, nullptr, gradmax_side);
-            else lin_ok = chol_blocked(A, na, na + 1, Dblk, &s_fail, nullptr, gradmax_side);
+            lin_ok = chol_blocked(A, na, na + 1, Dblk, &s_fail, nullptr, gradmax_side);
             CPROF(7);   // Cholesky
             if (lin_ok) {
-                if constexpr (tiled) {
-                    for (int i = wtid; i < 16 * Tt; i += nt) yv[i] = i < na ? A[tl_idx(na, i)] : 0.0;   // L^-1 rhs rode along as row na
-                    __syncthreads();
-                    tl_trsv_t(A, na, dinv16, yv);
-                } else {
-                    trsv_lower_t(A, na, y);
-                }
+                trsv_lower_t(A, na, y);
                 int bad = 0;
                 for (int i = wtid; i < na; i += nt) {
                     const double ya = y[i];

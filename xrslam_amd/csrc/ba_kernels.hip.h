@@ -1114,6 +1114,8 @@ __device__ __forceinline__ void solve_aux_block(const BaDims &d, const BaPtrs &p
         if (wave == 0 && cc < P6) p.wog[(size_t)ch * d.PF + cc] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
     }
 }
+__device__ __forceinline__ void gradmax_block(const BaDims &d, const BaPtrs &p, double *scratch);
+__device__ __forceinline__ void sum_cost_block(const BaDims &d, const BaPtrs &p, double *scratch);
 // Schur tiles and the solve's auxiliary passes in one launch: [tiles^2 | aux blocks]
 // (without free landmarks there is no Schur complement and no W^T (omega gl): only the quadratic-form blocks run)
 // layout of the grid: [Schur tiles | rest of S | aux blocks]
@@ -1136,6 +1138,17 @@ __global__ __launch_bounds__(256) void kb_schur_aux(BaDims d, BaPtrs p) {
     const int t2 = d.nla ? (d.PF / 16) * (d.PF / 16) : 0;
     const int nrest = (d.na * d.na + 255) / 256;
     int blk = blockIdx.x;
+    if (blk == (int)gridDim.x - 1) {
+        // Round 5: the linearisation's total cost and gradient max-norm -- two block-wide reductions and an exponential map per frame
+        // that nothing in this launch reads (kb_solve_try does) -- ride here as one more block beside the tiles instead of in front of
+        // them in the single-workgroup kb_cost_prepare (11 us per round, of which the preparation the tiles DO need is the smaller half:
+        // kb_prepare).  Same functions, same bits.
+        __shared__ double scratch[8];
+        sum_cost_block(d, p, scratch);
+        __syncthreads();
+        gradmax_block(d, p, scratch);
+        return;
+    }
     if (blk < t2) {
         schur_tile_block(d, p, blk, true);
         return;
