@@ -118,6 +118,8 @@ def device_power_state(index):
     import re
     import subprocess
     out = {}
+    if os.environ.get("XRSLAM_BENCH_NO_SMI"):   # development switch: is the tool's query what stalls a later leg?
+        return out
     try:
         txt = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--showmaxpower", "--showpower", "--showperflevel"],
                              capture_output=True, text=True, timeout=20).stdout
