@@ -15,6 +15,7 @@ from xrslam_amd import _lib  # noqa: E402
 s = runner.Session(_lib.LIB_PATH, seq, slam_yaml=os.path.join(ROOT, "configs", "bench_slam_150.yaml"), instance=True, threading=mode)
 rows = []
 prev = s.times()
+t_start = time.perf_counter()
 for k in range(0, n, 10):
     t0 = time.perf_counter()
     s.step_n(10)
@@ -22,11 +23,11 @@ for k in range(0, n, 10):
     dt = 1e3 * (time.perf_counter() - t0)
     t = s.times()
     rows.append((k, dt, t.keyframes - prev.keyframes, t.solve_iterations - prev.solve_iterations, t.marginalizations - prev.marginalizations,
-                 1e3 * (t.wall_scope[15] - prev.wall_scope[15])))
+                 1e3 * (t.wall_scope[15] - prev.wall_scope[15]), time.perf_counter() - t_start))
     prev = t
 med = sorted(r[1] for r in rows)[len(rows) // 2]
 print("mode", mode, "median ms per 10 frames", round(med, 2))
 for r in rows:
     if r[1] > 2.5 * med:
-        print("frames %d..%d: %.1f ms  keyframes %d iterations %d marginalisations %d backend_wait %.1f ms" % (r[0], r[0] + 10, r[1], r[2], r[3], r[4], r[5]))
+        print("frames %d..%d: %.1f ms  keyframes %d iterations %d marginalisations %d backend_wait %.1f ms, %.3f s after the first frame" % (r[0], r[0] + 10, r[1], r[2], r[3], r[4], r[5], r[6]))
 s.close()
