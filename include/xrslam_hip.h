@@ -399,6 +399,10 @@ int xrhip_group_get_stats(xrhip_group *group, xrhip_group_stats *out, int reset)
 int xrhip_ba_debug_linearize(xrhip_ba *ctx, const xrhip_ba_problem *problem, double *H, double *g, double *hll,
                              double *gl, double *W, double *cost);
 int xrhip_ba_debug_schur(xrhip_ba *ctx, const double *W, const double *w, int L, int P, double *out);
+/* parity aid (round 5): the eigenvalue bound the Cholesky fast path of the LAST collected marginalisation on this context computed
+ * (lambda_min >= 1 / trace(A^-1), csrc/marg_kernels.hip.h: km_chol) and its eight status words ([1] support size, [2] Cholesky failed /
+ * sweeps, [3] guard failed, [4] the eigen path ran) -- tests hold the bound to numpy's on the same matrix. */
+int xrhip_ba_debug_marg_guard(xrhip_ba *ctx, double *lambda_bound, int *status8);
 /* study aid (BASELINE.json config 5, "fp32 vs bf16 BA solve"): mode 1 / 2 run the Schur contraction of the following solves on this
  * context with f32 / bf16 matrix-core operands; mode 0 (the default, and what the product always uses) is f64. */
 int xrhip_ba_debug_set_schur_precision(xrhip_ba *ctx, int mode);

@@ -370,6 +370,10 @@ int xrhip_ba_solve_chained(xrhip_ba *c1, const xrhip_ba_problem *P1, xrhip_ba_su
     std::memcpy(P2->frame_state + 16 * (size_t)link_second, P1->frame_state + 16 * (size_t)link_first, sizeof(double) * 16);
     return xrhip_ba_solve(c2, P2, s2);
 }
+int xrhip_ba_debug_marg_guard(xrhip_ba *, double *, int *) {
+    g_err = "xrhip_ba_debug_marg_guard: the CPU checker has no fast path to guard";
+    return XRHIP_ESTATE;
+}
 int xrhip_ba_marginalize(xrhip_ba *, const xrhip_marg_problem *M, double *a, double *b, double *c) {
     const long long t_marg = clk_ns();
     int rc = orc_ba_marginalize(M, a, b, c);

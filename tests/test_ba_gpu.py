@@ -332,6 +332,28 @@ def test_preintegration_queued_behind_a_solve(ctx):
                                   ctx.preintegrate(smp, t_end, np.zeros(3), np.zeros(3), bs.NOISE36))
 
 
+def test_marginalization_guard_bound_is_the_trace_bound(ctx, bo):
+    """Round 5: km_chol's eigenvalue guard forms L^-1 in 16-wide blocks on the matrix cores (tri_inverse_blocked) instead of one forward
+    substitution per thread.  The bound it hands the gate, lambda_min >= 1 / trace(A^-1), against numpy on the same marginal matrix
+    (restricted to its support): equal to rounding, a rigorous lower bound of the smallest eigenvalue, and -- on these well-conditioned
+    priors -- the fast path stands (no eigen path)."""
+    for K, Ln, seed in ((11, 150, 21), (6, 80, 22), (16, 300, 23)):
+        pd, _ = bs.make_window(K=K, L=Ln, seed=seed)
+        pd.frame_state[1:, 4:7] += 1e-3
+        md = _marg_problem(pd, 0)
+        si_h, _, _ = ctx.marginalize(md)
+        lam, st = ctx.marg_guard()
+        A = si_h.T @ si_h
+        sup = np.where(np.abs(A).sum(1) > 0)[0]
+        assert st[1] == len(sup)                                   # support size as the device counted it
+        if st[4]:                                                  # (eigen path: the guard was not what decided -- not on these problems)
+            pytest.fail("fast path expected: status %r" % (st,))
+        Ac = A[np.ix_(sup, sup)]
+        ref = 1.0 / np.trace(np.linalg.inv(Ac))
+        assert abs(lam - ref) <= 1e-6 * ref, (K, lam, ref)
+        assert lam <= np.linalg.eigvalsh(Ac)[0] * (1 + 1e-9) and lam > 1e-8
+
+
 def _marg_problem(pd, victim=0):
     seen = set(pd.obs_lm[(pd.obs_ref == victim) | (pd.obs_tgt == victim)])
     sel = np.array([l in seen for l in pd.obs_lm])

@@ -187,6 +187,14 @@ class BaContext:
         check(self._lib.xrhip_ba_marginalize(self._h, C.byref(s), _p(si), _p(iv), _p(lin)))
         return si, iv, lin
 
+    def marg_guard(self):
+        """-> (eigenvalue bound of the last marginalisation's Cholesky fast path, its eight status words)"""
+        lam = C.c_double()
+        st = (C.c_int * 8)()
+        self._lib.xrhip_ba_debug_marg_guard.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        check(self._lib.xrhip_ba_debug_marg_guard(self._h, C.byref(lam), st))
+        return lam.value, list(st)
+
     def marginalize_begin(self, md):
         """Queues the marginalisation (xrhip_ba_marginalize_begin); marginalize_end() returns its result."""
         self._marg_k = len(md.frame_state) - 1

@@ -85,6 +85,7 @@ struct xrhip_ba {
         int K = 0, victim = 0, R = 0;
         std::vector<double> lin;
         int *dst = nullptr, *dsup = nullptr;
+        double *lam = nullptr;   // km_chol's eigenvalue bound of the last marginalisation (xrhip_ba_debug_marg_guard)
         double *As = nullptr, *bs = nullptr, *B = nullptr, *V = nullptr, *Ss = nullptr, *ivs = nullptr, *dsi = nullptr, *div = nullptr;
     } marg;
     int preint_pending = 0;            // jobs of the pre-integration batch in flight (begin/end), 0 = none
@@ -1394,6 +1395,15 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
 
 /* study aid (BASELINE config 5, "fp32 vs bf16 BA solve"): the Schur contraction of every following solve on this context runs with f32
  * (mode 1) or bf16 (mode 2) matrix-core operands instead of f64 (mode 0, what the product always uses). */
+int xrhip_ba_debug_marg_guard(xrhip_ba *c, double *lambda_bound, int *status8) {
+    if (!c || !lambda_bound || !status8) return xr_fail(XRHIP_EINVAL, "xrhip_ba_debug_marg_guard: null argument");
+    if (c->marg.pending || !c->marg.lam) return xr_fail(XRHIP_ESTATE, "xrhip_ba_debug_marg_guard: no collected marginalisation on this context");
+    XR_HIP(hipStreamSynchronize(c->stream));
+    XR_HIP(hipMemcpy(lambda_bound, c->marg.lam, sizeof(double), hipMemcpyDeviceToHost));
+    XR_HIP(hipMemcpy(status8, c->marg.dst, sizeof(int) * 8, hipMemcpyDeviceToHost));
+    return XRHIP_OK;
+}
+
 int xrhip_ba_debug_set_schur_precision(xrhip_ba *c, int mode) {
     if (!c || mode < 0 || mode > 2) return xr_fail(XRHIP_EINVAL, "xrhip_ba_debug_set_schur_precision: bad arguments");
     c->schur_mode = mode;
@@ -1616,6 +1626,7 @@ static int marg_launch(xrhip_ba *c, const xrhip_marg_problem *M) {
     mp.lin.assign(M->frame_state, M->frame_state + 16 * (size_t)K);
     mp.dst = dst;
     mp.dsup = dsup;
+    mp.lam = (double *)(W2 + o_lam);
     mp.As = As;
     mp.bs = bs;
     mp.B = B;
