@@ -35,6 +35,11 @@ been marginalised (once per sequence through the eigen path: a rank-deficient pr
 the missing frames run as an untimed pre-roll in front of the W warmup steps (config.untimed_preroll_frames) -- the frames it
 skips are cheaper on average (smaller windows), so this never flatters `value` except for that one-off, whose cost the line
 states as `one_off_ms` (the longest pre-roll frame against the pre-roll's median frame).
+Beside `value` the line carries (round 5): `sustained` -- the headline mode itself continued for --sustained-frames more frames of the
+same stream (a --steps 20 line is a 12 ms sample); `variants` -- each leg behind six untimed settle frames, in four timed chunks
+(`chunk_ms`), with its keyframe / solve / BA-iteration counts (legs cover different stretches of the stream: comparable at equal counts);
+`cpu_baseline.ms_per_ba_iteration` / `.ms_per_marginalization` -- the CPU checker's own solve and marginalisation clocks over the same
+frames (the second half of BASELINE.json's metric on the same host).
 One independent sequence per GPU: no data-path collective, only a barrier and a MAX
 reduction of the wall time over RCCL.  --sequences-per-gpu S puts S sequences on every GPU (instance-scoped entry points,
 XRSLAMAmdInstance*): `value` is then the aggregate over all sequences of all GPUs.

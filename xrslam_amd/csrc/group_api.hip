@@ -80,7 +80,7 @@ struct xrhip_group {
     std::atomic<int> gate_active{0};        // members that are neither busy nor absent
     std::atomic<int> gate_waiting{0};       // ... of which at the gate right now
     std::atomic<bool> gate_used{false};     // somebody has been through the gate: the linger below counts with it
-    bool gate_on = false;                   // XRHIP_GROUP_GATE=1 switches it on (measured: bigger batches, no more frames per second -- group.hip.h);
+    std::atomic<bool> gate_on{false};       // XRHIP_GROUP_GATE=1 switches it on (measured: bigger batches, no more frames per second -- group.hip.h);
                                             // too many timeouts in a row switch it off again: members are not driven concurrently
     int gate_timeout_us = 2500;             // XRHIP_GROUP_GATE_TIMEOUT_US: longer than a frame -- members that are out of phase (at the start, after a
                                             // straggler) meet at the gate within one frame; a member that is really gone costs the others this once
@@ -373,14 +373,14 @@ void group_gate_busy(xrhip_group *g, void *owner, bool busy) {
     else g->gate_recount_locked();
 }
 void group_gate_arrive(xrhip_group *g, void *owner) {
-    if (!g || !g->gate_on) return;
+    if (!g || !g->gate_on.load(std::memory_order_relaxed)) return;
     unsigned my_gen;
     {
         std::lock_guard<std::mutex> lk(g->gate_m);
         xrhip_group::GateMember *me = nullptr;
         for (xrhip_group::GateMember &m : g->gate_members)
             if (m.owner == owner) me = &m;
-        if (!me || !g->gate_on) return;
+        if (!me || !g->gate_on.load(std::memory_order_relaxed)) return;
         g->gate_used.store(true, std::memory_order_relaxed);
         me->absent = false;
         my_gen = g->gate_gen.load(std::memory_order_relaxed);
@@ -407,7 +407,7 @@ void group_gate_arrive(xrhip_group *g, void *owner) {
             if (!m.busy && !m.absent && m.arrived_gen != my_gen) m.absent = true;
         g->gate_timeouts++;
         if (++g->gate_timeouts_in_a_row >= 16) {
-            g->gate_on = false;
+            g->gate_on.store(false);
             g->gate_used.store(false, std::memory_order_relaxed);
             g->linger_us.store(0, std::memory_order_relaxed);
         }
@@ -453,9 +453,9 @@ int xrhip_group_create(xrhip_group **out) {
     hipGetDevice(&g->device);
     // the frame gate (group.hip.h) lines the members' frames up; behind it a short linger collects the requests of the members that
     // started the frame together (they arrive within microseconds of each other)
-    if (const char *e = std::getenv("XRHIP_GROUP_GATE")) g->gate_on = std::atoi(e) != 0;
+    if (const char *e = std::getenv("XRHIP_GROUP_GATE")) g->gate_on.store(std::atoi(e) != 0);
     if (const char *e = std::getenv("XRHIP_GROUP_GATE_TIMEOUT_US")) g->gate_timeout_us = std::max(1, std::atoi(e));
-    g->linger_us.store(g->gate_on ? 40 : 0);
+    g->linger_us.store(g->gate_on.load() ? 40 : 0);
     if (const char *e = std::getenv("XRHIP_GROUP_LINGER_US")) g->linger_us.store(std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("XRHIP_GROUP_LINGER_QUEUES")) g->linger_queues = std::atoi(e);
     if (const char *e = std::getenv("XRHIP_GROUP_PER_KIND")) g->per_kind = std::atoi(e) != 0;
@@ -567,7 +567,7 @@ int xrhip_group_get_stats(xrhip_group *g, xrhip_group_stats *out, int reset) {
     out->batches[7] = g->gate_opens;
     out->entries[7] = g->gate_full;
     out->timed[7] = g->gate_timeouts;
-    out->ms[7] = g->gate_on ? 1.0 : 0.0;
+    out->ms[7] = g->gate_on.load() ? 1.0 : 0.0;
     if (reset) g->gate_opens = g->gate_full = g->gate_timeouts = 0;
     return XRHIP_OK;
 }
