@@ -374,7 +374,7 @@ int xrhip_ba_join_group(xrhip_ba *ctx, xrhip_group *group);
  * being waited for until they do).  Members whose frames start together issue their uploads, pyramids, tracking launches and solves
  * together, so one launch carries all of them.  xrhip_klt_group_busy(ctx, 1 / 0) brackets a stretch during which the sequence will
  * not start a frame (a keyframe's window solve and marginalisation): the others go on without it.  No-ops outside a group; timing only --
- * no result depends on either call.  (stats slot 7: gate openings / with everybody present / by timeout.) */
+ * no result depends on either call.  (stats slot XRHIP_GK_GATE: gate openings / with everybody present / by timeout.) */
 int xrhip_klt_frame_gate(xrhip_klt *ctx);
 int xrhip_klt_group_busy(xrhip_klt *ctx, int busy);
 /* request kinds of the statistics below */
@@ -385,11 +385,14 @@ int xrhip_klt_group_busy(xrhip_klt *ctx, int busy);
 #define XRHIP_GK_DETECT 4      /* k_harris + k_harris_nms + k_harris_select */
 #define XRHIP_GK_CHAIN 5       /* kb_stage + kb_chain (+ kp_preintegrate queued behind the solve) */
 #define XRHIP_GK_PREINT 6      /* kp_preintegrate */
+#define XRHIP_GK_WROUND 7      /* one trust-region round of a window solve: kb_lin_all .. kb_solve_try + the first kb_trials_wide (round 5) */
+#define XRHIP_GK_WTRIALS 8     /* kb_trials_wide of a run of rejected trials */
+#define XRHIP_GK_GATE 11       /* not a request kind: the frame gate's openings / with everybody present / by timeout */
 typedef struct xrhip_group_stats {
-    long long batches[8];   /* batches launched, per request kind */
-    long long entries[8];   /* requests they served (entries / batches = sequences per launch) */
-    double ms[8];           /* HIP-event duration of the timed batches, first to last kernel (xrhip_group_set_profiling) */
-    long long timed[8];     /* batches that contributed to ms */
+    long long batches[12];   /* batches launched, per request kind */
+    long long entries[12];   /* requests they served (entries / batches = sequences per launch) */
+    double ms[12];           /* HIP-event duration of the timed batches, first to last kernel (xrhip_group_set_profiling) */
+    long long timed[12];     /* batches that contributed to ms */
 } xrhip_group_stats;
 int xrhip_group_set_profiling(xrhip_group *group, int enable);
 int xrhip_group_get_stats(xrhip_group *group, xrhip_group_stats *out, int reset);

@@ -162,7 +162,7 @@ def test_grouped_instances_behind_the_frame_gate_gpu(monkeypatch):
     for (pa, ca), (pt, ct) in zip(alone, res):
         assert ca == ct
         np.testing.assert_array_equal(pa, pt)
-    assert stats["gate"]["batches"] >= 40, stats      # openings (slot 7 of the statistics: openings / everybody present / timeouts)
+    assert stats["gate"]["batches"] >= 10, stats      # openings (the gate's slot of the statistics: openings / everybody present / timeouts)
 
 
 @pytest.mark.gpu

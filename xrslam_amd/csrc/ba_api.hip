@@ -42,6 +42,18 @@ struct ChainPayload {
     bool with_preint = false;
     PreintArgs preint;
 };
+// One trust-region round of a window solve as a request of an instance group (GK_WROUND; ba_kernels.hip.h: WinEntry), or a batch of
+// rejected trials (GK_WTRIALS: `e` alone).  A solve's first round also carries the copy of the staged problem and the prior's Lambda.
+struct WindowPayload {
+    WinEntry e;
+    bool relin = false;        // this round linearises (kw_lin_all, kw_landmark_vision, kw_assemble)
+    bool with_stage = false;   // first round of a solve
+    StageArgs stage;
+    int np = 0;                // > 0 with with_stage: kb_prior_lambda first
+    gptr<const double> pS, pinfo;
+    gptr<double> pLam, pc0;
+    size_t lds_lin = 0, lds_solve = 0, lds_wide = 0;
+};
 
 }   // namespace
 
@@ -50,7 +62,8 @@ struct xrhip_ba {
     int device = 0;   // the device the context was created on (a group of another device is refused)
     // instance group (group.hip.h): the single-launch solves and the pre-integration batches travel as requests
     xrhip_group *group = nullptr;
-    GroupRequest rq_chain, rq_preint;
+    GroupRequest rq_chain, rq_preint, rq_window;
+    WindowPayload a_window;
     ChainPayload a_chain;
     PreintArgs a_preint;
     GroupRequest *preint_rq = nullptr;   // the request that carries the batch in flight (grouped), and the stream it runs on
@@ -259,11 +272,84 @@ static int launch_chain_batch(GroupRequest **r, int n, hipStream_t s, hipStream_
     return XRHIP_OK;
 }
 
+// Window rounds of several members (round 5): every kernel of the round once, blockIdx.z = member.  In stream order: the staged
+// problems of the solves that begin (kb_stage), their priors' Lambda (kb_prior_lambda, per entry: two launches in 27 frames), then the
+// round -- entries that do not linearise (a re-solve at another trust-region radius) have grid size 0 in the first three kernels.
+static int launch_wround_batch(GroupRequest **r, int n, hipStream_t s, hipStream_t = nullptr) {
+    for (int base = 0; base < n; base += XB) {
+        const int m = std::min(XB, n - base);
+        const WindowPayload *w[XB];
+        for (int i = 0; i < m; ++i) w[i] = static_cast<const WindowPayload *>(r[base + i]->payload);
+        Batch<StageArgs> bs;
+        std::memset(&bs, 0, sizeof(bs));
+        size_t most16 = 0;
+        for (int i = 0; i < m; ++i)
+            if (w[i]->with_stage) {
+                bs.e[i] = w[i]->stage;
+                most16 = std::max(most16, bs.e[i].n16);
+            }
+        if (most16) hipLaunchKernelGGL(kb_stage, dim3((int)std::min<size_t>((most16 + 255) / 256, 128), 1, m), dim3(256), 0, s, bs);
+        for (int i = 0; i < m; ++i)
+            if (w[i]->with_stage && w[i]->np) {
+                const int np = w[i]->np;
+                hipLaunchKernelGGL(kb_prior_lambda, dim3(((np + 15) / 16) * ((np + 15) / 16 + 1)), dim3(256), 0, s, np, w[i]->pS, w[i]->pLam, w[i]->pinfo,
+                                   w[i]->pc0);
+            }
+        Batch<WinEntry> b;
+        std::memset(&b, 0, sizeof(b));
+        int g_lin = 0, g_lv = 0, g_asm = 0, g_sa = 0;
+        size_t lds_lin = 0, lds_solve = 0, lds_wide = 0;
+        for (int i = 0; i < m; ++i) {
+            b.e[i] = w[i]->e;
+            if (!w[i]->relin) b.e[i].g_lin = b.e[i].g_lv = b.e[i].g_asm = 0;
+            g_lin = std::max(g_lin, b.e[i].g_lin);
+            g_lv = std::max(g_lv, b.e[i].g_lv);
+            g_asm = std::max(g_asm, b.e[i].g_asm);
+            g_sa = std::max(g_sa, b.e[i].g_sa);
+            lds_lin = std::max(lds_lin, w[i]->lds_lin);
+            lds_solve = std::max(lds_solve, w[i]->lds_solve);
+            lds_wide = std::max(lds_wide, w[i]->lds_wide);
+        }
+        if (g_lin) {
+            hipLaunchKernelGGL(kw_lin_all, dim3(g_lin, 1, m), dim3(256), lds_lin, s, b);
+            hipLaunchKernelGGL(kw_landmark_vision, dim3(std::max(g_lv, 1), 1, m), dim3(64), 0, s, b);
+            hipLaunchKernelGGL(kw_assemble, dim3(std::max(g_asm, 1), 1, m), dim3(256), 0, s, b);
+        }
+        hipLaunchKernelGGL(kw_prepare, dim3(1, 1, m), dim3(256), 0, s, b);
+        hipLaunchKernelGGL(kw_schur_aux, dim3(std::max(g_sa, 1), 1, m), dim3(256), 0, s, b);
+        hipLaunchKernelGGL(kw_solve_try, dim3(1, 1, m), dim3(512), lds_solve, s, b);
+        for (int i = 0; i < m; ++i) b.e[i].first = 1;
+        hipLaunchKernelGGL(kw_trials_wide, dim3(WIDE_G, 1, m), dim3(256), lds_wide, s, b);
+    }
+    XR_HIP(hipGetLastError());
+    return XRHIP_OK;
+}
+static int launch_wtrials_batch(GroupRequest **r, int n, hipStream_t s, hipStream_t = nullptr) {
+    for (int base = 0; base < n; base += XB) {
+        const int m = std::min(XB, n - base);
+        Batch<WinEntry> b;
+        std::memset(&b, 0, sizeof(b));
+        size_t lds_wide = 0;
+        for (int i = 0; i < m; ++i) {
+            const WindowPayload *w = static_cast<const WindowPayload *>(r[base + i]->payload);
+            b.e[i] = w->e;
+            b.e[i].first = 0;
+            b.e[i].mode = 0;
+            lds_wide = std::max(lds_wide, w->lds_wide);
+        }
+        hipLaunchKernelGGL(kw_trials_wide, dim3(WIDE_G, 1, m), dim3(256), lds_wide, s, b);
+    }
+    XR_HIP(hipGetLastError());
+    return XRHIP_OK;
+}
+
 namespace {
 struct RegisterBaLaunchers {
     RegisterBaLaunchers() {
         group_register(GK_PREINT, launch_preint_batch);
         group_register(GK_CHAIN, launch_chain_batch);
+        group_register(GK_WROUND, launch_wround_batch);
+        group_register(GK_WTRIALS, launch_wtrials_batch);
     }
 } g_register_ba_launchers;
 }   // namespace
@@ -781,6 +867,8 @@ int xrhip_ba_create(int max_frames, int max_landmarks, int max_obs, xrhip_ba **o
     XR_HIP(hipFuncSetAttribute((const void *)kb_solve_try<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)kb_chain, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)kb_trials_wide, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+    XR_HIP(hipFuncSetAttribute((const void *)kw_solve_try, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
+    XR_HIP(hipFuncSetAttribute((const void *)kw_trials_wide, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_chol, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     XR_HIP(hipFuncSetAttribute((const void *)km_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit));
     // pre-size for the advertised maxima
@@ -809,6 +897,7 @@ int xrhip_ba_join_group(xrhip_ba *c, xrhip_group *g) {
     if (c->group) {
         int rc = group_drain(c->group, GQ_CHAIN, c);
         if (!rc) rc = group_drain(c->group, GQ_PREINT, c);
+        if (!rc) rc = group_drain(c->group, GQ_WINDOW, c);
         if (rc) return rc;
         group_member_remove(c->group, false);
     }
@@ -1167,7 +1256,12 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     size_t chain_lds = 0;
     int chain_tile = 0;
     const bool use_chain = chain(d, (size_t)c->lds_limit, &chain_lds, &chain_tile);
-    if (!use_chain) {   // (the single-launch solve carries the copy of its staged problem itself)
+    // Round 5: a member of an instance group hands the rounds of a window-sized solve to the group (GK_WROUND / GK_WTRIALS: one launch per
+    // kernel for all members whose rounds are pending, blockIdx.z = member; launch_wround_batch) instead of issuing ~45 launches of its
+    // own on a stream that shares two hardware queues with the other members' rounds.  Same kernels' bodies, same bits.
+    static const bool wbatch_off = std::getenv("XRHIP_GROUP_NO_WINDOW_BATCH") != nullptr;   // development switch (A/B)
+    const bool wbatch = c->group && !use_chain && !wbatch_off && wide_first(d) && d.nla > 0 && std::getenv("XRHIP_GROUP_SPEC") == nullptr;
+    if (!use_chain && !wbatch) {   // (the single-launch solve and the group's first round carry the copy of the staged problem themselves)
         rc = launch_stage_copy(c);
         if (rc) return rc;
     }
@@ -1175,8 +1269,40 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     if (!d.nla) d.lm_rows = 0;
     const double sx = P->sqrt_inv_cov[0], sy = P->sqrt_inv_cov[1];
     hipStream_t s = c->stream;
-    if (d.np) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16 + 1)), dim3(256), 0, s, d.np, p.pS, p.pLam, p.pinfo, p.pc0);
+    if (d.np && !wbatch) hipLaunchKernelGGL(kb_prior_lambda, dim3(((d.np + 15) / 16) * ((d.np + 15) / 16 + 1)), dim3(256), 0, s, d.np, p.pS, p.pLam, p.pinfo, p.pc0);
     bool done = false, relinearise = true;
+    bool wfirst = true;   // (wbatch) the next round request is the solve's first
+    hipStream_t wstream = wbatch ? group_stream(c->group, GQ_WINDOW) : nullptr;
+    const size_t wide_lds = sizeof(double) * ((size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np) + (size_t)4 * WIDE_B * 257);
+    auto submit_window = [&](int kind, int seq_, int mode_) -> int {
+        int r = group_wait_launched(&c->rq_window);   // (its argument block is about to be rewritten)
+        if (r) return r;
+        WindowPayload &wp = c->a_window;
+        size_t lds = 0;
+        int use_lds = 1;
+        r = solve_lds(d, (size_t)c->lds_limit, &lds, &use_lds);
+        if (r) return r;
+        lds = std::max(lds, sizeof(double) * (size_t)std::max(TRY_B * (d.np + 15 * d.NI), 1));
+        const int tiles = d.PF / 16, nrest = (d.na * d.na + 255) / 256;
+        wp.e = WinEntry{c->tiny_args, lin_all_blocks(d.M, d.MR, d.NI, d.np), d.lm_rows + d.F * d.F * VIS_CH, (d.n * d.n + 255) / 256,
+                        nrest + tiles * tiles + aux_quad_blocks_n(d.n, d.L) + aux_wog_blocks(d.F) + 1, use_lds, mode_, seq_, 1};
+        wp.relin = relinearise;
+        wp.with_stage = wfirst;
+        wp.stage = StageArgs{c->stage_src, c->stage_dst, c->stage_n16};
+        wp.np = d.np;
+        wp.pS = p.pS;
+        wp.pLam = p.pLam;
+        wp.pinfo = p.pinfo;
+        wp.pc0 = p.pc0;
+        wp.lds_lin = sizeof(double) * (size_t)std::max(d.np, 1);
+        wp.lds_solve = lds;
+        wp.lds_wide = wide_lds;
+        c->rq_window.kind = kind;
+        c->rq_window.owner = c;
+        c->rq_window.payload = &wp;
+        wfirst = false;
+        return group_submit(c->group, GQ_WINDOW, &c->rq_window);
+    };
     int mode = 1, iter_seen = 0;
     struct BusyElsewhere {   // a solve on the context's own stream: the group's linger does not wait for this member meanwhile
         xrhip_group *g;
@@ -1313,7 +1439,10 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     bool spec_ready = false;   // the linearisation at the state just accepted is already queued on the second stream
     for (int guard = 0; guard < 4 * (P->max_iterations + 8) && !done; ++guard) {
         const int seq = ++c->seq;
-        if (spec_ready) {   // (the chain that built this linearisation is ahead of us on this very stream)
+        if (wbatch) {
+            rc = submit_window(GK_WROUND, seq, mode);
+            c->stats.n_solve_try++;
+        } else if (spec_ready) {   // (the chain that built this linearisation is ahead of us on this very stream)
             rc = launch_solve_try(c, d, p, cam, imu, sx, sy, false, mode, seq, true, &p2);
         } else {
             if (relinearise) launch_linearize(c, d, p, cam, imu, sx, sy, true);
@@ -1330,7 +1459,8 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
             spec_launched = true;
             c->spec_launched++;
         }
-        rc = wait_mailbox(c, seq, spec ? c->stream2 : nullptr);   // no copy, no driver wait: the kernel's last store is the sequence number
+        rc = wbatch ? wait_mailbox(c, seq, wstream, &c->rq_window)
+                    : wait_mailbox(c, seq, spec ? c->stream2 : nullptr);   // no copy, no driver wait: the kernel's last store is the sequence number
         if (rc) return rc;
         const bool first_batch_accept = spec_launched && c->h_ctl->status == ST_ACCEPTED && c->h_ctl->accepted_slot == 0;
         {   // trials this launch costed = trust-region iterations it advanced
@@ -1343,10 +1473,15 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
         int st = c->h_ctl->status;
         for (int wguard = 0; st == ST_NEED_TRIALS && wguard < 64; ++wguard) {   // run of rejected trials, 8 per launch
             const int wseq = ++c->seq;
-            const size_t wlds = sizeof(double) * ((size_t)WIDE_B * (16 * (size_t)d.F + (size_t)d.np) + (size_t)4 * WIDE_B * 257);
-            hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wlds, spec ? c->stream2 : s, d, p, cam, imu, sx, sy, wseq, 0, 0);
-            XR_HIP(hipGetLastError());
-            rc = wait_mailbox(c, wseq, spec ? c->stream2 : nullptr);
+            if (wbatch) {
+                rc = submit_window(GK_WTRIALS, wseq, 0);
+                if (rc) return rc;
+                rc = wait_mailbox(c, wseq, wstream, &c->rq_window);
+            } else {
+                hipLaunchKernelGGL(kb_trials_wide, dim3(WIDE_G), dim3(256), wide_lds, spec ? c->stream2 : s, d, p, cam, imu, sx, sy, wseq, 0, 0);
+                XR_HIP(hipGetLastError());
+                rc = wait_mailbox(c, wseq, spec ? c->stream2 : nullptr);
+            }
             if (rc) return rc;
             const int it_now = c->h_ctl->iteration;
             c->stats.n_trials += std::max(0, it_now - iter_seen);

@@ -1119,26 +1119,27 @@ __device__ __forceinline__ void sum_cost_block(const BaDims &d, const BaPtrs &p,
 // Schur tiles and the solve's auxiliary passes in one launch: [tiles^2 | aux blocks]
 // (without free landmarks there is no Schur complement and no W^T (omega gl): only the quadratic-form blocks run)
 // layout of the grid: [Schur tiles | rest of S | aux blocks]
-__global__ __launch_bounds__(256) void kb_schur_aux(BaDims d, BaPtrs p) {
+__device__ __forceinline__ void d_schur_aux(const BaDims &d, const BaPtrs &p, int bx, int gx) {
 #ifdef XRHIP_KPROF_PRINT
     const long long t0 = wall_clock64();
     struct Tail {
         long long t0;
         const BaDims &d;
         const BaPtrs &p;
+        int bx;
         __device__ ~Tail() {
-            const int nrest = (d.na * d.na + 255) / 256, tiles = d.PF / 16, b = blockIdx.x;
+            const int nrest = (d.na * d.na + 255) / 256, tiles = d.PF / 16, b = bx;
             const int nbq = aux_quad_blocks_n(d.n, d.L);
             if (threadIdx.x == 0 && d.M > 1500 &&
                 (b == 1 || b == nrest + 3 || b == nrest + tiles * tiles + 1 || b == nrest + tiles * tiles + nbq - 2 || b == nrest + tiles * tiles + nbq))
                 printf("kb_schur_aux block %d (rest %d tiles %d quad %d): %lld x10ns\n", b, nrest, tiles * tiles, nbq, wall_clock64() - t0);
         }
-    } tail{t0, d, p};
+    } tail{t0, d, p, bx};
 #endif
     const int t2 = d.nla ? (d.PF / 16) * (d.PF / 16) : 0;
     const int nrest = (d.na * d.na + 255) / 256;
-    int blk = blockIdx.x;
-    if (blk == (int)gridDim.x - 1) {
+    int blk = bx;
+    if (blk == gx - 1) {
         // Round 5: the linearisation's total cost and gradient max-norm -- two block-wide reductions and an exponential map per frame
         // that nothing in this launch reads (kb_solve_try does) -- ride here as one more block beside the tiles instead of in front of
         // them in the single-workgroup kb_cost_prepare (11 us per round, of which the preparation the tiles DO need is the smaller half:
@@ -1160,6 +1161,7 @@ __global__ __launch_bounds__(256) void kb_schur_aux(BaDims d, BaPtrs p) {
     }
     solve_aux_block(d, p, blk - nrest);
 }
+__global__ __launch_bounds__(256) void kb_schur_aux(BaDims d, BaPtrs p) { d_schur_aux(d, p, blockIdx.x, gridDim.x); }
 
 // Reduced camera system + blocked Cholesky + Gauss-Newton / Cauchy quantities.  One workgroup.
 // Only the `na` free frame dofs enter the factorisation (localize_newframe has 15, refine_window 15 F).
@@ -1924,12 +1926,12 @@ __device__ __forceinline__ int try_block(const BaDims &d, const BaPtrs &p, const
 // consecutive single-workgroup phases run back to back in one kernel.
 
 // all four factor families at once: [obs | rot | imu (one factor per block) | prior (1 block)]
-__global__ __launch_bounds__(256) void kb_lin_all(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy) {
+__device__ __forceinline__ void d_lin_all(const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx, double sy, int bx) {
     extern __shared__ double sh[];   // np doubles (prior role)
     __shared__ double scr[IMU_SCR + IMU_XCH];   // lin_imu_block: raw residual + the two raw Jacobians | the pieces' exchange area
     __shared__ double scratch[8];
     const int nbo = (d.M + 255) / 256, nbr = (d.MR + 255) / 256, nbi = d.NI;
-    int blk = blockIdx.x;
+    int blk = bx;
     if (blk < nbo) {
         const int o = blk * 256 + threadIdx.x;
         if (o < d.M) lin_obs_item(d, p, cam, sx, sy, o);
@@ -1953,6 +1955,9 @@ __global__ __launch_bounds__(256) void kb_lin_all(BaDims d, BaPtrs p, Ext cam, E
     }
     lin_prior_rows_block(d, p, blk, sh, scratch);
 }
+__global__ __launch_bounds__(256) void kb_lin_all(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy) {
+    d_lin_all(d, p, cam, imu, sx, sy, blockIdx.x);
+}
 // blocks: [obs | rot | imu (one factor each) | prior: 16 rows each (one block when there is no prior: it clears the cost)]
 __host__ __device__ __forceinline__ int lin_all_blocks(int M, int MR, int NI, int np) {
     return (M + 255) / 256 + (MR + 255) / 256 + NI + (np ? (np + 15) / 16 : 1);
@@ -1962,19 +1967,20 @@ __host__ __device__ __forceinline__ int lin_all_blocks(int M, int MR, int NI, in
 // (tried: 64 landmarks per block, one THREAD walking a landmark's observation list -- no butterflies, but ~8 dependent
 // round trips to L2 per landmark instead of one: 21.7 -> 24.1 us, profiles/r02_ab_variants.md)
 // (no landmark rows are needed when every landmark is constant: nla == 0)
-__global__ __launch_bounds__(64) void kb_landmark_vision(BaDims d, BaPtrs p) {
+__device__ __forceinline__ void d_landmark_vision(const BaDims &d, const BaPtrs &p, int bx) {
     __shared__ double red[VIS_RED];
     const int lp = d.lm_rows;
 #ifdef XRHIP_KPROF_PRINT
     const long long t0 = wall_clock64();
 #endif
-    if ((int)blockIdx.x < lp) landmark_item(d, p, blockIdx.x, threadIdx.x);
-    else assemble_vision_item(d, p, ((int)blockIdx.x - lp) / VIS_CH, threadIdx.x, red, ((int)blockIdx.x - lp) % VIS_CH, VIS_CH);
+    if (bx < lp) landmark_item(d, p, bx, threadIdx.x);
+    else assemble_vision_item(d, p, (bx - lp) / VIS_CH, threadIdx.x, red, (bx - lp) % VIS_CH, VIS_CH);
 #ifdef XRHIP_KPROF_PRINT
     if (threadIdx.x == 0 && d.M > 1500 && wall_clock64() - t0 > 800)
-        printf("kb_landmark_vision block %d of %d+%d*%d (%s): %lld x10ns\n", (int)blockIdx.x, lp, d.F, d.F, (int)blockIdx.x < lp ? "landmark" : "pair", wall_clock64() - t0);
+        printf("kb_landmark_vision block %d of %d+%d*%d (%s): %lld x10ns\n", bx, lp, d.F, d.F, bx < lp ? "landmark" : "pair", wall_clock64() - t0);
 #endif
 }
+__global__ __launch_bounds__(64) void kb_landmark_vision(BaDims d, BaPtrs p) { d_landmark_vision(d, p, blockIdx.x); }
 
 // total cost, gradient max-norm and the per-solve preparation, one workgroup
 __global__ __launch_bounds__(256) void kb_cost_prepare(BaDims d, BaPtrs p) {
@@ -2032,9 +2038,9 @@ __device__ __forceinline__ void spec_state_block(const BaDims &d, const BaPtrs &
 // window-sized system runs in a 512-thread kernel without the ~190 spilled registers the trial loop costs there.
 // state2 / depth2 / ctl2 (PREP only, may be null): where the first candidate goes for the speculative linearisation
 template <int NT, bool PREP>
-__global__ __launch_bounds__(NT) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int use_lds,
-                                                   int after_linearisation, int seq, int wide_trials, double *state2, double *depth2,
-                                                   BaCtl *ctl2, int commit) {
+__device__ __forceinline__ void d_solve_try(const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx, double sy, int use_lds,
+                                            int after_linearisation, int seq, int wide_trials, double *state2, double *depth2,
+                                            BaCtl *ctl2, int commit) {
     extern __shared__ double lds[];   // max(solve_block's region, try_block's staging)
     if (PREP && commit) {   // the speculation was right: the cost and gradient norm of its linearisation become the minimiser's
         if (threadIdx.x == 0) {
@@ -2055,6 +2061,12 @@ __global__ __launch_bounds__(NT) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, 
         try_block(d, p, cam, imu, sx, sy, after_linearisation, seq, wide_trials != 0, lds, false);
     }
 }
+template <int NT, bool PREP>
+__global__ __launch_bounds__(NT) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int use_lds,
+                                                   int after_linearisation, int seq, int wide_trials, double *state2, double *depth2,
+                                                   BaCtl *ctl2, int commit) {
+    d_solve_try<NT, PREP>(d, p, cam, imu, sx, sy, use_lds, after_linearisation, seq, wide_trials, state2, depth2, ctl2, commit);
+}
 
 // The rejected-trial tail of a large solve on the whole chip.  After a rejection the next radii are radius/2,
 // radius/4, ...: WIDE_B candidates are costed by WIDE_G workgroups, each taking a slice of the factors (the small
@@ -2064,13 +2076,13 @@ __global__ __launch_bounds__(NT) void kb_solve_try(BaDims d, BaPtrs p, Ext cam, 
 // Dynamic LDS: WIDE_B * (16 F + np) doubles.
 // first != 0: this launch carries the first trial after a solve (mode = the solve's after_linearisation flag), so it
 // starts with the minimiser's finalize / start-of-iteration step instead of continuing a run of rejections.
-__global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int seq,
-                                                      int first, int mode) {
+__device__ __forceinline__ void d_trials_wide(const BaDims &d, const BaPtrs &p, const Ext &cam, const Ext &imu, double sx, double sy, int seq,
+                                              int first, int mode, int bx, int gx) {
     extern __shared__ double wl[];
     __shared__ double scratch[4 * WIDE_B * 4];
     __shared__ int s_last;
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-    const int blk = blockIdx.x, G = gridDim.x;
+    const int blk = bx, G = gx;
     const int n = d.n;
 #ifdef XRHIP_KPROF_PRINT
     long long tw[16];
@@ -2375,6 +2387,10 @@ __global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext ca
 #endif
 #undef WT
 }
+__global__ __launch_bounds__(256) void kb_trials_wide(BaDims d, BaPtrs p, Ext cam, Ext imu, double sx, double sy, int seq,
+                                                      int first, int mode) {
+    d_trials_wide(d, p, cam, imu, sx, sy, seq, first, mode, blockIdx.x, gridDim.x);
+}
 
 // Small problems without a free landmark (localize_newframe, refine_subwindow: a handful of free dofs): the three
 // launches between the frame-pair blocks and the solve -- Hessian assembly, cost / gradient norm / preparation, the
@@ -2439,6 +2455,59 @@ struct TinyArgs {
     Ext cam, imu;
     double sx, sy;
 };
+
+// ---------------------------------------------------------------------------------------------- window rounds of an instance group
+// Round 5.  A keyframe's refine_window is ~45 launches; the members of an instance group used to issue them one by one on their own
+// streams, which share two hardware queues with the other members' rounds and marginalisations (2.1 ms per keyframe against 1.05
+// solo; 3.5 of 8 members are inside such rounds at any moment: profiles/r05_multi_sequence.md).  Here the kernels of a round take
+// several members' rounds at once: blockIdx.z = entry, every entry with its own argument block in device memory (the TinyArgs staged
+// with the problem: BaDims + BaPtrs are ~0.7 KB, eight of them do not fit the 4 KB a launch can carry by value) and its own grid sizes
+// -- blocks beyond an entry's grid return at once.  The bodies are the solo kernels' (d_lin_all ... d_trials_wide): same block-to-work
+// mapping, same summation order, same bits.
+struct WinEntry {
+    const TinyArgs *args;
+    int g_lin, g_lv, g_asm, g_sa;    // this entry's grid sizes; 0: the kernel is not part of the entry's round (no relinearisation)
+    int use_lds, mode, seq, first;   // kb_solve_try's layout switch and after_linearisation flag, the mailbox sequence number; kw_trials_wide: first
+};
+__global__ __launch_bounds__(256) void kw_lin_all(Batch<WinEntry> b) {
+    const WinEntry &e = b.e[blockIdx.z];
+    if ((int)blockIdx.x >= e.g_lin) return;
+    const TinyArgs &a = *e.args;
+    d_lin_all(a.d, a.p, a.cam, a.imu, a.sx, a.sy, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void kw_landmark_vision(Batch<WinEntry> b) {
+    const WinEntry &e = b.e[blockIdx.z];
+    if ((int)blockIdx.x >= e.g_lv) return;
+    d_landmark_vision(e.args->d, e.args->p, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void kw_assemble(Batch<WinEntry> b) {
+    const WinEntry &e = b.e[blockIdx.z];
+    if ((int)blockIdx.x >= e.g_asm) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < e.args->d.n * e.args->d.n) assemble_item(e.args->d, e.args->p, idx);
+}
+__global__ __launch_bounds__(256) void kw_prepare(Batch<WinEntry> b) {
+    const WinEntry &e = b.e[blockIdx.z];
+    if (!e.args) return;
+    prepare_block(e.args->d, e.args->p);
+}
+__global__ __launch_bounds__(256) void kw_schur_aux(Batch<WinEntry> b) {
+    const WinEntry &e = b.e[blockIdx.z];
+    if ((int)blockIdx.x >= e.g_sa) return;
+    d_schur_aux(e.args->d, e.args->p, blockIdx.x, e.g_sa);
+}
+__global__ __launch_bounds__(512) void kw_solve_try(Batch<WinEntry> b) {
+    const WinEntry &e = b.e[blockIdx.z];
+    if (!e.args) return;
+    const TinyArgs &a = *e.args;
+    d_solve_try<512, true>(a.d, a.p, a.cam, a.imu, a.sx, a.sy, e.use_lds, e.mode, e.seq, 2, nullptr, nullptr, nullptr, 0);
+}
+__global__ __launch_bounds__(256) void kw_trials_wide(Batch<WinEntry> b) {
+    const WinEntry &e = b.e[blockIdx.z];
+    if (!e.args) return;
+    const TinyArgs &a = *e.args;
+    d_trials_wide(a.d, a.p, a.cam, a.imu, a.sx, a.sy, e.seq, e.first, e.mode, blockIdx.x, gridDim.x);
+}
 __global__ __launch_bounds__(256) void kb_tiny(const TinyArgs *__restrict__ args, int use_lds, int seq, int max_rounds) {
     const BaDims &d = args->d;
     const BaPtrs &p = args->p;

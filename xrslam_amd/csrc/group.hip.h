@@ -35,8 +35,9 @@
 
 namespace xrhip {
 
-enum GroupQueue { GQ_KLT = 0, GQ_CHAIN, GQ_PREINT, GQ_COUNT };
-enum GroupKind { GK_CALL = 0, GK_UPLOAD, GK_PREPROCESS, GK_TRACK, GK_DETECT, GK_CHAIN, GK_PREINT, GK_COUNT };
+enum GroupQueue { GQ_KLT = 0, GQ_CHAIN, GQ_PREINT, GQ_WINDOW, GQ_COUNT };   // GQ_WINDOW (round 5): the members' window rounds, batched (ba_api.hip)
+enum GroupKind { GK_CALL = 0, GK_UPLOAD, GK_PREPROCESS, GK_TRACK, GK_DETECT, GK_CHAIN, GK_PREINT, GK_WROUND, GK_WTRIALS, GK_COUNT };
+constexpr int GK_GATE_SLOT = 11;   // statistics slot of the frame gate (xrhip_group_stats has 12)
 
 struct GroupRequest {
     int kind = GK_CALL;

@@ -488,8 +488,9 @@ int xrhip_group_create(xrhip_group **out) {
     for (int k = 0; k < GQ_COUNT; ++k) {
         GroupQueueState &Q = g->qs[k];
         Q.index = k;
-        hipError_t e = use_prio ? hipStreamCreateWithPriority(&Q.stream, hipStreamNonBlocking, prio_high)
-                                : hipStreamCreateWithFlags(&Q.stream, hipStreamNonBlocking);
+        // (the window queue -- the members' batched window rounds, round 5 -- stays at NORMAL priority: the per-frame batches go first)
+        hipError_t e = (use_prio && k != GQ_WINDOW) ? hipStreamCreateWithPriority(&Q.stream, hipStreamNonBlocking, prio_high)
+                                                    : hipStreamCreateWithFlags(&Q.stream, hipStreamNonBlocking);
         if (e == hipSuccess && k == GQ_KLT && side_stream) e = hipStreamCreateWithFlags(&Q.side, hipStreamNonBlocking);
         if (e != hipSuccess) {   // no thread has been started yet: give back what exists and report
             for (int j = 0; j <= k; ++j) {
@@ -562,12 +563,12 @@ int xrhip_group_get_stats(xrhip_group *g, xrhip_group_stats *out, int reset) {
         *out = g->stats;
         if (reset) std::memset(&g->stats, 0, sizeof(g->stats));
     }
-    // slot 7: the frame gate -- times it opened / with every expected member present / by timeout
+    // the frame gate's slot -- times it opened / with every expected member present / by timeout
     std::lock_guard<std::mutex> lk(g->gate_m);
-    out->batches[7] = g->gate_opens;
-    out->entries[7] = g->gate_full;
-    out->timed[7] = g->gate_timeouts;
-    out->ms[7] = g->gate_on.load() ? 1.0 : 0.0;
+    out->batches[GK_GATE_SLOT] = g->gate_opens;
+    out->entries[GK_GATE_SLOT] = g->gate_full;
+    out->timed[GK_GATE_SLOT] = g->gate_timeouts;
+    out->ms[GK_GATE_SLOT] = g->gate_on.load() ? 1.0 : 0.0;
     if (reset) g->gate_opens = g->gate_full = g->gate_timeouts = 0;
     return XRHIP_OK;
 }

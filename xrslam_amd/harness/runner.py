@@ -39,10 +39,10 @@ class XRSLAMAmdTimes(C.Structure):
 
 
 class GroupStats(C.Structure):   # xrhip_group_stats (include/xrslam_hip.h)
-    _fields_ = [("batches", C.c_longlong * 8), ("entries", C.c_longlong * 8), ("ms", C.c_double * 8), ("timed", C.c_longlong * 8)]
+    _fields_ = [("batches", C.c_longlong * 12), ("entries", C.c_longlong * 12), ("ms", C.c_double * 12), ("timed", C.c_longlong * 12)]
 
 
-GROUP_KINDS = ("call", "upload", "preprocess", "track", "detect", "chain", "preint", "gate")   # gate: openings / all present / timeouts
+GROUP_KINDS = ("call", "upload", "preprocess", "track", "detect", "chain", "preint", "window_round", "window_trials", None, None, "gate")   # gate: openings / all present / timeouts
 
 
 class XRSLAMAmdInitReport(C.Structure):
@@ -132,7 +132,7 @@ class Group:
         st = GroupStats()
         self.lib.XRSLAMAmdGroupGetStats(self.handle, C.byref(st), 1 if reset else 0)
         return {name: {"batches": int(st.batches[i]), "requests": int(st.entries[i]), "ms": float(st.ms[i]), "timed": int(st.timed[i])}
-                for i, name in enumerate(GROUP_KINDS) if st.batches[i]}
+                for i, name in enumerate(GROUP_KINDS) if name and st.batches[i]}
 
     def close(self):
         if self.handle:
