@@ -358,8 +358,8 @@ int xrhip_ba_preintegrate_after_solve(xrhip_ba *ctx, const double *samples, cons
  * static id counters, xrslam/src/xrslam/utility/identifiable.h:23-30) allows ONE sequence per process, and BASELINE config 4 puts
  * eleven sequences on eight GPUs.  Contexts that have joined a group hand the launches of the per-frame path (frame upload, CLAHE /
  * pyramid, LK, Harris, pre-integration, the single-launch solves) to the group's submission thread, which issues ONE launch per
- * kernel for all requests pending at that moment (blockIdx.z = request); window solves and marginalisations keep the context's
- * own stream.  Results are those of the context running alone, bit for bit (same kernels, same per-request block mapping and
+ * kernel for all requests pending at that moment (blockIdx.z = request); since round 5 the rounds of a window-sized solve travel the same
+ * way (one request per trust-region round); marginalisations keep the context's own stream.  Results are those of the context running alone, bit for bit (same kernels, same per-request block mapping and
  * summation order); every entry point keeps its meaning, including the blocking ones (they wait on the context's own mailbox).
  * A context may be driven by one thread at a time as before; different contexts of a group from different threads.
  * Join right after creation, before the context's first use; leave (group = NULL) or destroy the context before the group.

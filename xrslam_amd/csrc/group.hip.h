@@ -23,8 +23,11 @@
 //   * Completion stays per context: every kernel publishes into its owner's pinned mailbox as before; the owner's thread spins on it.
 //   * Hardware queues: the group's streams are created at high priority when the runtime has two queues per priority level
 //     (GPU_MAX_HW_QUEUES=2): two queues for the batches of all members, two for the members' own work (group_api.hip).
-// Window solves and marginalisations (one frame in five) stay per-member launches on the members' own streams (without the
-// speculative linearisation, and with localize -> sub-window as two requests: ba_api.hip).
+// Round 5: a fourth queue, GQ_WINDOW (normal priority), carries the members' window rounds -- a round of refine_window is one request
+// (GK_WROUND: kb_stage + kb_prior_lambda of a solve's first round, then kw_lin_all .. kw_solve_try + the first kw_trials_wide with
+// blockIdx.z = member), a run of rejected trials another (GK_WTRIALS) -- instead of ~45 launches per keyframe on the member's own stream
+// (ba_api.hip: launch_wround_batch; XRHIP_GROUP_NO_WINDOW_BATCH=1 is the round-4 form).  Marginalisations stay per-member launches on
+// the members' own streams; the speculative linearisation stays off in a group; localize -> sub-window are two requests.
 #pragma once
 #include <hip/hip_runtime.h>
 
