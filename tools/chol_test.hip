@@ -10,6 +10,12 @@
 #include <cstdlib>
 #include <vector>
 
+#ifdef XR_TL_TIMELINE   // -DXR_TL_TIMELINE: tl_chol's phases in shader cycles as wavefront 0 sees them (see dense_lds.hip.h)
+__shared__ long long xr_tl_acc[16];
+__shared__ long long xr_tl_prev;
+#define XR_TL_CLK_RESET() do { if (threadIdx.x < 16) xr_tl_acc[threadIdx.x] = 0; __syncthreads(); if (threadIdx.x < 64) xr_tl_prev = __builtin_readcyclecounter(); } while (0)
+#define XR_TL_CLK(slot, on) do { if (on) { const long long n_ = __builtin_readcyclecounter(); xr_tl_acc[slot] += n_ - xr_tl_prev; xr_tl_prev = n_; } } while (0)
+#endif
 #include "dense_lds.hip.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -40,12 +46,12 @@ template <int NT> __global__ __launch_bounds__(NT) void k_packed(const double *s
     }
 }
 
-template <int NT> __global__ __launch_bounds__(NT) void k_tiled(const double *src, int n, double *out, double *Lout, long long *ticks, int *failed) {
+template <int NT> __global__ __launch_bounds__(NT) void k_tiled(const double *src, int n, double *out, double *Lout, long long *ticks, int *failed, long long *prof) {
     extern __shared__ double lds[];
     __shared__ double Dblk[CH_NB][CH_NB + 1];
     __shared__ int fail;
     const int T = tl_tile_rows(n + 1);
-    double *A = lds, *yv = A + tl_doubles(n + 1), *dinv = yv + 16 * T;
+    double *A = lds, *yv = A + tl_doubles(n + 1);
     const int tri = n * (n + 1) / 2;
     const long long tc0 = wall_clock64();
     tl_clear(A, n, n + 1);
@@ -70,12 +76,12 @@ template <int NT> __global__ __launch_bounds__(NT) void k_tiled(const double *sr
     }
     __syncthreads();
     const long long t0 = wall_clock64();
-    const bool ok = tl_chol(A, n, n + 1, Dblk, dinv, &fail);
+    const bool ok = tl_chol(A, n, n + 1, &Dblk[0][0], &fail, prof);   // prof: phase timers, -DXRHIP_KPROF builds only
     __syncthreads();
     const long long t1 = wall_clock64();
     for (int i = threadIdx.x; i < 16 * T; i += NT) yv[i] = i < n ? A[tl_idx(n, i)] : 0.0;
     __syncthreads();
-    if (ok) tl_trsv_t(A, n, dinv, yv);
+    if (ok) tl_trsv_t(A, n, yv);
     __syncthreads();
     const long long t2 = wall_clock64();
     for (int i = threadIdx.x; i < n; i += NT) out[i] = yv[i];
@@ -83,13 +89,18 @@ template <int NT> __global__ __launch_bounds__(NT) void k_tiled(const double *sr
         int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
         while (i * (i + 1) / 2 > e) --i;
         while ((i + 1) * (i + 2) / 2 <= e) ++i;
-        Lout[e] = A[tl_idx(i, e - i * (i + 1) / 2)];
+        const int jj = e - i * (i + 1) / 2;
+        // below the diagonal tiles: L; inside a diagonal tile: the block's inverse, kept transposed ((r, c) holds Linv[c][r])
+        Lout[e] = ((i >> 4) == (jj >> 4)) ? A[tl_tile(i >> 4, i >> 4) + (i & 15) * TL_LD + (jj & 15)] : A[tl_idx(i, jj)];
     }
     if (threadIdx.x == 0) {
         ticks[0] = t1 - t0;
         ticks[1] = t2 - t1;
         ticks[2] = t0 - tc0;
         *failed = ok ? 0 : 1;
+#ifdef XR_TL_TIMELINE
+        for (int i = 0; i < 10; ++i) prof[i] = xr_tl_acc[i];
+#endif
     }
 }
 
@@ -147,7 +158,9 @@ template <int NT> static void run(int n) {
     CK(hipMalloc(&d_f, sizeof(int)));
     CK(hipMemcpy(d_src, src.data(), sizeof(double) * (tri + n), hipMemcpyHostToDevice));
     std::vector<double> xp(n), xt(n), Lt(tri);
-    long long tp[4] = {0}, tt[4] = {0};
+    long long tp[4] = {0}, tt[4] = {0}, hp[16] = {0};
+    long long *d_p;
+    CK(hipMalloc(&d_p, sizeof(hp)));
     int fp = 0, ft = 0;
     const size_t lds_p = sizeof(double) * (size_t)((n + 1) * (n + 2) / 2 + 16);
     const size_t lds_t = sizeof(double) * (size_t)(tl_doubles(n + 1) + 32 * tl_tile_rows(n + 1));
@@ -159,12 +172,14 @@ template <int NT> static void run(int n) {
         CK(hipMemcpy(xp.data(), d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
         CK(hipMemcpy(tp, d_t, sizeof(long long) * 4, hipMemcpyDeviceToHost));
         CK(hipMemcpy(&fp, d_f, sizeof(int), hipMemcpyDeviceToHost));
-        hipLaunchKernelGGL(k_tiled<NT>, dim3(1), dim3(NT), lds_t, 0, d_src, n, d_out, d_L, d_t, d_f);
+        CK(hipMemset(d_p, 0, sizeof(hp)));
+        hipLaunchKernelGGL(k_tiled<NT>, dim3(1), dim3(NT), lds_t, 0, d_src, n, d_out, d_L, d_t, d_f, d_p);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(xt.data(), d_out, sizeof(double) * n, hipMemcpyDeviceToHost));
         CK(hipMemcpy(Lt.data(), d_L, sizeof(double) * tri, hipMemcpyDeviceToHost));
         CK(hipMemcpy(tt, d_t, sizeof(long long) * 4, hipMemcpyDeviceToHost));
         CK(hipMemcpy(&ft, d_f, sizeof(int), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hp, d_p, sizeof(hp), hipMemcpyDeviceToHost));
     }
     double xmax = 0, ep = 0, et = 0, el = 0, lmax = 0, ept = 0;
     for (int i = 0; i < n; ++i) xmax = fmax(xmax, fabs(x[i]));
@@ -173,19 +188,146 @@ template <int NT> static void run(int n) {
         et = fmax(et, fabs(xt[i] - x[i]));
         ept = fmax(ept, fabs(xt[i] - xp[i]));
     }
+    // the tiled form keeps the inverse of every 16x16 diagonal block of L in that block's place: same for the reference
+    std::vector<double> Lr(L);
+    for (int b0 = 0; b0 < n; b0 += 16) {
+        const int nbk = n - b0 < 16 ? n - b0 : 16;
+        for (int m = 0; m < nbk; ++m)
+            for (int r = 0; r < nbk; ++r) {
+                double sacc = (r == m) ? 1.0 : 0.0;
+                for (int k = m; k < r; ++k) sacc -= L[(b0 + r) * n + b0 + k] * Lr[(b0 + k) * n + b0 + m];
+                Lr[(b0 + r) * n + b0 + m] = (r < m) ? 0.0 : sacc / L[(b0 + r) * n + b0 + r];
+            }
+    }
     for (int i = 0; i < n; ++i)
         for (int j = 0; j <= i; ++j) {
-            lmax = fmax(lmax, fabs(L[i * n + j]));
-            el = fmax(el, fabs(Lt[i * (i + 1) / 2 + j] - L[i * n + j]));
+            lmax = fmax(lmax, fabs(Lr[i * n + j]));
+            el = fmax(el, fabs(Lt[i * (i + 1) / 2 + j] - Lr[i * n + j]));
         }
     printf("{\"threads\": %d, \"n\": %d, \"packed_fail\": %d, \"tiled_fail\": %d, \"x_err_packed\": %.2e, \"x_err_tiled\": %.2e, \"tiled_vs_packed\": %.2e, "
            "\"L_err_tiled\": %.2e, \"packed_us\": [%.2f, %.2f], \"tiled_us\": [%.2f, %.2f], \"tiled_copy_in_us\": %.2f}\n",
            NT, n, fp, ft, ep / xmax, et / xmax, ept / xmax, el / lmax, tp[0] * 0.01, tp[1] * 0.01, tt[0] * 0.01, tt[1] * 0.01, tt[2] * 0.01);
-    hipFree(d_src); hipFree(d_out); hipFree(d_L); hipFree(d_t); hipFree(d_f);
+#ifdef XRHIP_KPROF
+    // tl_chol's phases as thread 0 sees them: first block | panels | trailing update + next block (of which: load, factor, write-back)
+    printf("{\"kprof_tiled_us\": true, \"threads\": %d, \"n\": %d, \"first_block\": %.2f, \"panels\": %.2f, \"trailing_and_next_block\": %.2f, \"next_block_load\": %.2f, "
+           "\"next_block_factor\": %.2f, \"next_block_store\": %.2f}\n", NT, n, hp[0] * 0.01, hp[1] * 0.01, hp[2] * 0.01, hp[4] * 0.01, hp[5] * 0.01, hp[6] * 0.01);
+#endif
+#ifdef XR_TL_TIMELINE
+    printf("{\"tl_chol_wave0_cycles\": true, \"threads\": %d, \"n\": %d, \"first_block\": %lld, \"barrier_a\": %lld, \"panel\": %lld, \"barrier_b\": %lld, \"own_trailing_tile\": %lld, "
+           "\"block_load\": %lld, \"block_factor\": %lld, \"block_store\": %lld, \"barrier_c\": %lld, \"others_trailing_as_seen\": %lld}\n", NT, n, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], hp[8], hp[9]);
+#endif
+    CK(hipFree(d_p));
+    CK(hipFree(d_src)); CK(hipFree(d_out)); CK(hipFree(d_L)); CK(hipFree(d_t)); CK(hipFree(d_f));
+}
+
+
+// ---- the 16x16 diagonal block alone (tl_diag_wave): time per call and the block's inverse against a host Cholesky.
+// src: 16x16 symmetric block, row-major; nb pivots (rows >= nb: identity padding, as tl_clear leaves them).
+__global__ __launch_bounds__(64) void k_diag(const double *src, int nb, int reps, long long *ticks, double *Iout, int *failed) {
+    __shared__ double tile[TL_TILE], keep[TL_TILE], ident[TL_TILE];
+    const int lane = threadIdx.x;
+    for (int e = lane; e < 256; e += 64) {
+        const int r = e >> 4, c = e & 15;
+        keep[c * TL_LD + r] = (r < nb && c < nb) ? src[r * 16 + c] : (r == c ? 1.0 : 0.0);
+        ident[c * TL_LD + r] = r == c ? 1.0 : 0.0;
+    }
+    for (int e = lane; e < TL_TILE; e += 64) tile[e] = 0.0;
+    __syncthreads();
+    bool ok = true;
+    long long t0 = wall_clock64();
+    for (int rep = 0; rep < reps; ++rep) {
+        for (int e = lane; e < 256; e += 64) tile[(e & 15) * TL_LD + (e >> 4)] = keep[(e & 15) * TL_LD + (e >> 4)];
+        wave_sync();
+        ok = tl_diag_wave(tile, nb, ident, lane) && ok;
+        wave_sync();
+    }
+    long long t1 = wall_clock64();
+    for (int rep = 0; rep < reps; ++rep) {   // the copy alone
+        for (int e = lane; e < 256; e += 64) tile[(e & 15) * TL_LD + (e >> 4)] = keep[(e & 15) * TL_LD + (e >> 4)] + (double)rep * 0.0;
+        wave_sync();
+    }
+    long long t2 = wall_clock64();
+    // once more for the outputs (the timing loop above left the copy in `tile`)
+    ok = tl_diag_wave(tile, nb, ident, lane) && ok;
+    wave_sync();
+    for (int e = lane; e < 256; e += 64) {
+        const int r = e >> 4, c = e & 15;
+        Iout[e] = tile[r * TL_LD + c];   // Linv[r][c] sits at (c, r)
+    }
+    if (lane == 0) {
+        ticks[0] = t1 - t0;
+        ticks[1] = t2 - t1;
+        *failed = ok ? 0 : 1;
+    }
+}
+
+static void run_diag(int nb) {
+    double S[256], L[256] = {0}, Li[256] = {0};
+    {
+        double G[256];
+        for (auto &g : G) g = urand();
+        for (int i = 0; i < 16; ++i)
+            for (int j = 0; j < 16; ++j) {
+                double s = (i == j) ? 0.8 : 0.0;
+                for (int k = 0; k < 16; ++k) s += G[i * 16 + k] * G[j * 16 + k];
+                S[i * 16 + j] = s;
+            }
+        double dg[16];
+        for (int i = 0; i < 16; ++i) dg[i] = 1.0 / sqrt(S[i * 16 + i]);
+        for (int i = 0; i < 16; ++i)
+            for (int j = 0; j < 16; ++j) S[i * 16 + j] *= dg[i] * dg[j];
+    }
+    // host: Cholesky of the leading nb x nb block, identity below; its inverse
+    for (int j = 0; j < 16; ++j) {
+        if (j >= nb) { L[j * 16 + j] = 1.0; continue; }
+        double d = S[j * 16 + j];
+        for (int k = 0; k < j; ++k) d -= L[j * 16 + k] * L[j * 16 + k];
+        L[j * 16 + j] = sqrt(d);
+        for (int i = j + 1; i < nb; ++i) {
+            double s = S[i * 16 + j];
+            for (int k = 0; k < j; ++k) s -= L[i * 16 + k] * L[j * 16 + k];
+            L[i * 16 + j] = s / L[j * 16 + j];
+        }
+    }
+    for (int m = 0; m < 16; ++m)
+        for (int r = 0; r < 16; ++r) {
+            double s = (r == m) ? 1.0 : 0.0;
+            for (int k = 0; k < r; ++k) s -= L[r * 16 + k] * Li[k * 16 + m];
+            Li[r * 16 + m] = s / L[r * 16 + r];
+        }
+    double *d_src, *d_I;
+    long long *d_t;
+    int *d_f;
+    CK(hipMalloc(&d_src, sizeof(S)));
+    CK(hipMalloc(&d_I, sizeof(S)));
+    CK(hipMalloc(&d_t, sizeof(long long) * 16));
+    CK(hipMalloc(&d_f, sizeof(int)));
+    CK(hipMemcpy(d_src, S, sizeof(S), hipMemcpyHostToDevice));
+    const int reps = 200;
+    long long t[16] = {0};
+    double gI[256];
+    int f = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(k_diag, dim3(1), dim3(64), 0, 0, d_src, nb, reps, d_t, d_I, d_f);
+        CK(hipDeviceSynchronize());
+    }
+    CK(hipMemcpy(t, d_t, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gI, d_I, sizeof(S), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&f, d_f, sizeof(int), hipMemcpyDeviceToHost));
+    double eI = 0, mI = 0;
+    for (int i = 0; i < nb; ++i)   // the pivot rows' inverse (rows >= nb of the tile keep their own entries)
+        for (int j = 0; j < nb; ++j) {
+            eI = fmax(eI, fabs(gI[i * 16 + j] - Li[i * 16 + j]));
+            mI = fmax(mI, fabs(Li[i * 16 + j]));
+        }
+    printf("{\"diag_block\": true, \"nb\": %d, \"fail\": %d, \"inv_err_rel\": %.2e, \"us_per_block\": %.3f, \"copy_us\": %.3f}\n", nb, f, eI / mI,
+           (t[0] - t[1]) * 0.01 / reps, t[1] * 0.01 / reps);
+    CK(hipFree(d_src)); CK(hipFree(d_I)); CK(hipFree(d_t)); CK(hipFree(d_f));
 }
 
 int main() {
     srand(7);
+    for (int nb : {16, 15, 9, 1}) run_diag(nb);
     const int sizes[] = {1, 5, 15, 16, 17, 30, 31, 45, 60, 90, 150, 160, 165, 175};
     for (int n : sizes) {
         if (n <= 90) run<256>(n);

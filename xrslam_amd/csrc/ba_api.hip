@@ -675,7 +675,7 @@ static void launch_linearize(xrhip_ba *c, const BaDims &d, const BaPtrs &p, cons
 static int solve_lds(const BaDims &d, size_t limit, size_t *bytes, int *use_lds) {
     static const bool no_tiled = std::getenv("XRHIP_NO_TILED") != nullptr;   // development switch (A/B, parity)
     const size_t tri = (size_t)(d.na + 1) * (d.na + 2) / 2;
-    const size_t tiled = (size_t)tl_doubles(d.na + 1) + 32 * (size_t)tl_tile_rows(d.na + 1);   // tiles + L^-1 rhs + inverse diagonals
+    const size_t tiled = (size_t)tl_doubles(d.na + 1) + 16 * (size_t)tl_tile_rows(d.na + 1);   // tiles + L^-1 rhs
     const size_t aux = (size_t)d.PF;
     size_t lds = sizeof(double) * std::max(tiled, aux);
     *use_lds = 2;   // tiled layout (dense_lds.hip.h, round 3)

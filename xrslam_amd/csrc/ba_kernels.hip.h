@@ -1241,7 +1241,7 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
     // (column c = lane & 15, row rr + 4 pass): sixteen lanes read 128 contiguous bytes of one row.
     auto factor_stage_tiled = [&](double *A) __attribute__((always_inline)) -> bool {
         const int nrows = na + 1, T = tl_tile_rows(nrows);
-        double *yv = A + tl_doubles(nrows), *dinv = yv + 16 * T;
+        double *yv = A + tl_doubles(nrows);
         const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6, cc = lane & 15, rr = lane >> 4;
         const int n_tiles = T * (T + 1) / 2;
         const double *src = p.Sred;
@@ -1285,9 +1285,9 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
         __syncthreads();
         KPROF(1);
 #ifdef XRHIP_KPROF
-        const bool ok = tl_chol(A, na, nrows, Dblk, dinv, &fail, p.ctl->prof + 24);
+        const bool ok = tl_chol(A, na, nrows, &Dblk[0][0], &fail, p.ctl->prof + 24);
 #else
-        const bool ok = tl_chol(A, na, nrows, Dblk, dinv, &fail);
+        const bool ok = tl_chol(A, na, nrows, &Dblk[0][0], &fail);
 #endif
         KPROF(2);
         if (!ok) {
@@ -1297,7 +1297,7 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
         for (int i = tid; i < 16 * T; i += nt) yv[i] = i < na ? A[tl_idx(na, i)] : 0.0;   // L^-1 rhs; zero beyond n (tl_trsv_t)
         __syncthreads();
         KPROF(3);
-        tl_trsv_t(A, na, dinv, yv);
+        tl_trsv_t(A, na, yv);
         KPROF(4);
         for (int a = tid; a < n; a += nt) {
             p.gn[a] = 0.0;

@@ -48,7 +48,88 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
     } while (0)
 #endif
 
+// ---- The 16x16 diagonal block (round 6).
+//
+// What a single wavefront's double-precision code costs on gfx950 (tools/issue.hip, profiles/r06_issue.json): ~9 cycles per f64
+// operation WHETHER OR NOT it depends on the one before (the "32-36 cycles of dependent latency" of rounds 2-5 was the loop branch
+// of tools/latency.hip's un-unrolled chains), ~6-10 per 64-bit v_readlane broadcast, 20 per v_rcp_f64 / v_rsq_f64, 80 per
+// v_mfma_f64_16x16x4 (dependent or not), ~80 per LDS round trip.  The block is therefore bound by the NUMBER of operations its one
+// wavefront issues, and rounds 1-5's column-by-column form issued ~1000 of them: per pivot a reciprocal square root with two coupled
+// Newton steps, a column scaling, and per later column a broadcast, a multiply and a subtract.
+//
+// Now:
+//   * 2x2 block pivots.  For the pivot block [a b; b d] of columns (c, c+1) the Schur update of every later column k is
+//         X[k] += xk0 U + xk1 V,   U = -(d x0 - b x1) / det,   V = -(a x1 - b x0) / det,   det = a d - b^2
+//     (x0, x1: this lane's entries in the two pivot columns; xk0, xk1: row k's, broadcast): two fused operations and two
+//     broadcasts per column and PAIR of pivots, one reciprocal (v_rcp_f64 + a cubic correction) per pair, no square root.
+//   * The Cholesky factor's columns are the unscaled ones times a reciprocal square root: L[i][c] = x0 / sqrt(a),
+//     L[i][c+1] = v / sqrt(a det), v = a x1 - b x0.  The sixteen arguments (a in lane c -- it is that lane's own x0 --, a det in
+//     lane c+1 -- a times that lane's own v) are collected in ONE register across the lanes and go through v_rsq_f64 + correction
+//     once, at the end; the positivity test of all pivots is one comparison of that register.
+//   * Rows that only ride along (unit rows: they come out as the columns of L^-1; a right-hand side; rows of the panel below) sit
+//     in the other lanes and get the same column operations for free.
+// Same mathematics as the column-by-column form, other roundings (the 2x2 inverse is explicit): factors agree to a few ulp
+// (tools/chol_test.hip prints both against a host Cholesky).
+
+// 1 / x: v_rcp_f64 (24 bits, profiles/r06_issue.json) and the cubic step r0 (1 + e + e^2), e = 1 - x r0: 1.1e-16 relative
+__device__ __forceinline__ double rcp_cubic(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r0, 1.0);
+    const double p = fma(e, e, e);
+    return fma(r0, p, r0);
+}
+// 1 / sqrt(x): v_rsq_f64 (24 bits) and r0 (1 + e/2 + 3 e^2 / 8), e = 1 - x r0^2: 1.4e-16 relative
+__device__ __forceinline__ double rsqrt_cubic(double x) {
+    const double r0 = __builtin_amdgcn_rsq(x);
+    const double xr = x * r0;
+    const double e = fma(-xr, r0, 1.0);
+    const double p = fma(0.375 * e, e, 0.5 * e);
+    return fma(r0, p, r0);
+}
+
+// One wavefront.  X[k]: entry k of this lane's row.  Lanes 0-15 hold rows 0-15 of the block (lower triangle; what they hold above
+// the diagonal is never read by another lane and may be anything finite), every other lane a row that rides along.  Columns >= nb
+// are not pivots (padding, or a right-hand-side row that sits among the block's rows): they are left as they are.  On return X holds
+// the lane's row of L (block rows) or row * L^-T (riding rows).  Returns false (wave-uniform) if a pivot block is not positive
+// definite; X is then meaningless.
+__device__ __forceinline__ bool diag16_pivot_pairs(double (&X)[CH_NB], int nb, int lane) {
+    const int l16 = lane & 15;
+    double S = 1.0;   // lane c (< 16): the number whose reciprocal square root scales column c
+#pragma unroll
+    for (int c = 0; c < CH_NB; c += 2) {
+        const bool pv = c < nb, pw = c + 1 < nb;   // is column c / c + 1 a pivot
+        double a = lane_bcast(X[c], c), b = lane_bcast(X[c], c + 1), d = lane_bcast(X[c + 1], c + 1);
+        a = pv ? a : 1.0;
+        b = pw ? b : 0.0;
+        d = pw ? d : 1.0;
+        const double x0 = X[c], x1 = X[c + 1];
+        const double u = fma(d, x0, -(b * x1)), v = fma(a, x1, -(b * x0));   // in lane c + 1: v = a d - b^2 = det
+        if (c + 2 < CH_NB) {
+            const double det = fma(a, d, -(b * b));
+            const double rd = rcp_cubic(det);
+            const double U = -(u * rd), V = -(v * rd);
+#pragma unroll
+            for (int k = c + 2; k < CH_NB; ++k) X[k] = fma(lane_bcast(x1, k), V, fma(lane_bcast(x0, k), U, X[k]));
+        }
+        X[c + 1] = pw ? v : x1;
+        S = (l16 == c) ? (pv ? x0 : 1.0) : S;
+        S = (l16 == c + 1) ? (pw ? a * v : 1.0) : S;
+    }
+    // every pivot a > 0 and det > 0 (lane c: a; lane c + 1: a det) -- NaN and infinity fail
+    const unsigned long long bad = __ballot(!(S > 0.0) || !isfinite(S));
+    const double rs = rsqrt_cubic(S);
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) X[c] *= lane_bcast(rs, c);
+    return (bad & 0xffffull) == 0;
+}
+
 typedef double chol_d4 __attribute__((ext_vector_type(4)));
+
+// Development aid (tools/chol_test.hip -DXR_TL_TIMELINE): shader-clock phase sums of tl_chol as wavefront 0 sees them.
+#ifndef XR_TL_CLK
+#define XR_TL_CLK(slot, on)
+#define XR_TL_CLK_RESET()
+#endif
 
 // Wavefront 0 only.  Factors the nb x nb diagonal block at (j0, j0) of the packed matrix A in place (A gets L)
 // and leaves L^-1 (lower triangular, zero above the diagonal, identity-padded to 16x16) in Dinv.
@@ -75,86 +156,37 @@ __device__ __forceinline__ bool chol_diag_wave_t(double *A, int j0, int nb, doub
 #ifdef XRHIP_KPROF
     long long t_dg = wall_clock64();
 #endif
-    double x[CH_NB];   // row `lane` of the block; rows >= nb are identity rows
+    // lanes 0-15: row `lane` of the block (rows >= nb are identity rows); riding rows: the right-hand-side segment in lane 16
+    // (WITH_RHS) or the unit rows in lanes 16-31, which come out as the columns of L^-1 (X[r] = Linv[r][lane - 16])
+    const int l16 = lane & 15;
+    const bool is_row = lane < CH_NB, is_ride = WITH_RHS ? lane == CH_NB : (lane >= CH_NB && lane < 2 * CH_NB);
+    double X[CH_NB];
 #pragma unroll
-    for (int k = 0; k < CH_NB; ++k) x[k] = (lane < nb && k <= lane) ? A[tri_idx(j0 + lane, j0 + k)] : ((k == lane) ? 1.0 : 0.0);
-    DGPROF(4);   // block load
-    double dinv[CH_NB];
-    double xi[CH_NB];   // column `lane` of L^-1: xi[r] = Linv[r][lane]
-    // acc[r] = delta(r, lane) - sum_{k < r} L[r][k] Linv[k][lane], built up column by column (see below)
-    double acc[CH_NB];
-#pragma unroll
-    for (int r = 0; r < CH_NB; ++r) acc[r] = (r == lane) ? 1.0 : 0.0;
-    bool ok = true;
-#pragma unroll
-    for (int c = 0; c < CH_NB; ++c) {
-        double dcc = lane_bcast(x[c], c);
-        if (!(dcc > 0.0) || !isfinite(dcc)) {
-            ok = false;
-            dcc = 1.0;
-        }
-        // sqrt(d) and 1/sqrt(d) together from the hardware reciprocal square root (v_rsq_f64, ~27 bits) and two coupled
-        // Newton steps -- the library sqrt followed by a division is ~3x as long, and this sits on the serial chain of
-        // every panel.  Pivots here are O(1) after Jacobi scaling (1e30 at most, in the marginalisation): no denormals.
-        double dd, hh;
-        {
-            const double r0 = __builtin_amdgcn_rsq(dcc);
-            dd = dcc * r0;
-            hh = 0.5 * r0;
-            double e = fma(-hh, dd, 0.5);
-            dd = fma(dd, e, dd);
-            hh = fma(hh, e, hh);
-            e = fma(-hh, dd, 0.5);
-            dd = fma(dd, e, dd);
-            hh = fma(hh, e, hh);
-            const double res = fma(-dd, dd, dcc);
-            dd = fma(res, hh, dd);
-        }
-        dinv[c] = hh + hh;
-        x[c] = (lane == c) ? dd : x[c] * dinv[c];
-        // Row c of L^-1 is complete once the columns before c have been through (forward substitution, terms added in the
-        // order k = 0, 1, ...).  The inverse is built RIGHT-looking, beside the factorisation: the broadcast L[k][c] that
-        // updates column k of the block also carries row c of the inverse into acc[k].  (Left-looking -- row c summed up
-        // when column c is reached -- reads the same broadcasts a second time, up to fifteen columns later: the compiler
-        // keeps all 120 of them alive in scalar registers and spills them through v_writelane.)  Same products, same order of
-        // additions: the same bits.
-        if (!WITH_RHS) xi[c] = (c < lane) ? 0.0 : acc[c] * dinv[c];
-#pragma unroll
-        for (int k = c + 1; k < CH_NB; ++k) {
-            const double lkc = lane_bcast(x[c], k);   // L[k][c]
-            x[k] -= x[c] * lkc;                        // meaningful for lane >= k (lower triangle)
-            if (!WITH_RHS) acc[k] -= lkc * xi[c];      // L[k][c] * Linv[c][lane]
-        }
+    for (int k = 0; k < CH_NB; ++k) {
+        double v = 0.0;
+        if (is_row) v = (lane < nb && k <= lane) ? A[tri_idx(j0 + lane, j0 + k)] : ((k == lane) ? 1.0 : 0.0);
+        else if (WITH_RHS) v = (is_ride && k < nb) ? rhs[j0 + k] : 0.0;
+        else v = (is_ride && k == l16) ? 1.0 : 0.0;
+        X[k] = v;
     }
-    DGPROF(5);   // factorisation (+ inverse)
-    if (WITH_RHS) {
-        double r = (lane < nb) ? rhs[j0 + lane] : 0.0;
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c) {
-            const double xc = lane_bcast(r, c) * dinv[c];
-            if (lane == c) r = xc;
-            else if (lane > c) r -= x[c] * xc;   // L[lane][c]
-        }
+    DGPROF(4);   // block load
+    const bool ok = diag16_pivot_pairs(X, nb, lane);
+    DGPROF(5);   // factorisation (+ inverse / substitution, riding)
+    if (is_row) {
         if (lane < nb) {
-            rhs[j0 + lane] = r;
 #pragma unroll
             for (int k = 0; k < CH_NB; ++k)
-                if (k <= lane) A[tri_idx(j0 + lane, j0 + k)] = x[k];
+                if (k <= lane) A[tri_idx(j0 + lane, j0 + k)] = X[k];
         }
-        return ok;
-    }
-    // Every lane stores its column of the inverse -- lanes 16..63 into the padding column of Dinv.  Under `if (lane < 16)` the
-    // compiler sinks the whole inverse into that branch: it then runs AFTER the factorisation instead of beside it, from
-    // broadcasts it has kept in VGPR lanes (v_writelane / v_readlane, a third of this routine's instruction stream).
-    {
-        const int col = lane < CH_NB ? lane : CH_NB;
+    } else if (is_ride) {
 #pragma unroll
-        for (int r = 0; r < CH_NB; ++r) Dinv[r][col] = xi[r];
-    }
-    if (lane < CH_NB) {
-#pragma unroll
-        for (int k = 0; k < CH_NB; ++k)
-            if (lane < nb && k <= lane) A[tri_idx(j0 + lane, j0 + k)] = x[k];
+        for (int k = 0; k < CH_NB; ++k) {
+            if (WITH_RHS) {
+                if (k < nb) rhs[j0 + k] = X[k];
+            } else {
+                Dinv[k][l16] = X[k];
+            }
+        }
     }
     DGPROF(6);   // write-back
     return ok;
@@ -265,14 +297,16 @@ __device__ __forceinline__ bool chol_blocked(double *A, int n, int nrows, double
             __threadfence_block();   // other lanes of this wavefront read those entries next (A may be in global memory)
             if (!chol_diag_wave(A, jb, nb1, Dinv, lane, lwr1 ? rhs : nullptr, prof) && lane == 0) *s_fail = 1;
         } else {
+            // dealt round-robin with a counter that wraps (`t % workers` is a software division per tile visited, and every
+            // wavefront visits all of them)
             const int workers = look ? nw - 1 : nw, me = look ? wave - 1 : wave;
-            int t = 0;
+            int turn = 0;
             for (int ti = 0; ti < T; ++ti)
                 for (int tj = 0; tj <= ti; ++tj) {
                     if (jb + 16 * tj >= n) continue;   // rhs rows have no columns of their own
                     if (look && tj == 0 && (ti == 0 || (lwr1 && ti == rhs_ti))) continue;   // wavefront 0's tiles
-                    if (t++ % workers != me) continue;
-                    chol_trailing_tile(A, n, nrows, j0, nb, jb, ti, tj, r16, q);
+                    if (turn == me) chol_trailing_tile(A, n, nrows, j0, nb, jb, ti, tj, r16, q);
+                    turn = (turn + 1 == workers) ? 0 : turn + 1;
                 }
         }
         __syncthreads();
@@ -419,25 +453,28 @@ __device__ __forceinline__ void tri_inverse_blocked(const double *L, double *X, 
 }
 
 // =====================================================================================================================
-// Tiled variant (round 3) -- for systems that live in LDS.
+// Tiled variant (round 3; round 6: block inverses kept IN the diagonal tiles) -- for systems that live in LDS.
 //
 // Why a second layout.  In the packed triangle the 16x16 blocks the matrix cores consume have a different row stride in every
 // row (bank conflicts on every operand load), the diagonal block's load and write-back are sixteen predicated accesses each, and
-// the back-substitution has to re-solve every diagonal block as a 16-step dependent chain because the inverse of a block is
-// gone once the next panel has used it.  In-kernel timers of round 2 (profiles/r02_kprof_v39.md): of a panel step's 5.8 us the
-// serial diagonal block was 3.9 (0.5 load + 2.0 factor/invert + 1.4 write-back), the substitution another 1.6 us per block.
+// the back-substitution has to re-solve every diagonal block as a 16-step chain because the inverse of a block is gone once the
+// next panel has used it.
 //
 // Layout: the lower triangle in 16x16 tiles, tile (ti, tj), tj <= ti, at (ti (ti + 1) / 2 + tj) * TL_TILE doubles; inside a tile
-// element (r, c) at c * TL_LD + r with TL_LD = 17: "row = lane" reads (the matrix-core operands, the diagonal block) and "column =
-// lane" reads (the transposed accesses of the back-substitution) are both free of bank conflicts.  Rows >= nrows are zero, the
-// padding diagonal is 1: nothing in the loops is predicated.  A right-hand side rides along as row n (nrows = n + 1): the
-// factorisation leaves L^-1 rhs there.  The strictly upper triangle of a DIAGONAL tile -- unused by L -- keeps the transposed
-// strictly lower triangle of that block's inverse, its diagonal goes to dinv[tile][16]: the back-substitution is then one
-// 16x16 matrix-vector product per block instead of a 16-step chain.
+// element (r, c) at c * TL_LD + r with TL_LD = 17: "row = lane" accesses (the diagonal block's rows, the matrix-core operands)
+// and "column = lane" accesses (the transposed reads of the back-substitution) are both free of bank conflicts.  Rows >= nrows are
+// zero, the padding diagonal is 1: nothing in the loops is predicated.  A right-hand side rides along as row n (nrows = n + 1): the
+// factorisation leaves L^-1 rhs there.
 //
-// Diagonal block (tl_diag_wave): lanes 0-15 hold the rows of the block, lanes 16-31 the columns of the inverse under
-// construction, in the SAME registers: the rank-1 update of column c is one FMA per later column for both (the inverse was a second
-// FMA on the same lanes before).  Same products and sums as chol_diag_wave_t, in the same order: the same bits.
+// What the factorisation leaves behind: the tiles BELOW the diagonal hold L; a DIAGONAL tile holds the transpose of its block's
+// inverse, element (r, c) = Linv[c][r] (upper triangular, exact zeros below the diagonal) -- nobody reads the diagonal blocks of L
+// again (the right-hand side was substituted on the way), while the inverse is what the panel product P Linv^T and the
+// back-substitution (one 16x16 matrix-vector product per block instead of a 16-step chain) consume.  Rows of the last diagonal
+// tile that are not pivots (the right-hand-side row when n is not a multiple of 16, padding) keep their own entries.
+//
+// Diagonal block (tl_diag_wave): lanes 0-15 hold the rows of the block, lanes 16-31 unit rows that come out as the columns of the
+// inverse (diag16_pivot_pairs); every lane loads X[k] from base + k TL_LD and stores it there again, only the base differs per lane
+// group (the tile / an identity tile), so load and write-back are sixteen unpredicated LDS instructions each.
 constexpr int TL_LD = 17, TL_TILE = 16 * TL_LD;
 __host__ __device__ __forceinline__ int tl_tile_rows(int nrows) { return (nrows + 15) >> 4; }
 __host__ __device__ __forceinline__ int tl_doubles(int nrows) {
@@ -455,105 +492,88 @@ __device__ __forceinline__ void tl_clear(double *A, int n, int nrows) {
     for (int i = n + threadIdx.x; i < 16 * T; i += blockDim.x) A[tl_idx(i, i)] = 1.0;
 }
 
-// Wavefront 0.  Factors the diagonal tile `tile` (in place: L in the lower triangle), leaves the block's inverse in Dinv (for the
-// panel product) and, transposed, in the tile's upper triangle + dinv16 (for the back-substitution).  nb: rows of the block that are
-// matrix rows; rows nb.. (a right-hand-side row, padding) take part in the column operations but are never pivots.
-__device__ __forceinline__ bool tl_diag_wave(double *tile, int nb, double (*Dinv)[CH_NB + 1], double *dinv16, int lane,
-                                             long long *dprof = nullptr) {
+// One wavefront.  Factors the diagonal tile `tile` and replaces it by the transposed inverse of its factor (see above).  ident: an
+// identity tile (element (r, c) at c * TL_LD + r) in LDS.  nb: rows of the block that are pivots; rows nb.. (a right-hand-side row,
+// padding) take part in the column operations, are never pivots and are written back as rows.
+__device__ __forceinline__ bool tl_diag_wave(double *tile, int nb, const double *ident, int lane, long long *dprof = nullptr) {
 #ifdef XRHIP_KPROF
     long long t_dg = wall_clock64();
 #endif
     const int l16 = lane & 15;
-    const bool is_row = lane < 16, is_inv = lane >= 16 && lane < 32;
-    // lanes 0-15: X[k] = row l16 of the block (lower triangle); lanes 16-31: X[k] = delta(k, l16), the running forward substitution
-    // of unit vector l16 (column l16 of the inverse once divided through)
+    const double *src = (lane < CH_NB ? tile : ident) + l16;
     double X[CH_NB];
 #pragma unroll
-    for (int k = 0; k < CH_NB; ++k) {
-        const double v = tile[k * TL_LD + l16];
-        X[k] = is_row ? (k <= l16 ? v : 0.0) : ((k == l16) ? 1.0 : 0.0);
-    }
+    for (int k = 0; k < CH_NB; ++k) X[k] = src[k * TL_LD];
     DGPROF(4);   // block load
-    bool ok = true;
-#pragma unroll
-    for (int c = 0; c < CH_NB; ++c) {
-        double dcc = lane_bcast(X[c], c);
-        if (c >= nb) dcc = 1.0;   // not a pivot: the row only rides along
-        if (!(dcc > 0.0) || !isfinite(dcc)) {
-            ok = false;
-            dcc = 1.0;
-        }
-        double dd, hh;
-        {   // sqrt(d) and 1/sqrt(d): v_rsq_f64 + two coupled Newton steps (see chol_diag_wave_t)
-            const double r0 = __builtin_amdgcn_rsq(dcc);
-            dd = dcc * r0;
-            hh = 0.5 * r0;
-            double e = fma(-hh, dd, 0.5);
-            dd = fma(dd, e, dd);
-            hh = fma(hh, e, hh);
-            e = fma(-hh, dd, 0.5);
-            dd = fma(dd, e, dd);
-            hh = fma(hh, e, hh);
-            const double res = fma(-dd, dd, dcc);
-            dd = fma(res, hh, dd);
-        }
-        const double dinv = hh + hh;
-        // row lanes: L[l][c] = x / d (the pivot row itself: d); inverse lanes: Linv[c][m] = acc / d
-        X[c] = (lane == c) ? dd : X[c] * dinv;
-#pragma unroll
-        for (int k = c + 1; k < CH_NB; ++k) {
-            const double lkc = lane_bcast(X[c], k);   // L[k][c] (held by row lane k)
-            X[k] -= X[c] * lkc;                        // rows: A[l][k] -= L[l][c] L[k][c];  inverse: acc[k] -= Linv[c][m] L[k][c]
-        }
-    }
+    XR_TL_CLK(5, true);
+    const bool ok = diag16_pivot_pairs(X, nb, lane);
     DGPROF(5);   // factorisation + inverse
-    // write-back.  Row lane l: L[l][k], k <= l, to (l, k).  Inverse lane m (column m of the inverse, X[r] = Linv[r][m], r >= m): Dinv[r][m]
-    // for the panel product; transposed into the strictly upper triangle, (m, r) for r > m; the diagonal to dinv16.
-    double *dummy = &Dinv[0][CH_NB];   // padding column: a harmless target for lanes that have nothing to store
+    XR_TL_CLK(6, true);
+    // row r of the tile: for a pivot row the unit row that rode in lane 16 + r (now Linv[.][r], i.e. row r of the transposed inverse),
+    // otherwise the row itself (lane r)
+    if (lane < CH_NB ? lane >= nb : lane < CH_NB + nb) {
+        double *dst = tile + l16;
 #pragma unroll
-    for (int k = 0; k < CH_NB; ++k) {
-        double *dst = dummy;
-        if (is_row && k <= l16) dst = tile + k * TL_LD + l16;
-        else if (is_inv) dst = &Dinv[k][l16];
-        *dst = X[k];
-    }
-#pragma unroll
-    for (int r = 1; r < CH_NB; ++r) {
-        double *dst = dummy;
-        if (is_inv && r > l16) dst = tile + r * TL_LD + l16;
-        *dst = X[r];
-    }
-    {
-        // the diagonal of the inverse: lane 16 + m holds it in X[m] (register index = lane index): select without dynamic indexing
-        double dgl = 0.0;
-#pragma unroll
-        for (int k = 0; k < CH_NB; ++k) dgl = (k == l16) ? X[k] : dgl;
-        if (is_inv) dinv16[l16] = dgl;
+        for (int k = 0; k < CH_NB; ++k) dst[k * TL_LD] = X[k];
     }
     DGPROF(6);   // write-back
+    XR_TL_CLK(7, true);
     return ok;
 }
 
-// tile (ti, tj) -= P_ti P_tj^T with the panel tiles of tile column tc; computed as the TRANSPOSED product (operands swapped) so that
-// the accumulator's lane layout, D[(lane >> 4) + 4 r][lane & 15], is a column-major store
-__device__ __forceinline__ void tl_trailing_tile(double *A, int tc, int ti, int tj, int r16, int q) {
-    const double *pi = A + tl_tile(ti, tc) + r16, *pj = A + tl_tile(tj, tc) + r16;
-    double *out = A + tl_tile(ti, tj) + r16;
+// Matrix-core operand of a panel tile: lane (r16 = lane & 15, q = lane >> 4) holds P[r16][4 s + q], s = 0 .. 3 -- as the A operand
+// (rows r16) and as the B operand (columns r16) alike.  It is also EXACTLY what tl_panel_tile's accumulator holds, so a panel tile goes
+// from the product that made it into the products that consume it without touching LDS.
+__device__ __forceinline__ chol_d4 tl_load_operand(const double *tile, int r16, int q) {
+    chol_d4 v;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) v[s4] = tile[(4 * s4 + q) * TL_LD + r16];
+    return v;
+}
+// W = P Linv^T for the panel tile `pt` below the diagonal tile `dt` (which holds Linv^T: Linv[c][k] at (k, c)), computed as the
+// transposed product W^T = Linv P^T: the accumulator's lane layout D[(lane >> 4) + 4 r][lane & 15] = W[r16][q + 4 r] is a
+// column-major store and the operand layout of the products that follow.  The tile is overwritten by W; W is returned as well.
+__device__ __forceinline__ chol_d4 tl_panel_tile(const double *dt, double *pt, int r16, int q) {
+    const chol_d4 pv = tl_load_operand(pt, r16, q);
     chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        const int kc = (4 * s4 + q) * TL_LD;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[kc], pi[kc], acc, 0, 0, 0);   // D'[j][i] = sum_k P_tj[j][k] P_ti[i][k]
-    }
+    for (int s4 = 0; s4 < 4; ++s4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dt[r16 * TL_LD + 4 * s4 + q], pv[s4], acc, 0, 0, 0);   // D'[c][i] = sum_k Linv[c][k] P[i][k]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[(q + 4 * r) * TL_LD] -= acc[r];   // element (row r16, column q + 4 r)
+    for (int r = 0; r < 4; ++r) pt[(q + 4 * r) * TL_LD + r16] = acc[r];   // element (row r16, column q + 4 r); every lane read its operand above
+    return acc;
+}
+// acc += W_tj W_ti^T as the transposed product D'[j][i] = sum_k W_tj[j][k] W_ti[i][k] (operands: see tl_load_operand)
+__device__ __forceinline__ chol_d4 tl_mac_tile(chol_d4 acc, const chol_d4 wj, const chol_d4 wi) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wj[s4], wi[s4], acc, 0, 0, 0);
+    return acc;
+}
+// tile -= acc (accumulator layout: element (row r16, column q + 4 r) in acc[r])
+__device__ __forceinline__ void tl_sub_tile(double *tile, const chol_d4 acc, int r16, int q) {
+    double o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = tile[(q + 4 * r) * TL_LD + r16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[(q + 4 * r) * TL_LD + r16] = o[r] - acc[r];
 }
 
-// In-place blocked Cholesky in the tiled layout; rows n .. nrows-1 ride along as right-hand sides.  dinv: [tile rows][16].
-// All threads must call; returns false (uniformly) on a non-positive pivot.  `side`: see chol_blocked.
+// In-place blocked Cholesky in the tiled layout; rows n .. nrows-1 ride along as right-hand sides.  ident: TL_TILE doubles of LDS
+// scratch (becomes an identity tile).  All threads must call; returns false (uniformly) on a non-positive pivot.  `side`: see
+// chol_blocked.
+//
+// Schedule (round 6).  Wavefront 0 walks the critical path and nothing else: block j -> [barrier] -> the panel tile right below it and,
+// straight from that product's registers, the update of the NEXT diagonal tile -> [barrier] -> block j + 1.  The other wavefronts, per
+// step j: their share of the panel; then, while wavefront 0 factors block j + 1, (a) the update of tile column j + 1 by step j (what
+// the next panel needs) and (b) the update of tile column j + 2 by ALL steps 0 .. j at once, accumulated in the matrix cores'
+// registers (left-looking).  Right-looking -- every tile behind the panel updated at every step -- made the first steps five times as
+// long as the last ones (55 tile products at step 0 of an 11-tile system, 1 at step 9) with a workgroup barrier per step, so wavefront 0
+// waited for the trailing update early on and the workers idled later; left-looking is (T - j - 2)(j + 2) products per step, 18 .. 30 ..
+// 10, and hides behind the diagonal blocks throughout.  f64 matrix-core products cost 80 cycles per 16x16x4 whether dependent or not
+// (tools/issue.hip): a tile product is 320 cycles of its SIMD's matrix pipe, ~220 of them per system of 165 unknowns.
 template <class Side = CholNoSide>
-__device__ __forceinline__ bool tl_chol(double *A, int n, int nrows, double (*Dinv)[CH_NB + 1], double *dinv, int *s_fail,
-                                        long long *prof = nullptr, Side side = Side()) {
+__device__ __forceinline__ bool tl_chol(double *A, int n, int nrows, double *ident, int *s_fail, long long *prof = nullptr,
+                                        Side side = Side()) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const int T = tl_tile_rows(nrows), Tm = tl_tile_rows(n);
@@ -561,81 +581,87 @@ __device__ __forceinline__ bool tl_chol(double *A, int n, int nrows, double (*Di
     long long t_prev = wall_clock64();
 #endif
     if (tid == 0) *s_fail = 0;
+    for (int e = tid; e < TL_TILE; e += nt) ident[e] = (e / TL_LD == e % TL_LD) ? 1.0 : 0.0;
     __syncthreads();
+    XR_TL_CLK_RESET();
     if (n > 0 && wave == 0) {
-        if (!tl_diag_wave(A + tl_tile(0, 0), min(CH_NB, n), Dinv, dinv, lane) && lane == 0) *s_fail = 1;
+        if (!tl_diag_wave(A + tl_tile(0, 0), min(CH_NB, n), ident, lane) && lane == 0) *s_fail = 1;
     } else if (wave == 1) {
         side();
     }
+    XR_TL_CLK(0, wave == 0);
     __syncthreads();
+    XR_TL_CLK(1, wave == 0);
     CHPROF(0);
     if (*s_fail) return false;
+    const int workers = nw > 1 ? nw - 1 : 1, me = nw > 1 ? wave - 1 : 0;   // wavefront 0 of a multi-wavefront workgroup is no worker
+    const bool is_worker = nw == 1 || wave > 0;
     for (int j = 0; j < Tm; ++j) {
         if (j + 1 >= T) break;   // nothing below this block
-        // ---- panel: X = P Linv^T for the tile rows below, as X^T = Linv P^T (column-major store of the accumulator)
-        for (int t = j + 1 + wave; t < T; t += nw) {
-            double *pt = A + tl_tile(t, j) + r16;
-            chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int kcol = 4 * s4 + q;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dinv[r16][kcol], pt[kcol * TL_LD], acc, 0, 0, 0);   // D'[c][i] = sum_k Linv[c][k] P[i][k]
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // every lane has read the tile before anybody overwrites it
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pt[(q + 4 * r) * TL_LD] = acc[r];   // element (row r16, column q + 4 r)
+        const double *dt = A + tl_tile(j, j);
+        const bool has_next = j + 1 < Tm;   // tile row j + 1 is a matrix row (a diagonal block follows), not only right-hand sides
+        // ---- panel.  Row j + 1 is wavefront 0's, together with the next diagonal tile's update by this step.
+        if (wave == 0) {
+            const chol_d4 w = tl_panel_tile(dt, A + tl_tile(j + 1, j), r16, q);
+            if (has_next) tl_sub_tile(A + tl_tile(j + 1, j + 1), tl_mac_tile(chol_d4{0.0, 0.0, 0.0, 0.0}, w, w), r16, q);
         }
+        if (is_worker)
+            for (int t = j + 2 + me; t < T; t += workers) tl_panel_tile(dt, A + tl_tile(t, j), r16, q);
+        XR_TL_CLK(2, wave == 0);
         __syncthreads();
+        XR_TL_CLK(3, wave == 0);
         CHPROF(1);
-        // ---- trailing update over the tiles (ti, tj), j < tj <= ti < T, tj < Tm; wavefront 0 takes the next diagonal tile first and
-        // factors it while the others finish (one panel of look-ahead)
-        const bool has_next = j + 1 < Tm;
-        const bool look = has_next && nw > 1;
-        if (look && wave == 0) {
-            tl_trailing_tile(A, j, j + 1, j + 1, r16, q);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (!tl_diag_wave(A + tl_tile(j + 1, j + 1), min(CH_NB, n - 16 * (j + 1)), Dinv, dinv + 16 * (j + 1), lane, prof) && lane == 0)
-                *s_fail = 1;
-        } else {
-            const int workers = look ? nw - 1 : nw, me = look ? wave - 1 : wave;
-            int t = 0;
-            for (int ti = j + 1; ti < T; ++ti)
-                for (int tj = j + 1; tj <= ti && tj < Tm; ++tj) {
-                    if (look && ti == j + 1) continue;   // (j + 1, j + 1): wavefront 0's
-                    if (t++ % workers != me) continue;
-                    tl_trailing_tile(A, j, ti, tj, r16, q);
+        // ---- wavefront 0: the next block.  Workers: (a) column j + 1 by step j, (b) column j + 2 by steps 0 .. j.
+        if (wave == 0 && has_next) {
+            XR_TL_CLK(4, true);
+            if (!tl_diag_wave(A + tl_tile(j + 1, j + 1), min(CH_NB, n - 16 * (j + 1)), ident, lane, prof) && lane == 0) *s_fail = 1;
+        }
+        if (is_worker && has_next) {
+            int turn = 0;   // tiles dealt round-robin, (b) first (the heavier ones), with a counter that wraps
+            if (j + 2 < Tm) {
+                for (int t = j + 2; t < T; ++t) {
+                    if (turn == me) {
+                        chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                        for (int s_ = 0; s_ <= j; ++s_)
+                            acc = tl_mac_tile(acc, tl_load_operand(A + tl_tile(j + 2, s_), r16, q), tl_load_operand(A + tl_tile(t, s_), r16, q));
+                        tl_sub_tile(A + tl_tile(t, j + 2), acc, r16, q);
+                    }
+                    turn = (turn + 1 == workers) ? 0 : turn + 1;
                 }
+            }
+            const chol_d4 wd = tl_load_operand(A + tl_tile(j + 1, j), r16, q);
+            for (int t = j + 2; t < T; ++t) {
+                if (turn == me)
+                    tl_sub_tile(A + tl_tile(t, j + 1), tl_mac_tile(chol_d4{0.0, 0.0, 0.0, 0.0}, wd, tl_load_operand(A + tl_tile(t, j), r16, q)), r16, q);
+                turn = (turn + 1 == workers) ? 0 : turn + 1;
+            }
         }
+        XR_TL_CLK(9, wave == 0);
         __syncthreads();
-        if (has_next && !look) {
-            if (!tl_diag_wave(A + tl_tile(j + 1, j + 1), min(CH_NB, n - 16 * (j + 1)), Dinv, dinv + 16 * (j + 1), lane) && lane == 0) *s_fail = 1;
-            __syncthreads();
-        }
+        XR_TL_CLK(8, wave == 0);
         CHPROF(2);
         if (*s_fail) return false;
     }
     return true;
 }
 
-// y <- L^-T y with the factor and the block inverses tl_chol left behind.  y: a vector of 16 * tile_rows(n) doubles in LDS whose
-// entries >= n are ZERO.  All threads must call.
-__device__ __forceinline__ void tl_trsv_t(const double *A, int n, const double *dinv, double *y) {
+// y <- L^-T y with what tl_chol left behind (L below the diagonal, transposed block inverses on it).  y: a vector of
+// 16 * tile_rows(n) doubles in LDS whose entries >= n are ZERO.  All threads must call.
+__device__ __forceinline__ void tl_trsv_t(const double *A, int n, double *y) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int Tm = tl_tile_rows(n);
     for (int j = Tm - 1; j >= 0; --j) {
-        // x_r = sum_{c >= r} Linv[c][r] y_c : the diagonal from dinv, the rest from the upper triangle of the tile, (r, c) = Linv[c][r]
+        // x_r = sum_c Linv[c][r] y_c : row r of the diagonal tile (zeros left of the diagonal; whatever a non-pivot column holds meets a
+        // zero of y)
         double xr = 0.0;
         if (tid < 16) {
             const double *tile = A + tl_tile(j, j) + tid;
             const double *yj = y + 16 * j;
-            xr = dinv[16 * j + tid] * yj[tid];
 #pragma unroll
-            for (int c = 1; c < 16; ++c) xr += (c > tid ? tile[c * TL_LD] : 0.0) * yj[c];
+            for (int c = 0; c < 16; ++c) xr += tile[c * TL_LD] * yj[c];
         }
         __syncthreads();
-        if (tid < 16) y[16 * j + tid] = xr;
+        if (tid < 16) y[16 * j + tid] = (16 * j + tid < n) ? xr : 0.0;
         __syncthreads();
         // y_i -= sum_c L[16 j + c][i] x_c for the rows above: thread i reads element (c, i & 15) of tile (j, i >> 4), c = 0 .. 15
         for (int i = tid; i < 16 * j; i += nt) {
