@@ -61,7 +61,8 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
     L.cs = take(16 * F);
     L.Hp = take(na * (na + 1) / 2);
     L.gp = take(na);
-    L.A = take((na + 1) * (na + 2) / 2);
+    // the reduced system: at most 16 unknowns never leave registers; beyond that the tiled layout of dense_lds.hip.h + L^-1 rhs
+    L.A = take(na <= CH_NB ? 2 : tl_doubles(na + 1) + 16 * tl_tile_rows(na + 1));
     L.scr = take(NI * IMU_SCR);   // raw IMU residuals / Jacobians: a region of its own, so that its zero pattern survives the rounds
     L.sp = take(na);
     L.D = take(na);
@@ -520,24 +521,27 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
                 const double Dv = sqrt(fmin(fmax(spi * spi * h, 1e-6), 1e32));
                 const double gsv = on ? spi * gp[i] : 0.0;
                 const double gtv = on ? spi * (gsv / (Dv * Dv)) : 0.0;
-                // row i of S = sp H sp + mu D^2 and the right-hand side, into the packed triangle the factorisation reads
-                double *y = A + tri_idx(na, 0);
+                // The reduced system never leaves registers (round 6): lane i < 16 forms row i of S = sp H sp + mu D^2, lanes 16-31 carry
+                // the unit rows, lane 32 the right-hand side; diag16_pivot_pairs leaves column r of L^-1 in lane 16 + r and L^-1 rhs in
+                // lane 32, and x = L^-T (L^-1 rhs) is sixteen broadcast-multiply-adds.  (Rounds 2-5: the rows went to LDS, the block
+                // routine read them back and wrote L, a 16-step back-substitution read L again.)
+                double Xr[CH_NB];
                 double t_i = 0.0;   // (H g~)_i
+                const double yi = on ? gp[i] * spi : 0.0;
 #pragma unroll
                 for (int k = 0; k < CH_NB; ++k) {
-                    const double spk = lane_bcast(spi, k), gtk = lane_bcast(gtv, k);
+                    const double spk = lane_bcast(spi, k), gtk = lane_bcast(gtv, k), yk = lane_bcast(yi, k);
+                    double v = (k == lane) ? 1.0 : 0.0;   // rows >= na of the block, and (lanes 16-31) the unit rows
                     if (on && k < na) {
                         const double hik = Hp[k <= i ? tri_idx(i, k) : tri_idx(k, i)];
                         t_i += hik * gtk;
-                        if (k <= i) {
-                            double v = hik * (spi * spk);
-                            if (k == i) v += mu * Dv * Dv;
-                            A[tri_idx(i, k)] = v;
-                        }
+                        v = hik * (spi * spk);
+                        if (k == i) v += mu * Dv * Dv;
                     }
+                    if (lane >= CH_NB) v = (lane == 2 * CH_NB) ? yk : ((k == lane - CH_NB) ? 1.0 : 0.0);
+                    Xr[k] = v;
                 }
                 if (on) {
-                    y[i] = gp[i] * spi;
                     if (first_lin) sp[i] = spi;
                     Dg[i] = Dv;
                     gs[i] = gsv;
@@ -546,28 +550,13 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
 #pragma unroll
                 for (int off = 8; off > 0; off >>= 1) qgg += __shfl_xor(qgg, off);
                 qgg = lane_bcast(qgg, 0);
-                wave_sync();
-                bool ok = chol_diag_wave(A, 0, na, Dblk, lane, y);   // L in place, y <- L^-1 y
-                wave_sync();
-                // y <- L^-T y (trsv_lower_t's single block): lane k owns column k of L
-                double ya = 0.0;
-                {
-                    double col[CH_NB], dl = 1.0;
+                bool ok = diag16_pivot_pairs(Xr, na, lane);
+                double xs = 0.0;   // lane 16 + r: x_r = sum_c Linv[c][r] (L^-1 rhs)_c
 #pragma unroll
-                    for (int cc = 0; cc < CH_NB; ++cc) {
-                        col[cc] = (cc < na && lane <= cc) ? A[tri_idx(cc, min(lane, cc))] : ((cc == lane) ? 1.0 : 0.0);
-                        if (cc == lane) dl = col[cc];
-                    }
-                    const double dinv = 1.0 / dl;
-                    double r = on ? y[i] : 0.0;
-#pragma unroll
-                    for (int cc = CH_NB - 1; cc >= 0; --cc) {
-                        const double xc = lane_bcast(r, cc) * lane_bcast(dinv, cc);
-                        if (lane == cc) r = xc;
-                        else if (lane < cc) r -= col[cc] * xc;
-                    }
-                    ya = r;
-                }
+                for (int cc = 0; cc < CH_NB; ++cc) xs = fma(Xr[cc], lane_bcast(Xr[cc], 2 * CH_NB), xs);
+                // (the shuffle runs with every lane active: a ds_bpermute under `on` would read the inactive lanes 16-31 as zero)
+                const double xs_up = __shfl(xs, (lane + CH_NB) & 63);
+                const double ya = on ? xs_up : 0.0;
                 if (__ballot(on && !isfinite(ya)) != 0ull) ok = false;
                 const double gnv = on ? -Dv * ya : 0.0, grv = on ? gsv / Dv : 0.0;
                 if (on) {
@@ -630,7 +619,11 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
                 gt[i] = s * (gsv / (Dv * Dv));
             }
             __syncthreads();
-            // -------------------- reduced system S = sp H sp + mu D^2 (packed, the rhs as row na) and Q(g~, g~)
+            // -------------------- reduced system S = sp H sp + mu D^2 in the tiled layout (the rhs as row na) and Q(g~, g~)
+            const int nrows = na + 1, Tt = tl_tile_rows(nrows);
+            double *yv = A + tl_doubles(nrows);   // [16 Tt]
+            tl_clear(A, na, nrows);
+            __syncthreads();
             for (int e = wtid; e < na * (na + 1) / 2; e += nt) {
                 int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
                 while (i * (i + 1) / 2 > e) --i;
@@ -638,26 +631,27 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
                 const int j = e - i * (i + 1) / 2;
                 double v = Hp[e] * (sp[i] * sp[j]);
                 if (i == j) v += mu * Dg[i] * Dg[i];
-                A[e] = v;
+                A[tl_idx(i, j)] = v;
             }
-            double *y = A + na * (na + 1) / 2;
-            for (int i = wtid; i < na; i += nt) y[i] = gp[i] * sp[i];
+            for (int i = wtid; i < na; i += nt) A[tl_idx(na, i)] = gp[i] * sp[i];
             double qacc = 0;
             for (int i = wave; i < na; i += 4) {
                 double t = 0;
                 for (int j = lane; j < na; j += 64) t += Hp[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i] * gt[j];
                 qacc += gt[i] * t;
             }
-            const double qgg = block_sum(qacc, scratch);   // (block_sum ends with a barrier: A and y are complete)
+            const double qgg = block_sum(qacc, scratch);   // (block_sum ends with a barrier: the tiles are complete)
             CPROF(6);   // preparation, reduced system, Q(g~, g~)
             // -------------------- Cholesky + substitution (solve_block)
-            lin_ok = chol_blocked(A, na, na + 1, Dblk, &s_fail, nullptr, gradmax_side);
+            lin_ok = tl_chol(A, na, nrows, &Dblk[0][0], &s_fail, nullptr, gradmax_side);
             CPROF(7);   // Cholesky
             if (lin_ok) {
-                trsv_lower_t(A, na, y);
+                for (int i = wtid; i < 16 * Tt; i += nt) yv[i] = i < na ? A[tl_idx(na, i)] : 0.0;   // L^-1 rhs; zero beyond n (tl_trsv_t)
+                __syncthreads();
+                tl_trsv_t(A, na, yv);
                 int bad = 0;
                 for (int i = wtid; i < na; i += nt) {
-                    const double ya = y[i];
+                    const double ya = yv[i];
                     gn[i] = -Dg[i] * ya;
                     grad[i] = gs[i] / Dg[i];
                     if (!isfinite(ya)) bad = 1;

@@ -108,8 +108,13 @@ __device__ __forceinline__ bool diag16_pivot_pairs(double (&X)[CH_NB], int nb, i
             const double det = fma(a, d, -(b * b));
             const double rd = rcp_cubic(det);
             const double U = -(u * rd), V = -(v * rd);
+            // (the scheduling barriers keep the compiler from hoisting all broadcasts of a pair to its top: ~50 live scalar pairs, which
+            // the big kernels this is inlined into spill through v_writelane and on into scratch)
 #pragma unroll
-            for (int k = c + 2; k < CH_NB; ++k) X[k] = fma(lane_bcast(x1, k), V, fma(lane_bcast(x0, k), U, X[k]));
+            for (int k = c + 2; k < CH_NB; ++k) {
+                X[k] = fma(lane_bcast(x1, k), V, fma(lane_bcast(x0, k), U, X[k]));
+                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         X[c + 1] = pw ? v : x1;
         S = (l16 == c) ? (pv ? x0 : 1.0) : S;
