@@ -33,7 +33,6 @@ constexpr int CHAIN_THREADS = 256;
 #ifdef XRHIP_KPROF
 #define CPROF(slot)                                   \
     do {                                              \
-        __syncthreads();                              \
         if (threadIdx.x == 0) {                       \
             const long long cp_n = wall_clock64();    \
             s_ctl.prof[slot] += cp_n - cp_t;          \
@@ -87,7 +86,7 @@ __host__ __device__ __forceinline__ ChainLayout chain_layout(int F, int na, int 
 // (Tried: this workgroup pulling the staged problem from the pinned host arena itself instead of a kb_stage launch in
 // front of it -- one compute unit reads the host link slower than kb_stage's 128 workgroups: localize_newframe
 // 0.132 -> 0.139 ms per frame, profiles/r02_ab_variants.md.)
-constexpr int CHAIN_VIS_TILE = 27 * 257;   // doubles of LDS behind the layout when `opts & CHAIN_OPT_TILE`
+constexpr int CHAIN_VIS_TILE = 4 * 27 * 65;   // doubles of LDS behind the layout when `opts & CHAIN_OPT_TILE`: a [27][65] tile per wavefront
 constexpr int CHAIN_OBS_CACHE = 16;        // doubles per reprojection factor behind that when `opts & CHAIN_OPT_CACHE`
 enum { CHAIN_OPT_TILE = 1, CHAIN_OPT_CACHE = 2 };
 __host__ __device__ __forceinline__ int chain_cache_stride(int M) { return (M + 1) & ~1; }
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
     extern __shared__ double lds[];
     __shared__ double scratch[64];
     __shared__ double Dblk[CH_NB][CH_NB + 1];
-    __shared__ double s_vis[4][27];
+    __shared__ double s_vis[4][CHAIN_MAX_FREE][27];
     __shared__ int s_fail;
     __shared__ int s_free[CHAIN_MAX_FREE], s_slot[CHAIN_MAX_F], s_nfree;
     __shared__ BaCtl s_ctl;
@@ -362,8 +361,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
                 }
             }
             CPROF(2);   // IMU whitening
-            // ---------------- reprojection blocks of the free frames: the (f, f) pair list over all four wavefronts,
-            // upper triangle + gradient = 27 sums (kb_tiny's single-frame form, once per free frame)
+            // ---------------- reprojection blocks of the free frames: the (f, f) pair list over all four wavefronts, upper triangle +
+            // gradient = 27 sums per frame.  Round 6: every wavefront reduces ITS lanes' partial sums through a tile of its own (a store of
+            // 27 columns, 54 lanes add half a row each) and goes on to the next frame at once -- ONE workgroup barrier for all frames
+            // (rounds 2-5: a 256-wide tile and three barriers per free frame, 3.4 us each).
             for (int s = 0; s < nfree; ++s) {
                 const int f = s_free[s], pair = f * F + f;
                 const int s0 = p.pair_start[pair], s1 = p.pair_start[pair + 1];
@@ -387,31 +388,34 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
                     }
                 }
                 if (vis_tile) {
-                    // every thread parks its 27 partial sums as a column of an LDS tile; 108 threads add up a quarter row
-                    // each (27 butterfly reductions of doubles per free frame were 5 us of every round)
-                    double *tile = lds + Lo.total;
-                    if (worker)
+                    double *tw = lds + Lo.total + wave * (27 * 65);
 #pragma unroll
-                        for (int i = 0; i < 27; ++i) tile[i * 257 + tid] = acc[i];
-                    __syncthreads();
-                    if (tid < 108) {
-                        const int q = tid >> 2, w4 = tid & 3;
-                        const double *row = tile + q * 257 + 64 * w4;
-                        double s2 = 0.0;
-                        for (int i = 0; i < 64; ++i) s2 += row[i];
-                        s_vis[w4][q] = s2;
+                    for (int i = 0; i < 27; ++i) tw[i * 65 + lane] = acc[i];
+                    wave_sync();
+                    const int row = lane < 27 ? lane : lane - 27;   // lanes 0-26: entries 0-31 of row `lane`; lanes 27-53: entries 32-63
+                    double s2 = 0.0;
+                    if (lane < 54) {
+                        const double *rp = tw + row * 65 + (lane < 27 ? 0 : 32);
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) s2 += rp[i];
                     }
+                    const double hi = __shfl(s2, (lane + 27) & 63);   // every lane active (a ds_bpermute reads inactive lanes as zero)
+                    if (lane < 27) s_vis[wave][s][lane] = s2 + hi;
+                    wave_sync();   // the tile is free for the next frame
                 } else {
 #pragma unroll
                     for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
-                    if (lane == 0 && worker)
+                    if (lane == 0)
 #pragma unroll
-                        for (int i = 0; i < 27; ++i) s_vis[wave][i] = acc[i];
+                        for (int i = 0; i < 27; ++i) s_vis[wave][s][i] = acc[i];
                 }
-                __syncthreads();
-                if (tid < 27) Hv[28 * s + tid] = (s_vis[0][tid] + s_vis[1][tid]) + (s_vis[2][tid] + s_vis[3][tid]);
-                __syncthreads();
             }
+            __syncthreads();
+            for (int e = tid; e < 27 * nfree; e += nt) {
+                const int s = e / 27, q = e - 27 * s;
+                Hv[28 * s + q] = (s_vis[0][s][q] + s_vis[1][s][q]) + (s_vis[2][s][q] + s_vis[3][s][q]);
+            }
+            __syncthreads();
             CPROF(3);   // reprojection blocks
             // ---------------- assembly of the free x free entries (packed lower triangle) and of the gradient:
             // reprojection block, rotation priors, the IMU factor ending at the frame, the one starting at it --
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
                     i = e - na * (na + 1) / 2;
                     j = 0;
                 } else {   // e = i (i + 1) / 2 + j
-                    i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+                    i = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);   // e < 2^12: exact enough, corrected below
                     while (i * (i + 1) / 2 > e) --i;
                     while ((i + 1) * (i + 2) / 2 <= e) ++i;
                     j = e - i * (i + 1) / 2;
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
             tl_clear(A, na, nrows);
             __syncthreads();
             for (int e = wtid; e < na * (na + 1) / 2; e += nt) {
-                int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+                int i = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
                 while (i * (i + 1) / 2 > e) --i;
                 while ((i + 1) * (i + 2) / 2 <= e) ++i;
                 const int j = e - i * (i + 1) / 2;
