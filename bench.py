@@ -671,6 +671,17 @@ def main():
             out["kprof_ms"] = [round(v / 1e5, 3) for v in buf]    # 100 MHz ticks -> ms (whole run incl. warmup)
             for slot in (19, 27, 31):                             # counters: trust-region trials, single-launch rounds, solves
                 out["kprof_ms"][slot] = int(buf[slot])
+            lkb = (ctypes.c_longlong * 8)()
+            try:
+                ctypes.CDLL(_lib.LIB_PATH).xrhip_debug_lkprof(lkb, 0)
+                if lkb[6] > 0:    # shader cycles per point: level set-up | A exchange + tile | taps | scans | exchange | update | total
+                    out["lk_prof_cycles_per_point"] = {k: round(lkb[i] / lkb[6], 1) for i, k in enumerate(
+                        ("level_setup_templates", "a_exchange_tile_to_lds", "iter_weights_taps", "iter_dpp_scans", "iter_exchange",
+                         "iter_update_convergence"))}
+                    out["lk_prof_cycles_per_point"]["kernel"] = round(lkb[7] / lkb[6], 1)
+                    out["lk_prof_cycles_per_point"]["points"] = int(lkb[6])
+            except AttributeError:
+                pass
         if sustained_frames > 0:
             # the headline mode itself over a longer sample of the same stream (same call, same threading, same image path)
             sess.sync()

@@ -1219,3 +1219,19 @@ int xrhip_klt_synchronize(xrhip_klt *c) {
 }
 
 }   // extern "C"
+
+/* development aid: LK phase timers (shader cycles, summed over all points since the last reset) of -DXRHIP_KPROF builds; zeros otherwise */
+extern "C" void xrhip_debug_lkprof(long long *out8, int reset) {
+#ifdef XRHIP_KPROF
+    unsigned long long h[8] = {0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(xrhip::g_lk_prof), sizeof(h)) == hipSuccess)
+        for (int i = 0; i < 8; ++i) out8[i] = (long long)h[i];
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(xrhip::g_lk_prof), z, sizeof(z));
+    }
+#else
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    (void)reset;
+#endif
+}

@@ -989,20 +989,46 @@ __device__ __forceinline__ double wave_sum_i32_exact(int v) {
     return (double)hi * 65536.0 + (double)lo;
 }
 
+// -DXRHIP_KPROF: shader-clock sums of the LK phases as lane 0 of a point's first wavefront sees them (xrhip_debug_lkprof):
+//   0 level set-up (tile fetch issued, template gather, A sums)   1 A exchange, eigenvalue gate, tile -> LDS
+//   2 iteration: weights + taps   3 iteration: the four DPP scans   4 iteration: exchange (store, barrier, loads, adds)
+//   5 iteration: update + convergence tests   6 points   7 kernel entry -> exit per point
+#ifdef XRHIP_KPROF
+__device__ unsigned long long g_lk_prof[8];
+#define LKPROF(slot)                                                 \
+    do {                                                             \
+        const long long lk_n_ = (long long)__builtin_readcyclecounter(); \
+        lk_acc[slot] += lk_n_ - lk_t;                                \
+        lk_t = lk_n_;                                                \
+    } while (0)
+#else
+#define LKPROF(slot) \
+    do {             \
+    } while (0)
+#endif
 struct LkCounters {
     unsigned long long templates;
     unsigned long long iterations;
 };
 
-// One direction of cv::calcOpticalFlowPyrLK for ONE point, executed by one
-// wavefront (all lanes carry identical scalar state; the window is lane-striped).
-// Returns the status bit; nx,ny are the OPTFLOW_USE_INITIAL_FLOW guess on entry
-// and the tracked position on exit (level-0 pixels).
+// One direction of cv::calcOpticalFlowPyrLK for ONE point, executed by the LK_WAVES wavefronts of a workgroup (all lanes carry
+// identical scalar state; the window is lane-striped).  Returns the status bit; nx, ny are the OPTFLOW_USE_INITIAL_FLOW guess on
+// entry and the tracked position on exit (level-0 pixels).
+//
+// Round 6: everything a level needs from global memory is requested for ALL levels before the first one starts.  In-kernel cycle
+// counters (profiles/r06_lk_phases.md) had half of a point's 34 us in the set-up of its eight level visits -- per level the
+// template gather and the search-tile fetch (one round trip to L2 / HBM each, ~2000 cycles), an exchange of the template's A sums
+// (a barrier) and the tile's way into LDS (two more) -- against ~960 cycles per iteration.  The template of a level depends on the
+// point alone; the search tile of a level is fetched around the INITIAL GUESS scaled to that level (rounds 3-5: around the position
+// the coarser level ended at, known only then) -- an iteration whose footprint is not inside the tile reads global memory, as before,
+// so where the tile sits changes nothing but speed.  One round trip, one exchange and one barrier per direction.  The arithmetic of
+// every level is what it was: status bits and positions are bit-identical (tests/test_klt_gpu.py).
 __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, float px0, float py0, float &nx_io,
                                           float &ny_io, const int (&wx)[LK_SLOTS], const int (&wy)[LK_SLOTS],
                                           const bool (&wvalid)[LK_SLOTS], unsigned &n_templates,
-                                          unsigned &n_iters, uint32_t *tile, double (*xch)[LK_WAVES][4], int &xpar) {
-    // xch: [2][LK_WAVES][4] doubles of LDS through which the wavefronts of this point exchange their partial window sums
+                                          unsigned &n_iters, uint32_t (*tile)[LK_TILE_DWORDS], double (*xch)[LK_WAVES][3 * KLT_LEVELS], int &xpar,
+                                          long long (&lk_acc)[8], long long &lk_t) {
+    // xch: [2][LK_WAVES][12] doubles of LDS through which the wavefronts of this point exchange their partial window sums
     // (every value an exact integer below 2^53, so their sum is exact in any order); xpar alternates between the two
     // halves, which is what lets one barrier per exchange suffice (a wavefront can only be writing half h for exchange
     // n + 1 after every wavefront passed the barrier of exchange n, i.e. after all reads of half h for exchange n - 1)
@@ -1012,11 +1038,158 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
     const double epsilon = 0.01 * 0.01;
     int status = 1;
     float outx = nx_io, outy = ny_io;
-    for (int level = KLT_LEVELS - 1; level >= 0; --level) {
-        const LevelView I = A.lv[level];
+    // ---- (1) requests of all levels: search tiles around the scaled guess, then the template samples
+    uint32_t tile_regs[KLT_LEVELS][LK_TILE_LOADS];
+    int tx0[KLT_LEVELS], ty0[KLT_LEVELS];
+    bool staged[KLT_LEVELS], tmpl[KLT_LEVELS];
+    int tw[KLT_LEVELS][4];                                   // the template's bilinear weights
+    // per pixel two 16-bit loads (the two 8-bit samples of a row are neighbours) and two 8-byte loads (two derivative pairs): half the
+    // load instructions of one per tap -- the gather of 64 lanes x 16 loads per level was bound by the texture-address path
+    typedef uint16_t __attribute__((aligned(1))) lk_u16u;
+    typedef uint2 __attribute__((aligned(4))) lk_u2u;
+    uint32_t raw_i[KLT_LEVELS][LK_SLOTS][2];                 // two 8-bit samples each: rows y, y + 1
+    uint2 raw_d[KLT_LEVELS][LK_SLOTS][2];                    // two derivative pairs each: rows y, y + 1
+#pragma unroll
+    for (int level = 0; level < KLT_LEVELS; ++level) {
         const LevelView J = B.lv[level];
         const float lscale = (float)(1. / (1 << level));
-        float px = px0 * lscale, py = py0 * lscale;
+        staged[level] = false;
+        tx0[level] = ty0[level] = 0;
+        if (LK_STAGE_J) {
+            const float gx = nx_io * lscale, gy = ny_io * lscale;
+            const int inx0 = (int)floorf(gx - half), iny0 = (int)floorf(gy - half);
+            if (inx0 >= -KLT_WIN && inx0 < J.w && iny0 >= -KLT_WIN && iny0 < J.h) {
+                int x0 = inx0 - LK_TILE_R;
+                const int y0 = iny0 - LK_TILE_R;
+                x0 -= (int)(reinterpret_cast<uintptr_t>(J.img + x0) & 3);   // row strides are multiples of 64 bytes
+#pragma unroll
+                for (int k = 0; k < LK_TILE_LOADS; ++k) {
+                    const int idx = min((int)threadIdx.x + LK_THREADS * k, LK_TILE_DWORDS - 1);
+                    const int r = idx / LK_TILE_W4, c4 = idx - r * LK_TILE_W4;
+                    // rows / dwords outside the padded plane are never part of a valid footprint: clamp the address
+                    const int y = min(max(y0 + r, -KLT_PAD), J.h + KLT_PAD - 1);
+                    const int x = min(max(x0 + 4 * c4, -KLT_PADX), J.istride - KLT_PADX - 4);
+                    tile_regs[level][k] = *reinterpret_cast<const uint32_t *>(J.img + (ptrdiff_t)y * J.istride + x);
+                }
+                tx0[level] = x0;
+                ty0[level] = y0;
+                staged[level] = true;
+            }
+        }
+    }
+#pragma unroll
+    for (int level = 0; level < KLT_LEVELS; ++level) {
+        const LevelView I = A.lv[level];
+        const float lscale = (float)(1. / (1 << level));
+        const float px = px0 * lscale - half, py = py0 * lscale - half;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        tmpl[level] = !(ipx < -KLT_WIN || ipx >= I.w || ipy < -KLT_WIN || ipy >= I.h);
+        const float a = px - ipx, b = py - ipy;
+        tw[level][0] = __float2int_rn((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+        tw[level][1] = __float2int_rn(a * (1.f - b) * (1 << LK_W_BITS));
+        tw[level][2] = __float2int_rn((1.f - a) * b * (1 << LK_W_BITS));
+        tw[level][3] = (1 << LK_W_BITS) - tw[level][0] - tw[level][1] - tw[level][2];
+        // a template outside the plane is never used; its loads go to the plane's origin instead
+        const int cx = tmpl[level] ? ipx : 0, cy = tmpl[level] ? ipy : 0;
+#pragma unroll
+        for (int sl = 0; sl < LK_SLOTS; ++sl) {
+            const uint8_t *s0 = I.img + (ptrdiff_t)(cy + wy[sl]) * I.istride + (cx + wx[sl]);
+            const uint8_t *s1 = s0 + I.istride;
+            const short2 *d0 = I.der + (ptrdiff_t)(cy + wy[sl]) * I.pstride + (cx + wx[sl]);
+            const short2 *d1 = d0 + I.pstride;
+            raw_i[level][sl][0] = *reinterpret_cast<const lk_u16u *>(s0);
+            raw_i[level][sl][1] = *reinterpret_cast<const lk_u16u *>(s1);
+            raw_d[level][sl][0] = *reinterpret_cast<const lk_u2u *>(d0);
+            raw_d[level][sl][1] = *reinterpret_cast<const lk_u2u *>(d1);
+        }
+    }
+    // ---- (2) the search tiles go to LDS (every wavefront is past the last tile read of the previous direction: its last
+    // iteration's exchange barrier came after the taps), the templates are formed, their A sums reduced inside the wavefront
+#pragma unroll
+    for (int level = 0; level < KLT_LEVELS; ++level)
+        if (staged[level])
+#pragma unroll
+            for (int k = 0; k < LK_TILE_LOADS; ++k) {
+                const int idx = (int)threadIdx.x + LK_THREADS * k;
+                if (idx < LK_TILE_DWORDS) tile[level][idx] = tile_regs[level][k];
+            }
+    int Iv[KLT_LEVELS][LK_SLOTS], Ix[KLT_LEVELS][LK_SLOTS], Iy[KLT_LEVELS][LK_SLOTS];
+    double part[KLT_LEVELS][3];
+#pragma unroll
+    for (int level = 0; level < KLT_LEVELS; ++level) {
+        const int iw00 = tw[level][0], iw01 = tw[level][1], iw10 = tw[level][2], iw11 = tw[level][3];
+        long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+        for (int sl = 0; sl < LK_SLOTS; ++sl) {
+            const uint32_t r0 = raw_i[level][sl][0], r1 = raw_i[level][sl][1];
+            const uint2 e0 = raw_d[level][sl][0], e1 = raw_d[level][sl][1];   // .x: (Ix, Iy) of the left pixel, .y: of the right one
+            int ival = lk_descale(lk_tap((int)(r0 & 255u), iw00) + lk_tap((int)(r0 >> 8), iw01) + lk_tap((int)(r1 & 255u), iw10) + lk_tap((int)(r1 >> 8), iw11),
+                                  LK_W_BITS - 5);
+            int ixval = lk_descale(lk_tap((int)(short)(e0.x & 0xffffu), iw00) + lk_tap((int)(short)(e0.y & 0xffffu), iw01) +
+                                       lk_tap((int)(short)(e1.x & 0xffffu), iw10) + lk_tap((int)(short)(e1.y & 0xffffu), iw11),
+                                   LK_W_BITS);
+            int iyval = lk_descale(lk_tap((int)e0.x >> 16, iw00) + lk_tap((int)e0.y >> 16, iw01) + lk_tap((int)e1.x >> 16, iw10) + lk_tap((int)e1.y >> 16, iw11),
+                                   LK_W_BITS);
+            // OpenCV stores these as int16 (Iptr/dIptr are short); a lane without a pixel in this slot carries zeros
+            ival = wvalid[sl] ? (int)(short)ival : 0;
+            ixval = wvalid[sl] ? (int)(short)ixval : 0;
+            iyval = wvalid[sl] ? (int)(short)iyval : 0;
+            Iv[level][sl] = ival;
+            Ix[level][sl] = ixval;
+            Iy[level][sl] = iyval;
+            sA11 += (long long)(ixval * ixval);
+            sA12 += (long long)(ixval * iyval);
+            sA22 += (long long)(iyval * iyval);
+        }
+        if (LK_SLOTS <= 2) {
+            // |Ix|, |Iy| <= 4080: two slots stay below 2^25 per lane and 64 lanes below 2^31 -- the wavefront's sums are exact in 32
+            // bits (one fused DPP add per stage; the 64-bit scan is an add / add-with-carry pair and two moves)
+            part[level][0] = (double)dpp_scan_add_i32((int)sA11);
+            part[level][1] = (double)dpp_scan_add_i32((int)sA12);
+            part[level][2] = (double)dpp_scan_add_i32((int)sA22);
+        } else {
+            part[level][0] = (double)wave_sum_i64(sA11);   // < 2^37: exact
+            part[level][1] = (double)wave_sum_i64(sA12);
+            part[level][2] = (double)wave_sum_i64(sA22);
+        }
+    }
+    LKPROF(0);
+    // ---- (3) ONE exchange for the A sums of all levels; its barrier also publishes the tiles
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int level = 0; level < KLT_LEVELS; ++level)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xch[xpar][wave_id][3 * level + k] = part[level][k];
+    }
+    __syncthreads();
+    float A11[KLT_LEVELS], A12[KLT_LEVELS], A22[KLT_LEVELS], Dinv[KLT_LEVELS];
+    bool gate[KLT_LEVELS];
+#pragma unroll
+    for (int level = 0; level < KLT_LEVELS; ++level) {
+        double dA11 = 0.0, dA12 = 0.0, dA22 = 0.0;
+#pragma unroll
+        for (int w = 0; w < LK_WAVES; ++w) {
+            dA11 += xch[xpar][w][3 * level];
+            dA12 += xch[xpar][w][3 * level + 1];
+            dA22 += xch[xpar][w][3 * level + 2];
+        }
+        // (float) of the exact sum held as a double is the correctly rounded value, the same float (float)(int64 sum) is
+        A11[level] = (float)dA11 * FLT_SCALE;
+        A12[level] = (float)dA12 * FLT_SCALE;
+        A22[level] = (float)dA22 * FLT_SCALE;
+        const float D = A11[level] * A22[level] - A12[level] * A12[level];
+        const float minEig = (A22[level] + A11[level] - sqrtf((A11[level] - A22[level]) * (A11[level] - A22[level]) + 4.f * A12[level] * A12[level])) /
+                             (float)(2 * KLT_WIN * KLT_WIN);
+        gate[level] = !(minEig < 1e-4f || D < 1.1920929e-07f);
+        Dinv[level] = 1.f / D;
+    }
+    xpar ^= 1;
+    LKPROF(1);
+    // ---- (4) the levels, coarse to fine
+#pragma unroll
+    for (int level = KLT_LEVELS - 1; level >= 0; --level) {
+        const LevelView J = B.lv[level];
+        const float lscale = (float)(1. / (1 << level));
         float nx, ny;
         if (level == KLT_LEVELS - 1) {
             nx = outx * lscale;
@@ -1027,115 +1200,18 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
         }
         outx = nx;
         outy = ny;
-        // fetch the search neighbourhood of the level's starting position (wave-uniform control flow: one wavefront
-        // per workgroup); issued before the template gather so that both round trips overlap
-        bool staged = false;
-        int tx0 = 0, ty0 = 0;
-        uint32_t tile_regs[LK_TILE_LOADS];
-        if (LK_STAGE_J) {
-            const int inx0 = (int)floorf(nx - half), iny0 = (int)floorf(ny - half);
-            if (inx0 >= -KLT_WIN && inx0 < J.w && iny0 >= -KLT_WIN && iny0 < J.h) {
-                tx0 = inx0 - LK_TILE_R;
-                ty0 = iny0 - LK_TILE_R;
-                tx0 -= (int)(reinterpret_cast<uintptr_t>(J.img + tx0) & 3);   // row strides are multiples of 64 bytes
-#pragma unroll
-                for (int k = 0; k < LK_TILE_LOADS; ++k) {
-                    const int idx = min((int)threadIdx.x + LK_THREADS * k, LK_TILE_DWORDS - 1);
-                    const int r = idx / LK_TILE_W4, c4 = idx - r * LK_TILE_W4;
-                    // rows / dwords outside the padded plane are never part of a valid footprint: clamp the address
-                    const int y = min(max(ty0 + r, -KLT_PAD), J.h + KLT_PAD - 1);
-                    const int x = min(max(tx0 + 4 * c4, -KLT_PADX), J.istride - KLT_PADX - 4);
-                    tile_regs[k] = *reinterpret_cast<const uint32_t *>(J.img + (ptrdiff_t)y * J.istride + x);
-                }
-                staged = true;
-            }
-        }
-        px -= half;
-        py -= half;
-        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
-        if (ipx < -KLT_WIN || ipx >= I.w || ipy < -KLT_WIN || ipy >= I.h) {
+        if (!tmpl[level]) {
             if (level == 0) status = 0;
             continue;
-        }
-        float a = px - ipx, b = py - ipy;
-        int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
-        int iw01 = __float2int_rn(a * (1.f - b) * (1 << LK_W_BITS));
-        int iw10 = __float2int_rn((1.f - a) * b * (1 << LK_W_BITS));
-        int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
-        int Iv[LK_SLOTS], Ix[LK_SLOTS], Iy[LK_SLOTS];
-        long long sA11 = 0, sA12 = 0, sA22 = 0;
-        // Branch-free over the slots: a lane without a pixel in slot s (lk_lane_layout points it at window pixel 0)
-        // loads like the others and its template entries are zeroed afterwards, so the gathers of all seven slots are
-        // in flight together instead of one dependent round trip per slot.
-#pragma unroll
-        for (int s = 0; s < LK_SLOTS; ++s) {
-            const uint8_t *s0 = I.img + (ptrdiff_t)(ipy + wy[s]) * I.istride + (ipx + wx[s]);
-            const uint8_t *s1 = s0 + I.istride;
-            const short2 *d0 = I.der + (ptrdiff_t)(ipy + wy[s]) * I.pstride + (ipx + wx[s]);
-            const short2 *d1 = d0 + I.pstride;
-            short2 g00 = d0[0], g01 = d0[1], g10 = d1[0], g11 = d1[1];
-            int ival = lk_descale(lk_tap(s0[0], iw00) + lk_tap(s0[1], iw01) + lk_tap(s1[0], iw10) + lk_tap(s1[1], iw11),
-                                  LK_W_BITS - 5);
-            int ixval = lk_descale(lk_tap(g00.x, iw00) + lk_tap(g01.x, iw01) + lk_tap(g10.x, iw10) + lk_tap(g11.x, iw11),
-                                   LK_W_BITS);
-            int iyval = lk_descale(lk_tap(g00.y, iw00) + lk_tap(g01.y, iw01) + lk_tap(g10.y, iw10) + lk_tap(g11.y, iw11),
-                                   LK_W_BITS);
-            // OpenCV stores these as int16 (Iptr/dIptr are short)
-            ival = wvalid[s] ? (int)(short)ival : 0;
-            ixval = wvalid[s] ? (int)(short)ixval : 0;
-            iyval = wvalid[s] ? (int)(short)iyval : 0;
-            Iv[s] = ival;
-            Ix[s] = ixval;
-            Iy[s] = iyval;
-            sA11 += (long long)(ixval * ixval);
-            sA12 += (long long)(ixval * iyval);
-            sA22 += (long long)(iyval * iyval);
-        }
-        sA11 = wave_sum_i64(sA11);
-        sA12 = wave_sum_i64(sA12);
-        sA22 = wave_sum_i64(sA22);
-        double dA11 = (double)sA11, dA12 = (double)sA12, dA22 = (double)sA22;   // < 2^37: exact
-        if (LK_WAVES > 1) {
-            if ((threadIdx.x & 63) == 0) {
-                xch[xpar][wave_id][0] = dA11;
-                xch[xpar][wave_id][1] = dA12;
-                xch[xpar][wave_id][2] = dA22;
-            }
-            __syncthreads();
-            dA11 = dA12 = dA22 = 0.0;
-#pragma unroll
-            for (int w = 0; w < LK_WAVES; ++w) {
-                dA11 += xch[xpar][w][0];
-                dA12 += xch[xpar][w][1];
-                dA22 += xch[xpar][w][2];
-            }
-            xpar ^= 1;
         }
         n_templates++;
-        // (float) of the exact sum held as a double is the correctly rounded value, the same float (float)(int64 sum) is
-        const float A11 = (float)dA11 * FLT_SCALE;
-        const float A12 = (float)dA12 * FLT_SCALE;
-        const float A22 = (float)dA22 * FLT_SCALE;
-        float D = A11 * A22 - A12 * A12;
-        const float minEig =
-            (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * KLT_WIN * KLT_WIN);
-        if (minEig < 1e-4f || D < 1.1920929e-07f) {
+        if (!gate[level]) {
             if (level == 0) status = 0;
             continue;
         }
-        D = 1.f / D;
+        const float D = Dinv[level];
         nx -= half;
         ny -= half;
-        // the neighbourhood fetched at the top of the level goes to LDS now (its latency ran under the template work)
-        if (staged) {
-            __syncthreads();   // readers of the previous level's tile are done
-#pragma unroll
-            for (int k = 0; k < LK_TILE_LOADS; ++k) {
-                const int idx = (int)threadIdx.x + LK_THREADS * k;
-                if (idx < LK_TILE_DWORDS) tile[idx] = tile_regs[k];
-            }
-            __syncthreads();
-        }
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < 30; ++j) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
@@ -1143,63 +1219,62 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
                 if (level == 0) status = 0;
                 break;
             }
-            a = nx - inx;
-            b = ny - iny;
-            iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
-            iw01 = __float2int_rn(a * (1.f - b) * (1 << LK_W_BITS));
-            iw10 = __float2int_rn((1.f - a) * b * (1 << LK_W_BITS));
-            iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
+            const float a = nx - inx, b = ny - iny;
+            const int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << LK_W_BITS));
+            const int iw01 = __float2int_rn(a * (1.f - b) * (1 << LK_W_BITS));
+            const int iw10 = __float2int_rn((1.f - a) * b * (1 << LK_W_BITS));
+            const int iw11 = (1 << LK_W_BITS) - iw00 - iw01 - iw10;
             // per-lane partial sums stay in 32 bits: |diff| <= 8160 (8-bit pixels with 5 fractional bits), |Ix|, |Iy| <= 4080
             // (Scharr 3/10/3 of 8-bit pixels), seven slots: < 2.4e8
             int sb1 = 0, sb2 = 0;
-            const int rx = inx - tx0, ry = iny - ty0;
-            if (staged && rx >= 0 && rx <= LK_TILE_W - 22 && ry >= 0 && ry <= LK_TILE_H - 22) {
+            const int rx = inx - tx0[level], ry = iny - ty0[level];
+            if (staged[level] && rx >= 0 && rx <= LK_TILE_W - 22 && ry >= 0 && ry <= LK_TILE_H - 22) {
                 // LDS-qualified pointer: keeps these reads ds_read (the compiler otherwise sinks the last slot of this
                 // branch and of the global-memory branch below into one block of flat loads -- a second round trip)
                 typedef const __attribute__((address_space(3))) uint8_t *lds_bytes;
-                const lds_bytes t = (lds_bytes)tile + ry * LK_TILE_W + rx;
+                const lds_bytes t = (lds_bytes)tile[level] + ry * LK_TILE_W + rx;
                 // (a lane without a pixel in slot s holds Ix = Iy = 0 there: its products vanish, no branch needed)
 #pragma unroll
-                for (int s = 0; s < LK_SLOTS; ++s) {
-                    const lds_bytes j0 = t + wy[s] * LK_TILE_W + wx[s];
+                for (int sl = 0; sl < LK_SLOTS; ++sl) {
+                    const lds_bytes j0 = t + wy[sl] * LK_TILE_W + wx[sl];
                     const lds_bytes j1 = j0 + LK_TILE_W;
                     int acc = lk_tap_acc(j0[0], iw00, 1 << (LK_W_BITS - 5 - 1));   // the rounding term of lk_descale rides along
                     acc = lk_tap_acc(j0[1], iw01, acc);
                     acc = lk_tap_acc(j1[0], iw10, acc);
                     acc = lk_tap_acc(j1[1], iw11, acc);
-                    const int diff = (acc >> (LK_W_BITS - 5)) - Iv[s];
-                    sb1 = lk_tap_acc(diff, Ix[s], sb1);
-                    sb2 = lk_tap_acc(diff, Iy[s], sb2);
+                    const int diff = (acc >> (LK_W_BITS - 5)) - Iv[level][sl];
+                    sb1 = lk_tap_acc(diff, Ix[level][sl], sb1);
+                    sb2 = lk_tap_acc(diff, Iy[level][sl], sb2);
                 }
             } else {
 #pragma unroll
-                for (int s = 0; s < LK_SLOTS; ++s) {
-                    const uint8_t *j0 = J.img + (ptrdiff_t)(iny + wy[s]) * J.istride + (inx + wx[s]);
+                for (int sl = 0; sl < LK_SLOTS; ++sl) {
+                    const uint8_t *j0 = J.img + (ptrdiff_t)(iny + wy[sl]) * J.istride + (inx + wx[sl]);
                     const uint8_t *j1 = j0 + J.istride;
                     int acc = lk_tap_acc(j0[0], iw00, 1 << (LK_W_BITS - 5 - 1));
                     acc = lk_tap_acc(j0[1], iw01, acc);
                     acc = lk_tap_acc(j1[0], iw10, acc);
                     acc = lk_tap_acc(j1[1], iw11, acc);
-                    const int diff = (acc >> (LK_W_BITS - 5)) - Iv[s];
-                    sb1 = lk_tap_acc(diff, Ix[s], sb1);
-                    sb2 = lk_tap_acc(diff, Iy[s], sb2);
+                    const int diff = (acc >> (LK_W_BITS - 5)) - Iv[level][sl];
+                    sb1 = lk_tap_acc(diff, Ix[level][sl], sb1);
+                    sb2 = lk_tap_acc(diff, Iy[level][sl], sb2);
                 }
             }
             n_iters++;
-            // The wavefront's sums of the low (unsigned) and high (signed) 16-bit halves, each below 2^22; round 5: the four wavefronts
-            // exchange THESE integers (one 16-byte store, four 16-byte loads, integer adds) and the halves are recombined in double
-            // precision once -- rounds 1-4 recombined per wavefront and added four doubles per sum, two dependent conversions and three
-            // dependent f64 additions on every iteration's serial path.  Every partial sum is an exact integer either way: the same
-            // double, the same float.
+            LKPROF(2);
+            // The wavefront's sums of the low (unsigned) and high (signed) 16-bit halves, each below 2^22; the wavefronts exchange
+            // THESE integers (one 16-byte store, four 16-byte loads, integer adds) and the halves are recombined in double precision
+            // once.  Every partial sum is an exact integer: the same double, the same float as a 64-bit sum.
             int h4[4] = {dpp_scan_add_i32(sb1 & 0xffff), dpp_scan_add_i32(sb1 >> 16), dpp_scan_add_i32(sb2 & 0xffff), dpp_scan_add_i32(sb2 >> 16)};
+            LKPROF(3);
             if (LK_WAVES > 1) {
-                int4 *slots = reinterpret_cast<int4 *>(&xch[xpar][0][0]);   // one 32-byte slot per wavefront: its first 16 bytes
-                if ((threadIdx.x & 63) == 0) slots[2 * wave_id] = make_int4(h4[0], h4[1], h4[2], h4[3]);
+                int4 *slots = reinterpret_cast<int4 *>(&xch[xpar][0][0]);   // one 96-byte slot per wavefront: its first 16 bytes
+                if ((threadIdx.x & 63) == 0) slots[6 * wave_id] = make_int4(h4[0], h4[1], h4[2], h4[3]);
                 __syncthreads();
                 h4[0] = h4[1] = h4[2] = h4[3] = 0;
 #pragma unroll
                 for (int w = 0; w < LK_WAVES; ++w) {
-                    const int4 v = slots[2 * w];
+                    const int4 v = slots[6 * w];
                     h4[0] += v.x;
                     h4[1] += v.y;
                     h4[2] += v.z;
@@ -1207,11 +1282,12 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
                 }
                 xpar ^= 1;
             }
+            LKPROF(4);
             const double db1 = (double)h4[1] * 65536.0 + (double)h4[0], db2 = (double)h4[3] * 65536.0 + (double)h4[2];
             const float b1 = (float)db1 * FLT_SCALE;
             const float b2 = (float)db2 * FLT_SCALE;
-            const float dx = (A12 * b2 - A22 * b1) * D;
-            const float dy = (A12 * b1 - A11 * b2) * D;
+            const float dx = (A12[level] * b2 - A22[level] * b1) * D;
+            const float dy = (A12[level] * b1 - A11[level] * b2) * D;
             nx += dx;
             ny += dy;
             outx = nx + half;
@@ -1224,6 +1300,7 @@ __device__ __forceinline__ int lk_one_way(const PyrView &A, const PyrView &B, fl
             }
             pdx = dx;
             pdy = dy;
+            LKPROF(5);
         }
     }
     nx_io = outx;
@@ -1282,10 +1359,13 @@ __device__ __forceinline__ void d_lk_track(const PyrView &A, const PyrView &B, c
         }
     }
     unsigned n_templates = 0, n_iters = 0;
-    __shared__ uint32_t tile[LK_TILE_DWORDS];
-    __shared__ double xch[2][LK_WAVES][4];
+    __shared__ uint32_t tile[KLT_LEVELS][LK_TILE_DWORDS];
+    __shared__ double xch[2][LK_WAVES][3 * KLT_LEVELS];
     int xpar = 0;
-    int status = lk_one_way(A, B, cx, cy, nx, ny, wx, wy, wvalid, n_templates, n_iters, tile, xch, xpar);
+    long long lk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long lk_t = (long long)__builtin_readcyclecounter();
+    const long long lk_t0 = lk_t;
+    int status = lk_one_way(A, B, cx, cy, nx, ny, wx, wy, wvalid, n_templates, n_iters, tile, xch, xpar, lk_acc, lk_t);
     const int cols = A.lv[0].w, rows = A.lv[0].h;
     if (nx < 20 || nx >= cols - 20 || ny < 20 || ny >= rows - 20) status = 0;
     if (status) {
@@ -1295,11 +1375,20 @@ __device__ __forceinline__ void d_lk_track(const PyrView &A, const PyrView &B, c
     }
     if (status) {
         float rx = cx, ry = cy;
-        int st2 = lk_one_way(B, A, nx, ny, rx, ry, wx, wy, wvalid, n_templates, n_iters, tile, xch, xpar);
+        int st2 = lk_one_way(B, A, nx, ny, rx, ry, wx, wy, wvalid, n_templates, n_iters, tile, xch, xpar, lk_acc, lk_t);
         const float dx = cx - rx, dy = cy - ry;
         const double nrm = sqrt((double)dx * (double)dx + (double)dy * (double)dy);
         if (!st2 || nrm > 0.5) status = 0;
     }
+#ifdef XRHIP_KPROF
+    if (lane == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_lk_prof[i], (unsigned long long)lk_acc[i]);
+        atomicAdd(&g_lk_prof[6], 1ull);
+        atomicAdd(&g_lk_prof[7], (unsigned long long)((long long)__builtin_readcyclecounter() - lk_t0));
+    }
+#else
+    (void)lk_t0;
+#endif
     if (lane == 0) {
         status_out[pt] = (uint8_t)status;
         if (status) next_io[pt] = make_double2((double)nx, (double)ny);
@@ -1380,10 +1469,12 @@ __global__ __launch_bounds__(LK_THREADS) void k_lk_plain(PyrView A, PyrView B, c
     const float2 p = prev[pt];
     float2 q = next_io[pt];
     unsigned a = 0, b = 0;
-    __shared__ uint32_t tile[LK_TILE_DWORDS];
-    __shared__ double xch[2][LK_WAVES][4];
+    __shared__ uint32_t tile[KLT_LEVELS][LK_TILE_DWORDS];
+    __shared__ double xch[2][LK_WAVES][3 * KLT_LEVELS];
     int xpar = 0;
-    int status = lk_one_way(A, B, p.x, p.y, q.x, q.y, wx, wy, wvalid, a, b, tile, xch, xpar);
+    long long lk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long lk_t = 0;
+    int status = lk_one_way(A, B, p.x, p.y, q.x, q.y, wx, wy, wvalid, a, b, tile, xch, xpar, lk_acc, lk_t);
     if (lane == 0) {
         status_out[pt] = (uint8_t)status;
         next_io[pt] = q;
