@@ -45,6 +45,7 @@ reduction of the wall time over RCCL.  --sequences-per-gpu S puts S sequences on
 XRSLAMAmdInstance*): `value` is then the aggregate over all sequences of all GPUs.
 """
 import argparse
+import gc as pygc
 import glob
 import json
 import os
@@ -114,6 +115,16 @@ def roofline_extras(kernel_rev, workload="s1"):
         else:
             note = "committed PMC passes are of workload %s, this line is %s: not shown" % (wl, workload)
     return peaks, traffic, note
+
+
+def kernel_table(kernel_rev, workload="s1"):
+    """The committed rocprofv3 kernel-trace summary of THIS kernel revision on this workload (profiles/r*_kernel_stats.json, written by
+    tools/make_profile_summary.py from the trace of `bench.py --steps 100 --warmup 40`): kernel time per frame and per kernel.  None
+    when the newest committed trace is of other kernels."""
+    ks = newest_profile("r*_kernel_stats.json")
+    if not ks or ks.get("_kernel_rev") != kernel_rev or ks.get("_workload", "s1") != workload:
+        return None
+    return ks
 
 
 def device_power_state(index):
@@ -479,6 +490,12 @@ def main():
         if errs:
             raise SystemExit("sequence thread failed: " + errs[0])
 
+    # The interpreter's cyclic collector out of the measurement: with torch imported a full collection walks ~10^6 objects -- tens of
+    # milliseconds, once per process, whenever the allocation counters happen to trip (rounds 4-5: "a ~40 ms hiccup in a different leg
+    # every run", absent from the torch-free replays of tools/find_stall.py).  Everything that exists now is set-up: collect once, move it
+    # to the permanent generation (later collections only see what the measurement itself allocates) and leave the collector on.
+    pygc.collect()
+    pygc.freeze()
     # untimed frames (pre-roll + warmup), frame by frame when there is one sequence so that the one-off they hide can be stated
     pre_ms = []
     if preroll + args.warmup > 0:
@@ -625,6 +642,16 @@ def main():
                             "algorithmic_bytes_per_launch": round(lk_bytes / n_launch, 1),
                             "launch_us": round(lk_ms * 1e3, 3), **({"batched": lk_note} if lk_note else {})},
             "traffic_source": traffic_note,
+            # how much of a frame the device is busy: kernel time per frame of the committed kernel trace of this revision (rocprofv3;
+            # kernels on the auxiliary streams overlap the main chain, so this is an upper bound of the busy fraction) over this run's
+            # ms_per_step -- the frame IS its kernels' latency -- and where that time goes, kernel by kernel
+            **((lambda ks: {"device_busy_frac": round(ks["kernel_ms_per_frame"] / (1e3 * elapsed / args.steps), 4) if S == 1 else None,
+                            "kernel_ms_per_frame": ks["kernel_ms_per_frame"],
+                            "kernel_us_per_frame": {k: v["us_per_frame"] for k, v in list(ks["kernels"].items())[:16]},
+                            "kernel_table_source": "profiles/%s (rocprofv3 --kernel-trace of this kernel revision, %d frames)" % (
+                                ks["_source"], ks["_frames"])})(kernel_table(kernel_rev, args.workload))
+               if kernel_table(kernel_rev, args.workload) else {"device_busy_frac": None,
+                                                                "kernel_table_source": "no committed kernel trace of this kernel revision"}),
             # the whole GPU against the HBM roofline: ALGORITHMIC bytes of the tracker stage (B_trk = CLAHE + pyramid +
             # Scharr + Harris passes of every frame + the LK templates and iterations the kernels counted) of ALL sequences of this
             # rank over the timed wall clock.  (The BA's ~0.1-0.6 MB per iteration are not in it: a lower bound.)

@@ -396,6 +396,10 @@ typedef struct xrhip_group_stats {
 } xrhip_group_stats;
 int xrhip_group_set_profiling(xrhip_group *group, int enable);
 int xrhip_group_get_stats(xrhip_group *group, xrhip_group_stats *out, int reset);
+/* 1: the group's hardware-queue split (two queues for the batches, two for the members' window solves) is in effect -- it needs
+ * GPU_MAX_HW_QUEUES=2 in the environment before the process's first HIP call; 0: the slower unprioritised arrangement (same results,
+ * ~15 % less grouped throughput); < 0: error.  (Round 5 printed this to stderr; XRHIP_GROUP_VERBOSE=1 still does.) */
+int xrhip_group_queue_split(xrhip_group *group);
 
 /* parity/testing aids (not part of the reference interface): the unreduced normal equations of one
  * linearisation, and the MFMA Schur product kernel on arbitrary inputs. */
@@ -418,6 +422,8 @@ int xrhip_study_schur_precision(const double *W, const double *w, int L, int P, 
 /* development aid: accumulated in-kernel phase timers (100 MHz ticks) of the BA kernels; all zero unless the
  * library was built with -DXRHIP_KPROF (csrc/build.sh, XR_VARIANT=kprof) */
 void xrhip_debug_kprof(long long *out32, int reset);
+/* LK phase timers of -DXRHIP_KPROF builds (shader cycles summed over all points: 0-5 phases, 6 points, 7 kernel; zeros otherwise) */
+void xrhip_debug_lkprof(long long *out8, int reset);
 
 #ifdef __cplusplus
 }

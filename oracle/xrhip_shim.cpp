@@ -239,6 +239,7 @@ int xrhip_group_destroy(xrhip_group *g) {
     return 0;
 }
 int xrhip_group_set_profiling(xrhip_group *, int) { return 0; }
+int xrhip_group_queue_split(xrhip_group *) { return 0; }   // nothing is queued on the CPU build
 int xrhip_group_get_stats(xrhip_group *, xrhip_group_stats *out, int) {
     if (out) std::memset(out, 0, sizeof(*out));
     return 0;

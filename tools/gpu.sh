@@ -18,7 +18,7 @@ set -uo pipefail
 R="$(cd "$(dirname "$0")/.." && pwd)"
 TAG="${1:?tag}"; shift
 O="$R/gpurun_out"; mkdir -p "$O"; cd "$R"
-BENCH_PROF="--steps 100 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --sustained-frames 0 --no-profile"
+BENCH_PROF="--steps 100 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --no-profile"
 digest() { python - "$1" <<'PY'
 import json, sys
 try:
@@ -57,13 +57,13 @@ for step in "$@"; do
             env $ENVS timeout 500 python bench.py --sequences-per-gpu "$S" --steps 200 --warmup 50 --cpu-frames 0 $ARGS > "$O/bench_${TAG}_multi${S}_$n.json" 2> "$O/bench_${TAG}_multi${S}_$n.err"
             digest "$O/bench_${TAG}_multi${S}_$n.json"; tail -2 "$O/bench_${TAG}_multi${S}_$n.err" ;;
     procs)  set -- $arg; N="$1"; Q="${2:-2}"; S="${3:-1}"   # procs:N Q [S]: N processes on this GPU (gloo), Q hardware queues each, S grouped sequences in each
-            GPU_MAX_HW_QUEUES=$Q OMP_NUM_THREADS=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((29500 + N + Q + S)) bench.py --gpus "$N" --backend gloo --sequences-per-gpu "$S" --steps 200 --warmup 50 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --sustained-frames 0 > "$O/procs_${TAG}_${N}_${Q}_$S.json" 2> "$O/procs_${TAG}_${N}_${Q}_$S.err"
+            GPU_MAX_HW_QUEUES=$Q OMP_NUM_THREADS=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((29500 + N + Q + S)) bench.py --gpus "$N" --backend gloo --sequences-per-gpu "$S" --steps 200 --warmup 50 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 > "$O/procs_${TAG}_${N}_${Q}_$S.json" 2> "$O/procs_${TAG}_${N}_${Q}_$S.err"
             digest "$O/procs_${TAG}_${N}_${Q}_$S.json"; tail -2 "$O/procs_${TAG}_${N}_${Q}_$S.err" ;;
     rccl1)  timeout 120 python tools/check_rccl.py > "$O/rccl1_$TAG.txt" 2>&1; tail -2 "$O/rccl1_$TAG.txt" ;;
     trace)  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof_${TAG}_$n" -o full -- python "$R/bench.py" ${arg:-$BENCH_PROF} > "$O/prof_${TAG}_$n.log" 2>&1); kernel_avgs "$O/prof_${TAG}_$n" ;;
     pmc)    (cd /tmp && export TMPDIR=/tmp
-             timeout 150 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$O/pmc_$TAG/MFMA" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --sustained-frames 0 --no-profile $arg > "$O/pmc_${TAG}_MFMA.log" 2>&1
-             for C in FETCH_SIZE WRITE_SIZE; do timeout 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$O/pmc_$TAG/$C" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --sustained-frames 0 --no-profile $arg > "$O/pmc_${TAG}_$C.log" 2>&1; done); ls "$O/pmc_$TAG" ;;
+             timeout 150 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$O/pmc_$TAG/MFMA" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --no-profile $arg > "$O/pmc_${TAG}_MFMA.log" 2>&1
+             for C in FETCH_SIZE WRITE_SIZE; do timeout 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$O/pmc_$TAG/$C" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --no-profile $arg > "$O/pmc_${TAG}_$C.log" 2>&1; done); ls "$O/pmc_$TAG" ;;
     pmcg)   # the grouped run's counters (S = ${arg:-8} members): a batched launch should move ~S times a solo launch's bytes in about the time of one
             S="${arg:-8}"
             (cd /tmp && export TMPDIR=/tmp
@@ -71,7 +71,7 @@ for step in "$@"; do
     ab)     lib="$R/xrslam_amd/lib/libxrslam_hip_$arg.so"
             for rep in 1 2; do for v in default "$arg"; do
               e="XR_DUMMY=0"; [ "$v" != default ] && e="XRSLAM_HIP_LIB=$lib"
-              env $e timeout 200 python bench.py --steps 300 --warmup 50 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --sustained-frames 0 2>/dev/null > "$O/ab_${TAG}_${v}_$rep.json"; echo "$v rep$rep:"; digest "$O/ab_${TAG}_${v}_$rep.json" | head -2
+              env $e timeout 200 python bench.py --steps 300 --warmup 50 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 2>/dev/null > "$O/ab_${TAG}_${v}_$rep.json"; echo "$v rep$rep:"; digest "$O/ab_${TAG}_${v}_$rep.json" | head -2
             done; done
             for v in default "$arg"; do e="XR_DUMMY=0"; [ "$v" != default ] && e="XRSLAM_HIP_LIB=$lib"
               env $e timeout 200 python bench.py --workload s4 --steps 100 2>/dev/null | python -c "
@@ -79,10 +79,10 @@ import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); p
     abenv)  set -- $arg; VAR="$1"; REPS="${2:-3}"
             for r in $(seq "$REPS"); do for mode in off on; do
               if [ $mode = on ]; then export "$VAR"=1; else unset "$VAR"; fi
-              timeout 200 python bench.py --steps 300 --warmup 50 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --sustained-frames 0 2>/dev/null > "$O/abenv_${TAG}_${mode}_$r.json"; echo "$VAR $mode rep $r:"; digest "$O/abenv_${TAG}_${mode}_$r.json" | head -1
+              timeout 200 python bench.py --steps 300 --warmup 50 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 2>/dev/null > "$O/abenv_${TAG}_${mode}_$r.json"; echo "$VAR $mode rep $r:"; digest "$O/abenv_${TAG}_${mode}_$r.json" | head -1
             done; done; unset "$VAR" ;;
-    hostprof) XRHIP_HOSTPROF=1 timeout 300 python bench.py --steps 150 --warmup 50 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --sustained-frames 0 --threading inline > "$O/hostprof_$TAG.json" 2> "$O/hostprof_$TAG.txt"; grep hostprof "$O/hostprof_$TAG.txt" | cut -c1-130 | tail -40 ;;
-    kprint) XRSLAM_HIP_LIB="$R/xrslam_amd/lib/libxrslam_hip_kprint.so" timeout 200 python bench.py --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --sustained-frames 0 --threading inline 2>/dev/null | grep -v '^{' > "$O/blocks_$TAG.txt"; grep "${arg:-kb_}" "$O/blocks_$TAG.txt" | tail -12 ;;
+    hostprof) XRHIP_HOSTPROF=1 timeout 300 python bench.py --steps 150 --warmup 50 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --threading inline > "$O/hostprof_$TAG.json" 2> "$O/hostprof_$TAG.txt"; grep hostprof "$O/hostprof_$TAG.txt" | cut -c1-130 | tail -40 ;;
+    kprint) XRSLAM_HIP_LIB="$R/xrslam_amd/lib/libxrslam_hip_kprint.so" timeout 200 python bench.py --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --threading inline 2>/dev/null | grep -v '^{' > "$O/blocks_$TAG.txt"; grep "${arg:-kb_}" "$O/blocks_$TAG.txt" | tail -12 ;;
     multiq) for Q in ${arg:-4 8}; do echo "GPU_MAX_HW_QUEUES=$Q"; GPU_MAX_HW_QUEUES=$Q timeout 300 "$R/xrslam_amd/bin/xr-multiq" 1500 > "$O/multiq_${TAG}_q$Q.jsonl" 2> "$O/multiq_${TAG}_q$Q.err"; python - "$O/multiq_${TAG}_q$Q.jsonl" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]

@@ -62,6 +62,12 @@ for k, (t, n) in sorted(tot.items(), key=lambda x: -x[1][0]):
     lines.append("| `%s` | %d | %.2f | %.2f | %.1f / %.1f / %.1f | %.1f |" % (k, n, t / 1e6, t / 1e3 / n, d[0] / 1e3, d[len(d) // 2] / 1e3, d[-1] / 1e3,
                                                                    100 * t / total))
 open(os.path.join(ROOT, "profiles", "%s_full_%s_kernel_stats.md" % (rnd, ver)), "w").write("\n".join(lines) + "\n")
+# the same table for bench.py (`device_busy_frac`, `kernel_us_per_frame` of the line -- shown beside timings of the same kernel revision only)
+json.dump({"_kernel_rev": bj.get("kernel_rev"), "_workload": os.environ.get("XR_WORKLOAD", "s1"), "_frames": frames,
+           "_source": "%s_full_%s_kernel_stats.md" % (rnd, ver), "kernel_ms_per_frame": round(total / 1e6 / frames, 4),
+           "kernels": {k.replace("xrhip::", ""): {"calls": n, "avg_us": round(t / 1e3 / n, 2), "us_per_frame": round(t / 1e3 / frames, 2)}
+                       for k, (t, n) in sorted(tot.items(), key=lambda x: -x[1][0])}},
+          open(os.path.join(ROOT, "profiles", "%s_kernel_stats.json" % rnd), "w"), indent=1)
 open(os.path.join(ROOT, "profiles", "%s_full_%s_bench.json" % (rnd, ver)), "w").write(b + "\n")
 
 pmc_dir = os.path.join(go, "pmc_%s" % tag)

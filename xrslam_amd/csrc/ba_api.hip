@@ -1440,8 +1440,7 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
     for (int guard = 0; guard < 4 * (P->max_iterations + 8) && !done; ++guard) {
         const int seq = ++c->seq;
         if (wbatch) {
-            rc = submit_window(GK_WROUND, seq, mode);
-            c->stats.n_solve_try++;
+            rc = submit_window(GK_WROUND, seq, mode);   // (timed by the group as part of its GK_WROUND batch: no event pair, no count here)
         } else if (spec_ready) {   // (the chain that built this linearisation is ahead of us on this very stream)
             rc = launch_solve_try(c, d, p, cam, imu, sx, sy, false, mode, seq, true, &p2);
         } else {
@@ -1468,7 +1467,7 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
             const int trials = std::max(0, it_now - iter_seen);
             iter_seen = it_now;
             c->stats.n_trials += trials;
-            if (c->profiling && !c->pending.empty()) c->pending.back().iter_before = trials;
+            if (c->profiling && !wbatch && !c->pending.empty()) c->pending.back().iter_before = trials;   // this launch's own event pair
         }
         int st = c->h_ctl->status;
         for (int wguard = 0; st == ST_NEED_TRIALS && wguard < 64; ++wguard) {   // run of rejected trials, 8 per launch

@@ -9,8 +9,8 @@
 //   kb_lin_all           per-factor residuals + Jacobians of all four factor families
 //   kb_landmark_vision   per-landmark H_ll, g_l, dense cross-term row W_l; per-frame-pair reprojection blocks
 //   kb_assemble          deterministic gather of all factor blocks into the (15F)^2 frame Hessian
-//   kb_cost_prepare      cost, gradient norm, Jacobi scales, dogleg diagonal, landmark Schur weights
-//   kb_schur_aux         T = W^T diag(omega) W on the f64 matrix cores + the solve's wide auxiliary passes
+//   kb_prepare           Jacobi scales, dogleg diagonal, landmark Schur weights
+//   kb_schur_aux         T = W^T diag(omega) W on the f64 matrix cores + the solve's wide auxiliary passes; cost + gradient norm
 //   kb_solve_try         reduced system, LDS-resident blocked Cholesky, dogleg data, trust-region trials
 // The bodies are __device__ functions (..._item: one thread / wavefront per item, ..._block: one workgroup).
 // Summation orders are fixed (no floating-point atomics), so results are run-to-run identical.
@@ -1981,15 +1981,6 @@ __device__ __forceinline__ void d_landmark_vision(const BaDims &d, const BaPtrs 
 #endif
 }
 __global__ __launch_bounds__(64) void kb_landmark_vision(BaDims d, BaPtrs p) { d_landmark_vision(d, p, blockIdx.x); }
-
-// total cost, gradient max-norm and the per-solve preparation, one workgroup
-__global__ __launch_bounds__(256) void kb_cost_prepare(BaDims d, BaPtrs p) {
-    __shared__ double scratch[8];
-    sum_cost_block(d, p, scratch);
-    __syncthreads();
-    gradmax_block(d, p, scratch);
-    prepare_block(d, p);
-}
 
 // Speculative linearisation (window solves).  While kb_trials_wide costs the first candidate of a round on its 32
 // workgroups, the rest of the chip linearises the problem AT that candidate -- spec_state_block forms it (the same

@@ -55,6 +55,7 @@ struct GroupQueueState {
 
 struct xrhip_group {
     int device = 0;
+    int queue_split = 0;                  // 1: two hardware queues carry the batches, two the members' window solves (xrhip_group_queue_split)
     GroupQueueState qs[GQ_COUNT];
     std::atomic<bool> quit{false};
     std::atomic<int> members{0};
@@ -472,9 +473,11 @@ int xrhip_group_create(xrhip_group **out) {
     const char *qe = std::getenv("GPU_MAX_HW_QUEUES"), *pe = std::getenv("XRHIP_GROUP_PRIORITY");
     const bool want_prio = pe ? std::atoi(pe) != 0 : (qe && std::atoi(qe) > 0 && std::atoi(qe) <= 2);
     const bool use_prio = want_prio && hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) == hipSuccess && prio_high != prio_low;
-    // The split above rests on a process-global knob an embedding application may not know about: say so once instead of silently
-    // running the slower arrangement (XRHIP_GROUP_QUIET=1 silences it; the group works either way, bit for bit).
-    if (!(qe && std::atoi(qe) > 0 && std::atoi(qe) <= 2) && !std::getenv("XRHIP_GROUP_QUIET")) {
+    // The split above rests on a process-global knob an embedding application may not know about.  A library does not write into its
+    // host's stderr unasked: the condition is recorded in the group and can be queried (xrhip_group_queue_split: 1 = the
+    // 2 + 2 split is in effect, 0 = the slower unprioritised arrangement; bench.py prints it); XRHIP_GROUP_VERBOSE=1 says it once.
+    g->queue_split = use_prio ? 1 : 0;
+    if (!use_prio && std::getenv("XRHIP_GROUP_VERBOSE")) {
         static std::atomic<bool> warned{false};
         if (!warned.exchange(true))
             std::fprintf(stderr, "xrslam_hip: instance group created with GPU_MAX_HW_QUEUES=%s: the group's queue split (two hardware queues for "
@@ -571,6 +574,11 @@ int xrhip_group_get_stats(xrhip_group *g, xrhip_group_stats *out, int reset) {
     out->ms[GK_GATE_SLOT] = g->gate_on.load() ? 1.0 : 0.0;
     if (reset) g->gate_opens = g->gate_full = g->gate_timeouts = 0;
     return XRHIP_OK;
+}
+
+int xrhip_group_queue_split(xrhip_group *g) {
+    if (!g) return xr_fail(XRHIP_EINVAL, "xrhip_group_queue_split: null group");
+    return g->queue_split;
 }
 
 }   // extern "C"
