@@ -29,6 +29,21 @@ void hc_reprojection_cached(const double *st_t, const double *st_r, double inv_d
     eval_reprojection(t, rf, inv_depth, z_t, z_r, cam, sic2[0], sic2[1], r4 + 2, true, Jt24 + 12, Jr24 + 12, Jl);
     if (!ref_free) std::memset(Jr24 + 12, 0, sizeof(double) * 12);
 }
+// the free-target form with per-frame / per-camera tables (frame_table, ext_table, eval_reprojection_tgt) beside eval_reprojection:
+// r (2 + 2) and Jt (12 + 12)
+void hc_reprojection_tgt(const double *st_t, const double *st_r, double inv_depth, const double *zt, const double *zr,
+                         const double *cam7, const double *sic2, double *r4, double *Jt24) {
+    Ext cam{Q4{cam7[0], cam7[1], cam7[2], cam7[3]}, v3(cam7[4], cam7[5], cam7[6])};
+    const FState t = load_state(st_t), rf = load_state(st_r);
+    const V3 z_t = v3(zt[0], zt[1], zt[2]), z_r = v3(zr[0], zr[1], zr[2]);
+    const ObsConst c = reprojection_constants(rf, inv_depth, z_t, z_r, cam);
+    double ftab[12], ctab[12];
+    frame_table(t, ftab);
+    ext_table(cam, ctab);
+    eval_reprojection_tgt(ftab, ctab, c, z_t, sic2[0], sic2[1], r4, true, Jt24);
+    double Jr[12], Jl[2];
+    eval_reprojection(t, rf, inv_depth, z_t, z_r, cam, sic2[0], sic2[1], r4 + 2, true, Jt24 + 12, Jr, Jl);
+}
 void hc_rotation(const double *st_t, const double *st_r, const double *zt, const double *zr, const double *cam7,
                  const double *sic2, double *r2, double *Jq6) {
     Ext cam{Q4{cam7[0], cam7[1], cam7[2], cam7[3]}, v3(cam7[4], cam7[5], cam7[6])};

@@ -97,7 +97,8 @@ __host__ __device__ __forceinline__ int chain_cache_stride(int M) { return (M + 
 // | ref free << 17 (as a double).  An evaluation is then ~450 instead of ~1000 double-precision instructions per lane -- and the
 // linearisation of the reprojection factors, not the IMU factor, was the longest stream of a round (profiles/r03_ab_variants.md).
 __device__ __forceinline__ double obs_eval_cached(const BaDims &d, const double *oca, int Mp, int o, const double *state, const Ext &cam,
-                                                  double sx, double sy, bool want_j, double *rec) {
+                                                  double sx, double sy, bool want_j, double *rec, const double *ftab, const int *slot_of,
+                                                  const double *ctab) {
     const int inf = (int)oca[15 * Mp + o];
     const int ft = inf & 255, fr = (inf >> 8) & 255;
     const bool at = (inf >> 16) & 1, ar = (inf >> 17) & 1;
@@ -112,11 +113,17 @@ __device__ __forceinline__ double obs_eval_cached(const BaDims &d, const double 
     c.y_ref_center = v3(oca[6 * Mp + o], oca[7 * Mp + o], oca[8 * Mp + o]);
     c.x = v3(oca[9 * Mp + o], oca[10 * Mp + o], oca[11 * Mp + o]);
     const V3 zt = v3(oca[12 * Mp + o], oca[13 * Mp + o], oca[14 * Mp + o]);
-    const FState st = load_state(state + 16 * ft), sr = load_state(state + 16 * fr);
     double r[2], Jt[12], Jr[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Jr[i] = 0.0;
-    eval_reprojection_cached(st, sr, ar, c, zt, cam, sx, sy, r, want_j, Jt, Jr);
+    if (!ar) {
+        // free target, constant reference (every factor of localize_newframe, nearly every one of refine_subwindow): from the frame's
+        // table (ftab: R^T and p of the free frames at the state being evaluated, frame_table) and the camera's (ctab)
+        eval_reprojection_tgt(ftab + 12 * slot_of[ft], ctab, c, zt, sx, sy, r, want_j, Jt);
+    } else {
+        const FState st = load_state(state + 16 * ft), sr = load_state(state + 16 * fr);
+        eval_reprojection_cached(st, sr, ar, c, zt, cam, sx, sy, r, want_j, Jt, Jr);
+    }
     const double s = r[0] * r[0] + r[1] * r[1];
     if (want_j) {
         const double sc = d.robust ? sqrt(fmax(2.2250738585072014e-308, 1.0 / (1.0 + s))) : 1.0;
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
     __shared__ double s_vis[4][CHAIN_MAX_FREE][27];
     __shared__ int s_fail;
     __shared__ int s_free[CHAIN_MAX_FREE], s_slot[CHAIN_MAX_F], s_nfree;
+    __shared__ double s_ftab[2][CHAIN_MAX_FREE][12], s_ctab[12];   // frame_table of the free frames at x / at the candidate; ext_table
     __shared__ BaCtl s_ctl;
     const int tid = threadIdx.x, lane = tid & 63;
     // Who evaluates what.  A double-precision instruction costs its wavefront ~8 cycles of issue whatever the number of active
@@ -228,6 +236,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
     for (int e = wtid; e < XRHIP_IMU_DIM * NI; e += nt) recs[e] = p.imu_data[e];
     for (int e = wtid; e < NI * IMU_SCR; e += nt) scr[e] = 0.0;   // the blocks a linearisation writes are the same every round
     __syncthreads();
+    if (tid < nfree) frame_table(load_state(X + 16 * s_free[tid]), s_ftab[0][tid]);
+    else if (tid == 64) ext_table(cam, s_ctab);
     if (use_cache) {
         for (int o = wtid; o < M; o += nt) {
             const int ft = p.obs_tgt[o], fr = p.obs_ref[o];
@@ -244,8 +254,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
             }
             oca[15 * Mp + o] = (double)(ft | (fr << 8) | ((int)at << 16) | ((int)ar << 17));
         }
-        __syncthreads();
     }
+    __syncthreads();   // the table of constants, the frames' tables
     CPROF(0);   // set-up: control block, states, index slots
 
     bool relin = true;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
 #endif
             for (int o = otid; o < M; o += ostride) {
                 double rec[OREC];
-                const double co = use_cache ? obs_eval_cached(d, oca, Mp, o, X, cam, sx_, sy_, true, rec)
+                const double co = use_cache ? obs_eval_cached(d, oca, Mp, o, X, cam, sx_, sy_, true, rec, &s_ftab[0][0][0], s_slot, s_ctab)
                                             : obs_eval(d, p, o, X, p.depth, cam, sx_, sy_, true, rec);
                 oc[o] = co;
 #pragma unroll
@@ -779,12 +789,13 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
                         d15[k] = i >= 0 ? delta[i] : 0.0;
                     }
                     state_plus(X + 16 * f, d15, pose_free(p.fix[f]), motion_free(p.fix[f]), CS + 16 * f);
+                    if (s_slot[f] >= 0) frame_table(load_state(CS + 16 * f), s_ftab[1][s_slot[f]]);   // (this thread's own stores)
                 }
                 __syncthreads();
                 CPROF(14);  // trial: candidate states
                 double red[2] = {0, 0};   // cost, |x - candidate|^2
                 for (int o = otid; o < M; o += ostride)
-                    oc[o] = use_cache ? obs_eval_cached(d, oca, Mp, o, CS, cam, sx_, sy_, false, nullptr)
+                    oc[o] = use_cache ? obs_eval_cached(d, oca, Mp, o, CS, cam, sx_, sy_, false, nullptr, &s_ftab[1][0][0], s_slot, s_ctab)
                                       : obs_eval(d, p, o, CS, p.depth, cam, sx_, sy_, false, nullptr);
                 for (int o = otid; o < MR; o += ostride) oc[M + o] = rot_eval(d, p, o, CS, cam, sx_, sy_, false, nullptr);
                 if (imu_lane && wave >= 2) {   // lane k of wavefront 3: the rotation residual of factor k; of wavefront 2: the rest
@@ -850,6 +861,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
         }
         if (accepted) {
             for (int e = wtid; e < 16 * F; e += nt) X[e] = CS[e];
+            for (int e = wtid; e < 12 * nfree; e += nt) (&s_ftab[0][0][0])[e] = (&s_ftab[1][0][0])[e];   // the candidate's tables are x's now
         }
         if (tid == 0) trial_store(c, t);
         __syncthreads();

@@ -362,6 +362,69 @@ XD void eval_reprojection_cached(const FState &tgt, const FState &ref, bool ref_
         for (int j = 0; j < 3; ++j) Jr[6 * i + j] = -E[3 * i + j];
 }
 
+// The same factor once more for the case these LDS-resident solves meet nearly always -- constant landmark, constant reference frame,
+// free TARGET frame -- with everything that is the same for all factors of one target frame taken out of the factor (round 6): the
+// frame's R^T = q_mat(q_conj(q)) and p (frame_table, once per frame and evaluation point) and the camera extrinsics' R_c^T, p_c
+// (ext_table, once per solve).  Per factor that leaves two 3x3 matrix-vector products, three dot products and three 2x3 by 3x3
+// products: ~180 double-precision instructions where eval_reprojection_cached issues ~450 (quaternion rotations and two q_mat per
+// factor), and these kernels are bound by the instructions a wavefront issues.  Same mathematics, another order of operations than
+// eval_reprojection_cached: results agree to rounding (tests/test_ba_math_host.py), not bit for bit.
+XD void frame_table(const FState &f, double *tab12) {
+    const M3 Rt = q_mat(q_conj(f.q));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tab12[i] = Rt.m[i];
+    tab12[9] = f.p.x;
+    tab12[10] = f.p.y;
+    tab12[11] = f.p.z;
+}
+XD void ext_table(const Ext &cam, double *tab12) {
+    const M3 Rc = q_mat(q_conj(cam.q));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tab12[i] = Rc.m[i];
+    tab12[9] = cam.p.x;
+    tab12[10] = cam.p.y;
+    tab12[11] = cam.p.z;
+}
+XD void eval_reprojection_tgt(const double *ftab, const double *ctab, const ObsConst &c, V3 z_tgt, double sx, double sy, double *r,
+                              bool want_j, double *Jt) {
+    M3 RtT, RcT;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        RtT.m[i] = ftab[i];
+        RcT.m[i] = ctab[i];
+    }
+    const V3 b1 = c.b1, b2 = c.b2;
+    const V3 y_tgt_center = RtT * (c.x - v3(ftab[9], ftab[10], ftab[11]));
+    const V3 y_tgt = RcT * (y_tgt_center - v3(ctab[9], ctab[10], ctab[11]));
+    const double u0 = dot(b1, y_tgt), u1 = dot(b2, y_tgt), u2 = dot(z_tgt, y_tgt);
+    const double iu2 = 1.0 / u2;
+    r[0] = sx * (u0 * iu2);
+    r[1] = sy * (u1 * iu2);
+    if (!want_j) return;
+    const double d02 = -(u0 * iu2) * iu2, d12 = -(u1 * iu2) * iu2;
+    double A[6];
+    A[0] = sx * (iu2 * b1.x + d02 * z_tgt.x);
+    A[1] = sx * (iu2 * b1.y + d02 * z_tgt.y);
+    A[2] = sx * (iu2 * b1.z + d02 * z_tgt.z);
+    A[3] = sy * (iu2 * b2.x + d12 * z_tgt.x);
+    A[4] = sy * (iu2 * b2.y + d12 * z_tgt.y);
+    A[5] = sy * (iu2 * b2.z + d12 * z_tgt.z);
+    double B[6], C[6];
+    mul23(A, RcT, B);    // dr_dy_tgt_center
+    mul23(B, RtT, C);    // dr_dx
+    const V3 y = y_tgt_center;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // dr_dq_tgt = B hat(y_tgt_center)
+        Jt[6 * i + 0] = B[3 * i + 1] * y.z - B[3 * i + 2] * y.y;
+        Jt[6 * i + 1] = B[3 * i + 2] * y.x - B[3 * i + 0] * y.z;
+        Jt[6 * i + 2] = B[3 * i + 0] * y.y - B[3 * i + 1] * y.x;
+        Jt[6 * i + 3] = -C[3 * i + 0];
+        Jt[6 * i + 4] = -C[3 * i + 1];
+        Jt[6 * i + 5] = -C[3 * i + 2];
+    }
+}
+
 // CeresRotationPriorFactor::Evaluate.  Jq: 2x3 row-major.
 XD void eval_rotation(const FState &tgt, const FState &ref, V3 z_tgt, V3 z_ref, const Ext &cam, double sx, double sy,
                       double *r, bool want_j, double *Jq) {
