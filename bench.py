@@ -541,7 +541,14 @@ def main():
     # per-rank diagnostics into rank 0's line: a slow rank (clocked-down device, a device shared by two ranks) is visible there
     power1 = device_power_state(device_index)
     rows = group.gather_rows([rank, device_index, args.steps * S / my_elapsed, my_elapsed, power1.get("sclk_mhz", -1.0),
-                              power1.get("mclk_mhz", -1.0), power1.get("power_cap_w", -1.0), power1.get("power_w", -1.0)])
+                              power1.get("mclk_mhz", -1.0), power1.get("power_cap_w", -1.0), power1.get("power_w", -1.0),
+                              float(int(kernel_rev, 16)) if all(ch in "0123456789abcdef" for ch in kernel_rev) else -1.0])
+    # every rank must have run the same kernels (a stale in-tree .so on one rank would silently mix two revisions into one figure):
+    # the revisions travel as numbers (ten hexadecimal digits are exact in a double) and a mismatch fails the run on every rank
+    revs = sorted({r[8] for r in rows})
+    if len(revs) != 1:
+        raise SystemExit("bench.py: the ranks ran different kernel revisions (%s): rebuild xrslam_amd/lib on every rank" %
+                         ", ".join("%010x" % int(v) if v >= 0 else "?" for v in revs))
 
     if rank == 0:
         poses = list(sess.poses)
