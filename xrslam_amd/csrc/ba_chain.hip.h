@@ -324,18 +324,79 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
 #endif
             __syncthreads();
             CPROF(18);  // lin: phase A (reprojection factors; rotation residual, Jr^-1, B; rq-free pieces)
+            // ---------------- reprojection blocks of the free frames: the (f, f) pair list, upper triangle + gradient = 27 sums per frame.
+            // Every participating wavefront reduces ITS lanes' partial sums through a tile of its own (a store of 27 columns, 54 lanes add
+            // half a row each) and goes on to the next frame at once (rounds 2-5: a 256-wide tile and three barriers per free frame).
+            // With IMU factors the blocks are wavefronts 2 and 3's, BESIDE phase B (the IMU Jacobians' products, wavefronts 0 and 1): they
+            // read only what phase A left in the factor records.
+            auto vis_blocks = [&](int idx, int stride) __attribute__((always_inline)) {
+                for (int s = 0; s < nfree; ++s) {
+                    const int f = s_free[s], pair = f * F + f;
+                    const int s0 = p.pair_start[pair], s1 = p.pair_start[pair + 1];
+                    double acc[27];
+#pragma unroll
+                    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+                    for (int it = s0 + idx; it < s1; it += stride) {
+                        const int code = p.pair_items[it];
+                        const double *rec = p.orec + (size_t)(code >> 1) * OREC + ((code & 1) ? 12 : 0);
+                        double j[12];
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) j[i] = rec[i];
+                        const double *rr = p.orec + (size_t)(code >> 1) * OREC + 26;
+                        const double r0 = rr[0], r1 = rr[1];
+                        int e = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                            for (int b = a; b < 6; ++b) acc[e++] += j[a] * j[b] + j[6 + a] * j[6 + b];
+                            acc[21 + a] += j[a] * r0 + j[6 + a] * r1;
+                        }
+                    }
+                    if (vis_tile) {
+                        double *tw = lds + Lo.total + wave * (27 * 65);
+#pragma unroll
+                        for (int i = 0; i < 27; ++i) tw[i * 65 + lane] = acc[i];
+                        wave_sync();
+                        const int row = lane < 27 ? lane : lane - 27;   // lanes 0-26: entries 0-31 of row `lane`; lanes 27-53: entries 32-63
+                        double s2 = 0.0;
+                        if (lane < 54) {
+                            const double *rp = tw + row * 65 + (lane < 27 ? 0 : 32);
+#pragma unroll
+                            for (int i = 0; i < 32; ++i) s2 += rp[i];
+                        }
+                        const double hi = __shfl(s2, (lane + 27) & 63);   // every lane active (a ds_bpermute reads inactive lanes as zero)
+                        if (lane < 27) s_vis[wave][s][lane] = s2 + hi;
+                        wave_sync();   // the tile is free for the next frame
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
+                        if (lane == 0)
+#pragma unroll
+                            for (int i = 0; i < 27; ++i) s_vis[wave][s][i] = acc[i];
+                    }
+                }
+            };
             if (split) {
-                // phase B: the products
-                if (imu_on) {
+                // phase B: the products (wavefronts 0, 1) beside the reprojection blocks (wavefronts 2, 3)
+                if (wave >= 2) {
+                    vis_blocks(tid - 128, 128);
+                } else if (imu_on) {
                     double *rw = scr + lane * IMU_SCR;
                     const double *xk = xch + lane * IMU_XCH;
                     if (wave == 0) imu_jac_finish0(load33(xk + 45), xk, rw + 15, rw + 240, nfi, nfj);
                     else if (wave == 1)
                         imu_jac_finish1(load33(xk + 45), load33(xk + 36), xk, load33(recs + lane * XRHIP_IMU_DIM + 11), rw + 15, nfi);
                 }
-                __syncthreads();
+            } else {
+                vis_blocks(tid, nt);
             }
-            CPROF(1);   // linearisation of the factors
+            __syncthreads();
+            CPROF(1);   // linearisation of the factors; reprojection blocks
+            // the wavefronts' block sums, in wavefront order (beside the whitening below; the assembly reads them behind its barrier)
+            for (int e = tid; e < 27 * nfree; e += nt) {
+                const int s = e / 27, q = e - 27 * s;
+                Hv[28 * s + q] = split ? s_vis[2][s][q] + s_vis[3][s][q] : (s_vis[0][s][q] + s_vis[1][s][q]) + (s_vis[2][s][q] + s_vis[3][s][q]);
+            }
             // ---------------- whitening of the IMU factors (lin_imu_block's second half): the 225 entries of a factor's two
             // Jacobians over the whole workgroup, the residual on the first lanes of wavefront 0; sqrt_inv_cov from LDS
             for (int k = 0; k < NI; ++k) {
@@ -370,63 +431,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void kb_chain(Batch<ChainArgs> batch
                     wJj[225 * k + e] = b;
                 }
             }
-            CPROF(2);   // IMU whitening
-            // ---------------- reprojection blocks of the free frames: the (f, f) pair list over all four wavefronts, upper triangle +
-            // gradient = 27 sums per frame.  Round 6: every wavefront reduces ITS lanes' partial sums through a tile of its own (a store of
-            // 27 columns, 54 lanes add half a row each) and goes on to the next frame at once -- ONE workgroup barrier for all frames
-            // (rounds 2-5: a 256-wide tile and three barriers per free frame, 3.4 us each).
-            for (int s = 0; s < nfree; ++s) {
-                const int f = s_free[s], pair = f * F + f;
-                const int s0 = p.pair_start[pair], s1 = p.pair_start[pair + 1];
-                double acc[27];
-#pragma unroll
-                for (int i = 0; i < 27; ++i) acc[i] = 0.0;
-                for (int it = s0 + wtid; it < s1; it += nt) {
-                    const int code = p.pair_items[it];
-                    const double *rec = p.orec + (size_t)(code >> 1) * OREC + ((code & 1) ? 12 : 0);
-                    double j[12];
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) j[i] = rec[i];
-                    const double *rr = p.orec + (size_t)(code >> 1) * OREC + 26;
-                    const double r0 = rr[0], r1 = rr[1];
-                    int e = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                        for (int b = a; b < 6; ++b) acc[e++] += j[a] * j[b] + j[6 + a] * j[6 + b];
-                        acc[21 + a] += j[a] * r0 + j[6 + a] * r1;
-                    }
-                }
-                if (vis_tile) {
-                    double *tw = lds + Lo.total + wave * (27 * 65);
-#pragma unroll
-                    for (int i = 0; i < 27; ++i) tw[i * 65 + lane] = acc[i];
-                    wave_sync();
-                    const int row = lane < 27 ? lane : lane - 27;   // lanes 0-26: entries 0-31 of row `lane`; lanes 27-53: entries 32-63
-                    double s2 = 0.0;
-                    if (lane < 54) {
-                        const double *rp = tw + row * 65 + (lane < 27 ? 0 : 32);
-#pragma unroll
-                        for (int i = 0; i < 32; ++i) s2 += rp[i];
-                    }
-                    const double hi = __shfl(s2, (lane + 27) & 63);   // every lane active (a ds_bpermute reads inactive lanes as zero)
-                    if (lane < 27) s_vis[wave][s][lane] = s2 + hi;
-                    wave_sync();   // the tile is free for the next frame
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 27; ++i) acc[i] = wave_sum(acc[i]);
-                    if (lane == 0)
-#pragma unroll
-                        for (int i = 0; i < 27; ++i) s_vis[wave][s][i] = acc[i];
-                }
-            }
             __syncthreads();
-            for (int e = tid; e < 27 * nfree; e += nt) {
-                const int s = e / 27, q = e - 27 * s;
-                Hv[28 * s + q] = (s_vis[0][s][q] + s_vis[1][s][q]) + (s_vis[2][s][q] + s_vis[3][s][q]);
-            }
-            __syncthreads();
-            CPROF(3);   // reprojection blocks
+            CPROF(2);   // IMU whitening, block sums
             // ---------------- assembly of the free x free entries (packed lower triangle) and of the gradient:
             // reprojection block, rotation priors, the IMU factor ending at the frame, the one starting at it --
             // assemble_item's order
