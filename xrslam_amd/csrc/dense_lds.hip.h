@@ -652,24 +652,47 @@ __device__ __forceinline__ bool tl_chol(double *A, int n, int nrows, double *ide
 
 // y <- L^-T y with what tl_chol left behind (L below the diagonal, transposed block inverses on it).  y: a vector of
 // 16 * tile_rows(n) doubles in LDS whose entries >= n are ZERO.  All threads must call.
+//
+// Per block j, last to first: x_j = Linv_j^T y_j, then y_i -= L_ji^T x_j for the blocks i above.  One workgroup barrier per block
+// (round 6; three before): wavefront 0 forms x_j (lane = (row r, quarter q): four products, the quarters added by shuffles), hands it to
+// the others through y and the barrier, and takes block j - 1's share of the update -- the next block it needs -- itself, from its
+// registers, while the other wavefronts update the blocks above that.
 __device__ __forceinline__ void tl_trsv_t(const double *A, int n, double *y) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int Tm = tl_tile_rows(n);
+    const int r = lane & 15, q = lane >> 4;
+    // wavefront 0: what block j + 1's solution takes off y_j -- lane (r, any quarter): sum_c L[16 (j+1) + c][16 j + r] x_{j+1}[c].  Kept in
+    // registers, not subtracted in LDS: the other wavefronts are still updating y_j by x_{j+2} when it is formed.
+    double pend = 0.0;
     for (int j = Tm - 1; j >= 0; --j) {
-        // x_r = sum_c Linv[c][r] y_c : row r of the diagonal tile (zeros left of the diagonal; whatever a non-pivot column holds meets a
-        // zero of y)
-        double xr = 0.0;
-        if (tid < 16) {
-            const double *tile = A + tl_tile(j, j) + tid;
-            const double *yj = y + 16 * j;
+        if (wave == 0) {
+            // x_r = sum_c Linv[c][r] (y_c - pend_c): row r of the diagonal tile (zeros left of the diagonal; whatever a non-pivot column
+            // holds meets a zero of y); lane (r, q) takes c = 4 q .. 4 q + 3
+            const double *tile = A + tl_tile(j, j) + r + 4 * q * TL_LD;
+            const double *yj = y + 16 * j + 4 * q;
+            double s = 0.0;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) xr += tile[c * TL_LD] * yj[c];
+            for (int k = 0; k < 4; ++k) s += tile[k * TL_LD] * (yj[k] - __shfl(pend, 4 * q + k));
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const double xr = (16 * j + r < n) ? s : 0.0;
+            if (q == 0) y[16 * j + r] = xr;
+            pend = 0.0;
+            if (j > 0) {
+                const double *col = A + tl_tile(j, j - 1) + r * TL_LD + 4 * q;   // element (c, r) of tile (j, j - 1): L[16 j + c][16 (j - 1) + r]
+                double u = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u += col[k] * __shfl(xr, 4 * q + k);
+                u += __shfl_xor(u, 16);
+                u += __shfl_xor(u, 32);
+                pend = u;
+            }
         }
         __syncthreads();
-        if (tid < 16) y[16 * j + tid] = (16 * j + tid < n) ? xr : 0.0;
-        __syncthreads();
-        // y_i -= sum_c L[16 j + c][i] x_c for the rows above: thread i reads element (c, i & 15) of tile (j, i >> 4), c = 0 .. 15
-        for (int i = tid; i < 16 * j; i += nt) {
+        // y_i -= sum_c L[16 j + c][i] x_c for the blocks above j - 1, by the other wavefronts (by this one when it is alone): thread i
+        // reads element (c, i & 15) of tile (j, i >> 4), c = 0 .. 15
+        const int first = nt > 64 ? 64 : 0;
+        for (int i = tid - first; i >= 0 && i < 16 * (j - 1); i += nt - first) {
             const double *col = A + tl_tile(j, i >> 4) + (i & 15) * TL_LD;
             const double *xj = y + 16 * j;
             double s = 0.0;
@@ -677,8 +700,10 @@ __device__ __forceinline__ void tl_trsv_t(const double *A, int n, double *y) {
             for (int c = 0; c < 16; ++c) s += col[c] * xj[c];
             y[i] -= s;
         }
-        __syncthreads();
+        // (no second barrier: block j - 1 is solved from y_{j-1} as the barrier above left it -- the others' updates by x_{j+1}, ... were
+        // complete there -- minus `pend`; what the others write now are rows above block j - 1, read after the next barrier)
     }
+    __syncthreads();
 }
 
 }   // namespace xrhip
