@@ -3,6 +3,10 @@
 // library transcendentals; and the shader clock such a kernel actually runs at (s_memtime vs the 100 MHz wall clock).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/latency.hip -o xrslam_amd/bin/xr-latency
 // Prints one JSON line: ns per dependent operation (and shader cycles per operation).
+// CAUTION (round 6): the one-operation chains below are loops of ONE operation per trip, so what they report is the operation PLUS the
+// loop's compare-and-branch (~20 cycles): "fma_f64 32 cycles" is not a dependent latency.  tools/issue.hip measures the operations
+// unrolled (v_fma_f64: 9 cycles, dependent or not); the multi-operation entries here (rsq_newton_pivot, mat3_product_scaled, the
+// transcendental library calls, barriers and round trips) stand.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

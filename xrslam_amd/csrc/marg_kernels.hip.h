@@ -724,10 +724,9 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
         __syncthreads();
         PI_T(0);
         // ---- P2: the two chains, ONE lane.  The quaternion chain and the position / velocity chain are independent streams of
-        // dependent double-precision operations (q_{n+1} and q_n a_n both hang off q_n only); a lone lane issues a dependent
-        // instruction every ~34 cycles and an independent one every ~8, so interleaved they cost what the longer one does
-        // alone (they were 3.6 + 2.8 us one after the other at eleven samples).  Each chain's operations and their order are
-        // the reference's.
+        // double-precision operations (q_{n+1} and q_n a_n both hang off q_n only), interleaved in one loop.  (Round 6, tools/issue.hip: an
+        // f64 operation costs its wavefront ~9 cycles whether or not it depends on the previous one -- the loop is as long as its
+        // ~150 instructions per sample.)  Each chain's operations and their order are the reference's.
         if (tid == 0) {
             Q4 q = Q4{sq[0], sq[1], sq[2], sq[3]};
             V3 pv = v3(sp3[0], sp3[1], sp3[2]), vv = v3(sv3[0], sv3[1], sv3[2]);
