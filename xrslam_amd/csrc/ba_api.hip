@@ -357,6 +357,7 @@ struct RegisterBaLaunchers {
 // Packs the problem + gather indices into the input arena, carves the workspace and fills dims/ptrs.
 // defer_copy: do not queue the kb_stage launch; the caller hands the copy (c->stage_src / stage_dst / stage_n16) to a
 // kernel that pulls the problem itself before it starts (kb_chain), or calls launch_stage_copy().
+static int solve_lds(const BaDims &d, size_t limit, size_t *bytes, int *use_lds);
 static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPtrs &p, Ext &cam, Ext &imu, bool defer_copy = false) {
     d.F = P->n_frames;
     d.n = 15 * d.F;
@@ -596,6 +597,14 @@ static int stage_problem(xrhip_ba *c, const xrhip_ba_problem *P, BaDims &d, BaPt
     cam.p = V3{P->cam_p_bc[0], P->cam_p_bc[1], P->cam_p_bc[2]};
     imu.q = Q4{P->imu_q_bi[0], P->imu_q_bi[1], P->imu_q_bi[2], P->imu_q_bi[3]};
     imu.p = V3{P->imu_p_bi[0], P->imu_p_bi[1], P->imu_p_bi[2]};
+    {   // a reduced system that does not fit LDS is written (kb_schur_aux) and factored (kb_solve_try) in the tiled layout, in place
+        size_t lds_b = 0;
+        int use_lds_ = 1;
+        d.sred_tiled = 0;
+        solve_lds(d, (size_t)c->lds_limit, &lds_b, &use_lds_);
+        static const bool no_tiled = std::getenv("XRHIP_NO_TILED") != nullptr;
+        d.sred_tiled = (use_lds_ == 0 && !no_tiled) ? 1 : 0;
+    }
     {   // the argument block of the single-launch solve travels with the problem
         TinyArgs *ta = reinterpret_cast<TinyArgs *>(A.host + o_args);
         ta->d = d;
@@ -684,8 +693,8 @@ static int solve_lds(const BaDims &d, size_t limit, size_t *bytes, int *use_lds)
         *use_lds = 1;   // packed triangle in LDS
     }
     if (lds > limit) {
-        *use_lds = 0;   // packed triangle in the global buffer Sred
-        lds = sizeof(double) * aux;
+        *use_lds = 0;   // factored in the global buffer Sred, in the tiled layout (BaDims::sred_tiled); L^-1 rhs / the solution in LDS
+        lds = sizeof(double) * std::max(aux, (size_t)16 * tl_tile_rows(d.na + 1));
     }
     *bytes = lds;
     return XRHIP_OK;
@@ -700,7 +709,7 @@ static bool wide_first(const BaDims &d) { return wide_trials(d) && d.M >= 600 &&
 // reduced-system solve + trust-region trials: 2 launches (3 when mu changed without a new linearisation)
 static void launch_schur_aux(const BaDims &d, const BaPtrs &p, hipStream_t s) {
     const int tiles = d.PF / 16;
-    const int nrest = (d.na * d.na + 255) / 256;   // blocks that write the Schur-free entries of the reduced system
+    const int nrest = sred_rest_blocks(d);   // blocks that write the Schur-free entries of the reduced system (+ the tiled layout's padding)
     hipLaunchKernelGGL(kb_schur_aux, dim3(nrest + (d.nla ? tiles * tiles + aux_quad_blocks_n(d.n, d.L) + aux_wog_blocks(d.F)
                                                         : aux_quad_blocks_n(d.n, d.L)) + 1),   // + 1: total cost and gradient max-norm
                        dim3(256), 0, s, d, p);
@@ -1283,7 +1292,7 @@ static int ba_solve_impl(xrhip_ba *c, const xrhip_ba_problem *P, xrhip_ba_summar
         r = solve_lds(d, (size_t)c->lds_limit, &lds, &use_lds);
         if (r) return r;
         lds = std::max(lds, sizeof(double) * (size_t)std::max(TRY_B * (d.np + 15 * d.NI), 1));
-        const int tiles = d.PF / 16, nrest = (d.na * d.na + 255) / 256;
+        const int tiles = d.PF / 16, nrest = sred_rest_blocks(d);
         wp.e = WinEntry{c->tiny_args, lin_all_blocks(d.M, d.MR, d.NI, d.np), d.lm_rows + d.F * d.F * VIS_CH, (d.n * d.n + 255) / 256,
                         nrest + tiles * tiles + aux_quad_blocks_n(d.n, d.L) + aux_wog_blocks(d.F) + 1, use_lds, mode_, seq_, 1};
         wp.relin = relinearise;

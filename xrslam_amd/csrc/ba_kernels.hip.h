@@ -88,6 +88,8 @@ struct BaDims {
     int nffp;           // reprojection factors whose target AND reference pose are free (off-diagonal reprojection blocks)
     int schur_mode;     // 0 (always, in the product): f64 Schur contraction; 1 / 2: f32 / bf16 matrix-core operands -- BASELINE config 5's
                         // precision study only (xrhip_ba_debug_set_schur_precision)
+    int sred_tiled;     // 1: the reduced system does not fit LDS and is factored where kb_schur_aux writes it, in the tiled layout of
+                        // dense_lds.hip.h (round 6); 0: packed lower triangle (copied into LDS by the solve)
 };
 
 // Pointers of the argument blocks.  Kernels that receive BaPtrs by value see global-address-space pointers (the
@@ -884,6 +886,14 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // emit_s: also write the pose-pose entries of the reduced system  S = sp (Hpp - T) sp + mu D^2  (lower triangle,
 // packed over the active dofs) into Sred -- the solve kernel then only copies a contiguous block into LDS.
+// where entry (i, j), j <= i, of the reduced system goes in Sred
+__device__ __forceinline__ int sred_idx(const BaDims &d, int i, int j) { return d.sred_tiled ? tl_idx(i, j) : tri_idx(i, j); }
+// blocks of 256 entries that cover what the "rest" blocks write: the na x na square, or -- tiled -- the padded square of the tiles
+// (rows / columns >= na: identity padding and zeros, written every round: the factorisation runs in place)
+__host__ __device__ __forceinline__ int sred_rest_blocks(const BaDims &d) {
+    const int side = d.sred_tiled ? 16 * tl_tile_rows(d.na + 1) : d.na;
+    return (side * side + 255) / 256;
+}
 __device__ __forceinline__ void schur_tile_block(const BaDims &d, const BaPtrs &p, int tile, bool emit_s = false) {
     __shared__ double red[4][256];
     const int tiles = d.PF / 16;
@@ -963,7 +973,7 @@ __device__ __forceinline__ void schur_tile_block(const BaDims &d, const BaPtrs &
             if (ia >= 0 && ib >= 0 && ib <= ia) {
                 double v = (p.Hpp[(size_t)a * d.n + b] - s) * (p.sp[a] * p.sp[b]);
                 if (a == b) v += p.ctl->mu * p.diagD[a] * p.diagD[a];
-                p.Sred[tri_idx(ia, ib)] = v;
+                p.Sred[sred_idx(d, ia, ib)] = v;
             }
         }
     }
@@ -971,15 +981,23 @@ __device__ __forceinline__ void schur_tile_block(const BaDims &d, const BaPtrs &
 // the entries of S that carry no Schur term (a velocity / bias dof on either side, or no free landmark at all)
 __device__ __forceinline__ void reduced_rest_block(const BaDims &d, const BaPtrs &p, int blk) {
     const int e = blk * 256 + (int)threadIdx.x;
-    if (e >= d.na * d.na) return;
-    const int i = e / d.na, j = e - i * d.na;
-    if (j > i) return;
+    const int side = d.sred_tiled ? 16 * tl_tile_rows(d.na + 1) : d.na;
+    if (e >= side * side) return;
+    const int i = e / side, j = e - i * side;
+    if (j > i) {   // above the diagonal: only the diagonal tiles have such slots (never read by another lane; kept finite)
+        if (d.sred_tiled && (i >> 4) == (j >> 4)) p.Sred[tl_tile(i >> 4, i >> 4) + (j & 15) * TL_LD + (i & 15)] = 0.0;
+        return;
+    }
+    if (i >= d.na) {   // tiled only: padding rows (the right-hand side is put into row na by the solve itself)
+        p.Sred[tl_idx(i, j)] = (i == j) ? 1.0 : 0.0;
+        return;
+    }
     const int a = p.act_idx[i], b = p.act_idx[j];
     const int ka = a % 15, kb = b % 15;
     if (d.nla && ka < 6 && kb < 6) return;   // written by the Schur tile that owns it
     double v = p.Hpp[(size_t)a * d.n + b] * (p.sp[a] * p.sp[b]);
     if (a == b) v += p.ctl->mu * p.diagD[a] * p.diagD[a];
-    p.Sred[tri_idx(i, j)] = v;
+    p.Sred[sred_idx(d, i, j)] = v;
 }
 __global__ __launch_bounds__(256) void kb_schur_mfma(BaDims d, BaPtrs p) { schur_tile_block(d, p, blockIdx.x); }
 
@@ -1128,7 +1146,7 @@ __device__ __forceinline__ void d_schur_aux(const BaDims &d, const BaPtrs &p, in
         const BaPtrs &p;
         int bx;
         __device__ ~Tail() {
-            const int nrest = (d.na * d.na + 255) / 256, tiles = d.PF / 16, b = bx;
+            const int nrest = sred_rest_blocks(d), tiles = d.PF / 16, b = bx;
             const int nbq = aux_quad_blocks_n(d.n, d.L);
             if (threadIdx.x == 0 && d.M > 1500 &&
                 (b == 1 || b == nrest + 3 || b == nrest + tiles * tiles + 1 || b == nrest + tiles * tiles + nbq - 2 || b == nrest + tiles * tiles + nbq))
@@ -1137,7 +1155,7 @@ __device__ __forceinline__ void d_schur_aux(const BaDims &d, const BaPtrs &p, in
     } tail{t0, d, p, bx};
 #endif
     const int t2 = d.nla ? (d.PF / 16) * (d.PF / 16) : 0;
-    const int nrest = (d.na * d.na + 255) / 256;
+    const int nrest = sred_rest_blocks(d);
     int blk = bx;
     if (blk == gx - 1) {
         // Round 5: the linearisation's total cost and gradient max-norm -- two block-wide reductions and an exponential map per frame
@@ -1239,9 +1257,12 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
     // use_lds == 2: the tiled layout of dense_lds.hip.h (bank-conflict-free 16x16 tiles, block inverses kept for the
     // back-substitution).  The reduced system arrives as a packed triangle in Sred; it is dealt to the tiles by wavefront -- lane
     // (column c = lane & 15, row rr + 4 pass): sixteen lanes read 128 contiguous bytes of one row.
-    auto factor_stage_tiled = [&](double *A) __attribute__((always_inline)) -> bool {
+    // in_place (round 6): the system does not fit LDS -- kb_schur_aux wrote it into Sred in the tiled layout, padding included
+    // (BaDims::sred_tiled), and it is factored there, the tiles served by L2 (rounds 1-5: the packed routines on the global buffer,
+    // 314 us at 240 unknowns); only L^-1 rhs / the solution live in LDS.
+    auto factor_stage_tiled = [&](double *A, bool in_place) __attribute__((always_inline)) -> bool {
         const int nrows = na + 1, T = tl_tile_rows(nrows);
-        double *yv = A + tl_doubles(nrows);
+        double *yv = in_place ? work : A + tl_doubles(nrows);
         const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6, cc = lane & 15, rr = lane >> 4;
         const int n_tiles = T * (T + 1) / 2;
         const double *src = p.Sred;
@@ -1255,7 +1276,7 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
             rhs_v = (p.gp[a] - sacc) * p.sp[a];
         }
         constexpr int TU = 3;   // tiles (4 loads each) in flight per wavefront; loads are unconditional (clamped), selected afterwards
-        for (int t0 = wave; t0 < n_tiles; t0 += TU * nw) {
+        for (int t0 = wave; t0 < (in_place ? 0 : n_tiles); t0 += TU * nw) {
             double v[TU][4];
             int base[TU];
 #pragma unroll
@@ -1316,9 +1337,11 @@ __device__ __forceinline__ void solve_block(const BaDims &d, const BaPtrs &p, in
         return true;
     };
     if (use_lds == 2) {
-        if (!factor_stage_tiled(work)) return;
+        if (!factor_stage_tiled(work, false)) return;
     } else if (use_lds) {
         if (!factor_stage(work)) return;
+    } else if (d.sred_tiled) {
+        if (!factor_stage_tiled(static_cast<double *>(p.Sred), true)) return;
     } else {
         if (!factor_stage(static_cast<double *>(p.Sred))) return;
     }
@@ -2409,7 +2432,7 @@ __device__ __forceinline__ void small_mid_block(const BaDims &d, const BaPtrs &p
     }
     prepare_block(d, p);
     __syncthreads();
-    for (int blk = 0; blk * 256 < na * na; ++blk) reduced_rest_block(d, p, blk);
+    for (int blk = 0; blk < sred_rest_blocks(d); ++blk) reduced_rest_block(d, p, blk);
     double acc = 0;   // Q(g~,g~) over the active dofs (see kb_schur_aux)
     for (int i = wave; i < na; i += nw) {
         const int a = p.act_idx[i];
