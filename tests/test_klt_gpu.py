@@ -30,9 +30,9 @@ def _dump(name, **arrs):
         pass
 
 
-def _pair(ko, klt, a, b, clip=6.0, tiles=8):
+def _pair(ko, klt, a, b, clip=6.0, tiles=8, max_points=600):
     h, w = a.shape
-    ctx = klt.KltContext(w, h, 600)
+    ctx = klt.KltContext(w, h, max_points)
     HA, HB = ctx.image(a), ctx.image(b)
     HA.preprocess(clip, tiles, tiles)
     HB.preprocess(clip, tiles, tiles)
@@ -169,7 +169,9 @@ def test_detect_paths_prefetch_and_full_list_fallback(mods):
     g = np.full((h, w), 110, np.uint8)
     g[90:390, 200:500] = noise_image(300, 300, seed=77)          # > 1024 NMS survivors packed into 300 x 300 px
     g2 = warp_affine(g, np.eye(2), np.array([1.5, 0.5]))
-    ctx, HA, HB, OA, OB = _pair(ko, klt, g, g2)
+    # a 150-corner context hands the host's spacing pass the 896 strongest candidates (round 6: 8 per corner beyond 150 corners -- a
+    # 600-corner context would hand over all of them and never fall back)
+    ctx, HA, HB, OA, OB = _pair(ko, klt, g, g2, max_points=150)
     want = OA.detect_keypoints(np.zeros((0, 2)), 1000, 20.0)      # asks for more corners than 20 px spacing allows
     before = ctx.stats().detect_full_list
     got = HA.detect_keypoints(np.zeros((0, 2)), 1000, 20.0)

@@ -93,7 +93,7 @@ struct xrhip_klt {
     int *h_count = nullptr;          // pinned (2 ints)
     HarrisCand *h_top = nullptr;     // pinned, device-mapped: the strongest candidates (k_harris_select)
     SelectHeader *h_sel = nullptr;   // pinned, device-mapped
-    int top_cap = 4096;
+    int top_cap = 8192;
     int sel_seq = 0;
     // track scratch
     int pts_cap = 0;
@@ -903,7 +903,9 @@ static int fill_detect(xrhip_image *im, DetectPayload &d, int seq) {
     const int gx = (w + 63) / 64, gy = (h + 15) / 16;
     d.hr = HarrisArgs{pv.lv[0], 0.04, s2, c->resp, c->max_key, gx, gy};
     d.nms = HarrisNmsArgs{c->resp, w, h, c->max_key, 1.0e-3, c->cand, c->cand_count, c->cand_cap, gx, gy};
-    d.sel = HarrisSelectArgs{c->cand, c->cand_count, c->cand_cap, c->max_key, 1.0e-3, d_top, c->top_cap, d_sel, seq};
+    // the strongest candidates the spacing pass is handed: >= 896 (150 corners visit ~400), 8 per corner asked for beyond that
+    const int keep = std::min(c->top_cap - 1024, std::max(SEL_K, c->max_points > 150 ? 8 * c->max_points : SEL_K));
+    d.sel = HarrisSelectArgs{c->cand, c->cand_count, c->cand_cap, c->max_key, 1.0e-3, d_top, c->top_cap, d_sel, seq, keep};
     return XRHIP_OK;
 }
 

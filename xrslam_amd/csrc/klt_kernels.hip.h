@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void k_harris_nms(Batch<HarrisNmsArgs> b) {
 // bin boundary that keeps >= SEL_K candidates is found, and everything at or above it is written -- together
 // with a header and, last, a sequence number -- straight into pinned host memory.  One workgroup.
 constexpr int SEL_BINS = 4096;
-constexpr int SEL_K = 896;    // a few more than the ~400 the spacing pass usually visits; <= 1024 keeps the sort at 1024 entries
+constexpr int SEL_K = 896;    // the least `keep`: a few more than the ~400 the spacing pass usually visits for 150 corners; <= 1024 keeps the sort at 1024 entries
 constexpr int SEL_SORT = 2048;   // selected candidates that fit the LDS sort (SEL_BINS * 4 bytes = SEL_SORT * 8 bytes)
 struct SelectHeader {
     int n_candidates;   // all NMS survivors
@@ -671,7 +671,10 @@ struct SelectHeader {
 
 __device__ __forceinline__ void d_harris_select(const HarrisCand *__restrict__ cand, int *__restrict__ count,
                                                 int capacity, int *__restrict__ max_key, double quality,
-                                                HarrisCand *top_out, int top_cap, SelectHeader *hdr, int seq) {
+                                                HarrisCand *top_out, int top_cap, SelectHeader *hdr, int seq, int keep) {
+    // keep: how many of the strongest candidates the host's spacing pass is handed at least (round 6: scaled with the number of corners
+    // asked for -- with 896 for 300 / 600 corners the pass ran out on every frame and fell back to copying and heaping ALL ~10^4
+    // candidates on the host, 0.3-0.4 ms per frame of the S2 / S3 streams)
     __shared__ unsigned hist[SEL_BINS];
     __shared__ HarrisCand sorted_buf[SEL_SORT];
     __shared__ unsigned part[64];
@@ -731,13 +734,13 @@ __device__ __forceinline__ void d_harris_select(const HarrisCand *__restrict__ c
             return v;
         };
         const unsigned sg = suffix(part[lane]);
-        const unsigned long long mg = __ballot(sg >= (unsigned)SEL_K);
+        const unsigned long long mg = __ballot(sg >= (unsigned)keep);
         int b = 0;                                             // fewer than SEL_K candidates in total: keep all
         if (mg) {
             const int g = 63 - __builtin_clzll(mg);
             const unsigned above = __shfl(sg, g) - __shfl(part[lane], g);   // candidates in the groups above g
             const unsigned sb = above + suffix(hist[g * 64 + lane]);
-            const unsigned long long mb = __ballot(sb >= (unsigned)SEL_K);
+            const unsigned long long mb = __ballot(sb >= (unsigned)keep);
             b = g * 64 + (mb ? 63 - __builtin_clzll(mb) : 0);
         }
         if (lane == 0) s_bin = b;
@@ -867,10 +870,11 @@ struct HarrisSelectArgs {
     int top_cap;
     SelectHeader *hdr;
     int seq;
+    int keep;
 };
 __global__ __launch_bounds__(1024) void k_harris_select(Batch<HarrisSelectArgs> b) {
     const HarrisSelectArgs &a = b.e[blockIdx.z];
-    d_harris_select(a.cand, a.count, a.capacity, a.max_key, a.quality, a.top_out, a.top_cap, a.hdr, a.seq);
+    d_harris_select(a.cand, a.count, a.capacity, a.max_key, a.quality, a.top_out, a.top_cap, a.hdr, a.seq, a.keep);
 }
 
 // ----------------------------------------------------------------------- LK
