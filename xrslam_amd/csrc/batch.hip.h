@@ -6,6 +6,7 @@
 // not depend on what it is batched with.  The block travels in the kernel-argument segment (scalar loads; 4 KB at most: the largest
 // argument set, k_lk_track's two pyramid views, is 336 bytes).
 #pragma once
+#include "host_mailbox.hip.h"
 
 namespace xrhip {
 

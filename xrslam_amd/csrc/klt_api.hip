@@ -87,13 +87,14 @@ struct xrhip_klt {
     float *resp = nullptr;           // w*h Harris response
     int *max_key = nullptr;          // 1 int (+ candidate counter next to it)
     int *cand_count = nullptr;
+    unsigned *sel_hist = nullptr;    // SEL_BINS counters: k_harris_nms fills them, k_harris_select reads and clears them
     HarrisCand *cand = nullptr;
     int cand_cap = 0;
     HarrisCand *h_cand = nullptr;    // pinned
     int *h_count = nullptr;          // pinned (2 ints)
     HarrisCand *h_top = nullptr;     // pinned, device-mapped: the strongest candidates (k_harris_select)
     SelectHeader *h_sel = nullptr;   // pinned, device-mapped
-    int top_cap = 8192;
+    int top_cap = SEL_SORT;   // everything the selection kernel can hand over in visiting order
     int sel_seq = 0;
     // track scratch
     int pts_cap = 0;
@@ -290,7 +291,7 @@ static void launch_detect_chunk(const DetectPayload *const *d, int m, hipStream_
     }
     hipLaunchKernelGGL(k_harris, dim3(gx, gy, m), dim3(256), 0, s, bh);
     hipLaunchKernelGGL(k_harris_nms, dim3(gx, gy, m), dim3(256), 0, s, bn);
-    hipLaunchKernelGGL(k_harris_select, dim3(1, 1, m), dim3(1024), 0, s, bs);
+    hipLaunchKernelGGL(k_harris_select, dim3(1, 1, m), dim3(1024), SEL_LDS_BYTES, s, bs);
 }
 
 static int launch_detect_batch(GroupRequest **r, int n, hipStream_t s, hipStream_t) {
@@ -471,7 +472,10 @@ int xrhip_klt_create(int width, int height, int max_points, xrhip_klt **out) {
         XR_HIP(hipMemcpy(c->max_key, init, sizeof(init), hipMemcpyHostToDevice));
     }
     c->cand_cap = width * height / 2;
+    XR_HIP(hipFuncSetAttribute((const void *)k_harris_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEL_LDS_BYTES));
     XR_HIP(hipMalloc(&c->cand, sizeof(HarrisCand) * (size_t)c->cand_cap));
+    XR_HIP(hipMalloc(&c->sel_hist, sizeof(unsigned) * SEL_BINS));
+    XR_HIP(hipMemset(c->sel_hist, 0, sizeof(unsigned) * SEL_BINS));
     XR_HIP(hipHostMalloc(&c->h_cand, sizeof(HarrisCand) * (size_t)c->cand_cap, hipHostMallocDefault));
     XR_HIP(hipHostMalloc(&c->h_count, sizeof(int) * 2, hipHostMallocDefault));
     XR_HIP(hipHostMalloc(&c->h_top, sizeof(HarrisCand) * (size_t)c->top_cap, hipHostMallocDefault));
@@ -505,6 +509,7 @@ void xrhip_klt_destroy(xrhip_klt *c) {
     hipFree(c->resp);
     hipFree(c->max_key);
     hipFree(c->cand);
+    hipFree(c->sel_hist);
     hipHostFree(c->h_cand);
     hipHostFree(c->h_count);
     hipHostFree(c->h_top);
@@ -902,10 +907,10 @@ static int fill_detect(xrhip_image *im, DetectPayload &d, int seq) {
     XR_HIP(hipHostGetDevicePointer((void **)&d_sel, c->h_sel, 0));
     const int gx = (w + 63) / 64, gy = (h + 15) / 16;
     d.hr = HarrisArgs{pv.lv[0], 0.04, s2, c->resp, c->max_key, gx, gy};
-    d.nms = HarrisNmsArgs{c->resp, w, h, c->max_key, 1.0e-3, c->cand, c->cand_count, c->cand_cap, gx, gy};
+    d.nms = HarrisNmsArgs{c->resp, w, h, c->max_key, 1.0e-3, c->cand, c->cand_count, c->cand_cap, gx, gy, c->sel_hist};
     // the strongest candidates the spacing pass is handed: >= 896 (150 corners visit ~400), 8 per corner asked for beyond that
     const int keep = std::min(c->top_cap - 1024, std::max(SEL_K, c->max_points > 150 ? 8 * c->max_points : SEL_K));
-    d.sel = HarrisSelectArgs{c->cand, c->cand_count, c->cand_cap, c->max_key, 1.0e-3, d_top, c->top_cap, d_sel, seq, keep};
+    d.sel = HarrisSelectArgs{c->cand, c->cand_count, c->cand_cap, c->max_key, 1.0e-3, d_top, c->top_cap, d_sel, seq, keep, c->sel_hist};
     return XRHIP_OK;
 }
 

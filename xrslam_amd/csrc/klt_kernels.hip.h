@@ -582,6 +582,19 @@ struct HarrisCand {
     int idx;   // y*w + x
 };
 
+// Response bins of the candidate selection (k_harris_select below; counted here, where the candidates are found).  Bins are spaced
+// LOGARITHMICALLY above the threshold (the bit pattern of a positive float is monotone in its value): the responses fall off like a
+// power law, so linear bins put most of the ~10^4 candidates into the first few.  256 bins per binade: the 4096 bins span the 16
+// binades above the threshold (quality 1e-3 leaves ten between threshold and maximum; anything higher shares the top bin).
+constexpr int SEL_BINS = 4096;
+__device__ __forceinline__ unsigned sel_thr_bits(float maxv, double quality) {
+    return __float_as_uint(fmaxf((float)((double)maxv * quality), 1e-30f));
+}
+__device__ __forceinline__ int sel_bin(float v, unsigned thr_bits) {
+    const unsigned b = __float_as_uint(fmaxf(v, 1e-30f));
+    return b > thr_bits ? (int)min((unsigned)(SEL_BINS - 1), (b - thr_bits) >> 15) : 0;
+}
+
 // threshold (quality * max) + 3x3 non-maximum suppression over a 64x16 tile per
 // workgroup.  Candidates are gathered in LDS and appended with ONE global atomic
 // per workgroup (a per-pixel atomic on a single counter serialises at ~100
@@ -590,7 +603,7 @@ struct HarrisCand {
 __device__ __forceinline__ void d_harris_nms(const float *__restrict__ resp, int w, int h,
                                              const int *__restrict__ max_key, double quality,
                                              HarrisCand *__restrict__ cand, int *__restrict__ count,
-                                             int capacity) {
+                                             int capacity, unsigned *__restrict__ sel_hist) {
     __shared__ HarrisCand local[1024];
     __shared__ int nlocal;
     __shared__ int base;
@@ -632,9 +645,15 @@ __device__ __forceinline__ void d_harris_nms(const float *__restrict__ resp, int
     if (n == 0) return;
     if (tid == 0) base = atomicAdd(count, n);
     __syncthreads();
+    // each candidate is also counted in its response bin (round 6): the selection kernel -- one workgroup -- spent 3 of its 25 us reading
+    // all candidates a first time for this histogram; here it is one fire-and-forget L2 atomic beside the store
+    const unsigned thr_bits = sel_thr_bits(maxv, quality);
     for (int i = tid; i < n; i += 256) {
         int slot = base + i;
-        if (slot < capacity) cand[slot] = local[i];
+        if (slot < capacity) {
+            cand[slot] = local[i];
+            atomicAdd(&sel_hist[sel_bin(local[i].v, thr_bits)], 1u);
+        }
     }
 }
 struct HarrisNmsArgs {
@@ -646,21 +665,31 @@ struct HarrisNmsArgs {
     int *count;
     int capacity;
     int gx, gy;
+    unsigned *sel_hist;
 };
 __global__ __launch_bounds__(256) void k_harris_nms(Batch<HarrisNmsArgs> b) {
     const HarrisNmsArgs &a = b.e[blockIdx.z];
     if ((int)blockIdx.x >= a.gx || (int)blockIdx.y >= a.gy) return;
-    d_harris_nms(a.resp, a.w, a.h, a.max_key, a.quality, a.cand, a.count, a.capacity);
+    d_harris_nms(a.resp, a.w, a.h, a.max_key, a.quality, a.cand, a.count, a.capacity, a.sel_hist);
 }
 
 // The host's greedy spacing pass visits candidates in (response desc, index desc) order and normally stops
-// after a few hundred of the ~10^4 NMS survivors.  This kernel hands it a superset of the SEL_K strongest:
-// responses are binned linearly between the quality threshold and the maximum (monotone in the response), the
-// bin boundary that keeps >= SEL_K candidates is found, and everything at or above it is written -- together
-// with a header and, last, a sequence number -- straight into pinned host memory.  One workgroup.
-constexpr int SEL_BINS = 4096;
-constexpr int SEL_K = 896;    // the least `keep`: a few more than the ~400 the spacing pass usually visits for 150 corners; <= 1024 keeps the sort at 1024 entries
-constexpr int SEL_SORT = 2048;   // selected candidates that fit the LDS sort (SEL_BINS * 4 bytes = SEL_SORT * 8 bytes)
+// after a few hundred of the ~10^4 NMS survivors.  This kernel hands it a superset of the `keep` strongest, in
+// visiting order: responses are binned logarithmically above the quality threshold (monotone in the response), the
+// bin boundary that keeps >= keep candidates is found, everything at or above it is counting-sorted by bin and
+// ranked inside its bin, and written -- together with a header and, last, a sequence number -- straight into
+// pinned host memory.  One workgroup.
+//
+// Round 6 (in-kernel timers, profiles/r06_select_phases.md): the kernel was 3.2 us histogram + 1.1 boundary + 4.5 selection
+// (a second read of all candidates) + 9.0 bitonic sort of 1024 + 2.3 fence, + a second fence behind the header.  Now the histogram
+// is counted where the candidates are found (k_harris_nms: all workgroups), every thread reads its candidates once, beside the
+// histogram, and keeps them in registers; the histogram's suffix sums give each bin its slot range (the candidates above the
+// boundary are spread over ~10^3 bins, a handful each), a candidate's final slot is its bin's start + the number of its bin mates
+// that precede it, and the header rides in front of the one fence.
+constexpr int SEL_K = 896;     // the least `keep`: a few more than the ~400 the spacing pass usually visits for 150 corners
+constexpr int SEL_SORT = 8192; // selected candidates the (dynamic) LDS holds: everything the top block can take is sorted
+constexpr int SEL_HOLD = 16;   // candidates per thread kept in registers between the two passes (16384: a 752 x 480 frame has ~13000)
+constexpr size_t SEL_LDS_BYTES = sizeof(HarrisCand) * (size_t)SEL_SORT;
 struct SelectHeader {
     int n_candidates;   // all NMS survivors
     int n_top;          // candidates at or above the boundary bin (may exceed the capacity of the top block)
@@ -671,15 +700,15 @@ struct SelectHeader {
 
 __device__ __forceinline__ void d_harris_select(const HarrisCand *__restrict__ cand, int *__restrict__ count,
                                                 int capacity, int *__restrict__ max_key, double quality,
-                                                HarrisCand *top_out, int top_cap, SelectHeader *hdr, int seq, int keep) {
+                                                HarrisCand *top_out, int top_cap, SelectHeader *hdr, int seq, int keep,
+                                                unsigned *__restrict__ sel_hist, HarrisCand *__restrict__ sel) {
     // keep: how many of the strongest candidates the host's spacing pass is handed at least (round 6: scaled with the number of corners
     // asked for -- with 896 for 300 / 600 corners the pass ran out on every frame and fell back to copying and heaping ALL ~10^4
     // candidates on the host, 0.3-0.4 ms per frame of the S2 / S3 streams)
-    __shared__ unsigned hist[SEL_BINS];
-    __shared__ HarrisCand sorted_buf[SEL_SORT];
-    __shared__ unsigned part[64];
+    __shared__ __attribute__((aligned(16))) unsigned hist[SEL_BINS];   // each bin's next free slot
+    __shared__ unsigned wsum[16];
     __shared__ int s_bin, s_n;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef XRHIP_KPROF
     long long kp[8];
     int kpn = 0;
@@ -688,176 +717,116 @@ __device__ __forceinline__ void d_harris_select(const HarrisCand *__restrict__ c
 #define SELPROF() do { } while (0)
 #endif
     SELPROF();
-    const int nc = min(*count, capacity);
-    const float maxv = float_from_key(*max_key);
-    const float thr = (float)((double)maxv * quality);
-    // Bins are spaced LOGARITHMICALLY above the threshold (the bit pattern of a positive float is monotone in its value): the
-    // responses fall off like a power law, so linear bins put most of the ~10^4 candidates into the first few -- thousands of LDS
-    // atomics on the same words, which serialise (that histogram pass was ~25 of this kernel's 34 us).  64 bins per binade.
-    const unsigned thr_bits = __float_as_uint(fmaxf(thr, 1e-30f));
-    auto bin_of = [&](float v) __attribute__((always_inline)) -> int {
-        const unsigned b = __float_as_uint(fmaxf(v, 1e-30f));
-        return b > thr_bits ? (int)min((unsigned)(SEL_BINS - 1), (b - thr_bits) >> 17) : 0;
+    // this thread's candidates: all loads in flight at once (with one, every trip waited out a full L2 round trip), and issued
+    // beside the reads of the counter, the maximum and the histogram, not behind them: what lies beyond the count is ignored below
+    HarrisCand held[SEL_HOLD];
+#pragma unroll
+    for (int u = 0; u < SEL_HOLD; ++u) held[u] = cand[min(tid + u * 1024, capacity - 1)];
+    // the histogram k_harris_nms counted (four bins per thread), cleared for the context's next pass
+    const uint4 h4 = *reinterpret_cast<const uint4 *>(&sel_hist[4 * tid]);
+    *reinterpret_cast<uint4 *>(&sel_hist[4 * tid]) = make_uint4(0u, 0u, 0u, 0u);
+    const int n_raw = *count;
+    const int nc = min(n_raw, capacity);
+    const unsigned thr_bits = sel_thr_bits(float_from_key(*max_key), quality);
+    auto bin_of = [&](float v) __attribute__((always_inline)) -> int { return sel_bin(v, thr_bits); };
+    auto before = [](const HarrisCand &a, const HarrisCand &b) __attribute__((always_inline)) -> bool {   // a is visited before b
+        return (a.v > b.v) || (a.v == b.v && a.idx > b.idx);
     };
-    for (int i = tid; i < SEL_BINS; i += 1024) hist[i] = 0;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    // (eight candidate loads in flight per thread: with one, each of the ~13 trips of this loop waited out a full L2 round trip --
-    // that, not the atomics, was most of this kernel)
-    for (int i0 = tid; i0 < nc; i0 += 8 * 1024) {
-        float v8[8];
+    const int last = max(nc - 1, 0);
+    SELPROF();   // 1: (the histogram pass of rounds 3-5: now only the wait for the loads above)
+    // S(b) = candidates in bins >= b, by a suffix scan over the workgroup; boundary = the largest bin with S(b) >= keep (0 when
+    // there are fewer candidates: keep all); each bin's first slot = the candidates in the bins above it
+    const unsigned own = (h4.x + h4.y) + (h4.z + h4.w);
+    unsigned incl = own;   // over the lanes >= this one
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v8[u] = cand[min(i0 + u * 1024, nc - 1)].v;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (i0 + u * 1024 < nc) atomicAdd(&hist[bin_of(v8[u])], 1u);
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_down(incl, off);
+        if (lane + off < 64) incl += o;
+    }
+    if (lane == 0) wsum[wave] = incl;
+    if (tid == 0) {
+        s_bin = 0;
+        s_n = nc;
     }
     __syncthreads();
-    SELPROF();   // 1: histogram
-    // boundary = largest bin b with count(bins >= b) >= SEL_K (0 when there are fewer candidates)
-    if (tid < 64) {
-        unsigned sum = 0;
-        for (int b = 0; b < SEL_BINS / 64; ++b) sum += hist[tid * (SEL_BINS / 64) + b];
-        part[tid] = sum;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        // two suffix scans over 64 lanes instead of one thread walking up to 128 LDS words: group g = the largest group whose
-        // suffix count reaches SEL_K, then the same inside the group (SEL_BINS / 64 = 64 bins per group)
-        static_assert(SEL_BINS / 64 == 64, "one bin per lane in the second level");
-        auto suffix = [&](unsigned v) __attribute__((always_inline)) -> unsigned {   // sum over lanes >= this one
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned o = __shfl_down(v, off);
-                if (lane + off < 64) v += o;
-            }
-            return v;
-        };
-        const unsigned sg = suffix(part[lane]);
-        const unsigned long long mg = __ballot(sg >= (unsigned)keep);
-        int b = 0;                                             // fewer than SEL_K candidates in total: keep all
-        if (mg) {
-            const int g = 63 - __builtin_clzll(mg);
-            const unsigned above = __shfl(sg, g) - __shfl(part[lane], g);   // candidates in the groups above g
-            const unsigned sb = above + suffix(hist[g * 64 + lane]);
-            const unsigned long long mb = __ballot(sb >= (unsigned)keep);
-            b = g * 64 + (mb ? 63 - __builtin_clzll(mb) : 0);
+    unsigned higher = ((lane & 15) > wave) ? wsum[lane & 15] : 0u;   // the wavefronts above this one: 16 lanes, summed in four steps
+    higher += __shfl_xor(higher, 1);
+    higher += __shfl_xor(higher, 2);
+    higher += __shfl_xor(higher, 4);
+    higher += __shfl_xor(higher, 8);
+    const unsigned S4 = higher + incl - own;   // candidates in the bins above this thread's four
+    const unsigned S3 = S4 + h4.w, S2 = S3 + h4.z, S1 = S2 + h4.y, S0 = S1 + h4.x;
+    {
+        // S is monotone: exactly one bin has S(b) >= keep > S(b + 1) -- its owner alone writes (every thread below the boundary
+        // raising a shared maximum was a thousand atomics on one word)
+        const unsigned k = (unsigned)keep;
+        const int mine = (S3 >= k && S4 < k) ? 3 : (S2 >= k && S3 < k) ? 2 : (S1 >= k && S2 < k) ? 1 : (S0 >= k && S1 < k) ? 0 : -1;
+        if (mine >= 0 && 4 * tid + mine > 0) {
+            s_bin = 4 * tid + mine;
+            s_n = (int)(mine == 0 ? S0 : mine == 1 ? S1 : mine == 2 ? S2 : S3);
         }
-        if (lane == 0) s_bin = b;
     }
+    *reinterpret_cast<uint4 *>(&hist[4 * tid]) = make_uint4(S1, S2, S3, S4);
     __syncthreads();
     const int bin = s_bin;
-    SELPROF();   // 2: boundary
-    // the histogram is dead: its LDS now collects the selected candidates (SEL_SORT of them fit)
-    HarrisCand *sel = reinterpret_cast<HarrisCand *>(hist);
-    for (int i00 = 0; i00 < nc; i00 += 8 * 1024) {   // uniform trip counts: the ballot below wants whole wavefronts
-        HarrisCand c8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) c8[u] = cand[min(i00 + u * 1024 + tid, nc - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-        const int i = i00 + u * 1024 + tid;
-        if (i00 + u * 1024 >= nc) break;
-        HarrisCand cd = c8[u];
-        const bool take = i < nc && bin_of(cd.v) >= bin;
-        // one LDS atomic per wavefront instead of one per selected candidate (a thousand increments of ONE word serialise); the
-        // order inside the selection is irrelevant: it is sorted below, or (unsorted case) the host orders it
-        const unsigned long long m = __ballot(take);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&s_n, (int)__popcll(m));
-        base = __shfl(base, 0);
-        if (take) {
-            const int pos = base + (int)__popcll(m & ((1ull << lane) - 1ull));
-            if (pos < SEL_SORT) sel[pos] = cd;
-            else if (pos < top_cap) top_out[pos] = cd;
-        }
-      }
-    }
-    __syncthreads();
-    SELPROF();   // 3: selection
     const int n_top = s_n;
+    SELPROF();   // 2: boundary
     int sorted = 0;
-    if (n_top <= SEL_SORT && n_top <= top_cap) {
-        // Bitonic sort into the visiting order of the greedy spacing pass: response descending, then index descending (a strict total
-        // order: indices are unique).  Up to 1024 candidates (the usual case: SEL_K = 896): ONE element per thread, in registers --
-        // compare-exchange distances below 64 stay inside the wavefront (shuffles), only the 10 stages at distance >= 64 go through
-        // LDS and a workgroup barrier.  The 55-stage network over LDS this replaces was 16 of the kernel's 34 us (in-kernel timers);
-        // counting ranks instead (n_top broadcast reads per thread) measured 90 us.
-        if (n_top <= 1024) {
-            HarrisCand me;
-            me.v = -1.0f;   // responses above the threshold are positive: padding sorts last
-            me.idx = -1;
-            if (tid < n_top) me = sel[tid];
-            __syncthreads();
-            for (int k = 2; k <= 1024; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    HarrisCand other;
-                    if (j < 64) {
-                        other.v = __shfl_xor(me.v, j);
-                        other.idx = __shfl_xor(me.idx, j);
-                    } else {
-                        sorted_buf[tid] = me;
-                        __syncthreads();
-                        other = sorted_buf[tid ^ j];
-                        __syncthreads();
-                    }
-                    const bool me_first = (me.v > other.v) || (me.v == other.v && me.idx > other.idx);
-                    const bool want_first = ((tid & j) == 0) == ((tid & k) == 0);   // the lower slot of an ascending pair keeps the first
-                    if (me_first != want_first) me = other;
-                }
-            sorted_buf[tid] = me;
-        } else {
-            const int ns = SEL_SORT;
-            for (int i = n_top + tid; i < ns; i += 1024) {
-                sel[i].v = -1.0f;
-                sel[i].idx = -1;
+    if (n_top <= min(SEL_SORT, top_cap)) {
+        // counting sort by bin: a slot from the bin's range per candidate (arbitrary order inside a bin) ...
+#pragma unroll
+        for (int u = 0; u < SEL_HOLD; ++u) {
+            const int b = bin_of(held[u].v);
+            if (tid + u * 1024 < nc && b >= bin) sel[atomicAdd(&hist[b], 1u)] = held[u];
+        }
+        for (int i0 = SEL_HOLD * 1024 + tid; i0 < nc; i0 += 8 * 1024) {
+            HarrisCand c8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c8[u] = cand[min(i0 + u * 1024, last)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = bin_of(c8[u].v);
+                if (i0 + u * 1024 < nc && b >= bin) sel[atomicAdd(&hist[b], 1u)] = c8[u];
             }
-            __syncthreads();
-            for (int k = 2; k <= ns; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < ns; i += 1024) {
-                        const int l = i ^ j;
-                        if (l > i) {
-                            const HarrisCand ca = sel[i], cb = sel[l];
-                            const bool a_first = (ca.v > cb.v) || (ca.v == cb.v && ca.idx > cb.idx);
-                            const bool up = (i & k) == 0;
-                            if (up ? !a_first : a_first) {
-                                sel[i] = cb;
-                                sel[l] = ca;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-            for (int i = tid; i < n_top; i += 1024) sorted_buf[i] = sel[i];
         }
         __syncthreads();
-        for (int i = tid; i < n_top; i += 1024) top_out[i] = sorted_buf[i];
+        SELPROF();   // 3: selection
+        // ... then the visiting order (response descending, then index descending: a strict total order, indices are unique) inside
+        // each bin: bin b now occupies [hist[b + 1], hist[b]) -- every bin's counter has run up to the start of the bin below it
+        // (written straight to its final slot of the top block: 8-byte stores, scattered only inside a bin's range)
+        for (int i = tid; i < n_top; i += 1024) {
+            const HarrisCand cd = sel[i];
+            const int b = bin_of(cd.v);
+            const int s0 = (b == SEL_BINS - 1) ? 0 : (int)hist[b + 1], s1 = (int)hist[b];
+            int ahead = 0;
+            for (int j = s0; j < s1; ++j) ahead += before(sel[j], cd) ? 1 : 0;
+            host_store(reinterpret_cast<unsigned long long *>(top_out + s0 + ahead),
+                       ((unsigned long long)(unsigned)cd.idx << 32) | (unsigned long long)__float_as_uint(cd.v));
+        }
         sorted = 1;
     } else {
-        for (int i = tid; i < min(n_top, min(SEL_SORT, top_cap)); i += 1024) top_out[i] = sel[i];
+        SELPROF();   // (more candidates at the boundary than the top block takes: the host fetches the full list)
     }
-    SELPROF();   // 4: sort + copy out
-    __threadfence_system();
-    __syncthreads();
-    SELPROF();   // 5: fence
-#ifdef XRHIP_KPROF
-    if (tid == 0 && (seq & 63) == 0)
-        printf("k_harris_select nc %d n_top %d: hist %lld boundary %lld select %lld sort+out %lld fence %lld (x10 ns)\n", nc, n_top,
-               kp[1] - kp[0], kp[2] - kp[1], kp[3] - kp[2], kp[4] - kp[3], kp[5] - kp[4]);
-#endif
     if (tid == 0) {
-        hdr->n_candidates = *count;
-        hdr->n_top = n_top;
-        hdr->boundary_bin = bin;
-        hdr->sorted = sorted;
+        host_store(&hdr->n_candidates, n_raw);
+        host_store(&hdr->n_top, n_top);
+        host_store(&hdr->boundary_bin, bin);
+        host_store(&hdr->sorted, sorted);
         // this kernel is the last reader of the pass's running maximum and candidate counter: it leaves both reset for the context's
         // next detection (a host-side reset in front of k_harris was a copy command of its own per frame and per sequence)
         *max_key = (int)0x80000000;
         *count = 0;
-        __threadfence_system();
-        *reinterpret_cast<volatile int *>(&hdr->seq) = seq;
     }
+    SELPROF();   // 4: order + copy out
+    host_stores_wait();
+    __syncthreads();
+    SELPROF();   // 5: fence
+#ifdef XRHIP_KPROF
+    if (tid == 0 && (seq & 63) == 0)
+        printf("k_harris_select nc %d n_top %d: hist %lld boundary %lld select %lld order+out %lld fence %lld (x10 ns)\n", nc, n_top,
+               kp[1] - kp[0], kp[2] - kp[1], kp[3] - kp[2], kp[4] - kp[3], kp[5] - kp[4]);
+#endif
+    if (tid == 0) host_store(&hdr->seq, seq);   // header and top block are in host memory
     (void)lane;
 }
 struct HarrisSelectArgs {
@@ -871,10 +840,13 @@ struct HarrisSelectArgs {
     SelectHeader *hdr;
     int seq;
     int keep;
+    unsigned *sel_hist;
 };
 __global__ __launch_bounds__(1024) void k_harris_select(Batch<HarrisSelectArgs> b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sel_lds[];   // SEL_LDS_BYTES
     const HarrisSelectArgs &a = b.e[blockIdx.z];
-    d_harris_select(a.cand, a.count, a.capacity, a.max_key, a.quality, a.top_out, a.top_cap, a.hdr, a.seq, a.keep);
+    d_harris_select(a.cand, a.count, a.capacity, a.max_key, a.quality, a.top_out, a.top_cap, a.hdr, a.seq, a.keep, a.sel_hist,
+                    reinterpret_cast<HarrisCand *>(sel_lds));
 }
 
 // ----------------------------------------------------------------------- LK
@@ -1394,17 +1366,26 @@ __device__ __forceinline__ void d_lk_track(const PyrView &A, const PyrView &B, c
     (void)lk_t0;
 #endif
     if (lane == 0) {
-        status_out[pt] = (uint8_t)status;
-        if (status) next_io[pt] = make_double2((double)nx, (double)ny);
+        // the point's results go to the (pinned) point block; the point counts itself done once they are released, and the last one
+        // to do so raises the sequence number
+        host_store(&status_out[pt], (uint8_t)status);
+        if (status) {
+            host_store(&next_io[pt].x, (double)nx);
+            host_store(&next_io[pt].y, (double)ny);
+        }
         if (counters) {
             atomicAdd(&counters->templates, (unsigned long long)n_templates);
             atomicAdd(&counters->iterations, (unsigned long long)n_iters);
         }
         if (done) {
+            // (Round 6: the system-scope stores above would do without these fences -- wait for the acknowledgements, count -- as in
+            // k_harris_select and kp_preintegrate (host_mailbox.hip.h).  Measured, that made this kernel no faster (34.8 -> 36.2 us)
+            // and the k_harris launched behind it slower (11.1 -> 16.2 us), a release without the invalidation likewise: the cache
+            // maintenance the fences spread over the kernel is otherwise done at its end.  The fences stay.)
             __threadfence_system();
             if (atomicAdd(done, 1u) + 1u == done_target) {
                 __threadfence_system();
-                *reinterpret_cast<volatile int *>(host_seq) = seq;
+                host_store(host_seq, seq);
             }
         }
     }

@@ -529,10 +529,12 @@ constexpr int PN_E = 0, PN_P = 9, PN_V = 18, PN_T = 27, PN_C = 28, PN_G = 73, PN
 
 // completion mailbox: the job's status word (pinned host memory) is its last store -- 1 = record complete,
 // 3 = covariance not positive definite; the host spins on it instead of synchronising the stream
+// (round 6: the record is written with system-scope stores and the wavefronts wait for their acknowledgement -- no write-back and
+// invalidation of the whole L2 in front of the status word, host_mailbox.hip.h)
 __device__ __forceinline__ void preint_publish(int *status, int code) {
-    __threadfence_system();
+    host_stores_wait();
     __syncthreads();
-    if (threadIdx.x == 0) *reinterpret_cast<volatile int *>(status + blockIdx.x) = code;
+    if (threadIdx.x == 0) host_store(status + blockIdx.x, code);
 }
 
 // out[k] = in[2k+1] o in[2k] for the pairs of a list of maps (an odd last one is carried over); the kernel composes a chunk's map with
@@ -618,6 +620,20 @@ __device__ __forceinline__ void preint_compose(const double *__restrict__ in, in
     __syncthreads();
 }
 
+// x / d as the compiler's expansion of an f64 division computes it when no operand needs rescaling (|x| <= ~1, d ~ 1: a quaternion
+// over its norm): y = the reciprocal refined twice, q = x y, q + (x - d q) y.  div_recip is the part that depends on d alone -- four
+// divisions by one norm share it (written once per call below; the compiler merges the identical expressions).
+__device__ __forceinline__ double div_recip(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    return y;
+}
+__device__ __forceinline__ double div_by(double x, double d, double y) {
+    const double q = x * y;
+    return __builtin_fma(__builtin_fma(-d, q, x), y, q);
+}
+
 // blockIdx.x = job of an entry, blockIdx.z = entry: a launch carries the batches of up to XB contexts (group.hip.h)
 struct PreintArgs {
     const PreintJob *jobs;
@@ -651,6 +667,7 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
     __shared__ double sPart[2][PI_NE];
     __shared__ double sEq[PI_CHUNK][4], sQ[PI_CHUNK][4], sAc[PI_CHUNK][3], sDt[PI_CHUNK];
     __shared__ double sVn[PI_CHUNK][3], sPn[PI_CHUNK][3], sTn[PI_CHUNK];   // v, p, t AFTER sample n
+    __shared__ double sQa[PI_CHUNK][6];   // (q_n a_n) h_n^2 / 2 | (q_n a_n) h_n
     __shared__ double sq[4], sp3[3], sv3[3], sdt, s0v[3], s0p[3], s0t, sRN[9];
     __shared__ double Dinv[CH_NB][CH_NB + 1];
     __shared__ double noise36[36];   // the inputs live in pinned host memory: fetch each of them exactly once
@@ -723,30 +740,50 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
         }
         __syncthreads();
         PI_T(0);
-        // ---- P2: the two chains, ONE lane.  The quaternion chain and the position / velocity chain are independent streams of
-        // double-precision operations (q_{n+1} and q_n a_n both hang off q_n only), interleaved in one loop.  (Round 6, tools/issue.hip: an
-        // f64 operation costs its wavefront ~9 cycles whether or not it depends on the previous one -- the loop is as long as its
-        // ~150 instructions per sample.)  Each chain's operations and their order are the reference's.
+        // ---- P2: the chains.  An f64 operation costs its wavefront ~9 cycles whether or not it depends on the previous one (round 6,
+        // tools/issue.hip), so a chain on one lane is as long as the instructions it issues -- ~140 per sample when the quaternion chain,
+        // the rotation of the acceleration and the position / velocity recurrences shared one loop (0.59 us per sample).  Only
+        // q_{n+1} = normalized(q_n e_n) and p, v are recurrences; q_n a_n hangs off q_n alone.  So: (a) the quaternion chain on one lane,
+        // its four divisions by the norm sharing one refined reciprocal (the expansion the compiler emits per division, with its
+        // reciprocal iterations done once: same quotients); (b) a lane per sample: q_n a_n and its two scaled forms; (c) the p, v, t
+        // recurrences on a lane of the second wavefront, beside the first's rotation matrices (P3).  Each value is produced by the
+        // operations, in the order, of the reference's loop (the build has floating-point contraction off): the delta's bits are unchanged.
         if (tid == 0) {
             Q4 q = Q4{sq[0], sq[1], sq[2], sq[3]};
+            for (int n = 0; n < nc; ++n) {
+                sQ[n][0] = q.x; sQ[n][1] = q.y; sQ[n][2] = q.z; sQ[n][3] = q.w;
+                const Q4 m = q_mul(q, Q4{sEq[n][0], sEq[n][1], sEq[n][2], sEq[n][3]});
+                const double nn = sqrt(m.x * m.x + m.y * m.y + m.z * m.z + m.w * m.w);
+                q = Q4{div_by(m.x, nn, div_recip(nn)), div_by(m.y, nn, div_recip(nn)), div_by(m.z, nn, div_recip(nn)),
+                       div_by(m.w, nn, div_recip(nn))};
+            }
+            sq[0] = q.x; sq[1] = q.y; sq[2] = q.z; sq[3] = q.w;
+        }
+        __syncthreads();
+        PI_T(1);
+        if (tid < nc) {
+            const double h = sDt[tid];
+            const V3 qa = q_rot(Q4{sQ[tid][0], sQ[tid][1], sQ[tid][2], sQ[tid][3]}, v3(sAc[tid][0], sAc[tid][1], sAc[tid][2]));
+            const V3 a2 = qa * (0.5 * h * h), a1 = qa * h;
+            sQa[tid][0] = a2.x; sQa[tid][1] = a2.y; sQa[tid][2] = a2.z;
+            sQa[tid][3] = a1.x; sQa[tid][4] = a1.y; sQa[tid][5] = a1.z;
+        }
+        __syncthreads();
+        if (tid == 64) {
             V3 pv = v3(sp3[0], sp3[1], sp3[2]), vv = v3(sv3[0], sv3[1], sv3[2]);
             double T = sdt;
             s0p[0] = pv.x; s0p[1] = pv.y; s0p[2] = pv.z;
             s0v[0] = vv.x; s0v[1] = vv.y; s0v[2] = vv.z;
             s0t = T;
             for (int n = 0; n < nc; ++n) {
-                sQ[n][0] = q.x; sQ[n][1] = q.y; sQ[n][2] = q.z; sQ[n][3] = q.w;
                 const double h = sDt[n];
-                const V3 qa = q_rot(q, v3(sAc[n][0], sAc[n][1], sAc[n][2]));
-                q = q_normalized(q_mul(q, Q4{sEq[n][0], sEq[n][1], sEq[n][2], sEq[n][3]}));
-                pv = pv + vv * h + qa * (0.5 * h * h);
-                vv = vv + qa * h;
+                pv = pv + vv * h + v3(sQa[n][0], sQa[n][1], sQa[n][2]);
+                vv = vv + v3(sQa[n][3], sQa[n][4], sQa[n][5]);
                 T = T + h;
                 sPn[n][0] = pv.x; sPn[n][1] = pv.y; sPn[n][2] = pv.z;
                 sVn[n][0] = vv.x; sVn[n][1] = vv.y; sVn[n][2] = vv.z;
                 sTn[n] = T;
             }
-            sq[0] = q.x; sq[1] = q.y; sq[2] = q.z; sq[3] = q.w;
             sp3[0] = pv.x; sp3[1] = pv.y; sp3[2] = pv.z;
             sv3[0] = vv.x; sv3[1] = vv.y; sv3[2] = vv.z;
             sdt = T;
@@ -755,17 +792,15 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
             // delta of the interval the backend's integration covers (same samples, same biases) as soon as it exists, instead of
             // integrating the interval a second time without Jacobians (xrhip_ba_preintegrate_early).  Same values as at the end.
             if (n0 + PI_CHUNK >= job.sample_count) {
-                o[0] = T;
-                o[1] = q.x; o[2] = q.y; o[3] = q.z; o[4] = q.w;
-                o[5] = pv.x; o[6] = pv.y; o[7] = pv.z;
-                o[8] = vv.x; o[9] = vv.y; o[10] = vv.z;
-                __threadfence_system();
-                *reinterpret_cast<volatile int *>(ea.early + blockIdx.x) = 1;
+                host_store(o + 0, T);
+                for (int i = 0; i < 4; ++i) host_store(o + 1 + i, sq[i]);
+                host_store(o + 5, pv.x); host_store(o + 6, pv.y); host_store(o + 7, pv.z);
+                host_store(o + 8, vv.x); host_store(o + 9, vv.y); host_store(o + 10, vv.z);
+                host_stores_wait();
+                host_store(ea.early + blockIdx.x, 1);
             }
         }
-        __syncthreads();
-        PI_T(1);
-        // ---- P3: lane = sample: R_n and M_n = R_{n+1} Jr_n; one more lane: R_N of this chunk
+        // ---- P3 (beside the recurrences): lane = sample: R_n and M_n = R_{n+1} Jr_n; one more lane: R_N of this chunk
         if (cj) {
             if (tid < nc) {
                 const M3 R = q_mat(Q4{sQ[tid][0], sQ[tid][1], sQ[tid][2], sQ[tid][3]});
@@ -776,7 +811,7 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
                 for (int i = 0; i < 9; ++i) J.m[i] = sJr[tid][i];
                 const M3 M = R1 * J;
                 for (int i = 0; i < 9; ++i) sM[tid][i] = M.m[i];
-            } else if (tid == 64) {
+            } else if (tid == 128) {
                 const M3 R = q_mat(Q4{sq[0], sq[1], sq[2], sq[3]});
                 for (int i = 0; i < 9; ++i) sRN[i] = R.m[i];
             }
@@ -903,20 +938,20 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
     const double *res = maps[rb];
     // outputs
     if (tid == 0) {
-        o[0] = sdt;
-        for (int i = 0; i < 4; ++i) o[1 + i] = sq[i];
+        host_store(o + 0, sdt);
+        for (int i = 0; i < 4; ++i) host_store(o + 1 + i, sq[i]);
         for (int i = 0; i < 3; ++i) {
-            o[5 + i] = sp3[i];
-            o[8 + i] = sv3[i];
+            host_store(o + 5 + i, sp3[i]);
+            host_store(o + 8 + i, sv3[i]);
         }
         if (job.sample_count <= 0) {   // no chunk ran, so nobody published the early delta: it is the identity just written
-            __threadfence_system();
-            *reinterpret_cast<volatile int *>(ea.early + blockIdx.x) = 1;
+            host_stores_wait();
+            host_store(ea.early + blockIdx.x, 1);
         }
     }
-    if (tid < 45) o[11 + tid] = want_jac ? res[PN_C + tid] : 0.0;
+    if (tid < 45) host_store(o + 11 + tid, want_jac ? res[PN_C + tid] : 0.0);
     if (!want_cov) {
-        for (int e = tid; e < 225; e += PI_NT) o[56 + e] = 0.0;
+        for (int e = tid; e < 225; e += PI_NT) host_store(o + 56 + e, 0.0);
         preint_publish(status, 1);
         return;
     }
@@ -953,7 +988,7 @@ __global__ __launch_bounds__(PI_NT) void kp_preintegrate(Batch<PreintArgs> batch
     }
     for (int e = tid; e < 225; e += PI_NT) {
         const int i = e / 15, j = e - 15 * i;
-        o[56 + e] = (j >= i) ? Dinv[14 - i][14 - j] : 0.0;   // upper triangular, row-major
+        host_store(o + 56 + e, (j >= i) ? Dinv[14 - i][14 - j] : 0.0);   // upper triangular, row-major
     }
     preint_publish(status, 1);
 #ifdef XRHIP_KPROF_PRINT
