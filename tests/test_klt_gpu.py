@@ -190,6 +190,40 @@ def test_detect_paths_prefetch_and_full_list_fallback(mods):
     np.testing.assert_array_equal(HB.detect_keypoints(nx_o[st_o > 0], 150, 20.0), OB.detect_keypoints(nx_o[st_o > 0], 150, 20.0))
 
 
+def test_candidate_selection_edge_cases_few_candidates_and_massive_ties(mods):
+    """k_harris_select orders the strongest candidates on the device (response bins, rank inside a bin: ties broken by the pixel index).
+    (a) Fewer NMS survivors than it is asked to keep: all of them are handed over, in order.  (b) A periodic image (period 4, CLAHE tiles
+    that are multiples of it: identical lookup tables) gives thousands of candidates with IDENTICAL responses -- one bin, more entries than
+    the top block holds: the host fetches the full list, and the visiting order is decided by the index alone.  Both equal the oracle."""
+    ko, klt = mods
+    w, h = 752, 480
+    # (a) a flat frame with one small textured patch
+    g = np.full((h, w), 110, np.uint8)
+    g[200:240, 300:340] = noise_image(40, 40, seed=5)
+    ctx, HA, HB, OA, OB = _pair(ko, klt, g, g, max_points=150)
+    want = OA.detect_keypoints(np.zeros((0, 2)), 150, 20.0)
+    before = ctx.stats().detect_full_list
+    np.testing.assert_array_equal(HA.detect_keypoints(np.zeros((0, 2)), 150, 20.0), want)
+    assert 0 < len(want) < 20
+    assert ctx.stats().detect_full_list == before          # everything fitted the top block
+    # (b) period-4 texture, 4 x 4 CLAHE tiles of 188 x 120 pixels
+    cell = np.random.RandomState(9).randint(60, 200, (4, 4)).astype(np.uint8)
+    p = np.tile(cell, (h // 4, w // 4))
+    ctx, HA, HB, OA, OB = _pair(ko, klt, p, p, tiles=4, max_points=150)
+    resp = ko.harris_response(OA.image)
+    vals, counts = np.unique(resp[40:-40, 40:-40], return_counts=True)
+    assert counts.max() > 8192                                # thousands of exactly equal responses away from the border
+    want = OA.detect_keypoints(np.zeros((0, 2)), 150, 20.0)
+    before = ctx.stats().detect_full_list
+    got = HA.detect_keypoints(np.zeros((0, 2)), 150, 20.0)
+    np.testing.assert_array_equal(got, want)
+    assert len(want) > 50
+    # with a few existing points in the way as well
+    have = want[::7] + np.array([3.0, -2.0])
+    np.testing.assert_array_equal(HA.detect_keypoints(have, 150, 20.0), OA.detect_keypoints(have, 150, 20.0))
+    assert ctx.stats().detect_full_list >= before             # (whether the fallback ran depends on where the boundary bin falls)
+
+
 def test_plain_lk_parity_including_failures(mods):
     ko, klt = mods
     g = noise_image(752, 480, seed=41)

@@ -26,10 +26,9 @@ __device__ __forceinline__ void host_store(float *p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // Used where the payload is host memory only and the fence sat on the kernel's critical path: k_harris_select (fence 2.1 -> 0.45 us
-// of a 13 us kernel; without its invalidation the next frame's k_lk_track also finds the previous frame's pyramid in the L2:
-// 39.6 -> 34.8 us) and kp_preintegrate (record 2.7 -> 0.7 us).  NOT used where a kernel also leaves results in DEVICE memory that
+// of a 13 us kernel) and kp_preintegrate (record 2.7 -> 0.7 us).  NOT used where a kernel also leaves results in DEVICE memory that
 // another stream's kernel reads once the host has seen the flag (the solves' control blocks and states: kb_chain, kb_solve_try,
-// kb_trials_wide keep __threadfence_system()), nor in k_lk_track, where it measured slower (see there).
+// kb_trials_wide keep __threadfence_system()), nor in k_lk_track, where it made no measurable difference (see there).
 // this wavefront's host_store()s have been acknowledged
 __device__ __forceinline__ void host_stores_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

@@ -1379,9 +1379,8 @@ __device__ __forceinline__ void d_lk_track(const PyrView &A, const PyrView &B, c
         }
         if (done) {
             // (Round 6: the system-scope stores above would do without these fences -- wait for the acknowledgements, count -- as in
-            // k_harris_select and kp_preintegrate (host_mailbox.hip.h).  Measured, that made this kernel no faster (34.8 -> 36.2 us)
-            // and the k_harris launched behind it slower (11.1 -> 16.2 us), a release without the invalidation likewise: the cache
-            // maintenance the fences spread over the kernel is otherwise done at its end.  The fences stay.)
+            // k_harris_select and kp_preintegrate (host_mailbox.hip.h).  Measured in alternating traces of one call
+            // (profiles/r06_fence.md) it makes no difference here: the points' fences overlap the other points' work.  They stay.)
             __threadfence_system();
             if (atomicAdd(done, 1u) + 1u == done_target) {
                 __threadfence_system();
