@@ -158,7 +158,7 @@ def test_grouped_instances_behind_the_frame_gate_gpu(monkeypatch):
     them changes completely, what a member computes must not: same bits as the solo runs, and the gate did open."""
     from xrslam_amd import _lib
     monkeypatch.setenv("XRHIP_GROUP_GATE", "1")
-    alone, res, stats = _grouped(_lib.LIB_PATH, (1, 2, 3, 4), mode=0, n=72)
+    alone, res, stats = _grouped(_lib.LIB_PATH, (1, 2, 3, 4), mode=0, n=200)   # (round 6: 200 frames -- ~50 keyframes per member, the first marginalisation's eigen path included -- instead of 72)
     for (pa, ca), (pt, ct) in zip(alone, res):
         assert ca == ct
         np.testing.assert_array_equal(pa, pt)
