@@ -8,7 +8,7 @@
 #   multi:S [args]          bench.py --sequences-per-gpu S              procs:N Q [S]      N processes on this GPU (gloo), Q HW queues each, S grouped sequences in each
 #   rccl1                   RunGroup's collectives over nccl (= RCCL) with one rank (tools/check_rccl.py)
 #   trace[:bench.py args]   rocprofv3 --kernel-trace --stats + per-kernel averages         pmc[:args]   MFMA / FETCH_SIZE / WRITE_SIZE passes
-#   pmcg[:S]                FETCH_SIZE / WRITE_SIZE passes of S grouped sequences (default 8)
+#   pmcg[:S]                FETCH_SIZE / WRITE_SIZE passes of S grouped sequences (default 8)        pmcsq   SQ wave-cycle / instruction counters (tools/sq_summary.py)
 #   ab:VARIANT              default library vs lib/libxrslam_hip_VARIANT.so, alternating (S1 line and S4 replay)
 #   abenv:VAR [reps]        the default bench line with VAR unset / =1, interleaved
 #   hostprof                XRHIP_HOSTPROF scope accumulators of the S1 stream             kprint[:PATTERN]   in-kernel printf timers (kprint variant)
@@ -64,6 +64,11 @@ for step in "$@"; do
     pmc)    (cd /tmp && export TMPDIR=/tmp
              timeout 150 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$O/pmc_$TAG/MFMA" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --no-profile $arg > "$O/pmc_${TAG}_MFMA.log" 2>&1
              for C in FETCH_SIZE WRITE_SIZE; do timeout 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$O/pmc_$TAG/$C" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --no-profile $arg > "$O/pmc_${TAG}_$C.log" 2>&1; done); ls "$O/pmc_$TAG" ;;
+    pmcsq)  # where the wavefronts' cycles go (issue-bound or parked?): SQ counters of the solo run, two passes of four counters (own runs)
+            (cd /tmp && export TMPDIR=/tmp
+             timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$O/pmc_$TAG/SQ/a" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --no-profile $arg > "$O/pmc_${TAG}_SQa.log" 2>&1
+             timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d "$O/pmc_$TAG/SQ/b" -o pmc -- python "$R/bench.py" --steps 60 --warmup 40 --cpu-frames 0 --variant-frames 0 --sustained-frames 0 --no-profile $arg > "$O/pmc_${TAG}_SQb.log" 2>&1)
+            python "$R/tools/sq_summary.py" "$O/pmc_$TAG/SQ" ;;
     pmcg)   # the grouped run's counters (S = ${arg:-8} members): a batched launch should move ~S times a solo launch's bytes in about the time of one
             S="${arg:-8}"
             (cd /tmp && export TMPDIR=/tmp
